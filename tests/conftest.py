@@ -1,0 +1,50 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_schema(name):
+    with open(os.path.join(GOLDEN, name + ".schema.json")) as f:
+        return [(k, tuple(s), getattr(torch, d)) for k, s, d in json.load(f)]
+
+
+_SD_CACHE = {}
+
+
+def synth_sd(name, seed=0):
+    """Deterministic synthetic state_dict with the reference's key order (cached per session)."""
+    from msclip_amd import synth
+    key = (name, seed)
+    if key not in _SD_CACHE:
+        _SD_CACHE[key] = synth.synth_state_dict(load_schema(name), seed=seed)
+    return _SD_CACHE[key]
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def summarize(t):
+    f = t.detach().float().flatten().cpu()
+    idx = torch.linspace(0, f.numel() - 1, 64).long()
+    return np.concatenate([[f.mean().item(), f.abs().mean().item()], f[idx].numpy()]).astype(np.float32)
+
+
+@pytest.fixture(scope="session")
+def gpu_device():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")

@@ -1,0 +1,142 @@
+"""Generate tests/golden/ from the REAL reference (build container only).
+
+Imports /root/reference through tools/ref_import.py, fills it with the
+deterministic synthetic weights of msclip_amd.synth, runs it in fp32 on CPU
+and stores inputs-by-seed / outputs-by-value as small .npz fixtures, plus the
+state_dict schema (key order, shapes, dtypes) that is the checkpoint ABI.
+
+    python tools/make_golden.py            # writes tests/golden/*.npz, *.json
+
+Only data leaves this script: no reference source or bytecode is copied.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+import ref_import as R                      # noqa: E402
+from msclip_amd import synth                # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+SEED = 0
+BATCH = 4
+
+
+def summarize(t):
+    """Compact, order-sensitive summary of a big activation: mean, abs-mean and a
+    strided 64-element slice of the flattened tensor."""
+    f = t.detach().float().flatten()
+    idx = torch.linspace(0, f.numel() - 1, 64).long()
+    return np.concatenate([[f.mean().item(), f.abs().mean().item()], f[idx].numpy()]).astype(np.float32)
+
+
+def run_config(name):
+    model, cfg = R.build_reference_model(name)
+    schema = synth.schema_of(model)
+    sd = synth.synth_state_dict(schema, seed=SEED)
+    missing, unexpected = model.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    # aliasing sanity: shared tensors must still be shared after the load
+    v = model.visual.transformer.resblocks[3].attn.in_proj_weight
+    t = model.transformer.resblocks[3].attn.in_proj_weight
+    assert v.data_ptr() == t.data_ptr()
+
+    img = synth.synth_images(BATCH, seed=SEED)
+    tok = synth.synth_tokens(BATCH, seed=SEED + 1)
+
+    taps = {}
+    hooks = []
+    vt = model.visual.transformer
+
+    def tap(nm):
+        def fn(_m, _i, o):
+            taps[nm] = o[1] if isinstance(o, tuple) else o
+        return fn
+
+    hooks.append(vt.resblocks[0].register_forward_hook(tap("stem_out")))
+    hooks.append(vt.resblocks[0].relu.register_forward_hook(tap("stem_conv1")))
+    for i in range(4):
+        hooks.append(vt.resblocks[0].resnet_stage[i].register_forward_hook(tap(f"stem_stage{i}")))
+    hooks.append(model.visual.ln_pre.register_forward_hook(tap("tokens_ln_pre")))
+    for j in range(5):
+        hooks.append(vt.parallel_branch_v[j].register_forward_hook(tap(f"parallel{j}")))
+        hooks.append(vt.parallel_lateral_adapter[j].register_forward_hook(tap(f"adapter{j}")))
+    for i in (1, 2, 11):
+        hooks.append(vt.resblocks[i].register_forward_hook(tap(f"vblock{i}")))
+    for i in (0, 1, 11):
+        hooks.append(model.transformer.resblocks[i].register_forward_hook(tap(f"tblock{i}")))
+
+    with torch.no_grad():
+        fi = model.encode_image(img)
+        ft = model.encode_text(tok)
+        fi_raw = model.encode_image(img, norm=False)
+        ft_raw = model.encode_text(tok, norm=False)
+        for h in hooks:
+            h.remove()
+        R.ensure_single_rank_group()
+        logits = model(img, tok)
+
+    out = {
+        "seed": np.int64(SEED), "batch": np.int64(BATCH),
+        "image_features": fi.numpy(), "text_features": ft.numpy(),
+        "image_features_raw": fi_raw.numpy(), "text_features_raw": ft_raw.numpy(),
+        "logits": logits.numpy(),
+    }
+    for k, v in taps.items():
+        # reference activations are seq-first [L, B, C]; store batch-first
+        if k.startswith(("vblock", "tblock", "adapter")):
+            v = v.permute(1, 0, 2)
+        out["tap_" + k] = summarize(v)
+        out["tapshape_" + k] = np.array(v.shape, dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **out)
+
+    with open(os.path.join(OUT, f"{name}.schema.json"), "w") as f:
+        json.dump([[k, list(s), str(d).replace("torch.", "")] for k, s, d in schema], f, indent=0)
+    n_unique = sum(p.numel() for p in model.parameters())
+    print(f"{name}: {len(schema)} keys, {n_unique} unique params, logits diag {logits.diag().numpy()}")
+    return model, sd
+
+
+def multirank_gather_fixture():
+    """Reference gather_tensors under 2-rank gloo (lib/utils/comm.py:140-154):
+    rank-major concat, and gradient only through the local slice."""
+    import torch.multiprocessing as mp
+    path = os.path.join(OUT, "gather_2rank.npz")
+    mp.spawn(_gather_worker, args=(2, path), nprocs=2, join=True)
+
+
+def _gather_worker(rank, world, path):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = "29593"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    R.import_reference_module()
+    from utils.comm import gather_tensors
+    g = torch.Generator().manual_seed(100 + rank)
+    x = torch.randn(3, 8, generator=g, requires_grad=True)
+    allx = gather_tensors(x)
+    w = torch.arange(allx.numel(), dtype=torch.float32).reshape(allx.shape)
+    (allx * w).sum().backward()
+    if rank == 0:
+        np.savez(path, gathered=allx.detach().numpy(), grad_rank0=x.grad.numpy(), x_rank0=x.detach().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    for name in ("b32-yfcc-msclips", "b16-yfcc-msclips"):
+        run_config(name)
+    multirank_gather_fixture()
+
+
+if __name__ == "__main__":
+    main()
