@@ -1,0 +1,113 @@
+/* msclip_hip.h -- C ABI of libmsclip_hip.so (gfx950 / MI355X).
+ *
+ * The reference (Hxyou/MSCLIP) is pure Python: it has no FFI for this path, the
+ * boundary is an nn.Module.  These entry points are what the
+ * product's Python modules bind with ctypes; each one names the reference code
+ * it replaces ("M.py" = lib/models/clip_openai_pe_res_v1.py).
+ *
+ * Conventions: every pointer is a DEVICE pointer owned by the caller; kernels
+ * never allocate, never synchronise, and are ordered on `stream` (a
+ * hipStream_t passed as void*; NULL = the legacy default stream).  bf16 is the
+ * raw upper half of an IEEE fp32 (uint16).  Return value: 0 = launched,
+ * MSCLIP_EINVAL (-1) = rejected arguments, MSCLIP_ELAUNCH (-2) = HIP launch
+ * error.  "out_kind": 0 = bf16, 1 = fp32.
+ */
+#ifndef MSCLIP_HIP_H
+#define MSCLIP_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* out[row(m), n] = epi(alpha * sum_k X[m,k] * W[n,k])  -- bf16 MFMA GEMM.
+ * Replaces every F.linear / 1x1 / 3x3 conv on the path: M.py:612 (QKV in-proj),
+ * :747 (out_proj), :794-798 (MLP), :1993-2000 + :1920-1936 (stem stages, BN and the
+ * 1x1 shortcut folded into the 3x3 weight), :1842-1861 (bottleneck convs),
+ * :1573-1586 (adapter 1x1), :2690/:3074 (projections), :3141 (logits).
+ *   mode 0: X dense row-major [M, K], leading dimension ldx (elements, %8 == 0).
+ *   mode 1: X NHWC bf16 [B, H, Wd, Cin]; M = B*Ho*Wo; K-chunk c (8 channels) of a row is
+ *           described by ktab[c] = doff | kh<<20 | kw<<24 (negative = zero padding chunk),
+ *           doff = (kh*Wd + kw)*Cin + ch; taps outside the image read `zero`.
+ *   W is [N][ldw] bf16 with K % 64 == 0 (zero padded), ldw % 8 == 0; N % 4 == 0.
+ *   epilogue: v = alpha*acc + bias[n]; act 1 = QuickGELU (M.py:222-224); then
+ *   + resid (1: fp32 [m][n], 2: bf16 [m][n], 3: fp32 table row (m % rpg + roff), e.g.
+ *   positional embedding); act 2 = ReLU (after the residual); store to row
+ *   m + (m / rpg) * radd + roff (token scatter of M.py:2418-2425). */
+typedef struct msclip_gemm_desc {
+  const void* X;
+  const void* W;
+  const void* zero;      /* >= 16 bytes of zeros */
+  void* out;
+  const float* bias;     /* [N] or NULL */
+  const void* resid;     /* or NULL */
+  int M, N, K;
+  int ldx, ldw, ldo, ldr;  /* leading dimensions in elements; ldw >= K */
+  int mode;
+  int H, Wd, Cin, Ho, Wo, stride, pad;
+  const int* ktab;
+  int act;
+  int resid_kind;
+  int out_kind;
+  float alpha;
+  int rpg, radd, roff;   /* rpg > 0; use rpg = INT_MAX, radd = roff = 0 for the identity */
+} msclip_gemm_desc;
+
+int msclip_gemm(const msclip_gemm_desc* desc, void* stream);
+
+/* Fused softmax(q k^T [+ causal]) v per (sample, head), head_dim 64, L <= 224; q pre-scaled.
+ * qkv: bf16 [nsamples*L, ldq] with columns [q | k | v], each heads*64 wide.  out: bf16
+ * [nsamples*L, ldo].  Replaces M.py:707-738 (scale, reshapes, bmm, mask add, softmax, bmm). */
+int msclip_attention(const void* qkv, void* out, int nsamples, int L, int heads, int ldq, int ldo, int causal,
+                     void* stream);
+
+/* out[m] = LayerNorm(x[src(m)]) with fp32 statistics, eps inside the sqrt (M.py:204-219).
+ * src(m) = row_idx ? row_idx[m] : m*row_mul + row_add.  C in {256, 512, 768}.  raw_out (optional)
+ * receives the un-normalised fp32 row as well (moves a residual row between buffers for free). */
+int msclip_layernorm(const float* x, int ldx, const int* row_idx, int row_mul, int row_add, const float* gamma,
+                     const float* beta, void* out, int ldo, int out_kind, float* raw_out, int ld_raw, int M, int C,
+                     float eps, void* stream);
+
+/* x[row_base + b*L + l] = emb[tokens[b,l]] + pos[l]; eot_row[b] = row_base + b*L + argmax_l tokens[b,l]
+ * (M.py:3047-3048 and the EOT pick of :3057-3060).  tokens are int64. */
+int msclip_embed_tokens(const long long* tokens, const float* emb, const float* pos, float* x, int ldx, int* eot_row,
+                        int B, int L, int C, int vocab, int row_base, void* stream);
+
+/* x[b*L] = class_embedding + positional_embedding[0] (M.py:2421-2425). */
+int msclip_fill_cls(const float* cls, const float* pos, float* x, int ldx, int B, int L, int C, void* stream);
+
+/* Lateral_Adapter.forward bottom half + sum + ln_adapt (M.py:1763-1777):
+ * xout = LN([cls; BN(dw3x3(grid))] + [cls; t]); dww is [9][C] with BN folded, t fp32 [B*g*g, ldt]. */
+int msclip_adapter_combine_ln(const float* xin, int ldx, const float* t, int ldt, const float* dww, const float* dwb,
+                              const float* gamma, const float* beta, float* xout, int ldo, int B, int L, int g, int C,
+                              int usecls, float eps, void* stream);
+
+/* y = x / ||x||_2 (M.py:2983, :3076); writes fp32 and/or bf16 copies. */
+int msclip_l2norm(const float* x, int ldx, float* out_f32, int ldf, void* out_bf16, int ldb, int M, int E,
+                  void* stream);
+
+/* Both Cin=3 3x3/s2/p1 convs (stem conv1+bn1+relu, M.py:1993-1995; parallel stage 0, M.py:2260-2273)
+ * in one pass over the NCHW image.  w: fp32 [27][2*C1] (BN folded), bias [2*C1]; outputs NHWC bf16. */
+int msclip_stem_conv3x3s2_dual(const void* img, int img_is_bf16, const float* w, const float* bias, void* out_a,
+                               void* out_b, int B, int H, int W, int C1, void* stream);
+
+/* Depthwise kernel==stride conv of the adapters (M.py:1573-1581): NHWC bf16 in, [B*g*g, ldo] bf16 out,
+ * w fp32 [k*k][C] with the BN scale folded (the BN shift goes into the following 1x1's bias). */
+int msclip_dwpool(const void* top, const float* w, void* out, int ldo, int B, int H, int W, int C, int k,
+                  void* stream);
+
+/* lse[r] = log sum_n exp(logits[r, n]) over a fp32 block [R, N]. */
+int msclip_lse_rows(const float* logits, int ld, float* lse, int R, int N, void* stream);
+
+/* out[0] = scale * sum_i (lse_img[i] - d_i) + (lse_txt[i] - d_i), d_i = img_rows[i, label_off + i].
+ * With scale = 1/(2*N_global) the sum over ranks is the symmetric CLIP cross-entropy. */
+int msclip_clip_loss_partial(const float* lse_img, const float* lse_txt, const float* img_rows, int ld, int label_off,
+                             int R, float scale, float* out, void* stream);
+
+/* Library / device introspection (no GPU work). */
+int msclip_abi_version(void);
+const char* msclip_build_arch(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

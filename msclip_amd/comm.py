@@ -1,0 +1,99 @@
+"""Rank helpers and the feature all-gather of the contrastive head.
+
+Mirrors reference lib/utils/comm.py: `Comm` (:12-62) and `gather_tensors`
+(:140-154): every rank ends up with the rank-major concatenation of all ranks'
+rows, and autograd flows only through the local slice.  Differences, all
+MI355X-motivated: one collective into one contiguous buffer
+(`all_gather_into_tensor`, which is ncclAllGather == RCCL on ROCm) instead of
+world x `ones_like` + list all_gather + cat; image and text features can be
+packed into a single [B, 2, E] call (`gather_features`); the call can run on a
+side stream; and an uninitialised process group means world size 1 instead of
+an exception.
+"""
+import torch
+import torch.distributed as dist
+
+
+class Comm(object):
+    def __init__(self, local_rank=0):
+        self._local_rank = local_rank
+
+    @property
+    def world_size(self):
+        return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+    @property
+    def rank(self):
+        return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+    @property
+    def local_rank(self):
+        return self._local_rank if dist.is_available() and dist.is_initialized() else 0
+
+    @local_rank.setter
+    def local_rank(self, value):
+        self._local_rank = value
+
+    @property
+    def head(self):
+        return "Rank[{}/{}]".format(self.rank, self.world_size)
+
+    def is_main_process(self):
+        return self.rank == 0
+
+    def synchronize(self):
+        if self.world_size == 1:
+            return
+        dist.barrier()
+
+
+comm = Comm()
+
+
+def _all_gather_rows(t):
+    world = comm.world_size
+    out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    try:
+        dist.all_gather_into_tensor(out, t.contiguous())
+    except (RuntimeError, NotImplementedError):            # backends without the flat primitive
+        parts = list(out.chunk(world, dim=0))
+        dist.all_gather(parts, t.contiguous())
+    return out
+
+
+def gather_tensors(tensor):
+    """[B, ...] on every rank -> [B*world, ...], rank-major; gradient only through the local rows."""
+    if comm.world_size == 1:
+        return tensor
+    out = _all_gather_rows(tensor.detach())
+    if tensor.requires_grad:
+        b, r = tensor.shape[0], comm.rank
+        out = torch.cat([out[:r * b], tensor, out[(r + 1) * b:]], dim=0)
+    return out
+
+
+def gather_features(packed):
+    """packed [B, 2, E] (image | text features of the local batch) -> [world*B, 2, E] in ONE collective."""
+    if comm.world_size == 1:
+        return packed
+    return _all_gather_rows(packed)
+
+
+def local_label_offset(local_batch):
+    """Global label of local row i is offset + i (rank-major gather order, comm.py:150-153)."""
+    return comm.rank * local_batch
+
+
+def init_distributed(backend=None):
+    """env:// initialisation used by bench.py (reference lib/utils/utils.py:61-73: nccl == RCCL on ROCm)."""
+    import datetime
+    import os
+    if dist.is_initialized() or int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        return
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        comm.local_rank = local
+    dist.init_process_group(backend=backend, init_method="env://", timeout=datetime.timedelta(minutes=30))

@@ -1,0 +1,182 @@
+// Fused scaled-dot-product attention for short sequences (L <= 224): one wave
+// per (sample, head); S, P and O never leave registers, V^T is the only LDS
+// resident.  Replaces bmm + mask-add + softmax + bmm of Attention_CUST
+// (reference lib/models/clip_openai_pe_res_v1.py:707-738).
+//
+// Layout: qkv rows are tokens (sample-major, L per sample), columns
+// [q(H*64) | k(H*64) | v(H*64)], q already scaled by head_dim^-0.5 (folded into
+// the packed in_proj weight).  Output o[token][h*64 + d].
+//
+// MFMA plan (v_mfma_f32_32x32x16_bf16, operands swapped so that the softmax
+// axis is register-local):
+//   S^T[key][query]  = K . Q^T      A = K rows  (global -> VGPR, 16 B/lane)
+//                                   B = Q rows  (global -> VGPR)
+//   lane l holds query (l & 31) and 16 of every 32 keys; row max/sum = in-lane
+//   reduce + one exchange with lane l^32.
+//   O^T[d][query]    = V^T . P^T    A = V^T rows (LDS, ds_read_b128)
+//                                   B = P^T     = the S^T accumulators packed to
+//                                       bf16 in place (no cross-lane movement):
+//   k-step s of PV contracts 16 keys; the order of keys inside a k-step only has
+//   to agree between A and B, so V^T is written to LDS in the order the S^T
+//   accumulator layout yields: key 16s + w  ->  slot 16s + 8*((w>>2)&1) + (w&3) + 4*(w>>3).
+#include "common.h"
+#include "../../include/msclip_hip.h"
+
+namespace {
+
+template <int NT, bool CAUSAL, int WPB>
+__global__ __launch_bounds__(WPB * 64) void attn_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                   int nsamples, int L, int H, int ldq, int ldo) {
+  constexpr int KP = NT * 32;      // padded key count
+  constexpr int KPS = KP + 8;      // LDS row stride (elements): 16-B aligned, odd multiple of 16 B
+  extern __shared__ __attribute__((aligned(16))) bf16_t vt_all[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int pair = blockIdx.x * WPB + wave;
+  if (pair >= nsamples * H) return;
+  const int b = pair / H, h = pair - b * H;
+  bf16_t* vt = vt_all + wave * (64 * KPS);
+
+  const size_t row0 = (size_t)b * L;
+  const bf16_t* qbase = qkv + row0 * ldq + h * 64;
+  const bf16_t* kbase = qbase + H * 64;
+  const bf16_t* vbase = qbase + 2 * H * 64;
+
+  // ---- V -> LDS, transposed and slot-permuted; padded keys are zero
+  {
+    const int c = lane & 7;  // d chunk (8 values)
+#pragma unroll 2
+    for (int k0 = 0; k0 < KP; k0 += 8) {
+      const int key = k0 + (lane >> 3);
+      uint4 u = make_uint4(0, 0, 0, 0);
+      if (key < L) u = *(const uint4*)(vbase + (size_t)key * ldq + c * 8);
+      const int w = key & 15;
+      const int slot = (key & ~15) + (((w >> 2) & 1) << 3) + (w & 3) + ((w >> 3) << 2);
+      bf16_t* dst = vt + (c * 8) * KPS + slot;
+      dst[0 * KPS] = (bf16_t)(u.x & 0xffff); dst[1 * KPS] = (bf16_t)(u.x >> 16);
+      dst[2 * KPS] = (bf16_t)(u.y & 0xffff); dst[3 * KPS] = (bf16_t)(u.y >> 16);
+      dst[4 * KPS] = (bf16_t)(u.z & 0xffff); dst[5 * KPS] = (bf16_t)(u.z >> 16);
+      dst[6 * KPS] = (bf16_t)(u.w & 0xffff); dst[7 * KPS] = (bf16_t)(u.w >> 16);
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes done (wave-private region)
+  __builtin_amdgcn_wave_barrier();
+
+  const int fr = lane & 31, fhi = lane >> 5;
+
+  for (int qt = 0; qt < NT; ++qt) {
+    if (qt * 32 >= L) break;
+    // Q fragments for this query tile (rows clamped: padded queries are never stored)
+    const int qrow = min(qt * 32 + fr, L - 1);
+    bf16x8 qf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const bf16x8*)(qbase + (size_t)qrow * ldq + (kk * 2 + fhi) * 8);
+
+    const int nkt = CAUSAL ? (qt + 1) : NT;  // key tiles that can be unmasked
+    f32x16 s[NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+      if (kt < nkt && kt * 32 < L) {
+        const int krow = min(kt * 32 + fr, L - 1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const bf16x8 kf = *(const bf16x8*)(kbase + (size_t)krow * ldq + (kk * 2 + fhi) * 8);
+          s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[kt], 0, 0, 0);
+        }
+      }
+    }
+
+    // ---- masked softmax over keys (register-local + one half-wave exchange)
+    const int q = qt * 32 + fr;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
+        const bool ok = key < L && (!CAUSAL || key <= q) && kt < nkt;
+        s[kt][r] = ok ? s[kt][r] : -INFINITY;
+        mx = fmaxf(mx, s[kt][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __expf(s[kt][r] - mx);  // exp(-inf) = 0 for masked keys; key 0 is never masked
+        s[kt][r] = p;
+        sum += p;
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.f / sum;
+
+    // ---- O^T = V^T . P^T
+    f32x16 o[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+      if (kt < nkt && kt * 32 < L) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          bf16x8 pf;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) pf[e] = (__bf16)s[kt][half * 8 + e];
+          const int st = kt * 2 + half;
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            const bf16x8 vf = *(const bf16x8*)(vt + (dt * 32 + fr) * KPS + st * 16 + fhi * 8);
+            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
+          }
+        }
+      }
+    }
+
+    // ---- store: lane owns query q, d = dt*32 + 8g + 4*fhi + 0..3
+    if (q < L) {
+      bf16_t* orow = out + (row0 + q) * ldo + h * 64;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          uint2 v;
+          v.x = pack_bf16x2(o[dt][g * 4 + 0] * inv, o[dt][g * 4 + 1] * inv);
+          v.y = pack_bf16x2(o[dt][g * 4 + 2] * inv, o[dt][g * 4 + 3] * inv);
+          *(uint2*)(orow + dt * 32 + g * 8 + fhi * 4) = v;
+        }
+    }
+  }
+}
+
+template <int NT>
+int launch(const void* qkv, void* out, int nsamples, int L, int H, int ldq, int ldo, int causal, hipStream_t st) {
+  constexpr int WPB = NT > 4 ? 2 : 4;  // keep dynamic LDS under 64 KiB
+  const int pairs = nsamples * H;
+  const int grid = (pairs + WPB - 1) / WPB;
+  const size_t lds = WPB * 64 * (NT * 32 + 8) * sizeof(bf16_t);
+  if (causal)
+    hipLaunchKernelGGL((attn_kernel<NT, true, WPB>), dim3(grid), dim3(WPB * 64), lds, st, (const bf16_t*)qkv,
+                       (bf16_t*)out, nsamples, L, H, ldq, ldo);
+  else
+    hipLaunchKernelGGL((attn_kernel<NT, false, WPB>), dim3(grid), dim3(WPB * 64), lds, st, (const bf16_t*)qkv,
+                       (bf16_t*)out, nsamples, L, H, ldq, ldo);
+  return msclip_launch_status();
+}
+
+}  // namespace
+
+extern "C" int msclip_attention(const void* qkv, void* out, int nsamples, int L, int heads, int ldq, int ldo,
+                                int causal, void* stream) {
+  if (!qkv || !out || nsamples <= 0 || L <= 0 || heads <= 0 || (ldq % 8) || (ldo % 4)) return MSCLIP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (L <= 64) return launch<2>(qkv, out, nsamples, L, heads, ldq, ldo, causal, st);
+  if (L <= 96) return launch<3>(qkv, out, nsamples, L, heads, ldq, ldo, causal, st);
+  if (L <= 224) return launch<7>(qkv, out, nsamples, L, heads, ldq, ldo, causal, st);
+  return MSCLIP_EINVAL;
+}

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Build libmsclip_hip.so in-tree for gfx950 (cross-compiles without a GPU).
+set -euo pipefail
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffast-math -fno-finite-math-only -Wall -Wno-unused-function"
+mkdir -p build
+objs=()
+pids=()
+for f in gemm attention rows conv loss api; do
+  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ ../../include/msclip_hip.h -nt build/$f.o ]; then
+    $HIPCC $FLAGS -c $f.hip -o build/$f.o &
+    pids+=($!)
+  fi
+  objs+=(build/$f.o)
+done
+for p in "${pids[@]:-}"; do [ -n "$p" ] && wait $p; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o libmsclip_hip.so "${objs[@]}"
+echo "built $(pwd)/libmsclip_hip.so"

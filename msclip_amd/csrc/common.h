@@ -1,0 +1,59 @@
+// Shared device helpers for the gfx950 kernels (wave64, MFMA, bf16).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bf16 bits in HBM
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define AS1 __attribute__((address_space(1)))
+#define AS3 __attribute__((address_space(3)))
+
+#define MSCLIP_OK 0
+#define MSCLIP_EINVAL (-1)
+#define MSCLIP_ELAUNCH (-2)
+
+static inline int msclip_launch_status() {
+  return hipGetLastError() == hipSuccess ? MSCLIP_OK : MSCLIP_ELAUNCH;
+}
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t h) {
+  return __uint_as_float(((uint32_t)h) << 16);
+}
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {  // round-to-nearest-even (v_cvt_pk_bf16_f32)
+  __bf16 h = (__bf16)f;
+  return *reinterpret_cast<bf16_t*>(&h);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  bf16x2 v;
+  v[0] = (__bf16)lo;
+  v[1] = (__bf16)hi;
+  return *reinterpret_cast<uint32_t*>(&v);
+}
+__device__ __forceinline__ void unpack_bf16x8(const uint4& u, float* f) {
+  f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+  f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+  f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
+  f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// One 1-KiB LDS-DMA piece: every lane supplies its own 16-byte global source, the
+// destination is the wave-uniform LDS base + lane*16 (cdna_hip_programming.md s5).
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const AS1 void*)gsrc, (AS3 void*)lds_wave_base, 16, 0, 0);
+}

@@ -1,0 +1,134 @@
+// HBM-bound convolution front-ends that do not fit the implicit-GEMM loader:
+//  * the two Cin=3 3x3/s2 convolutions that open the stem and the parallel
+//    branch (reference lib/models/clip_openai_pe_res_v1.py:1993-1995 and
+//    2260-2273 via 2436) fused into ONE pass over the NCHW image: both read the
+//    same pixels, BatchNorm is folded into weights/bias, ReLU fused, output is
+//    two NHWC bf16 tensors;
+//  * the lateral adapters' non-overlapping depthwise "patch pooling" conv
+//    (kernel == stride, ibid. 1573-1581 with the PRALLEL_T2B_* geometry).
+#include "common.h"
+#include "../../include/msclip_hip.h"
+
+namespace {
+
+template <typename InT> __device__ __forceinline__ float ld_px(const InT* p);
+template <> __device__ __forceinline__ float ld_px<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ld_px<bf16_t>(const bf16_t* p) { return bf16_to_f32(*p); }
+
+// One thread per output pixel, all 2*C1 output channels in registers; the weights are
+// wave-uniform (compile-time indices) so they stream through the scalar cache.
+template <typename InT, int C1>
+__global__ __launch_bounds__(256) void stem_dual_kernel(const InT* __restrict__ img, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, bf16_t* __restrict__ out_a,
+                                                        bf16_t* __restrict__ out_b, int B, int H, int W, int Ho,
+                                                        int Wo) {
+  constexpr int CO = 2 * C1;
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)B * Ho * Wo;
+  if (p >= total) return;
+  const int b = (int)(p / (Ho * Wo));
+  const int r = (int)(p - (long long)b * Ho * Wo);
+  const int ho = r / Wo, wo = r - ho * Wo;
+
+  float xin[27];
+#pragma unroll
+  for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ih = 2 * ho - 1 + kh, iw = 2 * wo - 1 + kw;
+        const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+        xin[ci * 9 + kh * 3 + kw] = ok ? ld_px<InT>(img + (((size_t)b * 3 + ci) * H + ih) * W + iw) : 0.f;
+      }
+  float acc[CO];
+#pragma unroll
+  for (int c = 0; c < CO; ++c) acc[c] = bias[c];
+#pragma unroll
+  for (int t = 0; t < 27; ++t)
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] = fmaf(xin[t], w[t * CO + c], acc[c]);
+
+  bf16_t* oa = out_a + (size_t)p * C1;
+  bf16_t* ob = out_b + (size_t)p * C1;
+#pragma unroll
+  for (int c = 0; c < C1; c += 8) {
+    uint4 u, v;
+    u.x = pack_bf16x2(fmaxf(acc[c + 0], 0.f), fmaxf(acc[c + 1], 0.f));
+    u.y = pack_bf16x2(fmaxf(acc[c + 2], 0.f), fmaxf(acc[c + 3], 0.f));
+    u.z = pack_bf16x2(fmaxf(acc[c + 4], 0.f), fmaxf(acc[c + 5], 0.f));
+    u.w = pack_bf16x2(fmaxf(acc[c + 6], 0.f), fmaxf(acc[c + 7], 0.f));
+    v.x = pack_bf16x2(fmaxf(acc[C1 + c + 0], 0.f), fmaxf(acc[C1 + c + 1], 0.f));
+    v.y = pack_bf16x2(fmaxf(acc[C1 + c + 2], 0.f), fmaxf(acc[C1 + c + 3], 0.f));
+    v.z = pack_bf16x2(fmaxf(acc[C1 + c + 4], 0.f), fmaxf(acc[C1 + c + 5], 0.f));
+    v.w = pack_bf16x2(fmaxf(acc[C1 + c + 6], 0.f), fmaxf(acc[C1 + c + 7], 0.f));
+    *(uint4*)(oa + c) = u;
+    *(uint4*)(ob + c) = v;
+  }
+}
+
+// out[b, gy, gx, c] = sum_{ky,kx<k} w[ky*k+kx][c] * top[b, gy*k+ky, gx*k+kx, c]   (NHWC bf16, k == stride, pad 0)
+__global__ __launch_bounds__(256) void dwpool_kernel(const bf16_t* __restrict__ top, const float* __restrict__ w,
+                                                     bf16_t* __restrict__ out, int ldo, int B, int H, int W, int C,
+                                                     int k, int g) {
+  const int nch = C >> 3;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)B * g * g * nch;
+  if (idx >= total) return;
+  const int cc = (int)(idx % nch);
+  const long long pidx = idx / nch;
+  const int b = (int)(pidx / (g * g));
+  const int pr = (int)(pidx - (long long)b * g * g);
+  const int gy = pr / g, gx = pr - gy * g;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  for (int ky = 0; ky < k; ++ky) {
+    const bf16_t* rowp = top + (((size_t)b * H + gy * k + ky) * W + (size_t)gx * k) * C + cc * 8;
+    const float* wr = w + (size_t)(ky * k) * C + cc * 8;
+#pragma unroll 4
+    for (int kx = 0; kx < k; ++kx) {
+      const uint4 u = *(const uint4*)(rowp + (size_t)kx * C);
+      const float4 w0 = *(const float4*)(wr + (size_t)kx * C);
+      const float4 w1 = *(const float4*)(wr + (size_t)kx * C + 4);
+      float f[8];
+      unpack_bf16x8(u, f);
+      acc[0] = fmaf(f[0], w0.x, acc[0]); acc[1] = fmaf(f[1], w0.y, acc[1]);
+      acc[2] = fmaf(f[2], w0.z, acc[2]); acc[3] = fmaf(f[3], w0.w, acc[3]);
+      acc[4] = fmaf(f[4], w1.x, acc[4]); acc[5] = fmaf(f[5], w1.y, acc[5]);
+      acc[6] = fmaf(f[6], w1.z, acc[6]); acc[7] = fmaf(f[7], w1.w, acc[7]);
+    }
+  }
+  uint4 o;
+  o.x = pack_bf16x2(acc[0], acc[1]); o.y = pack_bf16x2(acc[2], acc[3]);
+  o.z = pack_bf16x2(acc[4], acc[5]); o.w = pack_bf16x2(acc[6], acc[7]);
+  *(uint4*)(out + (size_t)pidx * ldo + cc * 8) = o;
+}
+
+}  // namespace
+
+extern "C" int msclip_stem_conv3x3s2_dual(const void* img, int img_is_bf16, const float* w, const float* bias,
+                                          void* out_a, void* out_b, int B, int H, int W, int C1, void* stream) {
+  if (!img || !w || !bias || !out_a || !out_b || B <= 0 || C1 != 48) return MSCLIP_EINVAL;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const long long total = (long long)B * Ho * Wo;
+  const dim3 grid((unsigned)((total + 255) / 256)), blk(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (img_is_bf16)
+    hipLaunchKernelGGL((stem_dual_kernel<bf16_t, 48>), grid, blk, 0, st, (const bf16_t*)img, w, bias, (bf16_t*)out_a,
+                       (bf16_t*)out_b, B, H, W, Ho, Wo);
+  else
+    hipLaunchKernelGGL((stem_dual_kernel<float, 48>), grid, blk, 0, st, (const float*)img, w, bias, (bf16_t*)out_a,
+                       (bf16_t*)out_b, B, H, W, Ho, Wo);
+  return msclip_launch_status();
+}
+
+extern "C" int msclip_dwpool(const void* top, const float* w, void* out, int ldo, int B, int H, int W, int C, int k,
+                             void* stream) {
+  if (!top || !w || !out || B <= 0 || k <= 0 || (C % 8) || (ldo % 8) || (H % k) || H != W) return MSCLIP_EINVAL;
+  const int g = H / k;
+  const long long total = (long long)B * g * g * (C / 8);
+  hipLaunchKernelGGL(dwpool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)top, w, (bf16_t*)out, ldo, B, H, W, C, k, g);
+  return msclip_launch_status();
+}

@@ -1,0 +1,283 @@
+// Row-wise HBM-bound kernels: one wave64 per token row, 16-byte accesses,
+// reductions by lane shuffles (no LDS).  TF-style LayerNorm with fp32
+// statistics and eps inside the sqrt (reference
+// lib/models/clip_openai_pe_res_v1.py:204-219), token embedding, the fused
+// lateral-adapter combine (ibid. 1752-1778) and the L2 normalisation of the
+// projected features (ibid. 2983, 3076).
+#include "common.h"
+#include "../../include/msclip_hip.h"
+
+namespace {
+
+constexpr int WPB = 4;  // waves (rows) per block
+
+template <int NV>
+__device__ __forceinline__ void ln_core(float4 (&v)[NV], const float* __restrict__ gamma,
+                                        const float* __restrict__ beta, float eps, int lane) {
+  constexpr float invC = 1.f / (NV * 256);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  const float mean = wave_sum(s) * invC;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+    q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+  }
+  const float var = wave_sum(q) * invC;
+  const float rstd = 1.f / sqrtf(var + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float4 g = *(const float4*)(gamma + i * 256 + lane * 4);
+    const float4 b = *(const float4*)(beta + i * 256 + lane * 4);
+    v[i].x = g.x * (v[i].x * rstd) + b.x;
+    v[i].y = g.y * (v[i].y * rstd) + b.y;
+    v[i].z = g.z * (v[i].z * rstd) + b.z;
+    v[i].w = g.w * (v[i].w * rstd) + b.w;
+  }
+}
+
+template <int NV>
+__device__ __forceinline__ void store_row(const float4 (&v)[NV], void* out, size_t row, int ldo, int out_kind,
+                                          int lane) {
+  if (out_kind == 1) {
+    float* o = (float*)out + row * ldo;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) *(float4*)(o + i * 256 + lane * 4) = v[i];
+  } else {
+    bf16_t* o = (bf16_t*)out + row * ldo;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      uint2 p;
+      p.x = pack_bf16x2(v[i].x, v[i].y);
+      p.y = pack_bf16x2(v[i].z, v[i].w);
+      *(uint2*)(o + i * 256 + lane * 4) = p;
+    }
+  }
+}
+
+// y[m] = LN(x[src(m)]) ; src(m) = row_idx ? row_idx[m] : m * row_mul + row_add
+template <int NV>
+__global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, int ldx, const int* __restrict__ row_idx,
+                                                 int row_mul, int row_add, const float* __restrict__ gamma,
+                                                 const float* __restrict__ beta, void* out, int ldo, int out_kind,
+                                                 float* __restrict__ raw_out, int ld_raw, int M, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * WPB + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const size_t src = row_idx ? (size_t)row_idx[m] : (size_t)m * row_mul + row_add;
+  float4 v[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = *(const float4*)(x + src * ldx + i * 256 + lane * 4);
+  if (raw_out) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) *(float4*)(raw_out + (size_t)m * ld_raw + i * 256 + lane * 4) = v[i];
+  }
+  ln_core<NV>(v, gamma, beta, eps, lane);
+  store_row<NV>(v, out, (size_t)m, ldo, out_kind, lane);
+}
+
+// x[row_base + b*L + l] = emb[tok[b, l]] + pos[l]      (reference :3047-3048)
+template <int NV>
+__global__ __launch_bounds__(256) void embed_kernel(const long long* __restrict__ tok, const float* __restrict__ emb,
+                                                    const float* __restrict__ pos, float* __restrict__ x, int ldx,
+                                                    int rows, int L, int vocab) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * WPB + (threadIdx.x >> 6);
+  if (m >= rows) return;
+  const int l = m % L;
+  long long t = tok[m];
+  t = t < 0 ? 0 : (t >= vocab ? vocab - 1 : t);
+  const float* e = emb + (size_t)t * (NV * 256);
+  const float* p = pos + (size_t)l * (NV * 256);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float4 a = *(const float4*)(e + i * 256 + lane * 4);
+    const float4 b = *(const float4*)(p + i * 256 + lane * 4);
+    *(float4*)(x + (size_t)m * ldx + i * 256 + lane * 4) = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+  }
+}
+
+// eot_row[b] = row_base + b*L + argmax_l tok[b, l]   (first maximum, like torch.argmax; reference :3057-3060)
+__global__ __launch_bounds__(64) void eot_kernel(const long long* __restrict__ tok, int* __restrict__ eot_row, int B,
+                                                 int L, int row_base) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  long long best = -0x7fffffffffffffffLL;
+  int bi = 0x7fffffff;
+  for (int l = lane; l < L; l += 64) {
+    const long long t = tok[(size_t)b * L + l];
+    if (t > best) { best = t; bi = l; }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const long long ob = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  if (lane == 0) eot_row[b] = row_base + b * L + bi;
+}
+
+// x[b*L + 0] = cls + pos[0]   (reference :2421-2425, before ln_pre)
+template <int NV>
+__global__ __launch_bounds__(256) void cls_kernel(const float* __restrict__ cls, const float* __restrict__ pos,
+                                                  float* __restrict__ x, int ldx, int B, int L) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * WPB + (threadIdx.x >> 6);
+  if (b >= B) return;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float4 a = *(const float4*)(cls + i * 256 + lane * 4);
+    const float4 p = *(const float4*)(pos + i * 256 + lane * 4);
+    *(float4*)(x + (size_t)b * L * ldx + i * 256 + lane * 4) = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+  }
+}
+
+// Lateral adapter combine: out = ln_adapt( [cls ; BN(dw3x3(grid))] + [cls ; t] )
+//   row 0      : (1 + usecls) * x[b, 0]
+//   row 1 + p  : dwb + sum_taps dww[tap] * x[b, 1 + nbr(p, tap)] + t[b*g*g + p]
+template <int NV>
+__global__ __launch_bounds__(256) void adapter_kernel(const float* __restrict__ xin, int ldx,
+                                                      const float* __restrict__ t, int ldt,
+                                                      const float* __restrict__ dww, const float* __restrict__ dwb,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      float* __restrict__ xout, int ldo, int B, int L, int g,
+                                                      int usecls, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * WPB + (threadIdx.x >> 6);
+  if (m >= B * L) return;
+  const int b = m / L, l = m - b * L;
+  constexpr int C = NV * 256;
+  float4 v[NV];
+  if (l == 0) {
+    const float f = usecls ? 2.f : 1.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const float4 a = *(const float4*)(xin + (size_t)m * ldx + i * 256 + lane * 4);
+      v[i] = make_float4(a.x * f, a.y * f, a.z * f, a.w * f);
+    }
+  } else {
+    const int p = l - 1, gy = p / g, gx = p - gy * g;
+    const float* tr = t + ((size_t)b * g * g + p) * ldt;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const float4 a = *(const float4*)(tr + i * 256 + lane * 4);
+      const float4 c = *(const float4*)(dwb + i * 256 + lane * 4);
+      v[i] = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
+    }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int yy = gy + ky - 1;
+      if (yy < 0 || yy >= g) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int xx = gx + kx - 1;
+        if (xx < 0 || xx >= g) continue;
+        const float* nb = xin + ((size_t)b * L + 1 + yy * g + xx) * ldx;
+        const float* wt = dww + (ky * 3 + kx) * C;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          const float4 a = *(const float4*)(nb + i * 256 + lane * 4);
+          const float4 w = *(const float4*)(wt + i * 256 + lane * 4);
+          v[i].x += a.x * w.x; v[i].y += a.y * w.y; v[i].z += a.z * w.z; v[i].w += a.w * w.w;
+        }
+      }
+    }
+  }
+  ln_core<NV>(v, gamma, beta, eps, lane);
+  store_row<NV>(v, xout, (size_t)m, ldo, 1, lane);
+}
+
+// y = x / ||x||_2 per row, fp32 math; writes fp32 and (optionally) a bf16 copy for the logits GEMM
+__global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ x, int ldx, float* __restrict__ of,
+                                                     int ldf, bf16_t* __restrict__ ob, int ldb, int M, int E) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * WPB + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const float* r = x + (size_t)m * ldx;
+  float q = 0.f;
+  for (int c = lane * 4; c < E; c += 256) {
+    const float4 a = *(const float4*)(r + c);
+    q += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
+  }
+  const float inv = 1.f / sqrtf(wave_sum(q));
+  for (int c = lane * 4; c < E; c += 256) {
+    float4 a = *(const float4*)(r + c);
+    a.x *= inv; a.y *= inv; a.z *= inv; a.w *= inv;
+    if (of) *(float4*)(of + (size_t)m * ldf + c) = a;
+    if (ob) {
+      uint2 p;
+      p.x = pack_bf16x2(a.x, a.y);
+      p.y = pack_bf16x2(a.z, a.w);
+      *(uint2*)(ob + (size_t)m * ldb + c) = p;
+    }
+  }
+}
+
+}  // namespace
+
+#define NV_DISPATCH(C, CALL3, CALL2, CALL1)        \
+  if ((C) == 768) { CALL3; }                        \
+  else if ((C) == 512) { CALL2; }                   \
+  else if ((C) == 256) { CALL1; }                   \
+  else return MSCLIP_EINVAL;
+
+extern "C" int msclip_layernorm(const float* x, int ldx, const int* row_idx, int row_mul, int row_add,
+                                const float* gamma, const float* beta, void* out, int ldo, int out_kind,
+                                float* raw_out, int ld_raw, int M, int C, float eps, void* stream) {
+  if (!x || !gamma || !beta || !out || M <= 0 || (ldx % 4) || (ldo % 4)) return MSCLIP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((M + WPB - 1) / WPB), blk(256);
+  NV_DISPATCH(C,
+              hipLaunchKernelGGL(ln_kernel<3>, grid, blk, 0, st, x, ldx, row_idx, row_mul, row_add, gamma, beta, out, ldo, out_kind, raw_out, ld_raw, M, eps),
+              hipLaunchKernelGGL(ln_kernel<2>, grid, blk, 0, st, x, ldx, row_idx, row_mul, row_add, gamma, beta, out, ldo, out_kind, raw_out, ld_raw, M, eps),
+              hipLaunchKernelGGL(ln_kernel<1>, grid, blk, 0, st, x, ldx, row_idx, row_mul, row_add, gamma, beta, out, ldo, out_kind, raw_out, ld_raw, M, eps))
+  return msclip_launch_status();
+}
+
+extern "C" int msclip_embed_tokens(const long long* tokens, const float* emb, const float* pos, float* x, int ldx,
+                                   int* eot_row, int B, int L, int C, int vocab, int row_base, void* stream) {
+  if (!tokens || !emb || !pos || !x || B <= 0 || L <= 0 || (ldx % 4)) return MSCLIP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int rows = B * L;
+  const dim3 grid((rows + WPB - 1) / WPB), blk(256);
+  float* xb = x + (size_t)row_base * ldx;
+  NV_DISPATCH(C, hipLaunchKernelGGL(embed_kernel<3>, grid, blk, 0, st, tokens, emb, pos, xb, ldx, rows, L, vocab),
+              hipLaunchKernelGGL(embed_kernel<2>, grid, blk, 0, st, tokens, emb, pos, xb, ldx, rows, L, vocab),
+              hipLaunchKernelGGL(embed_kernel<1>, grid, blk, 0, st, tokens, emb, pos, xb, ldx, rows, L, vocab))
+  if (eot_row) hipLaunchKernelGGL(eot_kernel, dim3(B), dim3(64), 0, st, tokens, eot_row, B, L, row_base);
+  return msclip_launch_status();
+}
+
+extern "C" int msclip_fill_cls(const float* cls, const float* pos, float* x, int ldx, int B, int L, int C,
+                               void* stream) {
+  if (!cls || !pos || !x || B <= 0 || (ldx % 4)) return MSCLIP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((B + WPB - 1) / WPB), blk(256);
+  NV_DISPATCH(C, hipLaunchKernelGGL(cls_kernel<3>, grid, blk, 0, st, cls, pos, x, ldx, B, L),
+              hipLaunchKernelGGL(cls_kernel<2>, grid, blk, 0, st, cls, pos, x, ldx, B, L),
+              hipLaunchKernelGGL(cls_kernel<1>, grid, blk, 0, st, cls, pos, x, ldx, B, L))
+  return msclip_launch_status();
+}
+
+extern "C" int msclip_adapter_combine_ln(const float* xin, int ldx, const float* t, int ldt, const float* dww,
+                                         const float* dwb, const float* gamma, const float* beta, float* xout,
+                                         int ldo, int B, int L, int g, int C, int usecls, float eps, void* stream) {
+  if (!xin || !t || !dww || !dwb || !gamma || !beta || !xout || xin == xout || L != g * g + 1) return MSCLIP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int rows = B * L;
+  const dim3 grid((rows + WPB - 1) / WPB), blk(256);
+  NV_DISPATCH(C,
+              hipLaunchKernelGGL(adapter_kernel<3>, grid, blk, 0, st, xin, ldx, t, ldt, dww, dwb, gamma, beta, xout, ldo, B, L, g, usecls, eps),
+              hipLaunchKernelGGL(adapter_kernel<2>, grid, blk, 0, st, xin, ldx, t, ldt, dww, dwb, gamma, beta, xout, ldo, B, L, g, usecls, eps),
+              hipLaunchKernelGGL(adapter_kernel<1>, grid, blk, 0, st, xin, ldx, t, ldt, dww, dwb, gamma, beta, xout, ldo, B, L, g, usecls, eps))
+  return msclip_launch_status();
+}
+
+extern "C" int msclip_l2norm(const float* x, int ldx, float* out_f32, int ldf, void* out_bf16, int ldb, int M, int E,
+                             void* stream) {
+  if (!x || (!out_f32 && !out_bf16) || M <= 0 || (E % 4) || (ldx % 4)) return MSCLIP_EINVAL;
+  hipLaunchKernelGGL(l2norm_kernel, dim3((M + WPB - 1) / WPB), dim3(256), 0, (hipStream_t)stream, x, ldx, out_f32, ldf,
+                     (bf16_t*)out_bf16, ldb, M, E);
+  return msclip_launch_status();
+}

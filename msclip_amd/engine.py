@@ -1,0 +1,358 @@
+"""Execution engine of the MS-CLIP-S hot path on one MI355X.
+
+Packs the module's parameters once (bf16 GEMM weights, folded BatchNorm,
+chunk tables; msclip_amd.packing) and drives the HIP kernels of
+libmsclip_hip.so through msclip_amd.hip.  Data layout in HBM:
+
+* token stream: ONE fp32 residual matrix X[Mv + Mt, D], image tokens of all
+  samples first (sample-major, L_img rows each), then text tokens.  Layers whose
+  attention/MLP tensors are shared between the towers (reference M.py:2786-2830)
+  run ONE GEMM over all Mv + Mt rows per projection; LayerNorms and attention
+  stay per-modality (own gamma/beta, own sequence length / causal flag).
+* GEMM operands/outputs bf16 (LN output, QKV, attention output, MLP hidden),
+  accumulation and residual stream fp32.
+* convolutional activations NHWC bf16, so a conv is the gathering GEMM.
+
+Control flow follows Transformer.forward (M.py:2388-2459): stem -> tokens ->
+for i in 1..11: [parallel stage + lateral adapter before blocks 2,4,6,8,10] ->
+block i; text block 0 is text-only.
+"""
+import torch
+import torch.distributed as dist
+
+from . import comm as C
+from . import hip
+from . import packing as P
+
+
+class _BlockW:
+    """Packed weights of one ResidualAttentionBlock's shareable part."""
+
+    def __init__(self, blk, heads):
+        self.wqkv, self.bqkv = P.qkv_weights(blk.attn.in_proj_weight.detach(), blk.attn.in_proj_bias.detach(), heads)
+        bf = torch.bfloat16
+        self.wo = blk.attn.out_proj.weight.detach().to(bf).contiguous()
+        self.bo = blk.attn.out_proj.bias.detach().float().contiguous()
+        self.wfc = blk.mlp.c_fc.weight.detach().to(bf).contiguous()
+        self.bfc = blk.mlp.c_fc.bias.detach().float().contiguous()
+        self.wpr = blk.mlp.c_proj.weight.detach().to(bf).contiguous()
+        self.bpr = blk.mlp.c_proj.bias.detach().float().contiguous()
+
+
+class _LN:
+    def __init__(self, ln):
+        self.g = ln.weight.detach().float().contiguous()
+        self.b = ln.bias.detach().float().contiguous()
+
+
+class Engine:
+    def __init__(self, model):
+        hip.require_gpu()
+        ref = model.visual.positional_embedding
+        if not ref.is_cuda:
+            raise hip.HipUnavailable("model parameters are on the CPU: call model.cuda() (there is no CPU path)")
+        if ref.dtype != torch.float32:
+            raise NotImplementedError("keep the module in fp32 (checkpoint ABI); the engine makes its own bf16 copies")
+        self.dev = ref.device
+        self.model = model
+        self._ws = {}
+        with torch.cuda.device(self.dev), torch.no_grad():
+            self._pack(model)
+
+    # ------------------------------------------------------------------ packing
+    def _pack(self, m):
+        dev = self.dev
+        v, vt = m.visual, m.visual.transformer
+        sd = {k: t.detach() for k, t in m.state_dict().items()}
+        self.D = m.transformer_width
+        self.E = m.embed_dim
+        self.heads = m.heads
+        self.Lv = v.sequence_length
+        self.g = v.input_resolution // v.patch_size
+        self.Lt = m.context_length
+        self.S = v.input_resolution
+        self.n_layers = len(m.transformer.resblocks)
+        assert len(vt.resblocks) == self.n_layers, "vision and text depth must match for the batched layer loop"
+        self.logit_scale_exp = float(m.logit_scale.detach().exp())
+
+        # --- stem
+        sp = "visual.transformer.resblocks.0"
+        self.dual_w, self.dual_b = [t.to(dev) for t in P.stem_dual_weights(sd, sp, "visual.transformer.parallel_branch_v.0")]
+        stem = vt.resblocks[0]
+        h = (self.S + 2 - 3) // 2 + 1
+        self.h1 = h
+        self.stem_specs = []
+        for i, s in enumerate(stem.strides):
+            spec = P.stem_stage(sd, f"{sp}.resnet_stage.conv_{i}", h, s).to(dev)
+            self.stem_specs.append(spec)
+            h = spec.h_out
+        assert h == self.g, f"stem output grid {h} != token grid {self.g}"
+        self.w_last = sd[sp + ".last_conv.weight"][:, :, 0, 0].to(torch.bfloat16).contiguous()
+        self.cls = sd["visual.class_embedding"].float().contiguous()
+        self.vpos = sd["visual.positional_embedding"].float().contiguous()
+        self.ln_pre, self.ln_post = _LN(v.ln_pre), _LN(v.ln_post)
+        self.w_vproj = sd["visual.proj"].t().to(torch.bfloat16).contiguous()          # [E, D]
+
+        # --- parallel branch + adapters
+        self.lateral = list(vt.parallel_lateral_layers)
+        self.usecls = vt.t2b_usecls
+        self.par_specs, self.adapters = [None], []
+        h = self.h1
+        self.par_hw = [h]
+        for j in range(1, 5):
+            specs = P.bottleneck(sd, f"visual.transformer.parallel_branch_v.{j}.resnet_stage.conv_0", h,
+                                 vt.parallel_strides[j])
+            self.par_specs.append([s.to(dev) for s in specs])
+            h = specs[3].h_out
+            self.par_hw.append(h)
+        for j in range(5):
+            pool, k, pw, dww, dwb = P.adapter_weights(sd, f"visual.transformer.parallel_lateral_adapter.{j}", self.g)
+            assert self.par_hw[j] == self.g * k, (self.par_hw[j], self.g, k)
+            self.adapters.append(dict(pool=pool.to(dev), k=k, pw=pw.to(dev), dww=dww.to(dev), dwb=dwb.to(dev),
+                                      ln=_LN(vt.parallel_lateral_adapter[j].ln_adapt), C=pool.shape[1]))
+
+        # --- transformer blocks (shared tensors packed once)
+        cache = {}
+
+        def blockw(blk):
+            key = (blk.attn.in_proj_weight.data_ptr(), blk.attn.out_proj.weight.data_ptr(),
+                   blk.mlp.c_fc.weight.data_ptr(), blk.mlp.c_proj.weight.data_ptr())
+            if key not in cache:
+                cache[key] = _BlockW(blk, self.heads)
+            return cache[key]
+
+        self.vblk, self.tblk = [None] * self.n_layers, [None] * self.n_layers
+        for i in range(self.n_layers):
+            tb = m.transformer.resblocks[i]
+            self.tblk[i] = dict(w=blockw(tb), ln1=_LN(tb.ln_1), ln2=_LN(tb.ln_2))
+            if i >= 1:
+                vb = vt.resblocks[i]
+                self.vblk[i] = dict(w=blockw(vb), ln1=_LN(vb.ln_1), ln2=_LN(vb.ln_2))
+        self.n_packed_blocks = len(cache)
+
+        # --- text front / heads
+        self.emb = m.token_embedding.weight.detach()
+        self.tpos = sd["positional_embedding"].float().contiguous()
+        self.ln_final = _LN(m.ln_final)
+        self.w_tproj = sd["text_projection"].t().to(torch.bfloat16).contiguous()      # [E, D]
+
+    # ------------------------------------------------------------------ workspace
+    def _workspace(self, Bi, Bt):
+        key = (Bi, Bt)
+        w = self._ws.get(key)
+        if w is not None:
+            return w
+        dev, D, E = self.dev, self.D, self.E
+        bf, f32 = torch.bfloat16, torch.float32
+        Mv, Mt = Bi * self.Lv, Bt * self.Lt
+        M = Mv + Mt
+
+        def buf(*shape, dtype=bf):
+            return torch.empty(shape, dtype=dtype, device=dev)
+
+        w = dict(Mv=Mv, Mt=Mt, M=M)
+        w["X"] = buf(M, D, dtype=f32)
+        w["LNO"], w["QKV"], w["AO"], w["HID"] = buf(M, D), buf(M, 3 * D), buf(M, D), buf(M, 4 * D)
+        if Bi:
+            w["XA"] = buf(Mv, D, dtype=f32)
+            h1 = self.h1
+            w["S1"], w["P0"] = buf(Bi * h1 * h1, D // 16), buf(Bi * h1 * h1, D // 16)
+            w["stem"] = [buf(Bi * s.h_out * s.w_out, s.cout) for s in self.stem_specs]
+            w["par"] = [w["P0"]]
+            w["par_tmp"] = [None]
+            for j in range(1, 5):
+                c1, c2, cr, c3 = self.par_specs[j]
+                w["par_tmp"].append((buf(Bi * c1.h_out * c1.w_out, c1.cout), buf(Bi * c2.h_out * c2.w_out, c2.cout),
+                                     buf(Bi * cr.h_out * cr.w_out, cr.cout)))
+                w["par"].append(buf(Bi * c3.h_out * c3.w_out, c3.cout))
+            w["pool"] = [buf(Bi * self.g * self.g, a["C"]) for a in self.adapters]
+            w["T"] = buf(Bi * self.g * self.g, D, dtype=f32)
+            w["hv"] = buf(Bi, D)
+            w["fv_raw"], w["fv"] = buf(Bi, E, dtype=f32), buf(Bi, E, dtype=f32)
+        if Bt:
+            w["eot"] = torch.empty(Bt, dtype=torch.int32, device=dev)
+            w["ht"] = buf(Bt, D)
+            w["ft_raw"], w["ft"] = buf(Bt, E, dtype=f32), buf(Bt, E, dtype=f32)
+        if Bi and Bt and Bi == Bt:
+            w["packed"] = buf(Bi, 2, E)                      # bf16 [B, (image|text), E] for gather + logits GEMM
+            w["loss"] = buf(1, dtype=f32)
+        self._ws[key] = w
+        return w
+
+    # ------------------------------------------------------------------ pieces
+    def _conv(self, x, spec, out, B, act=hip.ACT_NONE, resid=None, out_f32=False):
+        return hip.gemm(x, spec.weight, out, M=B * spec.h_out * spec.w_out, N=spec.cout, bias=spec.bias, act=act,
+                        resid=resid, resid_kind=hip.RESID_BF16 if resid is not None else hip.RESID_NONE,
+                        conv=spec.geometry(), ktab=spec.ktab)
+
+    def _vision_front(self, img, w, Bi):
+        """Stem + tokenisation (M.py:2416-2426) and stage 0 of the parallel branch (M.py:2436)."""
+        hip.stem_conv_dual(img, self.dual_w, self.dual_b, w["S1"], w["P0"])
+        x = w["S1"]
+        for spec, out in zip(self.stem_specs, w["stem"]):
+            self._conv(x, spec, out, Bi, act=hip.ACT_RELU)
+            x = out
+        g2 = self.g * self.g
+        # last_conv (1x1, no BN/ReLU) fused with "+ positional_embedding" and the scatter to token rows b*L + 1 + p
+        hip.gemm(x, self.w_last, w["X"], M=Bi * g2, resid=self.vpos, resid_kind=hip.RESID_TABLE, rpg=g2, radd=1, roff=1)
+        hip.fill_cls(self.cls, self.vpos, w["X"], Bi, self.Lv)
+        xv = w["X"][:w["Mv"]]
+        hip.layernorm(xv, self.ln_pre.g, self.ln_pre.b, xv, w["Mv"])
+
+    def _parallel_stage(self, j, w, Bi):
+        if j == 0:
+            return
+        c1, c2, cr, c3 = self.par_specs[j]
+        t1, t2, tr = w["par_tmp"][j]
+        src = w["par"][j - 1]
+        self._conv(src, c1, t1, Bi, act=hip.ACT_RELU)
+        self._conv(t1, c2, t2, Bi, act=hip.ACT_RELU)
+        self._conv(src, cr, tr, Bi)
+        self._conv(t2, c3, w["par"][j], Bi, act=hip.ACT_RELU, resid=tr)
+
+    def _adapter(self, j, w, Bi):
+        """Lateral_Adapter (M.py:1752-1778): X[:Mv] -> XA."""
+        a = self.adapters[j]
+        hw = self.par_hw[j]
+        hip.dwpool(w["par"][j], a["pool"], w["pool"][j], Bi, hw, hw, a["C"], a["k"])
+        pw = a["pw"]
+        hip.gemm(w["pool"][j], pw.weight, w["T"], M=Bi * self.g * self.g, N=pw.cout, bias=pw.bias, conv=pw.geometry(),
+                 ktab=pw.ktab)
+        hip.adapter_combine_ln(w["X"][:w["Mv"]], w["T"], a["dww"], a["dwb"], a["ln"].g, a["ln"].b, w["XA"], Bi,
+                               self.Lv, self.g, self.usecls)
+
+    def _text_front(self, tok, w, Bt):
+        hip.embed_tokens(tok, self.emb, self.tpos, w["X"], w["eot"], w["Mv"])
+
+    def _blocks(self, w, Bi, Bt):
+        Mv, M = w["Mv"], w["M"]
+        X, LNO, QKV, AO, HID = w["X"], w["LNO"], w["QKV"], w["AO"], w["HID"]
+        for i in range(self.n_layers):
+            vb = self.vblk[i] if Bi else None
+            tb = self.tblk[i] if Bt else None
+            if vb is None and tb is None:
+                continue
+            segs = []                      # (row0, row1, block dict)
+            if vb is not None:
+                segs.append((0, Mv, vb))
+            if tb is not None:
+                segs.append((Mv, M, tb))
+            # --- lateral adapter in front of this vision block
+            vis_src = X[:Mv] if vb is not None else None
+            raw = None
+            if vb is not None and i in self.lateral:
+                j = self.lateral.index(i)
+                self._parallel_stage(j, w, Bi)
+                self._adapter(j, w, Bi)
+                vis_src, raw = w["XA"], X[:Mv]          # ln_1 reads the adapter output and moves it back into X
+            # --- ln_1 (modality specific)
+            for r0, r1, b in segs:
+                if b is vb:
+                    hip.layernorm(vis_src, b["ln1"].g, b["ln1"].b, LNO[r0:r1], r1 - r0, raw_out=raw)
+                else:
+                    hip.layernorm(X[r0:r1], b["ln1"].g, b["ln1"].b, LNO[r0:r1], r1 - r0)
+            # --- projections: one launch over both towers when the tensors are shared
+            groups = [(segs[0][0], segs[-1][1], segs[0][2]["w"])] if len(segs) == 2 and vb["w"] is tb["w"] else \
+                     [(r0, r1, b["w"]) for r0, r1, b in segs]
+            for r0, r1, bw in groups:
+                hip.gemm(LNO[r0:r1], bw.wqkv, QKV[r0:r1], bias=bw.bqkv)
+            if vb is not None:
+                hip.attention(QKV[:Mv], AO[:Mv], Bi, self.Lv, self.heads, False)
+            if tb is not None:
+                hip.attention(QKV[Mv:M], AO[Mv:M], Bt, self.Lt, self.heads, True)
+            for r0, r1, bw in groups:
+                hip.gemm(AO[r0:r1], bw.wo, X[r0:r1], bias=bw.bo, resid=X[r0:r1], resid_kind=hip.RESID_F32)
+            for r0, r1, b in segs:
+                hip.layernorm(X[r0:r1], b["ln2"].g, b["ln2"].b, LNO[r0:r1], r1 - r0)
+            for r0, r1, bw in groups:
+                hip.gemm(LNO[r0:r1], bw.wfc, HID[r0:r1], bias=bw.bfc, act=hip.ACT_QUICKGELU)
+                hip.gemm(HID[r0:r1], bw.wpr, X[r0:r1], bias=bw.bpr, resid=X[r0:r1], resid_kind=hip.RESID_F32)
+
+    def _heads(self, w, Bi, Bt, norm=True):
+        packed = w.get("packed")
+        if Bi:                                                            # M.py:2685-2690, 2983
+            hip.layernorm(w["X"], self.ln_post.g, self.ln_post.b, w["hv"], Bi, row_mul=self.Lv)
+            hip.gemm(w["hv"], self.w_vproj, w["fv_raw"])
+            if norm:
+                hip.l2norm(w["fv_raw"], w["fv"], packed[:, 0] if packed is not None else None)
+        if Bt:                                                            # M.py:3057-3077
+            hip.layernorm(w["X"], self.ln_final.g, self.ln_final.b, w["ht"], Bt, row_idx=w["eot"])
+            hip.gemm(w["ht"], self.w_tproj, w["ft_raw"])
+            if norm:
+                hip.l2norm(w["ft_raw"], w["ft"], packed[:, 1] if packed is not None else None)
+
+    # ------------------------------------------------------------------ public
+    def _check_img(self, img):
+        if not img.is_cuda:
+            raise hip.HipUnavailable("inputs must be on the HIP device (no CPU path)")
+        if img.dim() != 4 or img.shape[1] != 3 or img.shape[2] != self.S or img.shape[3] != self.S:
+            raise ValueError(f"expected images [B, 3, {self.S}, {self.S}], got {tuple(img.shape)}")
+        if img.dtype not in (torch.float32, torch.bfloat16):
+            img = img.float()
+        return img.contiguous()
+
+    def _check_tok(self, tok):
+        if not tok.is_cuda:
+            raise hip.HipUnavailable("inputs must be on the HIP device (no CPU path)")
+        if tok.dim() != 2 or tok.shape[1] != self.Lt:
+            raise ValueError(f"expected tokens [B, {self.Lt}], got {tuple(tok.shape)}")
+        return tok.to(torch.int64).contiguous()
+
+    def run(self, img=None, tok=None, norm=True):
+        """Both towers (either may be None) up to the (optionally L2-normalised) features; returns the workspace."""
+        with torch.cuda.device(self.dev):
+            Bi = img.shape[0] if img is not None else 0
+            Bt = tok.shape[0] if tok is not None else 0
+            w = self._workspace(Bi, Bt)
+            if Bi:
+                self._vision_front(self._check_img(img), w, Bi)
+            if Bt:
+                self._text_front(self._check_tok(tok), w, Bt)
+            self._blocks(w, Bi, Bt)
+            self._heads(w, Bi, Bt, norm)
+            return w
+
+    def encode_image(self, img, norm=True):
+        w = self.run(img=img, norm=norm)
+        return (w["fv"] if norm else w["fv_raw"]).clone()
+
+    def encode_text(self, tok, norm=True):
+        w = self.run(tok=tok, norm=norm)
+        return (w["ft"] if norm else w["ft_raw"]).clone()
+
+    def _gathered(self, img, tok, gather):
+        if img.shape[0] != tok.shape[0]:
+            raise ValueError("forward(image, text) needs the same number of images and captions")
+        w = self.run(img, tok)
+        packed = w["packed"]
+        allp = C.gather_features(packed) if gather else packed
+        return w, packed, allp
+
+    def forward_logits(self, img, tok, gather=True):
+        """Reference-faithful full N x N logits on every rank (M.py:3136-3141)."""
+        w, packed, allp = self._gathered(img, tok, gather)
+        n = allp.shape[0]
+        out = torch.empty(n, n, dtype=torch.float32, device=self.dev)
+        hip.gemm(allp[:, 0], allp[:, 1], out, alpha=self.logit_scale_exp)
+        return out
+
+    def forward_loss(self, img, tok, gather=True):
+        """Symmetric CE over the global batch from the LOCAL row and column blocks only (SURVEY.md s8e option B):
+        rows = s*I_loc@T_all^T, cols = s*T_loc@I_all^T, row-LSE of each, diagonal from rows; partial sums are
+        all-reduced.  Identical to 0.5*(CE(logits)+CE(logits^T)) of the full matrix."""
+        w, packed, allp = self._gathered(img, tok, gather)
+        B, n = packed.shape[0], allp.shape[0]
+        world = n // B
+        rows = torch.empty(B, n, dtype=torch.float32, device=self.dev)
+        cols = torch.empty(B, n, dtype=torch.float32, device=self.dev)
+        lse = torch.empty(2, B, dtype=torch.float32, device=self.dev)
+        hip.gemm(packed[:, 0], allp[:, 1], rows, alpha=self.logit_scale_exp)
+        hip.gemm(packed[:, 1], allp[:, 0], cols, alpha=self.logit_scale_exp)
+        hip.lse_rows(rows, lse[0])
+        hip.lse_rows(cols, lse[1])
+        off = C.local_label_offset(B) if world > 1 else 0
+        hip.clip_loss_partial(lse[0], lse[1], rows, off, 1.0 / (2.0 * n), w["loss"])
+        loss = w["loss"].clone()
+        if world > 1:
+            dist.all_reduce(loss)
+        return loss[0]

@@ -1,0 +1,226 @@
+"""ctypes binding of libmsclip_hip.so (the C ABI declared in include/msclip_hip.h).
+
+The library is built in-tree by msclip_amd/csrc/build.sh (hipcc, gfx950) and is
+the ONLY compute path of the product: there is no CPU or eager-PyTorch
+fallback.  Anything that needs a kernel raises HipUnavailable when the
+library is missing or no GPU is visible.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmsclip_hip.so")
+INT_MAX = 2 ** 31 - 1
+
+EXPORTS = (
+    "msclip_gemm", "msclip_attention", "msclip_layernorm", "msclip_embed_tokens", "msclip_fill_cls",
+    "msclip_adapter_combine_ln", "msclip_l2norm", "msclip_stem_conv3x3s2_dual", "msclip_dwpool",
+    "msclip_lse_rows", "msclip_clip_loss_partial", "msclip_abi_version", "msclip_build_arch",
+)
+
+
+class HipUnavailable(RuntimeError):
+    pass
+
+
+class HipError(RuntimeError):
+    pass
+
+
+class GemmDesc(ctypes.Structure):
+    """Mirror of struct msclip_gemm_desc."""
+    _fields_ = [
+        ("X", ctypes.c_void_p), ("W", ctypes.c_void_p), ("zero", ctypes.c_void_p),
+        ("out", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("resid", ctypes.c_void_p),
+        ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int),
+        ("ldx", ctypes.c_int), ("ldw", ctypes.c_int), ("ldo", ctypes.c_int), ("ldr", ctypes.c_int),
+        ("mode", ctypes.c_int),
+        ("H", ctypes.c_int), ("Wd", ctypes.c_int), ("Cin", ctypes.c_int), ("Ho", ctypes.c_int),
+        ("Wo", ctypes.c_int), ("stride", ctypes.c_int), ("pad", ctypes.c_int),
+        ("ktab", ctypes.c_void_p),
+        ("act", ctypes.c_int), ("resid_kind", ctypes.c_int), ("out_kind", ctypes.c_int),
+        ("alpha", ctypes.c_float),
+        ("rpg", ctypes.c_int), ("radd", ctypes.c_int), ("roff", ctypes.c_int),
+    ]
+
+
+_lib = None
+
+
+def build(force=False):
+    """Compile the library in-tree (used by __graft_entry__.build)."""
+    script = os.path.join(_HERE, "csrc", "build.sh")
+    if force and os.path.exists(LIB_PATH):
+        os.remove(LIB_PATH)
+    subprocess.run(["bash", script], check=True)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipUnavailable(f"{LIB_PATH} is missing: run msclip_amd/csrc/build.sh (no CPU fallback exists)")
+        L = ctypes.CDLL(LIB_PATH)
+        vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+        L.msclip_gemm.argtypes = [ctypes.POINTER(GemmDesc), vp]
+        L.msclip_attention.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, vp]
+        L.msclip_layernorm.argtypes = [vp, ci, vp, ci, ci, vp, vp, vp, ci, ci, vp, ci, ci, ci, cf, vp]
+        L.msclip_embed_tokens.argtypes = [vp, vp, vp, vp, ci, vp, ci, ci, ci, ci, ci, vp]
+        L.msclip_fill_cls.argtypes = [vp, vp, vp, ci, ci, ci, ci, vp]
+        L.msclip_adapter_combine_ln.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, vp]
+        L.msclip_l2norm.argtypes = [vp, ci, vp, ci, vp, ci, ci, ci, vp]
+        L.msclip_stem_conv3x3s2_dual.argtypes = [vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, vp]
+        L.msclip_dwpool.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
+        L.msclip_lse_rows.argtypes = [vp, ci, vp, ci, ci, vp]
+        L.msclip_clip_loss_partial.argtypes = [vp, vp, vp, ci, ci, ci, cf, vp, vp]
+        L.msclip_abi_version.restype = ci
+        L.msclip_build_arch.restype = ctypes.c_char_p
+        for name in EXPORTS:
+            if name not in ("msclip_build_arch",):
+                getattr(L, name).restype = ci
+        _lib = L
+    return _lib
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise HipUnavailable("no HIP device visible: msclip_amd has no CPU path (use oracle/ only as a test checker)")
+    lib()
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise HipError(f"{what} failed with code {rc} ({'bad arguments' if rc == -1 else 'launch error'})")
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+_ZERO = {}
+
+
+def zero_page(device):
+    z = _ZERO.get(device)
+    if z is None:
+        z = torch.zeros(256, dtype=torch.bfloat16, device=device)
+        _ZERO[device] = z
+    return z
+
+
+def _bf16(t):
+    assert t.dtype == torch.bfloat16 and t.is_cuda and t.stride(-1) == 1, (t.dtype, t.device, t.stride())
+
+
+def _f32(t):
+    assert t.dtype == torch.float32 and t.is_cuda and t.is_contiguous(), (t.dtype, t.device, t.is_contiguous())
+
+
+ACT_NONE, ACT_QUICKGELU, ACT_RELU = 0, 1, 2
+RESID_NONE, RESID_F32, RESID_BF16, RESID_TABLE = 0, 1, 2, 3
+
+
+def gemm(x, w, out, *, M=None, bias=None, resid=None, resid_kind=0, act=0, alpha=1.0, conv=None, ktab=None,
+         ldx=None, ldo=None, ldr=None, rpg=INT_MAX, radd=0, roff=0, N=None):
+    """out = epilogue(alpha * x @ w^T).  x: bf16 [M, K] (or NHWC activation when conv=(H, W, Cin, Ho, Wo, stride, pad)),
+    w: bf16 [N, Kpad]; out: bf16 or fp32 2-D buffer."""
+    _bf16(w)
+    d = GemmDesc()
+    d.X, d.W, d.zero, d.out = x.data_ptr(), w.data_ptr(), zero_page(x.device).data_ptr(), out.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.resid = resid.data_ptr() if resid is not None else None
+    d.N = N if N is not None else w.shape[0]
+    d.K = w.shape[1]
+    d.ldw = w.stride(0)
+    if conv is None:
+        d.mode = 0
+        d.M = M if M is not None else x.shape[0]
+        d.ldx = ldx if ldx is not None else x.stride(0)
+    else:
+        d.mode = 1
+        d.H, d.Wd, d.Cin, d.Ho, d.Wo, d.stride, d.pad = conv
+        d.M = M
+        d.ktab = ktab.data_ptr()
+    d.ldo = ldo if ldo is not None else out.stride(0)
+    d.ldr = ldr if ldr is not None else (resid.stride(0) if resid is not None and resid.dim() == 2 else d.ldo)
+    d.act, d.resid_kind = act, resid_kind
+    d.out_kind = 1 if out.dtype == torch.float32 else 0
+    d.alpha = alpha
+    d.rpg, d.radd, d.roff = rpg, radd, roff
+    _check(lib().msclip_gemm(ctypes.byref(d), _stream()), "msclip_gemm")
+    return out
+
+
+def attention(qkv, out, nsamples, L, heads, causal):
+    """qkv: bf16 [nsamples*L, 3*heads*64] (a row-range view is fine); out: bf16 [nsamples*L, heads*64]."""
+    _bf16(qkv)
+    _bf16(out)
+    assert qkv.shape[0] == nsamples * L and out.shape[0] == nsamples * L
+    _check(lib().msclip_attention(_p(qkv), _p(out), nsamples, L, heads, qkv.stride(0), out.stride(0), int(causal),
+                                  _stream()), "msclip_attention")
+    return out
+
+
+def layernorm(x, gamma, beta, out, M, *, row_idx=None, row_mul=1, row_add=0, eps=1e-12, raw_out=None):
+    """out[m] = LN(x[row_idx[m] or m*row_mul + row_add]); x fp32 2-D (a row-range view is fine)."""
+    assert x.dtype == torch.float32 and x.is_cuda and x.stride(-1) == 1
+    C = x.shape[-1]
+    _check(lib().msclip_layernorm(_p(x), x.stride(0), _p(row_idx), row_mul, row_add, _p(gamma), _p(beta), _p(out),
+                                  out.stride(0), 1 if out.dtype == torch.float32 else 0, _p(raw_out),
+                                  raw_out.stride(0) if raw_out is not None else 0, M, C, eps, _stream()),
+           "msclip_layernorm")
+    return out
+
+
+def embed_tokens(tokens, emb, pos, x, eot_row, row_base):
+    B, L = tokens.shape
+    assert tokens.dtype == torch.int64 and tokens.is_contiguous()
+    _check(lib().msclip_embed_tokens(_p(tokens), _p(emb), _p(pos), _p(x), x.stride(0), _p(eot_row), B, L, x.shape[1],
+                                     emb.shape[0], row_base, _stream()), "msclip_embed_tokens")
+
+
+def fill_cls(cls, pos, x, B, L):
+    _check(lib().msclip_fill_cls(_p(cls), _p(pos), _p(x), x.stride(0), B, L, x.shape[1], _stream()), "msclip_fill_cls")
+
+
+def adapter_combine_ln(xin, t, dww, dwb, gamma, beta, xout, B, L, g, usecls, eps=1e-12):
+    _check(lib().msclip_adapter_combine_ln(_p(xin), xin.stride(0), _p(t), t.stride(0), _p(dww), _p(dwb), _p(gamma),
+                                           _p(beta), _p(xout), xout.stride(0), B, L, g, xin.shape[1], int(usecls), eps,
+                                           _stream()), "msclip_adapter_combine_ln")
+
+
+def l2norm(x, out_f32=None, out_bf16=None):
+    M, E = x.shape
+    _check(lib().msclip_l2norm(_p(x), x.stride(0), _p(out_f32), out_f32.stride(0) if out_f32 is not None else 0,
+                               _p(out_bf16), out_bf16.stride(0) if out_bf16 is not None else 0, M, E, _stream()),
+           "msclip_l2norm")
+
+
+def stem_conv_dual(img, w, bias, out_a, out_b):
+    B, _, H, W = img.shape
+    assert img.is_contiguous() and img.dtype in (torch.float32, torch.bfloat16)
+    _check(lib().msclip_stem_conv3x3s2_dual(_p(img), int(img.dtype == torch.bfloat16), _p(w), _p(bias), _p(out_a),
+                                            _p(out_b), B, H, W, w.shape[1] // 2, _stream()), "msclip_stem_conv3x3s2_dual")
+
+
+def dwpool(top, w, out, B, H, W, C, k):
+    _check(lib().msclip_dwpool(_p(top), _p(w), _p(out), out.stride(0), B, H, W, C, k, _stream()), "msclip_dwpool")
+
+
+def lse_rows(logits, lse):
+    R, N = logits.shape
+    _check(lib().msclip_lse_rows(_p(logits), logits.stride(0), _p(lse), R, N, _stream()), "msclip_lse_rows")
+
+
+def clip_loss_partial(lse_img, lse_txt, img_rows, label_off, scale, out):
+    R = img_rows.shape[0]
+    _check(lib().msclip_clip_loss_partial(_p(lse_img), _p(lse_txt), _p(img_rows), img_rows.stride(0), label_off, R,
+                                          scale, _p(out), _stream()), "msclip_clip_loss_partial")

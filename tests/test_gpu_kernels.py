@@ -1,0 +1,252 @@
+"""Per-kernel parity on a real MI355X: each C-ABI entry point against a plain fp32 PyTorch statement of the same op,
+on seeded random (asymmetric, transpose-detecting) data, including ragged sizes that exercise every bounds guard."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from msclip_amd import hip, packing as P
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def rnd(*shape, seed=0, scale=1.0, dtype=torch.float32, dev="cuda"):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).to(dev)
+
+
+def close(got, ref, atol, rtol=0.0):
+    got, ref = got.float(), ref.float()
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    assert bool((err <= tol).all()), f"max err {err.max().item():.4g} (ref absmax {ref.abs().max().item():.4g})"
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 2304, 768), (1000, 768, 3072), (77, 512, 768), (513, 48, 128)])
+def test_gemm_dense_bias_and_shapes(gpu_device, M, N, K):
+    x, w, b = rnd(M, K, seed=1, dtype=BF), rnd(N, K, seed=2, scale=0.05, dtype=BF), rnd(N, seed=3)
+    ref = x.float() @ w.float().t() + b
+    out = torch.full((M, N), float("nan"), dtype=BF, device="cuda")
+    hip.gemm(x, w, out, bias=b)
+    close(out, ref, 2e-2, 1e-2)
+    outf = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    hip.gemm(x, w, outf, bias=b, alpha=0.5)
+    close(outf, 0.5 * (x.float() @ w.float().t()) + b, 2e-3, 1e-4)
+
+
+def test_gemm_epilogues(gpu_device):
+    M, N, K = 333, 256, 192
+    x, w, b = rnd(M, K, seed=4, dtype=BF), rnd(N, K, seed=5, scale=0.08, dtype=BF), rnd(N, seed=6)
+    base = x.float() @ w.float().t() + b
+    out = torch.empty(M, N, dtype=BF, device="cuda")
+    hip.gemm(x, w, out, bias=b, act=hip.ACT_QUICKGELU)
+    close(out, base * torch.sigmoid(1.702 * base), 2e-2, 1e-2)
+    hip.gemm(x, w, out, bias=b, act=hip.ACT_RELU)
+    close(out, F.relu(base), 2e-2, 1e-2)
+    r32 = rnd(M, N, seed=7)
+    xres = r32.clone()
+    hip.gemm(x, w, xres, bias=b, resid=xres, resid_kind=hip.RESID_F32)          # in-place residual update
+    close(xres, r32 + base, 2e-3, 1e-4)
+    r16 = rnd(M, N, seed=8, dtype=BF)
+    hip.gemm(x, w, out, bias=b, resid=r16, resid_kind=hip.RESID_BF16, act=hip.ACT_RELU)
+    close(out, F.relu(base + r16.float()), 3e-2, 1e-2)
+
+
+def test_gemm_token_scatter_with_table(gpu_device):
+    """Stem last_conv epilogue: + positional row (p + 1), scatter to token row b*L + 1 + p."""
+    B, g2, D = 3, 49, 256
+    L = g2 + 1
+    x, w = rnd(B * g2, D, seed=9, dtype=BF), rnd(D, D, seed=10, scale=0.05, dtype=BF)
+    pos = rnd(L, D, seed=11)
+    X = torch.zeros(B * L + 7, D, dtype=torch.float32, device="cuda")
+    hip.gemm(x, w, X, M=B * g2, resid=pos, resid_kind=hip.RESID_TABLE, rpg=g2, radd=1, roff=1)
+    ref = (x.float() @ w.float().t()).reshape(B, g2, D) + pos[1:]
+    got = X[:B * L].reshape(B, L, D)
+    close(got[:, 1:], ref, 2e-3, 1e-4)
+    assert float(got[:, 0].abs().max()) == 0.0 and float(X[B * L:].abs().max()) == 0.0
+
+
+def test_gemm_strided_operands_for_logits(gpu_device):
+    """Both operands are column slices of the packed [N, 2, E] feature buffer."""
+    n, E = 200, 512
+    packed = F.normalize(rnd(n, 2, E, seed=12), dim=-1).to(BF)
+    out = torch.empty(n, n, dtype=torch.float32, device="cuda")
+    hip.gemm(packed[:, 0], packed[:, 1], out, alpha=14.0)
+    close(out, 14.0 * packed[:, 0].float() @ packed[:, 1].float().t(), 2e-3)
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,k,stride,pad", [
+    (2, 28, 48, 96, 3, 2, 1), (3, 14, 96, 48, 1, 1, 0), (2, 14, 192, 384, 3, 1, 1), (2, 16, 48, 96, 1, 2, 0),
+    (1, 7, 768, 768, 1, 1, 0), (2, 56, 48, 48, 3, 2, 1)])
+def test_gemm_implicit_conv(gpu_device, B, H, Cin, Cout, k, stride, pad):
+    x = rnd(B, H, H, Cin, seed=13, dtype=BF)                      # NHWC
+    w = rnd(Cout, Cin, k, k, seed=14, scale=(2.0 / (Cin * k * k)) ** 0.5)
+    b = rnd(Cout, seed=15)
+    spec = P.ConvSpec(w, b, H, H, stride, pad).to("cuda")
+    out = torch.full((B * spec.h_out * spec.w_out, Cout), float("nan"), dtype=BF, device="cuda")
+    hip.gemm(x, spec.weight, out, M=out.shape[0], N=Cout, bias=spec.bias, act=hip.ACT_RELU, conv=spec.geometry(),
+             ktab=spec.ktab)
+    ref = F.relu(F.conv2d(x.float().permute(0, 3, 1, 2), w.to(BF).float(), b, stride=stride, padding=pad))
+    close(out.reshape(B, spec.h_out, spec.w_out, Cout), ref.permute(0, 2, 3, 1), 3e-2, 1e-2)
+
+
+@pytest.mark.parametrize("B,L,causal", [(3, 50, False), (5, 77, True), (2, 197, False), (1, 1, False), (2, 33, True),
+                                        (2, 64, True), (1, 96, False)])
+def test_attention(gpu_device, B, L, causal):
+    Hh, D = 12, 768
+    qkv = rnd(B * L + 5, 3 * D, seed=16, dtype=BF)                 # extra rows: nothing may read/write past B*L
+    out = torch.full((B * L + 5, D), 7.0, dtype=BF, device="cuda")
+    hip.attention(qkv[:B * L], out[:B * L], B, L, Hh, causal)
+    q, k, v = qkv[:B * L].float().reshape(B, L, 3, Hh, 64).permute(2, 0, 3, 1, 4)
+    s = q @ k.transpose(-1, -2)
+    if causal:
+        s = s + torch.full((L, L), float("-inf"), device="cuda").triu_(1)
+    ref = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B * L, D)
+    close(out[:B * L], ref, 2e-2, 2e-2)
+    assert bool((out[B * L:] == 7.0).all())
+
+
+def test_attention_forced_sharp_softmax(gpu_device):
+    """One key dominates each query (exercises max-subtraction across the half-wave exchange)."""
+    B, L, Hh, D = 2, 77, 12, 768
+    qkv = rnd(B * L, 3 * D, seed=17, dtype=BF)
+    qkv[:, :D] *= 6.0
+    out = torch.empty(B * L, D, dtype=BF, device="cuda")
+    hip.attention(qkv, out, B, L, Hh, True)
+    q, k, v = qkv.float().reshape(B, L, 3, Hh, 64).permute(2, 0, 3, 1, 4)
+    s = q @ k.transpose(-1, -2) + torch.full((L, L), float("-inf"), device="cuda").triu_(1)
+    ref = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B * L, D)
+    close(out, ref, 3e-2, 2e-2)
+
+
+def test_layernorm_variants(gpu_device):
+    M, C = 301, 768
+    x = rnd(M, C, seed=18, scale=3.0) + 0.7
+    g, b = rnd(C, seed=19) + 1.0, rnd(C, seed=20)
+
+    def ref_ln(t):
+        u = t.mean(-1, keepdim=True)
+        s = (t - u).pow(2).mean(-1, keepdim=True)
+        return g * ((t - u) / torch.sqrt(s + 1e-12)) + b
+    o32 = torch.empty(M, C, dtype=torch.float32, device="cuda")
+    hip.layernorm(x, g, b, o32, M)
+    close(o32, ref_ln(x), 1e-4, 1e-5)
+    o16 = torch.empty(M, C, dtype=BF, device="cuda")
+    raw = torch.zeros(M, C, dtype=torch.float32, device="cuda")
+    hip.layernorm(x, g, b, o16, M, raw_out=raw)
+    close(o16, ref_ln(x), 2e-2, 1e-2)
+    assert torch.equal(raw, x)
+    idx = torch.tensor([5, 300, 0, 17], dtype=torch.int32, device="cuda")
+    o = torch.empty(4, C, dtype=torch.float32, device="cuda")
+    hip.layernorm(x, g, b, o, 4, row_idx=idx)
+    close(o, ref_ln(x[idx.long()]), 1e-4, 1e-5)
+    o = torch.empty(6, C, dtype=torch.float32, device="cuda")
+    hip.layernorm(x, g, b, o, 6, row_mul=50)
+    close(o, ref_ln(x[::50][:6]), 1e-4, 1e-5)
+    xin = x.clone()
+    hip.layernorm(xin, g, b, xin, M)                               # in place
+    close(xin, ref_ln(x), 1e-4, 1e-5)
+    x512 = rnd(9, 512, seed=21)
+    o = torch.empty(9, 512, dtype=torch.float32, device="cuda")
+    hip.layernorm(x512, g[:512].contiguous(), b[:512].contiguous(), o, 9)
+    u = x512.mean(-1, keepdim=True)
+    close(o, g[:512] * ((x512 - u) / torch.sqrt((x512 - u).pow(2).mean(-1, keepdim=True) + 1e-12)) + b[:512], 1e-4, 1e-5)
+
+
+def test_embed_tokens_and_eot(gpu_device):
+    B, L, C, V = 5, 77, 768, 1000
+    emb, pos = rnd(V, C, seed=22), rnd(L, C, seed=23)
+    g = torch.Generator().manual_seed(24)
+    tok = torch.randint(1, V - 2, (B, L), generator=g)
+    eot_pos = [3, 76, 10, 1, 40]
+    for i, p in enumerate(eot_pos):
+        tok[i, p] = V - 1
+        tok[i, p + 1:] = 0
+    tok[2, 20] = V - 1                                             # duplicate maximum: argmax takes the first
+    tok = tok.cuda()
+    X = torch.zeros(11 + B * L, C, dtype=torch.float32, device="cuda")
+    eot = torch.empty(B, dtype=torch.int32, device="cuda")
+    hip.embed_tokens(tok, emb, pos, X, eot, 11)
+    close(X[11:].reshape(B, L, C), emb[tok] + pos, 1e-6)
+    assert float(X[:11].abs().max()) == 0.0
+    assert eot.tolist() == [11 + i * L + int(tok[i].argmax()) for i in range(B)]
+
+
+def test_fill_cls_adapter_l2norm(gpu_device):
+    B, g_, C = 3, 7, 768
+    L = g_ * g_ + 1
+    cls, pos = rnd(C, seed=25), rnd(L, C, seed=26)
+    X = torch.zeros(B * L, C, dtype=torch.float32, device="cuda")
+    hip.fill_cls(cls, pos, X, B, L)
+    close(X.reshape(B, L, C)[:, 0], (cls + pos[0]).expand(B, C), 1e-6)
+    assert float(X.reshape(B, L, C)[:, 1:].abs().max()) == 0.0
+
+    x = rnd(B * L, C, seed=27)
+    t = rnd(B * g_ * g_, C, seed=28)
+    dww, dwb = rnd(9, C, seed=29, scale=0.3), rnd(C, seed=30, scale=0.1)
+    ga, be = rnd(C, seed=31) + 1.0, rnd(C, seed=32)
+    out = torch.empty(B * L, C, dtype=torch.float32, device="cuda")
+    hip.adapter_combine_ln(x, t, dww, dwb, ga, be, out, B, L, g_, True)
+    xb = x.reshape(B, L, C)
+    grid = xb[:, 1:].transpose(1, 2).reshape(B, C, g_, g_)
+    bo = F.conv2d(grid, dww.t().reshape(C, 1, 3, 3), dwb, padding=1, groups=C).flatten(2).transpose(1, 2)
+    v = torch.cat([2 * xb[:, :1], bo + t.reshape(B, g_ * g_, C)], 1)
+    u = v.mean(-1, keepdim=True)
+    ref = ga * ((v - u) / torch.sqrt((v - u).pow(2).mean(-1, keepdim=True) + 1e-12)) + be
+    close(out.reshape(B, L, C), ref, 2e-4, 1e-5)
+
+    f = rnd(37, 512, seed=33, scale=4.0)
+    o32 = torch.empty(37, 512, dtype=torch.float32, device="cuda")
+    packed = torch.zeros(37, 2, 512, dtype=BF, device="cuda")
+    hip.l2norm(f, o32, packed[:, 1])
+    close(o32, f / f.norm(dim=-1, keepdim=True), 1e-6, 1e-6)
+    close(packed[:, 1], f / f.norm(dim=-1, keepdim=True), 1e-3)
+    assert float(packed[:, 0].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, BF])
+def test_stem_dual_conv(gpu_device, dtype):
+    B, S = 3, 64
+    img = rnd(B, 3, S, S, seed=34, dtype=dtype)
+    w, b = rnd(27, 96, seed=35, scale=0.3), rnd(96, seed=36, scale=0.2)
+    oa = torch.empty(B * 32 * 32, 48, dtype=BF, device="cuda")
+    ob = torch.empty(B * 32 * 32, 48, dtype=BF, device="cuda")
+    hip.stem_conv_dual(img, w, b, oa, ob)
+    ref = F.relu(F.conv2d(img.float(), w.t().reshape(96, 3, 3, 3), b, stride=2, padding=1)).permute(0, 2, 3, 1)
+    close(oa.reshape(B, 32, 32, 48), ref[..., :48], 2e-2, 1e-2)
+    close(ob.reshape(B, 32, 32, 48), ref[..., 48:], 2e-2, 1e-2)
+
+
+@pytest.mark.parametrize("C,k,g_", [(48, 16, 7), (96, 8, 7), (192, 4, 7), (768, 1, 7), (96, 4, 14)])
+def test_dwpool(gpu_device, C, k, g_):
+    B, H = 2, k * g_
+    top = rnd(B, H, H, C, seed=37, dtype=BF)
+    w = rnd(k * k, C, seed=38, scale=1.0 / k)
+    out = torch.empty(B * g_ * g_, C, dtype=BF, device="cuda")
+    hip.dwpool(top, w, out, B, H, H, C, k)
+    ref = F.conv2d(top.float().permute(0, 3, 1, 2), w.t().reshape(C, 1, k, k), stride=k, groups=C).permute(0, 2, 3, 1)
+    close(out.reshape(B, g_, g_, C), ref, 2e-2, 1e-2)
+
+
+def test_lse_and_loss(gpu_device):
+    R, N, off = 24, 72, 48
+    rows = rnd(R, N, seed=39, scale=6.0)
+    cols = rnd(R, N, seed=40, scale=6.0)
+    lse = torch.empty(2, R, dtype=torch.float32, device="cuda")
+    hip.lse_rows(rows, lse[0])
+    hip.lse_rows(cols, lse[1])
+    close(lse[0], torch.logsumexp(rows, 1), 1e-4)
+    close(lse[1], torch.logsumexp(cols, 1), 1e-4)
+    out = torch.empty(1, dtype=torch.float32, device="cuda")
+    hip.clip_loss_partial(lse[0], lse[1], rows, off, 1.0 / (2 * N), out)
+    d = rows[torch.arange(R), off + torch.arange(R)]
+    ref = ((torch.logsumexp(rows, 1) - d) + (torch.logsumexp(cols, 1) - d)).sum() / (2 * N)
+    close(out[0], ref, 1e-4)
+
+
+def test_bad_arguments_are_rejected(gpu_device):
+    x, w = rnd(8, 60, dtype=BF), rnd(8, 60, dtype=BF)             # K not a multiple of 64
+    with pytest.raises(hip.HipError):
+        hip.gemm(x, w, torch.empty(8, 8, dtype=BF, device="cuda"))
+    with pytest.raises(hip.HipError):
+        hip.attention(rnd(300, 2304, dtype=BF), torch.empty(300, 768, dtype=BF, device="cuda"), 1, 300, 12, False)

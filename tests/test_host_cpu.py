@@ -1,0 +1,181 @@
+"""Host-side logic that needs no GPU: config surface, checkpoint ABI, weight packing folds (checked against the
+oracle), the implicit-GEMM chunk table semantics, the C-ABI library's exports, and the loud failure without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import ROOT, load_schema, synth_sd
+from msclip_amd import hip, packing as P, synth
+from msclip_amd.clip_openai_pe_res_v1 import build_model, get_clip_model
+from msclip_amd.config import named_config
+from oracle import msclip_oracle as O
+
+
+def test_config_base_inheritance_and_opts():
+    c = named_config("b16-yfcc-msclips", ["MODEL.SPEC.EMBED_DIM", "256"])
+    assert c.MODEL.SPEC.VISION.PATCH_SIZE == 16 and c.MODEL.SPEC.VISION.WIDTH == 768      # overlay + BASE
+    assert c.MODEL.SPEC.TEXT.HEADS == 12 and c.MODEL.SPEC.TEXT.CONTEXT_LENGTH == 77
+    assert c.MODEL.SPEC.EMBED_DIM == 256
+    assert c.CUSTOM.EARLY_CONV_RES_STRIDES == [2, 2, 2, 1] and c.CUSTOM.CUSTOM_ATTN is True
+    with pytest.raises(AttributeError):
+        c.NAME = "frozen"
+
+
+@pytest.mark.parametrize("name", ["b32-yfcc-msclips", "b16-yfcc-msclips"])
+def test_state_dict_abi_matches_reference_schema(name):
+    model = get_clip_model(named_config(name))
+    mine = [(k, tuple(v.shape), v.dtype) for k, v in model.state_dict().items()]
+    assert mine == load_schema(name)                       # same 521 keys, order, shapes, dtypes
+    # aliases: text block i >= 1 shares attn/mlp tensors with vision block i; LayerNorms never shared
+    for i in range(1, 12):
+        v, t = model.visual.transformer.resblocks[i], model.transformer.resblocks[i]
+        assert v.attn.in_proj_weight is t.attn.in_proj_weight and v.attn.in_proj_bias is t.attn.in_proj_bias
+        assert v.attn.out_proj is t.attn.out_proj and v.mlp is t.mlp
+        assert v.ln_1 is not t.ln_1 and v.ln_2 is not t.ln_2
+    assert sum(p.numel() for p in model.parameters()) == (132408001 if name.startswith("b32") else 132503617)
+
+
+def test_strict_load_keeps_aliases_and_build_model_alias():
+    name = "b32-yfcc-msclips"
+    model = build_model(named_config(name))
+    model.load_state_dict(synth_sd(name), strict=True)
+    v, t = model.visual.transformer.resblocks[5], model.transformer.resblocks[5]
+    assert v.mlp.c_fc.weight.data_ptr() == t.mlp.c_fc.weight.data_ptr()
+    assert torch.equal(model.state_dict()["transformer.resblocks.5.attn.in_proj_weight"],
+                       synth_sd(name)["visual.transformer.resblocks.5.attn.in_proj_weight"])
+    assert model.dtype == torch.float32 and "logit_scale" in model.no_weight_decay()
+
+
+def test_experimental_switches_are_rejected():
+    for key in ("LORA_OPEN", "CONVIT_IN_V", "PARALLEL_B2T", "GUMBEL_SELECT"):
+        with pytest.raises(NotImplementedError, match=key):
+            get_clip_model(named_config("b32-yfcc-msclips", [f"CUSTOM.{key}", "True"]))
+    with pytest.raises(NotImplementedError):
+        get_clip_model(named_config("b32-yfcc-msclips", ["CUSTOM.EARLY_CONV", "False"]))
+
+
+def test_no_cpu_fallback():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    model = get_clip_model(named_config("b32-yfcc-msclips"))
+    with pytest.raises(hip.HipUnavailable):
+        model.encode_text(torch.zeros(1, 77, dtype=torch.long))
+
+
+def test_library_exports_every_declared_symbol():
+    with open(os.path.join(ROOT, "include", "msclip_hip.h")) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    declared = set(re.findall(r"\b(msclip_[a-z0-9_]+)\s*\(", text))
+    assert declared == set(hip.EXPORTS)
+    if not os.path.exists(hip.LIB_PATH):
+        hip.build()
+    lib = ctypes.CDLL(hip.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    lib.msclip_abi_version.restype = ctypes.c_int
+    lib.msclip_build_arch.restype = ctypes.c_char_p
+    assert lib.msclip_abi_version() == 1 and lib.msclip_build_arch() == b"gfx950"
+    # struct mirror must match the C layout (6 pointers + 24 ints/floats, then a pointer in the middle)
+    assert ctypes.sizeof(hip.GemmDesc) % 8 == 0 and hip.GemmDesc.ktab.offset % 8 == 0
+
+
+# ---------------------------------------------------------------- packing folds vs oracle (CPU, fp32 weights)
+
+def _run_spec(x_nchw, spec, relu=False, resid=None):
+    """Emulate the gathering GEMM with fp32 arithmetic on the bf16-rounded packed weight."""
+    w = spec.weight.float()[:, :spec.kh * spec.kw * spec.cin].reshape(spec.cout, spec.kh, spec.kw, spec.cin)
+    y = F.conv2d(x_nchw, w.permute(0, 3, 1, 2), stride=spec.stride, padding=spec.pad) + spec.bias[None, :, None, None]
+    if resid is not None:
+        y = y + resid
+    return F.relu(y) if relu else y
+
+
+def test_stem_and_parallel_folds_match_oracle():
+    name, arch = "b32-yfcc-msclips", O.arch_b32()
+    sd = synth_sd(name)
+    img = synth.synth_images(1, seed=3)[:, :, :64, :64]
+    # dual first conv
+    w, b = P.stem_dual_weights(sd, "visual.transformer.resblocks.0", "visual.transformer.parallel_branch_v.0")
+    y = F.relu(F.conv2d(img, w.t().reshape(96, 3, 3, 3), stride=2, padding=1) + b[None, :, None, None])
+    taps = {}
+    sp = "visual.transformer.resblocks.0"
+    s1 = F.relu(O.batch_norm(F.conv2d(img, sd[sp + ".conv1.weight"], stride=2, padding=1), sd, sp + ".bn1", 1e-5))
+    p0 = O.parallel_stage(img, sd, arch, 0)
+    assert (y[:, :48] - s1).abs().max() < 1e-5 and (y[:, 48:] - p0).abs().max() < 1e-5
+    # stem stage 0 with the shortcut merged into the centre tap (weights are bf16-rounded: loose tolerance)
+    spec = P.stem_stage(sd, sp + ".resnet_stage.conv_0", 32, 2)
+    q = sp + ".resnet_stage.conv_0"
+    ref = F.relu(O.batch_norm(F.conv2d(s1, sd[q + ".conv1.weight"], stride=2, padding=1), sd, q + ".bn1", 1e-5) +
+                 O.batch_norm(F.conv2d(s1, sd[q + ".downsample.0.weight"], stride=2), sd, q + ".downsample.1", 1e-5))
+    got = _run_spec(s1, spec, relu=True)
+    assert got.shape == ref.shape and (got - ref).abs().max() < 3e-2 * ref.abs().max()
+    assert (got - ref).abs().mean() < 3e-3 * ref.abs().mean() + 1e-4
+    # bottleneck stage 1
+    c1, c2, cr, c3 = P.bottleneck(sd, "visual.transformer.parallel_branch_v.1.resnet_stage.conv_0", 32, 2)
+    y1 = _run_spec(p0, c1, relu=True)
+    y2 = _run_spec(y1, c2, relu=True)
+    out = _run_spec(y2, c3, relu=True, resid=_run_spec(p0, cr))
+    ref = O.parallel_stage(p0, sd, arch, 1)
+    assert out.shape == ref.shape and (out - ref).abs().mean() < 5e-3 * ref.abs().mean() + 1e-4
+
+
+def test_adapter_fold_matches_oracle():
+    name, arch = "b32-yfcc-msclips", O.arch_b32()
+    sd = synth_sd(name)
+    g = arch.grid
+    torch.manual_seed(0)
+    j = 2
+    top = torch.randn(2, 192, g * 4, g * 4)
+    x = torch.randn(2, g * g + 1, 768)
+    ref = O.lateral_adapter(top, x, sd, arch, j)
+    pool, k, pw, dww, dwb = P.adapter_weights(sd, f"visual.transformer.parallel_lateral_adapter.{j}", g)
+    assert k == 4
+    pooled = F.conv2d(top, pool.t().reshape(192, 1, k, k), stride=k, groups=192)
+    t = _run_spec(pooled, pw).flatten(2).transpose(1, 2)
+    grid = x[:, 1:].transpose(1, 2).reshape(2, 768, g, g)
+    bo = (F.conv2d(grid, dww.t().reshape(768, 1, 3, 3), padding=1, groups=768) + dwb[None, :, None, None])
+    v = torch.cat([2 * x[:, :1], bo.flatten(2).transpose(1, 2) + t], 1)
+    p = f"visual.transformer.parallel_lateral_adapter.{j}"
+    got = O.layer_norm(v, sd[p + ".ln_adapt.weight"], sd[p + ".ln_adapt.bias"])
+    assert (got - ref).abs().max() < 2e-2
+
+
+def test_ktab_semantics_tiny_conv():
+    """Interpret the chunk table exactly like gemm.hip's loader and compare with F.conv2d."""
+    torch.manual_seed(1)
+    B, H, Cin, Cout, stride, pad = 2, 6, 16, 8, 2, 1
+    x = torch.randn(B, Cin, H, H)
+    w = torch.randn(Cout, Cin, 3, 3)
+    spec = P.ConvSpec(w, torch.zeros(Cout), H, H, stride, pad)
+    xn = x.permute(0, 2, 3, 1).contiguous().flatten().numpy()           # NHWC
+    tab = spec.ktab.numpy()
+    Ho = spec.h_out
+    rows = np.zeros((B * Ho * Ho, spec.weight.shape[1]), dtype=np.float32)
+    for m in range(B * Ho * Ho):
+        b, p = divmod(m, Ho * Ho)
+        ho, wo = divmod(p, Ho)
+        ih0, iw0 = ho * stride - pad, wo * stride - pad
+        pix = ((b * H + ih0) * H + iw0) * Cin
+        for c, e in enumerate(tab):
+            if e < 0:
+                continue
+            kh, kw, doff = (e >> 20) & 15, (e >> 24) & 15, e & 0xFFFFF
+            if 0 <= ih0 + kh < H and 0 <= iw0 + kw < H:
+                rows[m, c * 8:c * 8 + 8] = xn[pix + doff:pix + doff + 8]
+    got = torch.from_numpy(rows) @ spec.weight.float().t()
+    ref = F.conv2d(x, w.to(torch.bfloat16).float(), stride=stride, padding=pad).permute(0, 2, 3, 1).reshape(-1, Cout)
+    assert (got - ref).abs().max() < 1e-3
+    assert spec.weight.shape[1] % 64 == 0 and (tab[(9 * Cin) // 8:] < 0).all()
+
+
+def test_qkv_prescale_is_exact():
+    torch.manual_seed(0)
+    w, b = torch.randn(2304, 768), torch.randn(2304)
+    wq, bq = P.qkv_weights(w, b, 12)
+    assert torch.equal(wq[:768].float(), (w[:768].to(torch.bfloat16).float() * 0.125))
+    assert torch.equal(wq[768:], w[768:].to(torch.bfloat16)) and torch.equal(bq[:768], b[:768] * 0.125)
