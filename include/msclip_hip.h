@@ -28,7 +28,8 @@ extern "C" {
  *   mode 1: X NHWC bf16 [B, H, Wd, Cin]; M = B*Ho*Wo; K-chunk c (8 channels) of a row is
  *           described by ktab[c] = doff | kh<<20 | kw<<24 (negative = zero padding chunk),
  *           doff = (kh*Wd + kw)*Cin + ch; taps outside the image read `zero`.
- *   W is [N][ldw] bf16 with K % 64 == 0 (zero padded), ldw % 8 == 0; N % 4 == 0.
+ *   W is [N][ldw] bf16 with K % 64 == 0 (zero padded), ldw % 8 == 0.  N, ldo, ldr multiples of 4 take
+ *   the vectorised epilogue, anything else an element-wise tail path.
  *   epilogue: v = alpha*acc + bias[n]; act 1 = QuickGELU (M.py:222-224); then
  *   + resid (1: fp32 [m][n], 2: bf16 [m][n], 3: fp32 table row (m % rpg + roff), e.g.
  *   positional embedding); act 2 = ReLU (after the residual); store to row

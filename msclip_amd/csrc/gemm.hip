@@ -140,6 +140,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const msclip_gemm_desc a) 
 
   // ---- epilogue: lane owns row m = .. + (lane&31), columns n = .. + 8g + 4*(lane>>5) + 0..3
   const float* __restrict__ bias = a.bias;
+  const bool vec = !((a.N | a.ldo | (a.resid_kind ? a.ldr : 0)) & 3);
 #pragma unroll
   for (int tm = 0; tm < 2; ++tm) {
     const int m = m0 + wm + tm * 32 + fr;
@@ -157,33 +158,48 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const msclip_gemm_desc a) 
         float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = acc[tn][tm][g * 4 + j] * a.alpha;
-        if (bias) {
-          const float4 bv = *(const float4*)(bias + n);
-          v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-        }
-        if (a.act == 1) {
+        if (vec) {
+          if (bias) {
+            const float4 bv = *(const float4*)(bias + n);
+            v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+          }
+          if (a.act == 1) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = v[j] / (1.f + __expf(-1.702f * v[j]));
-        }
-        if (a.resid_kind == 1 || a.resid_kind == 3) {
-          const float4 rv = *(const float4*)((const float*)a.resid + rrow * a.ldr + n);
-          v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
-        } else if (a.resid_kind == 2) {
-          const uint2 rv = *(const uint2*)((const bf16_t*)a.resid + rrow * a.ldr + n);
-          v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
-          v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
-        }
-        if (a.act == 2) {
+            for (int j = 0; j < 4; ++j) v[j] = v[j] / (1.f + __expf(-1.702f * v[j]));
+          }
+          if (a.resid_kind == 1 || a.resid_kind == 3) {
+            const float4 rv = *(const float4*)((const float*)a.resid + rrow * a.ldr + n);
+            v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+          } else if (a.resid_kind == 2) {
+            const uint2 rv = *(const uint2*)((const bf16_t*)a.resid + rrow * a.ldr + n);
+            v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
+            v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
+          }
+          if (a.act == 2) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-        }
-        if (a.out_kind == 1) {
-          *(float4*)((float*)a.out + orow * a.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-          uint2 o;
-          o.x = pack_bf16x2(v[0], v[1]);
-          o.y = pack_bf16x2(v[2], v[3]);
-          *(uint2*)((bf16_t*)a.out + orow * a.ldo + n) = o;
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+          }
+          if (a.out_kind == 1) {
+            *(float4*)((float*)a.out + orow * a.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+            uint2 o;
+            o.x = pack_bf16x2(v[0], v[1]);
+            o.y = pack_bf16x2(v[2], v[3]);
+            *(uint2*)((bf16_t*)a.out + orow * a.ldo + n) = o;
+          }
+        } else {  // ragged N or unaligned leading dimensions: element-wise tail path
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (n + j >= a.N) break;
+            float y = v[j];
+            if (bias) y += bias[n + j];
+            if (a.act == 1) y = y / (1.f + __expf(-1.702f * y));
+            if (a.resid_kind == 1 || a.resid_kind == 3) y += ((const float*)a.resid)[rrow * a.ldr + n + j];
+            else if (a.resid_kind == 2) y += bf16_to_f32(((const bf16_t*)a.resid)[rrow * a.ldr + n + j]);
+            if (a.act == 2) y = fmaxf(y, 0.f);
+            if (a.out_kind == 1) ((float*)a.out)[orow * a.ldo + n + j] = y;
+            else ((bf16_t*)a.out)[orow * a.ldo + n + j] = f32_to_bf16(y);
+          }
         }
       }
     }
@@ -194,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const msclip_gemm_desc a) 
 
 extern "C" int msclip_gemm(const msclip_gemm_desc* d, void* stream) {
   if (!d || !d->X || !d->W || !d->out || !d->zero) return MSCLIP_EINVAL;
-  if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->K % BK) || (d->N % 4)) return MSCLIP_EINVAL;
+  if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->K % BK)) return MSCLIP_EINVAL;
   if (d->mode == 0 && (d->ldx % 8)) return MSCLIP_EINVAL;
   if (d->ldw < d->K || (d->ldw % 8)) return MSCLIP_EINVAL;
   if (d->mode == 1 && (!d->ktab || (d->Cin % 8))) return MSCLIP_EINVAL;

@@ -22,16 +22,25 @@ __global__ __launch_bounds__(256) void lse_rows_kernel(const float* __restrict__
                                                        int N) {
   __shared__ float sh[4];
   const float* r = lg + (size_t)blockIdx.x * ld;
+  const bool vec = !((N | ld) & 3);
   float mx = -INFINITY;
-  for (int c = threadIdx.x * 4; c < N; c += 1024) {
-    const float4 a = *(const float4*)(r + c);
-    mx = fmaxf(fmaxf(mx, fmaxf(a.x, a.y)), fmaxf(a.z, a.w));
+  if (vec) {
+    for (int c = threadIdx.x * 4; c < N; c += 1024) {
+      const float4 a = *(const float4*)(r + c);
+      mx = fmaxf(fmaxf(mx, fmaxf(a.x, a.y)), fmaxf(a.z, a.w));
+    }
+  } else {
+    for (int c = threadIdx.x; c < N; c += 256) mx = fmaxf(mx, r[c]);
   }
   mx = block_reduce(mx, true, sh);
   float s = 0.f;
-  for (int c = threadIdx.x * 4; c < N; c += 1024) {
-    const float4 a = *(const float4*)(r + c);
-    s += (__expf(a.x - mx) + __expf(a.y - mx)) + (__expf(a.z - mx) + __expf(a.w - mx));
+  if (vec) {
+    for (int c = threadIdx.x * 4; c < N; c += 1024) {
+      const float4 a = *(const float4*)(r + c);
+      s += (__expf(a.x - mx) + __expf(a.y - mx)) + (__expf(a.z - mx) + __expf(a.w - mx));
+    }
+  } else {
+    for (int c = threadIdx.x; c < N; c += 256) s += __expf(r[c] - mx);
   }
   s = block_reduce(s, false, sh);
   if (threadIdx.x == 0) lse[blockIdx.x] = mx + __logf(s);
@@ -53,7 +62,7 @@ __global__ __launch_bounds__(256) void clip_loss_kernel(const float* __restrict_
 }  // namespace
 
 extern "C" int msclip_lse_rows(const float* logits, int ld, float* lse, int R, int N, void* stream) {
-  if (!logits || !lse || R <= 0 || N <= 0 || (N % 4) || (ld % 4)) return MSCLIP_EINVAL;
+  if (!logits || !lse || R <= 0 || N <= 0) return MSCLIP_EINVAL;
   hipLaunchKernelGGL(lse_rows_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, logits, ld, lse, N);
   return msclip_launch_status();
 }

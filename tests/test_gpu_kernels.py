@@ -52,6 +52,19 @@ def test_gemm_epilogues(gpu_device):
     close(out, F.relu(base + r16.float()), 3e-2, 1e-2)
 
 
+def test_gemm_ragged_n_tail_path(gpu_device):
+    """N and ld not multiples of 4 (ragged global batch in the logits GEMM)."""
+    M, N, K = 37, 5, 128
+    x, w, b = rnd(M, K, seed=41, dtype=BF), rnd(N, K, seed=42, scale=0.1, dtype=BF), rnd(N, seed=43)
+    out = torch.full((M + 1, N), 3.0, dtype=torch.float32, device="cuda")
+    hip.gemm(x, w, out[:M], bias=b, alpha=2.0)
+    close(out[:M], 2.0 * (x.float() @ w.float().t()) + b, 2e-3, 1e-4)
+    assert bool((out[M] == 3.0).all())
+    o16 = torch.empty(M, N, dtype=BF, device="cuda")
+    hip.gemm(x, w, o16, bias=b, act=hip.ACT_RELU)
+    close(o16, F.relu(x.float() @ w.float().t() + b), 2e-2, 1e-2)
+
+
 def test_gemm_token_scatter_with_table(gpu_device):
     """Stem last_conv epilogue: + positional row (p + 1), scatter to token row b*L + 1 + p."""
     B, g2, D = 3, 49, 256
@@ -242,6 +255,10 @@ def test_lse_and_loss(gpu_device):
     d = rows[torch.arange(R), off + torch.arange(R)]
     ref = ((torch.logsumexp(rows, 1) - d) + (torch.logsumexp(cols, 1) - d)).sum() / (2 * N)
     close(out[0], ref, 1e-4)
+    odd = rnd(3, 5, seed=44, scale=4.0)
+    l3 = torch.empty(3, dtype=torch.float32, device="cuda")
+    hip.lse_rows(odd, l3)
+    close(l3, torch.logsumexp(odd, 1), 1e-4)
 
 
 def test_bad_arguments_are_rejected(gpu_device):
