@@ -1,0 +1,146 @@
+"""Headline benchmark: image-text pairs/s of the MS-CLIP-S ViT-B/32 bf16 forward + contrastive step
+(BASELINE.json configs[1]: batch 512 per GPU, synthetic 224x224 images + 77-token captions, random-init weights).
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over one batch per GPU with inputs resident in HBM: both towers, projection +
+L2 norm, feature all-gather (RCCL, N > 1), local row/column logits blocks, symmetric cross-entropy (+ scalar
+all-reduce).  Weak scaling: the per-GPU batch is fixed.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GFLOP_PER_PAIR = {"b32-yfcc-msclips": 23.549, "b16-yfcc-msclips": 49.617}   # SURVEY.md s8(d), counted on the reference
+PEAK_BF16_TFLOPS = 2500.0                                                      # MI355X_MICROARCH.md: dense bf16 MFMA
+
+
+def load_schema(name):
+    with open(os.path.join(ROOT, "tests", "golden", name + ".schema.json")) as f:
+        return [(k, tuple(s), getattr(torch, d)) for k, s, d in json.load(f)]
+
+
+def cpu_baseline(name, sd, batch=16, iters=2):
+    """The CPU oracle (a restatement of the reference's forward; the reference's Python cannot travel) timed on this
+    box's host cores: forward(image, text) + symmetric CE, fp32, on a bounded sample."""
+    from msclip_amd import synth
+    from oracle import msclip_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    arch = O.arch_b32() if name.startswith("b32") else O.arch_b16()
+    img, tok = synth.synth_images(batch, seed=3), synth.synth_tokens(batch, seed=4)
+    with torch.no_grad():
+        O.contrastive_loss(O.forward(img[:2], tok[:2], sd, arch))            # warm-up
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            O.contrastive_loss(O.forward(img, tok, sd, arch))
+        dt = (time.perf_counter() - t0) / iters
+    return {"value": round(batch / dt, 3), "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{iters} x forward+loss of {batch} pairs, fp32 torch CPU oracle, {torch.get_num_threads()} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=512, help="per-GPU batch (BASELINE config C2: 512)")
+    ap.add_argument("--model", default="b32-yfcc-msclips")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-probe", action="store_true", help="do not bracket GEMM launches with HIP events")
+    args = ap.parse_args()
+
+    from msclip_amd import comm as C, hip, synth
+    from msclip_amd.clip_openai_pe_res_v1 import get_clip_model
+    from msclip_amd.config import named_config
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    C.init_distributed("nccl")
+    rank = C.comm.rank
+    dev = torch.device("cuda", local)
+
+    sd = synth.synth_state_dict(load_schema(args.model), seed=0)
+    model = get_clip_model(named_config(args.model))
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).eval()
+    eng = model.engine()
+    B = args.batch
+    img = synth.synth_images(B, seed=10 + rank).to(dev)                      # fp32 pixels (reference API), resident in HBM
+    tok = synth.synth_tokens(B, seed=100 + rank).to(dev)
+
+    def step():
+        return eng.forward_loss(img, tok, gather=True)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = step()
+    probe = None if args.no_probe else hip.KernelProbe()
+    hip.set_gemm_probe(0, probe)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    hip.set_gemm_probe(0, None)
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    loss_val = float(loss)
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        pairs_s = B * world * args.steps / dt
+        gf = GFLOP_PER_PAIR[args.model]
+        rec = {
+            "metric": "image-text pairs/sec ViT-B/32 bf16" if args.model.startswith("b32") else "image-text pairs/sec ViT-B/16 bf16",
+            "value": round(pairs_s, 1), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"MS-CLIP-S {args.model} fwd + contrastive step (both towers, gather, logits, "
+                                   f"symmetric CE), per-GPU batch {B}, 224x224 images + 77-token captions, "
+                                   f"random-init weights", "per_gpu_batch": B, "global_batch": B * world,
+                       "parallelism": f"dp{world}", "bn": "eval (folded running statistics)"},
+            "step_tflops_per_gpu": round(pairs_s / world * gf / 1e3, 1),
+            "whole_step_mfma_frac": round(pairs_s / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4),
+            "loss": round(loss_val, 5),
+        }
+        if probe is not None:
+            n, kms, flops = probe.summary()
+            ach = flops / (kms * 1e-3) / 1e12
+            rec["roofline"] = {"kernel": "gemm_kernel<0> (dense bf16 MFMA GEMM, all transformer projections)",
+                               "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                               "launches_per_step": n // args.steps, "avg_launch_us": round(kms / n * 1e3, 2),
+                               "flops_per_launch_avg": round(flops / n / 1e9, 3), "flops_unit": "GFLOP",
+                               "time_share_of_step": round(kms / (dt * 1e3), 4)}
+        if world == 1 and not args.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline(args.model, sd)
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

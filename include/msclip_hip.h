@@ -51,6 +51,7 @@ typedef struct msclip_gemm_desc {
   int out_kind;
   float alpha;
   int rpg, radd, roff;   /* rpg > 0; use rpg = INT_MAX, radd = roff = 0 for the identity */
+  int tile;              /* 0 = auto, 1 = 128x128 (4 waves), 2 = 256x256 (8 waves; streaming ring when dense), 3 = 256x256 two-buffer */
 } msclip_gemm_desc;
 
 int msclip_gemm(const msclip_gemm_desc* desc, void* stream);

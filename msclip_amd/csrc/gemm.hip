@@ -5,22 +5,26 @@
 // X is either a dense row-major [M, K] matrix or an NHWC activation gathered on
 // the fly as the implicit-GEMM view of a KHxKW/stride/pad convolution (every
 // 16-byte K-chunk of a row is one LDS-DMA source address, padding taps read a
-// zero page).  W is always the pre-packed [N][Kpad] bf16 weight (Kpad % 64 == 0).
+// zero page).  W is the pre-packed [N][ldw] bf16 weight (K % 64 == 0, zero padded).
 //
-// Tile 128(m) x 128(n) x 64(k), 4 waves as 2x2, each wave 64x64 = 2x2
-// v_mfma_f32_32x32x16_bf16 tiles.  Operands are staged with global_load_lds
-// (16 B/lane, lane-linear LDS image); the LDS image is the XOR-swizzled
-// [row][8 chunks] layout: physical chunk = logical chunk ^ ((row >> 1) & 7),
-// applied on the per-lane SOURCE address and again on the ds_read_b128 address
-// (cdna_hip_programming.md s5.4 rule 21), conflict-free for the 32x32x16
-// fragment read.  MFMA operands are swapped (A = W rows, B = X rows) so every
-// lane owns 4 consecutive output columns of one output row.
+// Structure (measured choices, see DESIGN.md "GEMM"):
+//  * persistent workgroups walk tiles t = blockIdx.x, += gridDim.x in an XCD-aware order;
+//  * two 64-deep K-slabs in LDS, filled by global_load_lds (16 B/lane, lane-linear image);
+//    the image is XOR-swizzled: physical chunk = logical ^ ((row >> 1) & 7), applied on the
+//    per-lane SOURCE address and on the ds_read_b128 address (conflict-free, PMC-verified);
+//  * the LDS-DMA of slab s+1 (and, on the last slab, of the NEXT tile's first slab) and the
+//    fragment reads of k-step kk+1 are issued BETWEEN the MFMAs of k-step kk
+//    (sched_group_barrier), so memory instructions hide in MFMA issue gaps instead of
+//    forming a serial burst after each barrier;
+//  * MFMA operands are swapped (A = W rows, B = X rows): a lane owns 4 consecutive output
+//    columns of one row; interior tiles are transposed through the just-consumed LDS slab
+//    so every global store / residual load instruction moves full 128-byte lines.
 #include "common.h"
 #include "../../include/msclip_hip.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int BK = 64;
 
 struct RowSrc {          // per staged X row (conv mode)
   long long pix;         // element offset of the (ih0, iw0) tap pixel (may be negative)
@@ -28,132 +32,138 @@ struct RowSrc {          // per staged X row (conv mode)
   int ok;
 };
 
-template <int MODE>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const msclip_gemm_desc a) {
-  __shared__ __attribute__((aligned(1024))) bf16_t smem[2][2][BM * BK];  // [buf][X|W][row*64]
+constexpr int STG_BYTES = 4096;   // per-wave staging: 32 rows x 128 B, 16-byte chunks XOR-swizzled by (row & 7)
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-  const int nt_n = (a.N + BN - 1) / BN;
-  int id;
-  {  // XCD-aware bijective remap: consecutive ids stay on one XCD (shared X rows in its L2)
-    const int nwg = gridDim.x, b = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, x = b & 7;
-    id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
-  }
-  const int m0 = (id / nt_n) * BM;
-  const int n0 = (id % nt_n) * BN;
-
-  const bf16_t* __restrict__ X = (const bf16_t*)a.X;
-  const bf16_t* __restrict__ W = (const bf16_t*)a.W;
-  const bf16_t* __restrict__ Z = (const bf16_t*)a.zero;
-
-  // ---- loader state: lane owns (row = (i*4+wave)*8 + lane/8, physical chunk = lane%8), i = 0..3
-  const int pc = lane & 7;
-  const int lc = pc ^ ((lane >> 4) | ((wave & 1) << 2));  // logical chunk; == pc ^ ((row>>1)&7)
-  const int rsub = lane >> 3;
-
-  const bf16_t* xrow[4];
-  RowSrc xr[4];
-  const bf16_t* wrow[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = (i * 4 + wave) * 8 + rsub;
-    const int m = m0 + r, n = n0 + r;
-    wrow[i] = (n < a.N) ? W + (size_t)n * a.ldw + lc * 8 : nullptr;
-    if (MODE == 0) {
-      xrow[i] = (m < a.M) ? X + (size_t)m * a.ldx + lc * 8 : nullptr;
-    } else {
-      const int hw = a.Ho * a.Wo;
-      const int bi = m / hw, p = m - bi * hw;
-      const int ho = p / a.Wo, wo = p - ho * a.Wo;
-      xr[i].ih0 = ho * a.stride - a.pad;
-      xr[i].iw0 = wo * a.stride - a.pad;
-      xr[i].pix = (((long long)bi * a.H + xr[i].ih0) * a.Wd + xr[i].iw0) * a.Cin;
-      xr[i].ok = m < a.M;
-    }
-  }
-
-  auto stage = [&](int buf, int kt) {
-    int e = 0;
-    if (MODE == 1) e = a.ktab[kt * 8 + lc];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bf16_t* src;
-      if (MODE == 0) {
-        src = xrow[i] ? xrow[i] + kt * BK : Z;
-      } else {
-        const int kh = (e >> 20) & 15, kw = (e >> 24) & 15;
-        const int ih = xr[i].ih0 + kh, iw = xr[i].iw0 + kw;
-        const bool ok = xr[i].ok && e >= 0 && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.Wd;
-        src = ok ? X + (xr[i].pix + (e & 0xFFFFF)) : Z;
-      }
-      glds16(src, &smem[buf][0][(i * 4 + wave) * 8 * BK]);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bf16_t* src = wrow[i] ? wrow[i] + kt * BK : Z;
-      glds16(src, &smem[buf][1][(i * 4 + wave) * 8 * BK]);
-    }
-  };
-
-  // ---- fragment read state
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-  const int fr = lane & 31;
-  const int fsw = (lane >> 1) & 7;
-  const int fhi = lane >> 5;
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int nk = a.K / BK;
-  stage(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-    const bf16_t* xs = smem[kt & 1][0];
-    const bf16_t* ws = smem[kt & 1][1];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const int ph = ((kk * 2 + fhi) ^ fsw) * 8;
-      bf16x8 wf[2], xf[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        wf[t] = *(const bf16x8*)(ws + (wn + t * 32 + fr) * BK + ph);
-        xf[t] = *(const bf16x8*)(xs + (wm + t * 32 + fr) * BK + ph);
-      }
-#pragma unroll
-      for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
-          acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tn], xf[tm], acc[tn][tm], 0, 0, 0);
-    }
-  }
-
-  // ---- epilogue: lane owns row m = .. + (lane&31), columns n = .. + 8g + 4*(lane>>5) + 0..3
+// Interior tile (no guards): transpose the wave's TM x TN 32x32 accumulator tiles through LDS so that 8 lanes
+// cover one 128-byte line of one output row; bias/QuickGELU are applied in accumulator layout, the residual
+// add / ReLU / conversion after the transpose (row-contiguous, full-line residual loads).
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue_interior(f32x16 (&acc)[TN][TM], const msclip_gemm_desc& a, char* stg,
+                                                  int mw0, int nw0, int lane) {
+  const int fr = lane & 31, fhi = lane >> 5;
+  const int srow = lane >> 3, sch = lane & 7;      // read-back mapping: row i*8 + srow, 16-byte chunk sch
   const float* __restrict__ bias = a.bias;
-  const bool vec = !((a.N | a.ldo | (a.resid_kind ? a.ldr : 0)) & 3);
+  float4 bv[TN][4];
 #pragma unroll
-  for (int tm = 0; tm < 2; ++tm) {
-    const int m = m0 + wm + tm * 32 + fr;
+  for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      bv[tn][g] = bias ? *(const float4*)(bias + nw0 + fhi * 4 + tn * 32 + g * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool direct16 = a.out_kind == 0 && a.resid_kind == 0;   // bf16 out, nothing to add after the transpose
+  char* wr = stg + fr * 128;
+  const int wsw = fr & 7;
+  const char* rd = stg + srow * 128 + ((sch ^ srow) << 4);      // + i * 1024 for row block i
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int mrow0 = mw0 + tm * 32;
+    if (direct16) {
+      static_assert(TN == 2, "64 bf16 columns per staged row");
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float v0 = acc[tn][tm][g * 4 + 0] * a.alpha + bv[tn][g].x;
+          float v1 = acc[tn][tm][g * 4 + 1] * a.alpha + bv[tn][g].y;
+          float v2 = acc[tn][tm][g * 4 + 2] * a.alpha + bv[tn][g].z;
+          float v3 = acc[tn][tm][g * 4 + 3] * a.alpha + bv[tn][g].w;
+          if (a.act == 1) {
+            v0 = v0 / (1.f + __expf(-1.702f * v0)); v1 = v1 / (1.f + __expf(-1.702f * v1));
+            v2 = v2 / (1.f + __expf(-1.702f * v2)); v3 = v3 / (1.f + __expf(-1.702f * v3));
+          } else if (a.act == 2) {
+            v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+          }
+          uint2 o;
+          o.x = pack_bf16x2(v0, v1);
+          o.y = pack_bf16x2(v2, v3);
+          const int c = tn * 4 + g;                                // 16-byte chunk; this lane owns half fhi of it
+          *(uint2*)(wr + ((c ^ wsw) << 4) + fhi * 8) = o;
+        }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint4 u = *(const uint4*)(rd + i * 1024);
+#ifndef MSCLIP_ABLATE_EPI
+        *(uint4*)((bf16_t*)a.out + (size_t)(mrow0 + i * 8 + srow) * a.ldo + nw0 + sch * 8) = u;
+#else
+        asm volatile("" ::"v"(u.x), "v"(u.y), "v"(u.z), "v"(u.w));
+#endif
+      }
+    } else {
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float4 v;
+          v.x = acc[tn][tm][g * 4 + 0] * a.alpha + bv[tn][g].x;
+          v.y = acc[tn][tm][g * 4 + 1] * a.alpha + bv[tn][g].y;
+          v.z = acc[tn][tm][g * 4 + 2] * a.alpha + bv[tn][g].z;
+          v.w = acc[tn][tm][g * 4 + 3] * a.alpha + bv[tn][g].w;
+          if (a.act == 1) {
+            v.x = v.x / (1.f + __expf(-1.702f * v.x)); v.y = v.y / (1.f + __expf(-1.702f * v.y));
+            v.z = v.z / (1.f + __expf(-1.702f * v.z)); v.w = v.w / (1.f + __expf(-1.702f * v.w));
+          }
+          const int c = g * 2 + fhi;                               // 16-byte chunk = 4 fp32 columns
+          *(float4*)(wr + ((c ^ wsw) << 4)) = v;
+        }
+        float4 rv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const size_t row = (size_t)(mrow0 + i * 8 + srow);
+          const int n = nw0 + tn * 32 + sch * 4;
+          if (a.resid_kind == 1) {
+            rv[i] = *(const float4*)((const float*)a.resid + row * a.ldr + n);
+          } else if (a.resid_kind == 2) {
+            const uint2 u = *(const uint2*)((const bf16_t*)a.resid + row * a.ldr + n);
+            rv[i] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                                __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+          } else {
+            rv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float4 v = *(const float4*)(rd + i * 1024);
+          v.x += rv[i].x; v.y += rv[i].y; v.z += rv[i].z; v.w += rv[i].w;
+          if (a.act == 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          const size_t row = (size_t)(mrow0 + i * 8 + srow);
+          const int n = nw0 + tn * 32 + sch * 4;
+#ifndef MSCLIP_ABLATE_EPI
+          if (a.out_kind == 1) {
+            *(float4*)((float*)a.out + row * a.ldo + n) = v;
+          } else {
+            uint2 o;
+            o.x = pack_bf16x2(v.x, v.y);
+            o.y = pack_bf16x2(v.z, v.w);
+            *(uint2*)((bf16_t*)a.out + row * a.ldo + n) = o;
+          }
+#else
+          asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w), "v"(row), "v"(n));
+#endif
+        }
+      }
+    }
+  }
+}
+
+// Edge tiles, ragged N, unaligned leading dimensions, row scatter / table residual: guarded, straight from the
+// accumulator layout (lane owns row .. + (lane&31), columns .. + 8g + 4*(lane>>5) + 0..3).
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue_generic(f32x16 (&acc)[TN][TM], const msclip_gemm_desc& a, bool vec, int mw0,
+                                                 int nw0, int lane) {
+  const int fr = lane & 31, fhi = lane >> 5;
+  const float* __restrict__ bias = a.bias;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int m = mw0 + tm * 32 + fr;
     if (m >= a.M) continue;
     const int grp = m / a.rpg;
     const size_t orow = (size_t)(m + grp * a.radd + a.roff);
     size_t rrow = (size_t)m;
     if (a.resid_kind == 3) rrow = (size_t)(m - grp * a.rpg + a.roff);
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
+    for (int tn = 0; tn < TN; ++tn) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int n = n0 + wn + tn * 32 + g * 8 + fhi * 4;
+        const int n = nw0 + tn * 32 + g * 8 + fhi * 4;
         if (n >= a.N) continue;
         float v[4];
 #pragma unroll
@@ -206,7 +216,426 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const msclip_gemm_desc a) 
   }
 }
 
+// Tile configuration: BM x BN output tile, WM x WN waves, each wave owns TM x TN 32x32 MFMA tiles.
+//   big  : 256 x 256, 8 waves (2 x 4), 128 KiB LDS, one workgroup per CU  (transformer projections)
+//   small: 128 x 128, 4 waves (2 x 2),  64 KiB LDS, two workgroups per CU (narrow convolutions, tiny heads)
+template <int MODE, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const msclip_gemm_desc a) {
+  constexpr int NW = WM * WN;
+  constexpr int NT = NW * 64;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int XI = BM * 8 / NT, WI = BN * 8 / NT;   // LDS-DMA pieces per lane per K-slab
+  constexpr int NV = (XI + WI) / 4;                   // pieces issued per k-step
+  static_assert(XI >= 1 && WI >= 1 && (NW % 2) == 0 && (XI + WI) % 4 == 0 && TN == 2, "tile config");
+  static_assert((BM + BN) * BK * 2 >= NW * STG_BYTES, "staging region per wave");
+  __shared__ __attribute__((aligned(1024))) bf16_t smem[2][(BM + BN) * BK];  // [buf][X rows | W rows][64]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  const int nt_n = (a.N + BN - 1) / BN;
+  const int nt_m = (a.M + BM - 1) / BM;
+  const int ntiles = nt_n * nt_m;
+
+  const bf16_t* __restrict__ X = (const bf16_t*)a.X;
+  const bf16_t* __restrict__ W = (const bf16_t*)a.W;
+  const bf16_t* __restrict__ Z = (const bf16_t*)a.zero;
+
+  // ---- loader state: lane owns (row = (i*NW+wave)*8 + lane/8, physical chunk = lane%8)
+  const int pc = lane & 7;
+  const int lc = pc ^ ((lane >> 4) | ((wave & 1) << 2));  // logical chunk; == pc ^ ((row>>1)&7)
+  const int rsub = lane >> 3;
+
+  const bf16_t* xrow[XI];
+  RowSrc xr[XI];
+  const bf16_t* wrow[WI];
+
+  auto tile_origin = [&](int t, int& m0, int& n0) {
+    // XCD-aware bijective remap: tiles with consecutive ids run on one XCD (they share X rows in its L2)
+    const int q = ntiles >> 3, r = ntiles & 7, x = t & 7;
+    const int id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (t >> 3);
+    m0 = (id / nt_n) * BM;
+    n0 = (id % nt_n) * BN;
+  };
+
+  auto setup_rows = [&](int m0, int n0) {
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+      const int n = n0 + (i * NW + wave) * 8 + rsub;
+      wrow[i] = (n < a.N) ? W + (size_t)n * a.ldw + lc * 8 : nullptr;
+    }
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      const int m = m0 + (i * NW + wave) * 8 + rsub;
+      if (MODE == 0) {
+        xrow[i] = (m < a.M) ? X + (size_t)m * a.ldx + lc * 8 : nullptr;
+      } else {
+        const int hw = a.Ho * a.Wo;
+        const int bi = m / hw, p = m - bi * hw;
+        const int ho = p / a.Wo, wo = p - ho * a.Wo;
+        xr[i].ih0 = ho * a.stride - a.pad;
+        xr[i].iw0 = wo * a.stride - a.pad;
+        xr[i].pix = (((long long)bi * a.H + xr[i].ih0) * a.Wd + xr[i].iw0) * a.Cin;
+        xr[i].ok = m < a.M;
+      }
+    }
+  };
+
+  // source addresses of one K-slab for this lane (e = chunk-table entry of the slab in conv mode)
+  auto slab_sources = [&](int kt, int e, const bf16_t* (&src)[XI + WI]) {
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      if (MODE == 0) {
+        src[i] = xrow[i] ? xrow[i] + kt * BK : Z;
+      } else {
+        const int kh = (e >> 20) & 15, kw = (e >> 24) & 15;
+        const int ih = xr[i].ih0 + kh, iw = xr[i].iw0 + kw;
+        const bool ok = xr[i].ok && e >= 0 && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.Wd;
+        src[i] = ok ? X + (xr[i].pix + (e & 0xFFFFF)) : Z;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < WI; ++i) src[XI + i] = wrow[i] ? wrow[i] + kt * BK : Z;
+  };
+  auto piece_dst = [&](int buf, int j) -> bf16_t* {   // LDS destination (wave-uniform) of piece j
+    return j < XI ? &smem[buf][(j * NW + wave) * 8 * BK] : &smem[buf][BM * BK + ((j - XI) * NW + wave) * 8 * BK];
+  };
+
+  // ---- fragment read state
+  const int wm = (wave / WN) * (TM * 32), wn = (wave % WN) * (TN * 32);
+  const int fr = lane & 31;
+  const int fsw = (lane >> 1) & 7;
+  const int fhi = lane >> 5;
+  const bool vec = !((a.N | a.ldo | (a.resid_kind ? a.ldr : 0)) & 3);
+  const bool plain_rows = a.rpg == 0x7fffffff && a.resid_kind != 3;
+  const int nk = a.K / BK;
+
+  int t = blockIdx.x;
+  int m0 = 0, n0 = 0;
+  int e_next = 0;   // conv: chunk-table entry of the slab that will be ISSUED during the coming iteration
+  if (t < ntiles) {
+    tile_origin(t, m0, n0);
+    setup_rows(m0, n0);
+    const bf16_t* src[XI + WI];
+    slab_sources(0, MODE == 1 ? a.ktab[lc] : 0, src);
+#pragma unroll
+    for (int j = 0; j < XI + WI; ++j) glds16(src[j], piece_dst(0, j));
+    if (MODE == 1) e_next = a.ktab[(nk > 1 ? 8 : 0) + lc];
+  }
+  int it = 0;         // running K-slab counter: slab `it` lives in buffer it & 1
+  bool landed = false;  // the first slab of this tile was already waited for (and published) by the previous epilogue
+  for (; t < ntiles; t += gridDim.x) {
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int cm0 = m0, cn0 = n0;
+    const bool has_next = t + (int)gridDim.x < ntiles;
+    for (int kt = 0; kt < nk; ++kt, ++it) {
+      if (kt == 0 && landed) {
+        // slab already published by the epilogue's barrier; this one only orders the staging reads of all waves
+        // before the LDS-DMA into that buffer -- raw barrier, so this tile's stores keep draining in the background
+        __builtin_amdgcn_s_barrier();
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+      // ---- what to issue during this slab's MFMAs: slab kt+1 of this tile, or slab 0 of the next tile
+      const bf16_t* src[XI + WI];
+      const bool last = kt + 1 == nk;
+      if (last && has_next) {
+        tile_origin(t + gridDim.x, m0, n0);
+        setup_rows(m0, n0);
+      }
+      if (!last || has_next) {
+        slab_sources(last ? 0 : kt + 1, e_next, src);
+      } else {
+#pragma unroll
+        for (int j = 0; j < XI + WI; ++j) src[j] = Z;   // tail of the tile list: harmless dummy pieces
+      }
+      if (MODE == 1) {   // chunk-table entry for the slab after that one (used next iteration)
+        int kn = last ? 1 : kt + 2;
+        if (kn >= nk) kn -= nk;
+        e_next = a.ktab[kn * 8 + lc];
+      }
+      const int nb = (it + 1) & 1;
+      const bf16_t* xs = smem[it & 1] + (wm + fr) * BK;
+      const bf16_t* ws = smem[it & 1] + BM * BK + (wn + fr) * BK;
+      bf16x8 wf[2][TN], xf[2][TM];
+      {
+        const int ph = (fhi ^ fsw) * 8;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) wf[0][i] = *(const bf16x8*)(ws + i * 32 * BK + ph);
+#pragma unroll
+        for (int j = 0; j < TM; ++j) xf[0][j] = *(const bf16x8*)(xs + j * 32 * BK + ph);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        if (kk < 3) {
+          const int ph = (((kk + 1) * 2 + fhi) ^ fsw) * 8;
+#pragma unroll
+          for (int i = 0; i < TN; ++i) wf[(kk + 1) & 1][i] = *(const bf16x8*)(ws + i * 32 * BK + ph);
+#pragma unroll
+          for (int j = 0; j < TM; ++j) xf[(kk + 1) & 1][j] = *(const bf16x8*)(xs + j * 32 * BK + ph);
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) glds16(src[kk * NV + v], piece_dst(nb, kk * NV + v));
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int j = 0; j < TM; ++j) {
+#ifndef MSCLIP_ABLATE_MFMA
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk & 1][i], xf[kk & 1][j], acc[i][j], 0, 0, 0);
+#else
+            asm volatile("" ::"v"(wf[kk & 1][i]), "v"(xf[kk & 1][j]));
+#endif
+          }
+        // interleave: one memory instruction behind each MFMA (fragment reads first, then LDS-DMA pieces)
+#pragma unroll
+        for (int q = 0; q < TM * TN; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   // MFMA
+          if (kk < 3 && q < TM + TN) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);         // DS read
+          if (q >= TM * TN - NV) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);            // VMEM read
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+
+    // ---- the prefetched slab (next tile) lands under the epilogue math; wait for it BEFORE the stores are issued
+    //      so that the next tile's first barrier does not have to drain this tile's stores.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                  // also: every wave is done reading slab (it-1)&1 -> it becomes the staging area
+    landed = true;
+
+    // ---- epilogue
+    if (vec && plain_rows && cm0 + BM <= a.M && cn0 + BN <= a.N)
+      epilogue_interior<TM, TN>(acc, a, (char*)smem[(it + 1) & 1] + wave * STG_BYTES, cm0 + wm, cn0 + wn, lane);
+    else
+      epilogue_generic<TM, TN>(acc, a, vec, cm0 + wm, cn0 + wn, lane);
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// Streaming kernel for the dense transformer projections: 256 x 256 tile, 8 waves (2 x 4), K-slabs of 32 in a
+// 4-slot LDS ring (4 x 32 KiB).  Three slabs are always in flight and the synchronisation is software-pipelined.
+// Iteration s (slab s in slot s & 3):
+//   [A] k-step 0 MFMAs  interleaved with  ds_reads of (s, k-step 1)    and 2 LDS-DMA pieces of slab s+3
+//   [B] s_waitcnt vmcnt(6) ; s_barrier                                  -> slab s+1 is published
+//   [C] k-step 1 MFMAs  interleaved with  ds_reads of (s+1, k-step 0)  and 2 LDS-DMA pieces of slab s+3
+// so a slab starts with its first fragments already in registers, and the LDS latency, the DMA latency and the
+// barrier skew sit under MFMAs.  vmcnt(6): younger than slab s+1 are slab s+2 (4 pieces) and the 2 pieces issued in
+// [A]; loads retire in order, so "<= 6 outstanding" implies slab s+1 landed (stores in the queue only make the wait
+// conservative).  Slot (s+3) & 3 == (s-1) & 3 was last read before barrier B(s-1).  The stream runs across tile
+// boundaries (three slabs of the next tile fly under the epilogue).  LDS image per slab: [512 rows][4 chunks of
+// 16 B], physical chunk = logical ^ ((row >> 3) & 3): conflict-free for the 32x32x16 fragment read (PMC: 0).
+//
+// Variants measured on MI355X (M 65024, shared-layer shapes, sum of the four GEMMs): 128x128 two-buffer 1780 us;
+// 256x256 two-buffer 1350 us; this kernel 1262 us; a ping-pong variant (memory / MFMA segments, waves 4-7 one
+// barrier behind) 1354 us.  Ceiling probes: MFMA-only streams clock down to ~1.5 GHz (~1650 TF); MFMA plus the
+// 7.8 GB/s-per-TF DMA stream this tile shape needs, issued from independent waves, reach ~945 TF.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int RBK = 32, RSLOTS = 4, RBM = 256, RBN = 256;
+
+__global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const msclip_gemm_desc a) {
+  constexpr int NW = 8, TM = 4, TN = 2;
+  static_assert((RBM + RBN) * RBK * 2 >= NW * STG_BYTES, "staging fits one ring slot");
+  __shared__ __attribute__((aligned(1024))) bf16_t smem[RSLOTS][(RBM + RBN) * RBK];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nt_n = (a.N + RBN - 1) / RBN;
+  const int nt_m = (a.M + RBM - 1) / RBM;
+  const int ntiles = nt_n * nt_m;
+  const int nk = a.K / RBK;
+
+  const bf16_t* __restrict__ X = (const bf16_t*)a.X;
+  const bf16_t* __restrict__ W = (const bf16_t*)a.W;
+  const bf16_t* __restrict__ Z = (const bf16_t*)a.zero;
+
+  auto tile_origin = [&](int t, int& m0, int& n0) {
+    const int q = ntiles >> 3, r = ntiles & 7, x = t & 7;
+    const int id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (t >> 3);
+    m0 = (id / nt_n) * RBM;
+    n0 = (id % nt_n) * RBN;
+  };
+
+  // ---- issue side: lane owns (row = (i*8 + wave)*16 + lane/4, physical chunk = lane%4), i = 0..1 per operand
+  const int lc = (lane & 3) ^ ((lane >> 5) | ((wave & 1) << 1));   // == pc ^ ((row >> 3) & 3)
+  const int rsub = lane >> 2;
+  const bf16_t* rowp[4];        // X piece 0, X piece 1, W piece 0, W piece 1 (nullptr = out of range -> zero page)
+  int ti = blockIdx.x, kti = 0, si = 0;
+  auto setup_rows = [&](int t) {
+    int m0, n0;
+    tile_origin(t, m0, n0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = m0 + (i * NW + wave) * 16 + rsub;
+      const int n = n0 + (i * NW + wave) * 16 + rsub;
+      rowp[i] = (m < a.M) ? X + (size_t)m * a.ldx + lc * 8 : nullptr;
+      rowp[2 + i] = (n < a.N) ? W + (size_t)n * a.ldw + lc * 8 : nullptr;
+    }
+  };
+  // sources + LDS slot of the NEXT slab to issue (consumed piece by piece inside the MFMA stream)
+  const bf16_t* src[4];
+  bf16_t* dst0 = nullptr;
+  auto plan_next = [&]() {
+    if (ti < ntiles) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) src[j] = rowp[j] ? rowp[j] + kti * RBK : Z;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) src[j] = Z;      // past the end of the tile list: dummy pieces keep the counts exact
+    }
+    dst0 = smem[si & (RSLOTS - 1)];
+  };
+  auto advance = [&]() {
+    ++si;
+    if (ti < ntiles && ++kti == nk) {
+      kti = 0;
+      ti += gridDim.x;
+      if (ti < ntiles) setup_rows(ti);
+    }
+  };
+  auto piece_dst = [&](int j) -> bf16_t* {
+    return dst0 + (j < 2 ? 0 : RBM * RBK) + ((j & 1) * NW + wave) * 16 * RBK;
+  };
+
+  // ---- compute side
+  const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
+  const int fr = lane & 31, fhi = lane >> 5;
+  const int fsw = (fr >> 3) & 3;
+  const bool vec = !((a.N | a.ldo | (a.resid_kind ? a.ldr : 0)) & 3);
+  const bool plain_rows = a.rpg == 0x7fffffff && a.resid_kind != 3;
+
+  if (ti < ntiles) setup_rows(ti);
+#pragma unroll 1
+  for (int p = 0; p < 3; ++p) {   // prologue: three slabs in flight
+    plan_next();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) glds16(src[j], piece_dst(j));
+    advance();
+  }
+
+  int sc = 0;
+  bf16x8 wf[2][TN], xf[2][TM];
+  auto read_frags = [&](int slot, int kk, int set) {
+    const bf16_t* xs = smem[slot] + (wm + fr) * RBK;
+    const bf16_t* ws = smem[slot] + RBM * RBK + (wn + fr) * RBK;
+    const int ph = ((kk * 2 + fhi) ^ fsw) * 8;
+#pragma unroll
+    for (int i = 0; i < TN; ++i) wf[set][i] = *(const bf16x8*)(ws + i * 32 * RBK + ph);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) xf[set][j] = *(const bf16x8*)(xs + j * 32 * RBK + ph);
+  };
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  read_frags(0, 0, 0);
+
+  bool first_tile = true;
+  for (int tc = blockIdx.x; tc < ntiles; tc += gridDim.x) {
+    int cm0, cn0;
+    tile_origin(tc, cm0, cn0);
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    if (!first_tile) {
+      // every wave has finished reading its epilogue staging (slot (sc-1) & 3) before slab sc+3 is DMA'd into it
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+    first_tile = false;
+
+    for (int kt = 0; kt < nk; ++kt, ++sc) {
+      plan_next();
+      // ---- [A]
+      read_frags(sc & (RSLOTS - 1), 1, 1);
+      glds16(src[0], piece_dst(0));
+      glds16(src[1], piece_dst(1));
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+#ifndef MSCLIP_ABLATE_MFMA
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0][i], xf[0][j], acc[i][j], 0, 0, 0);
+#else
+          asm volatile("" ::"v"(wf[0][i]), "v"(xf[0][j]));
+#endif
+        }
+#pragma unroll
+      for (int q = 0; q < TM * TN; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   // MFMA
+        if (q < TM + TN) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                   // DS read
+        if (q >= TM * TN - 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);             // VMEM read
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- [B]
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- [C]
+      read_frags((sc + 1) & (RSLOTS - 1), 0, 0);
+      glds16(src[2], piece_dst(2));
+      glds16(src[3], piece_dst(3));
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+#ifndef MSCLIP_ABLATE_MFMA
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1][i], xf[1][j], acc[i][j], 0, 0, 0);
+#else
+          asm volatile("" ::"v"(wf[1][i]), "v"(xf[1][j]));
+#endif
+        }
+#pragma unroll
+      for (int q = 0; q < TM * TN; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (q < TM + TN) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if (q >= TM * TN - 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      advance();
+    }
+
+    // Slot (sc-1) & 3 (the tile's last slab) is not read by anyone after the last [B]: it is the staging area.
+    if (vec && plain_rows && cm0 + RBM <= a.M && cn0 + RBN <= a.N)
+      epilogue_interior<TM, TN>(acc, a, (char*)smem[(sc + RSLOTS - 1) & (RSLOTS - 1)] + wave * STG_BYTES, cm0 + wm,
+                                cn0 + wn, lane);
+    else
+      epilogue_generic<TM, TN>(acc, a, vec, cm0 + wm, cn0 + wn, lane);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // dummy tail pieces must land before the LDS is released
+}
+
 }  // namespace
+
+template <int MODE, int BM, int BN, int WM, int WN>
+static void launch_cfg(const msclip_gemm_desc* d, hipStream_t st, int blocks_per_cu) {
+  static int ncu = 0;
+  if (!ncu) {
+    hipDeviceProp_t p;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    ncu = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+  }
+  const int tiles = ((d->M + BM - 1) / BM) * ((d->N + BN - 1) / BN);
+  const int cap = ncu * blocks_per_cu;
+  const int grid = tiles < cap ? tiles : cap;
+  hipLaunchKernelGGL((gemm_kernel<MODE, BM, BN, WM, WN>), dim3(grid), dim3(WM * WN * 64), 0, st, *d);
+}
 
 extern "C" int msclip_gemm(const msclip_gemm_desc* d, void* stream) {
   if (!d || !d->X || !d->W || !d->out || !d->zero) return MSCLIP_EINVAL;
@@ -214,11 +643,28 @@ extern "C" int msclip_gemm(const msclip_gemm_desc* d, void* stream) {
   if (d->mode == 0 && (d->ldx % 8)) return MSCLIP_EINVAL;
   if (d->ldw < d->K || (d->ldw % 8)) return MSCLIP_EINVAL;
   if (d->mode == 1 && (!d->ktab || (d->Cin % 8))) return MSCLIP_EINVAL;
+  if (d->mode != 0 && d->mode != 1) return MSCLIP_EINVAL;
   if (d->rpg <= 0) return MSCLIP_EINVAL;
-  const int grid = ((d->M + BM - 1) / BM) * ((d->N + BN - 1) / BN);
-  if (d->mode == 0)
-    hipLaunchKernelGGL(gemm_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d);
-  else
-    hipLaunchKernelGGL(gemm_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *d);
+  hipStream_t st = (hipStream_t)stream;
+  // tile choice: the 256x256 / 8-wave config whenever the problem fills the chip with it, else 128x128
+  const long long big_tiles = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256);
+  const bool big = d->tile >= 2 || (d->tile == 0 && d->N >= 192 && big_tiles >= 128);
+  if (d->mode == 0) {
+    if (big && d->tile != 3) {   // streaming ring kernel (tile 3 selects the two-buffer 256x256 kernel for A/B tests)
+      static int ncu = 0;
+      if (!ncu) {
+        hipDeviceProp_t p;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        ncu = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+      }
+      const int tiles = ((d->M + 255) / 256) * ((d->N + 255) / 256);
+      hipLaunchKernelGGL(gemm_ring_kernel, dim3(tiles < ncu ? tiles : ncu), dim3(512), 0, st, *d);
+    } else if (big) launch_cfg<0, 256, 256, 2, 4>(d, st, 1);
+    else launch_cfg<0, 128, 128, 2, 2>(d, st, 2);
+  } else {
+    if (big) launch_cfg<1, 256, 256, 2, 4>(d, st, 1);
+    else launch_cfg<1, 128, 128, 2, 2>(d, st, 2);
+  }
   return msclip_launch_status();
 }

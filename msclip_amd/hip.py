@@ -12,7 +12,7 @@ import subprocess
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmsclip_hip.so")
+LIB_PATH = os.environ.get("MSCLIP_HIP_LIB") or os.path.join(_HERE, "csrc", "libmsclip_hip.so")   # override: kernel A/B probes only
 INT_MAX = 2 ** 31 - 1
 
 EXPORTS = (
@@ -43,7 +43,7 @@ class GemmDesc(ctypes.Structure):
         ("ktab", ctypes.c_void_p),
         ("act", ctypes.c_int), ("resid_kind", ctypes.c_int), ("out_kind", ctypes.c_int),
         ("alpha", ctypes.c_float),
-        ("rpg", ctypes.c_int), ("radd", ctypes.c_int), ("roff", ctypes.c_int),
+        ("rpg", ctypes.c_int), ("radd", ctypes.c_int), ("roff", ctypes.c_int), ("tile", ctypes.c_int),
     ]
 
 
@@ -124,12 +124,42 @@ def _f32(t):
     assert t.dtype == torch.float32 and t.is_cuda and t.is_contiguous(), (t.dtype, t.device, t.is_contiguous())
 
 
+class KernelProbe:
+    """Brackets every launch of one kernel family with HIP events on the launch stream (bench.py's roofline leg).
+    `units` is the algorithmic work of the launch (FLOPs for the GEMM)."""
+
+    def __init__(self):
+        self.records = []          # (start_event, end_event, units)
+
+    def begin(self):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def end(self, start, units):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        self.records.append((start, ev, units))
+
+    def summary(self):
+        """-> (launches, total_ms, total_units); call after a synchronize."""
+        ms = sum(s.elapsed_time(e) for s, e, _ in self.records)
+        return len(self.records), ms, sum(u for _, _, u in self.records)
+
+
+_gemm_probe = {0: None, 1: None}   # per loader mode (0 dense, 1 implicit conv)
+
+
+def set_gemm_probe(mode, probe):
+    _gemm_probe[mode] = probe
+
+
 ACT_NONE, ACT_QUICKGELU, ACT_RELU = 0, 1, 2
 RESID_NONE, RESID_F32, RESID_BF16, RESID_TABLE = 0, 1, 2, 3
 
 
 def gemm(x, w, out, *, M=None, bias=None, resid=None, resid_kind=0, act=0, alpha=1.0, conv=None, ktab=None,
-         ldx=None, ldo=None, ldr=None, rpg=INT_MAX, radd=0, roff=0, N=None):
+         ldx=None, ldo=None, ldr=None, rpg=INT_MAX, radd=0, roff=0, N=None, tile=0):
     """out = epilogue(alpha * x @ w^T).  x: bf16 [M, K] (or NHWC activation when conv=(H, W, Cin, Ho, Wo, stride, pad)),
     w: bf16 [N, Kpad]; out: bf16 or fp32 2-D buffer."""
     _bf16(w)
@@ -155,8 +185,29 @@ def gemm(x, w, out, *, M=None, bias=None, resid=None, resid_kind=0, act=0, alpha
     d.out_kind = 1 if out.dtype == torch.float32 else 0
     d.alpha = alpha
     d.rpg, d.radd, d.roff = rpg, radd, roff
+    d.tile = tile
+    probe = _gemm_probe[d.mode]
+    if probe is not None:
+        k_alg = d.K if conv is None else conv[2] * (ktab_taps(ktab) if ktab is not None else 1)
+        t0 = probe.begin()
+        _check(lib().msclip_gemm(ctypes.byref(d), _stream()), "msclip_gemm")
+        probe.end(t0, 2.0 * d.M * d.N * k_alg)
+        return out
     _check(lib().msclip_gemm(ctypes.byref(d), _stream()), "msclip_gemm")
     return out
+
+
+_TAPS = {}
+
+
+def ktab_taps(ktab):
+    """Number of real (non-padding) filter taps described by a chunk table (cached; used by the probe only)."""
+    key = ktab.data_ptr()
+    if key not in _TAPS:
+        t = ktab.cpu()
+        valid = t[t >= 0]
+        _TAPS[key] = int(torch.unique(valid >> 20).numel())
+    return _TAPS[key]
 
 
 def attention(qkv, out, nsamples, L, heads, causal):

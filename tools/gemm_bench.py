@@ -1,0 +1,72 @@
+"""Micro-benchmark of the GEMM kernel on the transformer's projection shapes (GPU box only).
+    python tools/gemm_bench.py [--tiles 1 2]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from msclip_amd import hip  # noqa: E402
+
+SHAPES = [  # (name, M, N, K, epilogue)
+    ("qkv  ", 65024, 2304, 768, "bias"),
+    ("out  ", 65024, 768, 768, "resid"),
+    ("fc   ", 65024, 3072, 768, "gelu"),
+    ("proj ", 65024, 768, 3072, "resid"),
+    ("txt0 ", 39424, 3072, 768, "gelu"),
+]
+
+
+def run(name, M, N, K, epi, tile, iters=20, check=False):
+    g = torch.Generator().manual_seed(0)
+    x = (torch.randn(M, K, generator=g)).to(torch.bfloat16).cuda()
+    w = (torch.randn(N, K, generator=g) * 0.03).to(torch.bfloat16).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    if epi == "resid":
+        out = torch.randn(M, N, generator=g).cuda()
+        kw = dict(bias=b, resid=out, resid_kind=hip.RESID_F32)
+    elif epi == "gelu":
+        out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        kw = dict(bias=b, act=hip.ACT_QUICKGELU)
+    else:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        kw = dict(bias=b)
+    if check:
+        ref_in = out.clone() if epi == "resid" else None
+        hip.gemm(x, w, out, tile=tile, **kw)
+        rows = torch.tensor([0, 1, 255, 256, 4095, M - 1, M // 2 + 3], device="cuda")
+        ref = x[rows].float() @ w.float().t() + b
+        if epi == "gelu":
+            ref = ref * torch.sigmoid(1.702 * ref)
+        if epi == "resid":
+            ref = ref + ref_in[rows]
+        err = (out[rows].float() - ref).abs().max().item()
+        if not os.environ.get("MSCLIP_HIP_LIB"):
+            assert err < 0.05 * max(1.0, ref.abs().max().item()), (name, tile, err)
+    for _ in range(3):
+        hip.gemm(x, w, out, tile=tile, **kw)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        hip.gemm(x, w, out, tile=tile, **kw)
+    e.record()
+    torch.cuda.synchronize()
+    us = s.elapsed_time(e) / iters * 1e3
+    return us, 2.0 * M * N * K / us / 1e6
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tiles", type=int, nargs="+", default=[1, 2])
+    args = ap.parse_args()
+    tot = {t: 0.0 for t in args.tiles}
+    for name, M, N, K, epi in SHAPES:
+        line = f"{name} M={M} N={N} K={K} {epi:5s}"
+        for t in args.tiles:
+            us, tf = run(name, M, N, K, epi, t, check=True)
+            if name.strip() != "txt0":
+                tot[t] += us
+            line += f" | tile{t}: {us:8.1f} us {tf:7.1f} TF"
+        print(line)
+    print("sum of the 4 shared-layer GEMMs (us):", {t: round(v, 1) for t, v in tot.items()})

@@ -1,0 +1,57 @@
+// Do LDS-DMA streaming and MFMA issue overlap on one CU?  Waves 0-3: MFMA only.  Waves 4-7: global_load_lds only.
+// mode bit0 = run MFMA waves, bit1 = run DMA waves, bit2 = DMA waves use plain global_load (to VGPR) instead.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+#define AS1 __attribute__((address_space(1)))
+#define AS3 __attribute__((address_space(3)))
+__global__ __launch_bounds__(512, 2) void probe(const uint16_t* X, size_t xelems, int iters, int mode, float* sink, unsigned long long* clk) {
+  const unsigned long long c0 = clock64(), w0 = wall_clock64();
+  __shared__ __attribute__((aligned(1024))) uint16_t smem[4 * 16384];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wave < 4) {
+    if (!(mode & 1)) return;
+    bf16x8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(0.001f * (lane + i)); b[i] = (__bf16)(0.002f * (lane - i)); }
+    f32x16 acc[8];
+    for (int t = 0; t < 8; ++t) for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) acc[t & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t & 7], 0, 0, 0);
+    }
+    float s = 0; for (int t = 0; t < 8; ++t) s += acc[t][0];
+    if (s == 123.456f) sink[0] = s;
+  } else {
+    if (!(mode & 2)) return;
+    const int w = wave - 4;
+    size_t off = ((size_t)blockIdx.x * 4 + w) * 4096 * 64;          // elements; each wave streams its own region
+    const size_t stride = (size_t)gridDim.x * 4 * 4096 * 64;
+    if (mode & 4) {
+      uint4 accv = make_uint4(0, 0, 0, 0);
+      for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint4 v = *(const uint4*)(X + ((off + (size_t)(it * 4 + j) * 512 + lane * 8) & (xelems - 1)));
+          accv.x ^= v.x; accv.y ^= v.y; accv.z ^= v.z; accv.w ^= v.w;
+        }
+      }
+      if (accv.x == 0x12345678) sink[1] = accv.y;
+    } else {
+      for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          __builtin_amdgcn_global_load_lds((const AS1 void*)(X + ((off + (size_t)(it * 4 + j) * 512 + lane * 8) & (xelems - 1))),
+                                           (AS3 void*)&smem[((it & 3) * 4 + w) * 2048 + j * 512], 16, 0, 0);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    (void)stride;
+  }
+  if (lane == 0 && blockIdx.x == 0 && (wave == 0 || wave == 4)) { clk[wave / 4 * 2] = clock64() - c0; clk[wave / 4 * 2 + 1] = wall_clock64() - w0; }
+}
+extern "C" int run_overlap(const void* X, size_t xelems, int iters, int mode, float* sink, unsigned long long* clk, void* st) {
+  hipLaunchKernelGGL(probe, dim3(256), dim3(512), 0, (hipStream_t)st, (const uint16_t*)X, xelems, iters, mode, sink, clk);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
