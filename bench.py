@@ -30,12 +30,12 @@ def load_schema(name):
         return [(k, tuple(s), getattr(torch, d)) for k, s, d in json.load(f)]
 
 
-def cpu_baseline(name, sd, batch=16, iters=2):
+def cpu_baseline(name, sd, batch=32, iters=3):
     """The CPU oracle (a restatement of the reference's forward; the reference's Python cannot travel) timed on this
     box's host cores: forward(image, text) + symmetric CE, fp32, on a bounded sample."""
     from msclip_amd import synth
     from oracle import msclip_oracle as O
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)     # more intra-op threads than this only adds barrier overhead on these op sizes
     torch.set_num_threads(cores)
     arch = O.arch_b32() if name.startswith("b32") else O.arch_b16()
     img, tok = synth.synth_images(batch, seed=3), synth.synth_tokens(batch, seed=4)

@@ -130,16 +130,18 @@ class KernelProbe:
 
     def __init__(self):
         self.records = []          # (start_event, end_event, units)
+        self.tags = []             # optional per-launch description
 
     def begin(self):
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
         return ev
 
-    def end(self, start, units):
+    def end(self, start, units, tag=None):
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
         self.records.append((start, ev, units))
+        self.tags.append(tag)
 
     def summary(self):
         """-> (launches, total_ms, total_units); call after a synchronize."""
@@ -191,7 +193,7 @@ def gemm(x, w, out, *, M=None, bias=None, resid=None, resid_kind=0, act=0, alpha
         k_alg = d.K if conv is None else conv[2] * (ktab_taps(ktab) if ktab is not None else 1)
         t0 = probe.begin()
         _check(lib().msclip_gemm(ctypes.byref(d), _stream()), "msclip_gemm")
-        probe.end(t0, 2.0 * d.M * d.N * k_alg)
+        probe.end(t0, 2.0 * d.M * d.N * k_alg, (d.M, d.N, d.K, k_alg, conv))
         return out
     _check(lib().msclip_gemm(ctypes.byref(d), _stream()), "msclip_gemm")
     return out
