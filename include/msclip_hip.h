@@ -97,6 +97,19 @@ int msclip_stem_conv3x3s2_dual(const void* img, int img_is_bf16, const float* w,
 int msclip_dwpool(const void* top, const float* w, void* out, int ldo, int B, int H, int W, int C, int k,
                   void* stream);
 
+/* Fused contrastive reduction: per-row (max, sum-exp) partials of scale * A[R,E] @ B[N,E]^T over `nsplit` column
+ * ranges, and the label logit diag[i] = scale * A[i] . B[label_off + i]; the [R, N] logits are never written
+ * (MFMA GEMM + online log-sum-exp; the logits themselves are M.py:3141, the loss is not in the reference).
+ * A, B: bf16, E % 16 == 0, E <= 512.  part_max / part_sum: fp32 [R, nsplit]. */
+int msclip_clip_lse_fused(const void* A, int lda, const void* B, int ldb, int R, int N, int E, float scale,
+                          int label_off, int nsplit, float* part_max, float* part_sum, float* diag, void* stream);
+
+/* out[0] = scale * sum_i (LSE_img[i] - diag[i]) + (LSE_txt[i] - diag[i]) from the partials of the image->text and
+ * text->image sweeps; lse_out (optional, fp32 [2, R]) receives the merged LSEs. */
+int msclip_clip_loss_from_partials(const float* pmax_img, const float* psum_img, const float* pmax_txt,
+                                   const float* psum_txt, const float* diag, int R, int nsplit, float scale, float* out,
+                                   float* lse_out, void* stream);
+
 /* lse[r] = log sum_n exp(logits[r, n]) over a fp32 block [R, N]. */
 int msclip_lse_rows(const float* logits, int ld, float* lse, int R, int N, void* stream);
 

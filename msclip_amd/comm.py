@@ -79,6 +79,16 @@ def gather_features(packed):
     return _all_gather_rows(packed)
 
 
+def gather_rows_async(t):
+    """Start the rank-major all-gather of t [B, ...] (RCCL runs it on the process group's own stream, i.e. beside
+    the compute stream); returns (out, work).  work is None at world size 1 (out is t itself)."""
+    if comm.world_size == 1:
+        return t, None
+    out = torch.empty((comm.world_size * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    work = dist.all_gather_into_tensor(out, t.contiguous(), async_op=True)
+    return out, work
+
+
 def local_label_offset(local_batch):
     """Global label of local row i is offset + i (rank-major gather order, comm.py:150-153)."""
     return comm.rank * local_batch

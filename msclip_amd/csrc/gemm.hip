@@ -48,7 +48,8 @@ __device__ __forceinline__ void epilogue_interior(f32x16 (&acc)[TN][TM], const m
   for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
     for (int g = 0; g < 4; ++g)
-      bv[tn][g] = bias ? *(const float4*)(bias + nw0 + fhi * 4 + tn * 32 + g * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
+      bv[tn][g] = (bias && nw0 + fhi * 4 + tn * 32 + g * 8 < a.N) ? *(const float4*)(bias + nw0 + fhi * 4 + tn * 32 + g * 8)
+                                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
   const bool direct16 = a.out_kind == 0 && a.resid_kind == 0;   // bf16 out, nothing to add after the transpose
   char* wr = stg + fr * 128;
   const int wsw = fr & 7;
@@ -82,7 +83,8 @@ __device__ __forceinline__ void epilogue_interior(f32x16 (&acc)[TN][TM], const m
       for (int i = 0; i < 4; ++i) {
         const uint4 u = *(const uint4*)(rd + i * 1024);
 #ifndef MSCLIP_ABLATE_EPI
-        *(uint4*)((bf16_t*)a.out + (size_t)(mrow0 + i * 8 + srow) * a.ldo + nw0 + sch * 8) = u;
+        if (nw0 + sch * 8 < a.N)   // N % 8 == 0 on this path
+          *(uint4*)((bf16_t*)a.out + (size_t)(mrow0 + i * 8 + srow) * a.ldo + nw0 + sch * 8) = u;
 #else
         asm volatile("" ::"v"(u.x), "v"(u.y), "v"(u.z), "v"(u.w));
 #endif
@@ -109,7 +111,9 @@ __device__ __forceinline__ void epilogue_interior(f32x16 (&acc)[TN][TM], const m
         for (int i = 0; i < 4; ++i) {
           const size_t row = (size_t)(mrow0 + i * 8 + srow);
           const int n = nw0 + tn * 32 + sch * 4;
-          if (a.resid_kind == 1) {
+          if (n >= a.N) {
+            rv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+          } else if (a.resid_kind == 1) {
             rv[i] = *(const float4*)((const float*)a.resid + row * a.ldr + n);
           } else if (a.resid_kind == 2) {
             const uint2 u = *(const uint2*)((const bf16_t*)a.resid + row * a.ldr + n);
@@ -127,7 +131,8 @@ __device__ __forceinline__ void epilogue_interior(f32x16 (&acc)[TN][TM], const m
           const size_t row = (size_t)(mrow0 + i * 8 + srow);
           const int n = nw0 + tn * 32 + sch * 4;
 #ifndef MSCLIP_ABLATE_EPI
-          if (a.out_kind == 1) {
+          if (n >= a.N) {
+          } else if (a.out_kind == 1) {
             *(float4*)((float*)a.out + row * a.ldo + n) = v;
           } else {
             uint2 o;
@@ -414,7 +419,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const msclip_gemm
     landed = true;
 
     // ---- epilogue
-    if (vec && plain_rows && cm0 + BM <= a.M && cn0 + BN <= a.N)
+    if (vec && plain_rows && cm0 + BM <= a.M && (cn0 + BN <= a.N || !(a.N & 7)))
       epilogue_interior<TM, TN>(acc, a, (char*)smem[(it + 1) & 1] + wave * STG_BYTES, cm0 + wm, cn0 + wn, lane);
     else
       epilogue_generic<TM, TN>(acc, a, vec, cm0 + wm, cn0 + wn, lane);
@@ -611,7 +616,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const msclip_gemm_des
     }
 
     // Slot (sc-1) & 3 (the tile's last slab) is not read by anyone after the last [B]: it is the staging area.
-    if (vec && plain_rows && cm0 + RBM <= a.M && cn0 + RBN <= a.N)
+    if (vec && plain_rows && cm0 + RBM <= a.M && (cn0 + RBN <= a.N || !(a.N & 7)))
       epilogue_interior<TM, TN>(acc, a, (char*)smem[(sc + RSLOTS - 1) & (RSLOTS - 1)] + wave * STG_BYTES, cm0 + wm,
                                 cn0 + wn, lane);
     else

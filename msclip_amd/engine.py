@@ -148,6 +148,10 @@ class Engine:
         M = Mv + Mt
 
         def buf(*shape, dtype=bf):
+            if len(shape) == 2 and dtype == bf:        # 64 elements of finite slack behind every bf16 matrix
+                n = shape[0] * shape[1]
+                flat = torch.zeros(n + 64, dtype=dtype, device=dev)
+                return flat[:n].view(shape)
             return torch.empty(shape, dtype=dtype, device=dev)
 
         w = dict(Mv=Mv, Mt=Mt, M=M)
@@ -173,16 +177,26 @@ class Engine:
             w["eot"] = torch.empty(Bt, dtype=torch.int32, device=dev)
             w["ht"] = buf(Bt, D)
             w["ft_raw"], w["ft"] = buf(Bt, E, dtype=f32), buf(Bt, E, dtype=f32)
+        if Bi:
+            w["fvb"] = buf(Bi, E)                            # bf16 unit features: gather payload / logits operand
+        if Bt:
+            w["ftb"] = buf(Bt, E)
         if Bi and Bt and Bi == Bt:
-            w["packed"] = buf(Bi, 2, E)                      # bf16 [B, (image|text), E] for gather + logits GEMM
             w["loss"] = buf(1, dtype=f32)
+            w["diag"] = buf(Bi, dtype=f32)
         self._ws[key] = w
         return w
 
     # ------------------------------------------------------------------ pieces
-    def _conv(self, x, spec, out, B, act=hip.ACT_NONE, resid=None, out_f32=False):
-        return hip.gemm(x, spec.weight, out, M=B * spec.h_out * spec.w_out, N=spec.cout, bias=spec.bias, act=act,
-                        resid=resid, resid_kind=hip.RESID_BF16 if resid is not None else hip.RESID_NONE,
+    def _conv(self, x, spec, out, B, act=hip.ACT_NONE, resid=None):
+        rk = hip.RESID_BF16 if resid is not None else hip.RESID_NONE
+        M = B * spec.h_out * spec.w_out
+        if spec.kh == 1 and spec.kw == 1 and spec.stride == 1 and spec.pad == 0:
+            # pointwise conv on NHWC == dense GEMM with ldx = Cin.  K is padded to 64: the tail chunks of a row read
+            # the next row's (finite) activations against zero weights; activation buffers carry 64 elements of slack.
+            return hip.gemm(x, spec.weight, out, M=M, N=spec.cout, bias=spec.bias, act=act, resid=resid,
+                            resid_kind=rk, ldx=spec.cin)
+        return hip.gemm(x, spec.weight, out, M=M, N=spec.cout, bias=spec.bias, act=act, resid=resid, resid_kind=rk,
                         conv=spec.geometry(), ktab=spec.ktab)
 
     def _vision_front(self, img, w, Bi):
@@ -216,8 +230,7 @@ class Engine:
         hw = self.par_hw[j]
         hip.dwpool(w["par"][j], a["pool"], w["pool"][j], Bi, hw, hw, a["C"], a["k"])
         pw = a["pw"]
-        hip.gemm(w["pool"][j], pw.weight, w["T"], M=Bi * self.g * self.g, N=pw.cout, bias=pw.bias, conv=pw.geometry(),
-                 ktab=pw.ktab)
+        hip.gemm(w["pool"][j], pw.weight, w["T"], M=Bi * self.g * self.g, N=pw.cout, bias=pw.bias, ldx=pw.cin)
         hip.adapter_combine_ln(w["X"][:w["Mv"]], w["T"], a["dww"], a["dwb"], a["ln"].g, a["ln"].b, w["XA"], Bi,
                                self.Lv, self.g, self.usecls)
 
@@ -268,18 +281,34 @@ class Engine:
                 hip.gemm(LNO[r0:r1], bw.wfc, HID[r0:r1], bias=bw.bfc, act=hip.ACT_QUICKGELU)
                 hip.gemm(HID[r0:r1], bw.wpr, X[r0:r1], bias=bw.bpr, resid=X[r0:r1], resid_kind=hip.RESID_F32)
 
-    def _heads(self, w, Bi, Bt, norm=True):
-        packed = w.get("packed")
-        if Bi:                                                            # M.py:2685-2690, 2983
-            hip.layernorm(w["X"], self.ln_post.g, self.ln_post.b, w["hv"], Bi, row_mul=self.Lv)
-            hip.gemm(w["hv"], self.w_vproj, w["fv_raw"])
-            if norm:
-                hip.l2norm(w["fv_raw"], w["fv"], packed[:, 0] if packed is not None else None)
-        if Bt:                                                            # M.py:3057-3077
-            hip.layernorm(w["X"], self.ln_final.g, self.ln_final.b, w["ht"], Bt, row_idx=w["eot"])
-            hip.gemm(w["ht"], self.w_tproj, w["ft_raw"])
-            if norm:
-                hip.l2norm(w["ft_raw"], w["ft"], packed[:, 1] if packed is not None else None)
+    def _head_image(self, w, Bi, norm=True):                              # M.py:2685-2690, 2983
+        hip.layernorm(w["X"], self.ln_post.g, self.ln_post.b, w["hv"], Bi, row_mul=self.Lv)
+        hip.gemm(w["hv"], self.w_vproj, w["fv_raw"])
+        if norm:
+            hip.l2norm(w["fv_raw"], w["fv"], w["fvb"])
+
+    def _head_text(self, w, Bt, norm=True):                               # M.py:3057-3077
+        hip.layernorm(w["X"], self.ln_final.g, self.ln_final.b, w["ht"], Bt, row_idx=w["eot"])
+        hip.gemm(w["ht"], self.w_tproj, w["ft_raw"])
+        if norm:
+            hip.l2norm(w["ft_raw"], w["ft"], w["ftb"])
+
+    def _heads(self, w, Bi, Bt, norm=True, gather=False):
+        """Projection heads.  With gather=True the image features' all-gather is started as soon as they exist and
+        runs on RCCL's stream while the text head computes (returns the gathered operands and the work handles)."""
+        allI = allT = wi = wt = None
+        if Bi:
+            self._head_image(w, Bi, norm)
+            if gather:
+                allI, wi = C.gather_rows_async(w["fvb"])
+        if Bt:
+            self._head_text(w, Bt, norm)
+            if gather:
+                allT, wt = C.gather_rows_async(w["ftb"])
+        for h in (wi, wt):
+            if h is not None:
+                h.wait()                                                  # compute stream waits; the host does not
+        return allI, allT
 
     # ------------------------------------------------------------------ public
     def _check_img(self, img):
@@ -298,8 +327,9 @@ class Engine:
             raise ValueError(f"expected tokens [B, {self.Lt}], got {tuple(tok.shape)}")
         return tok.to(torch.int64).contiguous()
 
-    def run(self, img=None, tok=None, norm=True):
-        """Both towers (either may be None) up to the (optionally L2-normalised) features; returns the workspace."""
+    def run(self, img=None, tok=None, norm=True, gather=False):
+        """Both towers (either may be None) up to the (optionally L2-normalised) features; returns the workspace
+        (plus the gathered bf16 features under "allI"/"allT" when gather=True)."""
         with torch.cuda.device(self.dev):
             Bi = img.shape[0] if img is not None else 0
             Bt = tok.shape[0] if tok is not None else 0
@@ -309,7 +339,9 @@ class Engine:
             if Bt:
                 self._text_front(self._check_tok(tok), w, Bt)
             self._blocks(w, Bi, Bt)
-            self._heads(w, Bi, Bt, norm)
+            allI, allT = self._heads(w, Bi, Bt, norm, gather)
+            if gather:
+                w["allI"], w["allT"] = allI, allT
             return w
 
     def encode_image(self, img, norm=True):
@@ -323,35 +355,38 @@ class Engine:
     def _gathered(self, img, tok, gather):
         if img.shape[0] != tok.shape[0]:
             raise ValueError("forward(image, text) needs the same number of images and captions")
-        w = self.run(img, tok)
-        packed = w["packed"]
-        allp = C.gather_features(packed) if gather else packed
-        return w, packed, allp
+        w = self.run(img, tok, gather=True) if gather else self.run(img, tok)
+        if gather:
+            return w, w["allI"], w["allT"]
+        return w, w["fvb"], w["ftb"]
 
     def forward_logits(self, img, tok, gather=True):
         """Reference-faithful full N x N logits on every rank (M.py:3136-3141)."""
-        w, packed, allp = self._gathered(img, tok, gather)
-        n = allp.shape[0]
+        w, allI, allT = self._gathered(img, tok, gather)
+        n = allI.shape[0]
         out = torch.empty(n, n, dtype=torch.float32, device=self.dev)
-        hip.gemm(allp[:, 0], allp[:, 1], out, alpha=self.logit_scale_exp)
+        hip.gemm(allI, allT, out, alpha=self.logit_scale_exp)
         return out
 
     def forward_loss(self, img, tok, gather=True):
-        """Symmetric CE over the global batch from the LOCAL row and column blocks only (SURVEY.md s8e option B):
-        rows = s*I_loc@T_all^T, cols = s*T_loc@I_all^T, row-LSE of each, diagonal from rows; partial sums are
+        """Symmetric CE over the global batch from the LOCAL row and column blocks only (SURVEY.md s8e option B),
+        each as one fused MFMA GEMM + online log-sum-exp sweep (no logits block is written): image rows against all
+        captions, caption rows against all images, label logit from the first sweep; the per-rank partial sums are
         all-reduced.  Identical to 0.5*(CE(logits)+CE(logits^T)) of the full matrix."""
-        w, packed, allp = self._gathered(img, tok, gather)
-        B, n = packed.shape[0], allp.shape[0]
+        w, allI, allT = self._gathered(img, tok, gather)
+        B, n = w["fvb"].shape[0], allI.shape[0]
         world = n // B
-        rows = torch.empty(B, n, dtype=torch.float32, device=self.dev)
-        cols = torch.empty(B, n, dtype=torch.float32, device=self.dev)
-        lse = torch.empty(2, B, dtype=torch.float32, device=self.dev)
-        hip.gemm(packed[:, 0], allp[:, 1], rows, alpha=self.logit_scale_exp)
-        hip.gemm(packed[:, 1], allp[:, 0], cols, alpha=self.logit_scale_exp)
-        hip.lse_rows(rows, lse[0])
-        hip.lse_rows(cols, lse[1])
+        ntile = (n + 31) // 32
+        nsplit = max(1, min(ntile, 64, 2048 // max(1, (B + 31) // 32)))
+        key = ("lse", B, nsplit)
+        if key not in w:
+            w[key] = torch.empty(4, B, nsplit, dtype=torch.float32, device=self.dev)
+        part = w[key]
         off = C.local_label_offset(B) if world > 1 else 0
-        hip.clip_loss_partial(lse[0], lse[1], rows, off, 1.0 / (2.0 * n), w["loss"])
+        s = self.logit_scale_exp
+        hip.clip_lse_fused(w["fvb"], allT, s, off, nsplit, part[0], part[1], w["diag"])
+        hip.clip_lse_fused(w["ftb"], allI, s, off, nsplit, part[2], part[3], w["diag"])
+        hip.clip_loss_from_partials(part[0], part[1], part[2], part[3], w["diag"], 1.0 / (2.0 * n), w["loss"])
         loss = w["loss"].clone()
         if world > 1:
             dist.all_reduce(loss)

@@ -18,7 +18,8 @@ INT_MAX = 2 ** 31 - 1
 EXPORTS = (
     "msclip_gemm", "msclip_attention", "msclip_layernorm", "msclip_embed_tokens", "msclip_fill_cls",
     "msclip_adapter_combine_ln", "msclip_l2norm", "msclip_stem_conv3x3s2_dual", "msclip_dwpool",
-    "msclip_lse_rows", "msclip_clip_loss_partial", "msclip_abi_version", "msclip_build_arch",
+    "msclip_lse_rows", "msclip_clip_loss_partial", "msclip_clip_lse_fused", "msclip_clip_loss_from_partials",
+    "msclip_abi_version", "msclip_build_arch",
 )
 
 
@@ -77,6 +78,8 @@ def lib():
         L.msclip_dwpool.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
         L.msclip_lse_rows.argtypes = [vp, ci, vp, ci, ci, vp]
         L.msclip_clip_loss_partial.argtypes = [vp, vp, vp, ci, ci, ci, cf, vp, vp]
+        L.msclip_clip_lse_fused.argtypes = [vp, ci, vp, ci, ci, ci, ci, cf, ci, ci, vp, vp, vp, vp]
+        L.msclip_clip_loss_from_partials.argtypes = [vp, vp, vp, vp, vp, ci, ci, cf, vp, vp, vp]
         L.msclip_abi_version.restype = ci
         L.msclip_build_arch.restype = ctypes.c_char_p
         for name in EXPORTS:
@@ -277,3 +280,18 @@ def clip_loss_partial(lse_img, lse_txt, img_rows, label_off, scale, out):
     R = img_rows.shape[0]
     _check(lib().msclip_clip_loss_partial(_p(lse_img), _p(lse_txt), _p(img_rows), img_rows.stride(0), label_off, R,
                                           scale, _p(out), _stream()), "msclip_clip_loss_partial")
+
+
+def clip_lse_fused(a, b, scale, label_off, nsplit, part_max, part_sum, diag):
+    """Partials of logsumexp_n(scale * a @ b^T) per row of a (bf16 [R, E] vs bf16 [N, E]) + the label logits."""
+    _bf16(a)
+    _bf16(b)
+    R, E = a.shape
+    _check(lib().msclip_clip_lse_fused(_p(a), a.stride(0), _p(b), b.stride(0), R, b.shape[0], E, scale, label_off,
+                                       nsplit, _p(part_max), _p(part_sum), _p(diag), _stream()), "msclip_clip_lse_fused")
+
+
+def clip_loss_from_partials(pm_i, ps_i, pm_t, ps_t, diag, scale, out, lse_out=None):
+    R, nsplit = pm_i.shape
+    _check(lib().msclip_clip_loss_from_partials(_p(pm_i), _p(ps_i), _p(pm_t), _p(ps_t), _p(diag), R, nsplit, scale,
+                                                _p(out), _p(lse_out), _stream()), "msclip_clip_loss_from_partials")

@@ -32,6 +32,10 @@ def _worker(rank, world, port, q):
     local = feats[rank * 4:(rank + 1) * 4].contiguous()
     allp = C.gather_features(local)
     res["packed_ok"] = bool(torch.equal(allp, feats))
+    out_i, work_i = C.gather_rows_async(local[:, 0].contiguous())      # per-modality async gathers (engine path)
+    out_t, work_t = C.gather_rows_async(local[:, 1].contiguous())
+    work_i.wait(); work_t.wait()
+    res["async_ok"] = bool(torch.equal(out_i, feats[:, 0]) and torch.equal(out_t, feats[:, 1]))
     s = 14.285
     rows = s * local[:, 0] @ allp[:, 1].t()
     cols = s * local[:, 1] @ allp[:, 0].t()
@@ -56,7 +60,7 @@ def test_two_rank_gather_and_sharded_loss():
     ref = np.load(os.path.join(GOLDEN, "gather_2rank.npz"))
     np.testing.assert_array_equal(res["gathered"], ref["gathered"])      # same values/order as the reference's gather
     np.testing.assert_array_equal(res["grad"], ref["grad_rank0"])        # gradient only through the local slice
-    assert res["rank"] == 0 and res["world"] == 2 and res["off"] == 0 and res["packed_ok"]
+    assert res["rank"] == 0 and res["world"] == 2 and res["off"] == 0 and res["packed_ok"] and res["async_ok"]
     assert abs(res["loss_sharded"] - res["loss_full"]) < 1e-5
 
 

@@ -261,6 +261,32 @@ def test_lse_and_loss(gpu_device):
     close(l3, torch.logsumexp(odd, 1), 1e-4)
 
 
+@pytest.mark.parametrize("R,N,off,nsplit", [(24, 72, 48, 3), (512, 512, 0, 16), (100, 333, 200, 5), (32, 8192, 4096, 64)])
+def test_fused_lse_and_loss(gpu_device, R, N, off, nsplit):
+    """MFMA GEMM + online log-sum-exp (no logits written) vs logsumexp of the explicit fp32 logits."""
+    E, scale = 512, 14.285
+    a = F.normalize(rnd(R, E, seed=50), dim=-1).to(BF)
+    b = F.normalize(rnd(N, E, seed=51), dim=-1).to(BF)
+    a2 = F.normalize(rnd(R, E, seed=52), dim=-1).to(BF)
+    part = torch.full((4, R, nsplit), float("nan"), dtype=torch.float32, device="cuda")
+    diag = torch.full((R,), float("nan"), dtype=torch.float32, device="cuda")
+    hip.clip_lse_fused(a, b, scale, off, nsplit, part[0], part[1], diag)
+    lg = scale * a.float() @ b.float().t()
+    lse = torch.logsumexp(lg, 1)
+    got = part[0].max(1).values + torch.log((part[1] * torch.exp(part[0] - part[0].max(1, keepdim=True).values)).sum(1))
+    close(got, lse, 2e-3)
+    close(diag, lg[torch.arange(R), off + torch.arange(R)], 2e-3)
+    diag2 = torch.empty_like(diag)
+    hip.clip_lse_fused(a2, b, scale, off, nsplit, part[2], part[3], diag2)
+    out = torch.empty(1, dtype=torch.float32, device="cuda")
+    lse_out = torch.empty(2, R, dtype=torch.float32, device="cuda")
+    hip.clip_loss_from_partials(part[0], part[1], part[2], part[3], diag, 1.0 / (2 * N), out, lse_out)
+    lg2 = scale * a2.float() @ b.float().t()
+    ref = ((lse - diag) + (torch.logsumexp(lg2, 1) - diag)).sum() / (2 * N)
+    close(out[0], ref, 2e-3)
+    close(lse_out[1], torch.logsumexp(lg2, 1), 2e-3)
+
+
 def test_bad_arguments_are_rejected(gpu_device):
     x, w = rnd(8, 60, dtype=BF), rnd(8, 60, dtype=BF)             # K not a multiple of 64
     with pytest.raises(hip.HipError):
