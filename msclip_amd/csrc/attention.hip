@@ -43,6 +43,126 @@ __global__ __launch_bounds__(WPB * 64) void attn_kernel(const bf16_t* __restrict
   const bf16_t* kbase = qbase + H * 64;
   const bf16_t* vbase = qbase + 2 * H * 64;
 
+  const int fr = lane & 31, fhi = lane >> 5;
+
+  if constexpr (NT <= 3) {
+    // ---- Short sequences: EVERY global load of this (sample, head) is issued up front (V rows, then all Q and K
+    // fragments), so the wave pays one memory round trip instead of one per tile; V is transposed into LDS while
+    // the Q/K fragments are still in flight, and the rest runs from registers / LDS.
+    constexpr int NVI = KP / 8;
+    uint4 vreg[NVI];
+    {
+      const int c = lane & 7;
+#pragma unroll
+      for (int i = 0; i < NVI; ++i) {
+        const int key = i * 8 + (lane >> 3);
+        vreg[i] = key < L ? *(const uint4*)(vbase + (size_t)key * ldq + c * 8) : make_uint4(0, 0, 0, 0);
+      }
+    }
+    bf16x8 qf[NT][4], kf[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int row = min(t * 32 + fr, L - 1);       // clamped: padded queries are never stored, padded keys masked
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        qf[t][kk] = *(const bf16x8*)(qbase + (size_t)row * ldq + (kk * 2 + fhi) * 8);
+        kf[t][kk] = *(const bf16x8*)(kbase + (size_t)row * ldq + (kk * 2 + fhi) * 8);
+      }
+    }
+    {
+      const int c = lane & 7;
+#pragma unroll
+      for (int i = 0; i < NVI; ++i) {
+        const int key = i * 8 + (lane >> 3);
+        const int w = key & 15;
+        const int slot = (key & ~15) + (((w >> 2) & 1) << 3) + (w & 3) + ((w >> 3) << 2);
+        bf16_t* dst = vt + (c * 8) * KPS + slot;
+        const uint4 u = vreg[i];
+        dst[0 * KPS] = (bf16_t)(u.x & 0xffff); dst[1 * KPS] = (bf16_t)(u.x >> 16);
+        dst[2 * KPS] = (bf16_t)(u.y & 0xffff); dst[3 * KPS] = (bf16_t)(u.y >> 16);
+        dst[4 * KPS] = (bf16_t)(u.z & 0xffff); dst[5 * KPS] = (bf16_t)(u.z >> 16);
+        dst[6 * KPS] = (bf16_t)(u.w & 0xffff); dst[7 * KPS] = (bf16_t)(u.w >> 16);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+#pragma unroll
+    for (int qt = 0; qt < NT; ++qt) {
+      if (qt * 32 < L) {
+        const int nkt = CAUSAL ? (qt + 1) : NT;
+        f32x16 s[NT];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+          if (kt < nkt && kt * 32 < L) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+              s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][kk], qf[qt][kk], s[kt], 0, 0, 0);
+          }
+        }
+        const int q = qt * 32 + fr;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
+            const bool ok = key < L && (!CAUSAL || key <= q) && kt < nkt;
+            s[kt][r] = ok ? s[kt][r] : -INFINITY;
+            mx = fmaxf(mx, s[kt][r]);
+          }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float p = __expf(s[kt][r] - mx);
+            s[kt][r] = p;
+            sum += p;
+          }
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.f / sum;
+        f32x16 o[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+          if (kt < nkt && kt * 32 < L) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+              bf16x8 pf;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) pf[e] = (__bf16)s[kt][half * 8 + e];
+              const int st = kt * 2 + half;
+#pragma unroll
+              for (int dt = 0; dt < 2; ++dt) {
+                const bf16x8 vf = *(const bf16x8*)(vt + (dt * 32 + fr) * KPS + st * 16 + fhi * 8);
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
+              }
+            }
+          }
+        }
+        if (q < L) {
+          bf16_t* orow = out + (row0 + q) * ldo + h * 64;
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              uint2 v;
+              v.x = pack_bf16x2(o[dt][g * 4 + 0] * inv, o[dt][g * 4 + 1] * inv);
+              v.y = pack_bf16x2(o[dt][g * 4 + 2] * inv, o[dt][g * 4 + 3] * inv);
+              *(uint2*)(orow + dt * 32 + g * 8 + fhi * 4) = v;
+            }
+        }
+      }
+    }
+    return;
+  }
+
   // ---- V -> LDS, transposed and slot-permuted; padded keys are zero
   {
     const int c = lane & 7;  // d chunk (8 values)
@@ -62,8 +182,6 @@ __global__ __launch_bounds__(WPB * 64) void attn_kernel(const bf16_t* __restrict
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes done (wave-private region)
   __builtin_amdgcn_wave_barrier();
-
-  const int fr = lane & 31, fhi = lane >> 5;
 
   for (int qt = 0; qt < NT; ++qt) {
     if (qt * 32 >= L) break;

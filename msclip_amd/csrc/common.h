@@ -52,6 +52,17 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Buffer-addressed LDS-DMA piece (buffer_load_dwordx4 ... lds): SGPR descriptor + 32-bit per-lane byte offset +
+// scalar byte offset.  Measured on MI355X (tools/probes/overlap_probe): beside a saturated MFMA stream this form
+// costs the MFMA waves nothing (1738 TF vs 1650 alone) while global_load_lds with 64-bit lane addresses drops them
+// to 1295 TF -- the address VALU work and operands compete for the SIMD's issue slots.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, void* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (AS3 void*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+
 // One 1-KiB LDS-DMA piece: every lane supplies its own 16-byte global source, the
 // destination is the wave-uniform LDS base + lane*16 (cdna_hip_programming.md s5).
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {

@@ -152,11 +152,22 @@ class KernelProbe:
         return len(self.records), ms, sum(u for _, _, u in self.records)
 
 
-_gemm_probe = {0: None, 1: None}   # per loader mode (0 dense, 1 implicit conv)
+_gemm_probe = {}   # kernel variant -> KernelProbe
 
 
-def set_gemm_probe(mode, probe):
-    _gemm_probe[mode] = probe
+def gemm_variant(mode, M, N, tile=0):
+    """Which kernel msclip_gemm dispatches to (mirror of the rule in csrc/gemm.hip): 'ring' = gemm_ring_kernel
+    (dense streaming 256x256), 'conv256'/'conv128' = gemm_kernel<1,...>, 'dense256'/'dense128' = gemm_kernel<0,...>."""
+    big_tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    big = tile >= 2 or (tile == 0 and N >= 192 and big_tiles >= 128)
+    if mode == 0:
+        return "ring" if (big and tile != 3) else ("dense256" if big else "dense128")
+    return "conv256" if big else "conv128"
+
+
+def set_gemm_probe(variant, probe):
+    """variant: a gemm_variant() name, or 0 / 1 for every dense / every implicit-conv launch."""
+    _gemm_probe[variant] = probe
 
 
 ACT_NONE, ACT_QUICKGELU, ACT_RELU = 0, 1, 2
@@ -191,7 +202,7 @@ def gemm(x, w, out, *, M=None, bias=None, resid=None, resid_kind=0, act=0, alpha
     d.alpha = alpha
     d.rpg, d.radd, d.roff = rpg, radd, roff
     d.tile = tile
-    probe = _gemm_probe[d.mode]
+    probe = _gemm_probe.get(d.mode) or _gemm_probe.get(gemm_variant(d.mode, d.M, d.N, tile)) if _gemm_probe else None
     if probe is not None:
         k_alg = d.K if conv is None else conv[2] * (ktab_taps(ktab) if ktab is not None else 1)
         t0 = probe.begin()

@@ -16,6 +16,18 @@ __global__ __launch_bounds__(512, 2) void probe(const uint16_t* X, size_t xelems
     for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(0.001f * (lane + i)); b[i] = (__bf16)(0.002f * (lane - i)); }
     f32x16 acc[8];
     for (int t = 0; t < 8; ++t) for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    if (mode & 32) {
+      // GEMM-like: 12 ds_read_b128 per 16 MFMAs, operands really come from LDS (other waves' DMA target area)
+      const uint16_t* lp = smem + (lane & 31) * 32 + ((lane >> 5) ^ ((lane >> 3) & 3)) * 8;
+      for (int it = 0; it < iters; ++it) {
+        bf16x8 f[12];
+#pragma unroll
+        for (int r = 0; r < 12; ++r) f[r] = *(const bf16x8*)(lp + ((it + r) & 15) * 1024 + (r & 3) * 16384);
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+          acc[t & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[t % 12], f[(t + 5) % 12], acc[t & 7], 0, 0, 0);
+      }
+    } else
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
       for (int t = 0; t < 16; ++t) acc[t & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t & 7], 0, 0, 0);
@@ -37,6 +49,29 @@ __global__ __launch_bounds__(512, 2) void probe(const uint16_t* X, size_t xelems
         }
       }
       if (accv.x == 0x12345678) sink[1] = accv.y;
+    } else if (mode & 8) {
+      // buffer form: SGPR descriptor + 32-bit per-lane offset + scalar offset
+      const uint16_t* base = X + (size_t)((blockIdx.x * 4 + w) & 127) * (1 << 20);
+      __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+      const unsigned voff = lane * 16;
+      for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (AS3 void*)&smem[((it & 3) * 4 + w) * 2048 + j * 512], 16, voff,
+                                               (unsigned)(((it & 255) * 4 + j) * 1024), 0, 0);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (mode & 16) {
+      const uint16_t* base = X + (size_t)((blockIdx.x * 4 + w) & 127) * (1 << 20);
+      for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          __builtin_amdgcn_global_load_lds((const AS1 void*)(base + (size_t)(((it & 255) * 4 + j) * 512) + lane * 8),
+                                           (AS3 void*)&smem[((it & 3) * 4 + w) * 2048 + j * 512], 16, 0, 0);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
       for (int it = 0; it < iters; ++it) {
 #pragma unroll

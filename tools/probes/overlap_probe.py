@@ -7,7 +7,7 @@ X = torch.randn(2 ** 27, device="cuda").to(torch.bfloat16)   # 256 MiB, power-of
 clk = torch.zeros(4, dtype=torch.int64, device="cuda")
 sink = torch.zeros(4, device="cuda")
 iters = 2000
-for mode, name in [(1, "MFMA only"), (2, "LDS-DMA only"), (3, "MFMA + LDS-DMA"), (6, "plain loads only"), (7, "MFMA + plain loads")]:
+for mode, name in [(1, "MFMA only"), (2, "LDS-DMA only"), (3, "MFMA + LDS-DMA"), (6, "plain loads only"), (7, "MFMA + plain loads"), (10, "buffer LDS-DMA only"), (11, "MFMA + buffer LDS-DMA"), (18, "global LDS-DMA L2-res only"), (19, "MFMA + global LDS-DMA L2-res"), (33, "MFMA+ds_read only"), (43, "MFMA+ds_read + buffer DMA")]:
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     lib.run_overlap(X.data_ptr(), X.numel(), iters, mode, sink.data_ptr(), clk.data_ptr(), st)
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
