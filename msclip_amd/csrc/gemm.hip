@@ -447,6 +447,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const msclip_gemm
 // 7.8 GB/s-per-TF DMA stream this tile shape needs, issued from independent waves, reach ~945 TF.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int RBK = 32, RSLOTS = 4, RBM = 256, RBN = 256;
+#ifdef MSCLIP_ABLATE_BARRIER   // probe builds only (timing without workgroup synchronisation; results are garbage)
+#define RING_BARRIER() asm volatile("" ::: "memory")
+#else
+#define RING_BARRIER() __builtin_amdgcn_s_barrier()
+#endif
 
 __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const msclip_gemm_desc a) {
   constexpr int NW = 8, TM = 4, TN = 2;
@@ -463,6 +468,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const msclip_gemm_des
 
   const bf16_t* __restrict__ X = (const bf16_t*)a.X;
   const bf16_t* __restrict__ W = (const bf16_t*)a.W;
+  const bf16_t* __restrict__ Z = (const bf16_t*)a.zero;
 
   auto tile_origin = [&](int t, int& m0, int& n0) {
     const int q = ntiles >> 3, r = ntiles & 7, x = t & 7;
@@ -471,31 +477,33 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const msclip_gemm_des
     n0 = (id % nt_n) * RBN;
   };
 
-  // ---- issue side: lane owns (row = (i*8 + wave)*16 + lane/4, physical chunk = lane%4), i = 0..1 per operand.
-  // Buffer-addressed LDS-DMA: per-lane 32-bit byte offsets are fixed per tile (rows clamped into range: an
-  // out-of-range row only feeds output rows/columns that are never stored), the K position is a scalar offset.
+  // ---- issue side: lane owns (row = (i*8 + wave)*16 + lane/4, physical chunk = lane%4), i = 0..1 per operand
   const int lc = (lane & 3) ^ ((lane >> 5) | ((wave & 1) << 1));   // == pc ^ ((row >> 3) & 3)
   const int rsub = lane >> 2;
-  const __amdgpu_buffer_rsrc_t rsX = make_rsrc(X, (unsigned)min((unsigned long long)a.M * a.ldx * 2ull, 0x7fffffffull));
-  const __amdgpu_buffer_rsrc_t rsW = make_rsrc(W, (unsigned)min((unsigned long long)a.N * a.ldw * 2ull, 0x7fffffffull));
-  unsigned voff[4];             // X piece 0, X piece 1, W piece 0, W piece 1
+  const bf16_t* rowp[4];        // X piece 0, X piece 1, W piece 0, W piece 1 (nullptr = out of range -> zero page)
   int ti = blockIdx.x, kti = 0, si = 0;
   auto setup_rows = [&](int t) {
     int m0, n0;
     tile_origin(t, m0, n0);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int m = min(m0 + (i * NW + wave) * 16 + rsub, a.M - 1);
-      const int n = min(n0 + (i * NW + wave) * 16 + rsub, a.N - 1);
-      voff[i] = ((unsigned)m * (unsigned)a.ldx + lc * 8) * 2u;
-      voff[2 + i] = ((unsigned)n * (unsigned)a.ldw + lc * 8) * 2u;
+      const int m = m0 + (i * NW + wave) * 16 + rsub;
+      const int n = n0 + (i * NW + wave) * 16 + rsub;
+      rowp[i] = (m < a.M) ? X + (size_t)m * a.ldx + lc * 8 : nullptr;
+      rowp[2 + i] = (n < a.N) ? W + (size_t)n * a.ldw + lc * 8 : nullptr;
     }
   };
-  // scalar K offset + LDS slot of the NEXT slab to issue (consumed piece by piece inside the MFMA stream)
-  unsigned soff = 0;
+  // sources + LDS slot of the NEXT slab to issue (consumed piece by piece inside the MFMA stream)
+  const bf16_t* src[4];
   bf16_t* dst0 = nullptr;
   auto plan_next = [&]() {
-    soff = (ti < ntiles) ? (unsigned)kti * (RBK * 2) : 0u;   // past the end: dummy pieces keep the counts exact
+    if (ti < ntiles) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) src[j] = rowp[j] ? rowp[j] + kti * RBK : Z;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) src[j] = Z;      // past the end of the tile list: dummy pieces keep the counts exact
+    }
     dst0 = smem[si & (RSLOTS - 1)];
   };
   auto advance = [&]() {
@@ -506,8 +514,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const msclip_gemm_des
       if (ti < ntiles) setup_rows(ti);
     }
   };
-  auto issue_piece = [&](int j) {
-    blds16(j < 2 ? rsX : rsW, voff[j], soff, dst0 + (j < 2 ? 0 : RBM * RBK) + ((j & 1) * NW + wave) * 16 * RBK);
+  auto piece_dst = [&](int j) -> bf16_t* {
+    return dst0 + (j < 2 ? 0 : RBM * RBK) + ((j & 1) * NW + wave) * 16 * RBK;
   };
 
   // ---- compute side
@@ -522,7 +530,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const msclip_gemm_des
   for (int p = 0; p < 3; ++p) {   // prologue: three slabs in flight
     plan_next();
 #pragma unroll
-    for (int j = 0; j < 4; ++j) issue_piece(j);
+    for (int j = 0; j < 4; ++j) glds16(src[j], piece_dst(j));
     advance();
   }
 
@@ -538,7 +546,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const msclip_gemm_des
     for (int j = 0; j < TM; ++j) xf[set][j] = *(const bf16x8*)(xs + j * 32 * RBK + ph);
   };
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
+  RING_BARRIER();
   asm volatile("" ::: "memory");
   read_frags(0, 0, 0);
 
@@ -555,7 +563,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const msclip_gemm_des
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     if (!first_tile) {
       // every wave has finished reading its epilogue staging (slot (sc-1) & 3) before slab sc+3 is DMA'd into it
-      __builtin_amdgcn_s_barrier();
+      RING_BARRIER();
       asm volatile("" ::: "memory");
     }
     first_tile = false;
@@ -564,8 +572,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const msclip_gemm_des
       plan_next();
       // ---- [A]
       read_frags(sc & (RSLOTS - 1), 1, 1);
-      issue_piece(0);
-      issue_piece(1);
+      glds16(src[0], piece_dst(0));
+      glds16(src[1], piece_dst(1));
 #pragma unroll
       for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -585,13 +593,13 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const msclip_gemm_des
       __builtin_amdgcn_sched_barrier(0);
       // ---- [B]
       asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      RING_BARRIER();
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       // ---- [C]
       read_frags((sc + 1) & (RSLOTS - 1), 0, 0);
-      issue_piece(2);
-      issue_piece(3);
+      glds16(src[2], piece_dst(2));
+      glds16(src[3], piece_dst(3));
 #pragma unroll
       for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -652,9 +660,7 @@ extern "C" int msclip_gemm(const msclip_gemm_desc* d, void* stream) {
   const long long big_tiles = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256);
   const bool big = d->tile >= 2 || (d->tile == 0 && d->N >= 192 && big_tiles >= 128);
   if (d->mode == 0) {
-    const bool fits32 = (unsigned long long)d->M * d->ldx * 2ull < 0x7fffffffull &&
-                        (unsigned long long)d->N * d->ldw * 2ull < 0x7fffffffull;   // 32-bit buffer offsets
-    if (big && d->tile != 3 && fits32) {   // streaming ring kernel (tile 3 selects the two-buffer 256x256 kernel for A/B tests)
+    if (big && d->tile != 3) {   // streaming ring kernel (tile 3 selects the two-buffer 256x256 kernel for A/B tests)
       static int ncu = 0;
       if (!ncu) {
         hipDeviceProp_t p;

@@ -12,6 +12,7 @@ build noDMA "-DMSCLIP_ABLATE_DMA" &
 build noDS "-DMSCLIP_ABLATE_DSREAD" &
 build noDMADS "-DMSCLIP_ABLATE_DMA -DMSCLIP_ABLATE_DSREAD" &
 build noWAIT "-DMSCLIP_ABLATE_DMAWAIT" &
+build noBAR "-DMSCLIP_ABLATE_BARRIER" &
 build noDMADSEPI "-DMSCLIP_ABLATE_DMA -DMSCLIP_ABLATE_DSREAD -DMSCLIP_ABLATE_EPI" &
 wait
 ls -la $OUT/*.so

@@ -10,6 +10,37 @@ __global__ __launch_bounds__(512, 2) void probe(const uint16_t* X, size_t xelems
   const unsigned long long c0 = clock64(), w0 = wall_clock64();
   __shared__ __attribute__((aligned(1024))) uint16_t smem[4 * 16384];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (mode & 64) {
+    // GEMM-like: ALL 8 waves issue MFMAs (2 per SIMD) and each interleaves 4 LDS-DMA pieces per 16 MFMAs.
+    // bit7: buffer form instead of global form.  bit8: no DMA at all (8-wave MFMA reference).
+    bf16x8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(0.001f * (lane + i)); b[i] = (__bf16)(0.002f * (lane - i)); }
+    f32x16 acc[8];
+    for (int t = 0; t < 8; ++t) for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const uint16_t* base = X + (size_t)((blockIdx.x * 8 + wave) & 127) * (1 << 20);
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+    const unsigned voff = lane * 16;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        acc[t & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t & 7], 0, 0, 0);
+        if (!(mode & 256) && (t & 3) == 3) {
+          const int j = t >> 2;
+          void* dst = &smem[((it & 3) * 8 + wave) * 2048 + j * 512];
+          if (mode & 128)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (AS3 void*)dst, 16, voff, (unsigned)(((it & 255) * 4 + j) * 1024), 0, 0);
+          else
+            __builtin_amdgcn_global_load_lds((const AS1 void*)(base + (size_t)(((it & 255) * 4 + j) * 512) + lane * 8), (AS3 void*)dst, 16, 0, 0);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float sacc = 0; for (int t = 0; t < 8; ++t) sacc += acc[t][0];
+    if (sacc == 123.456f) sink[0] = sacc;
+    if (lane == 0 && blockIdx.x == 0 && wave == 0) { clk[0] = clock64() - c0; clk[1] = wall_clock64() - w0; }
+    return;
+  }
   if (wave < 4) {
     if (!(mode & 1)) return;
     bf16x8 a, b;
