@@ -127,10 +127,15 @@ def main():
         }
         if probe is not None:
             n, kms, flops = probe.summary()
+            traffic = None      # HBM bytes per launch of the same kernel from a separate rocprofv3 --pmc run of this command
+            tpath = os.path.join(ROOT, "profiles", "r01_bench_hbm_traffic.json")
+            if B == 512 and args.model.startswith("b32") and os.path.exists(tpath):
+                with open(tpath) as f:
+                    traffic = round(json.load(f)["hbm_bytes_per_launch"])
             ach = flops / (kms * 1e-3) / 1e12
             rec["roofline"] = {"kernel": "gemm_ring_kernel (dense bf16 MFMA GEMM: all transformer projections + wide pointwise convs)",
                                "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                               "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_bench_hbm_traffic.json)",
                                "launches_per_step": n // args.steps, "avg_launch_us": round(kms / n * 1e3, 2),
                                "flops_per_launch_avg": round(flops / n / 1e9, 3), "flops_unit": "GFLOP",
                                "time_share_of_step": round(kms / (dt * 1e3), 4)}
