@@ -73,7 +73,7 @@ def synth_tensor(key, shape, dtype=torch.float32, seed=0, share_from_layer=1):
         a = r.standard_normal(shape) * (0.03 if ".c_fc." in key else 0.02)
     else:
         raise KeyError(f"no synthetic rule for {key} {shape}")
-    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64 if a.dtype == np.float64 else a.dtype)).to(dtype)
+    return torch.from_numpy(np.ascontiguousarray(a)).reshape(shape).to(dtype)
 
 
 def synth_state_dict(schema, seed=0, share_from_layer=1):

@@ -1,0 +1,117 @@
+"""Zero-shot classification driver (reference tools/zero_shot.py:122-134, 149-163, 183-310).
+
+* classifier: per class, tokenize every prompt template, encode_text, mean over templates, renormalise, stack as
+  columns -> W[embed, n_classes]                                         (zero_shot.py:122-134)
+* images: Resize(224, bicubic) -> CenterCrop(224) -> ToTensor -> Normalize(ImageNet mean/std), done with PIL + numpy
+  (torchvision is not installed; the reference uses lib/config/default.py:84-85 statistics)   (zero_shot.py:202-207)
+* logits = 100 * f_img @ W, top-k accuracy                                (zero_shot.py:265-266, 149-163)
+* ImageFolder layout val/<wnid>/*.JPEG, class index = sorted directory names (DATASET/DATA.md:5-14)
+
+Class names and prompt templates are DATA the caller supplies (the reference keeps ImageNet's 1000 names and 80
+templates in lib/dataset/prompts/constants.py); `load_prompts` reads such a python/json file.
+"""
+import json
+import os
+import runpy
+
+import numpy as np
+import torch
+
+from . import hip
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+IMG_EXT = (".jpg", ".jpeg", ".png", ".bmp", ".ppm", ".webp")
+
+
+def load_prompts(path):
+    """-> (classnames, templates).  Accepts a json {"classes": [...], "templates": [...]} or a python constants file
+    defining IMAGENET_CLASSES / IMAGENET_DEFAULT_TEMPLATES (the reference's constants.py layout)."""
+    if path.endswith(".json"):
+        with open(path) as f:
+            d = json.load(f)
+        return list(d["classes"]), list(d["templates"])
+    ns = runpy.run_path(path)
+    classes = ns.get("IMAGENET_CLASSES") or ns["ALL_CLASSES_DICT"]["imagenet"]
+    templates = ns.get("IMAGENET_DEFAULT_TEMPLATES") or ns["ALL_TEMPLATES_DICT"]["imagenet"]
+    return list(classes), [t if isinstance(t, str) else t("{}") for t in templates]
+
+
+@torch.no_grad()
+def zeroshot_classifier(model, tokenizer, classnames, templates, device="cuda", classes_per_batch=8):
+    """W[embed, n_classes]; several classes are encoded per encode_text call (the reference does one class at a time)."""
+    cols = []
+    n_t = len(templates)
+    for c0 in range(0, len(classnames), classes_per_batch):
+        group = classnames[c0:c0 + classes_per_batch]
+        texts = [t.format(c) for c in group for t in templates]
+        emb = model.encode_text(tokenizer(texts).to(device)).float()          # unit rows
+        emb = emb.reshape(len(group), n_t, -1).mean(dim=1)
+        cols.append(emb / emb.norm(dim=-1, keepdim=True))
+    return torch.cat(cols, 0).t().contiguous()
+
+
+def accuracy(output, target, topk=(1,)):
+    """Top-k hits in percent (zero_shot.py:149-163)."""
+    maxk = max(topk)
+    pred = output.topk(maxk, 1, True, True)[1].t()
+    correct = pred.eq(target.reshape(1, -1).expand_as(pred))
+    return [correct[:k].reshape(-1).float().sum().item() * 100.0 / target.shape[0] for k in topk]
+
+
+def preprocess(img, size=224, mean=IMAGENET_MEAN, std=IMAGENET_STD):
+    """PIL image -> float32 [3, size, size]: shorter side to `size` (bicubic), centre crop, /255, normalise."""
+    from PIL import Image
+    img = img.convert("RGB")
+    w, h = img.size
+    if w <= h:
+        nw, nh = size, int(size * h / w)
+    else:
+        nw, nh = int(size * w / h), size
+    img = img.resize((nw, nh), Image.BICUBIC)
+    left, top = int(round((nw - size) / 2.0)), int(round((nh - size) / 2.0))
+    img = img.crop((left, top, left + size, top + size))
+    x = np.asarray(img, dtype=np.float32) / 255.0
+    x = (x - np.asarray(mean, dtype=np.float32)) / np.asarray(std, dtype=np.float32)
+    return torch.from_numpy(np.ascontiguousarray(x.transpose(2, 0, 1)))
+
+
+def image_folder(root):
+    """[(path, class_index)], class directories sorted like torchvision's ImageFolder."""
+    classes = sorted(d for d in os.listdir(root) if os.path.isdir(os.path.join(root, d)))
+    items = []
+    for ci, c in enumerate(classes):
+        for dp, _, files in sorted(os.walk(os.path.join(root, c))):
+            for f in sorted(files):
+                if f.lower().endswith(IMG_EXT):
+                    items.append((os.path.join(dp, f), ci))
+    return classes, items
+
+
+@torch.no_grad()
+def evaluate(model, tokenizer, val_root, classnames, templates, batch_size=32, device="cuda", max_images=None,
+             size=224, log=print):
+    """Full zero-shot run: returns dict(top1, top5, n).  Prints the reference's final log line format."""
+    from PIL import Image
+    hip.require_gpu()
+    dirs, items = image_folder(val_root)
+    if len(dirs) != len(classnames):
+        raise ValueError(f"{len(dirs)} class directories under {val_root} but {len(classnames)} class names")
+    if max_images:
+        step = max(1, len(items) // max_images)
+        items = items[::step][:max_images]
+    W = zeroshot_classifier(model, tokenizer, classnames, templates, device)
+    hits1 = hits5 = n = 0
+    for i in range(0, len(items), batch_size):
+        chunk = items[i:i + batch_size]
+        x = torch.stack([preprocess(Image.open(p), size) for p, _ in chunk]).to(device)
+        y = torch.tensor([c for _, c in chunk], device=device)
+        logits = 100.0 * model.encode_image(x).float() @ W
+        a1, a5 = accuracy(logits, y, (1, min(5, logits.shape[1])))
+        hits1 += a1 * len(chunk) / 100.0
+        hits5 += a5 * len(chunk) / 100.0
+        n += len(chunk)
+    top1, top5 = 100.0 * hits1 / max(n, 1), 100.0 * hits5 / max(n, 1)
+    log("=> imagenet% TEST: Error@1 {:.3f}%\taccuracy@1 {:.3f}%\taccuracy@5 {:.3f}%\t({} images)".format(
+        100.0 - top1, top1, top5, n))
+    return dict(top1=top1, top5=top5, n=n)

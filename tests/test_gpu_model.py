@@ -123,3 +123,47 @@ def test_inputs_validated(gpu_device):
         m.encode_text(torch.zeros(1, 60, dtype=torch.long, device="cuda"))
     with pytest.raises(hip.HipUnavailable):
         m.encode_text(torch.zeros(1, 77, dtype=torch.long))
+
+
+def test_zeroshot_pipeline_against_oracle(gpu_device, tmp_path):
+    """BASELINE config C1 plumbing (zero-shot driver) on generated images: classifier columns, 100*f@W logits and
+    the top-1 decisions must follow the oracle's (reference tools/zero_shot.py:122-134, 265-266)."""
+    import zlib
+    from PIL import Image
+    from msclip_amd import zeroshot
+    name, arch = "b32-yfcc-msclips", O.arch_b32()
+    m, sd = model_for(name), synth_sd(name)
+
+    class FakeTok:                                       # deterministic stand-in for the BPE (vocab file not on this box)
+        def __call__(self, texts, context_length=77):
+            if isinstance(texts, str):
+                texts = [texts]
+            out = torch.zeros(len(texts), context_length, dtype=torch.long)
+            for i, t in enumerate(texts):
+                r = np.random.default_rng(zlib.crc32(t.encode()))
+                n = int(r.integers(3, 20))
+                out[i, 0], out[i, 1:1 + n], out[i, 1 + n] = 49406, torch.from_numpy(r.integers(1, 49000, n)), 49407
+            return out
+
+    tok = FakeTok()
+    classes = ["tench", "goldfish", "shark"]
+    templates = ["a photo of a {}.", "a bad photo of a {}.", "art of the {}.", "itap of a {}."]
+    W = zeroshot.zeroshot_classifier(m, tok, classes, templates, classes_per_batch=2)
+    with torch.no_grad():
+        Wref = O.zeroshot_classifier([tok([t.format(c) for t in templates]) for c in classes], sd, arch)
+    assert W.shape == (512, 3) and (W.float().cpu() - Wref).abs().max().item() <= FEAT_TOL
+    rng = np.random.default_rng(5)
+    for ci, c in enumerate(["n01", "n02", "n03"]):
+        (tmp_path / "val" / c).mkdir(parents=True)
+        for k in range(3):
+            Image.fromarray(rng.integers(0, 256, (240 + 10 * k, 260, 3), dtype=np.uint8)).save(tmp_path / "val" / c / f"{k}.png")
+    res = zeroshot.evaluate(m, tok, str(tmp_path / "val"), classes, templates, batch_size=4, log=lambda s: None)
+    assert res["n"] == 9 and 0.0 <= res["top1"] <= 100.0
+    _, items = zeroshot.image_folder(str(tmp_path / "val"))
+    x = torch.stack([zeroshot.preprocess(Image.open(p)) for p, _ in items])
+    with torch.no_grad():
+        ref_logits = 100.0 * O.encode_image(x, sd, arch) @ Wref
+    got_logits = 100.0 * m.encode_image(x.cuda()).float().cpu() @ W.float().cpu()
+    assert (got_logits - ref_logits).abs().max().item() <= 0.3        # stated zero-shot logit tolerance (x100 scale)
+    y = torch.tensor([c for _, c in items])
+    assert abs(res["top1"] - zeroshot.accuracy(ref_logits, y)[0]) <= 100.0 / 9 + 1e-6
