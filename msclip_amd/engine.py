@@ -344,6 +344,39 @@ class Engine:
                 w["allI"], w["allT"] = allI, allT
             return w
 
+    # ------------------------------------------------------------------ hipGraph replay
+    def graph(self, Bi=0, Bt=0, img_dtype=torch.float32):
+        """Capture run() for a fixed (Bi, Bt) into a hipGraph (torch.cuda.CUDAGraph records the kernels the C ABI
+        launches on the capture stream).  Returns a callable replay(img=None, tok=None) -> workspace: inputs are
+        copied into static buffers, the ~230 launches of a step become one graph launch -- what matters for the
+        launch-bound small batches of the zero-shot loops (reference tools/zero_shot.py:122-134, 253-275)."""
+        key = ("graph", Bi, Bt, img_dtype)
+        if key in self._ws:
+            return self._ws[key]
+        with torch.cuda.device(self.dev):
+            simg = torch.zeros(Bi, 3, self.S, self.S, dtype=img_dtype, device=self.dev) if Bi else None
+            stok = torch.zeros(Bt, self.Lt, dtype=torch.int64, device=self.dev) if Bt else None
+            if Bt:
+                stok[:, 0], stok[:, 1] = 1, 2
+            side = torch.cuda.Stream(device=self.dev)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                      # warm-up outside capture (workspace allocation, lazy init)
+                self.run(simg, stok)
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                w = self.run(simg, stok)
+
+        def replay(img=None, tok=None):
+            if Bi:
+                simg.copy_(self._check_img(img))
+            if Bt:
+                stok.copy_(self._check_tok(tok))
+            g.replay()
+            return w
+        self._ws[key] = replay
+        return replay
+
     def encode_image(self, img, norm=True):
         w = self.run(img=img, norm=norm)
         return (w["fv"] if norm else w["fv_raw"]).clone()

@@ -167,3 +167,21 @@ def test_zeroshot_pipeline_against_oracle(gpu_device, tmp_path):
     assert (got_logits - ref_logits).abs().max().item() <= 0.3        # stated zero-shot logit tolerance (x100 scale)
     y = torch.tensor([c for _, c in items])
     assert abs(res["top1"] - zeroshot.accuracy(ref_logits, y)[0]) <= 100.0 / 9 + 1e-6
+
+
+def test_hipgraph_replay_matches_eager(gpu_device):
+    m = model_for("b32-yfcc-msclips")
+    eng = m.engine()
+    img = synth.synth_images(4, seed=61).cuda()
+    tok = synth.synth_tokens(4, seed=62).cuda()
+    w = eng.run(img, tok)
+    fi, ft = w["fv"].clone(), w["ft"].clone()
+    replay = eng.graph(4, 4)
+    w2 = replay(img, tok)
+    assert torch.equal(w2["fv"], fi) and torch.equal(w2["ft"], ft)          # same kernels, same order: bitwise equal
+    img2 = synth.synth_images(4, seed=63).cuda()
+    w3 = replay(img2, tok)
+    assert torch.equal(w3["fv"], eng.run(img2, tok)["fv"])
+    only_txt = eng.graph(0, 80)
+    t80 = synth.synth_tokens(80, seed=64).cuda()
+    assert torch.equal(only_txt(tok=t80)["ft"], eng.run(tok=t80)["ft"])
