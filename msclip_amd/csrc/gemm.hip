@@ -19,6 +19,7 @@
 //  * MFMA operands are swapped (A = W rows, B = X rows): a lane owns 4 consecutive output
 //    columns of one row; interior tiles are transposed through the just-consumed LDS slab
 //    so every global store / residual load instruction moves full 128-byte lines.
+#include <type_traits>
 #include "common.h"
 #include "../../include/msclip_hip.h"
 
@@ -630,6 +631,228 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const msclip_gemm_des
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // dummy tail pieces must land before the LDS is released
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Ping-pong kernel for the dense projections: 256 x 256 tile, 8 waves (2 x 4), K-tiles of 64.  LDS is a ring of
+// ten 16-KiB regions; a region holds one half-operand of one K-tile (128 rows x 128 B, full cache lines):
+// W rows 0-127, W rows 128-255, X rows 0-127, X rows 128-255, in that order.  One region is issued per phase
+// (2 LDS-DMA pieces per wave, buffer-addressed: SGPR descriptor + 32-bit lane offset + scalar K offset), a K-tile
+// is computed in 4 phases (one 64 x 32 quadrant of the wave's 128 x 64 block over the whole K-tile each):
+//     phase q:  [ ds_reads of the quadrant's new fragments ; 2 DMA pieces ; (q == 3: s_waitcnt vmcnt(6)) ]
+//               s_barrier ; lgkmcnt(0) ; 8 MFMAs at raised priority ; s_barrier
+// Waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave is in its memory section while the other
+// owns the MFMA pipe, and a barrier resolves under the tail of the other wave's last MFMA.
+// Region r is issued in phase r, waited for (by its issuers) in phase r+3 .. r+6 and first read in phase r+4 or
+// later -- i.e. after a barrier that follows the wait; K-tile t (regions 4t..4t+3) is computed in phases
+// 4t+7 .. 4t+10 and its ring slots are re-issued in phases 4t+10 .. 4t+13, at least two barriers after their last
+// ds_read retired.  The DMA stream runs across tile boundaries (seven regions of the next tile fly under the
+// epilogue).  Rows past M / N are out of range of the tile's buffer descriptor (read as zero).
+// ------------------------------------------------------------------------------------------------------------
+constexpr int PSLOTS = 10, PREG = 128 * 64;   // ring regions, bf16 elements per region
+
+__global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) {
+  constexpr int TM = 4, TN = 2;
+  __shared__ __attribute__((aligned(1024))) bf16_t smem[PSLOTS * PREG];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;                       // 0: leading group, 1: one barrier behind
+  const int nt_n = (a.N + 255) / 256;
+  const int nt_m = (a.M + 255) / 256;
+  const int ntiles = nt_n * nt_m;
+  const int nk = a.K / 64;
+
+  auto tile_origin = [&](int t, int& m0, int& n0) {
+    const int q = ntiles >> 3, r = ntiles & 7, x = t & 7;
+    const int id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (t >> 3);
+    m0 = (id / nt_n) * 256;
+    n0 = (id % nt_n) * 256;
+  };
+
+  // ---- issue side.  Piece p (rows 8p .. 8p+7 of a region) is issued by wave p & 7; lane -> row 8p + lane/8,
+  // physical 16-byte chunk lane%8 holds logical chunk (lane%8) ^ ((row >> 1) & 7).
+  unsigned vx[2], vw[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (wave + 8 * i) * 8 + (lane >> 3);
+    const unsigned ch = (unsigned)((lane & 7) ^ ((row >> 1) & 7)) << 4;
+    vx[i] = (unsigned)row * (unsigned)a.ldx * 2u + ch;
+    vw[i] = (unsigned)row * (unsigned)a.ldw * 2u + ch;
+  }
+  const unsigned xhalf = 128u * (unsigned)a.ldx * 2u, whalf = 128u * (unsigned)a.ldw * 2u;
+  int ti = blockIdx.x, kti = 0, islot = 0;
+  __amdgpu_buffer_rsrc_t rx, rw;
+  auto set_tile = [&](int t) {
+    if (t < ntiles) {
+      int m0, n0;
+      tile_origin(t, m0, n0);
+      const unsigned long long xb = (unsigned long long)(a.M - m0) * (unsigned long long)a.ldx * 2ull;
+      const unsigned long long wb = (unsigned long long)(a.N - n0) * (unsigned long long)a.ldw * 2ull;
+      rx = make_rsrc((const bf16_t*)a.X + (size_t)m0 * a.ldx, xb > 0xffffffffull ? 0xffffffffu : (unsigned)xb);
+      rw = make_rsrc((const bf16_t*)a.W + (size_t)n0 * a.ldw, wb > 0xffffffffull ? 0xffffffffu : (unsigned)wb);
+    } else {                                       // past the tile list: empty descriptors, the counts stay exact
+      rx = make_rsrc(a.X, 0);
+      rw = make_rsrc(a.W, 0);
+    }
+  };
+  auto issue = [&](auto jc) {                      // region j of K-tile (ti, kti) -> ring slot islot
+    constexpr int J = decltype(jc)::value;
+    bf16_t* dst = smem + islot * PREG + wave * 512;
+    const unsigned ko = (unsigned)kti * 128u;
+    if (J < 2) {
+      blds16(rw, vw[0], ko + (J & 1) * whalf, dst);
+      blds16(rw, vw[1], ko + (J & 1) * whalf, dst + 8 * 512);
+    } else {
+      blds16(rx, vx[0], ko + (J & 1) * xhalf, dst);
+      blds16(rx, vx[1], ko + (J & 1) * xhalf, dst + 8 * 512);
+    }
+    islot = islot == PSLOTS - 1 ? 0 : islot + 1;
+    if (J == 3) {
+      if (++kti == nk) {
+        kti = 0;
+        ti += gridDim.x;
+        set_tile(ti);
+      }
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+
+  // ---- compute side
+  const int wm = grp * 128, wn = (wave & 3) * 64;
+  const int fr = lane & 31, fhi = lane >> 5;
+  const bool vec = !((a.N | a.ldo | (a.resid_kind ? a.ldr : 0)) & 3);
+  const bool plain_rows = a.rpg == 0x7fffffff && a.resid_kind != 3;
+  int la[4];                                       // byte offset of this lane's fragment chunk of k-step kk in row fr
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) la[kk] = fr * 128 + ((((kk << 1) | fhi) ^ ((fr >> 1) & 7)) << 4);
+  const int wsub = ((wave >> 1) & 1);              // W half-region of this wave
+  const int woff = (wave & 1) * 64 * 128;          // byte offset of its 64 rows inside that region
+  const char* lds = (const char*)smem;
+
+  set_tile(ti);
+  issue(I0{}); issue(I1{}); issue(I2{}); issue(I3{});
+  issue(I0{}); issue(I1{}); issue(I2{});
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (grp) __builtin_amdgcn_s_barrier();           // stagger
+
+  int cslot = 0;                                   // ring slot of region 0 of the K-tile being computed
+  bf16x8 w0[4], w1[4], xf[2][4];
+  for (int tc = blockIdx.x; tc < ntiles; tc += gridDim.x) {
+    int cm0, cn0;
+    tile_origin(tc, cm0, cn0);
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int kt = 0; kt < nk; ++kt) {
+      int s1 = cslot + wsub, s2 = cslot + 2 + grp;
+      if (s1 >= PSLOTS) s1 -= PSLOTS;
+      if (s2 >= PSLOTS) s2 -= PSLOTS;
+      const char* wreg = lds + s1 * (PREG * 2) + woff;
+      const char* xreg = lds + s2 * (PREG * 2);
+      cslot = cslot + 4 >= PSLOTS ? cslot + 4 - PSLOTS : cslot + 4;
+
+#define PP_SYNC_IN()                                   \
+  __builtin_amdgcn_sched_barrier(0);                   \
+  __builtin_amdgcn_s_barrier();                        \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
+  __builtin_amdgcn_sched_barrier(0);                   \
+  __builtin_amdgcn_s_setprio(1)
+#define PP_SYNC_OUT()                                  \
+  __builtin_amdgcn_s_setprio(0);                       \
+  __builtin_amdgcn_sched_barrier(0);                   \
+  __builtin_amdgcn_s_barrier();                        \
+  asm volatile("" ::: "memory");                       \
+  __builtin_amdgcn_sched_barrier(0)
+
+      // ---- phase 0: W sub 0, X sub 0 -> quadrant (0, 0)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) w0[kk] = *(const bf16x8*)(wreg + la[kk]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) xf[j][kk] = *(const bf16x8*)(xreg + j * 4096 + la[kk]);
+      issue(I3{});
+      PP_SYNC_IN();
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0[kk], xf[j][kk], acc[0][j], 0, 0, 0);
+      PP_SYNC_OUT();
+
+      // ---- phase 1: W sub 1 -> quadrant (0, 1)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) w1[kk] = *(const bf16x8*)(wreg + 4096 + la[kk]);
+      issue(I0{});
+      PP_SYNC_IN();
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[kk], xf[j][kk], acc[1][j], 0, 0, 0);
+      PP_SYNC_OUT();
+
+      // ---- phase 2: X sub 1 -> quadrant (1, 1)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) xf[j][kk] = *(const bf16x8*)(xreg + 8192 + j * 4096 + la[kk]);
+      issue(I1{});
+      PP_SYNC_IN();
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[1][2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[kk], xf[j][kk], acc[1][2 + j], 0, 0, 0);
+      PP_SYNC_OUT();
+
+      // ---- phase 3: nothing new to read -> quadrant (1, 0); the next K-tile's last region is waited for here
+      issue(I2{});
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      PP_SYNC_IN();
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[0][2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0[kk], xf[j][kk], acc[0][2 + j], 0, 0, 0);
+      PP_SYNC_OUT();
+    }
+
+    // Both groups run the epilogue together: the leading group waits one barrier, the trailing one re-staggers after.
+    // Staging = the ring slots of the last K-tile's X regions (dead since its phase 2; re-issued in phases 1 and 2 of
+    // the next tile, behind a barrier every wave reaches only after its epilogue).
+    if (!grp) __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    {
+      int ss = cslot + 8 + (wave >> 2);            // cslot already points 4 ahead: X regions of the last K-tile = cslot - 2, - 1
+      while (ss >= PSLOTS) ss -= PSLOTS;
+      char* stg = (char*)smem + ss * (PREG * 2) + (wave & 3) * STG_BYTES;
+      if (vec && plain_rows && cm0 + 256 <= a.M && (cn0 + 256 <= a.N || !(a.N & 7)))
+        epilogue_interior<TM, TN>(acc, a, stg, cm0 + wm, cn0 + wn, lane);
+      else
+        epilogue_generic<TM, TN>(acc, a, vec, cm0 + wm, cn0 + wn, lane);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (grp) __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing empty pieces must retire before the LDS is released
+#undef PP_SYNC_IN
+#undef PP_SYNC_OUT
+}
+
 }  // namespace
 
 template <int MODE, int BM, int BN, int WM, int WN>
@@ -660,7 +883,17 @@ extern "C" int msclip_gemm(const msclip_gemm_desc* d, void* stream) {
   const long long big_tiles = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256);
   const bool big = d->tile >= 2 || (d->tile == 0 && d->N >= 192 && big_tiles >= 128);
   if (d->mode == 0) {
-    if (big && d->tile != 3) {   // streaming ring kernel (tile 3 selects the two-buffer 256x256 kernel for A/B tests)
+    if (d->tile == 4) {
+      static int ncu4 = 0;
+      if (!ncu4) {
+        hipDeviceProp_t p;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        ncu4 = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+      }
+      const int tiles = ((d->M + 255) / 256) * ((d->N + 255) / 256);
+      hipLaunchKernelGGL(gemm_pp_kernel, dim3(tiles < ncu4 ? tiles : ncu4), dim3(512), 0, st, *d);
+    } else if (big && d->tile != 3) {   // streaming ring kernel (tile 3 selects the two-buffer 256x256 kernel for A/B tests)
       static int ncu = 0;
       if (!ncu) {
         hipDeviceProp_t p;

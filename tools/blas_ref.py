@@ -1,6 +1,6 @@
 """Reference point only (not used by the product): vendor GEMM (hipBLASLt via torch) on the projection shapes."""
 import torch
-for (M, N, K) in [(65024, 2304, 768), (65024, 768, 768), (65024, 3072, 768), (65024, 768, 3072)]:
+for (M, N, K) in [(65024, 2304, 768), (65024, 768, 768), (65024, 3072, 768), (65024, 768, 3072), (8192, 8192, 8192), (4096, 4096, 4096)]:
     x = torch.randn(M, K, device="cuda").to(torch.bfloat16)
     w = (torch.randn(N, K, device="cuda") * 0.03).to(torch.bfloat16)
     for _ in range(3): y = torch.nn.functional.linear(x, w)
