@@ -94,14 +94,14 @@ def main():
     for _ in range(args.warmup):
         loss = step()
     probe = None if args.no_probe else hip.KernelProbe()
-    hip.set_gemm_probe("ring", probe)
+    hip.set_gemm_probe("pp", probe)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     fence()
     dt = time.perf_counter() - t0
-    hip.set_gemm_probe("ring", None)
+    hip.set_gemm_probe("pp", None)
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -133,7 +133,7 @@ def main():
                 with open(tpath) as f:
                     traffic = round(json.load(f)["hbm_bytes_per_launch"])
             ach = flops / (kms * 1e-3) / 1e12
-            rec["roofline"] = {"kernel": "gemm_ring_kernel (dense bf16 MFMA GEMM: all transformer projections + wide pointwise convs)",
+            rec["roofline"] = {"kernel": "gemm_pp_kernel (dense bf16 MFMA GEMM: all transformer projections + wide pointwise convs)",
                                "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_bench_hbm_traffic.json)",
                                "launches_per_step": n // args.steps, "avg_launch_us": round(kms / n * 1e3, 2),

@@ -650,6 +650,27 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const msclip_gemm_des
 // ------------------------------------------------------------------------------------------------------------
 constexpr int PSLOTS = 10, PREG = 128 * 64;   // ring regions, bf16 elements per region
 
+#ifdef PP_NODS   // probe builds only: fragments come from nowhere
+__device__ __forceinline__ bf16x8 pp_ld(const void* p) {
+  union { unsigned u[4]; bf16x8 v; } x;
+  asm volatile("" : "=v"(x.u[0]), "=v"(x.u[1]), "=v"(x.u[2]), "=v"(x.u[3]) : "v"(p));
+  return x.v;
+}
+#else
+__device__ __forceinline__ bf16x8 pp_ld(const void* p) { return *(const bf16x8*)p; }
+#endif
+
+#ifdef PP_TRACE   // probe builds only: cycle stamps of workgroup 0 (waves 0 and 4)
+__device__ unsigned long long pp_trace_buf[2 * 512];
+#define PP_STAMP(id)                                                                       \
+  if (trace_on && tcnt < 510) {                                                            \
+    pp_trace_buf[(wave >> 2) * 512 + tcnt] = ((unsigned long long)(id) << 56) | (__builtin_amdgcn_s_memtime() & 0xffffffffffffffull); \
+    ++tcnt;                                                                                \
+  }
+#else
+#define PP_STAMP(id) (void)0
+#endif
+
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) {
   constexpr int TM = 4, TN = 2;
   __shared__ __attribute__((aligned(1024))) bf16_t smem[PSLOTS * PREG];
@@ -658,6 +679,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2;                       // 0: leading group, 1: one barrier behind
+#ifdef PP_TRACE
+  const bool trace_on = blockIdx.x == 0 && (tid & 255) == 0;
+  int tcnt = 0;
+#endif
   const int nt_n = (a.N + 255) / 256;
   const int nt_m = (a.M + 255) / 256;
   const int ntiles = nt_n * nt_m;
@@ -699,14 +724,26 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
   auto issue = [&](auto jc) {                      // region j of K-tile (ti, kti) -> ring slot islot
     constexpr int J = decltype(jc)::value;
     bf16_t* dst = smem + islot * PREG + wave * 512;
+#ifdef PP_HOTSRC
+    const unsigned ko = 0;
+#else
     const unsigned ko = (unsigned)kti * 128u;
+#endif
+#ifdef PP_NODMA
+    asm volatile("" ::"s"(ko), "v"(dst));
+#else
     if (J < 2) {
       blds16(rw, vw[0], ko + (J & 1) * whalf, dst);
+#ifndef PP_ONEDMA
       blds16(rw, vw[1], ko + (J & 1) * whalf, dst + 8 * 512);
+#endif
     } else {
       blds16(rx, vx[0], ko + (J & 1) * xhalf, dst);
+#ifndef PP_ONEDMA
       blds16(rx, vx[1], ko + (J & 1) * xhalf, dst + 8 * 512);
+#endif
     }
+#endif
     islot = islot == PSLOTS - 1 ? 0 : islot + 1;
     if (J == 3) {
       if (++kti == nk) {
@@ -733,6 +770,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
   const int woff = (wave & 1) * 64 * 128;          // byte offset of its 64 rows inside that region
   const char* lds = (const char*)smem;
 
+#ifdef PP_DESYNC   // probe: spread the workgroups' epilogue bursts
+  for (int i = ((blockIdx.x >> 3) & 31) * PP_DESYNC; i > 0; --i) __builtin_amdgcn_s_sleep(8);   // 512-cycle steps
+#endif
   set_tile(ti);
   issue(I0{}); issue(I1{}); issue(I2{}); issue(I3{});
   issue(I0{}); issue(I1{}); issue(I2{});
@@ -753,8 +793,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
       for (int j = 0; j < TM; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    PP_STAMP(1);
 
     for (int kt = 0; kt < nk; ++kt) {
+      if (kt) { PP_STAMP(2); }
       int s1 = cslot + wsub, s2 = cslot + 2 + grp;
       if (s1 >= PSLOTS) s1 -= PSLOTS;
       if (s2 >= PSLOTS) s2 -= PSLOTS;
@@ -762,14 +804,24 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
       const char* xreg = lds + s2 * (PREG * 2);
       cslot = cslot + 4 >= PSLOTS ? cslot + 4 - PSLOTS : cslot + 4;
 
+#ifdef PP_NOPRIO
+#define PP_PRIO(x) (void)0
+#else
+#define PP_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#endif
+#ifdef PP_NOLGK
+#define PP_LGK() asm volatile("" ::: "memory")
+#else
+#define PP_LGK() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#endif
 #define PP_SYNC_IN()                                   \
   __builtin_amdgcn_sched_barrier(0);                   \
   __builtin_amdgcn_s_barrier();                        \
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
+  PP_LGK();                                            \
   __builtin_amdgcn_sched_barrier(0);                   \
-  __builtin_amdgcn_s_setprio(1)
+  PP_PRIO(1)
 #define PP_SYNC_OUT()                                  \
-  __builtin_amdgcn_s_setprio(0);                       \
+  PP_PRIO(0);                                          \
   __builtin_amdgcn_sched_barrier(0);                   \
   __builtin_amdgcn_s_barrier();                        \
   asm volatile("" ::: "memory");                       \
@@ -777,12 +829,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
 
       // ---- phase 0: W sub 0, X sub 0 -> quadrant (0, 0)
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) w0[kk] = *(const bf16x8*)(wreg + la[kk]);
+      for (int kk = 0; kk < 4; ++kk) w0[kk] = pp_ld(wreg + la[kk]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) xf[j][kk] = *(const bf16x8*)(xreg + j * 4096 + la[kk]);
+        for (int kk = 0; kk < 4; ++kk) xf[j][kk] = pp_ld(xreg + j * 4096 + la[kk]);
       issue(I3{});
       PP_SYNC_IN();
 #pragma unroll
@@ -794,7 +846,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
 
       // ---- phase 1: W sub 1 -> quadrant (0, 1)
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) w1[kk] = *(const bf16x8*)(wreg + 4096 + la[kk]);
+      for (int kk = 0; kk < 4; ++kk) w1[kk] = pp_ld(wreg + 4096 + la[kk]);
       issue(I0{});
       PP_SYNC_IN();
 #pragma unroll
@@ -808,7 +860,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) xf[j][kk] = *(const bf16x8*)(xreg + 8192 + j * 4096 + la[kk]);
+        for (int kk = 0; kk < 4; ++kk) xf[j][kk] = pp_ld(xreg + 8192 + j * 4096 + la[kk]);
       issue(I1{});
       PP_SYNC_IN();
 #pragma unroll
@@ -820,7 +872,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
 
       // ---- phase 3: nothing new to read -> quadrant (1, 0); the next K-tile's last region is waited for here
       issue(I2{});
+#ifndef PP_NOWAIT
       asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+#endif
       PP_SYNC_IN();
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk)
@@ -833,24 +887,40 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
     // Both groups run the epilogue together: the leading group waits one barrier, the trailing one re-staggers after.
     // Staging = the ring slots of the last K-tile's X regions (dead since its phase 2; re-issued in phases 1 and 2 of
     // the next tile, behind a barrier every wave reaches only after its epilogue).
+    PP_STAMP(3);
     if (!grp) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    PP_STAMP(4);
     {
       int ss = cslot + 8 + (wave >> 2);            // cslot already points 4 ahead: X regions of the last K-tile = cslot - 2, - 1
       while (ss >= PSLOTS) ss -= PSLOTS;
       char* stg = (char*)smem + ss * (PREG * 2) + (wave & 3) * STG_BYTES;
+#ifdef PP_NOEPI
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[i][j][r]));
+      asm volatile("" ::"v"(stg));
+#else
       if (vec && plain_rows && cm0 + 256 <= a.M && (cn0 + 256 <= a.N || !(a.N & 7)))
         epilogue_interior<TM, TN>(acc, a, stg, cm0 + wm, cn0 + wn, lane);
       else
         epilogue_generic<TM, TN>(acc, a, vec, cm0 + wm, cn0 + wn, lane);
+#endif
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    PP_STAMP(5);
     if (grp) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   }
+  PP_STAMP(6);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing empty pieces must retire before the LDS is released
 #undef PP_SYNC_IN
 #undef PP_SYNC_OUT
+#undef PP_PRIO
+#undef PP_LGK
 }
 
 }  // namespace
@@ -870,6 +940,12 @@ static void launch_cfg(const msclip_gemm_desc* d, hipStream_t st, int blocks_per
   hipLaunchKernelGGL((gemm_kernel<MODE, BM, BN, WM, WN>), dim3(grid), dim3(WM * WN * 64), 0, st, *d);
 }
 
+#ifdef PP_TRACE
+extern "C" int msclip_pp_trace(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(pp_trace_buf), sizeof(unsigned long long) * 1024) == hipSuccess ? 0 : -1;
+}
+#endif
+
 extern "C" int msclip_gemm(const msclip_gemm_desc* d, void* stream) {
   if (!d || !d->X || !d->W || !d->out || !d->zero) return MSCLIP_EINVAL;
   if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->K % BK)) return MSCLIP_EINVAL;
@@ -883,25 +959,20 @@ extern "C" int msclip_gemm(const msclip_gemm_desc* d, void* stream) {
   const long long big_tiles = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256);
   const bool big = d->tile >= 2 || (d->tile == 0 && d->N >= 192 && big_tiles >= 128);
   if (d->mode == 0) {
-    if (d->tile == 4) {
-      static int ncu4 = 0;
-      if (!ncu4) {
-        hipDeviceProp_t p;
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        ncu4 = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
-      }
-      const int tiles = ((d->M + 255) / 256) * ((d->N + 255) / 256);
-      hipLaunchKernelGGL(gemm_pp_kernel, dim3(tiles < ncu4 ? tiles : ncu4), dim3(512), 0, st, *d);
-    } else if (big && d->tile != 3) {   // streaming ring kernel (tile 3 selects the two-buffer 256x256 kernel for A/B tests)
-      static int ncu = 0;
-      if (!ncu) {
-        hipDeviceProp_t p;
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        ncu = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
-      }
-      const int tiles = ((d->M + 255) / 256) * ((d->N + 255) / 256);
+    static int ncu = 0;
+    if (!ncu) {
+      hipDeviceProp_t p;
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      ncu = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+    }
+    const int tiles = ((d->M + 255) / 256) * ((d->N + 255) / 256);
+    // 256-row tile offsets must fit the 32-bit buffer offsets of the ping-pong kernel's loads
+    const bool pp_ok = (long long)d->ldx * 2 * 256 + (long long)d->K * 2 < (1ll << 31) &&
+                       (long long)d->ldw * 2 * 256 + (long long)d->K * 2 < (1ll << 31);
+    if (pp_ok && (d->tile == 4 || (d->tile == 0 && big))) {        // ping-pong kernel (default for the projections)
+      hipLaunchKernelGGL(gemm_pp_kernel, dim3(tiles < ncu ? tiles : ncu), dim3(512), 0, st, *d);
+    } else if (big && d->tile != 3) {   // streaming ring kernel (tile 2; tile 3 selects the two-buffer 256x256 kernel: A/B tests)
       hipLaunchKernelGGL(gemm_ring_kernel, dim3(tiles < ncu ? tiles : ncu), dim3(512), 0, st, *d);
     } else if (big) launch_cfg<0, 256, 256, 2, 4>(d, st, 1);
     else launch_cfg<0, 128, 128, 2, 2>(d, st, 2);

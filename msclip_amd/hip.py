@@ -156,11 +156,14 @@ _gemm_probe = {}   # kernel variant -> KernelProbe
 
 
 def gemm_variant(mode, M, N, tile=0):
-    """Which kernel msclip_gemm dispatches to (mirror of the rule in csrc/gemm.hip): 'ring' = gemm_ring_kernel
-    (dense streaming 256x256), 'conv256'/'conv128' = gemm_kernel<1,...>, 'dense256'/'dense128' = gemm_kernel<0,...>."""
+    """Which kernel msclip_gemm dispatches to (mirror of the rule in csrc/gemm.hip): 'pp' = gemm_pp_kernel (dense
+    256x256 ping-pong, the default for large problems), 'ring' = gemm_ring_kernel (tile 2), 'conv256'/'conv128' =
+    gemm_kernel<1,...>, 'dense256'/'dense128' = gemm_kernel<0,...>."""
     big_tiles = ((M + 255) // 256) * ((N + 255) // 256)
     big = tile >= 2 or (tile == 0 and N >= 192 and big_tiles >= 128)
     if mode == 0:
+        if tile == 4 or (tile == 0 and big):
+            return "pp"
         return "ring" if (big and tile != 3) else ("dense256" if big else "dense128")
     return "conv256" if big else "conv128"
 

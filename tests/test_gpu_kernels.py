@@ -34,6 +34,24 @@ def test_gemm_dense_bias_and_shapes(gpu_device, M, N, K):
     close(outf, 0.5 * (x.float() @ w.float().t()) + b, 2e-3, 1e-4)
 
 
+@pytest.mark.parametrize("tile", [1, 2, 3, 4])
+@pytest.mark.parametrize("M,N,K", [(1000, 768, 3072), (700, 520, 128), (256, 256, 64), (2051, 1096, 768)])
+def test_gemm_every_tile_config(gpu_device, tile, M, N, K):
+    """Each main-loop variant (128x128, streaming ring, two-buffer, ping-pong) on ragged edges, all three epilogue kinds."""
+    x, w, b = rnd(M, K, seed=11, dtype=BF), rnd(N, K, seed=12, scale=0.05, dtype=BF), rnd(N, seed=13)
+    base = x.float() @ w.float().t() + b
+    out = torch.full((M + 3, N), float("nan"), dtype=BF, device="cuda")
+    hip.gemm(x, w, out[:M], bias=b, act=hip.ACT_QUICKGELU, tile=tile)
+    close(out[:M], base * torch.sigmoid(1.702 * base), 2e-2, 1e-2)
+    assert bool(torch.isnan(out[M:].float()).all())                              # nothing written past M
+    r32 = rnd(M, N, seed=14)
+    xres = r32.clone()
+    for _ in range(2):                                                           # back-to-back launches: ring state, races
+        xres.copy_(r32)
+        hip.gemm(x, w, xres, bias=b, resid=xres, resid_kind=hip.RESID_F32, tile=tile)
+        close(xres, r32 + base, 4e-3, 1e-4)
+
+
 def test_gemm_epilogues(gpu_device):
     M, N, K = 333, 256, 192
     x, w, b = rnd(M, K, seed=4, dtype=BF), rnd(N, K, seed=5, scale=0.08, dtype=BF), rnd(N, seed=6)

@@ -17,6 +17,7 @@ SHAPES = [  # (name, M, N, K, epilogue)
     ("txt0 ", 39424, 3072, 768, "gelu"),
 ]
 FULL = False
+ZEROS = False
 SQUARE = [("sq8k ", 8192, 8192, 8192, "bias"), ("sq4k ", 4096, 4096, 4096, "bias")]   # calibration against published tiers
 
 
@@ -24,6 +25,8 @@ def run(name, M, N, K, epi, tile, iters=20, check=False):
     g = torch.Generator().manual_seed(0)
     x = (torch.randn(M, K, generator=g)).to(torch.bfloat16).cuda()
     w = (torch.randn(N, K, generator=g) * 0.03).to(torch.bfloat16).cuda()
+    if ZEROS:                                       # power calibration: all-zero operands
+        x.zero_(); w.zero_()
     b = torch.randn(N, generator=g).cuda()
     if epi == "resid":
         out = torch.randn(M, N, generator=g).cuda()
@@ -81,8 +84,10 @@ if __name__ == "__main__":
     ap.add_argument("--tiles", type=int, nargs="+", default=[1, 2])
     ap.add_argument("--square", action="store_true")
     ap.add_argument("--full", action="store_true")
+    ap.add_argument("--zeros", action="store_true")
     args = ap.parse_args()
     FULL = args.full
+    ZEROS = args.zeros
     if args.square:
         SHAPES = SQUARE
     tot = {t: 0.0 for t in args.tiles}
