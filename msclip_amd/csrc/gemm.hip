@@ -33,6 +33,23 @@ struct RowSrc {          // per staged X row (conv mode)
   int ok;
 };
 
+#ifdef PP_TRACE   // probe builds only: cycle stamps of workgroup 0 (waves 0 and 4) of the ping-pong kernel
+__device__ unsigned long long pp_trace_buf[2 * 512];
+struct PpTrace { bool on; int cnt; int grp; };
+__device__ __forceinline__ void pp_stamp(PpTrace& t, int id) {
+  if (t.on && t.cnt < 510) {
+    pp_trace_buf[t.grp * 512 + t.cnt] = ((unsigned long long)id << 56) | (__builtin_amdgcn_s_memtime() & 0xffffffffffffffull);
+    ++t.cnt;
+  }
+}
+#define PP_STAMP(id) pp_stamp(tr, id)
+#define EPI_STAMP(id) if (tr) pp_stamp(*tr, id)
+#else
+struct PpTrace {};
+#define PP_STAMP(id) (void)0
+#define EPI_STAMP(id) (void)0
+#endif
+
 constexpr int STG_BYTES = 4096;   // per-wave staging: 32 rows x 128 B, 16-byte chunks XOR-swizzled by (row & 7)
 
 // Interior tile (no guards): transpose the wave's TM x TN 32x32 accumulator tiles through LDS so that 8 lanes
@@ -40,7 +57,7 @@ constexpr int STG_BYTES = 4096;   // per-wave staging: 32 rows x 128 B, 16-byte 
 // add / ReLU / conversion after the transpose (row-contiguous, full-line residual loads).
 template <int TM, int TN>
 __device__ __forceinline__ void epilogue_interior(f32x16 (&acc)[TN][TM], const msclip_gemm_desc& a, char* stg,
-                                                  int mw0, int nw0, int lane) {
+                                                  int mw0, int nw0, int lane, PpTrace* tr = nullptr) {
   const int fr = lane & 31, fhi = lane >> 5;
   const int srow = lane >> 3, sch = lane & 7;      // read-back mapping: row i*8 + srow, 16-byte chunk sch
   const float* __restrict__ bias = a.bias;
@@ -55,9 +72,11 @@ __device__ __forceinline__ void epilogue_interior(f32x16 (&acc)[TN][TM], const m
   char* wr = stg + fr * 128;
   const int wsw = fr & 7;
   const char* rd = stg + srow * 128 + ((sch ^ srow) << 4);      // + i * 1024 for row block i
+  EPI_STAMP(10);
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     const int mrow0 = mw0 + tm * 32;
+    EPI_STAMP(11);
     if (direct16) {
       static_assert(TN == 2, "64 bf16 columns per staged row");
 #pragma unroll
@@ -147,6 +166,122 @@ __device__ __forceinline__ void epilogue_interior(f32x16 (&acc)[TN][TM], const m
         }
       }
     }
+  }
+}
+
+// Interior tile of the ping-pong kernel.  Every 32x32 accumulator tile goes through the wave's 4-KiB staging block
+// as fp32 (32 rows x 128 B, chunks XOR-swizzled by row & 7) so that afterwards lane (srow = lane/8, sch = lane%8)
+// owns 4 consecutive columns sch*4.. of rows srow, srow+8, ...: bias (8 registers, loaded at tile start by the
+// caller), activation and residual are applied there.  Nothing is loaded in the epilogue for the bf16 outputs
+// (a load would sit behind the in-flight LDS-DMA of the next tile: the VM counter retires in order), the fp32
+// residual rows of two 32-row blocks are requested up front and re-requested two blocks ahead.
+// fp32 outputs leave as full 128-byte lines, bf16 outputs as aligned 64-byte half lines.
+// RK / ACT / OUTK: resid_kind / act / out_kind known at compile time, or -1 = read the descriptor.
+// The staging traffic is inline asm: a compiler-visible LDS access after an LDS-DMA gets an s_waitcnt vmcnt(0) in front of
+// it (the DMA is a pending LDS write), i.e. a stall on the next tile's in-flight prefetch.  A wave's DS instructions
+// execute in issue order, so block b+1 may be written over block b as soon as b's reads are issued.
+__device__ __forceinline__ void stg_write16(unsigned addr, f32x4 v) {
+  asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ f32x4 stg_read16(unsigned addr) {
+  f32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+
+template <int TM, int TN, int RK, int ACT, int OUTK>
+__device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[TN][TM], const msclip_gemm_desc& a, unsigned stg, int mw0,
+                                              int nw0, int lane, const float4 (&bias4)[TN], PpTrace* tr = nullptr) {
+  const int fr = lane & 31, fhi = lane >> 5;
+  const int srow = lane >> 3, sch = lane & 7;
+  const unsigned wr = stg + fr * 128;
+  const int wsw = fr & 7;
+  const unsigned rd = stg + srow * 128 + ((sch ^ srow) << 4);    // + i * 1024 for rows i*8 + srow
+  const int rk = RK >= 0 ? RK : a.resid_kind;
+  const int act = ACT >= 0 ? ACT : a.act;
+  const int outk = OUTK >= 0 ? OUTK : a.out_kind;
+  constexpr int RAHEAD = 3;                                      // residual blocks (32 x 32) requested ahead
+  float4 rv[RAHEAD][4];                                          // raw: fp32 x 4, or bf16 x 4 in .x/.y (unpacked at use)
+  auto load_res = [&](int b, float4 (&dst)[4]) {
+    const int tm = b / TN, tn = b % TN;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const size_t row = (size_t)(mw0 + tm * 32 + i * 8 + srow);
+      const int n = nw0 + tn * 32 + sch * 4;
+      if (n >= a.N) {
+        dst[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else if (rk == 1) {
+        dst[i] = *(const float4*)((const float*)a.resid + row * a.ldr + n);
+      } else {
+        const uint2 u = *(const uint2*)((const bf16_t*)a.resid + row * a.ldr + n);
+        dst[i] = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), 0.f, 0.f);
+      }
+    }
+  };
+  if (rk) {
+#pragma unroll
+    for (int b = 0; b < RAHEAD; ++b) load_res(b, rv[b]);
+  }
+  EPI_STAMP(10);
+  f32x4 x[2][4];
+  auto stage = [&](int b, f32x4 (&dst)[4]) {                     // block b = tm * TN + tn -> LDS -> row-major registers
+    const int tm = b / TN, tn = b % TN;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 v;
+      v[0] = acc[tn][tm][g * 4 + 0] * a.alpha; v[1] = acc[tn][tm][g * 4 + 1] * a.alpha;
+      v[2] = acc[tn][tm][g * 4 + 2] * a.alpha; v[3] = acc[tn][tm][g * 4 + 3] * a.alpha;
+      stg_write16(wr + (((g * 2 + fhi) ^ wsw) << 4), v);
+    }
+    dst[0] = stg_read16<0>(rd); dst[1] = stg_read16<1024>(rd);
+    dst[2] = stg_read16<2048>(rd); dst[3] = stg_read16<3072>(rd);
+  };
+  stage(0, x[0]);
+#pragma unroll
+  for (int b = 0; b < TM * TN; ++b) {
+    const int tm = b / TN, tn = b % TN;
+    if (tn == 0) { EPI_STAMP(11); }
+    f32x4(&xb)[4] = x[b & 1];
+    if (b + 1 < TM * TN) {
+      stage(b + 1, x[(b + 1) & 1]);
+      asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(xb[0]), "+v"(xb[1]), "+v"(xb[2]), "+v"(xb[3])::"memory");
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xb[0]), "+v"(xb[1]), "+v"(xb[2]), "+v"(xb[3])::"memory");
+    }
+    const int n = nw0 + tn * 32 + sch * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float4 v = make_float4(xb[i][0] + bias4[tn].x, xb[i][1] + bias4[tn].y, xb[i][2] + bias4[tn].z, xb[i][3] + bias4[tn].w);
+      if (act == 1) {
+        v.x = v.x / (1.f + __expf(-1.702f * v.x)); v.y = v.y / (1.f + __expf(-1.702f * v.y));
+        v.z = v.z / (1.f + __expf(-1.702f * v.z)); v.w = v.w / (1.f + __expf(-1.702f * v.w));
+      }
+      if (rk == 1) {
+        const float4 r = rv[b % RAHEAD][i];
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+      } else if (rk) {
+        const unsigned ux = __float_as_uint(rv[b % RAHEAD][i].x), uy = __float_as_uint(rv[b % RAHEAD][i].y);
+        v.x += __uint_as_float(ux << 16); v.y += __uint_as_float(ux & 0xffff0000u);
+        v.z += __uint_as_float(uy << 16); v.w += __uint_as_float(uy & 0xffff0000u);
+      }
+      if (act == 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      const size_t row = (size_t)(mw0 + tm * 32 + i * 8 + srow);
+#ifndef MSCLIP_ABLATE_EPI
+      if (n >= a.N) {
+      } else if (outk == 1) {
+        *(float4*)((float*)a.out + row * a.ldo + n) = v;
+      } else {
+        uint2 o;
+        o.x = pack_bf16x2(v.x, v.y);
+        o.y = pack_bf16x2(v.z, v.w);
+        *(uint2*)((bf16_t*)a.out + row * a.ldo + n) = o;
+      }
+#else
+      asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w), "v"(row), "v"(n));
+#endif
+    }
+    if (rk && b + RAHEAD < TM * TN) load_res(b + RAHEAD, rv[b % RAHEAD]);
   }
 }
 
@@ -660,17 +795,6 @@ __device__ __forceinline__ bf16x8 pp_ld(const void* p) {
 __device__ __forceinline__ bf16x8 pp_ld(const void* p) { return *(const bf16x8*)p; }
 #endif
 
-#ifdef PP_TRACE   // probe builds only: cycle stamps of workgroup 0 (waves 0 and 4)
-__device__ unsigned long long pp_trace_buf[2 * 512];
-#define PP_STAMP(id)                                                                       \
-  if (trace_on && tcnt < 510) {                                                            \
-    pp_trace_buf[(wave >> 2) * 512 + tcnt] = ((unsigned long long)(id) << 56) | (__builtin_amdgcn_s_memtime() & 0xffffffffffffffull); \
-    ++tcnt;                                                                                \
-  }
-#else
-#define PP_STAMP(id) (void)0
-#endif
-
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) {
   constexpr int TM = 4, TN = 2;
   __shared__ __attribute__((aligned(1024))) bf16_t smem[PSLOTS * PREG];
@@ -680,8 +804,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2;                       // 0: leading group, 1: one barrier behind
 #ifdef PP_TRACE
-  const bool trace_on = blockIdx.x == 0 && (tid & 255) == 0;
-  int tcnt = 0;
+  PpTrace tr{blockIdx.x == 0 && (tid & 255) == 0, 0, grp};
 #endif
   const int nt_n = (a.N + 255) / 256;
   const int nt_m = (a.M + 255) / 256;
@@ -793,6 +916,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
       for (int j = 0; j < TM; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float4 bias4[TN];                              // this lane's epilogue columns (see epilogue_rows)
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int n = cn0 + wn + i * 32 + (lane & 7) * 4;
+      bias4[i] = (a.bias && vec && n < a.N) ? *(const float4*)(a.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     PP_STAMP(1);
 
     for (int kt = 0; kt < nk; ++kt) {
@@ -875,6 +1004,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
 #ifndef PP_NOWAIT
       asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
 #endif
+      // the bias loads of this tile are older than the six pieces still in flight: tell the compiler they landed
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+        asm volatile("" : "+v"(bias4[i].x), "+v"(bias4[i].y), "+v"(bias4[i].z), "+v"(bias4[i].w));
       PP_SYNC_IN();
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk)
@@ -894,7 +1027,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
     {
       int ss = cslot + 8 + (wave >> 2);            // cslot already points 4 ahead: X regions of the last K-tile = cslot - 2, - 1
       while (ss >= PSLOTS) ss -= PSLOTS;
-      char* stg = (char*)smem + ss * (PREG * 2) + (wave & 3) * STG_BYTES;
+      const unsigned stg = (unsigned)(size_t)(AS3 bf16_t*)smem + ss * (PREG * 2) + (wave & 3) * STG_BYTES;
 #ifdef PP_NOEPI
 #pragma unroll
       for (int i = 0; i < TN; ++i)
@@ -904,13 +1037,35 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
           for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[i][j][r]));
       asm volatile("" ::"v"(stg));
 #else
-      if (vec && plain_rows && cm0 + 256 <= a.M && (cn0 + 256 <= a.N || !(a.N & 7)))
-        epilogue_interior<TM, TN>(acc, a, stg, cm0 + wm, cn0 + wn, lane);
+      // lane id recomputed from scratch: the epilogue's lane constants must not live (spilled) across the main loop
+      int lane_e;
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+      if (vec && plain_rows && cm0 + 256 <= a.M)
+      {
+#ifdef PP_TRACE
+        PpTrace* trp = &tr;
+#else
+        PpTrace* trp = nullptr;
+#endif
+        const int mw0 = cm0 + wm, nw0 = cn0 + wn;
+#ifdef PP_OLDEPI
+        (void)trp;
+        epilogue_interior<TM, TN>(acc, a, (char*)smem + ss * (PREG * 2) + (wave & 3) * STG_BYTES, mw0, nw0, lane_e);
+#else
+        if (a.resid_kind == 0 && a.act == 0 && a.out_kind == 0)
+          epilogue_rows<TM, TN, 0, 0, 0>(acc, a, stg, mw0, nw0, lane_e, bias4, trp);          // QKV
+        else if (a.resid_kind == 0 && a.act == 1 && a.out_kind == 0)
+          epilogue_rows<TM, TN, 0, 1, 0>(acc, a, stg, mw0, nw0, lane_e, bias4, trp);          // c_fc + QuickGELU
+        else if (a.resid_kind == 1 && a.act == 0 && a.out_kind == 1)
+          epilogue_rows<TM, TN, 1, 0, 1>(acc, a, stg, mw0, nw0, lane_e, bias4, trp);          // out_proj / c_proj into the fp32 stream
+        else
+          epilogue_rows<TM, TN, -1, -1, -1>(acc, a, stg, mw0, nw0, lane_e, bias4, trp);       // pointwise convolutions, heads
+#endif
+      }
       else
-        epilogue_generic<TM, TN>(acc, a, vec, cm0 + wm, cn0 + wn, lane);
+        epilogue_generic<TM, TN>(acc, a, vec, cm0 + wm, cn0 + wn, lane_e);
 #endif
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     PP_STAMP(5);
     if (grp) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");

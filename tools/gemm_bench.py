@@ -15,6 +15,7 @@ SHAPES = [  # (name, M, N, K, epilogue)
     ("fc   ", 65024, 3072, 768, "gelu"),
     ("proj ", 65024, 768, 3072, "resid"),
     ("txt0 ", 39424, 3072, 768, "gelu"),
+    ("qkvnb", 65024, 2304, 768, "none"),
 ]
 FULL = False
 ZEROS = False
@@ -34,6 +35,10 @@ def run(name, M, N, K, epi, tile, iters=20, check=False):
     elif epi == "gelu":
         out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
         kw = dict(bias=b, act=hip.ACT_QUICKGELU)
+    elif epi == "none":
+        out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        kw = dict()
+        b = torch.zeros_like(b)
     else:
         out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
         kw = dict(bias=b)
