@@ -1101,6 +1101,8 @@ extern "C" int msclip_pp_trace(unsigned long long* out) {
 }
 #endif
 
+bool msclip_gemm_small_try(const msclip_gemm_desc* d, hipStream_t st, int ncu);   // gemm_small.hip
+
 extern "C" int msclip_gemm(const msclip_gemm_desc* d, void* stream) {
   if (!d || !d->X || !d->W || !d->out || !d->zero) return MSCLIP_EINVAL;
   if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->K % BK)) return MSCLIP_EINVAL;
@@ -1121,6 +1123,7 @@ extern "C" int msclip_gemm(const msclip_gemm_desc* d, void* stream) {
       (void)hipGetDevice(&dev);
       ncu = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
     }
+    if ((d->tile == 0 || d->tile == 5) && msclip_gemm_small_try(d, st, ncu)) return msclip_launch_status();
     const int tiles = ((d->M + 255) / 256) * ((d->N + 255) / 256);
     // 256-row tile offsets must fit the 32-bit buffer offsets of the ping-pong kernel's loads
     const bool pp_ok = (long long)d->ldx * 2 * 256 + (long long)d->K * 2 < (1ll << 31) &&

@@ -155,13 +155,15 @@ class KernelProbe:
 _gemm_probe = {}   # kernel variant -> KernelProbe
 
 
-def gemm_variant(mode, M, N, tile=0):
+def gemm_variant(mode, M, N, tile=0, K=None):
     """Which kernel msclip_gemm dispatches to (mirror of the rule in csrc/gemm.hip): 'pp' = gemm_pp_kernel (dense
-    256x256 ping-pong, the default for large problems), 'ring' = gemm_ring_kernel (tile 2), 'conv256'/'conv128' =
+    256x256 ping-pong, the default for large problems), 'ring' = gemm_ring_kernel (tile 2), 'stream' = gemm_stream_kernel (K <= 192), 'conv256'/'conv128' =
     gemm_kernel<1,...>, 'dense256'/'dense128' = gemm_kernel<0,...>."""
     big_tiles = ((M + 255) // 256) * ((N + 255) // 256)
     big = tile >= 2 or (tile == 0 and N >= 192 and big_tiles >= 128)
     if mode == 0:
+        if tile in (0, 5) and K is not None and K <= 192 and K % 64 == 0 and M >= 4096:
+            return "stream"
         if tile == 4 or (tile == 0 and big):
             return "pp"
         return "ring" if (big and tile != 3) else ("dense256" if big else "dense128")
@@ -205,7 +207,7 @@ def gemm(x, w, out, *, M=None, bias=None, resid=None, resid_kind=0, act=0, alpha
     d.alpha = alpha
     d.rpg, d.radd, d.roff = rpg, radd, roff
     d.tile = tile
-    probe = _gemm_probe.get(d.mode) or _gemm_probe.get(gemm_variant(d.mode, d.M, d.N, tile)) if _gemm_probe else None
+    probe = _gemm_probe.get(d.mode) or _gemm_probe.get(gemm_variant(d.mode, d.M, d.N, tile, d.K if d.rpg == INT_MAX and resid_kind != RESID_TABLE else None)) if _gemm_probe else None
     if probe is not None:
         k_alg = d.K if conv is None else conv[2] * (ktab_taps(ktab) if ktab is not None else 1)
         t0 = probe.begin()

@@ -52,6 +52,32 @@ def test_gemm_every_tile_config(gpu_device, tile, M, N, K):
         close(xres, r32 + base, 4e-3, 1e-4)
 
 
+@pytest.mark.parametrize("M,N,K,ldx", [(5000, 96, 64, 48), (4099, 48, 64, 48), (8000, 192, 128, 96), (4700, 192, 64, 64),
+                                         (4100, 768, 192, 192), (6000, 384, 192, 192), (4096, 40, 64, 64)])
+def test_gemm_streaming_small_k(gpu_device, M, N, K, ldx):
+    """Pointwise-conv shapes (K <= 192, rows of ldx < K elements overlapping the next row against zero weights)."""
+    cin = ldx
+    x = rnd(M + 2, ldx, seed=21, dtype=BF)                                       # 2 rows of slack past M
+    w = torch.zeros(N, K, dtype=BF, device="cuda")
+    w[:, :cin] = rnd(N, cin, seed=22, scale=0.08, dtype=BF)
+    b = rnd(N, seed=23)
+    base = x[:M].float() @ w[:, :cin].float().t() + b
+    assert hip.gemm_variant(0, M, N, 0, K) == "stream"
+    out = torch.full((M + 1, N), float("nan"), dtype=BF, device="cuda")
+    hip.gemm(x, w, out[:M], M=M, bias=b, act=hip.ACT_RELU, ldx=ldx)
+    close(out[:M], F.relu(base), 2e-2, 1e-2)
+    assert bool(torch.isnan(out[M].float()).all())
+    r16 = rnd(M, N, seed=24, dtype=BF)
+    hip.gemm(x, w, out[:M], M=M, bias=b, act=hip.ACT_RELU, resid=r16, resid_kind=hip.RESID_BF16, ldx=ldx)
+    close(out[:M], F.relu(base + r16.float()), 3e-2, 1e-2)
+    o32 = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    hip.gemm(x, w, o32, M=M, bias=b, alpha=0.5, ldx=ldx)
+    close(o32, 0.5 * (base - b) + b, 2e-3, 1e-4)
+    ref1 = out[:M].clone()
+    hip.gemm(x, w, out[:M], M=M, bias=b, act=hip.ACT_RELU, resid=r16, resid_kind=hip.RESID_BF16, ldx=ldx, tile=1)
+    close(out[:M], ref1, 2e-2, 1e-2)                                             # agrees with the 128x128 kernel
+
+
 def test_gemm_epilogues(gpu_device):
     M, N, K = 333, 256, 192
     x, w, b = rnd(M, K, seed=4, dtype=BF), rnd(N, K, seed=5, scale=0.08, dtype=BF), rnd(N, seed=6)
