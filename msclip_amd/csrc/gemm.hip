@@ -190,6 +190,22 @@ __device__ __forceinline__ f32x4 stg_read16(unsigned addr) {
   return v;
 }
 
+// Global-memory accesses of these epilogues carry address space 1 explicitly: a store through a generic pointer "may
+// alias LDS", and while it is pending the compiler guards the K loop's fragment reads with s_waitcnt vmcnt(0).
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+__device__ __forceinline__ void st_global(void* p, float4 v) { *(AS1 f32x4*)p = f32x4{v.x, v.y, v.z, v.w}; }
+__device__ __forceinline__ void st_global(void* p, uint4 v) { *(AS1 u32x4*)p = u32x4{v.x, v.y, v.z, v.w}; }
+__device__ __forceinline__ void st_global(void* p, uint2 v) { *(AS1 u32x2*)p = u32x2{v.x, v.y}; }
+__device__ __forceinline__ float4 ld_global_f4(const void* p) {
+  const f32x4 v = *(const AS1 f32x4*)p;
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ uint2 ld_global_u2(const void* p) {
+  const u32x2 v = *(const AS1 u32x2*)p;
+  return make_uint2(v[0], v[1]);
+}
+
 template <int TM, int TN, int RK, int ACT, int OUTK>
 __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[TN][TM], const msclip_gemm_desc& a, unsigned stg, int mw0,
                                               int nw0, int lane, const float4 (&bias4)[TN], PpTrace* tr = nullptr) {
@@ -201,7 +217,7 @@ __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[TN][TM], const mscli
   const int rk = RK >= 0 ? RK : a.resid_kind;
   const int act = ACT >= 0 ? ACT : a.act;
   const int outk = OUTK >= 0 ? OUTK : a.out_kind;
-  constexpr int RAHEAD = 3;                                      // residual blocks (32 x 32) requested ahead
+  constexpr int RAHEAD = 2;                                      // residual blocks (32 x 32) requested ahead
   float4 rv[RAHEAD][4];                                          // raw: fp32 x 4, or bf16 x 4 in .x/.y (unpacked at use)
   auto load_res = [&](int b, float4 (&dst)[4]) {
     const int tm = b / TN, tn = b % TN;
@@ -212,9 +228,9 @@ __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[TN][TM], const mscli
       if (n >= a.N) {
         dst[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       } else if (rk == 1) {
-        dst[i] = *(const float4*)((const float*)a.resid + row * a.ldr + n);
+        dst[i] = ld_global_f4((const float*)a.resid + row * a.ldr + n);
       } else {
-        const uint2 u = *(const uint2*)((const bf16_t*)a.resid + row * a.ldr + n);
+        const uint2 u = ld_global_u2((const bf16_t*)a.resid + row * a.ldr + n);
         dst[i] = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), 0.f, 0.f);
       }
     }
@@ -270,12 +286,12 @@ __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[TN][TM], const mscli
 #ifndef MSCLIP_ABLATE_EPI
       if (n >= a.N) {
       } else if (outk == 1) {
-        *(float4*)((float*)a.out + row * a.ldo + n) = v;
+        st_global((float*)a.out + row * a.ldo + n, v);
       } else {
         uint2 o;
         o.x = pack_bf16x2(v.x, v.y);
         o.y = pack_bf16x2(v.z, v.w);
-        *(uint2*)((bf16_t*)a.out + row * a.ldo + n) = o;
+        st_global((bf16_t*)a.out + row * a.ldo + n, o);
       }
 #else
       asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w), "v"(row), "v"(n));
@@ -916,11 +932,26 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
       for (int j = 0; j < TM; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    float4 bias4[TN];                              // this lane's epilogue columns (see epilogue_rows)
+    // Bias of this tile: requested here, first touched after the first vmcnt wait of the K loop.  The loads are
+    // unconditional (clamped index, zero page when there is no bias) and the lane id is recomputed: a predicated load
+    // or a reloaded spill at this point would bring an s_waitcnt vmcnt(0), i.e. a wait for the previous tile's stores.
+    int lane_s;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_s));
+    const float* bsrc = a.bias ? a.bias : (const float*)a.zero;
+    const int nlast = a.bias ? a.N - 1 : 0;
+    // bias4[i]: this lane's 4 epilogue columns of 32-column block i (see epilogue_rows).
+    // The loads are inline asm: the compiler must not know they are pending (it would wait for them -- and so for the
+    // previous tile's stores, the VM counter retires in order -- before entering the K loop).  They are older than the
+    // six DMA pieces the first vmcnt(6) of the K loop leaves in flight, and first read in the epilogue.
+    float4 bias4[TN];
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
-      const int n = cn0 + wn + i * 32 + (lane & 7) * 4;
-      bias4[i] = (a.bias && vec && n < a.N) ? *(const float4*)(a.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+      int n = cn0 + wn + i * 32 + (lane_s & 7) * 4;
+      n = n + 3 < nlast ? n : (nlast & ~3);
+      const float* p = bsrc + (vec ? n : 0);
+      f32x4 v;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(v) : "v"(p));
+      bias4[i] = make_float4(v[0], v[1], v[2], v[3]);
     }
     PP_STAMP(1);
 
@@ -1004,10 +1035,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
 #ifndef PP_NOWAIT
       asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
 #endif
-      // the bias loads of this tile are older than the six pieces still in flight: tell the compiler they landed
-#pragma unroll
-      for (int i = 0; i < TN; ++i)
-        asm volatile("" : "+v"(bias4[i].x), "+v"(bias4[i].y), "+v"(bias4[i].z), "+v"(bias4[i].w));
       PP_SYNC_IN();
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk)

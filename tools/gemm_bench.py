@@ -16,6 +16,9 @@ SHAPES = [  # (name, M, N, K, epilogue)
     ("proj ", 65024, 768, 3072, "resid"),
     ("txt0 ", 39424, 3072, 768, "gelu"),
     ("qkvnb", 65024, 2304, 768, "none"),
+    ("qkvs ", 2048, 2304, 768, "bias"),        # 72 tiles: a quarter of the CUs busy (epilogue without chip-wide bursts)
+    ("fcs  ", 2048, 3072, 768, "gelu"),
+    ("outs ", 6144, 768, 768, "resid"),
 ]
 FULL = False
 ZEROS = False
@@ -45,7 +48,7 @@ def run(name, M, N, K, epi, tile, iters=20, check=False):
     if check:
         ref_in = out.clone() if epi == "resid" else None
         hip.gemm(x, w, out, tile=tile, **kw)
-        rows = torch.tensor([0, 1, 255, 256, 4095, M - 1, M // 2 + 3], device="cuda")
+        rows = torch.tensor([0, 1, 255, 256, 4095, M - 1, M // 2 + 3], device="cuda").clamp(max=M - 1)
         ref = x[rows].float() @ w.float().t() + b
         if epi == "gelu":
             ref = ref * torch.sigmoid(1.702 * ref)
