@@ -301,6 +301,85 @@ __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[TN][TM], const mscli
   }
 }
 
+// bf16 outputs without a residual (QKV, c_fc).  The staged fp32 epilogue above is bound by its LDS-write and
+// store-instruction issue (8-byte stores, 16-byte LDS writes), so here bias and activation are applied in the
+// accumulator layout, the tile is packed to bf16 BEFORE staging (8-byte LDS writes, half the bytes) and a whole
+// 32-row x 64-column block of the wave is staged at once: the read-back hands every lane 16 bytes and a store
+// instruction writes 8 full 128-byte lines.  The wave's 64 bias values live in ONE register (lane j: column j,
+// requested at tile start) and reach the accumulator layout through v_readlane.
+__device__ __forceinline__ void stg_write8(unsigned addr, unsigned lo, unsigned hi) {
+  u32x2 v = {lo, hi};
+  asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ u32x4 stg_read16u(unsigned addr) {
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+
+template <int TM, int TN, int ACT>
+__device__ __forceinline__ void epilogue_pack16(f32x16 (&acc)[TN][TM], const msclip_gemm_desc& a, unsigned stg, int mw0,
+                                                int nw0, int lane, float bcol, PpTrace* tr = nullptr) {
+  static_assert(TN == 2, "64 bf16 columns = one 128-byte staged row");
+  const int fr = lane & 31, fhi = lane >> 5;
+  const int srow = lane >> 3, sch = lane & 7;
+  const unsigned wr = stg + fr * 128 + fhi * 8;
+  const int wsw = fr & 7;
+  const unsigned rd = stg + srow * 128 + ((sch ^ srow) << 4);    // + i * 1024 for rows i*8 + srow
+  float b[TN][16];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bcol), tn * 32 + g * 8 + e));
+        const float hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bcol), tn * 32 + g * 8 + 4 + e));
+        b[tn][g * 4 + e] = fhi ? hi : lo;
+      }
+  EPI_STAMP(10);
+  u32x4 x[2][4];
+  auto stage = [&](int tm, u32x4 (&dst)[4]) {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = acc[tn][tm][g * 4 + e] * a.alpha + b[tn][g * 4 + e];
+          if (ACT == 1) v[e] = v[e] / (1.f + __expf(-1.702f * v[e]));
+        }
+        stg_write8(wr + (((tn * 4 + g) ^ wsw) << 4), pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+      }
+    dst[0] = stg_read16u<0>(rd); dst[1] = stg_read16u<1024>(rd);
+    dst[2] = stg_read16u<2048>(rd); dst[3] = stg_read16u<3072>(rd);
+  };
+  stage(0, x[0]);
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    EPI_STAMP(11);
+    u32x4(&xb)[4] = x[tm & 1];
+    if (tm + 1 < TM) {
+      stage(tm + 1, x[(tm + 1) & 1]);
+      asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(xb[0]), "+v"(xb[1]), "+v"(xb[2]), "+v"(xb[3])::"memory");
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xb[0]), "+v"(xb[1]), "+v"(xb[2]), "+v"(xb[3])::"memory");
+    }
+    const int n = nw0 + sch * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const size_t row = (size_t)(mw0 + tm * 32 + i * 8 + srow);
+#ifndef MSCLIP_ABLATE_EPI
+      if (n < a.N) *(AS1 u32x4*)((bf16_t*)a.out + row * a.ldo + n) = xb[i];
+#else
+      asm volatile("" ::"v"(xb[i]), "v"(row), "v"(n));
+#endif
+    }
+  }
+}
+
 // Edge tiles, ragged N, unaligned leading dimensions, row scatter / table residual: guarded, straight from the
 // accumulator layout (lane owns row .. + (lane&31), columns .. + 8g + 4*(lane>>5) + 0..3).
 template <int TM, int TN>
@@ -943,6 +1022,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
     // The loads are inline asm: the compiler must not know they are pending (it would wait for them -- and so for the
     // previous tile's stores, the VM counter retires in order -- before entering the K loop).  They are older than the
     // six DMA pieces the first vmcnt(6) of the K loop leaves in flight, and first read in the epilogue.
+    float bcol;                                    // packed bf16 epilogue: lane j holds the bias of the wave's column j
+    {
+      const int n = cn0 + wn + lane_s;
+      const float* p = bsrc + (n < nlast ? n : nlast);
+      asm volatile("global_load_dword %0, %1, off" : "=&v"(bcol) : "v"(p));
+    }
     float4 bias4[TN];
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
@@ -1079,10 +1164,18 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
         (void)trp;
         epilogue_interior<TM, TN>(acc, a, (char*)smem + ss * (PREG * 2) + (wave & 3) * STG_BYTES, mw0, nw0, lane_e);
 #else
+#ifndef PP_ROWS16
+        const bool pack16 = a.resid_kind == 0 && a.out_kind == 0 && !((a.N | a.ldo) & 7);
+        if (pack16 && a.act == 0)
+          epilogue_pack16<TM, TN, 0>(acc, a, stg, mw0, nw0, lane_e, bcol, trp);               // QKV
+        else if (pack16 && a.act == 1)
+          epilogue_pack16<TM, TN, 1>(acc, a, stg, mw0, nw0, lane_e, bcol, trp);               // c_fc + QuickGELU
+#else
         if (a.resid_kind == 0 && a.act == 0 && a.out_kind == 0)
-          epilogue_rows<TM, TN, 0, 0, 0>(acc, a, stg, mw0, nw0, lane_e, bias4, trp);          // QKV
+          epilogue_rows<TM, TN, 0, 0, 0>(acc, a, stg, mw0, nw0, lane_e, bias4, trp);
         else if (a.resid_kind == 0 && a.act == 1 && a.out_kind == 0)
-          epilogue_rows<TM, TN, 0, 1, 0>(acc, a, stg, mw0, nw0, lane_e, bias4, trp);          // c_fc + QuickGELU
+          epilogue_rows<TM, TN, 0, 1, 0>(acc, a, stg, mw0, nw0, lane_e, bias4, trp);
+#endif
         else if (a.resid_kind == 1 && a.act == 0 && a.out_kind == 1)
           epilogue_rows<TM, TN, 1, 0, 1>(acc, a, stg, mw0, nw0, lane_e, bias4, trp);          // out_proj / c_proj into the fp32 stream
         else
