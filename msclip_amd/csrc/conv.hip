@@ -6,6 +6,7 @@
 //    two NHWC bf16 tensors;
 //  * the lateral adapters' non-overlapping depthwise "patch pooling" conv
 //    (kernel == stride, ibid. 1573-1581 with the PRALLEL_T2B_* geometry).
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/msclip_hip.h"
 
@@ -67,6 +68,117 @@ __global__ __launch_bounds__(256) void stem_dual_kernel(const InT* __restrict__ 
   }
 }
 
+
+// MFMA version of the same pass (what ships; the scalar kernel above stays as the cross-check of the parity test).
+// out[p, 0..95] = relu(bias + sum_{k<27} x[p, k] * w[k, :]) is a GEMM with K = 27 (padded to 32): a wave takes 32
+// consecutive output pixels, builds their im2col rows directly in the MFMA operand layout (lane = pixel, 16 of the
+// 32 taps per lane: 16 scalar loads from the NCHW image, requested one block ahead), multiplies them with the
+// 96 x 32 filter bank held in registers as bf16 (6 v_mfma_f32_32x32x16_bf16) and writes the two NHWC outputs through
+// a 6-KiB staging block as two contiguous 3-KiB runs (consecutive pixels are adjacent in NHWC).
+// The pass is HBM-bound: 4 B/pixel/channel in, 2 x 96 B per output pixel out.
+template <typename InT>
+__global__ __launch_bounds__(256) void stem_dual_mfma_kernel(const InT* __restrict__ img, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, bf16_t* __restrict__ out_a,
+                                                             bf16_t* __restrict__ out_b, int B, int H, int W, int Ho,
+                                                             int Wo) {
+  __shared__ __attribute__((aligned(16))) char stg_all[4 * 6144];
+  __shared__ __attribute__((aligned(16))) float bias_l[96];
+  if (threadIdx.x < 96) bias_l[threadIdx.x] = bias[threadIdx.x];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  char* stg = stg_all + wave * 6144;
+  const int fr = lane & 31, fhi = lane >> 5;
+
+  // filter bank as A fragments: tile t (32 output channels), k-step s (16 taps): lane (fr, fhi) holds taps
+  // s*16 + fhi*8 .. +8 of channel t*32 + fr
+  bf16x8 wf[3][2];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = s2 * 16 + fhi * 8 + e;
+        wf[t][s2][e] = (__bf16)(k < 27 ? w[k * 96 + t * 32 + fr] : 0.f);
+      }
+  // this lane's 16 taps: j < 8 -> tap fhi*8 + j, j >= 8 -> tap 16 + fhi*8 + (j - 8); offset inside the image + (kh, kw)
+  int toff[16];
+  unsigned top = 0, left = 0;                        // bit j: tap j sits in the window's top row / left column
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int k = (j < 8 ? 0 : 16) + fhi * 8 + (j & 7);
+    const int ci = k / 9, kh = (k % 9) / 3, kw = k % 3;
+    toff[j] = k < 27 ? (ci * H + kh) * W + kw : -1;
+    top |= (unsigned)(kh == 0) << j;
+    left |= (unsigned)(kw == 0) << j;
+  }
+
+  const long long total = (long long)B * Ho * Wo;
+  const long long nblk = (total + 31) / 32;
+  const long long stride = (long long)gridDim.x * 4;
+  auto load_block = [&](long long blk, float (&x)[16]) {
+    long long p = blk * 32 + fr;
+    p = p < total ? p : total - 1;
+    const int b = (int)(p / (Ho * Wo));
+    const int r = (int)(p - (long long)b * Ho * Wo);
+    const int ho = r / Wo, wo = r - ho * Wo;
+    const InT* base = img + ((size_t)b * 3 * H + (2 * ho - 1)) * W + (2 * wo - 1);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      // stride 2, pad 1, even H and W: only the top row at ho == 0 and the left column at wo == 0 leave the image
+      const bool ok = toff[j] >= 0 && !(ho == 0 && ((top >> j) & 1)) && !(wo == 0 && ((left >> j) & 1));
+      x[j] = ok ? ld_px<InT>(base + toff[j]) : 0.f;
+    }
+  };
+
+  long long blk = (long long)blockIdx.x * 4 + wave;
+  float xc[16], xn[16];
+  if (blk < nblk) load_block(blk, xc);
+  for (; blk < nblk; blk += stride) {
+    if (blk + stride < nblk) load_block(blk + stride, xn);
+    bf16x8 xf[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xf[s2][e] = (__bf16)xc[s2 * 8 + e];
+    f32x16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 b4 = *(const float4*)(bias_l + t * 32 + g * 8 + fhi * 4);
+        acc[t][g * 4 + 0] = b4.x; acc[t][g * 4 + 1] = b4.y; acc[t][g * 4 + 2] = b4.z; acc[t][g * 4 + 3] = b4.w;
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t][s2], xf[s2], acc[t], 0, 0, 0);
+    }
+    // stage: plane 0 = out_a rows [32][48], plane 1 = out_b rows; lane (fr, fhi) owns channels t*32 + g*8 + fhi*4 .. +4
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c = t * 32 + g * 8 + fhi * 4;                  // never straddles 48
+        uint2 o;
+        o.x = pack_bf16x2(fmaxf(acc[t][g * 4 + 0], 0.f), fmaxf(acc[t][g * 4 + 1], 0.f));
+        o.y = pack_bf16x2(fmaxf(acc[t][g * 4 + 2], 0.f), fmaxf(acc[t][g * 4 + 3], 0.f));
+        const int plane = c >= 48, cc = c - plane * 48;
+        *(uint2*)(stg + plane * 3072 + fr * 96 + cc * 2) = o;
+      }
+    const long long p0 = blk * 32;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int ch = i * 64 + lane;                              // 16-byte chunk of the 3-KiB run; 6 chunks per pixel
+      if (p0 + ch / 6 < total) {
+        *(uint4*)((char*)(out_a + (size_t)p0 * 48) + ch * 16) = *(const uint4*)(stg + ch * 16);
+        *(uint4*)((char*)(out_b + (size_t)p0 * 48) + ch * 16) = *(const uint4*)(stg + 3072 + ch * 16);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) xc[j] = xn[j];
+  }
+}
+
 // out[b, gy, gx, c] = sum_{ky,kx<k} w[ky*k+kx][c] * top[b, gy*k+ky, gx*k+kx, c]   (NHWC bf16, k == stride, pad 0)
 __global__ __launch_bounds__(256) void dwpool_kernel(const bf16_t* __restrict__ top, const float* __restrict__ w,
                                                      bf16_t* __restrict__ out, int ldo, int B, int H, int W, int C,
@@ -109,16 +221,30 @@ __global__ __launch_bounds__(256) void dwpool_kernel(const bf16_t* __restrict__ 
 
 extern "C" int msclip_stem_conv3x3s2_dual(const void* img, int img_is_bf16, const float* w, const float* bias,
                                           void* out_a, void* out_b, int B, int H, int W, int C1, void* stream) {
-  if (!img || !w || !bias || !out_a || !out_b || B <= 0 || C1 != 48) return MSCLIP_EINVAL;
+  if (!img || !w || !bias || !out_a || !out_b || B <= 0 || C1 != 48 || H < 2 || W < 2 || (H & 1) || (W & 1)) return MSCLIP_EINVAL;
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const long long total = (long long)B * Ho * Wo;
-  const dim3 grid((unsigned)((total + 255) / 256)), blk(256);
   hipStream_t st = (hipStream_t)stream;
+  const char* scalar = getenv("MSCLIP_STEM_SCALAR");            // the VALU kernel, for cross-checks only
+  if (scalar && scalar[0] == '1') {
+    const dim3 grid((unsigned)((total + 255) / 256)), blk(256);
+    if (img_is_bf16)
+      hipLaunchKernelGGL((stem_dual_kernel<bf16_t, 48>), grid, blk, 0, st, (const bf16_t*)img, w, bias, (bf16_t*)out_a,
+                         (bf16_t*)out_b, B, H, W, Ho, Wo);
+    else
+      hipLaunchKernelGGL((stem_dual_kernel<float, 48>), grid, blk, 0, st, (const float*)img, w, bias, (bf16_t*)out_a,
+                         (bf16_t*)out_b, B, H, W, Ho, Wo);
+    return msclip_launch_status();
+  }
+  const long long nblk = (total + 31) / 32;
+  long long g = (nblk + 3) / 4;
+  if (g > 256 * 8) g = 256 * 8;                                  // persistent: up to 8 workgroups of 4 waves per CU
+  const dim3 grid((unsigned)g), blk(256);
   if (img_is_bf16)
-    hipLaunchKernelGGL((stem_dual_kernel<bf16_t, 48>), grid, blk, 0, st, (const bf16_t*)img, w, bias, (bf16_t*)out_a,
+    hipLaunchKernelGGL((stem_dual_mfma_kernel<bf16_t>), grid, blk, 0, st, (const bf16_t*)img, w, bias, (bf16_t*)out_a,
                        (bf16_t*)out_b, B, H, W, Ho, Wo);
   else
-    hipLaunchKernelGGL((stem_dual_kernel<float, 48>), grid, blk, 0, st, (const float*)img, w, bias, (bf16_t*)out_a,
+    hipLaunchKernelGGL((stem_dual_mfma_kernel<float>), grid, blk, 0, st, (const float*)img, w, bias, (bf16_t*)out_a,
                        (bf16_t*)out_b, B, H, W, Ho, Wo);
   return msclip_launch_status();
 }
