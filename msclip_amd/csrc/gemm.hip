@@ -1235,15 +1235,15 @@ extern "C" int msclip_gemm(const msclip_gemm_desc* d, void* stream) {
   // tile choice: the 256x256 / 8-wave config whenever the problem fills the chip with it, else 128x128
   const long long big_tiles = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256);
   const bool big = d->tile >= 2 || (d->tile == 0 && d->N >= 192 && big_tiles >= 128);
+  static int ncu = 0;
+  if (!ncu) {
+    hipDeviceProp_t p;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    ncu = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+  }
+  if ((d->tile == 0 || d->tile == 5) && msclip_gemm_small_try(d, st, ncu)) return msclip_launch_status();
   if (d->mode == 0) {
-    static int ncu = 0;
-    if (!ncu) {
-      hipDeviceProp_t p;
-      int dev = 0;
-      (void)hipGetDevice(&dev);
-      ncu = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
-    }
-    if ((d->tile == 0 || d->tile == 5) && msclip_gemm_small_try(d, st, ncu)) return msclip_launch_status();
     const int tiles = ((d->M + 255) / 256) * ((d->N + 255) / 256);
     // 256-row tile offsets must fit the 32-bit buffer offsets of the ping-pong kernel's loads
     const bool pp_ok = (long long)d->ldx * 2 * 256 + (long long)d->K * 2 < (1ll << 31) &&

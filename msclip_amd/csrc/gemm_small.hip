@@ -10,23 +10,27 @@
 //     consecutive columns of one row -> bias / activation / residual / conversion -> 16-byte stores (bf16) or two
 //     16-byte stores (fp32) that cover whole 64 / 128-byte row segments.
 // N wider than NW is covered by several column chunks (blockIdx.y); X is then re-read from L2.
+// The same kernel runs the implicit-GEMM convolutions whose weights fit LDS (CONV = true): the 1x1 stride-2
+// shortcuts and the two 3x3 stride-2 layers with 48 input channels (K = 432).  A lane's row is an output pixel and
+// k-step s reads 16 bytes at pixel base + ktab[2s + lane/32] (the table of include/msclip_hip.h, mode 1; taps outside
+// the image and table padding read as zero).
+#include <type_traits>
 #include "common.h"
 #include "../../include/msclip_hip.h"
 
 namespace {
 
-constexpr int SW = 4;                       // waves per workgroup
-constexpr int SSTG_ROW = 144;               // staging row: 32 fp32 + 16 B pad (9 slots: conflict-free both ways)
+constexpr int SSTG_ROW = 144;               // staging row: 32 fp32 + 16 B pad (an odd number of 16-byte slots)
 constexpr int SSTG_BYTES = 32 * SSTG_ROW;   // per wave
 
-template <int NT>
-__global__ __launch_bounds__(SW * 64) void gemm_stream_kernel(const msclip_gemm_desc a) {
+// NT: 32-column tiles per wave, NKC: K / 64, SWV: waves per workgroup
+template <int NT, int NKC, bool CONV, int SWV>
+__global__ __launch_bounds__(SWV * 64) void gemm_stream_kernel(const msclip_gemm_desc a) {
   extern __shared__ __attribute__((aligned(16))) char slds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  constexpr int NW = NT * 32;
-  const int K = a.K;
-  const int wstride = K * 2 + 16;                               // bytes per weight row in LDS
+  constexpr int NW = NT * 32, K = NKC * 64;
+  constexpr int wstride = K * 2 + 16;                           // bytes per weight row in LDS
   char* wl = slds;                                              // [NW][wstride]
   float* bl = (float*)(slds + NW * wstride);                    // [NW]
   char* stg = slds + NW * wstride + NW * 4 + wave * SSTG_BYTES;
@@ -34,42 +38,69 @@ __global__ __launch_bounds__(SW * 64) void gemm_stream_kernel(const msclip_gemm_
 
   // ---- resident operands
   const bf16_t* __restrict__ W = (const bf16_t*)a.W;
-  const int cpr = K / 8;                                        // 16-byte chunks per weight row
-  for (int i = tid; i < NW * cpr; i += SW * 64) {
+  constexpr int cpr = K / 8;                                    // 16-byte chunks per weight row
+  for (int i = tid; i < NW * cpr; i += SWV * 64) {
     const int r = i / cpr, c = i - r * cpr;
     uint4 v = make_uint4(0u, 0u, 0u, 0u);
     if (n0 + r < a.N) v = *(const uint4*)(W + (size_t)(n0 + r) * a.ldw + c * 8);
     *(uint4*)(wl + r * wstride + c * 16) = v;
   }
-  for (int i = tid; i < NW; i += SW * 64) bl[i] = (a.bias && n0 + i < a.N) ? a.bias[n0 + i] : 0.f;
+  for (int i = tid; i < NW; i += SWV * 64) bl[i] = (a.bias && n0 + i < a.N) ? a.bias[n0 + i] : 0.f;
   __syncthreads();
 
   const int fr = lane & 31, fhi = lane >> 5;
   const bf16_t* __restrict__ X = (const bf16_t*)a.X;
   const int nblk = (a.M + 31) / 32;
-  const int nkc = K / 64;
-  const int wpc = gridDim.x * SW;                               // waves per column chunk
+  const int wpc = gridDim.x * SWV;                              // waves per column chunk
+
+  // conv mode: this lane's chunk-table entries, k-step s -> entry 2s + fhi
+  int ent[CONV ? NKC * 4 : 1];
+  if (CONV) {
+#pragma unroll
+    for (int s2 = 0; s2 < NKC * 4; ++s2) ent[s2] = a.ktab[s2 * 2 + fhi];
+  }
+  struct Row { const bf16_t* p; int ih0, iw0; };
   auto xrow = [&](int blk) {
     int m = blk * 32 + fr;
     m = m < a.M ? m : a.M - 1;
-    return X + (size_t)m * a.ldx + fhi * 8;
+    Row r;
+    if (CONV) {
+      const int hw = a.Ho * a.Wo;
+      const int b = m / hw, rem = m - b * hw;
+      const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+      r.ih0 = ho * a.stride - a.pad;
+      r.iw0 = wo * a.stride - a.pad;
+      r.p = X + (((long long)b * a.H + r.ih0) * a.Wd + r.iw0) * a.Cin;   // may point before the image: guarded below
+    } else {
+      r.p = X + (size_t)m * a.ldx + fhi * 8;
+      r.ih0 = r.iw0 = 0;
+    }
+    return r;
   };
-  auto load_chunk = [&](const bf16_t* p, int kc, uint4 (&d)[4]) {
+  auto load_chunk = [&](const Row& r, auto kcc, uint4 (&d)[4]) {
+    constexpr int kc = decltype(kcc)::value;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) d[ks] = *(const uint4*)(p + kc * 64 + ks * 16);
+    for (int ks = 0; ks < 4; ++ks) {
+      if (CONV) {
+        const int e = ent[kc * 4 + ks];
+        const int ih = r.ih0 + ((e >> 20) & 15), iw = r.iw0 + ((e >> 24) & 15);
+        const bool ok = e >= 0 && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.Wd;
+        const uint4 v = *(const uint4*)(ok ? r.p + (e & 0xfffff) : X);
+        d[ks] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
+      } else {
+        d[ks] = *(const uint4*)(r.p + kc * 64 + ks * 16);
+      }
+    }
   };
 
   // read-back mapping of the staging block: pass p covers rows 16p + lane/4, the lane owns columns 8*(lane%4) .. +8
   const int rr = lane >> 2, rc = lane & 3;
   const bool vec = !((a.N | a.ldo | (a.resid_kind ? a.ldr : 0)) & 7);
 
-  int blk = blockIdx.x * SW + wave;
-  uint4 xa[4], xb[4];
-  const bf16_t* xp = nullptr;
-  if (blk < nblk) {
-    xp = xrow(blk);
-    load_chunk(xp, 0, xa);
-  }
+  int blk = blockIdx.x * SWV + wave;
+  uint4 xq[2][4];
+  Row xp = xrow(blk < nblk ? blk : 0);
+  if (blk < nblk) load_chunk(xp, std::integral_constant<int, 0>{}, xq[0]);
   for (; blk < nblk; blk += wpc) {
     f32x16 acc[NT];
 #pragma unroll
@@ -77,37 +108,34 @@ __global__ __launch_bounds__(SW * 64) void gemm_stream_kernel(const msclip_gemm_
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     const int nxt = blk + wpc;
-    const bf16_t* xn = nxt < nblk ? xrow(nxt) : xp;
+    const Row xn = xrow(nxt < nblk ? nxt : blk);
 
-    // ---- K loop: chunk kc lives in xa (even) / xb (odd), the following chunk is requested before the MFMAs
-    for (int kc = 0; kc < nkc; kc += 2) {
-      if (kc + 1 < nkc) load_chunk(xp, kc + 1, xb);
-      else load_chunk(xn, 0, xb);                               // last chunk of the block: next block's first one
+    // ---- K loop: chunk kc sits in xq[kc & 1]; the following chunk (or the next block's first) is requested first
+    auto kstep = [&](auto kcc) {
+      constexpr int kc = decltype(kcc)::value;
+      if (kc + 1 < NKC) load_chunk(xp, std::integral_constant<int, (kc + 1 < NKC ? kc + 1 : 0)>{}, xq[(kc + 1) & 1]);
+      else load_chunk(xn, std::integral_constant<int, 0>{}, xq[(kc + 1) & 1]);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(&xa[ks]);
+        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(&xq[kc & 1][ks]);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const bf16x8 wf = *(const bf16x8*)(wl + (t * 32 + fr) * wstride + (kc * 8 + ks * 2 + fhi) * 16);
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[t], 0, 0, 0);
         }
       }
-      if (kc + 1 < nkc) {
-        if (kc + 2 < nkc) load_chunk(xp, kc + 2, xa);
-        else load_chunk(xn, 0, xa);
+    };
+    kstep(std::integral_constant<int, 0>{});
+    if constexpr (NKC > 1) kstep(std::integral_constant<int, 1>{});
+    if constexpr (NKC > 2) kstep(std::integral_constant<int, 2>{});
+    if constexpr (NKC > 3) kstep(std::integral_constant<int, 3>{});
+    if constexpr (NKC > 4) kstep(std::integral_constant<int, 4>{});
+    if constexpr (NKC > 5) kstep(std::integral_constant<int, 5>{});
+    if constexpr (NKC > 6) kstep(std::integral_constant<int, 6>{});
+    static_assert(NKC <= 7, "unrolled K chunks");
+    if constexpr (NKC & 1) {                                    // the prefetched chunk moves to the even buffer
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const bf16x8 xf = *reinterpret_cast<const bf16x8*>(&xb[ks]);
-#pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            const bf16x8 wf = *(const bf16x8*)(wl + (t * 32 + fr) * wstride + ((kc + 1) * 8 + ks * 2 + fhi) * 16);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[t], 0, 0, 0);
-          }
-        }
-      } else {
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) xa[ks] = xb[ks];         // odd chunk count: the prefetched chunk moves to xa
-      }
+      for (int ks = 0; ks < 4; ++ks) xq[0][ks] = xq[1][ks];
     }
     xp = xn;
 
@@ -185,37 +213,72 @@ __global__ __launch_bounds__(SW * 64) void gemm_stream_kernel(const msclip_gemm_
   }
 }
 
-template <int NT>
-void launch_stream(const msclip_gemm_desc* d, hipStream_t st, int ncu) {
+template <int NT, int NKC, bool CONV, int SWV>
+void launch_stream(const msclip_gemm_desc* d, hipStream_t st, int ncu, int wg_per_cu) {
   constexpr int NW = NT * 32;
   const int chunks = (d->N + NW - 1) / NW;
-  const size_t lds = (size_t)NW * (d->K * 2 + 16) + NW * 4 + SW * SSTG_BYTES;
+  const size_t lds = (size_t)NW * (NKC * 128 + 16) + NW * 4 + SWV * SSTG_BYTES;
+  if (lds > 65536) {
+    static bool done = false;                                   // per instantiation
+    if (!done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stream_kernel<NT, NKC, CONV, SWV>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      done = true;
+    }
+  }
   const int nblk = (d->M + 31) / 32;
-  int gx = (2 * ncu + chunks - 1) / chunks;                     // ~2 workgroups per CU over all column chunks
-  const int need = (nblk + SW - 1) / SW;
+  int gx = (wg_per_cu * ncu + chunks - 1) / chunks;
+  const int need = (nblk + SWV - 1) / SWV;
   if (gx > need) gx = need;
   if (gx < 1) gx = 1;
-  hipLaunchKernelGGL(gemm_stream_kernel<NT>, dim3(gx, chunks), dim3(SW * 64), lds, st, *d);
+  hipLaunchKernelGGL((gemm_stream_kernel<NT, NKC, CONV, SWV>), dim3(gx, chunks), dim3(SWV * 64), lds, st, *d);
+}
+
+template <bool CONV>
+bool dispatch_stream(const msclip_gemm_desc* d, hipStream_t st, int ncu) {
+  const int n32 = (d->N + 31) / 32;
+  const int nkc = d->K / 64;
+  if (nkc == 7) {                                               // 3x3, 48 input channels: all of W resident, 8 waves
+    if (!CONV || n32 > 3) return false;
+    if (n32 == 3) launch_stream<3, 7, CONV, 8>(d, st, ncu, 1);
+    else launch_stream<2, 7, CONV, 8>(d, st, ncu, 1);
+    return true;
+  }
+  // the resident weights (K*2 + 16 B per row) stay under 40 KiB so that, with the staging blocks, two workgroups fit
+  // a CU: up to 192 columns at K = 64, 96 beyond
+  int nt;
+  if (n32 <= 2) nt = 2;
+  else if (nkc == 1 && n32 % 6 == 0) nt = 6;
+  else if (n32 % 3 == 0) nt = 3;
+  else nt = 2;
+  if (nkc == 1) {
+    if (nt == 2) launch_stream<2, 1, CONV, 4>(d, st, ncu, 2);
+    else if (nt == 3) launch_stream<3, 1, CONV, 4>(d, st, ncu, 2);
+    else launch_stream<6, 1, CONV, 4>(d, st, ncu, 2);
+  } else if (nkc == 2) {
+    if (nt == 2) launch_stream<2, 2, CONV, 4>(d, st, ncu, 2);
+    else launch_stream<3, 2, CONV, 4>(d, st, ncu, 2);
+  } else {
+    if (nt == 2) launch_stream<2, 3, CONV, 4>(d, st, ncu, 2);
+    else launch_stream<3, 3, CONV, 4>(d, st, ncu, 2);
+  }
+  return true;
 }
 
 }  // namespace
 
-// Takes the launch if the problem is a plain dense GEMM with a short K; returns false otherwise.
+// Takes the launch if the problem streams (short K, weights resident in LDS); returns false otherwise.
 bool msclip_gemm_small_try(const msclip_gemm_desc* d, hipStream_t st, int ncu) {
-  if (d->mode != 0 || d->K > 192 || (d->K % 64) || d->M < 4096) return false;
+  if ((d->K % 64) || d->M < 4096) return false;
   if (d->rpg != 0x7fffffff || d->radd || d->roff || d->resid_kind == 3) return false;
-  if ((d->ldx % 8) || (d->ldw % 8)) return false;
-  // columns per workgroup: weights (K*2 + 16 B per row) + staging must leave room for two workgroups per CU
-  // columns per workgroup: the resident weights (K*2 + 16 B per row) stay under 40 KiB so that, with the staging
-  // blocks, two workgroups fit a CU: up to 192 columns at K = 64, 96 beyond
-  const int n32 = (d->N + 31) / 32;
-  int nt;
-  if (n32 <= 2) nt = 2;
-  else if (d->K == 64 && n32 % 6 == 0) nt = 6;
-  else if (n32 % 3 == 0) nt = 3;
-  else nt = 2;
-  if (nt == 2) launch_stream<2>(d, st, ncu);
-  else if (nt == 3) launch_stream<3>(d, st, ncu);
-  else launch_stream<6>(d, st, ncu);
-  return true;
+  if (d->ldw % 8) return false;
+  if (d->mode == 0) {
+    if (d->K > 192 || (d->ldx % 8)) return false;
+    return dispatch_stream<false>(d, st, ncu);
+  }
+  if (d->mode == 1) {
+    if (!d->ktab || (d->Cin % 8) || !(d->K <= 192 || d->K == 448)) return false;
+    return dispatch_stream<true>(d, st, ncu);
+  }
+  return false;
 }
