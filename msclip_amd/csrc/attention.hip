@@ -19,6 +19,7 @@
 //   k-step s of PV contracts 16 keys; the order of keys inside a k-step only has
 //   to agree between A and B, so V^T is written to LDS in the order the S^T
 //   accumulator layout yields: key 16s + w  ->  slot 16s + 8*((w>>2)&1) + (w&3) + 4*(w>>3).
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/msclip_hip.h"
 
@@ -272,6 +273,152 @@ __global__ __launch_bounds__(WPB * 64) void attn_kernel(const bf16_t* __restrict
   }
 }
 
+// Longer sequences (L = 197 for the 16-pixel patch grid): one WORKGROUP of 4 waves per (sample, head).  K (row-major,
+// rows padded to 144 B: conflict-free fragment reads) and V^T (slot-permuted as above) are loaded into LDS once,
+// cooperatively and in full rows; wave w then takes the query tiles w, w+4: its Q fragments come straight from HBM
+// (requested one tile ahead), the K fragments of S^T = K.Q^T and the V^T fragments of O^T = V^T.P^T from LDS.
+// Two workgroups fit a CU (57 KiB each), i.e. two waves per SIMD overlap one wave's softmax VALU work with the
+// other's MFMAs.  (The one-wave-per-pair kernel above re-read K from HBM for every query tile and ran at one wave
+// per SIMD: 268 us per layer at B = 256 against 61 GFLOP of work.)
+template <int NT, bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_wg_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                      int nsamples, int L, int H, int ldq, int ldo) {
+  constexpr int KP = NT * 32;
+  constexpr int KPS = KP + 8;        // V^T row stride (elements)
+  constexpr int KROW = 72;           // K row stride (elements): 144 B
+  __shared__ __attribute__((aligned(16))) bf16_t kl[KP * KROW];
+  __shared__ __attribute__((aligned(16))) bf16_t vt[64 * KPS];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pair = blockIdx.x;
+  const int b = pair / H, h = pair - b * H;
+  const size_t row0 = (size_t)b * L;
+  const bf16_t* qbase = qkv + row0 * ldq + h * 64;
+  const bf16_t* kbase = qbase + H * 64;
+  const bf16_t* vbase = qbase + 2 * H * 64;
+  const int fr = lane & 31, fhi = lane >> 5;
+
+  // ---- this wave's first Q tile is requested before the cooperative K / V pass
+  auto load_q = [&](int qt, bf16x8 (&qf)[4]) {
+    const int qrow = min(qt * 32 + fr, L - 1);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const bf16x8*)(qbase + (size_t)qrow * ldq + (kk * 2 + fhi) * 8);
+  };
+  bf16x8 qcur[4], qnext[4];
+  if (wave * 32 < L) load_q(wave, qcur);
+
+  // ---- K rows and V^T into LDS (8 threads per row, 16 B each; padded keys are zero)
+  {
+    const int c = tid & 7;
+    for (int key = tid >> 3; key < KP; key += 32) {
+      uint4 ku = make_uint4(0, 0, 0, 0), vu = make_uint4(0, 0, 0, 0);
+      if (key < L) {
+        ku = *(const uint4*)(kbase + (size_t)key * ldq + c * 8);
+        vu = *(const uint4*)(vbase + (size_t)key * ldq + c * 8);
+      }
+      *(uint4*)(kl + key * KROW + c * 8) = ku;
+      const int w = key & 15;
+      const int slot = (key & ~15) + (((w >> 2) & 1) << 3) + (w & 3) + ((w >> 3) << 2);
+      bf16_t* dst = vt + (c * 8) * KPS + slot;
+      dst[0 * KPS] = (bf16_t)(vu.x & 0xffff); dst[1 * KPS] = (bf16_t)(vu.x >> 16);
+      dst[2 * KPS] = (bf16_t)(vu.y & 0xffff); dst[3 * KPS] = (bf16_t)(vu.y >> 16);
+      dst[4 * KPS] = (bf16_t)(vu.z & 0xffff); dst[5 * KPS] = (bf16_t)(vu.z >> 16);
+      dst[6 * KPS] = (bf16_t)(vu.w & 0xffff); dst[7 * KPS] = (bf16_t)(vu.w >> 16);
+    }
+  }
+  __syncthreads();
+
+  for (int qt = wave; qt < NT && qt * 32 < L; qt += 4) {
+    if ((qt + 4) < NT && (qt + 4) * 32 < L) load_q(qt + 4, qnext);
+    const int nkt = CAUSAL ? (qt + 1) : NT;
+    f32x16 s[NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+      if (kt < nkt && kt * 32 < L) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const bf16x8 kf = *(const bf16x8*)(kl + (kt * 32 + fr) * KROW + (kk * 2 + fhi) * 8);
+          s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qcur[kk], s[kt], 0, 0, 0);
+        }
+      }
+    }
+    const int q = qt * 32 + fr;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
+        const bool ok = key < L && (!CAUSAL || key <= q) && kt < nkt;
+        s[kt][r] = ok ? s[kt][r] : -INFINITY;
+        mx = fmaxf(mx, s[kt][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __expf(s[kt][r] - mx);
+        s[kt][r] = p;
+        sum += p;
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.f / sum;
+    f32x16 o[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+      if (kt < nkt && kt * 32 < L) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          bf16x8 pf;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) pf[e] = (__bf16)s[kt][half * 8 + e];
+          const int st = kt * 2 + half;
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            const bf16x8 vf = *(const bf16x8*)(vt + (dt * 32 + fr) * KPS + st * 16 + fhi * 8);
+            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (q < L) {
+      bf16_t* orow = out + (row0 + q) * ldo + h * 64;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          uint2 v;
+          v.x = pack_bf16x2(o[dt][g * 4 + 0] * inv, o[dt][g * 4 + 1] * inv);
+          v.y = pack_bf16x2(o[dt][g * 4 + 2] * inv, o[dt][g * 4 + 3] * inv);
+          *(uint2*)(orow + dt * 32 + g * 8 + fhi * 4) = v;
+        }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qcur[kk] = qnext[kk];
+  }
+}
+
+template <int NT>
+int launch_wg(const void* qkv, void* out, int nsamples, int L, int H, int ldq, int ldo, int causal, hipStream_t st) {
+  const int pairs = nsamples * H;
+  if (causal)
+    hipLaunchKernelGGL((attn_wg_kernel<NT, true>), dim3(pairs), dim3(256), 0, st, (const bf16_t*)qkv, (bf16_t*)out,
+                       nsamples, L, H, ldq, ldo);
+  else
+    hipLaunchKernelGGL((attn_wg_kernel<NT, false>), dim3(pairs), dim3(256), 0, st, (const bf16_t*)qkv, (bf16_t*)out,
+                       nsamples, L, H, ldq, ldo);
+  return msclip_launch_status();
+}
+
 template <int NT>
 int launch(const void* qkv, void* out, int nsamples, int L, int H, int ldq, int ldo, int causal, hipStream_t st) {
   constexpr int WPB = NT > 4 ? 2 : 4;  // keep dynamic LDS under 64 KiB
@@ -295,6 +442,10 @@ extern "C" int msclip_attention(const void* qkv, void* out, int nsamples, int L,
   hipStream_t st = (hipStream_t)stream;
   if (L <= 64) return launch<2>(qkv, out, nsamples, L, heads, ldq, ldo, causal, st);
   if (L <= 96) return launch<3>(qkv, out, nsamples, L, heads, ldq, ldo, causal, st);
-  if (L <= 224) return launch<7>(qkv, out, nsamples, L, heads, ldq, ldo, causal, st);
+  if (L <= 224) {
+    const char* old = getenv("MSCLIP_ATTN_WAVE");           // the one-wave-per-pair kernel, for cross-checks only
+    if (old && old[0] == '1') return launch<7>(qkv, out, nsamples, L, heads, ldq, ldo, causal, st);
+    return launch_wg<7>(qkv, out, nsamples, L, heads, ldq, ldo, causal, st);
+  }
   return MSCLIP_EINVAL;
 }
