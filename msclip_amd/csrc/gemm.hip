@@ -372,7 +372,9 @@ __device__ __forceinline__ void epilogue_pack16(f32x16 (&acc)[TN][TM], const msc
     for (int i = 0; i < 4; ++i) {
       const size_t row = (size_t)(mw0 + tm * 32 + i * 8 + srow);
 #ifndef MSCLIP_ABLATE_EPI
-      if (n < a.N) *(AS1 u32x4*)((bf16_t*)a.out + row * a.ldo + n) = xb[i];
+      // non-temporal: the tile leaves faster (QKV 262 -> 249 us, c_fc 378 -> 365 us; +0.7 % on the step), the fp32
+      // stream of out_proj / c_proj stays cacheable for the LayerNorm that follows
+      if (n < a.N) __builtin_nontemporal_store(xb[i], (AS1 u32x4*)((bf16_t*)a.out + row * a.ldo + n));
 #else
       asm volatile("" ::"v"(xb[i]), "v"(row), "v"(n));
 #endif
