@@ -51,7 +51,7 @@ typedef struct msclip_gemm_desc {
   int out_kind;
   float alpha;
   int rpg, radd, roff;   /* rpg > 0; use rpg = INT_MAX, radd = roff = 0 for the identity */
-  int tile;              /* 0 = auto, 1 = 128x128 (4 waves), 2 = 256x256 streaming ring (dense) / two-buffer (conv), 3 = 256x256 two-buffer, 4 = 256x256 ping-pong (dense; what auto picks for large problems), 5 = streaming kernel with LDS-resident weights (K <= 192, or the 3x3 convolutions with 48 input channels; M >= 4096; auto picks it there) */
+  int tile;              /* 0 = auto, 1 = 128x128 (4 waves), 2 = 256x256 streaming ring (dense) / two-buffer (conv), 3 = 256x256 two-buffer, 4 = 256x256 ping-pong (dense; what auto picks for large problems), 5 = streaming kernel with LDS-resident weights (K <= 192, or the 3x3 convolutions with 48 input channels; M >= 4096; auto picks it there), 6 = 256x192 two-buffer (implicit conv with N % 192 == 0) */
 } msclip_gemm_desc;
 
 int msclip_gemm(const msclip_gemm_desc* desc, void* stream);

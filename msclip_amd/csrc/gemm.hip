@@ -68,7 +68,7 @@ __device__ __forceinline__ void epilogue_interior(f32x16 (&acc)[TN][TM], const m
     for (int g = 0; g < 4; ++g)
       bv[tn][g] = (bias && nw0 + fhi * 4 + tn * 32 + g * 8 < a.N) ? *(const float4*)(bias + nw0 + fhi * 4 + tn * 32 + g * 8)
                                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
-  const bool direct16 = a.out_kind == 0 && a.resid_kind == 0;   // bf16 out, nothing to add after the transpose
+  const bool direct16 = TN == 2 && a.out_kind == 0 && a.resid_kind == 0;   // bf16 out, nothing to add after the transpose
   char* wr = stg + fr * 128;
   const int wsw = fr & 7;
   const char* rd = stg + srow * 128 + ((sch ^ srow) << 4);      // + i * 1024 for row block i
@@ -77,10 +77,9 @@ __device__ __forceinline__ void epilogue_interior(f32x16 (&acc)[TN][TM], const m
   for (int tm = 0; tm < TM; ++tm) {
     const int mrow0 = mw0 + tm * 32;
     EPI_STAMP(11);
-    if (direct16) {
-      static_assert(TN == 2, "64 bf16 columns per staged row");
+    if (direct16) {                                  // 64 bf16 columns per staged row: TN == 2 only
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn)
+      for (int tn = 0; tn < (TN == 2 ? TN : 0); ++tn)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           float v0 = acc[tn][tm][g * 4 + 0] * a.alpha + bv[tn][g].x;
@@ -463,8 +462,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const msclip_gemm
   constexpr int NT = NW * 64;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int XI = BM * 8 / NT, WI = BN * 8 / NT;   // LDS-DMA pieces per lane per K-slab
-  constexpr int NV = (XI + WI) / 4;                   // pieces issued per k-step
-  static_assert(XI >= 1 && WI >= 1 && (NW % 2) == 0 && (XI + WI) % 4 == 0 && TN == 2, "tile config");
+  constexpr int NPC = XI + WI;                        // pieces per lane per K-slab, spread over the 4 k-steps
+  static_assert(XI >= 1 && WI >= 1 && (NW % 2) == 0 && NPC >= 4 && (TN == 2 || TN == 3), "tile config");
   static_assert((BM + BN) * BK * 2 >= NW * STG_BYTES, "staging region per wave");
   __shared__ __attribute__((aligned(1024))) bf16_t smem[2][(BM + BN) * BK];  // [buf][X rows | W rows][64]
 
@@ -622,8 +621,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const msclip_gemm
 #pragma unroll
           for (int j = 0; j < TM; ++j) xf[(kk + 1) & 1][j] = *(const bf16x8*)(xs + j * 32 * BK + ph);
         }
+        constexpr int NV0 = NPC / 4, NVR = NPC % 4;  // k-step kk issues NV0 (+1 while kk < NVR) pieces
+        const int nvk = NV0 + (kk < NVR ? 1 : 0);
+        const int pv0 = kk * NV0 + (kk < NVR ? kk : NVR);
 #pragma unroll
-        for (int v = 0; v < NV; ++v) glds16(src[kk * NV + v], piece_dst(nb, kk * NV + v));
+        for (int v = 0; v < NV0 + 1; ++v)
+          if (v < nvk) glds16(src[pv0 + v], piece_dst(nb, pv0 + v));
 #pragma unroll
         for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -639,7 +642,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const msclip_gemm
         for (int q = 0; q < TM * TN; ++q) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   // MFMA
           if (kk < 3 && q < TM + TN) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);         // DS read
-          if (q >= TM * TN - NV) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);            // VMEM read
+          if (q >= TM * TN - nvk) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);           // VMEM read
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -1257,7 +1260,10 @@ extern "C" int msclip_gemm(const msclip_gemm_desc* d, void* stream) {
     } else if (big) launch_cfg<0, 256, 256, 2, 4>(d, st, 1);
     else launch_cfg<0, 128, 128, 2, 2>(d, st, 2);
   } else {
-    if (big) launch_cfg<1, 256, 256, 2, 4>(d, st, 1);
+    // N a multiple of 192 (192 / 384 / 768 output channels): 256 x 192 tiles leave no idle columns
+    const long long t192 = (long long)((d->M + 255) / 256) * ((d->N + 191) / 192);
+    if (d->tile == 6 || (d->tile == 0 && d->N % 192 == 0 && t192 >= 128)) launch_cfg<1, 256, 192, 4, 2>(d, st, 1);
+    else if (big) launch_cfg<1, 256, 256, 2, 4>(d, st, 1);
     else launch_cfg<1, 128, 128, 2, 2>(d, st, 2);
   }
   return msclip_launch_status();

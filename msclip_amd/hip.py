@@ -169,6 +169,8 @@ def gemm_variant(mode, M, N, tile=0, K=None):
         return "ring" if (big and tile != 3) else ("dense256" if big else "dense128")
     if tile in (0, 5) and K is not None and (K <= 192 or K == 448) and K % 64 == 0 and M >= 4096 and (K != 448 or N <= 96):
         return "stream"
+    if tile == 6 or (tile == 0 and N % 192 == 0 and ((M + 255) // 256) * ((N + 191) // 192) >= 128):
+        return "conv192"
     return "conv256" if big else "conv128"
 
 
