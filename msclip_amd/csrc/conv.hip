@@ -217,6 +217,82 @@ __global__ __launch_bounds__(256) void dwpool_kernel(const bf16_t* __restrict__ 
   *(uint4*)(out + (size_t)pidx * ldo + cc * 8) = o;
 }
 
+
+// Row-streaming version of the same pooling (what ships when k * C <= 768: 768 for the 32-pixel patch grid, 384 for
+// the 16-pixel one).  A window row top[b, gy*k + ky, gx*k .. gx*k + k, :] is k * C contiguous bf16 whatever the stage,
+// and the weights of that row, w[ky*k .. ky*k + k][:], are the matching k * C contiguous floats: a wave takes one output
+// position, lane l multiplies 16-byte chunks l and l + 64 of every window row (coalesced full-line loads; the
+// thread-per-channel-chunk kernel above reads 96-byte pieces 1.5 KB apart and reaches 2.4 TB/s at k = 16) against
+// the weight table held in LDS, and the k partial sums of a channel are added up through a 3-KiB LDS block.
+__global__ __launch_bounds__(256) void dwpool_rows_kernel(const bf16_t* __restrict__ top, const float* __restrict__ w,
+                                                          bf16_t* __restrict__ out, int ldo, int B, int H, int W,
+                                                          int C, int k, int g) {
+  extern __shared__ __attribute__((aligned(16))) float dsm[];
+  const int RL = k * C;                              // window-row length in elements (<= 768)
+  float* wl = dsm;                                   // [k][RL]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* red = dsm + k * RL + wave * RL;             // [RL / 8 chunks][8]
+  for (int i = threadIdx.x; i < k * RL / 4; i += 256) *(float4*)(wl + i * 4) = *(const float4*)(w + i * 4);
+  __syncthreads();
+  const int npos = B * g * g;
+  const bool one = lane * 8 < RL, two = (lane + 64) * 8 < RL;   // chunks l and l + 64 of the row
+  for (int pos = blockIdx.x * 4 + wave; pos < npos; pos += gridDim.x * 4) {
+    const int b = pos / (g * g), pr = pos - b * g * g;
+    const int gy = pr / g, gx = pr - gy * g;
+    const bf16_t* base = top + (((size_t)b * H + (size_t)gy * k) * W + (size_t)gx * k) * C;
+    float a0[8], a1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a0[e] = a1[e] = 0.f;
+#pragma unroll 4
+    for (int ky = 0; ky < k; ++ky) {
+      const bf16_t* row = base + (size_t)ky * W * C;
+      const float* wr = wl + ky * RL;
+      uint4 u0 = make_uint4(0, 0, 0, 0);
+      if (one) u0 = *(const uint4*)(row + lane * 8);
+      uint4 u1 = make_uint4(0, 0, 0, 0);
+      if (two) u1 = *(const uint4*)(row + (lane + 64) * 8);
+      float f[8];
+      unpack_bf16x8(u0, f);
+      const int wo = one ? lane * 8 : 0;
+      const float4 w0 = *(const float4*)(wr + wo), w1 = *(const float4*)(wr + wo + 4);
+      a0[0] = fmaf(f[0], w0.x, a0[0]); a0[1] = fmaf(f[1], w0.y, a0[1]); a0[2] = fmaf(f[2], w0.z, a0[2]);
+      a0[3] = fmaf(f[3], w0.w, a0[3]); a0[4] = fmaf(f[4], w1.x, a0[4]); a0[5] = fmaf(f[5], w1.y, a0[5]);
+      a0[6] = fmaf(f[6], w1.z, a0[6]); a0[7] = fmaf(f[7], w1.w, a0[7]);
+      if (two) {
+        unpack_bf16x8(u1, f);
+        const float4 x0 = *(const float4*)(wr + (lane + 64) * 8), x1 = *(const float4*)(wr + (lane + 64) * 8 + 4);
+        a1[0] = fmaf(f[0], x0.x, a1[0]); a1[1] = fmaf(f[1], x0.y, a1[1]); a1[2] = fmaf(f[2], x0.z, a1[2]);
+        a1[3] = fmaf(f[3], x0.w, a1[3]); a1[4] = fmaf(f[4], x1.x, a1[4]); a1[5] = fmaf(f[5], x1.y, a1[5]);
+        a1[6] = fmaf(f[6], x1.z, a1[6]); a1[7] = fmaf(f[7], x1.w, a1[7]);
+      }
+    }
+    if (one) {
+      *(float4*)(red + lane * 8) = make_float4(a0[0], a0[1], a0[2], a0[3]);
+      *(float4*)(red + lane * 8 + 4) = make_float4(a0[4], a0[5], a0[6], a0[7]);
+    }
+    if (two) {
+      *(float4*)(red + (lane + 64) * 8) = make_float4(a1[0], a1[1], a1[2], a1[3]);
+      *(float4*)(red + (lane + 64) * 8 + 4) = make_float4(a1[4], a1[5], a1[6], a1[7]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // element x of the window row belongs to channel x % C; channel c = sum over kx of red[kx * C + c]
+    bf16_t* orow = out + (size_t)pos * ldo;
+    for (int c0 = lane * 4; c0 < C; c0 += 256) {
+      float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int kx = 0; kx < k; ++kx) {
+        const float4 v = *(const float4*)(red + kx * C + c0);
+        s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
+      }
+      uint2 o;
+      o.x = pack_bf16x2(s4.x, s4.y);
+      o.y = pack_bf16x2(s4.z, s4.w);
+      *(uint2*)(orow + c0) = o;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 }  // namespace
 
 extern "C" int msclip_stem_conv3x3s2_dual(const void* img, int img_is_bf16, const float* w, const float* bias,
@@ -253,6 +329,17 @@ extern "C" int msclip_dwpool(const void* top, const float* w, void* out, int ldo
                              void* stream) {
   if (!top || !w || !out || B <= 0 || k <= 0 || (C % 8) || (ldo % 8) || (H % k) || H != W) return MSCLIP_EINVAL;
   const int g = H / k;
+  const char* oldk = getenv("MSCLIP_DWPOOL_SCALAR");            // the thread-per-chunk kernel, for cross-checks only
+  if (k >= 4 && k * C <= 768 && !(oldk && oldk[0] == '1')) {   // k <= 2: the per-chunk kernel is as fast
+    const int npos = B * g * g;
+    int grid = (npos + 3) / 4;
+    if (grid > 256 * 4) grid = 256 * 4;
+    const size_t lds = (size_t)(k * k * C + 4 * k * C) * sizeof(float);
+    if (lds > 65536) return MSCLIP_EINVAL;
+    hipLaunchKernelGGL(dwpool_rows_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)top, w,
+                       (bf16_t*)out, ldo, B, H, W, C, k, g);
+    return msclip_launch_status();
+  }
   const long long total = (long long)B * g * g * (C / 8);
   hipLaunchKernelGGL(dwpool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)top, w, (bf16_t*)out, ldo, B, H, W, C, k, g);
