@@ -179,3 +179,20 @@ def test_qkv_prescale_is_exact():
     wq, bq = P.qkv_weights(w, b, 12)
     assert torch.equal(wq[:768].float(), (w[:768].to(torch.bfloat16).float() * 0.125))
     assert torch.equal(wq[768:], w[768:].to(torch.bfloat16)) and torch.equal(bq[:768], b[:768] * 0.125)
+
+
+def test_gemm_dispatch_rule_mirror():
+    """hip.gemm_variant mirrors the kernel choice of csrc/gemm.hip for the shapes of the B/32 step at batch 512
+    (bench.py probes the dominant kernel by this name)."""
+    from msclip_amd import hip
+    assert hip.gemm_variant(0, 65024, 2304, 0, 768) == "pp"            # QKV over image + text rows
+    assert hip.gemm_variant(0, 65024, 768, 0, 3072) == "pp"            # c_proj
+    assert hip.gemm_variant(0, 65024, 768, 4, 768) == "pp"
+    assert hip.gemm_variant(0, 65024, 768, 2, 768) == "ring"
+    assert hip.gemm_variant(0, 6422528, 48, 0, 64) == "stream"         # pointwise conv of the conv branch
+    assert hip.gemm_variant(0, 25088, 768, 0, 192) == "stream"         # adapter 1x1
+    assert hip.gemm_variant(0, 512, 512, 0, 768) == "dense128"         # heads
+    assert hip.gemm_variant(1, 1605632, 96, 0, 448) == "stream"        # 3x3 stride 2, 48 input channels
+    assert hip.gemm_variant(1, 401408, 192, 0, 896) == "conv192"       # 3x3 stride 2, 96 -> 192
+    assert hip.gemm_variant(1, 401408, 96, 0, 896) == "conv128"
+    assert hip.gemm_variant(1, 1000, 64, 0, 576) == "conv128"
