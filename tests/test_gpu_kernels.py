@@ -78,6 +78,34 @@ def test_gemm_streaming_small_k(gpu_device, M, N, K, ldx):
     close(out[:M], ref1, 2e-2, 1e-2)                                             # agrees with the 128x128 kernel
 
 
+def test_gemm_pingpong_race_screen(gpu_device):
+    """The ping-pong kernel orders LDS-DMA writes, fragment reads and ring-slot reuse by counted waits and barriers only;
+    a misplaced one shows up as rare wrong tiles.  Many launches, every output element, bitwise-equal results."""
+    M, N, K = 8192 + 77, 1024, 1536                                            # 33 x 4 tiles, several tiles per workgroup
+    x, w, b = rnd(M, K, seed=51, dtype=BF), rnd(N, K, seed=52, scale=0.04, dtype=BF), rnd(N, seed=53)
+    ref = x.float() @ w.float().t() + b
+    first = None
+    out = torch.empty(M, N, dtype=BF, device="cuda")
+    for it in range(25):
+        out.fill_(float("nan"))
+        hip.gemm(x, w, out, bias=b, tile=4)
+        if first is None:
+            close(out, ref, 2e-2, 1e-2)
+            first = out.clone()
+        else:
+            assert torch.equal(out, first), f"launch {it} differs from launch 0"
+    r32 = rnd(M, N, seed=54)
+    acc = r32.clone()
+    for it in range(10):
+        acc.copy_(r32)
+        hip.gemm(x, w, acc, bias=b, resid=acc, resid_kind=hip.RESID_F32, tile=4)
+        if it == 0:
+            close(acc, r32 + ref, 4e-3, 1e-4)
+            first = acc.clone()
+        else:
+            assert torch.equal(acc, first), f"launch {it} differs from launch 0"
+
+
 def test_gemm_epilogues(gpu_device):
     M, N, K = 333, 256, 192
     x, w, b = rnd(M, K, seed=4, dtype=BF), rnd(N, K, seed=5, scale=0.08, dtype=BF), rnd(N, seed=6)
