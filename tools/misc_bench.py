@@ -19,3 +19,22 @@ for (C, k, H) in [(48, 16, 112), (96, 8, 56), (192, 4, 28), (384, 2, 14), (768, 
     us = s.elapsed_time(e) / 20 * 1e3
     mb = top.numel() * 2 / 1e6
     print(f"dwpool C={C:4d} k={k:2d} {H}x{H}: {us:8.1f} us  {mb / us:6.2f} TB/s")
+
+# lateral adapter combine (depthwise 3x3 over the token grid + t + LayerNorm)
+for (Bq, g) in [(512, 7), (256, 14)]:
+    L, C = g * g + 1, 768
+    xin = torch.randn(Bq * L, C, device="cuda")
+    t = torch.randn(Bq * g * g, C, device="cuda")
+    dww, dwb = torch.randn(9, C, device="cuda") * 0.2, torch.randn(C, device="cuda") * 0.1
+    gam, bet = torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda") * 0.1
+    xout = torch.empty_like(xin)
+    for _ in range(3):
+        hip.adapter_combine_ln(xin, t, dww, dwb, gam, bet, xout, Bq, L, g, True)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(20):
+        hip.adapter_combine_ln(xin, t, dww, dwb, gam, bet, xout, Bq, L, g, True)
+    e.record(); torch.cuda.synchronize()
+    us = s.elapsed_time(e) / 20 * 1e3
+    mb = (xin.numel() * 2 + t.numel()) * 4 / 1e6
+    print(f"adapter B={Bq} g={g}: {us:8.1f} us  {mb / us:6.2f} TB/s of x, t, out traffic")
