@@ -58,7 +58,7 @@ int msclip_gemm(const msclip_gemm_desc* desc, void* stream);
 
 /* Fused softmax(q k^T [+ causal]) v per (sample, head), head_dim 64, L <= 224; q pre-scaled.
  * qkv: bf16 [nsamples*L, ldq] with columns [q | k | v], each heads*64 wide.  out: bf16
- * [nsamples*L, ldo].  Replaces M.py:707-738 (scale, reshapes, bmm, mask add, softmax, bmm). */
+ * [nsamples*L, ldo], ldq % 8 == 0 and ldo % 8 == 0 (16-byte row pieces).  Replaces M.py:707-738 (scale, reshapes, bmm, mask add, softmax, bmm). */
 int msclip_attention(const void* qkv, void* out, int nsamples, int L, int heads, int ldq, int ldo, int causal,
                      void* stream);
 

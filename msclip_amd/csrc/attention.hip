@@ -147,17 +147,25 @@ __global__ __launch_bounds__(WPB * 64) void attn_kernel(const bf16_t* __restrict
             }
           }
         }
-        if (q < L) {
-          bf16_t* orow = out + (row0 + q) * ldo + h * 64;
+        {
+          // lane (q, fhi) holds d = dt*32 + 8g + 4*fhi .. +4; v_permlane32_swap trades group 2s+1 of the low half-wave
+          // against group 2s of the high one, so every lane ends up with 8 consecutive d (16-byte stores)
+          bf16_t* orow = out + (row0 + min(q, L - 1)) * ldo + h * 64;
 #pragma unroll
-          for (int dt = 0; dt < 2; ++dt)
+          for (int dt = 0; dt < 2; ++dt) {
+            unsigned pk[4][2];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-              uint2 v;
-              v.x = pack_bf16x2(o[dt][g * 4 + 0] * inv, o[dt][g * 4 + 1] * inv);
-              v.y = pack_bf16x2(o[dt][g * 4 + 2] * inv, o[dt][g * 4 + 3] * inv);
-              *(uint2*)(orow + dt * 32 + g * 8 + fhi * 4) = v;
+              pk[g][0] = pack_bf16x2(o[dt][g * 4 + 0] * inv, o[dt][g * 4 + 1] * inv);
+              pk[g][1] = pack_bf16x2(o[dt][g * 4 + 2] * inv, o[dt][g * 4 + 3] * inv);
             }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+              const auto x = __builtin_amdgcn_permlane32_swap(pk[2 * s2][0], pk[2 * s2 + 1][0], false, false);
+              const auto y = __builtin_amdgcn_permlane32_swap(pk[2 * s2][1], pk[2 * s2 + 1][1], false, false);
+              if (q < L) *(uint4*)(orow + dt * 32 + s2 * 16 + fhi * 8) = make_uint4(x[0], y[0], x[1], y[1]);
+            }
+          }
         }
       }
     }
@@ -390,17 +398,23 @@ __global__ __launch_bounds__(256, 2) void attn_wg_kernel(const bf16_t* __restric
         }
       }
     }
-    if (q < L) {
-      bf16_t* orow = out + (row0 + q) * ldo + h * 64;
+    {
+      bf16_t* orow = out + (row0 + min(q, L - 1)) * ldo + h * 64;
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
+      for (int dt = 0; dt < 2; ++dt) {
+        unsigned pk[4][2];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          uint2 v;
-          v.x = pack_bf16x2(o[dt][g * 4 + 0] * inv, o[dt][g * 4 + 1] * inv);
-          v.y = pack_bf16x2(o[dt][g * 4 + 2] * inv, o[dt][g * 4 + 3] * inv);
-          *(uint2*)(orow + dt * 32 + g * 8 + fhi * 4) = v;
+          pk[g][0] = pack_bf16x2(o[dt][g * 4 + 0] * inv, o[dt][g * 4 + 1] * inv);
+          pk[g][1] = pack_bf16x2(o[dt][g * 4 + 2] * inv, o[dt][g * 4 + 3] * inv);
         }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {                           // 8 consecutive d per lane (see attn_kernel)
+          const auto x = __builtin_amdgcn_permlane32_swap(pk[2 * s2][0], pk[2 * s2 + 1][0], false, false);
+          const auto y = __builtin_amdgcn_permlane32_swap(pk[2 * s2][1], pk[2 * s2 + 1][1], false, false);
+          if (q < L) *(uint4*)(orow + dt * 32 + s2 * 16 + fhi * 8) = make_uint4(x[0], y[0], x[1], y[1]);
+        }
+      }
     }
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) qcur[kk] = qnext[kk];
@@ -438,7 +452,7 @@ int launch(const void* qkv, void* out, int nsamples, int L, int H, int ldq, int 
 
 extern "C" int msclip_attention(const void* qkv, void* out, int nsamples, int L, int heads, int ldq, int ldo,
                                 int causal, void* stream) {
-  if (!qkv || !out || nsamples <= 0 || L <= 0 || heads <= 0 || (ldq % 8) || (ldo % 4)) return MSCLIP_EINVAL;
+  if (!qkv || !out || nsamples <= 0 || L <= 0 || heads <= 0 || (ldq % 8) || (ldo % 8)) return MSCLIP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   if (L <= 64) return launch<2>(qkv, out, nsamples, L, heads, ldq, ldo, causal, st);
   if (L <= 96) return launch<3>(qkv, out, nsamples, L, heads, ldq, ldo, causal, st);
