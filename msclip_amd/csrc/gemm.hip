@@ -870,18 +870,22 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const msclip_gemm_des
 // ------------------------------------------------------------------------------------------------------------
 // Ping-pong kernel for the dense projections: 256 x 256 tile, 8 waves (2 x 4), K-tiles of 64.  LDS is a ring of
 // ten 16-KiB regions; a region holds one half-operand of one K-tile (128 rows x 128 B, full cache lines):
-// W rows 0-127, W rows 128-255, X rows 0-127, X rows 128-255, in that order.  One region is issued per phase
-// (2 LDS-DMA pieces per wave, buffer-addressed: SGPR descriptor + 32-bit lane offset + scalar K offset), a K-tile
-// is computed in 4 phases (one 64 x 32 quadrant of the wave's 128 x 64 block over the whole K-tile each):
-//     phase q:  [ ds_reads of the quadrant's new fragments ; 2 DMA pieces ; (q == 3: s_waitcnt vmcnt(6)) ]
-//               s_barrier ; lgkmcnt(0) ; 8 MFMAs at raised priority ; s_barrier
+// W rows 0-127, W rows 128-255, X rows 0-127, X rows 128-255, in that order (2 LDS-DMA pieces per wave and region,
+// buffer-addressed: SGPR descriptor + 32-bit lane offset + scalar K offset).  A K-tile is computed in 4 phases (one
+// 64 x 32 quadrant of the wave's 128 x 64 block over the whole K-tile each):
+//     phase q:  [ ds_reads of the quadrant's new fragments (12 / 4 / 8 / 0) ; q == 1, 3: 4 DMA pieces ;
+//                 q == 3: s_waitcnt vmcnt(8) ]   s_barrier ; lgkmcnt(0) ; 8 MFMAs at raised priority ; s_barrier
 // Waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave is in its memory section while the other
 // owns the MFMA pipe, and a barrier resolves under the tail of the other wave's last MFMA.
-// Region r is issued in phase r, waited for (by its issuers) in phase r+3 .. r+6 and first read in phase r+4 or
-// later -- i.e. after a barrier that follows the wait; K-tile t (regions 4t..4t+3) is computed in phases
-// 4t+7 .. 4t+10 and its ring slots are re-issued in phases 4t+10 .. 4t+13, at least two barriers after their last
-// ds_read retired.  The DMA stream runs across tile boundaries (seven regions of the next tile fly under the
-// epilogue).  Rows past M / N are out of range of the tile's buffer descriptor (read as zero).
+// Phases are numbered so that K-tile t (regions 4t .. 4t+3) is computed in phases 4t+7 .. 4t+10.  Its phase 4t+8
+// issues regions 4t+8, 4t+9 and phase 4t+10 issues regions 4t+10, 4t+11 (the DMA pieces sit in the two phases with
+// the fewest fragment reads; 1 % over one region per phase), then waits until at most 8 pieces are in flight: the
+// regions of K-tile t+1 (issued in phases 4t+4 and 4t+6) have landed, and they are first read in phase 4t+11, after
+// a barrier that follows every wave's wait.  Region r+10 overwrites the ring slot of region r: the X regions of
+// K-tile t-1 (last read in phase 4t+5) in phase 4t+8, the W regions of K-tile t (last read in phase 4t+8) in phase
+// 4t+10 -- at least two barriers after the last ds_read retired.  The DMA stream runs across tile boundaries (eight
+// regions of the next tile fly under the epilogue).  Rows past M / N are out of range of the tile's buffer
+// descriptor (read as zero).
 // ------------------------------------------------------------------------------------------------------------
 constexpr int PSLOTS = 10, PREG = 128 * 64;   // ring regions, bf16 elements per region
 
@@ -999,7 +1003,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
   set_tile(ti);
   issue(I0{}); issue(I1{}); issue(I2{}); issue(I3{});
   issue(I0{}); issue(I1{}); issue(I2{});
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  issue(I3{});
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   if (grp) __builtin_amdgcn_s_barrier();           // stagger
@@ -1026,7 +1031,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
     // bias4[i]: this lane's 4 epilogue columns of 32-column block i (see epilogue_rows).
     // The loads are inline asm: the compiler must not know they are pending (it would wait for them -- and so for the
     // previous tile's stores, the VM counter retires in order -- before entering the K loop).  They are older than the
-    // six DMA pieces the first vmcnt(6) of the K loop leaves in flight, and first read in the epilogue.
+    // eight DMA pieces the first vmcnt(8) of the K loop leaves in flight, and first read in the epilogue.
     float bcol;                                    // packed bf16 epilogue: lane j holds the bias of the wave's column j
     {
       const int n = cn0 + wn + lane_s;
@@ -1085,7 +1090,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) xf[j][kk] = pp_ld(xreg + j * 4096 + la[kk]);
-      issue(I3{});
       PP_SYNC_IN();
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk)
@@ -1098,6 +1102,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) w1[kk] = pp_ld(wreg + 4096 + la[kk]);
       issue(I0{});
+      issue(I1{});
       PP_SYNC_IN();
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk)
@@ -1111,7 +1116,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) xf[j][kk] = pp_ld(xreg + 8192 + j * 4096 + la[kk]);
-      issue(I1{});
       PP_SYNC_IN();
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk)
@@ -1122,8 +1126,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
 
       // ---- phase 3: nothing new to read -> quadrant (1, 0); the next K-tile's last region is waited for here
       issue(I2{});
+      issue(I3{});
 #ifndef PP_NOWAIT
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 #endif
       PP_SYNC_IN();
 #pragma unroll
@@ -1135,8 +1140,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
     }
 
     // Both groups run the epilogue together: the leading group waits one barrier, the trailing one re-staggers after.
-    // Staging = the ring slots of the last K-tile's X regions (dead since its phase 2; re-issued in phases 1 and 2 of
-    // the next tile, behind a barrier every wave reaches only after its epilogue).
+    // Staging = the ring slots of the last K-tile's X regions (dead since its phase 2; re-issued in phase 1 of the
+    // next tile, behind a barrier every wave reaches only after its epilogue).
     PP_STAMP(3);
     if (!grp) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
