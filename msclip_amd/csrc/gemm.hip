@@ -206,12 +206,14 @@ __device__ __forceinline__ uint2 ld_global_u2(const void* p) {
 }
 
 template <int TM, int TN, int RK, int ACT, int OUTK>
-__device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[TN][TM], const msclip_gemm_desc& a, unsigned stg, int mw0,
-                                              int nw0, int lane, const float4 (&bias4)[TN], PpTrace* tr = nullptr) {
-  const int fr = lane & 31, fhi = lane >> 5;
+__device__ __forceinline__ void epilogue_rows(f32x4 (&acc)[2 * TN][2 * TM], const msclip_gemm_desc& a, unsigned stg,
+                                              int mw0, int nw0, int lane, const float4 (&bias4)[TN],
+                                              PpTrace* tr = nullptr) {
+  // accumulator layout of v_mfma_f32_16x16x32 with swapped operands: acc[ni][mi][r] = C[mi*16 + lane%16][ni*16 + 4*(lane/16) + r]
+  const int r16 = lane & 15, quad = lane >> 4;
   const int srow = lane >> 3, sch = lane & 7;
-  const unsigned wr = stg + fr * 128;
-  const int wsw = fr & 7;
+  const unsigned wr = stg + r16 * 128;
+  const int wsw = r16 & 7;
   const unsigned rd = stg + srow * 128 + ((sch ^ srow) << 4);    // + i * 1024 for rows i*8 + srow
   const int rk = RK >= 0 ? RK : a.resid_kind;
   const int act = ACT >= 0 ? ACT : a.act;
@@ -243,12 +245,12 @@ __device__ __forceinline__ void epilogue_rows(f32x16 (&acc)[TN][TM], const mscli
   auto stage = [&](int b, f32x4 (&dst)[4]) {                     // block b = tm * TN + tn -> LDS -> row-major registers
     const int tm = b / TN, tn = b % TN;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      f32x4 v;
-      v[0] = acc[tn][tm][g * 4 + 0] * a.alpha; v[1] = acc[tn][tm][g * 4 + 1] * a.alpha;
-      v[2] = acc[tn][tm][g * 4 + 2] * a.alpha; v[3] = acc[tn][tm][g * 4 + 3] * a.alpha;
-      stg_write16(wr + (((g * 2 + fhi) ^ wsw) << 4), v);
-    }
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {                              // the four 16 x 16 tiles of this 32 x 32 block
+        const f32x4 v = acc[2 * tn + ni][2 * tm + mi] * a.alpha;
+        stg_write16(wr + mi * 2048 + (((ni * 4 + quad) ^ wsw) << 4), v);
+      }
     dst[0] = stg_read16<0>(rd); dst[1] = stg_read16<1024>(rd);
     dst[2] = stg_read16<2048>(rd); dst[3] = stg_read16<3072>(rd);
   };
@@ -318,39 +320,39 @@ __device__ __forceinline__ u32x4 stg_read16u(unsigned addr) {
 }
 
 template <int TM, int TN, int ACT>
-__device__ __forceinline__ void epilogue_pack16(f32x16 (&acc)[TN][TM], const msclip_gemm_desc& a, unsigned stg, int mw0,
-                                                int nw0, int lane, float bcol, PpTrace* tr = nullptr) {
+__device__ __forceinline__ void epilogue_pack16(f32x4 (&acc)[2 * TN][2 * TM], const msclip_gemm_desc& a, unsigned stg,
+                                                int mw0, int nw0, int lane, float bcol, PpTrace* tr = nullptr) {
   static_assert(TN == 2, "64 bf16 columns = one 128-byte staged row");
-  const int fr = lane & 31, fhi = lane >> 5;
+  const int r16 = lane & 15, quad = lane >> 4;
   const int srow = lane >> 3, sch = lane & 7;
-  const unsigned wr = stg + fr * 128 + fhi * 8;
-  const int wsw = fr & 7;
+  const unsigned wr = stg + r16 * 128 + (quad & 1) * 8;
+  const int wsw = r16 & 7;
   const unsigned rd = stg + srow * 128 + ((sch ^ srow) << 4);    // + i * 1024 for rows i*8 + srow
-  float b[TN][16];
+  float b[4][4];                                                 // bias of columns ni*16 + 4*quad + r
 #pragma unroll
-  for (int tn = 0; tn < TN; ++tn)
+  for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bcol), tn * 32 + g * 8 + e));
-        const float hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bcol), tn * 32 + g * 8 + 4 + e));
-        b[tn][g * 4 + e] = fhi ? hi : lo;
-      }
+    for (int r = 0; r < 4; ++r) {
+      const float q0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bcol), ni * 16 + r));
+      const float q1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bcol), ni * 16 + 4 + r));
+      const float q2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bcol), ni * 16 + 8 + r));
+      const float q3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bcol), ni * 16 + 12 + r));
+      b[ni][r] = quad == 0 ? q0 : quad == 1 ? q1 : quad == 2 ? q2 : q3;
+    }
   EPI_STAMP(10);
   u32x4 x[2][4];
-  auto stage = [&](int tm, u32x4 (&dst)[4]) {
+  auto stage = [&](int tm, u32x4 (&dst)[4]) {                    // 32 rows x 64 columns of the wave, packed to bf16
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn)
+    for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
+      for (int ni = 0; ni < 4; ++ni) {
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          v[e] = acc[tn][tm][g * 4 + e] * a.alpha + b[tn][g * 4 + e];
+          v[e] = acc[ni][2 * tm + mi][e] * a.alpha + b[ni][e];
           if (ACT == 1) v[e] = v[e] / (1.f + __expf(-1.702f * v[e]));
         }
-        stg_write8(wr + (((tn * 4 + g) ^ wsw) << 4), pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        stg_write8(wr + mi * 2048 + (((ni * 2 + (quad >> 1)) ^ wsw) << 4), pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
       }
     dst[0] = stg_read16u<0>(rd); dst[1] = stg_read16u<1024>(rd);
     dst[2] = stg_read16u<2048>(rd); dst[3] = stg_read16u<3072>(rd);
@@ -377,6 +379,72 @@ __device__ __forceinline__ void epilogue_pack16(f32x16 (&acc)[TN][TM], const msc
 #else
       asm volatile("" ::"v"(xb[i]), "v"(row), "v"(n));
 #endif
+    }
+  }
+}
+
+// Edge tiles of the ping-pong kernel (rows past M, ragged N, unaligned leading dimensions): guarded, straight from the
+// 16 x 16 accumulator layout (lane owns row mi*16 + lane%16, columns ni*16 + 4*(lane/16) + 0..3).
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue_generic16(f32x4 (&acc)[2 * TN][2 * TM], const msclip_gemm_desc& a, bool vec,
+                                                   int mw0, int nw0, int lane) {
+  const int r16 = lane & 15, quad = lane >> 4;
+  const float* __restrict__ bias = a.bias;
+#pragma unroll
+  for (int mi = 0; mi < 2 * TM; ++mi) {
+    const int m = mw0 + mi * 16 + r16;
+    if (m >= a.M) continue;
+    const size_t row = (size_t)m;
+#pragma unroll
+    for (int ni = 0; ni < 2 * TN; ++ni) {
+      const int n = nw0 + ni * 16 + quad * 4;
+      if (n >= a.N) continue;
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][j] * a.alpha;
+      if (vec) {
+        if (bias) {
+          const float4 bv = *(const float4*)(bias + n);
+          v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+        }
+        if (a.act == 1) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = v[j] / (1.f + __expf(-1.702f * v[j]));
+        }
+        if (a.resid_kind == 1) {
+          const float4 rv = *(const float4*)((const float*)a.resid + row * a.ldr + n);
+          v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+        } else if (a.resid_kind == 2) {
+          const uint2 rv = *(const uint2*)((const bf16_t*)a.resid + row * a.ldr + n);
+          v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
+          v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
+        }
+        if (a.act == 2) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        if (a.out_kind == 1) {
+          *(float4*)((float*)a.out + row * a.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          uint2 o;
+          o.x = pack_bf16x2(v[0], v[1]);
+          o.y = pack_bf16x2(v[2], v[3]);
+          *(uint2*)((bf16_t*)a.out + row * a.ldo + n) = o;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (n + j >= a.N) break;
+          float y = v[j];
+          if (bias) y += bias[n + j];
+          if (a.act == 1) y = y / (1.f + __expf(-1.702f * y));
+          if (a.resid_kind == 1) y += ((const float*)a.resid)[row * a.ldr + n + j];
+          else if (a.resid_kind == 2) y += bf16_to_f32(((const bf16_t*)a.resid)[row * a.ldr + n + j]);
+          if (a.act == 2) y = fmaxf(y, 0.f);
+          if (a.out_kind == 1) ((float*)a.out)[row * a.ldo + n + j] = y;
+          else ((bf16_t*)a.out)[row * a.ldo + n + j] = f32_to_bf16(y);
+        }
+      }
     }
   }
 }
@@ -987,12 +1055,15 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
 
   // ---- compute side
   const int wm = grp * 128, wn = (wave & 3) * 64;
-  const int fr = lane & 31, fhi = lane >> 5;
+  // v_mfma_f32_16x16x32_bf16 (on random operands it sustains 2.03 PF against 1.73-1.82 PF for 32x32x16 at the same
+  // power limit, tools/probes/mfma_probe): a fragment is 16 rows x 32 K, lane l holds row l % 16, 16-byte chunk l / 16
+  // (+ 4 for the second k-step); la[ks] = byte offset of that chunk in a 128-byte LDS row (same swizzle as the image)
+  const int r16 = lane & 15, quad = lane >> 4;
   const bool vec = !((a.N | a.ldo | (a.resid_kind ? a.ldr : 0)) & 3);
   const bool plain_rows = a.rpg == 0x7fffffff && a.resid_kind != 3;
-  int la[4];                                       // byte offset of this lane's fragment chunk of k-step kk in row fr
+  int la[2];
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) la[kk] = fr * 128 + ((((kk << 1) | fhi) ^ ((fr >> 1) & 7)) << 4);
+  for (int ks = 0; ks < 2; ++ks) la[ks] = r16 * 128 + ((((ks << 2) | quad) ^ ((r16 >> 1) & 7)) << 4);
   const int wsub = ((wave >> 1) & 1);              // W half-region of this wave
   const int woff = (wave & 1) * 64 * 128;          // byte offset of its 64 rows inside that region
   const char* lds = (const char*)smem;
@@ -1010,17 +1081,17 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
   if (grp) __builtin_amdgcn_s_barrier();           // stagger
 
   int cslot = 0;                                   // ring slot of region 0 of the K-tile being computed
-  bf16x8 w0[4], w1[4], xf[2][4];
+  bf16x8 w0[2][2], w1[2][2], xf[4][2];             // [16-row tile][k-step]: W rows 0-31 / 32-63 of the wave, X rows of a sub-block
   for (int tc = blockIdx.x; tc < ntiles; tc += gridDim.x) {
     int cm0, cn0;
     tile_origin(tc, cm0, cn0);
-    f32x16 acc[TN][TM];
+    f32x4 acc[4][8];                               // [16-column tile][16-row tile] of the wave's 128 x 64 block
 #pragma unroll
-    for (int i = 0; i < TN; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < TM; ++j)
+      for (int j = 0; j < 8; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
     // Bias of this tile: requested here, first touched after the first vmcnt wait of the K loop.  The loads are
     // unconditional (clamped index, zero page when there is no bias) and the lane id is recomputed: a predicated load
     // or a reloaded spill at this point would bring an s_waitcnt vmcnt(0), i.e. a wait for the previous tile's stores.
@@ -1082,49 +1153,59 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
   asm volatile("" ::: "memory");                       \
   __builtin_amdgcn_sched_barrier(0)
 
-      // ---- phase 0: W sub 0, X sub 0 -> quadrant (0, 0)
+      // ---- phase 0: W sub 0 (32 rows), X sub 0 (64 rows) -> quadrant (0, 0)
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) w0[kk] = pp_ld(wreg + la[kk]);
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) w0[i][ks] = pp_ld(wreg + i * 2048 + la[ks]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) xf[j][kk] = pp_ld(xreg + j * 4096 + la[kk]);
+        for (int ks = 0; ks < 2; ++ks) xf[j][ks] = pp_ld(xreg + j * 2048 + la[ks]);
       PP_SYNC_IN();
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk)
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0[kk], xf[j][kk], acc[0][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[i][ks], xf[j][ks], acc[i][j], 0, 0, 0);
       PP_SYNC_OUT();
 
       // ---- phase 1: W sub 1 -> quadrant (0, 1)
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) w1[kk] = pp_ld(wreg + 4096 + la[kk]);
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) w1[i][ks] = pp_ld(wreg + 4096 + i * 2048 + la[ks]);
       issue(I0{});
       issue(I1{});
       PP_SYNC_IN();
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk)
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[kk], xf[j][kk], acc[1][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            acc[2 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[i][ks], xf[j][ks], acc[2 + i][j], 0, 0, 0);
       PP_SYNC_OUT();
 
       // ---- phase 2: X sub 1 -> quadrant (1, 1)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) xf[j][kk] = pp_ld(xreg + 8192 + j * 4096 + la[kk]);
+        for (int ks = 0; ks < 2; ++ks) xf[j][ks] = pp_ld(xreg + 8192 + j * 2048 + la[ks]);
       PP_SYNC_IN();
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk)
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[1][2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[kk], xf[j][kk], acc[1][2 + j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            acc[2 + i][4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[i][ks], xf[j][ks], acc[2 + i][4 + j], 0, 0, 0);
       PP_SYNC_OUT();
 
-      // ---- phase 3: nothing new to read -> quadrant (1, 0); the next K-tile's last region is waited for here
+      // ---- phase 3: nothing new to read -> quadrant (1, 0); the next K-tile's regions are waited for here
       issue(I2{});
       issue(I3{});
 #ifndef PP_NOWAIT
@@ -1132,10 +1213,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
 #endif
       PP_SYNC_IN();
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk)
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[0][2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0[kk], xf[j][kk], acc[0][2 + j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            acc[i][4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[i][ks], xf[j][ks], acc[i][4 + j], 0, 0, 0);
       PP_SYNC_OUT();
     }
 
@@ -1152,11 +1235,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
       const unsigned stg = (unsigned)(size_t)(AS3 bf16_t*)smem + ss * (PREG * 2) + (wave & 3) * STG_BYTES;
 #ifdef PP_NOEPI
 #pragma unroll
-      for (int i = 0; i < TN; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < TM; ++j)
+        for (int j = 0; j < 8; ++j)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[i][j][r]));
+          for (int r = 0; r < 4; ++r) asm volatile("" ::"v"(acc[i][j][r]));
       asm volatile("" ::"v"(stg));
 #else
       // lane id recomputed from scratch: the epilogue's lane constants must not live (spilled) across the main loop
@@ -1193,7 +1276,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
 #endif
       }
       else
-        epilogue_generic<TM, TN>(acc, a, vec, cm0 + wm, cn0 + wn, lane_e);
+        epilogue_generic16<TM, TN>(acc, a, vec, cm0 + wm, cn0 + wn, lane_e);
 #endif
     }
     PP_STAMP(5);
