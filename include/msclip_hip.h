@@ -69,6 +69,13 @@ int msclip_layernorm(const float* x, int ldx, const int* row_idx, int row_mul, i
                      const float* beta, void* out, int ldo, int out_kind, float* raw_out, int ld_raw, int M, int C,
                      float eps, void* stream);
 
+/* The same over one [M, C] matrix whose rows [0, split) and [split, M) carry different parameters: the image and
+ * the text tokens of the shared residual matrix with their modality-specific LayerNorms (M.py:1027-1028 run per
+ * tower) in one launch. */
+int msclip_layernorm_split(const float* x, int ldx, const float* gamma, const float* beta, const float* gamma2,
+                           const float* beta2, int split, void* out, int ldo, int out_kind, int M, int C, float eps,
+                           void* stream);
+
 /* x[row_base + b*L + l] = emb[tokens[b,l]] + pos[l]; eot_row[b] = row_base + b*L + argmax_l tokens[b,l]
  * (M.py:3047-3048 and the EOT pick of :3057-3060).  tokens are int64. */
 int msclip_embed_tokens(const long long* tokens, const float* emb, const float* pos, float* x, int ldx, int* eot_row,

@@ -394,7 +394,10 @@ __device__ __forceinline__ void epilogue_generic16(f32x4 (&acc)[2 * TN][2 * TM],
   for (int mi = 0; mi < 2 * TM; ++mi) {
     const int m = mw0 + mi * 16 + r16;
     if (m >= a.M) continue;
-    const size_t row = (size_t)m;
+    const int grp = m / a.rpg;
+    const size_t orow = (size_t)(m + grp * a.radd + a.roff);       // row scatter (stem -> token rows)
+    size_t row = (size_t)m;                                         // residual row
+    if (a.resid_kind == 3) row = (size_t)(m - grp * a.rpg + a.roff);
 #pragma unroll
     for (int ni = 0; ni < 2 * TN; ++ni) {
       const int n = nw0 + ni * 16 + quad * 4;
@@ -411,7 +414,7 @@ __device__ __forceinline__ void epilogue_generic16(f32x4 (&acc)[2 * TN][2 * TM],
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = v[j] / (1.f + __expf(-1.702f * v[j]));
         }
-        if (a.resid_kind == 1) {
+        if (a.resid_kind == 1 || a.resid_kind == 3) {
           const float4 rv = *(const float4*)((const float*)a.resid + row * a.ldr + n);
           v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
         } else if (a.resid_kind == 2) {
@@ -424,12 +427,12 @@ __device__ __forceinline__ void epilogue_generic16(f32x4 (&acc)[2 * TN][2 * TM],
           for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
         }
         if (a.out_kind == 1) {
-          *(float4*)((float*)a.out + row * a.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
+          *(float4*)((float*)a.out + orow * a.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
           uint2 o;
           o.x = pack_bf16x2(v[0], v[1]);
           o.y = pack_bf16x2(v[2], v[3]);
-          *(uint2*)((bf16_t*)a.out + row * a.ldo + n) = o;
+          *(uint2*)((bf16_t*)a.out + orow * a.ldo + n) = o;
         }
       } else {
 #pragma unroll
@@ -438,11 +441,11 @@ __device__ __forceinline__ void epilogue_generic16(f32x4 (&acc)[2 * TN][2 * TM],
           float y = v[j];
           if (bias) y += bias[n + j];
           if (a.act == 1) y = y / (1.f + __expf(-1.702f * y));
-          if (a.resid_kind == 1) y += ((const float*)a.resid)[row * a.ldr + n + j];
+          if (a.resid_kind == 1 || a.resid_kind == 3) y += ((const float*)a.resid)[row * a.ldr + n + j];
           else if (a.resid_kind == 2) y += bf16_to_f32(((const bf16_t*)a.resid)[row * a.ldr + n + j]);
           if (a.act == 2) y = fmaxf(y, 0.f);
-          if (a.out_kind == 1) ((float*)a.out)[row * a.ldo + n + j] = y;
-          else ((bf16_t*)a.out)[row * a.ldo + n + j] = f32_to_bf16(y);
+          if (a.out_kind == 1) ((float*)a.out)[orow * a.ldo + n + j] = y;
+          else ((bf16_t*)a.out)[orow * a.ldo + n + j] = f32_to_bf16(y);
         }
       }
     }

@@ -57,15 +57,21 @@ __device__ __forceinline__ void store_row(const float4 (&v)[NV], void* out, size
   }
 }
 
-// y[m] = LN(x[src(m)]) ; src(m) = row_idx ? row_idx[m] : m * row_mul + row_add
+// y[m] = LN(x[src(m)]) ; src(m) = row_idx ? row_idx[m] : m * row_mul + row_add; rows >= split use (gamma2, beta2)
 template <int NV>
 __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, int ldx, const int* __restrict__ row_idx,
                                                  int row_mul, int row_add, const float* __restrict__ gamma,
                                                  const float* __restrict__ beta, void* out, int ldo, int out_kind,
-                                                 float* __restrict__ raw_out, int ld_raw, int M, float eps) {
+                                                 float* __restrict__ raw_out, int ld_raw, int M, float eps,
+                                                 const float* __restrict__ gamma2, const float* __restrict__ beta2,
+                                                 int split) {
   const int lane = threadIdx.x & 63;
   const int m = blockIdx.x * WPB + (threadIdx.x >> 6);
   if (m >= M) return;
+  if (m >= split) {                                  // second parameter set (the other modality's rows); wave-uniform
+    gamma = gamma2;
+    beta = beta2;
+  }
   const size_t src = row_idx ? (size_t)row_idx[m] : (size_t)m * row_mul + row_add;
   float4 v[NV];
 #pragma unroll
@@ -222,17 +228,32 @@ __global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ x
   else if ((C) == 256) { CALL1; }                   \
   else return MSCLIP_EINVAL;
 
+static int launch_ln(const float* x, int ldx, const int* row_idx, int row_mul, int row_add, const float* gamma,
+                     const float* beta, void* out, int ldo, int out_kind, float* raw_out, int ld_raw, int M, int C,
+                     float eps, const float* gamma2, const float* beta2, int split, hipStream_t st) {
+  const dim3 grid((M + WPB - 1) / WPB), blk(256);
+  NV_DISPATCH(C,
+              hipLaunchKernelGGL(ln_kernel<3>, grid, blk, 0, st, x, ldx, row_idx, row_mul, row_add, gamma, beta, out, ldo, out_kind, raw_out, ld_raw, M, eps, gamma2, beta2, split),
+              hipLaunchKernelGGL(ln_kernel<2>, grid, blk, 0, st, x, ldx, row_idx, row_mul, row_add, gamma, beta, out, ldo, out_kind, raw_out, ld_raw, M, eps, gamma2, beta2, split),
+              hipLaunchKernelGGL(ln_kernel<1>, grid, blk, 0, st, x, ldx, row_idx, row_mul, row_add, gamma, beta, out, ldo, out_kind, raw_out, ld_raw, M, eps, gamma2, beta2, split))
+  return msclip_launch_status();
+}
+
 extern "C" int msclip_layernorm(const float* x, int ldx, const int* row_idx, int row_mul, int row_add,
                                 const float* gamma, const float* beta, void* out, int ldo, int out_kind,
                                 float* raw_out, int ld_raw, int M, int C, float eps, void* stream) {
   if (!x || !gamma || !beta || !out || M <= 0 || (ldx % 4) || (ldo % 4)) return MSCLIP_EINVAL;
-  hipStream_t st = (hipStream_t)stream;
-  const dim3 grid((M + WPB - 1) / WPB), blk(256);
-  NV_DISPATCH(C,
-              hipLaunchKernelGGL(ln_kernel<3>, grid, blk, 0, st, x, ldx, row_idx, row_mul, row_add, gamma, beta, out, ldo, out_kind, raw_out, ld_raw, M, eps),
-              hipLaunchKernelGGL(ln_kernel<2>, grid, blk, 0, st, x, ldx, row_idx, row_mul, row_add, gamma, beta, out, ldo, out_kind, raw_out, ld_raw, M, eps),
-              hipLaunchKernelGGL(ln_kernel<1>, grid, blk, 0, st, x, ldx, row_idx, row_mul, row_add, gamma, beta, out, ldo, out_kind, raw_out, ld_raw, M, eps))
-  return msclip_launch_status();
+  return launch_ln(x, ldx, row_idx, row_mul, row_add, gamma, beta, out, ldo, out_kind, raw_out, ld_raw, M, C, eps, gamma,
+                   beta, M, (hipStream_t)stream);
+}
+
+extern "C" int msclip_layernorm_split(const float* x, int ldx, const float* gamma, const float* beta,
+                                      const float* gamma2, const float* beta2, int split, void* out, int ldo,
+                                      int out_kind, int M, int C, float eps, void* stream) {
+  if (!x || !gamma || !beta || !gamma2 || !beta2 || !out || M <= 0 || split < 0 || split > M || (ldx % 4) || (ldo % 4))
+    return MSCLIP_EINVAL;
+  return launch_ln(x, ldx, nullptr, 1, 0, gamma, beta, out, ldo, out_kind, nullptr, 0, M, C, eps, gamma2, beta2, split,
+                   (hipStream_t)stream);
 }
 
 extern "C" int msclip_embed_tokens(const long long* tokens, const float* emb, const float* pos, float* x, int ldx,

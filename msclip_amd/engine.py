@@ -258,12 +258,16 @@ class Engine:
                 self._parallel_stage(j, w, Bi)
                 self._adapter(j, w, Bi)
                 vis_src, raw = w["XA"], X[:Mv]          # ln_1 reads the adapter output and moves it back into X
-            # --- ln_1 (modality specific)
-            for r0, r1, b in segs:
-                if b is vb:
-                    hip.layernorm(vis_src, b["ln1"].g, b["ln1"].b, LNO[r0:r1], r1 - r0, raw_out=raw)
-                else:
-                    hip.layernorm(X[r0:r1], b["ln1"].g, b["ln1"].b, LNO[r0:r1], r1 - r0)
+            # --- ln_1 (modality specific parameters; one launch over both towers' rows unless the adapter output
+            #     has to be picked up from its own buffer)
+            if len(segs) == 2 and raw is None:
+                hip.layernorm_split(X[:M], vb["ln1"].g, vb["ln1"].b, tb["ln1"].g, tb["ln1"].b, Mv, LNO[:M], M)
+            else:
+                for r0, r1, b in segs:
+                    if b is vb:
+                        hip.layernorm(vis_src, b["ln1"].g, b["ln1"].b, LNO[r0:r1], r1 - r0, raw_out=raw)
+                    else:
+                        hip.layernorm(X[r0:r1], b["ln1"].g, b["ln1"].b, LNO[r0:r1], r1 - r0)
             # --- projections: one launch over both towers when the tensors are shared
             groups = [(segs[0][0], segs[-1][1], segs[0][2]["w"])] if len(segs) == 2 and vb["w"] is tb["w"] else \
                      [(r0, r1, b["w"]) for r0, r1, b in segs]
@@ -275,8 +279,11 @@ class Engine:
                 hip.attention(QKV[Mv:M], AO[Mv:M], Bt, self.Lt, self.heads, True)
             for r0, r1, bw in groups:
                 hip.gemm(AO[r0:r1], bw.wo, X[r0:r1], bias=bw.bo, resid=X[r0:r1], resid_kind=hip.RESID_F32)
-            for r0, r1, b in segs:
-                hip.layernorm(X[r0:r1], b["ln2"].g, b["ln2"].b, LNO[r0:r1], r1 - r0)
+            if len(segs) == 2:
+                hip.layernorm_split(X[:M], vb["ln2"].g, vb["ln2"].b, tb["ln2"].g, tb["ln2"].b, Mv, LNO[:M], M)
+            else:
+                for r0, r1, b in segs:
+                    hip.layernorm(X[r0:r1], b["ln2"].g, b["ln2"].b, LNO[r0:r1], r1 - r0)
             for r0, r1, bw in groups:
                 hip.gemm(LNO[r0:r1], bw.wfc, HID[r0:r1], bias=bw.bfc, act=hip.ACT_QUICKGELU)
                 hip.gemm(HID[r0:r1], bw.wpr, X[r0:r1], bias=bw.bpr, resid=X[r0:r1], resid_kind=hip.RESID_F32)

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("MSCLIP_HIP_LIB") or os.path.join(_HERE, "csrc", "libm
 INT_MAX = 2 ** 31 - 1
 
 EXPORTS = (
-    "msclip_gemm", "msclip_attention", "msclip_layernorm", "msclip_embed_tokens", "msclip_fill_cls",
+    "msclip_gemm", "msclip_attention", "msclip_layernorm", "msclip_layernorm_split", "msclip_embed_tokens", "msclip_fill_cls",
     "msclip_adapter_combine_ln", "msclip_l2norm", "msclip_stem_conv3x3s2_dual", "msclip_dwpool",
     "msclip_lse_rows", "msclip_clip_loss_partial", "msclip_clip_lse_fused", "msclip_clip_loss_from_partials",
     "msclip_abi_version", "msclip_build_arch",
@@ -70,6 +70,7 @@ def lib():
         L.msclip_gemm.argtypes = [ctypes.POINTER(GemmDesc), vp]
         L.msclip_attention.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, vp]
         L.msclip_layernorm.argtypes = [vp, ci, vp, ci, ci, vp, vp, vp, ci, ci, vp, ci, ci, ci, cf, vp]
+        L.msclip_layernorm_split.argtypes = [vp, ci, vp, vp, vp, vp, ci, vp, ci, ci, ci, ci, cf, vp]
         L.msclip_embed_tokens.argtypes = [vp, vp, vp, vp, ci, vp, ci, ci, ci, ci, ci, vp]
         L.msclip_fill_cls.argtypes = [vp, vp, vp, ci, ci, ci, ci, vp]
         L.msclip_adapter_combine_ln.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, vp]
@@ -253,6 +254,15 @@ def layernorm(x, gamma, beta, out, M, *, row_idx=None, row_mul=1, row_add=0, eps
                                   out.stride(0), 1 if out.dtype == torch.float32 else 0, _p(raw_out),
                                   raw_out.stride(0) if raw_out is not None else 0, M, C, eps, _stream()),
            "msclip_layernorm")
+    return out
+
+
+def layernorm_split(x, gamma, beta, gamma2, beta2, split, out, M, eps=1e-12):
+    """out[m] = LN(x[m]) with (gamma, beta) for m < split and (gamma2, beta2) from there on."""
+    assert x.dtype == torch.float32 and x.is_cuda and x.stride(-1) == 1
+    _check(lib().msclip_layernorm_split(_p(x), x.stride(0), _p(gamma), _p(beta), _p(gamma2), _p(beta2), split, _p(out),
+                                        out.stride(0), 1 if out.dtype == torch.float32 else 0, M, x.shape[-1], eps,
+                                        _stream()), "msclip_layernorm_split")
     return out
 
 

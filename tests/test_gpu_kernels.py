@@ -151,6 +151,20 @@ def test_gemm_token_scatter_with_table(gpu_device):
     assert float(got[:, 0].abs().max()) == 0.0 and float(X[B * L:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
+def test_gemm_token_scatter_every_tile_config(gpu_device, tile):
+    """The stem -> token-row scatter with the positional table at a batch where the large-tile kernels take it."""
+    B, g2, D, K = 700, 49, 768, 768                                # M = 34300: 134 row tiles of 256
+    x, w = rnd(B * g2, K, seed=71, dtype=BF), rnd(D, K, seed=72, scale=0.05, dtype=BF)
+    pos = rnd(g2 + 1, D, seed=73)
+    X = torch.full((B * (g2 + 1), D), float("nan"), dtype=torch.float32, device="cuda")
+    hip.gemm(x, w, X, M=B * g2, resid=pos, resid_kind=hip.RESID_TABLE, rpg=g2, radd=1, roff=1, tile=tile)
+    ref = (x.float() @ w.float().t()).reshape(B, g2, D) + pos[1:]
+    got = X.reshape(B, g2 + 1, D)
+    close(got[:, 1:], ref, 4e-3, 1e-4)
+    assert bool(torch.isnan(got[:, 0]).all())                                   # class-token rows untouched
+
+
 def test_gemm_strided_operands_for_logits(gpu_device):
     """Both operands are column slices of the packed [N, 2, E] feature buffer."""
     n, E = 200, 512
@@ -241,6 +255,24 @@ def test_layernorm_variants(gpu_device):
     hip.layernorm(x512, g[:512].contiguous(), b[:512].contiguous(), o, 9)
     u = x512.mean(-1, keepdim=True)
     close(o, g[:512] * ((x512 - u) / torch.sqrt((x512 - u).pow(2).mean(-1, keepdim=True) + 1e-12)) + b[:512], 1e-4, 1e-5)
+
+
+def test_layernorm_split_parameters(gpu_device):
+    M, C, split = 700, 768, 257
+    x = rnd(M, C, seed=61, scale=3.0) + 0.5
+    g1, b1, g2, b2 = rnd(C, seed=62) * 0.2 + 1, rnd(C, seed=63) * 0.1, rnd(C, seed=64) * 0.2 + 1, rnd(C, seed=65) * 0.1
+    out = torch.empty(M, C, dtype=BF, device="cuda")
+    hip.layernorm_split(x, g1, b1, g2, b2, split, out, M)
+
+    def ln(v, g, b):
+        u = v.mean(-1, keepdim=True)
+        s = ((v - u) ** 2).mean(-1, keepdim=True)
+        return g * ((v - u) / torch.sqrt(s + 1e-12)) + b
+    close(out[:split], ln(x[:split], g1, b1), 2e-2, 1e-2)
+    close(out[split:], ln(x[split:], g2, b2), 2e-2, 1e-2)
+    ref1 = torch.empty(split, C, dtype=BF, device="cuda")
+    hip.layernorm(x[:split], g1, b1, ref1, split)
+    assert torch.equal(out[:split], ref1)                                       # bitwise the single-set kernel
 
 
 def test_embed_tokens_and_eot(gpu_device):
