@@ -114,6 +114,26 @@ def test_full_bench_batch_properties(gpu_device):
     # the small run goes through other tile configurations (fp32 sums associate differently -> bf16 rounding flips)
     assert (small_i - fi[100:104]).abs().max().item() <= 2e-3
     assert (small_t - ft[300:303]).abs().max().item() <= 2e-3
+    # and the full-size path (large-tile kernels everywhere) is pinned to the oracle on a few of its samples
+    sd, arch = synth_sd("b32-yfcc-msclips"), O.arch_b32()
+    with torch.no_grad():
+        check_feats(fi[[0, 255, 511]], O.encode_image(img[[0, 255, 511]].cpu(), sd, arch))
+        check_feats(ft[[1, 256, 510]], O.encode_text(tok[[1, 256, 510]].cpu(), sd, arch))
+
+
+def test_full_batch_b16_against_oracle(gpu_device):
+    """BASELINE config C3 (ViT-B/16, B = 256: 197-token attention, 14 x 14 adapters) against the oracle on a few samples."""
+    name = "b16-yfcc-msclips"
+    m, sd, arch = model_for(name), synth_sd(name), O.arch_b16()
+    B = 256
+    img = synth.synth_images(B, seed=43).cuda()
+    tok = synth.synth_tokens(B, seed=44).cuda()
+    w = m.engine().run(img, tok)
+    fi, ft = w["fv"].clone(), w["ft"].clone()
+    assert torch.isfinite(fi).all() and torch.isfinite(ft).all()
+    with torch.no_grad():
+        check_feats(fi[[0, 128, 255]], O.encode_image(img[[0, 128, 255]].cpu(), sd, arch))
+        check_feats(ft[[2, 100, 254]], O.encode_text(tok[[2, 100, 254]].cpu(), sd, arch))
 
 
 def test_inputs_validated(gpu_device):
