@@ -989,8 +989,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
   auto tile_origin = [&](int t, int& m0, int& n0) {
     const int q = ntiles >> 3, r = ntiles & 7, x = t & 7;
     const int id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (t >> 3);
-    m0 = (id / nt_n) * 256;
-    n0 = (id % nt_n) * 256;
+    // column groups of 4 tiles, rows fastest inside a group: the ~32 tiles an XCD runs together then cover 8 row blocks
+    // x 4 column slices (12 distinct operand slices in its L2) instead of 2.7 x 12 (14.7); +1 % on the step
+    constexpr int CG = 4;
+    const int per = nt_m * CG;
+    const int g = id / per, idg = id - g * per;
+    const int wg = min(CG, nt_n - g * CG);
+    m0 = (idg / wg) * 256;
+    n0 = (g * CG + idg % wg) * 256;
   };
 
   // ---- issue side.  Piece p (rows 8p .. 8p+7 of a region) is issued by wave p & 7; lane -> row 8p + lane/8,
