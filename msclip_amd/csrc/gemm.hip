@@ -351,6 +351,7 @@ __device__ __forceinline__ void epilogue_pack16(f32x4 (&acc)[2 * TN][2 * TM], co
         for (int e = 0; e < 4; ++e) {
           v[e] = acc[ni][2 * tm + mi][e] * a.alpha + b[ni][e];
           if (ACT == 1) v[e] = v[e] / (1.f + __expf(-1.702f * v[e]));
+          if (ACT == 2) v[e] = fmaxf(v[e], 0.f);
         }
         stg_write8(wr + mi * 2048 + (((ni * 2 + (quad >> 1)) ^ wsw) << 4), pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
       }
@@ -970,6 +971,11 @@ __device__ __forceinline__ bf16x8 pp_ld(const void* p) {
 __device__ __forceinline__ bf16x8 pp_ld(const void* p) { return *(const bf16x8*)p; }
 #endif
 
+// MODE 1: implicit GEMM of a convolution whose input-channel count is a multiple of 64 (a K-tile never straddles a
+// filter tap).  X rows are output pixels: the lane keeps the byte offset of its four pixels' window origin and their
+// (ih0, iw0); a K-tile adds the tap's offset (chunk table entry 8*kti, fetched a phase ahead as a scalar load) and taps
+// outside the image -- or rows past M -- get an offset beyond the descriptor's range (read as zero).
+template <int MODE>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) {
   constexpr int TM = 4, TN = 2;
   __shared__ __attribute__((aligned(1024))) bf16_t smem[PSLOTS * PREG];
@@ -1012,7 +1018,32 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
   const unsigned xhalf = 128u * (unsigned)a.ldx * 2u, whalf = 128u * (unsigned)a.ldw * 2u;
   int ti = blockIdx.x, kti = 0, islot = 0;
   __amdgpu_buffer_rsrc_t rx, rw;
+  // conv mode: window origin of this lane's pixel rows [half][piece]: byte offset + 16-byte chunk, and (ih0, iw0)
+  int cpix[2][2], chw[2][2];                       // (ih0 in the low half, iw0 in the high half)
+  int ce = 0;                                      // chunk-table entry of the K-tile whose X regions are issued next
   auto set_tile = [&](int t) {
+    if (MODE == 1) {
+      int m0 = 0, n0 = 0;
+      if (t < ntiles) tile_origin(t, m0, n0);
+      const int hw = a.Ho * a.Wo;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int row = (wave + 8 * i) * 8 + (lane >> 3);
+          const int m = m0 + h * 128 + row;
+          const int b = m / hw, rem = m - b * hw;
+          const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+          const int ih0 = ho * a.stride - a.pad, iw0 = wo * a.stride - a.pad;
+          const int ihs = (t < ntiles && m < a.M) ? ih0 : -(1 << 14);     // rows past M: every tap is "outside"
+          chw[h][i] = (ihs & 0xffff) | (iw0 << 16);
+          cpix[h][i] = (((b * a.H + ih0) * a.Wd + iw0) * a.Cin) * 2 + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
+        }
+      const unsigned long long wb = (unsigned long long)(a.N - n0) * (unsigned long long)a.ldw * 2ull;
+      rw = t < ntiles ? make_rsrc((const bf16_t*)a.W + (size_t)n0 * a.ldw, wb > 0xffffffffull ? 0xffffffffu : (unsigned)wb)
+                      : make_rsrc(a.W, 0);
+      return;
+    }
     if (t < ntiles) {
       int m0, n0;
       tile_origin(t, m0, n0);
@@ -1041,6 +1072,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
 #ifndef PP_ONEDMA
       blds16(rw, vw[1], ko + (J & 1) * whalf, dst + 8 * 512);
 #endif
+    } else if (MODE == 1) {
+      const int kh = (ce >> 20) & 15, kw = (ce >> 24) & 15, doff = (ce & 0xfffff) * 2;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ih = ((chw[J & 1][i] << 16) >> 16) + kh, iw = (chw[J & 1][i] >> 16) + kw;
+        const bool ok = (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.Wd;
+        blds16(rx, ok ? (unsigned)(cpix[J & 1][i] + doff) : 0x80000000u, 0, dst + i * 8 * 512);
+      }
     } else {
       blds16(rx, vx[0], ko + (J & 1) * xhalf, dst);
 #ifndef PP_ONEDMA
@@ -1048,6 +1087,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
 #endif
     }
 #endif
+    if (MODE == 1 && J == 1) {
+      // entry for the X regions of this K-tile, issued two phases on.  A scalar load in inline asm (with its own wait,
+      // so the value is valid wherever the compiler keeps or moves it): as a tracked vector load it would sit in the
+      // VM counter's in-order queue and its use would drain every DMA piece in flight.
+      const int* tp = a.ktab + kti * 8;
+      asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ce) : "s"(tp));
+    }
     islot = islot == PSLOTS - 1 ? 0 : islot + 1;
     if (J == 3) {
       if (++kti == nk) {
@@ -1080,6 +1126,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
 #ifdef PP_DESYNC   // probe: spread the workgroups' epilogue bursts
   for (int i = ((blockIdx.x >> 3) & 31) * PP_DESYNC; i > 0; --i) __builtin_amdgcn_s_sleep(8);   // 512-cycle steps
 #endif
+  if (MODE == 1)                                   // one descriptor over the whole NHWC input (< 2 GiB, checked by the host)
+    rx = make_rsrc(a.X, (unsigned)((long long)(a.M / (a.Ho * a.Wo)) * a.H * a.Wd * a.Cin * 2));
   set_tile(ti);
   issue(I0{}); issue(I1{}); issue(I2{}); issue(I3{});
   issue(I0{}); issue(I1{}); issue(I2{});
@@ -1272,6 +1320,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
           epilogue_pack16<TM, TN, 0>(acc, a, stg, mw0, nw0, lane_e, bcol, trp);               // QKV
         else if (pack16 && a.act == 1)
           epilogue_pack16<TM, TN, 1>(acc, a, stg, mw0, nw0, lane_e, bcol, trp);               // c_fc + QuickGELU
+        else if (pack16 && a.act == 2)
+          epilogue_pack16<TM, TN, 2>(acc, a, stg, mw0, nw0, lane_e, bcol, trp);               // convolution + ReLU
 #else
         if (a.resid_kind == 0 && a.act == 0 && a.out_kind == 0)
           epilogue_rows<TM, TN, 0, 0, 0>(acc, a, stg, mw0, nw0, lane_e, bias4, trp);
@@ -1351,12 +1401,21 @@ extern "C" int msclip_gemm(const msclip_gemm_desc* d, void* stream) {
     const bool pp_ok = (long long)d->ldx * 2 * 256 + (long long)d->K * 2 < (1ll << 31) &&
                        (long long)d->ldw * 2 * 256 + (long long)d->K * 2 < (1ll << 31);
     if (pp_ok && (d->tile == 4 || (d->tile == 0 && big))) {        // ping-pong kernel (default for the projections)
-      hipLaunchKernelGGL(gemm_pp_kernel, dim3(tiles < ncu ? tiles : ncu), dim3(512), 0, st, *d);
+      hipLaunchKernelGGL(gemm_pp_kernel<0>, dim3(tiles < ncu ? tiles : ncu), dim3(512), 0, st, *d);
     } else if (big && d->tile != 3) {   // streaming ring kernel (tile 2; tile 3 selects the two-buffer 256x256 kernel: A/B tests)
       hipLaunchKernelGGL(gemm_ring_kernel, dim3(tiles < ncu ? tiles : ncu), dim3(512), 0, st, *d);
     } else if (big) launch_cfg<0, 256, 256, 2, 4>(d, st, 1);
     else launch_cfg<0, 128, 128, 2, 2>(d, st, 2);
   } else {
+    // input channels a multiple of 64 (a K-tile stays inside one filter tap): the ping-pong kernel gathers the rows itself
+    const long long in_bytes = (long long)(d->M / (d->Ho * d->Wo)) * d->H * d->Wd * d->Cin * 2;
+    const long long t256 = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256);
+    if ((d->tile == 0 || d->tile == 4) && d->Cin % 64 == 0 && d->K % d->Cin == 0 && in_bytes < (1ll << 31) &&
+        (long long)d->ldw * 2 * 256 + (long long)d->K * 2 < (1ll << 31) && d->rpg == 0x7fffffff && d->resid_kind != 3 &&
+        d->M % (d->Ho * d->Wo) == 0 && (t256 >= 128 || d->tile == 4)) {
+      hipLaunchKernelGGL(gemm_pp_kernel<1>, dim3(t256 < ncu ? (int)t256 : ncu), dim3(512), 0, st, *d);
+      return msclip_launch_status();
+    }
     // N a multiple of 192 (192 / 384 / 768 output channels): 256 x 192 tiles leave no idle columns
     const long long t192 = (long long)((d->M + 255) / 256) * ((d->N + 191) / 192);
     if (d->tile == 6 || (d->tile == 0 && d->N % 192 == 0 && t192 >= 128)) launch_cfg<1, 256, 192, 4, 2>(d, st, 1);

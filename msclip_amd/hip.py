@@ -156,7 +156,7 @@ class KernelProbe:
 _gemm_probe = {}   # kernel variant -> KernelProbe
 
 
-def gemm_variant(mode, M, N, tile=0, K=None):
+def gemm_variant(mode, M, N, tile=0, K=None, cin=None):
     """Which kernel msclip_gemm dispatches to (mirror of the rule in csrc/gemm.hip): 'pp' = gemm_pp_kernel (dense
     256x256 ping-pong, the default for large problems), 'ring' = gemm_ring_kernel (tile 2), 'stream' = gemm_stream_kernel (K <= 192), 'conv256'/'conv128' =
     gemm_kernel<1,...>, 'dense256'/'dense128' = gemm_kernel<0,...>."""
@@ -170,6 +170,8 @@ def gemm_variant(mode, M, N, tile=0, K=None):
         return "ring" if (big and tile != 3) else ("dense256" if big else "dense128")
     if tile in (0, 5) and K is not None and (K <= 192 or K == 448) and K % 64 == 0 and M >= 4096 and (K != 448 or N <= 96):
         return "stream"
+    if tile in (0, 4) and cin is not None and cin % 64 == 0 and ((M + 255) // 256) * ((N + 255) // 256) >= 128:
+        return "ppconv"
     if tile == 6 or (tile == 0 and N % 192 == 0 and ((M + 255) // 256) * ((N + 191) // 192) >= 128):
         return "conv192"
     return "conv256" if big else "conv128"
@@ -212,7 +214,7 @@ def gemm(x, w, out, *, M=None, bias=None, resid=None, resid_kind=0, act=0, alpha
     d.alpha = alpha
     d.rpg, d.radd, d.roff = rpg, radd, roff
     d.tile = tile
-    probe = _gemm_probe.get(d.mode) or _gemm_probe.get(gemm_variant(d.mode, d.M, d.N, tile, d.K if d.rpg == INT_MAX and resid_kind != RESID_TABLE else None)) if _gemm_probe else None
+    probe = _gemm_probe.get(d.mode) or _gemm_probe.get(gemm_variant(d.mode, d.M, d.N, tile, d.K if d.rpg == INT_MAX and resid_kind != RESID_TABLE else None, conv[2] if conv is not None else None)) if _gemm_probe else None
     if probe is not None:
         k_alg = d.K if conv is None else conv[2] * (ktab_taps(ktab) if ktab is not None else 1)
         t0 = probe.begin()

@@ -181,7 +181,9 @@ def test_gemm_strided_operands_for_logits(gpu_device):
     (3, 112, 48, 96, 3, 2, 1), (2, 112, 48, 48, 3, 2, 1), (5, 56, 48, 96, 1, 2, 0), (6, 56, 96, 192, 1, 2, 0),
     (24, 28, 192, 384, 1, 2, 0), (3, 90, 48, 40, 3, 2, 1),
     # N % 192 == 0 and enough tiles: the 256 x 192 two-buffer configuration
-    (45, 56, 96, 192, 3, 2, 1), (200, 14, 384, 768, 3, 2, 1)])
+    (45, 56, 96, 192, 3, 2, 1), (200, 14, 384, 768, 3, 2, 1),
+    # input channels a multiple of 64 and >= 128 tiles of 256 x 256: the ping-pong kernel in implicit-conv mode
+    (180, 28, 192, 384, 3, 2, 1), (170, 28, 192, 192, 3, 2, 1), (700, 14, 384, 768, 3, 2, 1), (150, 28, 64, 200, 3, 1, 1)])
 def test_gemm_implicit_conv(gpu_device, B, H, Cin, Cout, k, stride, pad):
     x = rnd(B, H, H, Cin, seed=13, dtype=BF)                      # NHWC
     w = rnd(Cout, Cin, k, k, seed=14, scale=(2.0 / (Cin * k * k)) ** 0.5)
