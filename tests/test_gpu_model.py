@@ -117,8 +117,12 @@ def test_full_bench_batch_properties(gpu_device):
     # and the full-size path (large-tile kernels everywhere) is pinned to the oracle on a few of its samples
     sd, arch = synth_sd("b32-yfcc-msclips"), O.arch_b32()
     with torch.no_grad():
-        check_feats(fi[[0, 255, 511]], O.encode_image(img[[0, 255, 511]].cpu(), sd, arch))
-        check_feats(ft[[1, 256, 510]], O.encode_text(tok[[1, 256, 510]].cpu(), sd, arch))
+        ri, rt = O.encode_image(img[[0, 255, 511]].cpu(), sd, arch), O.encode_text(tok[[1, 256, 510]].cpu(), sd, arch)
+    check_feats(fi[[0, 255, 511]], ri)
+    check_feats(ft[[1, 256, 510]], rt)
+    # single-tower calls at the same size (other row counts -> other tile grids)
+    check_feats(m.encode_image(img)[[0, 255, 511]], ri)
+    check_feats(m.encode_text(tok)[[1, 256, 510]], rt)
 
 
 def test_full_batch_b16_against_oracle(gpu_device):
