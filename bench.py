@@ -133,7 +133,7 @@ def main():
                 with open(tpath) as f:
                     traffic = round(json.load(f)["hbm_bytes_per_launch"])
             ach = flops / (kms * 1e-3) / 1e12
-            rec["roofline"] = {"kernel": "gemm_pp_kernel (dense bf16 MFMA GEMM: all transformer projections + wide pointwise convs)",
+            rec["roofline"] = {"kernel": "gemm_pp_kernel<0> (dense bf16 MFMA GEMM: all transformer projections + wide pointwise convs)",
                                "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_bench_hbm_traffic.json)",
                                "launches_per_step": n // args.steps, "avg_launch_us": round(kms / n * 1e3, 2),

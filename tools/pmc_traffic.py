@@ -17,8 +17,14 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         if r["Counter_Name"] == c:
             agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
     per[c] = {k: {"launches": len(v), "mean_kb": sum(v) / len(v)} for k, v in agg.items() if sum(v) / len(v) > 20000}
-f = per["FETCH_SIZE"][dominant]["mean_kb"]
-w = per["WRITE_SIZE"][dominant]["mean_kb"]
+def pick(table):   # exact name, else the kernel whose name starts with it and has the most launches (template suffixes)
+    if dominant in table:
+        return table[dominant]
+    cands = [v for k, v in table.items() if k.startswith(dominant)]
+    return max(cands, key=lambda v: v["launches"])
+
+f = pick(per["FETCH_SIZE"])["mean_kb"]
+w = pick(per["WRITE_SIZE"])["mean_kb"]
 print(json.dumps({
     "command": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-probe (separate passes)",
     "kernel": dominant, "fetch_size_kb_per_launch": f, "write_size_kb_per_launch": w,
