@@ -196,6 +196,22 @@ def test_gemm_implicit_conv(gpu_device, B, H, Cin, Cout, k, stride, pad):
     close(out.reshape(B, spec.h_out, spec.w_out, Cout), ref.permute(0, 2, 3, 1), 3e-2, 1e-2)
 
 
+@pytest.mark.parametrize("B,H,Cin,Cout,k,stride,pad", [(2, 14, 64, 96, 3, 2, 1), (3, 9, 128, 264, 3, 1, 1), (1, 20, 192, 40, 1, 1, 0)])
+def test_gemm_conv_pingpong_forced_small(gpu_device, B, H, Cin, Cout, k, stride, pad):
+    """The ping-pong kernel's implicit-conv mode on a single ragged tile (rows past M, columns past N, every border)."""
+    x = rnd(B, H, H, Cin, seed=81, dtype=BF)
+    w = rnd(Cout, Cin, k, k, seed=82, scale=(2.0 / (Cin * k * k)) ** 0.5)
+    b = rnd(Cout, seed=83)
+    spec = P.ConvSpec(w, b, H, H, stride, pad).to("cuda")
+    M = B * spec.h_out * spec.w_out
+    out = torch.full((M + 2, Cout), float("nan"), dtype=BF, device="cuda")
+    hip.gemm(x, spec.weight, out[:M], M=M, N=Cout, bias=spec.bias, act=hip.ACT_RELU, conv=spec.geometry(),
+             ktab=spec.ktab, tile=4)
+    ref = F.relu(F.conv2d(x.float().permute(0, 3, 1, 2), w.to(BF).float(), b, stride=stride, padding=pad))
+    close(out[:M].reshape(B, spec.h_out, spec.w_out, Cout), ref.permute(0, 2, 3, 1), 3e-2, 1e-2)
+    assert bool(torch.isnan(out[M:].float()).all())
+
+
 @pytest.mark.parametrize("B,L,causal", [(3, 50, False), (5, 77, True), (2, 197, False), (1, 1, False), (2, 33, True),
                                         (2, 64, True), (1, 96, False)])
 def test_attention(gpu_device, B, L, causal):
