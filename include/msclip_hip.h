@@ -99,6 +99,20 @@ int msclip_l2norm(const float* x, int ldx, float* out_f32, int ldf, void* out_bf
 int msclip_stem_conv3x3s2_dual(const void* img, int img_is_bf16, const float* w, const float* bias, void* out_a,
                                void* out_b, int B, int H, int W, int C1, void* stream);
 
+/* The same pass fused with the 3x3/s2/p1 convolution that consumes branch a (stem resnet_stage.conv_0 with its folded
+ * 1x1 shortcut and ReLU, M.py:1920-1936): branch a's 48-channel map stays in LDS (8x8 output tiles, 17x17 windows),
+ * branch b (parallel stage 0) is written as before.  w2: bf16 [Cout][448] (K = (kh*3+kw)*48 + c, zero padded),
+ * b2 [Cout], out2 NHWC bf16 [B, Ho/2.., Cout]; C1 is 48, Cout 48 or 96. */
+int msclip_stem_dual_conv3x3s2(const void* img, int img_is_bf16, const float* w, const float* bias, void* out_b,
+                               const void* w2, const float* b2, void* out2, int B, int H, int W, int Cout,
+                               void* stream);
+
+/* relu(conv3x3/s2/p1(relu(conv1x1(x)))) with folded BatchNorms (ConvResBlock conv1-bn1-relu-conv2-bn2-relu,
+ * M.py:1825-1840) without materialising the 1x1's output.  x NHWC bf16 [B, H, W, 48]; w1 bf16 [48][64] (K padded),
+ * w2 bf16 [Cout][448]; out NHWC bf16 [B, (H-1)/2+1, (W-1)/2+1, Cout]; Cout 48 or 96. */
+int msclip_conv1x1_conv3x3s2(const void* x, const void* w1, const float* b1, const void* w2, const float* b2,
+                             void* out, int B, int H, int W, int Cout, void* stream);
+
 /* Depthwise kernel==stride conv of the adapters (M.py:1573-1581): NHWC bf16 in, [B*g*g, ldo] bf16 out,
  * w fp32 [k*k][C] with the BN scale folded (the BN shift goes into the following 1x1's bias). */
 int msclip_dwpool(const void* top, const float* w, void* out, int ldo, int B, int H, int W, int C, int k,

@@ -160,7 +160,7 @@ class Engine:
         if Bi:
             w["XA"] = buf(Mv, D, dtype=f32)
             h1 = self.h1
-            w["S1"], w["P0"] = buf(Bi * h1 * h1, D // 16), buf(Bi * h1 * h1, D // 16)
+            w["P0"] = buf(Bi * h1 * h1, D // 16)            # S1 (conv1's map) only exists on the unfused path: _s1()
             w["stem"] = [buf(Bi * s.h_out * s.w_out, s.cout) for s in self.stem_specs]
             w["par"] = [w["P0"]]
             w["par_tmp"] = [None]
@@ -199,11 +199,24 @@ class Engine:
         return hip.gemm(x, spec.weight, out, M=M, N=spec.cout, bias=spec.bias, act=act, resid=resid, resid_kind=rk,
                         conv=spec.geometry(), ktab=spec.ktab)
 
+    @staticmethod
+    def _fusable_3x3s2(spec):
+        """3x3 / stride 2 / pad 1 over 48 channels: what the fused front kernels (csrc/front.hip) consume."""
+        return (spec.kh, spec.kw, spec.stride, spec.pad, spec.cin) == (3, 3, 2, 1, 48) and spec.cout in (48, 96)
+
     def _vision_front(self, img, w, Bi):
         """Stem + tokenisation (M.py:2416-2426) and stage 0 of the parallel branch (M.py:2436)."""
-        hip.stem_conv_dual(img, self.dual_w, self.dual_b, w["S1"], w["P0"])
-        x = w["S1"]
-        for spec, out in zip(self.stem_specs, w["stem"]):
+        first = self.stem_specs[0]
+        fused = (self.dual_w.shape[1] == 96 and self._fusable_3x3s2(first) and not hip.env_flag("MSCLIP_FRONT_UNFUSED")
+                 and img.numel() * img.element_size() < 2 ** 31)
+        if fused:
+            # conv1 + parallel stage 0 + stem stage 0 in one pass: conv1's 48-channel map never reaches HBM
+            hip.stem_dual_conv3x3s2(img, self.dual_w, self.dual_b, w["P0"], first.weight, first.bias, w["stem"][0])
+            x, rest = w["stem"][0], list(zip(self.stem_specs, w["stem"]))[1:]
+        else:
+            hip.stem_conv_dual(img, self.dual_w, self.dual_b, self._s1(w, Bi), w["P0"])
+            x, rest = w["S1"], list(zip(self.stem_specs, w["stem"]))
+        for spec, out in rest:
             self._conv(x, spec, out, Bi, act=hip.ACT_RELU)
             x = out
         g2 = self.g * self.g
@@ -219,8 +232,13 @@ class Engine:
         c1, c2, cr, c3 = self.par_specs[j]
         t1, t2, tr = w["par_tmp"][j]
         src = w["par"][j - 1]
-        self._conv(src, c1, t1, Bi, act=hip.ACT_RELU)
-        self._conv(t1, c2, t2, Bi, act=hip.ACT_RELU)
+        if ((c1.kh, c1.kw, c1.stride, c1.pad, c1.cin, c1.cout) == (1, 1, 1, 0, 48, 48) and self._fusable_3x3s2(c2)
+                and not hip.env_flag("MSCLIP_FRONT_UNFUSED") and src.numel() * 2 < 2 ** 31):
+            # conv1 -> conv2 of the bottleneck without its 112 x 112 intermediate map
+            hip.conv1x1_conv3x3s2(src, c1.weight, c1.bias, c2.weight, c2.bias, t2, Bi, c1.h_in, c1.w_in)
+        else:
+            self._conv(src, c1, t1, Bi, act=hip.ACT_RELU)
+            self._conv(t1, c2, t2, Bi, act=hip.ACT_RELU)
         self._conv(src, cr, tr, Bi)
         self._conv(t2, c3, w["par"][j], Bi, act=hip.ACT_RELU, resid=tr)
 
@@ -233,6 +251,12 @@ class Engine:
         hip.gemm(w["pool"][j], pw.weight, w["T"], M=Bi * self.g * self.g, N=pw.cout, bias=pw.bias, ldx=pw.cin)
         hip.adapter_combine_ln(w["X"][:w["Mv"]], w["T"], a["dww"], a["dwb"], a["ln"].g, a["ln"].b, w["XA"], Bi,
                                self.Lv, self.g, self.usecls)
+
+    def _s1(self, w, Bi):
+        if "S1" not in w:
+            n = Bi * self.h1 * self.h1 * (self.D // 16)
+            w["S1"] = torch.zeros(n + 64, dtype=torch.bfloat16, device=self.dev)[:n].view(-1, self.D // 16)
+        return w["S1"]
 
     def _text_front(self, tok, w, Bt):
         hip.embed_tokens(tok, self.emb, self.tpos, w["X"], w["eot"], w["Mv"])

@@ -18,6 +18,7 @@ INT_MAX = 2 ** 31 - 1
 EXPORTS = (
     "msclip_gemm", "msclip_attention", "msclip_layernorm", "msclip_layernorm_split", "msclip_embed_tokens", "msclip_fill_cls",
     "msclip_adapter_combine_ln", "msclip_l2norm", "msclip_stem_conv3x3s2_dual", "msclip_dwpool",
+    "msclip_stem_dual_conv3x3s2", "msclip_conv1x1_conv3x3s2",
     "msclip_lse_rows", "msclip_clip_loss_partial", "msclip_clip_lse_fused", "msclip_clip_loss_from_partials",
     "msclip_abi_version", "msclip_build_arch",
 )
@@ -77,6 +78,8 @@ def lib():
         L.msclip_l2norm.argtypes = [vp, ci, vp, ci, vp, ci, ci, ci, vp]
         L.msclip_stem_conv3x3s2_dual.argtypes = [vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, vp]
         L.msclip_dwpool.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
+        L.msclip_stem_dual_conv3x3s2.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
+        L.msclip_conv1x1_conv3x3s2.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
         L.msclip_lse_rows.argtypes = [vp, ci, vp, ci, ci, vp]
         L.msclip_clip_loss_partial.argtypes = [vp, vp, vp, ci, ci, ci, cf, vp, vp]
         L.msclip_clip_lse_fused.argtypes = [vp, ci, vp, ci, ci, ci, ci, cf, ci, ci, vp, vp, vp, vp]
@@ -88,6 +91,11 @@ def lib():
                 getattr(L, name).restype = ci
         _lib = L
     return _lib
+
+
+def env_flag(name):
+    """Selection knobs for A/B runs and cross-checks: set to 1 to take the older kernel chain."""
+    return os.environ.get(name, "0") == "1"
 
 
 def require_gpu():
@@ -297,6 +305,25 @@ def stem_conv_dual(img, w, bias, out_a, out_b):
     assert img.is_contiguous() and img.dtype in (torch.float32, torch.bfloat16)
     _check(lib().msclip_stem_conv3x3s2_dual(_p(img), int(img.dtype == torch.bfloat16), _p(w), _p(bias), _p(out_a),
                                             _p(out_b), B, H, W, w.shape[1] // 2, _stream()), "msclip_stem_conv3x3s2_dual")
+
+
+def stem_dual_conv3x3s2(img, w, bias, out_b, w2, b2, out2):
+    """Both Cin=3 convs + the 3x3/s2 conv that consumes the first one's map (which never reaches HBM)."""
+    B, _, H, W = img.shape
+    assert img.is_contiguous() and img.dtype in (torch.float32, torch.bfloat16)
+    assert w.shape[1] == 96 and w2.dtype == torch.bfloat16 and tuple(w2.shape[1:]) == (448,)
+    _check(lib().msclip_stem_dual_conv3x3s2(_p(img), int(img.dtype == torch.bfloat16), _p(w), _p(bias), _p(out_b),
+                                            _p(w2), _p(b2), _p(out2), B, H, W, w2.shape[0], _stream()),
+           "msclip_stem_dual_conv3x3s2")
+
+
+def conv1x1_conv3x3s2(x, w1, b1, w2, b2, out, B, H, W):
+    """relu(conv3x3/s2(relu(conv1x1(x)))) on NHWC bf16 with 48 channels in and between."""
+    _bf16(x)
+    assert tuple(w1.shape) == (48, 64) and w1.dtype == torch.bfloat16
+    assert w2.dtype == torch.bfloat16 and tuple(w2.shape[1:]) == (448,)
+    _check(lib().msclip_conv1x1_conv3x3s2(_p(x), _p(w1), _p(b1), _p(w2), _p(b2), _p(out), B, H, W, w2.shape[0],
+                                          _stream()), "msclip_conv1x1_conv3x3s2")
 
 
 def dwpool(top, w, out, B, H, W, C, k):

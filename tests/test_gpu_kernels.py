@@ -357,6 +357,54 @@ def test_stem_dual_conv(gpu_device, dtype):
     close(ob.reshape(B, 32, 32, 48), ref[..., 48:], 2e-2, 1e-2)
 
 
+@pytest.mark.parametrize("B,H,Cout", [(2, 32, 48), (3, 23, 48), (1, 112, 48), (2, 20, 96), (600, 8, 48)])
+def test_fused_conv1x1_conv3x3s2(gpu_device, B, H, Cout):
+    """Bottleneck conv1 -> conv2 without the intermediate map: tile interiors, halos, odd sizes, many tiles per CU."""
+    x = rnd(B, H, H, 48, seed=91, dtype=BF)
+    w1, b1 = rnd(48, 48, 1, 1, seed=92, scale=(2.0 / 48) ** 0.5), rnd(48, seed=93, scale=0.2)
+    w2, b2 = rnd(Cout, 48, 3, 3, seed=94, scale=(2.0 / 432) ** 0.5), rnd(Cout, seed=95, scale=0.2)
+    c1 = P.ConvSpec(w1, b1, H, H, 1, 0).to("cuda")
+    c2 = P.ConvSpec(w2, b2, H, H, 2, 1).to("cuda")
+    Ho = c2.h_out
+    out = torch.full((B * Ho * Ho + 3, Cout), float("nan"), dtype=BF, device="cuda")
+    hip.conv1x1_conv3x3s2(x, c1.weight, c1.bias, c2.weight, c2.bias, out, B, H, H)
+    xn = x.float().permute(0, 3, 1, 2)
+    t1 = F.relu(F.conv2d(xn, w1.to(BF).float(), b1)).to(BF).float()
+    ref = F.relu(F.conv2d(t1, w2.to(BF).float(), b2, stride=2, padding=1)).permute(0, 2, 3, 1)
+    close(out[:B * Ho * Ho].reshape(B, Ho, Ho, Cout), ref, 3e-2, 1e-2)
+    assert bool(torch.isnan(out[B * Ho * Ho:].float()).all())
+
+
+@pytest.mark.parametrize("dtype,B,S,Cout", [(torch.float32, 3, 64, 96), (BF, 2, 48, 96), (torch.float32, 2, 224, 96),
+                                            (torch.float32, 2, 40, 48)])
+def test_stem_dual_fused_with_next_conv(gpu_device, dtype, B, S, Cout):
+    """Stem conv1 + parallel stage 0 + the stem's 3x3/s2 stage 0 in one pass: branch b as the unfused kernel writes
+    it, the 96-channel map as the unfused chain computes it."""
+    img = rnd(B, 3, S, S, seed=34, dtype=dtype)
+    w, b = rnd(27, 96, seed=35, scale=0.3), rnd(96, seed=36, scale=0.2)
+    w2, b2 = rnd(Cout, 48, 3, 3, seed=96, scale=(2.0 / 432) ** 0.5), rnd(Cout, seed=97, scale=0.2)
+    Hm = S // 2
+    c2 = P.ConvSpec(w2, b2, Hm, Hm, 2, 1).to("cuda")
+    Ho = c2.h_out
+    ob = torch.full((B * Hm * Hm + 2, 48), float("nan"), dtype=BF, device="cuda")
+    out = torch.full((B * Ho * Ho + 2, Cout), float("nan"), dtype=BF, device="cuda")
+    hip.stem_dual_conv3x3s2(img, w, b, ob, c2.weight, c2.bias, out)
+    # operands rounded to bf16 as the kernel rounds them: what is left is summation order and the output rounding
+    mid = F.relu(F.conv2d(img.to(BF).float(), w.to(BF).float().t().reshape(96, 3, 3, 3), b, stride=2, padding=1))
+    close(ob[:B * Hm * Hm].reshape(B, Hm, Hm, 48), mid[:, 48:].permute(0, 2, 3, 1), 2e-3, 8e-3)
+    ref = F.relu(F.conv2d(mid[:, :48].to(BF).float(), w2.to(BF).float(), b2, stride=2, padding=1)).permute(0, 2, 3, 1)
+    close(out[:B * Ho * Ho].reshape(B, Ho, Ho, Cout), ref, 4e-2, 1e-2)
+    assert bool(torch.isnan(ob[B * Hm * Hm:].float()).all()) and bool(torch.isnan(out[B * Ho * Ho:].float()).all())
+    # the unfused kernels are the second opinion
+    oa2 = torch.empty(B * Hm * Hm, 48, dtype=BF, device="cuda")
+    ob2 = torch.empty(B * Hm * Hm, 48, dtype=BF, device="cuda")
+    hip.stem_conv_dual(img, w, b, oa2, ob2)
+    close(ob[:B * Hm * Hm], ob2, 1e-2, 1e-2)
+    out2 = torch.empty(B * Ho * Ho, Cout, dtype=BF, device="cuda")
+    hip.gemm(oa2, c2.weight, out2, M=B * Ho * Ho, N=Cout, bias=c2.bias, act=hip.ACT_RELU, conv=c2.geometry(), ktab=c2.ktab)
+    close(out[:B * Ho * Ho], out2, 4e-2, 1e-2)
+
+
 @pytest.mark.parametrize("C,k,g_", [(48, 16, 7), (96, 8, 7), (192, 4, 7), (768, 1, 7), (96, 4, 14)])
 def test_dwpool(gpu_device, C, k, g_):
     B, H = 2, k * g_

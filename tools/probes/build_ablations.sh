@@ -1,14 +1,16 @@
 #!/bin/bash
-# Build probe copies of libmsclip_hip.so with -D knobs (A/B runs of the GEMM main loop in one GPU call; never shipped).
-#   usage: build_ablations.sh name1 "-DX -DY" name2 "-DZ" ...
+# Build probe copies of libmsclip_hip.so with -D knobs on ONE source file (A/B runs in one GPU call; never shipped).
+#   usage: [ABL_FILE=front] build_ablations.sh name1 "-DX -DY" name2 "-DZ" ...     (default file: gemm)
 set -u
 SRC=/root/repo/msclip_amd/csrc
 OUT=/root/repo/tools/probes
+FILE=${ABL_FILE:-gemm}
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffast-math -fno-finite-math-only -Wno-unused-value"
+OTHERS=$(ls $SRC/build/*.o | grep -v "/$FILE.o")
 build() {  # name, defines
-  /opt/rocm/bin/hipcc $F $2 -c $SRC/gemm.hip -o $OUT/gemm_$1.o 2>&1 | grep -E "error" | head -3
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libgemm_$1.so $OUT/gemm_$1.o $SRC/build/gemm_small.o $SRC/build/api.o $SRC/build/attention.o $SRC/build/rows.o $SRC/build/conv.o $SRC/build/loss.o || echo "BUILD FAILED $1"
-  rm -f $OUT/gemm_$1.o
+  /opt/rocm/bin/hipcc $F $2 -c $SRC/$FILE.hip -o $OUT/abl_$1.o 2>&1 | grep -E "error" | head -3
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libgemm_$1.so $OUT/abl_$1.o $OTHERS || echo "BUILD FAILED $1"
+  rm -f $OUT/abl_$1.o
 }
 rm -f $OUT/libgemm_*.so
 while [ $# -ge 2 ]; do build "$1" "$2" & shift 2; done
