@@ -357,9 +357,12 @@ def test_stem_dual_conv(gpu_device, dtype):
     close(ob.reshape(B, 32, 32, 48), ref[..., 48:], 2e-2, 1e-2)
 
 
+@pytest.mark.parametrize("form", ["8wave", "4wave"])
 @pytest.mark.parametrize("B,H,Cout", [(2, 32, 48), (3, 23, 48), (1, 112, 48), (2, 20, 96), (600, 8, 48)])
-def test_fused_conv1x1_conv3x3s2(gpu_device, B, H, Cout):
-    """Bottleneck conv1 -> conv2 without the intermediate map: tile interiors, halos, odd sizes, many tiles per CU."""
+def test_fused_conv1x1_conv3x3s2(gpu_device, monkeypatch, B, H, Cout, form):
+    """Bottleneck conv1 -> conv2 without the intermediate map: tile interiors, halos, odd sizes, many tiles per CU
+    (more tiles than workgroups: the persistent loop, both window buffers, the prefetch chain)."""
+    monkeypatch.setenv("MSCLIP_FRONT_4WAVE", "1" if form == "4wave" else "0")
     x = rnd(B, H, H, 48, seed=91, dtype=BF)
     w1, b1 = rnd(48, 48, 1, 1, seed=92, scale=(2.0 / 48) ** 0.5), rnd(48, seed=93, scale=0.2)
     w2, b2 = rnd(Cout, 48, 3, 3, seed=94, scale=(2.0 / 432) ** 0.5), rnd(Cout, seed=95, scale=0.2)
@@ -375,11 +378,14 @@ def test_fused_conv1x1_conv3x3s2(gpu_device, B, H, Cout):
     assert bool(torch.isnan(out[B * Ho * Ho:].float()).all())
 
 
+@pytest.mark.parametrize("form", ["8wave", "4wave"])
 @pytest.mark.parametrize("dtype,B,S,Cout", [(torch.float32, 3, 64, 96), (BF, 2, 48, 96), (torch.float32, 2, 224, 96),
-                                            (torch.float32, 2, 40, 48)])
-def test_stem_dual_fused_with_next_conv(gpu_device, dtype, B, S, Cout):
+                                            (torch.float32, 2, 40, 48), (torch.float32, 300, 32, 96), (BF, 2, 42, 96)])
+def test_stem_dual_fused_with_next_conv(gpu_device, monkeypatch, dtype, B, S, Cout, form):
     """Stem conv1 + parallel stage 0 + the stem's 3x3/s2 stage 0 in one pass: branch b as the unfused kernel writes
-    it, the 96-channel map as the unfused chain computes it."""
+    it, the 96-channel map as the unfused chain computes it.  300 x 32 x 32 gives every workgroup several tiles (the
+    two-deep prefetch and both window buffers); width 42 is not a multiple of 4 (single-group kernel either way)."""
+    monkeypatch.setenv("MSCLIP_FRONT_4WAVE", "1" if form == "4wave" else "0")
     img = rnd(B, 3, S, S, seed=34, dtype=dtype)
     w, b = rnd(27, 96, seed=35, scale=0.3), rnd(96, seed=36, scale=0.2)
     w2, b2 = rnd(Cout, 48, 3, 3, seed=96, scale=(2.0 / 432) ** 0.5), rnd(Cout, seed=97, scale=0.2)
