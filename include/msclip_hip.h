@@ -113,6 +113,15 @@ int msclip_stem_dual_conv3x3s2(const void* img, int img_is_bf16, const float* w,
 int msclip_conv1x1_conv3x3s2(const void* x, const void* w1, const float* b1, const void* w2, const float* b2,
                              void* out, int B, int H, int W, int Cout, void* stream);
 
+/* A whole ConvResBlock with projection shortcut, 48 -> (48 mid) -> 96 channels at stride 2 (the first stage of the
+ * parallel branch, M.py:1825-1861): relu(conv3(relu(conv2(relu(conv1 x)))) + shortcut(x)), BatchNorms folded.  conv1's
+ * map, conv2's output and the shortcut's output stay on chip; conv3, the strided 1x1 shortcut and the residual add run
+ * as one K = 96 contraction per output pixel.  w1 bf16 [48][64], w2 bf16 [48][448], w3 / wr bf16 [96][64] (K = 48
+ * zero padded), b3r = conv3 bias + shortcut bias [96]; x NHWC bf16 [B, H, W, 48]; out NHWC bf16 [B, Ho, Wo, 96]. */
+int msclip_convresblock48_s2(const void* x, const void* w1, const float* b1, const void* w2, const float* b2,
+                             const void* w3, const void* wr, const float* b3r, void* out, int B, int H, int W,
+                             void* stream);
+
 /* Depthwise kernel==stride conv of the adapters (M.py:1573-1581): NHWC bf16 in, [B*g*g, ldo] bf16 out,
  * w fp32 [k*k][C] with the BN scale folded (the BN shift goes into the following 1x1's bias). */
 int msclip_dwpool(const void* top, const float* w, void* out, int ldo, int B, int H, int W, int C, int k,

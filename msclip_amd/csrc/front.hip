@@ -42,6 +42,7 @@ constexpr int KS = KP / 32;               // 14 K-steps
 constexpr int WS = KP * 2 + 16;           // weight row stride in LDS (912: conflict-free 16-byte reads over 16 rows)
 constexpr int KREG = 7;                   // consumer K-steps whose weights live in registers
 constexpr int WS2 = (KS - KREG) * 64 + 16;  // LDS row stride of the other K-steps (464: conflict-free over 16 rows)
+constexpr int RS = 2 * CM * 2 + 16;        // TAIL staging row: 48 + 48 channels (208 bytes: conflict-free over 16 rows)
 constexpr int PSTB = 4 * TS * TS * CM * 2;  // stage-0 map of the tile interior (16 x 16 pixels)
 constexpr int PATCHB = 3 * (4 * TS + 3) * (4 * TS + 4) * 2 + 8;   // bf16 image patch [3][35][36]
 
@@ -52,6 +53,9 @@ struct FrontArgs {
   const bf16_t* w2;     // bf16 [Cout][448], K = (kh*3 + kw)*48 + c
   const float* b2;      // [Cout]
   bf16_t* side;         // PROD 0: stage-0 map NHWC bf16 [B, Hm, Wm, 48]
+  const bf16_t* w3;     // TAIL: conv3 [96][64] and shortcut [96][64] weights (K = 48 padded), b3 = conv3 + shortcut bias
+  const bf16_t* wr;
+  const float* b3;
   bf16_t* out;          // NHWC bf16 [B, Ho, Wo, Cout]
   unsigned xbytes;      // extent of x (< 2^31: offsets beyond it mark padding)
   unsigned sbytes;      // extent of side
@@ -348,14 +352,17 @@ __device__ unsigned long long g_front_trace[32];
 //  * Only the consumer group stores to HBM (the producer's stage-0 map goes through an LDS staging block and leaves
 //    as full lines from the consumer waves); only the producer group loads.  A wave that both loads and stores has
 //    to wait for its slowly acknowledged stores before the VM counter tells it that an older prefetch has landed.
-template <int PROD, int NTT, typename InT>
+template <int PROD, int NTT, typename InT, bool TAIL = false>
 __global__ __launch_bounds__(512) void front_ws_kernel(FrontArgs a) {
+  static_assert(!TAIL || (PROD == 1 && NTT == 3), "the fused block tail belongs to the 48-channel bottleneck");
   extern __shared__ __attribute__((aligned(128))) char lds[];
   char* const mid0 = lds;
   char* const pst = mid0 + 2 * MIDB;                    // PROD 0: stage-0 map of the tile interior [16 x 16][48]
-  char* const patch = pst + PSTB;                       // PROD 0: bf16 [3][35][36] image patch
-  char* const wl = patch + PATCHB;                      // 3x3 weights, K-steps KREG.. : [COUT][WS2]
+  char* const patch = pst + (PROD == 0 ? PSTB : 0);     // PROD 0: bf16 [3][35][36] image patch
+  char* const wl = patch + (PROD == 0 ? PATCHB : 0);    // 3x3 weights, K-steps KREG.. : [COUT][WS2]
   char* const trash = wl + NTT * 16 * WS2;              // 128 bytes that masked-out lanes write to
+  char* const rows = trash + 128;                       // TAIL: [2][64 pixels][RS]: conv2 output | centre pixel of x
+  char* const wt = rows + 2 * 64 * RS;                  // TAIL: [96][RS]: conv3 weights | shortcut weights
   constexpr int COUT = NTT * 16;
   constexpr int MT = NTT / 3;
   constexpr int NP = PROD == 0 ? 6 : 3;
@@ -484,7 +491,8 @@ __global__ __launch_bounds__(512) void front_ws_kernel(FrontArgs a) {
         }
       }
     };
-    auto produce = [&](int t, char* mid) __attribute__((always_inline)) {
+    auto produce = [&](int t, int wb) __attribute__((always_inline)) {
+      char* const mid = mid0 + wb * MIDB;
       int b, oy0, ox0;
       coords(t, b, oy0, ox0);
 #pragma unroll
@@ -500,6 +508,14 @@ __global__ __launch_bounds__(512) void front_ws_kernel(FrontArgs a) {
         if constexpr (PROD == 1) {
           xb[0] = as_bf16x8(pre1[i][0]);
           xb[1] = as_bf16x8(pre1[i][1]);
+          if constexpr (TAIL) {
+            // the strided 1x1 shortcut samples x at the window's odd positions (= input pixel (2*oy, 2*ox)): park
+            // those pixels beside the slot where the consumer will put conv2's output for the same output pixel
+            const bool ctr = mp < NMID && (my & 1) && (mx & 1);
+            char* const cdst = rows + (wb * 64 + ((my - 1) >> 1) * 8 + ((mx - 1) >> 1)) * RS + CM * 2;
+            *(u32x4*)(ctr ? cdst + q * 16 : trash + q * 16) = pre1[i][0];
+            *(u32x4*)((ctr && q < 2) ? cdst + 64 + q * 16 : trash + q * 16) = pre1[i][1];
+          }
         } else {
           const char* src = patch + (2 * my * PWS + 2 * mx) * 2;
           unsigned short h[8];
@@ -541,7 +557,7 @@ __global__ __launch_bounds__(512) void front_ws_kernel(FrontArgs a) {
       __syncthreads();
       if (t + G < a.ntile) request(t + G, prawA);
       if (t + 2 * G < a.ntile) request(t + 2 * G, prawB);
-      produce(t, mid0);
+      produce(t, 0);
       __syncthreads();
       auto step = [&](u32x4 (&praw)[NPL]) __attribute__((always_inline)) {   // one iteration: tile t consumed, t+G produced
         const int tn = t + G;
@@ -553,7 +569,7 @@ __global__ __launch_bounds__(512) void front_ws_kernel(FrontArgs a) {
         if (gw == 0) WS_STAMP(1);
         __syncthreads();                                          // B1
         if (gw == 0) WS_STAMP(2);
-        if (tn < a.ntile) produce(tn, mid0 + (buf ^ 1) * MIDB);
+        if (tn < a.ntile) produce(tn, buf ^ 1);
         if (gw == 0) WS_STAMP(3);
         __syncthreads();                                          // B2
         if (gw == 0) WS_STAMP(4);
@@ -569,14 +585,14 @@ __global__ __launch_bounds__(512) void front_ws_kernel(FrontArgs a) {
     } else {
       request(t, prawA);
       __syncthreads();
-      produce(t, mid0);
+      produce(t, 0);
       if (t + G < a.ntile) request(t + G, prawA);
       __syncthreads();
       for (; t < a.ntile; t += G) {
         const int tn = t + G;
         __syncthreads();                                          // B1
         if (tn < a.ntile) {
-          produce(tn, mid0 + (buf ^ 1) * MIDB);
+          produce(tn, buf ^ 1);
           if (tn + G < a.ntile) request(tn + G, prawA);
         }
         __syncthreads();                                          // B2
@@ -599,6 +615,18 @@ __global__ __launch_bounds__(512) void front_ws_kernel(FrontArgs a) {
       *(u32x4*)(wl + r * WS2 + c * 16) = *(const u32x4*)(a.w2 + (size_t)r * KP + KREG * 32 + c * 8);
     }
     const char* const wrow = wl + (cn0 * 16 + p) * WS2 + q * 16;
+    [[maybe_unused]] float tb[6][4];
+    if constexpr (TAIL) {
+      for (int i = gtid; i < 96 * 12; i += 256) {                 // [W3 | Wr] rows of 96 K-values
+        const int n = i / 12, c = i - n * 12;
+        const bf16_t* src = c < 6 ? a.w3 + n * 64 + c * 8 : a.wr + n * 64 + (c - 6) * 8;
+        *(u32x4*)(wt + n * RS + c * 16) = *(const u32x4*)src;
+      }
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tb[j][r] = a.b3[j * 16 + 4 * q + r];
+    }
     float cb[3][4];
 #pragma unroll
     for (int j = 0; j < 3; ++j)
@@ -691,26 +719,69 @@ __global__ __launch_bounds__(512) void front_ws_kernel(FrontArgs a) {
       if (gw == 0) WS_STAMP(10);
       ksteps(KS / 2, KS);
       if (gw == 0) WS_STAMP(11);
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const int oy = oy0 + oyl[m], ox = ox0 + oxl[m];
-        // channel tiles cn0 and cn0+1: after swapping tile 0's odd lane rows with tile 1's even rows a lane holds 16
-        // contiguous bytes (rows 0, 2 -> channels 8*(q/2).. of tile 0, rows 1, 3 -> 16 + 8*(q/2).. of tile 1)
-        uint2 o[3];
+      if constexpr (TAIL) {
+        // Block tail: out = relu([W3 | Wr] . [relu(conv2) ; x(2oy, 2ox)] + (b3 + br)) -- conv3, the strided shortcut
+        // and the residual add as ONE K = 96 contraction per pixel.  This wave's 16 pixels of conv2 output go to its
+        // own rows of the staging block (beside the centre pixels the producer parked there), come back in the MFMA
+        // operand layout and meet the 96 x 96 weight block in LDS; neither conv2's output nor the shortcut's reaches HBM.
+        char* const rr = rows + (buf * 64 + gw * 16 + p) * RS;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-          o[j].x = relu_pack_bf16x2(acc[m][j][0], acc[m][j][1]);
-          o[j].y = relu_pack_bf16x2(acc[m][j][2], acc[m][j][3]);
+          uint2 o;
+          o.x = relu_pack_bf16x2(acc[0][j][0], acc[0][j][1]);
+          o.y = relu_pack_bf16x2(acc[0][j][2], acc[0][j][3]);
+          *(uint2*)(rr + (j * 16 + 4 * q) * 2) = o;
         }
-        uint2 lo = o[0], hi = o[1];
-        auto sw = __builtin_amdgcn_permlane16_swap(lo.x, hi.x, false, false);
-        lo.x = sw[0]; hi.x = sw[1];
-        sw = __builtin_amdgcn_permlane16_swap(lo.y, hi.y, false, false);
-        lo.y = sw[0]; hi.y = sw[1];
-        if (oy < a.Ho && ox < a.Wo) {
-          bf16_t* dst = a.out + (((size_t)b * a.Ho + oy) * a.Wo + ox) * COUT + cn0 * 16;
-          *(u32x4*)(dst + (q & 1) * 16 + (q >> 1) * 8) = u32x4{lo.x, lo.y, hi.x, hi.y};
-          *(uint2*)(dst + 32 + 4 * q) = o[2];
+        f32x4 acc2[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc2[j] = f32x4{tb[j][0], tb[j][1], tb[j][2], tb[j][3]};
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+          const bf16x8 xb = as_bf16x8(*(const u32x4*)(rr + (4 * s + q) * 16));
+#pragma unroll
+          for (int j = 0; j < 6; ++j) {
+            const bf16x8 wk = as_bf16x8(*(const u32x4*)(wt + (j * 16 + p) * RS + (4 * s + q) * 16));
+            acc2[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wk, xb, acc2[j], 0, 0, 0);
+          }
+        }
+        const int oy = oy0 + oyl[0], ox = ox0 + oxl[0];
+        const bool ok = oy < a.Ho && ox < a.Wo;
+        bf16_t* const dst = a.out + (((size_t)b * a.Ho + oy) * a.Wo + ox) * 96;
+#pragma unroll
+        for (int jp = 0; jp < 3; ++jp) {                           // channel-tile pairs: 16 contiguous bytes per lane
+          uint2 lo, hi;
+          lo.x = relu_pack_bf16x2(acc2[2 * jp][0], acc2[2 * jp][1]);
+          lo.y = relu_pack_bf16x2(acc2[2 * jp][2], acc2[2 * jp][3]);
+          hi.x = relu_pack_bf16x2(acc2[2 * jp + 1][0], acc2[2 * jp + 1][1]);
+          hi.y = relu_pack_bf16x2(acc2[2 * jp + 1][2], acc2[2 * jp + 1][3]);
+          auto sw = __builtin_amdgcn_permlane16_swap(lo.x, hi.x, false, false);
+          lo.x = sw[0]; hi.x = sw[1];
+          sw = __builtin_amdgcn_permlane16_swap(lo.y, hi.y, false, false);
+          lo.y = sw[0]; hi.y = sw[1];
+          if (ok) *(u32x4*)(dst + jp * 32 + (q & 1) * 16 + (q >> 1) * 8) = u32x4{lo.x, lo.y, hi.x, hi.y};
+        }
+      } else {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const int oy = oy0 + oyl[m], ox = ox0 + oxl[m];
+          // channel tiles cn0 and cn0+1: after swapping tile 0's odd lane rows with tile 1's even rows a lane holds 16
+          // contiguous bytes (rows 0, 2 -> channels 8*(q/2).. of tile 0, rows 1, 3 -> 16 + 8*(q/2).. of tile 1)
+          uint2 o[3];
+  #pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            o[j].x = relu_pack_bf16x2(acc[m][j][0], acc[m][j][1]);
+            o[j].y = relu_pack_bf16x2(acc[m][j][2], acc[m][j][3]);
+          }
+          uint2 lo = o[0], hi = o[1];
+          auto sw = __builtin_amdgcn_permlane16_swap(lo.x, hi.x, false, false);
+          lo.x = sw[0]; hi.x = sw[1];
+          sw = __builtin_amdgcn_permlane16_swap(lo.y, hi.y, false, false);
+          lo.y = sw[0]; hi.y = sw[1];
+          if (oy < a.Ho && ox < a.Wo) {
+            bf16_t* dst = a.out + (((size_t)b * a.Ho + oy) * a.Wo + ox) * COUT + cn0 * 16;
+            *(u32x4*)(dst + (q & 1) * 16 + (q >> 1) * 8) = u32x4{lo.x, lo.y, hi.x, hi.y};
+            *(uint2*)(dst + 32 + 4 * q) = o[2];
+          }
         }
       }
       if (gw == 0) WS_STAMP(12);
@@ -744,7 +815,7 @@ int launch_front(FrontArgs a, hipStream_t st) {
     hipLaunchKernelGGL((front_kernel<PROD, NTT, InT>), dim3(grid), dim3(256), lds, st, a);
     return msclip_launch_status();
   }
-  const size_t lds = (size_t)2 * MIDB + PSTB + PATCHB + (size_t)NTT * 16 * WS2 + 128;
+  const size_t lds = (size_t)2 * MIDB + (PROD == 0 ? PSTB + PATCHB : 0) + (size_t)NTT * 16 * WS2 + 128;
   static bool attr_ws = false;
   if (!attr_ws) {
     if (hipFuncSetAttribute((const void*)front_ws_kernel<PROD, NTT, InT>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -755,6 +826,25 @@ int launch_front(FrontArgs a, hipStream_t st) {
   int grid = ncu;                                               // one 8-wave workgroup per CU, persistent
   if (grid > a.ntile) grid = a.ntile;
   hipLaunchKernelGGL((front_ws_kernel<PROD, NTT, InT>), dim3(grid), dim3(512), lds, st, a);
+  return msclip_launch_status();
+}
+
+int launch_block_tail(FrontArgs a, hipStream_t st) {
+  int dev = 0, ncu = 256;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+    ncu = 256;
+  const size_t lds = (size_t)2 * MIDB + (size_t)3 * 16 * WS2 + 128 + 2 * 64 * RS + 96 * RS;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)front_ws_kernel<1, 3, bf16_t, true>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return MSCLIP_ELAUNCH;
+    attr_done = true;
+  }
+  int grid = ncu;
+  if (grid > a.ntile) grid = a.ntile;
+  hipLaunchKernelGGL((front_ws_kernel<1, 3, bf16_t, true>), dim3(grid), dim3(512), lds, st, a);
   return msclip_launch_status();
 }
 
@@ -792,6 +882,21 @@ extern "C" int msclip_conv1x1_conv3x3s2(const void* x, const void* w1, const flo
   if (xb >= 0x80000000ull) return MSCLIP_EINVAL;
   a.xbytes = (unsigned)xb;
   return Cout == 48 ? launch_front<1, 3, bf16_t>(a, (hipStream_t)stream) : launch_front<1, 6, bf16_t>(a, (hipStream_t)stream);
+}
+
+extern "C" int msclip_convresblock48_s2(const void* x, const void* w1, const float* b1, const void* w2, const float* b2,
+                                        const void* w3, const void* wr, const float* b3r, void* out, int B, int H,
+                                        int W, void* stream) {
+  if (!x || !w1 || !b1 || !w2 || !b2 || !w3 || !wr || !b3r || !out || B <= 0 || H <= 0 || W <= 0) return MSCLIP_EINVAL;
+  FrontArgs a{};
+  a.x = x; a.w1 = w1; a.b1 = b1; a.w2 = (const bf16_t*)w2; a.b2 = b2; a.side = nullptr; a.out = (bf16_t*)out;
+  a.w3 = (const bf16_t*)w3; a.wr = (const bf16_t*)wr; a.b3 = b3r;
+  a.Himg = a.Wimg = 0;
+  if (fill_geometry(a, B, H, W) != MSCLIP_OK) return MSCLIP_EINVAL;
+  const unsigned long long xb = (unsigned long long)B * H * W * CM * 2;
+  if (xb >= 0x80000000ull) return MSCLIP_EINVAL;
+  a.xbytes = (unsigned)xb;
+  return launch_block_tail(a, (hipStream_t)stream);
 }
 
 extern "C" int msclip_stem_dual_conv3x3s2(const void* img, int img_is_bf16, const float* w, const float* bias,

@@ -96,13 +96,14 @@ class Engine:
         # --- parallel branch + adapters
         self.lateral = list(vt.parallel_lateral_layers)
         self.usecls = vt.t2b_usecls
-        self.par_specs, self.adapters = [None], []
+        self.par_specs, self.par_b3r, self.adapters = [None], [None], []
         h = self.h1
         self.par_hw = [h]
         for j in range(1, 5):
             specs = P.bottleneck(sd, f"visual.transformer.parallel_branch_v.{j}.resnet_stage.conv_0", h,
                                  vt.parallel_strides[j])
             self.par_specs.append([s.to(dev) for s in specs])
+            self.par_b3r.append((specs[3].bias + specs[2].bias).contiguous().to(dev))      # conv3 + shortcut bias
             h = specs[3].h_out
             self.par_hw.append(h)
         for j in range(5):
@@ -232,8 +233,16 @@ class Engine:
         c1, c2, cr, c3 = self.par_specs[j]
         t1, t2, tr = w["par_tmp"][j]
         src = w["par"][j - 1]
-        if ((c1.kh, c1.kw, c1.stride, c1.pad, c1.cin, c1.cout) == (1, 1, 1, 0, 48, 48) and self._fusable_3x3s2(c2)
-                and not hip.env_flag("MSCLIP_FRONT_UNFUSED") and src.numel() * 2 < 2 ** 31):
+        lead = ((c1.kh, c1.kw, c1.stride, c1.pad, c1.cin, c1.cout) == (1, 1, 1, 0, 48, 48) and self._fusable_3x3s2(c2)
+                and not hip.env_flag("MSCLIP_FRONT_UNFUSED") and src.numel() * 2 < 2 ** 31)
+        if (lead and c2.cout == 48 and (cr.kh, cr.kw, cr.stride, cr.pad, cr.cin, cr.cout) == (1, 1, 2, 0, 48, 96)
+                and (c3.kh, c3.kw, c3.stride, c3.pad, c3.cin, c3.cout) == (1, 1, 1, 0, 48, 96)
+                and (cr.h_out, cr.w_out) == (c2.h_out, c2.w_out) and not hip.env_flag("MSCLIP_BLOCK_UNFUSED")):
+            # the whole stride-2 bottleneck in one launch: conv1's map, conv2's output and the shortcut stay on chip
+            hip.convresblock48_s2(src, c1.weight, c1.bias, c2.weight, c2.bias, c3.weight, cr.weight, self.par_b3r[j],
+                                  w["par"][j], Bi, c1.h_in, c1.w_in)
+            return
+        if lead:
             # conv1 -> conv2 of the bottleneck without its 112 x 112 intermediate map
             hip.conv1x1_conv3x3s2(src, c1.weight, c1.bias, c2.weight, c2.bias, t2, Bi, c1.h_in, c1.w_in)
         else:

@@ -18,7 +18,7 @@ INT_MAX = 2 ** 31 - 1
 EXPORTS = (
     "msclip_gemm", "msclip_attention", "msclip_layernorm", "msclip_layernorm_split", "msclip_embed_tokens", "msclip_fill_cls",
     "msclip_adapter_combine_ln", "msclip_l2norm", "msclip_stem_conv3x3s2_dual", "msclip_dwpool",
-    "msclip_stem_dual_conv3x3s2", "msclip_conv1x1_conv3x3s2",
+    "msclip_stem_dual_conv3x3s2", "msclip_conv1x1_conv3x3s2", "msclip_convresblock48_s2",
     "msclip_lse_rows", "msclip_clip_loss_partial", "msclip_clip_lse_fused", "msclip_clip_loss_from_partials",
     "msclip_abi_version", "msclip_build_arch",
 )
@@ -80,6 +80,7 @@ def lib():
         L.msclip_dwpool.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
         L.msclip_stem_dual_conv3x3s2.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
         L.msclip_conv1x1_conv3x3s2.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
+        L.msclip_convresblock48_s2.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]
         L.msclip_lse_rows.argtypes = [vp, ci, vp, ci, ci, vp]
         L.msclip_clip_loss_partial.argtypes = [vp, vp, vp, ci, ci, ci, cf, vp, vp]
         L.msclip_clip_lse_fused.argtypes = [vp, ci, vp, ci, ci, ci, ci, cf, ci, ci, vp, vp, vp, vp]
@@ -324,6 +325,16 @@ def conv1x1_conv3x3s2(x, w1, b1, w2, b2, out, B, H, W):
     assert w2.dtype == torch.bfloat16 and tuple(w2.shape[1:]) == (448,)
     _check(lib().msclip_conv1x1_conv3x3s2(_p(x), _p(w1), _p(b1), _p(w2), _p(b2), _p(out), B, H, W, w2.shape[0],
                                           _stream()), "msclip_conv1x1_conv3x3s2")
+
+
+def convresblock48_s2(x, w1, b1, w2, b2, w3, wr, b3r, out, B, H, W):
+    """Whole stride-2 bottleneck 48 -> 48 -> 96 with projection shortcut (one launch, no intermediate in HBM)."""
+    _bf16(x)
+    for w, shape in ((w1, (48, 64)), (w2, (48, 448)), (w3, (96, 64)), (wr, (96, 64))):
+        assert tuple(w.shape) == shape and w.dtype == torch.bfloat16 and w.is_contiguous(), (tuple(w.shape), shape)
+    assert b3r.numel() == 96 and b3r.dtype == torch.float32
+    _check(lib().msclip_convresblock48_s2(_p(x), _p(w1), _p(b1), _p(w2), _p(b2), _p(w3), _p(wr), _p(b3r), _p(out),
+                                          B, H, W, _stream()), "msclip_convresblock48_s2")
 
 
 def dwpool(top, w, out, B, H, W, C, k):

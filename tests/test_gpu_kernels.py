@@ -378,6 +378,33 @@ def test_fused_conv1x1_conv3x3s2(gpu_device, monkeypatch, B, H, Cout, form):
     assert bool(torch.isnan(out[B * Ho * Ho:].float()).all())
 
 
+@pytest.mark.parametrize("B,H", [(2, 32), (3, 23), (1, 112), (700, 8)])
+def test_fused_convresblock48_s2(gpu_device, B, H):
+    """The whole stride-2 bottleneck (conv1, conv2, conv3 + strided shortcut + add, ReLUs) in one launch against the
+    unfused chain's arithmetic: intermediates rounded to bf16 where the chain stores them."""
+    x = rnd(B, H, H, 48, seed=91, dtype=BF)
+    w1, b1 = rnd(48, 48, 1, 1, seed=92, scale=(2.0 / 48) ** 0.5), rnd(48, seed=93, scale=0.2)
+    w2, b2 = rnd(48, 48, 3, 3, seed=94, scale=(2.0 / 432) ** 0.5), rnd(48, seed=95, scale=0.2)
+    w3, b3 = rnd(96, 48, 1, 1, seed=96, scale=(1.0 / 48) ** 0.5), rnd(96, seed=97, scale=0.2)
+    wr, br = rnd(96, 48, 1, 1, seed=98, scale=(1.0 / 48) ** 0.5), rnd(96, seed=99, scale=0.2)
+    c1 = P.ConvSpec(w1, b1, H, H, 1, 0).to("cuda")
+    c2 = P.ConvSpec(w2, b2, H, H, 2, 1).to("cuda")
+    cr = P.ConvSpec(wr, br, H, H, 2, 0).to("cuda")
+    c3 = P.ConvSpec(w3, b3, c2.h_out, c2.w_out, 1, 0).to("cuda")
+    Ho = c2.h_out
+    assert cr.h_out == Ho
+    out = torch.full((B * Ho * Ho + 3, 96), float("nan"), dtype=BF, device="cuda")
+    hip.convresblock48_s2(x, c1.weight, c1.bias, c2.weight, c2.bias, c3.weight, cr.weight, (c3.bias + cr.bias).contiguous(),
+                          out, B, H, H)
+    xn = x.float().permute(0, 3, 1, 2)
+    t1 = F.relu(F.conv2d(xn, w1.to(BF).float(), b1)).to(BF).float()
+    t2 = F.relu(F.conv2d(t1, w2.to(BF).float(), b2, stride=2, padding=1)).to(BF).float()
+    tr = F.conv2d(xn, wr.to(BF).float(), br, stride=2)
+    ref = F.relu(F.conv2d(t2, w3.to(BF).float(), b3) + tr).permute(0, 2, 3, 1)
+    close(out[:B * Ho * Ho].reshape(B, Ho, Ho, 96), ref, 4e-2, 1e-2)
+    assert bool(torch.isnan(out[B * Ho * Ho:].float()).all())
+
+
 @pytest.mark.parametrize("form", ["8wave", "4wave"])
 @pytest.mark.parametrize("dtype,B,S,Cout", [(torch.float32, 3, 64, 96), (BF, 2, 48, 96), (torch.float32, 2, 224, 96),
                                             (torch.float32, 2, 40, 48), (torch.float32, 300, 32, 96), (BF, 2, 42, 96)])

@@ -50,6 +50,17 @@ def main():
                                   conv=c2.geometry(), ktab=c2.ktab))
     t_f = timeit(lambda: hip.conv1x1_conv3x3s2(x, c1.weight, c1.bias, c2.weight, c2.bias, out, B, Hm, Hm))
     print(f"par1  Cout=48: unfused {t_a:.1f} + {t_b:.1f} = {t_a + t_b:.1f} us   fused {t_f:.1f} us", flush=True)
+    cr = P.ConvSpec(torch.randn(96, 48, 1, 1, generator=g) * 0.14, torch.randn(96, generator=g) * 0.2, Hm, Hm, 2, 0).to("cuda")
+    c3 = P.ConvSpec(torch.randn(96, 48, 1, 1, generator=g) * 0.14, torch.randn(96, generator=g) * 0.2, Ho, Ho, 1, 0).to("cuda")
+    tr = torch.empty(B * Ho * Ho, 96, dtype=BF, device="cuda")
+    o3 = torch.empty(B * Ho * Ho, 96, dtype=BF, device="cuda")
+    outs = torch.zeros(B * Ho * Ho * 48 + 64, dtype=BF, device="cuda")[:B * Ho * Ho * 48].view(-1, 48)
+    t_c = timeit(lambda: hip.gemm(x, cr.weight, tr, M=B * Ho * Ho, N=96, bias=cr.bias, conv=cr.geometry(), ktab=cr.ktab))
+    t_d = timeit(lambda: hip.gemm(outs, c3.weight, o3, M=B * Ho * Ho, N=96, bias=c3.bias, act=hip.ACT_RELU, resid=tr,
+                                  resid_kind=hip.RESID_BF16, ldx=48))
+    b3r = (c3.bias + cr.bias).contiguous()
+    t_g = timeit(lambda: hip.convresblock48_s2(x, c1.weight, c1.bias, c2.weight, c2.bias, c3.weight, cr.weight, b3r, o3, B, Hm, Hm))
+    print(f"block: fused conv1-conv2 {t_f:.1f} + shortcut {t_c:.1f} + conv3 {t_d:.1f} = {t_f + t_c + t_d:.1f} us   one launch {t_g:.1f} us", flush=True)
 
 
 if __name__ == "__main__":
