@@ -4,6 +4,7 @@
 // lib/models/clip_openai_pe_res_v1.py:204-219), token embedding, the fused
 // lateral-adapter combine (ibid. 1752-1778) and the L2 normalisation of the
 // projected features (ibid. 2983, 3076).
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/msclip_hip.h"
 
@@ -194,6 +195,71 @@ __global__ __launch_bounds__(256) void adapter_kernel(const float* __restrict__ 
   store_row<NV>(v, xout, (size_t)m, ldo, 1, lane);
 }
 
+// The same pass with a wave owning one ROW of the token grid (g tokens): the nine depthwise filter rows and the bias
+// stay in registers across the row instead of being re-read for every token (they were half of the kernel's L1
+// traffic: 9 x C weights against 9 x C neighbour values + C of t per token).  The wave of grid row 0 also does the
+// class token.
+template <int NV>
+__global__ __launch_bounds__(256) void adapter_gridrow_kernel(const float* __restrict__ xin, int ldx,
+                                                              const float* __restrict__ t, int ldt,
+                                                              const float* __restrict__ dww, const float* __restrict__ dwb,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              float* __restrict__ xout, int ldo, int B, int L, int g,
+                                                              int usecls, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * WPB + (threadIdx.x >> 6);
+  if (r >= B * g) return;
+  const int b = r / g, gy = r - b * g;
+  constexpr int C = NV * 256;
+  float4 w[9][NV], bias[NV];
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int i = 0; i < NV; ++i) w[k][i] = *(const float4*)(dww + k * C + i * 256 + lane * 4);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) bias[i] = *(const float4*)(dwb + i * 256 + lane * 4);
+  float4 v[NV];
+  if (gy == 0) {
+    const float f = usecls ? 2.f : 1.f;
+    const size_t m = (size_t)b * L;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const float4 a = *(const float4*)(xin + m * ldx + i * 256 + lane * 4);
+      v[i] = make_float4(a.x * f, a.y * f, a.z * f, a.w * f);
+    }
+    ln_core<NV>(v, gamma, beta, eps, lane);
+    store_row<NV>(v, xout, m, ldo, 1, lane);
+  }
+  for (int gx = 0; gx < g; ++gx) {
+    const int p = gy * g + gx;
+    const float* tr = t + ((size_t)b * g * g + p) * ldt;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const float4 a = *(const float4*)(tr + i * 256 + lane * 4);
+      v[i] = make_float4(a.x + bias[i].x, a.y + bias[i].y, a.z + bias[i].z, a.w + bias[i].w);
+    }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int yy = gy + ky - 1;
+      if (yy < 0 || yy >= g) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int xx = gx + kx - 1;
+        if (xx < 0 || xx >= g) continue;
+        const float* nb = xin + ((size_t)b * L + 1 + yy * g + xx) * ldx;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          const float4 a = *(const float4*)(nb + i * 256 + lane * 4);
+          const float4 ww = w[ky * 3 + kx][i];
+          v[i].x += a.x * ww.x; v[i].y += a.y * ww.y; v[i].z += a.z * ww.z; v[i].w += a.w * ww.w;
+        }
+      }
+    }
+    ln_core<NV>(v, gamma, beta, eps, lane);
+    store_row<NV>(v, xout, (size_t)b * L + 1 + p, ldo, 1, lane);
+  }
+}
+
 // y = x / ||x||_2 per row, fp32 math; writes fp32 and (optionally) a bf16 copy for the logits GEMM
 __global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ x, int ldx, float* __restrict__ of,
                                                      int ldf, bf16_t* __restrict__ ob, int ldb, int M, int E) {
@@ -286,6 +352,15 @@ extern "C" int msclip_adapter_combine_ln(const float* xin, int ldx, const float*
                                          int ldo, int B, int L, int g, int C, int usecls, float eps, void* stream) {
   if (!xin || !t || !dww || !dwb || !gamma || !beta || !xout || xin == xout || L != g * g + 1) return MSCLIP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  const char* perrow = getenv("MSCLIP_ADAPTER_PER_TOKEN");       // the wave-per-token kernel, for cross-checks only
+  if (!(perrow && perrow[0] == '1')) {
+    const dim3 grid((B * g + WPB - 1) / WPB), blk(256);
+    NV_DISPATCH(C,
+                hipLaunchKernelGGL(adapter_gridrow_kernel<3>, grid, blk, 0, st, xin, ldx, t, ldt, dww, dwb, gamma, beta, xout, ldo, B, L, g, usecls, eps),
+                hipLaunchKernelGGL(adapter_gridrow_kernel<2>, grid, blk, 0, st, xin, ldx, t, ldt, dww, dwb, gamma, beta, xout, ldo, B, L, g, usecls, eps),
+                hipLaunchKernelGGL(adapter_gridrow_kernel<1>, grid, blk, 0, st, xin, ldx, t, ldt, dww, dwb, gamma, beta, xout, ldo, B, L, g, usecls, eps))
+    return msclip_launch_status();
+  }
   const int rows = B * L;
   const dim3 grid((rows + WPB - 1) / WPB), blk(256);
   NV_DISPATCH(C,

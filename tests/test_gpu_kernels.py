@@ -344,6 +344,28 @@ def test_fill_cls_adapter_l2norm(gpu_device):
     assert float(packed[:, 0].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("kernel", ["gridrow", "per_token"])
+@pytest.mark.parametrize("B,g_,C,usecls", [(5, 7, 768, True), (3, 14, 768, False), (2, 1, 768, True), (9, 3, 256, True)])
+def test_adapter_combine_ln(gpu_device, monkeypatch, B, g_, C, usecls, kernel):
+    """Lateral adapter bottom half + sum + LayerNorm (M.py:1763-1777): the wave-per-grid-row kernel (filters in
+    registers) and the wave-per-token one, grids 1 / 3 / 7 / 14, both class-token modes."""
+    monkeypatch.setenv("MSCLIP_ADAPTER_PER_TOKEN", "1" if kernel == "per_token" else "0")
+    L = g_ * g_ + 1
+    x, t = rnd(B * L, C, seed=61), rnd(B * g_ * g_, C, seed=62)
+    dww, dwb = rnd(9, C, seed=63, scale=0.3), rnd(C, seed=64, scale=0.1)
+    ga, be = 1.0 + rnd(C, seed=65, scale=0.1), rnd(C, seed=66, scale=0.1)
+    out = torch.full((B * L + 1, C), float("nan"), dtype=torch.float32, device="cuda")
+    hip.adapter_combine_ln(x, t, dww, dwb, ga, be, out[:B * L], B, L, g_, usecls)
+    xb = x.reshape(B, L, C)
+    grid = xb[:, 1:].transpose(1, 2).reshape(B, C, g_, g_)
+    bo = F.conv2d(grid, dww.t().reshape(C, 1, 3, 3), dwb, padding=1, groups=C).flatten(2).transpose(1, 2)
+    v = torch.cat([(2 if usecls else 1) * xb[:, :1], bo + t.reshape(B, g_ * g_, C)], 1)
+    u = v.mean(-1, keepdim=True)
+    ref = ga * ((v - u) / torch.sqrt((v - u).pow(2).mean(-1, keepdim=True) + 1e-12)) + be
+    close(out[:B * L].reshape(B, L, C), ref, 2e-4, 1e-5)
+    assert bool(torch.isnan(out[B * L:]).all())
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, BF])
 def test_stem_dual_conv(gpu_device, dtype):
     B, S = 3, 64

@@ -3,5 +3,7 @@
 cd "$(dirname "$0")/../.."
 for pass in 1 2; do
   echo "== default (pass $pass)"; timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>&1 | grep -o '"value": [0-9.]*, \|"ms_per_step": [0-9.]*' | tr '\n' ' '; echo
-  echo "== $1=1 (pass $pass)"; env $1=1 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>&1 | grep -o '"value": [0-9.]*, \|"ms_per_step": [0-9.]*' | tr '\n' ' '; echo
+  for v in "$@"; do
+    echo "== $v=1 (pass $pass)"; env $v=1 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>&1 | grep -o '"value": [0-9.]*, \|"ms_per_step": [0-9.]*' | tr '\n' ' '; echo
+  done
 done
