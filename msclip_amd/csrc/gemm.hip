@@ -328,17 +328,25 @@ __device__ __forceinline__ void epilogue_pack16(f32x4 (&acc)[2 * TN][2 * TM], co
   const unsigned wr = stg + r16 * 128 + (quad & 1) * 8;
   const int wsw = r16 & 7;
   const unsigned rd = stg + srow * 128 + ((sch ^ srow) << 4);    // + i * 1024 for rows i*8 + srow
-  float b[4][4];                                                 // bias of columns ni*16 + 4*quad + r
+  // bias of columns ni*16 + 4*quad + r: lane c of bcol holds column c's bias; 16 lane-crossbar reads (ds_bpermute
+  // touches no LDS memory).  The v_readlane + three-way select this replaces compiled into divergent control flow
+  // (one exec-mask branch nest per value: ~400 scalar-heavy instructions, 3-4 k cycles per tile in the phase trace).
+  float b[4][4];
+  {
+    const int src = __float_as_int(bcol), base = quad * 16;
 #pragma unroll
-  for (int ni = 0; ni < 4; ++ni)
+    for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float q0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bcol), ni * 16 + r));
-      const float q1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bcol), ni * 16 + 4 + r));
-      const float q2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bcol), ni * 16 + 8 + r));
-      const float q3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bcol), ni * 16 + 12 + r));
-      b[ni][r] = quad == 0 ? q0 : quad == 1 ? q1 : quad == 2 ? q2 : q3;
-    }
+      for (int r = 0; r < 4; ++r)
+        b[ni][r] = __int_as_float(__builtin_amdgcn_ds_bpermute(base + (ni * 16 + r) * 4, src));
+    // all sixteen are back before the first hand-counted LDS operation of the staging code is issued
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][2]), "+v"(b[0][3]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[1][2]),
+                   "+v"(b[1][3]), "+v"(b[2][0]), "+v"(b[2][1]), "+v"(b[2][2]), "+v"(b[2][3]), "+v"(b[3][0]), "+v"(b[3][1]),
+                   "+v"(b[3][2]), "+v"(b[3][3])
+                 :
+                 : "memory");
+  }
   EPI_STAMP(10);
   u32x4 x[2][4];
   auto stage = [&](int tm, u32x4 (&dst)[4]) {                    // 32 rows x 64 columns of the wave, packed to bf16
