@@ -1000,17 +1000,27 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
   const int ntiles = nt_n * nt_m;
   const int nk = a.K / 64;
 
+  // Tile id -> origin runs twice per tile in every wave (issue side and compute side).  Its two divisions by launch
+  // constants go through multiply-high with reciprocals made once here (exact while id * divisor < 2^32; the host
+  // keeps ntiles below 2^15): scalar ALU work instead of two ~40-instruction VALU division sequences, which cost
+  // ~2 k of a 54 k-cycle QKV tile in the phase trace.
+  constexpr int CG = 4;
+  const unsigned tper = (unsigned)(nt_m * CG);
+  const unsigned tper_rcp = 0xffffffffu / tper + 1u;
+  const int wg_tail = nt_n - (nt_n - 1) / CG * CG;                 // width of the last column group (1..CG)
+  const unsigned wgt_rcp = 0xffffffffu / (unsigned)wg_tail + 1u;   // unused when wg_tail == 1
   auto tile_origin = [&](int t, int& m0, int& n0) {
     const int q = ntiles >> 3, r = ntiles & 7, x = t & 7;
-    const int id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (t >> 3);
+    const unsigned id = (unsigned)((x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (t >> 3));
     // column groups of 4 tiles, rows fastest inside a group: the ~32 tiles an XCD runs together then cover 8 row blocks
     // x 4 column slices (12 distinct operand slices in its L2) instead of 2.7 x 12 (14.7); +1 % on the step
-    constexpr int CG = 4;
-    const int per = nt_m * CG;
-    const int g = id / per, idg = id - g * per;
-    const int wg = min(CG, nt_n - g * CG);
-    m0 = (idg / wg) * 256;
-    n0 = (g * CG + idg % wg) * 256;
+    const unsigned g = (unsigned)(((unsigned long long)id * tper_rcp) >> 32);
+    const unsigned idg = id - g * tper;
+    const bool tail = (int)(g * CG + CG) > nt_n;
+    const unsigned wg = tail ? (unsigned)wg_tail : (unsigned)CG;
+    const unsigned row = !tail ? idg >> 2 : wg_tail == 1 ? idg : (unsigned)(((unsigned long long)idg * wgt_rcp) >> 32);
+    m0 = (int)(row * 256u);
+    n0 = (int)((g * CG + (idg - row * wg)) * 256u);
   };
 
   // ---- issue side.  Piece p (rows 8p .. 8p+7 of a region) is issued by wave p & 7; lane -> row 8p + lane/8,
@@ -1406,8 +1416,10 @@ extern "C" int msclip_gemm(const msclip_gemm_desc* d, void* stream) {
   if (d->mode == 0) {
     const int tiles = ((d->M + 255) / 256) * ((d->N + 255) / 256);
     // 256-row tile offsets must fit the 32-bit buffer offsets of the ping-pong kernel's loads
+    // ... and tile id x (4 row-tile counts) below 2^32 for the kernel's reciprocal-multiply tile mapping
     const bool pp_ok = (long long)d->ldx * 2 * 256 + (long long)d->K * 2 < (1ll << 31) &&
-                       (long long)d->ldw * 2 * 256 + (long long)d->K * 2 < (1ll << 31);
+                       (long long)d->ldw * 2 * 256 + (long long)d->K * 2 < (1ll << 31) &&
+                       (long long)tiles * ((d->M + 255) / 256) * 4 < (1ll << 32);
     if (pp_ok && (d->tile == 4 || (d->tile == 0 && big))) {        // ping-pong kernel (default for the projections)
       hipLaunchKernelGGL(gemm_pp_kernel<0>, dim3(tiles < ncu ? tiles : ncu), dim3(512), 0, st, *d);
     } else if (big && d->tile != 3) {   // streaming ring kernel (tile 2; tile 3 selects the two-buffer 256x256 kernel: A/B tests)
@@ -1420,7 +1432,7 @@ extern "C" int msclip_gemm(const msclip_gemm_desc* d, void* stream) {
     const long long t256 = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256);
     if ((d->tile == 0 || d->tile == 4) && d->Cin % 64 == 0 && d->K % d->Cin == 0 && in_bytes < (1ll << 31) &&
         (long long)d->ldw * 2 * 256 + (long long)d->K * 2 < (1ll << 31) && d->rpg == 0x7fffffff && d->resid_kind != 3 &&
-        d->M % (d->Ho * d->Wo) == 0 && (t256 >= 128 || d->tile == 4)) {
+        d->M % (d->Ho * d->Wo) == 0 && (t256 >= 128 || d->tile == 4) && t256 * ((d->M + 255) / 256) * 4 < (1ll << 32)) {
       hipLaunchKernelGGL(gemm_pp_kernel<1>, dim3(t256 < ncu ? (int)t256 : ncu), dim3(512), 0, st, *d);
       return msclip_launch_status();
     }

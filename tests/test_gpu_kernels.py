@@ -52,6 +52,22 @@ def test_gemm_every_tile_config(gpu_device, tile, M, N, K):
         close(xres, r32 + base, 4e-3, 1e-4)
 
 
+@pytest.mark.parametrize("nt_m,nt_n", [(1, 1), (3, 2), (5, 3), (2, 4), (7, 5), (4, 6), (3, 7), (9, 9), (40, 3), (300, 1)])
+def test_gemm_pingpong_tile_map_covers_every_tile(gpu_device, nt_m, nt_n):
+    """The ping-pong kernel's tile-id -> origin map (XCD remap, column groups of four, reciprocal-multiply divisions):
+    every 256 x 256 tile is computed exactly once for full, ragged and single-column group layouts, with fewer and
+    with more tiles than workgroups."""
+    M, N, K = nt_m * 256 - 19, nt_n * 256 - 40, 64
+    x, w = rnd(M, K, seed=21, dtype=BF), rnd(N, K, seed=22, scale=0.1, dtype=BF)
+    out = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+    acc = torch.zeros(M, N, dtype=torch.float32, device="cuda")
+    hip.gemm(x, w, out, tile=4)
+    ref = x.float() @ w.float().t()
+    close(out, ref, 2e-3, 1e-3)
+    hip.gemm(x, w, acc, resid=acc, resid_kind=hip.RESID_F32, tile=4)                 # a tile done twice would add twice
+    close(acc, ref, 2e-3, 1e-3)
+
+
 @pytest.mark.parametrize("M,N,K,ldx", [(5000, 96, 64, 48), (4099, 48, 64, 48), (8000, 192, 128, 96), (4700, 192, 64, 64),
                                          (4100, 768, 192, 192), (6000, 384, 192, 192), (4096, 40, 64, 64)])
 def test_gemm_streaming_small_k(gpu_device, M, N, K, ldx):
