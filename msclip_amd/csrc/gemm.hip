@@ -1157,6 +1157,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
 
   int cslot = 0;                                   // ring slot of region 0 of the K-tile being computed
   bf16x8 w0[2][2], w1[2][2], xf[4][2];             // [16-row tile][k-step]: W rows 0-31 / 32-63 of the wave, X rows of a sub-block
+  int epi_stores = 0;                              // stores this wave is known to have issued in the previous tile's epilogue
   for (int tc = blockIdx.x; tc < ntiles; tc += gridDim.x) {
     int cm0, cn0;
     tile_origin(tc, cm0, cn0);
@@ -1284,7 +1285,17 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
       issue(I2{});
       issue(I3{});
 #ifndef PP_NOWAIT
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      // First K-tile after an epilogue: the regions this wait is for (K-tile 1's) were issued BEFORE the epilogue's
+      // stores, but the VM counter retires in order, so "at most 8 in flight" would also wait for the write
+      // acknowledgements of the whole output tile (+2 k cycles on the first K-tile of every c_fc tile in the phase
+      // trace).  The stores are younger than those regions and older than this K-tile's 8 pieces: leaving 8 + (a lower
+      // bound of their number) in flight asks for exactly the regions.  K-tile 1's wait is the strict one again.
+#ifndef PP_NORELAX
+      if (kt == 0 && nk >= 3 && epi_stores == 16) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+      else if (kt == 0 && nk >= 3 && epi_stores == 32) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+      else
+#endif
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 #endif
       PP_SYNC_IN();
 #pragma unroll
@@ -1320,8 +1331,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
       // lane id recomputed from scratch: the epilogue's lane constants must not live (spilled) across the main loop
       int lane_e;
       asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+      epi_stores = 0;
       if (vec && plain_rows && cm0 + 256 <= a.M)
       {
+        const bool full_n = cn0 + 256 <= a.N;      // no lane's store is predicated off
 #ifdef PP_TRACE
         PpTrace* trp = &tr;
 #else
@@ -1334,6 +1347,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
 #else
 #ifndef PP_ROWS16
         const bool pack16 = a.resid_kind == 0 && a.out_kind == 0 && !((a.N | a.ldo) & 7);
+        if (full_n) epi_stores = pack16 && a.act <= 2 ? 4 * TM : 4 * TM * TN;   // 16 / 32 store instructions per wave
         if (pack16 && a.act == 0)
           epilogue_pack16<TM, TN, 0>(acc, a, stg, mw0, nw0, lane_e, bcol, trp);               // QKV
         else if (pack16 && a.act == 1)
