@@ -97,7 +97,7 @@ def test_gemm_streaming_small_k(gpu_device, M, N, K, ldx):
 def test_gemm_pingpong_race_screen(gpu_device):
     """The ping-pong kernel orders LDS-DMA writes, fragment reads and ring-slot reuse by counted waits and barriers only;
     a misplaced one shows up as rare wrong tiles.  Many launches, every output element, bitwise-equal results."""
-    M, N, K = 8192 + 77, 1024, 1536                                            # 33 x 4 tiles, several tiles per workgroup
+    M, N, K = 8192 + 77, 1024, 1536                                            # 33 x 4 tiles, ragged last row block
     x, w, b = rnd(M, K, seed=51, dtype=BF), rnd(N, K, seed=52, scale=0.04, dtype=BF), rnd(N, seed=53)
     ref = x.float() @ w.float().t() + b
     first = None
@@ -120,6 +120,40 @@ def test_gemm_pingpong_race_screen(gpu_device):
             first = acc.clone()
         else:
             assert torch.equal(acc, first), f"launch {it} differs from launch 0"
+
+
+@pytest.mark.parametrize("act", [hip.ACT_NONE, hip.ACT_QUICKGELU])
+def test_gemm_pingpong_race_screen_multi_tile(gpu_device, act):
+    """Same screen with several tiles per workgroup (768 tiles on <= 256 workgroups, 12 K-tiles each): the DMA stream
+    crossing tile boundaries under the epilogue, and the first wait of a tile that leaves the previous tile's stores
+    in flight, both epilogue families."""
+    M, N, K = 256 * 64 - 5, 256 * 12, 768
+    x, w, b = rnd(M, K, seed=55, dtype=BF), rnd(N, K, seed=56, scale=0.04, dtype=BF), rnd(N, seed=57)
+    ref = x.float() @ w.float().t() + b
+    if act == hip.ACT_QUICKGELU:
+        ref = ref * torch.sigmoid(1.702 * ref)
+    out = torch.empty(M, N, dtype=BF, device="cuda")
+    first = None
+    for it in range(12):
+        out.fill_(float("nan"))
+        hip.gemm(x, w, out, bias=b, act=act, tile=4)
+        if first is None:
+            close(out, ref, 2e-2, 1e-2)
+            first = out.clone()
+        else:
+            assert torch.equal(out, first), f"launch {it} differs from launch 0"
+    del out, first
+    if act == hip.ACT_NONE:
+        r32 = rnd(M, N, seed=58)
+        acc = r32.clone()
+        for it in range(6):
+            acc.copy_(r32)
+            hip.gemm(x, w, acc, bias=b, resid=acc, resid_kind=hip.RESID_F32, tile=4)
+            if it == 0:
+                close(acc, r32 + ref, 4e-3, 1e-4)
+                first = acc.clone()
+            else:
+                assert torch.equal(acc, first), f"launch {it} differs from launch 0"
 
 
 def test_gemm_epilogues(gpu_device):
