@@ -951,21 +951,25 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const msclip_gemm_des
 // Ping-pong kernel for the dense projections: 256 x 256 tile, 8 waves (2 x 4), K-tiles of 64.  LDS is a ring of
 // ten 16-KiB regions; a region holds one half-operand of one K-tile (128 rows x 128 B, full cache lines):
 // W rows 0-127, W rows 128-255, X rows 0-127, X rows 128-255, in that order (2 LDS-DMA pieces per wave and region,
-// buffer-addressed: SGPR descriptor + 32-bit lane offset + scalar K offset).  A K-tile is computed in 4 phases (one
-// 64 x 32 quadrant of the wave's 128 x 64 block over the whole K-tile each):
-//     phase q:  [ ds_reads of the quadrant's new fragments (12 / 4 / 8 / 0) ; q == 1, 3: 4 DMA pieces ;
-//                 q == 3: s_waitcnt vmcnt(8) ]   s_barrier ; lgkmcnt(0) ; 8 MFMAs at raised priority ; s_barrier
+// buffer-addressed: SGPR descriptor + 32-bit lane offset + scalar K offset).  A K-tile is computed in 2 phases (one
+// 64-row half of the wave's 128 x 64 block over the whole K-tile each):
+//     phase A:  [ ds_reads: both W fragment sets + X rows 0-63 (16) ; 4 DMA pieces ]
+//     phase B:  [ ds_reads: X rows 64-127 (8) ; 4 DMA pieces ; s_waitcnt vmcnt(8) ]
+//     each followed by   s_barrier ; lgkmcnt(0) ; 32 MFMAs at raised priority ; s_barrier
 // Waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave is in its memory section while the other
-// owns the MFMA pipe, and a barrier resolves under the tail of the other wave's last MFMA.
-// Phases are numbered so that K-tile t (regions 4t .. 4t+3) is computed in phases 4t+7 .. 4t+10.  Its phase 4t+8
-// issues regions 4t+8, 4t+9 and phase 4t+10 issues regions 4t+10, 4t+11 (the DMA pieces sit in the two phases with
-// the fewest fragment reads; 1 % over one region per phase), then waits until at most 8 pieces are in flight: the
-// regions of K-tile t+1 (issued in phases 4t+4 and 4t+6) have landed, and they are first read in phase 4t+11, after
-// a barrier that follows every wave's wait.  Region r+10 overwrites the ring slot of region r: the X regions of
-// K-tile t-1 (last read in phase 4t+5) in phase 4t+8, the W regions of K-tile t (last read in phase 4t+8) in phase
-// 4t+10 -- at least two barriers after the last ds_read retired.  The DMA stream runs across tile boundaries (eight
-// regions of the next tile fly under the epilogue).  Rows past M / N are out of range of the tile's buffer
-// descriptor (read as zero).
+// owns the MFMA pipe, and a barrier resolves under the tail of the other wave's last MFMA.  (The first version split
+// the K-tile into four quadrant phases: twice the barrier hand-overs for the same work; two phases are +1.7 % on the
+// step.  -DPP_4PHASE rebuilds it.)
+// The wait of phase B leaves the 8 pieces of this K-tile's issues in flight: the regions of the NEXT K-tile (issued
+// one K-tile earlier) have landed, and they are first read after the barrier that follows every wave's wait.  Region
+// r+10 overwrites the ring slot of region r: phase A of K-tile t re-issues the slots of K-tile t-1's X regions (last
+// read in its phase B), phase B those of K-tile t's W regions (last read in phase A).  The last reader's ds_reads
+// were issued before the barrier the issuing wave has just passed (the other group waits for them right behind that
+// barrier), and the wave issues its own fragment reads before its DMA pieces, whose data is a memory round trip
+// away.  At a tile's first K-tile the phase-A pieces move to phase B: their slots are the epilogue's staging until
+// the first barrier of the tile, which every wave reaches only after its epilogue.  The DMA stream runs across tile
+// boundaries (eight regions of the next tile fly under the epilogue).  Rows past M / N are out of range of the
+// tile's buffer descriptor (read as zero).
 // ------------------------------------------------------------------------------------------------------------
 constexpr int PSLOTS = 10, PREG = 128 * 64;   // ring regions, bf16 elements per region
 
@@ -1239,6 +1243,16 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) xf[j][ks] = pp_ld(xreg + j * 2048 + la[ks]);
+#ifndef PP_4PHASE
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) w1[i][ks] = pp_ld(wreg + 4096 + i * 2048 + la[ks]);
+      if (kt) {                                    // K-tile 0: the slots are still the epilogue's staging until the first barrier
+        issue(I0{});
+        issue(I1{});
+      }
+#endif
       PP_SYNC_IN();
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
@@ -1247,6 +1261,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
 #pragma unroll
           for (int i = 0; i < 2; ++i)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[i][ks], xf[j][ks], acc[i][j], 0, 0, 0);
+#ifdef PP_4PHASE
       PP_SYNC_OUT();
 
       // ---- phase 1: W sub 1 -> quadrant (0, 1)
@@ -1257,6 +1272,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
       issue(I0{});
       issue(I1{});
       PP_SYNC_IN();
+#endif
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -1271,6 +1287,17 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) xf[j][ks] = pp_ld(xreg + 8192 + j * 2048 + la[ks]);
+#ifndef PP_4PHASE
+      if (!kt) {
+        issue(I0{});
+        issue(I1{});
+      }
+      issue(I2{});
+      issue(I3{});
+      if (kt == 0 && nk >= 3 && epi_stores == 16) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+      else if (kt == 0 && nk >= 3 && epi_stores == 32) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#endif
       PP_SYNC_IN();
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
@@ -1279,9 +1306,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
 #pragma unroll
           for (int i = 0; i < 2; ++i)
             acc[2 + i][4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[i][ks], xf[j][ks], acc[2 + i][4 + j], 0, 0, 0);
+#ifdef PP_4PHASE
       PP_SYNC_OUT();
+#endif
 
       // ---- phase 3: nothing new to read -> quadrant (1, 0); the next K-tile's regions are waited for here
+#ifdef PP_4PHASE
       issue(I2{});
       issue(I3{});
 #ifndef PP_NOWAIT
@@ -1298,6 +1328,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 #endif
       PP_SYNC_IN();
+#endif
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
