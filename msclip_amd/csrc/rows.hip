@@ -85,6 +85,74 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, in
   store_row<NV>(v, out, (size_t)m, ldo, out_kind, lane);
 }
 
+// Two rows per wave for the big contiguous launches (the per-layer LayerNorms over all token rows): both rows' loads
+// are in flight together and gamma / beta are fetched once for the pair (per row they were two thirds of the wave's
+// L1 traffic).  Rows m0 = 2*pair, m0 + 1; a pair that straddles `split` falls back to per-row parameters.
+template <int NV>
+__global__ __launch_bounds__(256) void ln_pair_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, void* out, int ldo, int out_kind,
+                                                      int M, float eps, const float* __restrict__ gamma2,
+                                                      const float* __restrict__ beta2, int split) {
+  const int lane = threadIdx.x & 63;
+  const int m0 = (blockIdx.x * WPB + (threadIdx.x >> 6)) * 2;
+  if (m0 >= M) return;
+  const bool two = m0 + 1 < M;
+  const int m1 = two ? m0 + 1 : m0;
+  constexpr float invC = 1.f / (NV * 256);
+  float4 a[NV], b[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    a[i] = *(const float4*)(x + (size_t)m0 * ldx + i * 256 + lane * 4);
+    b[i] = *(const float4*)(x + (size_t)m1 * ldx + i * 256 + lane * 4);
+  }
+  const float* g0 = m0 >= split ? gamma2 : gamma;
+  const float* b0 = m0 >= split ? beta2 : beta;
+  const float* g1 = m1 >= split ? gamma2 : gamma;
+  const float* b1 = m1 >= split ? beta2 : beta;
+  float4 gv[NV], bv[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    gv[i] = *(const float4*)(g0 + i * 256 + lane * 4);
+    bv[i] = *(const float4*)(b0 + i * 256 + lane * 4);
+  }
+  float sa = 0.f, sb = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    sa += (a[i].x + a[i].y) + (a[i].z + a[i].w);
+    sb += (b[i].x + b[i].y) + (b[i].z + b[i].w);
+  }
+  const float ma = wave_sum(sa) * invC, mb = wave_sum(sb) * invC;
+  float qa = 0.f, qb = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    a[i].x -= ma; a[i].y -= ma; a[i].z -= ma; a[i].w -= ma;
+    b[i].x -= mb; b[i].y -= mb; b[i].z -= mb; b[i].w -= mb;
+    qa += (a[i].x * a[i].x + a[i].y * a[i].y) + (a[i].z * a[i].z + a[i].w * a[i].w);
+    qb += (b[i].x * b[i].x + b[i].y * b[i].y) + (b[i].z * b[i].z + b[i].w * b[i].w);
+  }
+  const float ra = 1.f / sqrtf(wave_sum(qa) * invC + eps), rb = 1.f / sqrtf(wave_sum(qb) * invC + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    a[i].x = gv[i].x * (a[i].x * ra) + bv[i].x; a[i].y = gv[i].y * (a[i].y * ra) + bv[i].y;
+    a[i].z = gv[i].z * (a[i].z * ra) + bv[i].z; a[i].w = gv[i].w * (a[i].w * ra) + bv[i].w;
+  }
+  store_row<NV>(a, out, (size_t)m0, ldo, out_kind, lane);
+  if (!two) return;
+  if (g1 != g0) {                                     // the pair straddles the modality boundary (wave-uniform)
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      gv[i] = *(const float4*)(g1 + i * 256 + lane * 4);
+      bv[i] = *(const float4*)(b1 + i * 256 + lane * 4);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    b[i].x = gv[i].x * (b[i].x * rb) + bv[i].x; b[i].y = gv[i].y * (b[i].y * rb) + bv[i].y;
+    b[i].z = gv[i].z * (b[i].z * rb) + bv[i].z; b[i].w = gv[i].w * (b[i].w * rb) + bv[i].w;
+  }
+  store_row<NV>(b, out, (size_t)m1, ldo, out_kind, lane);
+}
+
 // x[row_base + b*L + l] = emb[tok[b, l]] + pos[l]      (reference :3047-3048)
 template <int NV>
 __global__ __launch_bounds__(256) void embed_kernel(const long long* __restrict__ tok, const float* __restrict__ emb,
@@ -297,6 +365,15 @@ __global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ x
 static int launch_ln(const float* x, int ldx, const int* row_idx, int row_mul, int row_add, const float* gamma,
                      const float* beta, void* out, int ldo, int out_kind, float* raw_out, int ld_raw, int M, int C,
                      float eps, const float* gamma2, const float* beta2, int split, hipStream_t st) {
+  const char* single = getenv("MSCLIP_LN_SINGLE_ROW");            // the wave-per-row kernel, for cross-checks only
+  if (!row_idx && row_mul == 1 && row_add == 0 && !raw_out && M >= 4096 && !(single && single[0] == '1')) {
+    const dim3 grid2(((M + 1) / 2 + WPB - 1) / WPB), blk2(256);
+    NV_DISPATCH(C,
+                hipLaunchKernelGGL(ln_pair_kernel<3>, grid2, blk2, 0, st, x, ldx, gamma, beta, out, ldo, out_kind, M, eps, gamma2, beta2, split),
+                hipLaunchKernelGGL(ln_pair_kernel<2>, grid2, blk2, 0, st, x, ldx, gamma, beta, out, ldo, out_kind, M, eps, gamma2, beta2, split),
+                hipLaunchKernelGGL(ln_pair_kernel<1>, grid2, blk2, 0, st, x, ldx, gamma, beta, out, ldo, out_kind, M, eps, gamma2, beta2, split))
+    return msclip_launch_status();
+  }
   const dim3 grid((M + WPB - 1) / WPB), blk(256);
   NV_DISPATCH(C,
               hipLaunchKernelGGL(ln_kernel<3>, grid, blk, 0, st, x, ldx, row_idx, row_mul, row_add, gamma, beta, out, ldo, out_kind, raw_out, ld_raw, M, eps, gamma2, beta2, split),

@@ -325,6 +325,36 @@ def test_layernorm_variants(gpu_device):
     close(o, g[:512] * ((x512 - u) / torch.sqrt((x512 - u).pow(2).mean(-1, keepdim=True) + 1e-12)) + b[:512], 1e-4, 1e-5)
 
 
+@pytest.mark.parametrize("M,split,C", [(4097, 2049, 768), (5000, 5000, 768), (4100, 0, 512), (8192, 4096, 256)])
+def test_layernorm_pair_kernel(gpu_device, monkeypatch, M, split, C):
+    """The two-rows-per-wave LayerNorm of the big launches: odd row counts, an odd / even / absent modality boundary,
+    fp32 and bf16 outputs, in place; agrees with the wave-per-row kernel to fp32 rounding (the compiler contracts the
+    affine step differently)."""
+    x = rnd(M, C, seed=71, scale=3.0) + 0.5
+    g1, b1, g2, b2 = rnd(C, seed=72) * 0.2 + 1, rnd(C, seed=73) * 0.1, rnd(C, seed=74) * 0.2 + 1, rnd(C, seed=75) * 0.1
+
+    def ln(v, g, b):
+        u = v.mean(-1, keepdim=True)
+        s = ((v - u) ** 2).mean(-1, keepdim=True)
+        return g * ((v - u) / torch.sqrt(s + 1e-12)) + b
+    ref = torch.cat([ln(x[:split], g1, b1), ln(x[split:], g2, b2)])
+    out = torch.full((M + 1, C), float("nan"), dtype=BF, device="cuda")
+    hip.layernorm_split(x, g1, b1, g2, b2, split, out[:M], M)
+    close(out[:M], ref, 2e-2, 1e-2)
+    assert bool(torch.isnan(out[M:].float()).all())
+    o32 = torch.empty(M, C, dtype=torch.float32, device="cuda")
+    hip.layernorm_split(x, g1, b1, g2, b2, split, o32, M)
+    close(o32, ref, 1e-4, 1e-5)
+    monkeypatch.setenv("MSCLIP_LN_SINGLE_ROW", "1")
+    one = torch.empty(M, C, dtype=torch.float32, device="cuda")
+    hip.layernorm_split(x, g1, b1, g2, b2, split, one, M)
+    close(o32, one, 2e-6, 2e-6)
+    monkeypatch.setenv("MSCLIP_LN_SINGLE_ROW", "0")
+    xin = x.clone()
+    hip.layernorm(xin, g1, b1, xin, M)                                           # in place, single parameter set
+    close(xin, ln(x, g1, b1), 1e-4, 1e-5)
+
+
 def test_layernorm_split_parameters(gpu_device):
     M, C, split = 700, 768, 257
     x = rnd(M, C, seed=61, scale=3.0) + 0.5
