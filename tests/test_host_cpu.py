@@ -84,6 +84,38 @@ def test_library_exports_every_declared_symbol():
     assert ctypes.sizeof(hip.GemmDesc) % 8 == 0 and hip.GemmDesc.ktab.offset % 8 == 0
 
 
+def test_entry_points_reject_bad_arguments_before_launching():
+    """Argument validation of the C ABI runs on the host, before any launch: null pointers, unsupported channel
+    counts, sizes whose byte offsets would not fit the kernels' 32-bit buffer addressing (include/msclip_hip.h)."""
+    if not os.path.exists(hip.LIB_PATH):
+        hip.build()
+    lib = ctypes.CDLL(hip.LIB_PATH)
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    EINVAL = -1
+    buf = ctypes.create_string_buffer(64)
+    p = ctypes.cast(buf, vp)
+    lib.msclip_conv1x1_conv3x3s2.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
+    assert lib.msclip_conv1x1_conv3x3s2(None, p, p, p, p, p, 1, 8, 8, 48, None) == EINVAL          # null input
+    assert lib.msclip_conv1x1_conv3x3s2(p, p, p, p, p, p, 1, 8, 8, 64, None) == EINVAL             # Cout not 48 / 96
+    assert lib.msclip_conv1x1_conv3x3s2(p, p, p, p, p, p, 4096, 112, 112, 48, None) == EINVAL      # input >= 2 GiB
+    lib.msclip_convresblock48_s2.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]
+    assert lib.msclip_convresblock48_s2(p, p, p, p, p, p, None, p, p, 1, 8, 8, None) == EINVAL     # null shortcut weights
+    assert lib.msclip_convresblock48_s2(p, p, p, p, p, p, p, p, p, 0, 8, 8, None) == EINVAL        # empty batch
+    lib.msclip_stem_dual_conv3x3s2.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
+    assert lib.msclip_stem_dual_conv3x3s2(p, 0, p, p, p, p, p, p, 1, 224, 224, 32, None) == EINVAL
+    assert lib.msclip_stem_dual_conv3x3s2(p, 0, p, p, p, p, p, p, 4000, 224, 224, 96, None) == EINVAL   # image >= 2 GiB
+    lib.msclip_layernorm_split.argtypes = [vp, ci, vp, vp, vp, vp, ci, vp, ci, ci, ci, ci, ctypes.c_float, vp]
+    assert lib.msclip_layernorm_split(p, 768, p, p, p, p, 9, p, 768, 0, 8, 768, 1e-12, None) == EINVAL   # split > M
+    assert lib.msclip_layernorm_split(p, 770, p, p, p, p, 4, p, 768, 0, 8, 768, 1e-12, None) == EINVAL   # ldx % 4
+    lib.msclip_adapter_combine_ln.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ctypes.c_float, vp]
+    assert lib.msclip_adapter_combine_ln(p, 768, p, 768, p, p, p, p, p, 768, 1, 51, 7, 768, 1, 1e-12, None) == EINVAL   # L != g*g+1
+    assert lib.msclip_adapter_combine_ln(p, 768, p, 768, p, p, p, p, p, 768, 1, 50, 7, 768, 1, 1e-12, None) == EINVAL   # in place
+    lib.msclip_dwpool.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
+    assert lib.msclip_dwpool(p, p, p, 48, 1, 112, 112, 48, 5, None) == EINVAL                      # H % k
+    lib.msclip_gemm.argtypes = [vp, vp]
+    assert lib.msclip_gemm(None, None) == EINVAL
+
+
 # ---------------------------------------------------------------- packing folds vs oracle (CPU, fp32 weights)
 
 def _run_spec(x_nchw, spec, relu=False, resid=None):
