@@ -571,7 +571,8 @@ def test_lse_and_loss(gpu_device):
     close(l3, torch.logsumexp(odd, 1), 1e-4)
 
 
-@pytest.mark.parametrize("R,N,off,nsplit", [(24, 72, 48, 3), (512, 512, 0, 16), (100, 333, 200, 5), (32, 8192, 4096, 64)])
+@pytest.mark.parametrize("R,N,off,nsplit", [(24, 72, 48, 3), (512, 512, 0, 16), (100, 333, 200, 5), (32, 8192, 4096, 64),
+                                            (512, 4096, 1536, 64), (1024, 8192, 7168, 64)])  # rank 3 of 8 at batch 512; rank 7 of 8 at 1024
 def test_fused_lse_and_loss(gpu_device, R, N, off, nsplit):
     """MFMA GEMM + online log-sum-exp (no logits written) vs logsumexp of the explicit fp32 logits."""
     E, scale = 512, 14.285
