@@ -92,6 +92,26 @@ def test_batch_invariance_and_determinism(gpu_device):
     assert (a[2:3] - c).abs().max().item() <= 1e-5                    # per-sample result independent of the batch
 
 
+@pytest.mark.parametrize("name", ["b32-yfcc-msclips", "b16-yfcc-msclips"])
+def test_fused_front_paths_against_the_conv_by_conv_chain(gpu_device, monkeypatch, name):
+    """The fused stem pass / fused first bottleneck and the kernel-by-kernel chain they replace give the same image
+    features (same bf16 roundings of every tensor that exists in both; the fused block keeps the shortcut in fp32)."""
+    m = model_for(name)
+    img = synth.synth_images(5, seed=37).cuda()
+    fused = m.encode_image(img)
+    monkeypatch.setenv("MSCLIP_BLOCK_UNFUSED", "1")
+    no_block = m.encode_image(img)
+    monkeypatch.setenv("MSCLIP_FRONT_UNFUSED", "1")
+    chain = m.encode_image(img)
+    monkeypatch.setenv("MSCLIP_FRONT_4WAVE", "1")
+    monkeypatch.setenv("MSCLIP_FRONT_UNFUSED", "0")
+    monkeypatch.setenv("MSCLIP_BLOCK_UNFUSED", "1")
+    four_wave = m.encode_image(img)
+    for other in (no_block, chain, four_wave):
+        assert (fused - other).abs().max().item() <= 2e-3
+        assert torch.nn.functional.cosine_similarity(fused, other, dim=-1).min().item() >= 0.99995
+
+
 def test_full_bench_batch_properties(gpu_device):
     """BASELINE config C2 (B = 512): finite, unit-norm, logits = scaled cosine, loss identity, rows match a small run."""
     m = model_for("b32-yfcc-msclips")
