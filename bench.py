@@ -125,7 +125,8 @@ def main():
             "whole_step_mfma_frac": round(pairs_s / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4),
             "loss": round(loss_val, 5),
         }
-        if probe is not None:
+        n = probe.summary()[0] if probe is not None else 0
+        if n > 0:                       # tiny batches never reach the ping-pong kernel: no roofline line then
             n, kms, flops = probe.summary()
             traffic = None      # HBM bytes per launch of the same kernel from a separate rocprofv3 --pmc run of this command
             tpath = os.path.join(ROOT, "profiles", "r01_bench_hbm_traffic.json")
