@@ -23,6 +23,50 @@ sys.path.insert(0, ROOT)
 
 GFLOP_PER_PAIR = {"b32-yfcc-msclips": 23.549, "b16-yfcc-msclips": 49.617}   # SURVEY.md s8(d), counted on the reference
 PEAK_BF16_TFLOPS = 2500.0                                                      # MI355X_MICROARCH.md: dense bf16 MFMA
+DOMINANT = {"variant": "pp", "kernel": "gemm_pp_kernel<0>",                    # what hip.gemm_variant calls it / rocprof's name
+            "what": "dense bf16 MFMA GEMM: all transformer projections + wide pointwise convs"}
+N_SIMD, N_XCD = 1024, 8                                                        # 256 CUs x 4 SIMDs; GRBM counters sum over XCDs
+
+
+def pmc_passes(args, kernel):
+    """HBM traffic and MFMA-pipe occupancy of the dominant kernel inside THIS workload, from rocprofv3 counters:
+    separate --pmc passes of a short child run of the same command (FETCH_SIZE and WRITE_SIZE cannot share a pass;
+    MI355X_MICROARCH.md "rocprofv3 PMC slots"), --kernel-trace only.  Corrections per that guide's HBM section:
+    FETCH_SIZE (KiB) x 2 (gfx950 tallies the 128-byte requests of wide coalesced reads at 64 B), WRITE_SIZE as
+    reported.  mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs.  Profiled passes run at
+    a lower clock: only the counters are taken from them, never a time."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    short = lambda n: n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+    out = {}
+    sets = {"fetch": ["FETCH_SIZE"], "write": ["WRITE_SIZE"], "mfma": ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]}
+    for tag, counters in sets.items():
+        d = tempfile.mkdtemp(prefix=f"msclip_pmc_{tag}_", dir="/tmp")
+        cmd = ["rocprofv3", "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", d, "-o", "run", "--",
+               sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--batch", str(args.batch),
+               "--model", args.model, "--no-cpu-baseline", "--no-probe", "--no-pmc"]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=900, capture_output=True, check=True)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            vals, tot = {}, {}
+            for r in csv.DictReader(open(files[0])):
+                tot[r["Counter_Name"]] = tot.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+                if short(r["Kernel_Name"]) == kernel:
+                    vals.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            for c in counters:
+                out[c] = sum(vals[c]) / len(vals[c])
+                out["ALL_" + c] = tot[c]                      # summed over every kernel of the child run
+            out["launches_" + tag] = len(vals[counters[0]])
+        except Exception as e:                      # a box without counter access still gets its bench line
+            out["error_" + tag] = f"{type(e).__name__}: {str(e)[:200]}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return out
 
 
 def load_schema(name):
@@ -58,6 +102,8 @@ def main():
     ap.add_argument("--model", default="b32-yfcc-msclips")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true", help="do not bracket GEMM launches with HIP events")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic = null)")
+    ap.add_argument("--shapes", action="store_true", help="add the per-shape table of the dominant kernel to the record")
     args = ap.parse_args()
 
     from msclip_amd import comm as C, hip, synth
@@ -71,6 +117,9 @@ def main():
     torch.cuda.set_device(local)
     C.init_distributed("nccl")
     rank = C.comm.rank
+    if world > 1:                                     # the collectives really are RCCL over all N ranks
+        assert dist.is_initialized() and dist.get_backend() == "nccl" and dist.get_world_size() == args.gpus, \
+            (dist.get_backend(), dist.get_world_size(), args.gpus)
     dev = torch.device("cuda", local)
 
     sd = synth.synth_state_dict(load_schema(args.model), seed=0)
@@ -94,14 +143,14 @@ def main():
     for _ in range(args.warmup):
         loss = step()
     probe = None if args.no_probe else hip.KernelProbe()
-    hip.set_gemm_probe("pp", probe)
+    hip.set_gemm_probe(DOMINANT["variant"], probe)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     fence()
     dt = time.perf_counter() - t0
-    hip.set_gemm_probe("pp", None)
+    hip.set_gemm_probe(DOMINANT["variant"], None)
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -114,6 +163,7 @@ def main():
         gf = GFLOP_PER_PAIR[args.model]
         rec = {
             "metric": "image-text pairs/sec ViT-B/32 bf16" if args.model.startswith("b32") else "image-text pairs/sec ViT-B/16 bf16",
+            "mfma_util_pct": None,
             "value": round(pairs_s, 1), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
@@ -125,21 +175,45 @@ def main():
             "whole_step_mfma_frac": round(pairs_s / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4),
             "loss": round(loss_val, 5),
         }
+        rec["config"]["rccl_ranks"] = dist.get_world_size() if world > 1 else 1
         n = probe.summary()[0] if probe is not None else 0
         if n > 0:                       # tiny batches never reach the ping-pong kernel: no roofline line then
             n, kms, flops = probe.summary()
-            traffic = None      # HBM bytes per launch of the same kernel from a separate rocprofv3 --pmc run of this command
-            tpath = os.path.join(ROOT, "profiles", "r01_bench_hbm_traffic.json")
-            if B == 512 and args.model.startswith("b32") and os.path.exists(tpath):
-                with open(tpath) as f:
-                    traffic = round(json.load(f)["hbm_bytes_per_launch"])
+            alg_bytes = sum(probe.bytes) / n
             ach = flops / (kms * 1e-3) / 1e12
-            rec["roofline"] = {"kernel": "gemm_pp_kernel<0> (dense bf16 MFMA GEMM: all transformer projections + wide pointwise convs)",
+            rec["roofline"] = {"kernel": f"{DOMINANT['kernel']} ({DOMINANT['what']})",
                                "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_bench_hbm_traffic.json)",
+                               "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
                                "launches_per_step": n // args.steps, "avg_launch_us": round(kms / n * 1e3, 2),
                                "flops_per_launch_avg": round(flops / n / 1e9, 3), "flops_unit": "GFLOP",
+                               "algorithmic_bytes_per_launch": round(alg_bytes),
                                "time_share_of_step": round(kms / (dt * 1e3), 4)}
+            if args.shapes:
+                rec["roofline"]["shapes"] = [
+                    {"M": t[0], "N": t[1], "K": t[2], "conv": t[4], "act": t[5], "resid": t[6], "out_fp32": t[7],
+                     "launches_per_step": c // args.steps, "avg_us": round(ms / c * 1e3, 1),
+                     "tflops": round(u / (ms * 1e-3) / 1e12, 1), "algorithmic_MB": round(b / c / 1e6, 1)}
+                    for t, (c, ms, u, b) in sorted(probe.by_shape().items(), key=lambda kv: -kv[1][1])]
+            if world == 1 and not args.no_pmc:
+                pmc = pmc_passes(args, DOMINANT["kernel"])
+                if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+                    traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
+                    rec["roofline"]["traffic"] = round(traffic)
+                    rec["roofline"]["traffic_unit"] = ("HBM bytes/launch, live rocprofv3 --pmc passes of this command: "
+                                                       "FETCH_SIZE KiB x2 (gfx950 correction) + WRITE_SIZE KiB")
+                    rec["roofline"]["traffic_over_algorithmic"] = round(traffic / alg_bytes, 3)
+                if pmc and "SQ_VALU_MFMA_BUSY_CYCLES" in pmc and pmc.get("GRBM_GUI_ACTIVE"):
+                    rec["roofline"]["mfma_busy_pct"] = round(100.0 * (pmc["SQ_VALU_MFMA_BUSY_CYCLES"] / N_SIMD) /
+                                                             (pmc["GRBM_GUI_ACTIVE"] / N_XCD), 1)
+                if pmc and pmc.get("ALL_GRBM_GUI_ACTIVE"):
+                    rec["roofline"]["mfma_busy_pct_whole_step"] = round(
+                        100.0 * (pmc["ALL_SQ_VALU_MFMA_BUSY_CYCLES"] / N_SIMD) / (pmc["ALL_GRBM_GUI_ACTIVE"] / N_XCD), 1)
+                if pmc:
+                    errs = {k: v for k, v in pmc.items() if k.startswith("error_")}
+                    if errs:
+                        rec["roofline"]["pmc_errors"] = errs
+        if "roofline" in rec and "mfma_busy_pct_whole_step" in rec["roofline"]:
+            rec["mfma_util_pct"] = rec["roofline"]["mfma_busy_pct_whole_step"]   # BASELINE metric's second half (all kernels of a step)
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(args.model, sd)
         print(json.dumps(rec), flush=True)

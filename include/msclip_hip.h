@@ -56,6 +56,11 @@ typedef struct msclip_gemm_desc {
 
 int msclip_gemm(const msclip_gemm_desc* desc, void* stream);
 
+/* Name of the kernel msclip_gemm would launch for this descriptor ("pp", "ppconv", "stream", "ring", "dense256",
+ * "dense128", "conv192", "conv256", "conv128"; "invalid" for rejected arguments): the library's own dispatch rule, so
+ * that measurement code (bench.py's roofline leg) counts exactly the launches of one kernel.  No GPU work. */
+const char* msclip_gemm_variant(const msclip_gemm_desc* desc);
+
 /* Fused softmax(q k^T [+ causal]) v per (sample, head), head_dim 64, L <= 224; q pre-scaled.
  * qkv: bf16 [nsamples*L, ldq] with columns [q | k | v], each heads*64 wide.  out: bf16
  * [nsamples*L, ldo], ldq % 8 == 0 and ldo % 8 == 0 (16-byte row pieces).  Replaces M.py:707-738 (scale, reshapes, bmm, mask add, softmax, bmm). */

@@ -26,7 +26,19 @@ _UNSUPPORTED_TRUTHY = (
     "PARALLEL_T2B_WINDOWATTN", "PARALLEL_T2B_POOL_SIZE", "PRALLEL_T2B_ADD_BN_RELU", "PRALLEL_T2B_ADD_BN_LN_RELU",
     "PRALLEL_T2B_NOLN_ADD", "CONTAINER_IN_V", "OUTPUT_ATTN_RAW", "OUTPUT_BEFORE_ATTN", "OUTPUT_AFTER_ATTN",
     "OUTPUT_AFTER_ATTN_LN", "OUTPUT_LAST_LN", "LORA_INIT", "VISUAL_LAYER_MINUS1",
+    # read by Attention_CUST through custom_config even without LORA_OPEN (M.py:346-395): LoRA adapters inside attention
+    "LORA_ATTN_DIM", "VISUAL_LORA_LOCAL", "LORA_ALPHA", "LORA_DROPOUT", "LORA_R_DROPOUT",
 )
+# CUSTOM keys this build honours plus the trainer-only ones the model never reads.  Any OTHER key with a
+# truthy value is an experimental switch of the reference (or a typo): rejected instead of silently building another net.
+_ACCEPTED = {
+    "CUSTOM_ATTN", "SHARE_MODULES", "N_LAYERS", "VISUAL_LAYER_MINUS1", "PARALLEL_IN_V", "PARALLEL_N_LAYERS",
+    "PARALLEL_LATERAL_LAYER", "PARALLEL_KERNELS", "PARALLEL_PADDINGS", "PARALLEL_STRIDES", "PRALLEL_T2B_KERNELS",
+    "PRALLEL_T2B_PADDINGS", "PRALLEL_T2B_STRIDES", "PRALLEL_T2B_USECLS", "PARALLEL_RESNET", "PARALLEL_RESNET_LAYERS",
+    "EARLY_CONV", "EARLY_CONV_NEW_IMPLEMENT", "EARLY_CONV_RES", "EARLY_CONV_RES_FIRSTCONV_KERNEL", "EARLY_CONV_RES_BLOCK",
+    "EARLY_CONV_RES_LAYERS", "EARLY_CONV_RES_STRIDES",
+    "LR_SHARE", "WD_SHARE", "LORA_WHERE_ADD", "GUMBEL_LR", "WITHOUT_WD_LIST",      # trainer / inert defaults (default.py:189-191)
+}
 
 
 def _get(node, key, default=None):
@@ -219,6 +231,11 @@ class CLIP(nn.Module):
             if _get(custom_config, key, False):
                 raise NotImplementedError(f"CUSTOM.{key} selects an experimental branch of the reference that no "
                                           f"released MS-CLIP-S config enables; it is not built here")
+        if isinstance(custom_config, dict):
+            for key, val in custom_config.items():
+                if key not in _ACCEPTED and key not in _UNSUPPORTED_TRUTHY and val not in (None, False, 0, 0.0, "", [], ()):
+                    raise NotImplementedError(f"CUSTOM.{key}={val!r} is not a switch of the released MS-CLIP-S configs "
+                                              f"(accepted keys: {sorted(_ACCEPTED)})")
         if not _get(custom_config, "CUSTOM_ATTN", False):
             raise NotImplementedError("CUSTOM.CUSTOM_ATTN must be True (b32.yaml:59-60)")
         if vision_width % 64 or vision_width != transformer_width:
@@ -302,7 +319,9 @@ class CLIP(nn.Module):
     def train(self, mode=True):
         if mode:
             logging.getLogger(__name__).warning(
-                "msclip_amd runs eval-mode BatchNorm (folded running statistics); train(True) only flips the flags")
+                "msclip_amd: the HIP forward runs eval-mode BatchNorm (folded running statistics) and the backward "
+                "slice (msclip_amd.train) covers the transformer blocks and the contrastive head only; "
+                "train(True) flips the module flags and nothing else")
         return super().train(mode)
 
     def engine(self):

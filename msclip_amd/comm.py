@@ -6,8 +6,9 @@ rows, and autograd flows only through the local slice.  Differences, all
 MI355X-motivated: one collective into one contiguous buffer
 (`all_gather_into_tensor`, which is ncclAllGather == RCCL on ROCm) instead of
 world x `ones_like` + list all_gather + cat; image and text features can be
-packed into a single [B, 2, E] call (`gather_features`); the call can run on a
-side stream; and an uninitialised process group means world size 1 instead of
+packed into a single [B, 2, E] call (`gather_features`); the engine issues one
+asynchronous gather per modality from a side HIP stream (`gather_rows_async`: the image
+gather runs under the text head); and an uninitialised process group means world size 1 instead of
 an exception.
 """
 import torch
@@ -79,14 +80,56 @@ def gather_features(packed):
     return _all_gather_rows(packed)
 
 
+_SIDE = {}
+
+
+def side_stream(device):
+    """The HIP stream the feature collectives are issued from (one per device): RCCL orders its kernel behind the
+    work already queued on the stream that is current at the call, so issuing from a side stream that waited for
+    "features ready" keeps the collective independent of everything the compute stream launches afterwards."""
+    s = _SIDE.get(device)
+    if s is None:
+        s = _SIDE[device] = torch.cuda.Stream(device=device)
+    return s
+
+
+class GatherHandle:
+    """An in-flight all-gather.  wait() makes the CURRENT stream wait for it (the host does not block).  An asynchronous
+    RCCL error (ncclCommGetAsyncError; ProcessGroupNCCL polls it in its watchdog and rethrows it from Work.wait) is
+    re-raised here with the rank and the collective named, instead of surfacing later as a hang or a bare abort."""
+
+    def __init__(self, work, out, side):
+        self.work, self.out, self.side = work, out, side
+
+    def wait(self):
+        try:
+            self.work.wait()
+        except RuntimeError as exc:
+            raise RuntimeError(f"{comm.head} feature all-gather of {tuple(self.out.shape)} failed: {exc}") from exc
+        if self.side is not None:
+            torch.cuda.current_stream(self.out.device).wait_stream(self.side)
+        return self.out
+
+
 def gather_rows_async(t):
-    """Start the rank-major all-gather of t [B, ...] (RCCL runs it on the process group's own stream, i.e. beside
-    the compute stream); returns (out, work).  work is None at world size 1 (out is t itself)."""
+    """Start the rank-major all-gather of t [B, ...]; returns (out, handle).  On a HIP device the collective is issued
+    from the side stream behind an event recorded now on the compute stream ("t is final"), so it overlaps whatever
+    the compute stream runs next.  handle is None at world size 1 (out is t itself)."""
     if comm.world_size == 1:
         return t, None
+    t = t.contiguous()
     out = torch.empty((comm.world_size * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    work = dist.all_gather_into_tensor(out, t.contiguous(), async_op=True)
-    return out, work
+    if not t.is_cuda:
+        return out, GatherHandle(dist.all_gather_into_tensor(out, t, async_op=True), out, None)
+    side = side_stream(t.device)
+    ready = torch.cuda.Event()
+    ready.record(torch.cuda.current_stream(t.device))
+    side.wait_event(ready)
+    with torch.cuda.stream(side):
+        work = dist.all_gather_into_tensor(out, t, async_op=True)
+    out.record_stream(side)
+    t.record_stream(side)
+    return out, GatherHandle(work, out, side)
 
 
 def local_label_offset(local_batch):

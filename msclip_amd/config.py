@@ -84,12 +84,14 @@ def default_config():
     c.RANK = 0
     c.DIST_BACKEND = "nccl"            # == RCCL on ROCm
     c.MODEL = CfgNode({"NAME": "clip_openai_pe_res_v1", "PRETRAINED_MODEL": "", "SPEC": {}})
-    c.TRAIN = CfgNode({"IMAGE_SIZE": [224, 224], "BATCH_SIZE_PER_GPU": 256, "LR": 1e-4})
+    # trainer keys the optimizer set-up of the (unreleased) trainer reads (default.py:126-133, 189-190)
+    c.TRAIN = CfgNode({"IMAGE_SIZE": [224, 224], "BATCH_SIZE_PER_GPU": 256, "LR": 1e-3, "SCALE_LR": True,
+                       "OPTIMIZER": "sgd", "MOMENTUM": 0.9, "WD": 1e-4, "WITHOUT_WD_LIST": []})
     c.TEST = CfgNode({"IMAGE_SIZE": [224, 224], "BATCH_SIZE_PER_GPU": 32, "MODEL_FILE": "", "CENTER_CROP": True,
                       "INTERPOLATION": 3})
     c.INPUT = CfgNode({"MEAN": [0.485, 0.456, 0.406], "STD": [0.229, 0.224, 0.225]})  # default.py:84-85
     c.DATASET = CfgNode({"DATASET": "imagenet", "ROOT": "", "TEST_SET": "val"})
-    c.CUSTOM = CfgNode()
+    c.CUSTOM = CfgNode({"LR_SHARE": 0.0, "WD_SHARE": 0.0})
     return c
 
 
@@ -111,8 +113,13 @@ def update_config(config, args):
     opts = getattr(args, "opts", None)
     if opts:
         config.merge_from_list(opts)
+    if config.TRAIN.get("SCALE_LR", False):                 # default.py:299-304: linear LR scaling with the world size
+        from .comm import comm
+        config.TRAIN.LR = config.TRAIN.LR * comm.world_size
+        if config.CUSTOM.get("LR_SHARE", False):
+            config.CUSTOM.LR_SHARE = config.CUSTOM.LR_SHARE * comm.world_size
     name = os.path.splitext(os.path.basename(args.cfg))[0]
-    config.NAME = (config.NAME + "_" + name) if config.NAME else name
+    config.NAME = name + config.NAME                        # default.py:305-306 (file name is a PREFIX)
     config.freeze()
     return config
 

@@ -1437,19 +1437,9 @@ extern "C" int msclip_pp_trace(unsigned long long* out) {
 #endif
 
 bool msclip_gemm_small_try(const msclip_gemm_desc* d, hipStream_t st, int ncu);   // gemm_small.hip
+bool msclip_gemm_small_eligible(const msclip_gemm_desc* d);
 
-extern "C" int msclip_gemm(const msclip_gemm_desc* d, void* stream) {
-  if (!d || !d->X || !d->W || !d->out || !d->zero) return MSCLIP_EINVAL;
-  if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->K % BK)) return MSCLIP_EINVAL;
-  if (d->mode == 0 && (d->ldx % 8)) return MSCLIP_EINVAL;
-  if (d->ldw < d->K || (d->ldw % 8)) return MSCLIP_EINVAL;
-  if (d->mode == 1 && (!d->ktab || (d->Cin % 8))) return MSCLIP_EINVAL;
-  if (d->mode != 0 && d->mode != 1) return MSCLIP_EINVAL;
-  if (d->rpg <= 0) return MSCLIP_EINVAL;
-  hipStream_t st = (hipStream_t)stream;
-  // tile choice: the 256x256 / 8-wave config whenever the problem fills the chip with it, else 128x128
-  const long long big_tiles = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256);
-  const bool big = d->tile >= 2 || (d->tile == 0 && d->N >= 192 && big_tiles >= 128);
+static int device_cus() {
   static int ncu = 0;
   if (!ncu) {
     hipDeviceProp_t p;
@@ -1457,35 +1447,68 @@ extern "C" int msclip_gemm(const msclip_gemm_desc* d, void* stream) {
     (void)hipGetDevice(&dev);
     ncu = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
   }
-  if ((d->tile == 0 || d->tile == 5) && msclip_gemm_small_try(d, st, ncu)) return msclip_launch_status();
+  return ncu;
+}
+
+// ---- kernel choice: ONE function decides, msclip_gemm launches what it says and msclip_gemm_variant reports it
+enum GemmVariant { GV_INVALID = 0, GV_STREAM, GV_PP, GV_RING, GV_DENSE256, GV_DENSE128, GV_PPCONV, GV_CONV192, GV_CONV256, GV_CONV128 };
+static const char* const kVariantName[] = {"invalid", "stream", "pp", "ring", "dense256", "dense128", "ppconv", "conv192",
+                                           "conv256", "conv128"};
+
+static GemmVariant pick_variant(const msclip_gemm_desc* d) {
+  if (!d || !d->X || !d->W || !d->out || !d->zero) return GV_INVALID;
+  if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->K % BK)) return GV_INVALID;
+  if (d->mode == 0 && (d->ldx % 8)) return GV_INVALID;
+  if (d->ldw < d->K || (d->ldw % 8)) return GV_INVALID;
+  if (d->mode == 1 && (!d->ktab || (d->Cin % 8))) return GV_INVALID;
+  if (d->mode != 0 && d->mode != 1) return GV_INVALID;
+  if (d->rpg <= 0) return GV_INVALID;
+  // tile choice: the 256x256 / 8-wave config whenever the problem fills the chip with it, else 128x128
+  const long long big_tiles = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256);
+  const bool big = d->tile >= 2 || (d->tile == 0 && d->N >= 192 && big_tiles >= 128);
+  if ((d->tile == 0 || d->tile == 5) && msclip_gemm_small_eligible(d)) return GV_STREAM;
   if (d->mode == 0) {
-    const int tiles = ((d->M + 255) / 256) * ((d->N + 255) / 256);
     // 256-row tile offsets must fit the 32-bit buffer offsets of the ping-pong kernel's loads
     // ... and tile id x (4 row-tile counts) below 2^32 for the kernel's reciprocal-multiply tile mapping
     const bool pp_ok = (long long)d->ldx * 2 * 256 + (long long)d->K * 2 < (1ll << 31) &&
                        (long long)d->ldw * 2 * 256 + (long long)d->K * 2 < (1ll << 31) &&
-                       (long long)tiles * ((d->M + 255) / 256) * 4 < (1ll << 32);
-    if (pp_ok && (d->tile == 4 || (d->tile == 0 && big))) {        // ping-pong kernel (default for the projections)
-      hipLaunchKernelGGL(gemm_pp_kernel<0>, dim3(tiles < ncu ? tiles : ncu), dim3(512), 0, st, *d);
-    } else if (big && d->tile != 3) {   // streaming ring kernel (tile 2; tile 3 selects the two-buffer 256x256 kernel: A/B tests)
-      hipLaunchKernelGGL(gemm_ring_kernel, dim3(tiles < ncu ? tiles : ncu), dim3(512), 0, st, *d);
-    } else if (big) launch_cfg<0, 256, 256, 2, 4>(d, st, 1);
-    else launch_cfg<0, 128, 128, 2, 2>(d, st, 2);
-  } else {
-    // input channels a multiple of 64 (a K-tile stays inside one filter tap): the ping-pong kernel gathers the rows itself
-    const long long in_bytes = (long long)(d->M / (d->Ho * d->Wo)) * d->H * d->Wd * d->Cin * 2;
-    const long long t256 = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256);
-    if ((d->tile == 0 || d->tile == 4) && d->Cin % 64 == 0 && d->K % d->Cin == 0 && in_bytes < (1ll << 31) &&
-        (long long)d->ldw * 2 * 256 + (long long)d->K * 2 < (1ll << 31) && d->rpg == 0x7fffffff && d->resid_kind != 3 &&
-        d->M % (d->Ho * d->Wo) == 0 && (t256 >= 128 || d->tile == 4) && t256 * ((d->M + 255) / 256) * 4 < (1ll << 32)) {
-      hipLaunchKernelGGL(gemm_pp_kernel<1>, dim3(t256 < ncu ? (int)t256 : ncu), dim3(512), 0, st, *d);
-      return msclip_launch_status();
-    }
-    // N a multiple of 192 (192 / 384 / 768 output channels): 256 x 192 tiles leave no idle columns
-    const long long t192 = (long long)((d->M + 255) / 256) * ((d->N + 191) / 192);
-    if (d->tile == 6 || (d->tile == 0 && d->N % 192 == 0 && t192 >= 128)) launch_cfg<1, 256, 192, 4, 2>(d, st, 1);
-    else if (big) launch_cfg<1, 256, 256, 2, 4>(d, st, 1);
-    else launch_cfg<1, 128, 128, 2, 2>(d, st, 2);
+                       big_tiles * ((d->M + 255) / 256) * 4 < (1ll << 32);
+    if (pp_ok && (d->tile == 4 || (d->tile == 0 && big))) return GV_PP;     // ping-pong kernel (default for the projections)
+    if (big && d->tile != 3) return GV_RING;   // streaming ring kernel (tile 2; tile 3 selects the two-buffer 256x256 kernel: A/B tests)
+    return big ? GV_DENSE256 : GV_DENSE128;
+  }
+  // input channels a multiple of 64 (a K-tile stays inside one filter tap): the ping-pong kernel gathers the rows itself
+  const long long in_bytes = (long long)(d->M / (d->Ho * d->Wo)) * d->H * d->Wd * d->Cin * 2;
+  if ((d->tile == 0 || d->tile == 4) && d->Cin % 64 == 0 && d->K % d->Cin == 0 && in_bytes < (1ll << 31) &&
+      (long long)d->ldw * 2 * 256 + (long long)d->K * 2 < (1ll << 31) && d->rpg == 0x7fffffff && d->resid_kind != 3 &&
+      d->M % (d->Ho * d->Wo) == 0 && (big_tiles >= 128 || d->tile == 4) && big_tiles * ((d->M + 255) / 256) * 4 < (1ll << 32))
+    return GV_PPCONV;
+  // N a multiple of 192 (192 / 384 / 768 output channels): 256 x 192 tiles leave no idle columns
+  const long long t192 = (long long)((d->M + 255) / 256) * ((d->N + 191) / 192);
+  if (d->tile == 6 || (d->tile == 0 && d->N % 192 == 0 && t192 >= 128)) return GV_CONV192;
+  return big ? GV_CONV256 : GV_CONV128;
+}
+
+extern "C" const char* msclip_gemm_variant(const msclip_gemm_desc* d) { return kVariantName[pick_variant(d)]; }
+
+extern "C" int msclip_gemm(const msclip_gemm_desc* d, void* stream) {
+  const GemmVariant v = pick_variant(d);
+  if (v == GV_INVALID) return MSCLIP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int ncu = device_cus();
+  const int tiles = ((d->M + 255) / 256) * ((d->N + 255) / 256);
+  const int grid = tiles < ncu ? tiles : ncu;
+  switch (v) {
+    case GV_STREAM: if (!msclip_gemm_small_try(d, st, ncu)) return MSCLIP_EINVAL; break;
+    case GV_PP: hipLaunchKernelGGL(gemm_pp_kernel<0>, dim3(grid), dim3(512), 0, st, *d); break;
+    case GV_PPCONV: hipLaunchKernelGGL(gemm_pp_kernel<1>, dim3(grid), dim3(512), 0, st, *d); break;
+    case GV_RING: hipLaunchKernelGGL(gemm_ring_kernel, dim3(grid), dim3(512), 0, st, *d); break;
+    case GV_DENSE256: launch_cfg<0, 256, 256, 2, 4>(d, st, 1); break;
+    case GV_DENSE128: launch_cfg<0, 128, 128, 2, 2>(d, st, 2); break;
+    case GV_CONV192: launch_cfg<1, 256, 192, 4, 2>(d, st, 1); break;
+    case GV_CONV256: launch_cfg<1, 256, 256, 2, 4>(d, st, 1); break;
+    case GV_CONV128: launch_cfg<1, 128, 128, 2, 2>(d, st, 2); break;
+    default: return MSCLIP_EINVAL;
   }
   return msclip_launch_status();
 }

@@ -267,18 +267,22 @@ bool dispatch_stream(const msclip_gemm_desc* d, hipStream_t st, int ncu) {
 
 }  // namespace
 
-// Takes the launch if the problem streams (short K, weights resident in LDS); returns false otherwise.
-bool msclip_gemm_small_try(const msclip_gemm_desc* d, hipStream_t st, int ncu) {
+// Does the problem stream (short K, weights resident in LDS)?  The one predicate both the launch and
+// msclip_gemm_variant() use.
+bool msclip_gemm_small_eligible(const msclip_gemm_desc* d) {
   if ((d->K % 64) || d->M < 4096) return false;
   if (d->rpg != 0x7fffffff || d->radd || d->roff || d->resid_kind == 3) return false;
   if (d->ldw % 8) return false;
-  if (d->mode == 0) {
-    if (d->K > 192 || (d->ldx % 8)) return false;
-    return dispatch_stream<false>(d, st, ncu);
-  }
+  if (d->mode == 0) return d->K <= 192 && !(d->ldx % 8);
   if (d->mode == 1) {
     if (!d->ktab || (d->Cin % 8) || !(d->K <= 192 || d->K == 448)) return false;
-    return dispatch_stream<true>(d, st, ncu);
+    return d->K != 448 || (d->N + 31) / 32 <= 3;               // 3x3 over 48 channels: at most 96 output channels
   }
   return false;
+}
+
+// Takes the launch if the problem streams; returns false otherwise.
+bool msclip_gemm_small_try(const msclip_gemm_desc* d, hipStream_t st, int ncu) {
+  if (!msclip_gemm_small_eligible(d)) return false;
+  return d->mode == 0 ? dispatch_stream<false>(d, st, ncu) : dispatch_stream<true>(d, st, ncu);
 }

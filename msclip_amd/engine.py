@@ -58,6 +58,32 @@ class Engine:
         self._ws = {}
         with torch.cuda.device(self.dev), torch.no_grad():
             self._pack(model)
+        self._stamp = self._fingerprint()
+
+    def _fingerprint(self):
+        """Identity + in-place version of every parameter and buffer the packed copies were made from.  Any mutation
+        the module hooks cannot see (submodule load_state_dict, param.copy_/fill_/clamp_, an optimizer step, a
+        re-assigned .data) changes it; run() then re-packs instead of silently serving stale weights."""
+        v = 0
+        for t in self.model.parameters():
+            v = (v * 1000003 + t._version * 31 + t.data_ptr()) & 0xFFFFFFFFFFFF
+        for t in self.model.buffers():
+            v = (v * 1000003 + t._version * 31 + t.data_ptr()) & 0xFFFFFFFFFFFF
+        return v
+
+    def refresh(self, force=False):
+        """Re-pack the weights if the module's tensors changed since the last pack (cheap check: ~0.1 ms)."""
+        stamp = self._fingerprint()
+        if force or stamp != self._stamp:
+            ref = self.model.visual.positional_embedding
+            if not ref.is_cuda or ref.device != self.dev:
+                raise hip.HipUnavailable("model parameters left the engine's device: rebuild the engine (model.engine())")
+            with torch.cuda.device(self.dev), torch.no_grad():
+                self._pack(self.model)
+            self._stamp = stamp
+            self._ws = {k: w for k, w in self._ws.items() if not (isinstance(k, tuple) and k and k[0] == "graph")}
+            return True
+        return False
 
     # ------------------------------------------------------------------ packing
     def _pack(self, m):
@@ -142,7 +168,14 @@ class Engine:
         key = (Bi, Bt)
         w = self._ws.get(key)
         if w is not None:
+            self._ws[key] = self._ws.pop(key)                  # most recently used last
             return w
+        if not torch.cuda.is_current_stream_capturing():
+            # keep at most two eager workspaces (e.g. the steady batch and a ragged last batch): a third shape evicts the
+            # least recently used one instead of growing without bound (graph captures own theirs)
+            eager = [k for k in self._ws if isinstance(k, tuple) and len(k) == 2 and not self._ws[k].get("pinned")]
+            for k in eager[:-1] if len(eager) >= 2 else []:
+                del self._ws[k]
         dev, D, E = self.dev, self.D, self.E
         bf, f32 = torch.bfloat16, torch.float32
         Mv, Mt = Bi * self.Lv, Bt * self.Lt
@@ -182,9 +215,6 @@ class Engine:
             w["fvb"] = buf(Bi, E)                            # bf16 unit features: gather payload / logits operand
         if Bt:
             w["ftb"] = buf(Bt, E)
-        if Bi and Bt and Bi == Bt:
-            w["loss"] = buf(1, dtype=f32)
-            w["diag"] = buf(Bi, dtype=f32)
         self._ws[key] = w
         return w
 
@@ -205,11 +235,20 @@ class Engine:
         """3x3 / stride 2 / pad 1 over 48 channels: what the fused front kernels (csrc/front.hip) consume."""
         return (spec.kh, spec.kw, spec.stride, spec.pad, spec.cin) == (3, 3, 2, 1, 48) and spec.cout in (48, 96)
 
-    def _vision_front(self, img, w, Bi):
+    def _tap_nhwc(self, taps, name, t, Bi, h, c):
+        if taps is not None:
+            taps[name] = t[:Bi * h * h].view(Bi, h, h, c).permute(0, 3, 1, 2).float()        # reference layout: NCHW
+
+    def _tap_tokens(self, taps, name, t, n, L):
+        if taps is not None:
+            taps[name] = t[:n * L].view(n, L, -1).float().clone()                            # batch-first [B, L, C]
+
+    def _vision_front(self, img, w, Bi, taps=None):
         """Stem + tokenisation (M.py:2416-2426) and stage 0 of the parallel branch (M.py:2436)."""
         first = self.stem_specs[0]
         fused = (self.dual_w.shape[1] == 96 and self._fusable_3x3s2(first) and not hip.env_flag("MSCLIP_FRONT_UNFUSED")
-                 and img.numel() * img.element_size() < 2 ** 31)
+                 and img.numel() * img.element_size() < 2 ** 31
+                 and Bi * self.h1 * self.h1 * (self.D // 16) * 2 < 2 ** 31)      # the kernel's own 32-bit offset limits
         if fused:
             # conv1 + parallel stage 0 + stem stage 0 in one pass: conv1's 48-channel map never reaches HBM
             hip.stem_dual_conv3x3s2(img, self.dual_w, self.dual_b, w["P0"], first.weight, first.bias, w["stem"][0])
@@ -220,12 +259,19 @@ class Engine:
         for spec, out in rest:
             self._conv(x, spec, out, Bi, act=hip.ACT_RELU)
             x = out
+        if taps is not None:
+            if not fused:
+                self._tap_nhwc(taps, "stem_conv1", w["S1"], Bi, self.h1, self.D // 16)
+            for i, (spec, out) in enumerate(zip(self.stem_specs, w["stem"])):
+                self._tap_nhwc(taps, f"stem_stage{i}", out, Bi, spec.h_out, spec.cout)
+            self._tap_nhwc(taps, "parallel0", w["P0"], Bi, self.h1, self.D // 16)
         g2 = self.g * self.g
         # last_conv (1x1, no BN/ReLU) fused with "+ positional_embedding" and the scatter to token rows b*L + 1 + p
         hip.gemm(x, self.w_last, w["X"], M=Bi * g2, resid=self.vpos, resid_kind=hip.RESID_TABLE, rpg=g2, radd=1, roff=1)
         hip.fill_cls(self.cls, self.vpos, w["X"], Bi, self.Lv)
         xv = w["X"][:w["Mv"]]
         hip.layernorm(xv, self.ln_pre.g, self.ln_pre.b, xv, w["Mv"])
+        self._tap_tokens(taps, "tokens_ln_pre", xv, Bi, self.Lv)
 
     def _parallel_stage(self, j, w, Bi):
         if j == 0:
@@ -270,7 +316,7 @@ class Engine:
     def _text_front(self, tok, w, Bt):
         hip.embed_tokens(tok, self.emb, self.tpos, w["X"], w["eot"], w["Mv"])
 
-    def _blocks(self, w, Bi, Bt):
+    def _blocks(self, w, Bi, Bt, taps=None):
         Mv, M = w["Mv"], w["M"]
         X, LNO, QKV, AO, HID = w["X"], w["LNO"], w["QKV"], w["AO"], w["HID"]
         for i in range(self.n_layers):
@@ -290,6 +336,11 @@ class Engine:
                 j = self.lateral.index(i)
                 self._parallel_stage(j, w, Bi)
                 self._adapter(j, w, Bi)
+                if taps is not None:
+                    if j:
+                        c3 = self.par_specs[j][3]
+                        self._tap_nhwc(taps, f"parallel{j}", w["par"][j], Bi, c3.h_out, c3.cout)
+                    self._tap_tokens(taps, f"adapter{j}", w["XA"], Bi, self.Lv)
                 vis_src, raw = w["XA"], X[:Mv]          # ln_1 reads the adapter output and moves it back into X
             # --- ln_1 (modality specific parameters; one launch over both towers' rows unless the adapter output
             #     has to be picked up from its own buffer)
@@ -320,6 +371,11 @@ class Engine:
             for r0, r1, bw in groups:
                 hip.gemm(LNO[r0:r1], bw.wfc, HID[r0:r1], bias=bw.bfc, act=hip.ACT_QUICKGELU)
                 hip.gemm(HID[r0:r1], bw.wpr, X[r0:r1], bias=bw.bpr, resid=X[r0:r1], resid_kind=hip.RESID_F32)
+            if taps is not None:
+                if vb is not None:
+                    self._tap_tokens(taps, f"vblock{i}", X[:Mv], Bi, self.Lv)
+                if tb is not None:
+                    self._tap_tokens(taps, f"tblock{i}", X[Mv:M], Bt, self.Lt)
 
     def _head_image(self, w, Bi, norm=True):                              # M.py:2685-2690, 2983
         hip.layernorm(w["X"], self.ln_post.g, self.ln_post.b, w["hv"], Bi, row_mul=self.Lv)
@@ -367,18 +423,21 @@ class Engine:
             raise ValueError(f"expected tokens [B, {self.Lt}], got {tuple(tok.shape)}")
         return tok.to(torch.int64).contiguous()
 
-    def run(self, img=None, tok=None, norm=True, gather=False):
+    def run(self, img=None, tok=None, norm=True, gather=False, taps=None):
         """Both towers (either may be None) up to the (optionally L2-normalised) features; returns the workspace
-        (plus the gathered bf16 features under "allI"/"allT" when gather=True)."""
+        (plus the gathered bf16 features under "allI"/"allT" when gather=True).  `taps` (a dict) receives fp32 copies
+        of the intermediate tensors the reference exposes through forward hooks (tests/golden tap_* names)."""
         with torch.cuda.device(self.dev):
+            if not torch.cuda.is_current_stream_capturing():
+                self.refresh()
             Bi = img.shape[0] if img is not None else 0
             Bt = tok.shape[0] if tok is not None else 0
             w = self._workspace(Bi, Bt)
             if Bi:
-                self._vision_front(self._check_img(img), w, Bi)
+                self._vision_front(self._check_img(img), w, Bi, taps)
             if Bt:
                 self._text_front(self._check_tok(tok), w, Bt)
-            self._blocks(w, Bi, Bt)
+            self._blocks(w, Bi, Bt, taps)
             allI, allT = self._heads(w, Bi, Bt, norm, gather)
             if gather:
                 w["allI"], w["allT"] = allI, allT
@@ -403,11 +462,17 @@ class Engine:
             with torch.cuda.stream(side):                      # warm-up outside capture (workspace allocation, lazy init)
                 self.run(simg, stok)
             torch.cuda.current_stream().wait_stream(side)
+            self._workspace(Bi, Bt)["pinned"] = True           # the capture bakes this workspace's addresses in
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 w = self.run(simg, stok)
 
+        stamp = self._stamp
+
         def replay(img=None, tok=None):
+            if self._fingerprint() != stamp:
+                raise RuntimeError("model tensors changed after this hipGraph was captured (its kernels read the old "
+                                   "packed weights): call engine.graph(...) again")
             if Bi:
                 simg.copy_(self._check_img(img))
             if Bt:
@@ -449,18 +514,28 @@ class Engine:
         w, allI, allT = self._gathered(img, tok, gather)
         B, n = w["fvb"].shape[0], allI.shape[0]
         world = n // B
-        ntile = (n + 31) // 32
-        nsplit = max(1, min(ntile, 64, 2048 // max(1, (B + 31) // 32)))
-        key = ("lse", B, nsplit)
-        if key not in w:
-            w[key] = torch.empty(4, B, nsplit, dtype=torch.float32, device=self.dev)
-        part = w[key]
-        off = C.local_label_offset(B) if world > 1 else 0
-        s = self.logit_scale_exp
-        hip.clip_lse_fused(w["fvb"], allT, s, off, nsplit, part[0], part[1], w["diag"])
-        hip.clip_lse_fused(w["ftb"], allI, s, off, nsplit, part[2], part[3], w["diag"])
-        hip.clip_loss_from_partials(part[0], part[1], part[2], part[3], w["diag"], 1.0 / (2.0 * n), w["loss"])
-        loss = w["loss"].clone()
+        loss = self.loss_from_features(w["fvb"], w["ftb"], allI, allT, C.local_label_offset(B) if world > 1 else 0)
         if world > 1:
             dist.all_reduce(loss)
         return loss[0]
+
+    def loss_from_features(self, loc_i, loc_t, all_i, all_t, label_off):
+        """This rank's share of the symmetric CE: local unit features [B, E] (bf16) against the rank-major gathered
+        ones [N, E]; global label of local row r is label_off + r (reference lib/utils/comm.py:150-153).  Returns a
+        1-element tensor; the sum over ranks is the loss.  (forward_loss = towers + gather + this + all-reduce.)"""
+        B, n = loc_i.shape[0], all_i.shape[0]
+        assert loc_t.shape[0] == B and all_t.shape[0] == n and 0 <= label_off and label_off + B <= n
+        ntile = (n + 31) // 32
+        nsplit = max(1, min(ntile, 64, 2048 // max(1, (B + 31) // 32)))
+        key = ("lse", B, nsplit)
+        w = self._ws.setdefault("loss_ws", {})
+        if key not in w:
+            w[key] = (torch.empty(4, B, nsplit, dtype=torch.float32, device=self.dev),
+                      torch.empty(B, dtype=torch.float32, device=self.dev),
+                      torch.empty(1, dtype=torch.float32, device=self.dev))
+        part, diag, out = w[key]
+        s = self.logit_scale_exp
+        hip.clip_lse_fused(loc_i, all_t, s, label_off, nsplit, part[0], part[1], diag)
+        hip.clip_lse_fused(loc_t, all_i, s, label_off, nsplit, part[2], part[3], diag)
+        hip.clip_loss_from_partials(part[0], part[1], part[2], part[3], diag, 1.0 / (2.0 * n), out)
+        return out.clone()

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("MSCLIP_HIP_LIB") or os.path.join(_HERE, "csrc", "libm
 INT_MAX = 2 ** 31 - 1
 
 EXPORTS = (
-    "msclip_gemm", "msclip_attention", "msclip_layernorm", "msclip_layernorm_split", "msclip_embed_tokens", "msclip_fill_cls",
+    "msclip_gemm", "msclip_gemm_variant", "msclip_attention", "msclip_layernorm", "msclip_layernorm_split", "msclip_embed_tokens", "msclip_fill_cls",
     "msclip_adapter_combine_ln", "msclip_l2norm", "msclip_stem_conv3x3s2_dual", "msclip_dwpool",
     "msclip_stem_dual_conv3x3s2", "msclip_conv1x1_conv3x3s2", "msclip_convresblock48_s2",
     "msclip_lse_rows", "msclip_clip_loss_partial", "msclip_clip_lse_fused", "msclip_clip_loss_from_partials",
@@ -69,6 +69,8 @@ def lib():
         L = ctypes.CDLL(LIB_PATH)
         vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
         L.msclip_gemm.argtypes = [ctypes.POINTER(GemmDesc), vp]
+        L.msclip_gemm_variant.argtypes = [ctypes.POINTER(GemmDesc)]
+        L.msclip_gemm_variant.restype = ctypes.c_char_p
         L.msclip_attention.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, vp]
         L.msclip_layernorm.argtypes = [vp, ci, vp, ci, ci, vp, vp, vp, ci, ci, vp, ci, ci, ci, cf, vp]
         L.msclip_layernorm_split.argtypes = [vp, ci, vp, vp, vp, vp, ci, vp, ci, ci, ci, ci, cf, vp]
@@ -88,7 +90,7 @@ def lib():
         L.msclip_abi_version.restype = ci
         L.msclip_build_arch.restype = ctypes.c_char_p
         for name in EXPORTS:
-            if name not in ("msclip_build_arch",):
+            if name not in ("msclip_build_arch", "msclip_gemm_variant"):
                 getattr(L, name).restype = ci
         _lib = L
     return _lib
@@ -144,17 +146,27 @@ class KernelProbe:
     def __init__(self):
         self.records = []          # (start_event, end_event, units)
         self.tags = []             # optional per-launch description
+        self.bytes = []            # algorithmic HBM bytes of the launch (operands once + residual once + output once)
 
     def begin(self):
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
         return ev
 
-    def end(self, start, units, tag=None):
+    def end(self, start, units, tag=None, nbytes=0):
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
         self.records.append((start, ev, units))
         self.tags.append(tag)
+        self.bytes.append(nbytes)
+
+    def by_shape(self):
+        """-> {tag: (launches, total_ms, total_units, total_bytes)}; call after a synchronize."""
+        out = {}
+        for (s, e, u), tag, nb in zip(self.records, self.tags, self.bytes):
+            n, ms, uu, bb = out.get(tag, (0, 0.0, 0.0, 0))
+            out[tag] = (n + 1, ms + s.elapsed_time(e), uu + u, bb + nb)
+        return out
 
     def summary(self):
         """-> (launches, total_ms, total_units); call after a synchronize."""
@@ -165,25 +177,26 @@ class KernelProbe:
 _gemm_probe = {}   # kernel variant -> KernelProbe
 
 
-def gemm_variant(mode, M, N, tile=0, K=None, cin=None):
-    """Which kernel msclip_gemm dispatches to (mirror of the rule in csrc/gemm.hip): 'pp' = gemm_pp_kernel (dense
-    256x256 ping-pong, the default for large problems), 'ring' = gemm_ring_kernel (tile 2), 'stream' = gemm_stream_kernel (K <= 192), 'conv256'/'conv128' =
-    gemm_kernel<1,...>, 'dense256'/'dense128' = gemm_kernel<0,...>."""
-    big_tiles = ((M + 255) // 256) * ((N + 255) // 256)
-    big = tile >= 2 or (tile == 0 and N >= 192 and big_tiles >= 128)
-    if mode == 0:
-        if tile in (0, 5) and K is not None and K <= 192 and K % 64 == 0 and M >= 4096:
-            return "stream"
-        if tile == 4 or (tile == 0 and big):
-            return "pp"
-        return "ring" if (big and tile != 3) else ("dense256" if big else "dense128")
-    if tile in (0, 5) and K is not None and (K <= 192 or K == 448) and K % 64 == 0 and M >= 4096 and (K != 448 or N <= 96):
-        return "stream"
-    if tile in (0, 4) and cin is not None and cin % 64 == 0 and ((M + 255) // 256) * ((N + 255) // 256) >= 128:
-        return "ppconv"
-    if tile == 6 or (tile == 0 and N % 192 == 0 and ((M + 255) // 256) * ((N + 191) // 192) >= 128):
-        return "conv192"
-    return "conv256" if big else "conv128"
+def gemm_variant(desc):
+    """Which kernel msclip_gemm dispatches this descriptor to -- asked from the library itself (msclip_gemm_variant):
+    'pp' = gemm_pp_kernel<0> (dense 256x256 ping-pong, the default for large problems), 'ppconv' = gemm_pp_kernel<1>,
+    'stream' = gemm_stream_kernel (K <= 192), 'ring', 'dense256'/'dense128' = gemm_kernel<0,...>,
+    'conv192'/'conv256'/'conv128' = gemm_kernel<1,...>."""
+    return lib().msclip_gemm_variant(ctypes.byref(desc)).decode()
+
+
+def describe_gemm(mode, M, N, K, tile=0, conv=None, ldx=None, resid_kind=0, rpg=INT_MAX):
+    """A shape-only descriptor (dummy non-null pointers) for asking msclip_gemm_variant about a launch without data.
+    conv = (H, W, Cin, Ho, Wo, stride, pad) for mode 1."""
+    d = GemmDesc()
+    d.X = d.W = d.zero = d.out = 1
+    d.M, d.N, d.K, d.mode, d.tile = M, N, K, mode, tile
+    d.ldx, d.ldw, d.ldo, d.ldr = (ldx if ldx is not None else K), K, N, N
+    d.rpg, d.resid_kind, d.alpha = rpg, resid_kind, 1.0
+    if mode == 1:
+        d.H, d.Wd, d.Cin, d.Ho, d.Wo, d.stride, d.pad = conv
+        d.ktab = 1
+    return d
 
 
 def set_gemm_probe(variant, probe):
@@ -223,12 +236,16 @@ def gemm(x, w, out, *, M=None, bias=None, resid=None, resid_kind=0, act=0, alpha
     d.alpha = alpha
     d.rpg, d.radd, d.roff = rpg, radd, roff
     d.tile = tile
-    probe = _gemm_probe.get(d.mode) or _gemm_probe.get(gemm_variant(d.mode, d.M, d.N, tile, d.K if d.rpg == INT_MAX and resid_kind != RESID_TABLE else None, conv[2] if conv is not None else None)) if _gemm_probe else None
+    probe = (_gemm_probe.get(d.mode) or _gemm_probe.get(gemm_variant(d))) if _gemm_probe else None
     if probe is not None:
         k_alg = d.K if conv is None else conv[2] * (ktab_taps(ktab) if ktab is not None else 1)
         t0 = probe.begin()
         _check(lib().msclip_gemm(ctypes.byref(d), _stream()), "msclip_gemm")
-        probe.end(t0, 2.0 * d.M * d.N * k_alg, (d.M, d.N, d.K, k_alg, conv))
+        esz = 4 if d.out_kind else 2
+        x_bytes = d.M * d.K * 2 if conv is None else (d.M // (conv[3] * conv[4])) * conv[0] * conv[1] * conv[2] * 2
+        r_bytes = {RESID_NONE: 0, RESID_F32: d.M * d.N * 4, RESID_BF16: d.M * d.N * 2, RESID_TABLE: 0}[resid_kind]
+        nbytes = x_bytes + d.N * d.K * 2 + d.M * d.N * esz + r_bytes + (d.N * 4 if bias is not None else 0)
+        probe.end(t0, 2.0 * d.M * d.N * k_alg, (d.M, d.N, d.K, k_alg, conv is not None, act, resid_kind, d.out_kind), nbytes)
         return out
     _check(lib().msclip_gemm(ctypes.byref(d), _stream()), "msclip_gemm")
     return out

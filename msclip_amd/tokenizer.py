@@ -5,13 +5,22 @@ text -> html-unescape twice, collapse whitespace, lower-case -> regex pre-tokens
 code points -> greedy lowest-rank pair merges with an end-of-word marker -> ids; `tokenize` wraps with SOT / EOT,
 zero-pads to `context_length` and truncates longer sequences (the reference truncates silently, :160-163).
 
-The merge table is DATA that this repository does not ship: pass the path of the reference's
-`bpe_simple_vocab_16e6.txt.gz` (or set MSCLIP_BPE_VOCAB).  `ftfy` is not required: the reference only uses it for
-mojibake repair, which is the identity on clean text.
+The merge table is DATA: the 48 894 merges the 49 408-entry vocabulary uses ship as
+msclip_amd/data/clip_bpe_merges.txt.gz (extracted by tools/make_data.py; the released checkpoints' token ids are
+defined by it).  `bpe_path=` / MSCLIP_BPE_VOCAB may point at another table in the same format, e.g. the reference's
+full `bpe_simple_vocab_16e6.txt.gz`.
+
+Text cleaning: the reference calls `ftfy.fix_text` first (simple_tokenizer.py:54-57).  It is used when importable;
+otherwise (ftfy is not installed in this image) the text is NFC-normalised only and a warning is logged once: ids
+are identical to the reference's on text ftfy leaves alone (all ASCII, and already-normalised Unicode -- pinned by
+tests/golden/tokenizer.json, which has non-ASCII cases), and may differ on mojibake / curly quotes / ligatures /
+full-width forms that ftfy would rewrite.
 """
 import gzip
 import html
+import logging
 import os
+import unicodedata
 
 import regex
 import torch
@@ -19,8 +28,27 @@ import torch
 _PRETOKEN = regex.compile(
     r"<\|startoftext\|>|<\|endoftext\|>|'s|'t|'re|'ve|'m|'ll|'d|[\p{L}]+|[\p{N}]|[^\s\p{L}\p{N}]+", regex.IGNORECASE)
 _EOW = "</w>"
-_CANDIDATE_PATHS = ("bpe_simple_vocab_16e6.txt.gz", "lib/dataset/languages/bpe_simple_vocab_16e6.txt.gz",
-                    "/root/reference/lib/dataset/languages/bpe_simple_vocab_16e6.txt.gz")
+_PACKAGED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "clip_bpe_merges.txt.gz")
+_CANDIDATE_PATHS = (_PACKAGED, "bpe_simple_vocab_16e6.txt.gz", "lib/dataset/languages/bpe_simple_vocab_16e6.txt.gz")
+
+try:
+    import ftfy as _ftfy
+except ImportError:
+    _ftfy = None
+_warned = []
+
+
+def basic_clean(text):
+    """simple_tokenizer.py:54-57: ftfy.fix_text, html.unescape twice, strip."""
+    if _ftfy is not None:
+        text = _ftfy.fix_text(text)
+    else:
+        if not text.isascii() and not _warned:
+            _warned.append(1)
+            logging.getLogger(__name__).warning("ftfy is not installed: non-ASCII captions are NFC-normalised only "
+                                                "(token ids can differ from the reference's on text ftfy would repair)")
+        text = unicodedata.normalize("NFC", text)
+    return html.unescape(html.unescape(text)).strip()
 
 
 def find_vocab(path=None):
@@ -98,7 +126,7 @@ class SimpleTokenizer:
         return parts
 
     def encode(self, text):
-        text = html.unescape(html.unescape(text)).strip()
+        text = basic_clean(text)
         text = regex.sub(r"\s+", " ", text).strip().lower()
         ids = []
         for piece in _PRETOKEN.findall(text):

@@ -7,8 +7,9 @@
 * logits = 100 * f_img @ W, top-k accuracy                                (zero_shot.py:265-266, 149-163)
 * ImageFolder layout val/<wnid>/*.JPEG, class index = sorted directory names (DATASET/DATA.md:5-14)
 
-Class names and prompt templates are DATA the caller supplies (the reference keeps ImageNet's 1000 names and 80
-templates in lib/dataset/prompts/constants.py); `load_prompts` reads such a python/json file.
+Class names and prompt templates are DATA: ImageNet's 1000 names and 80 templates (the values of the reference's
+lib/dataset/prompts/constants.py) ship as msclip_amd/data/imagenet_prompts.json; `load_prompts` reads that file, another
+json of the same layout, or a python constants file.
 """
 import json
 import os
@@ -24,9 +25,25 @@ IMAGENET_STD = (0.229, 0.224, 0.225)
 IMG_EXT = (".jpg", ".jpeg", ".png", ".bmp", ".ppm", ".webp")
 
 
-def load_prompts(path):
-    """-> (classnames, templates).  Accepts a json {"classes": [...], "templates": [...]} or a python constants file
+PROMPTS = {"imagenet": os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "imagenet_prompts.json")}
+
+
+TRANSFER_NAME = {"oxford-flower-102": "flower102-tf", "fgvc-aircraft-2013b": "fgvc-aircraft-2013b-variants102"}
+
+
+def prompt_name(dataset):
+    """zero_shot.py:235-238."""
+    return TRANSFER_NAME.get(dataset, dataset)
+
+
+def load_prompts(path="imagenet"):
+    """-> (classnames, templates).  `path`: a dataset name with packaged prompts ("imagenet", as config.DATASET.DATASET
+    selects them in zero_shot.py:235-243), a json {"classes": [...], "templates": [...]} or a python constants file
     defining IMAGENET_CLASSES / IMAGENET_DEFAULT_TEMPLATES (the reference's constants.py layout)."""
+    if path in PROMPTS:
+        path = PROMPTS[path]
+    elif not os.path.exists(path):
+        raise ValueError("Can not find prompt for dataset: {}".format(path))        # zero_shot.py:243
     if path.endswith(".json"):
         with open(path) as f:
             d = json.load(f)
@@ -76,6 +93,12 @@ def preprocess(img, size=224, mean=IMAGENET_MEAN, std=IMAGENET_STD):
     return torch.from_numpy(np.ascontiguousarray(x.transpose(2, 0, 1)))
 
 
+def preprocess_array(a, size=224, mean=IMAGENET_MEAN, std=IMAGENET_STD):
+    """uint8 [H, W, 3] array -> the same tensor `preprocess` gives for the image file holding those pixels."""
+    from PIL import Image
+    return preprocess(Image.fromarray(np.asarray(a, dtype=np.uint8)), size, mean, std)
+
+
 def image_folder(root):
     """[(path, class_index)], class directories sorted like torchvision's ImageFolder."""
     classes = sorted(d for d in os.listdir(root) if os.path.isdir(os.path.join(root, d)))
@@ -90,28 +113,44 @@ def image_folder(root):
 
 @torch.no_grad()
 def evaluate(model, tokenizer, val_root, classnames, templates, batch_size=32, device="cuda", max_images=None,
-             size=224, log=print):
-    """Full zero-shot run: returns dict(top1, top5, n).  Prints the reference's final log line format."""
+             size=224, log=print, max_classes=None, mean=IMAGENET_MEAN, std=IMAGENET_STD, dataset="imagenet",
+             metric="accuracy", return_logits=False):
+    """Full zero-shot run: returns dict(top1, top5, n).  Logs the reference's final line (zero_shot.py:304-308).
+    max_classes keeps the first C class directories and class names (subset runs); max_images a strided subset."""
     from PIL import Image
     hip.require_gpu()
+    if metric != "accuracy":
+        raise NotImplementedError(f"TEST.METRIC {metric!r}: only top-1 'accuracy' (ImageNet) is on the MS-CLIP-S eval path")
     dirs, items = image_folder(val_root)
+    if max_classes:
+        classnames = list(classnames)[:max_classes]
+        items = [(p, c) for p, c in items if c < max_classes]
+        dirs = dirs[:max_classes]
     if len(dirs) != len(classnames):
         raise ValueError(f"{len(dirs)} class directories under {val_root} but {len(classnames)} class names")
     if max_images:
         step = max(1, len(items) // max_images)
         items = items[::step][:max_images]
     W = zeroshot_classifier(model, tokenizer, classnames, templates, device)
+    log("=> Start to inference")
     hits1 = hits5 = n = 0
+    keep = []
     for i in range(0, len(items), batch_size):
         chunk = items[i:i + batch_size]
-        x = torch.stack([preprocess(Image.open(p), size) for p, _ in chunk]).to(device)
+        x = torch.stack([preprocess(Image.open(p), size, mean, std) for p, _ in chunk]).to(device)
         y = torch.tensor([c for _, c in chunk], device=device)
         logits = 100.0 * model.encode_image(x).float() @ W
+        if return_logits:
+            keep.append(logits.float().cpu())
         a1, a5 = accuracy(logits, y, (1, min(5, logits.shape[1])))
         hits1 += a1 * len(chunk) / 100.0
         hits5 += a5 * len(chunk) / 100.0
         n += len(chunk)
     top1, top5 = 100.0 * hits1 / max(n, 1), 100.0 * hits5 / max(n, 1)
-    log("=> imagenet% TEST: Error@1 {:.3f}%\taccuracy@1 {:.3f}%\taccuracy@5 {:.3f}%\t({} images)".format(
-        100.0 - top1, top1, top5, n))
-    return dict(top1=top1, top5=top5, n=n)
+    log("=> {dataset}% TEST:\tError@1 {error1:.3f}%\t{metric}@1 {top1:.3f}%\t".format(
+        dataset=dataset, metric=metric, top1=top1, error1=100.0 - top1) + "accuracy@5 {:.3f}%\t({} images)".format(top5, n))
+    res = dict(top1=top1, top5=top5, n=n)
+    if return_logits:
+        res["logits"], res["classifier"] = torch.cat(keep), W.float().cpu()
+        res["labels"] = torch.tensor([c for _, c in items])
+    return res

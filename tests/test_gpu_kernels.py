@@ -78,7 +78,7 @@ def test_gemm_streaming_small_k(gpu_device, M, N, K, ldx):
     w[:, :cin] = rnd(N, cin, seed=22, scale=0.08, dtype=BF)
     b = rnd(N, seed=23)
     base = x[:M].float() @ w[:, :cin].float().t() + b
-    assert hip.gemm_variant(0, M, N, 0, K) == "stream"
+    assert hip.gemm_variant(hip.describe_gemm(0, M, N, K, ldx=ldx)) == "stream"
     out = torch.full((M + 1, N), float("nan"), dtype=BF, device="cuda")
     hip.gemm(x, w, out[:M], M=M, bias=b, act=hip.ACT_RELU, ldx=ldx)
     close(out[:M], F.relu(base), 2e-2, 1e-2)

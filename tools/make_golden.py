@@ -103,6 +103,49 @@ def run_config(name):
     return model, sd
 
 
+def c1_images(n_classes=8, per_class=8, seed=7):
+    """The generated 64-image ImageFolder of BASELINE config C1: uint8 [n_classes, per_class, 224, 224, 3] from a seed
+    (smooth random fields so that PNG round trips and the conv stem see image-like statistics)."""
+    rng = np.random.default_rng(seed)
+    low = rng.integers(0, 256, (n_classes, per_class, 14, 14, 3)).astype(np.float32)
+    img = np.repeat(np.repeat(low, 16, axis=2), 16, axis=3)
+    img += rng.normal(0, 12, img.shape).astype(np.float32)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def zeroshot_fixture(model, name):
+    """Real-token text features and the C1 zero-shot protocol from the reference (tools/zero_shot.py:122-134, 265-266):
+    features of the committed prompts of tests/golden/tokenizer.json, the classifier columns of the first 8 ImageNet
+    classes over all 80 templates, and 100 * f_img @ W for the 64 generated images."""
+    from dataset.languages.simple_tokenizer import SimpleTokenizer
+    from msclip_amd import zeroshot
+    tok = SimpleTokenizer()
+    g = json.load(open(os.path.join(OUT, "tokenizer.json")))
+    ids = torch.tensor(g["ids"], dtype=torch.long)
+    assert tok(g["prompts"]).tolist() == g["ids"]
+    classes, templates = zeroshot.load_prompts("imagenet")
+    classes = classes[:8]
+    imgs = c1_images()
+    x = torch.stack([zeroshot.preprocess_array(a) for a in imgs.reshape(-1, 224, 224, 3)])
+    with torch.no_grad():
+        ft = model.encode_text(ids)
+        cols = []
+        for c in classes:                                                    # zero_shot.py:122-134
+            e = model.encode_text(tok([t.format(c) for t in templates]))
+            e = e / e.norm(dim=-1, keepdim=True)
+            e = e.mean(dim=0)
+            cols.append(e / e.norm())
+        W = torch.stack(cols, dim=1)
+        fi = torch.cat([model.encode_image(x[i:i + 16]) for i in range(0, x.shape[0], 16)])
+        logits = 100.0 * fi @ W
+    y = torch.arange(8).repeat_interleave(8)
+    top1 = (logits.argmax(-1) == y).float().mean().item() * 100.0
+    np.savez_compressed(os.path.join(OUT, f"{name}.zeroshot.npz"), prompt_text_features=ft.numpy(),
+                        classifier=W.numpy(), image_features=fi.numpy(), logits=logits.numpy(),
+                        top1=np.float32(top1), n_classes=np.int64(8), per_class=np.int64(8), image_seed=np.int64(7))
+    print(f"{name}: zero-shot fixture top1 {top1:.2f}% on 64 generated images, W {tuple(W.shape)}")
+
+
 def multirank_gather_fixture():
     """Reference gather_tensors under 2-rank gloo (lib/utils/comm.py:140-154):
     rank-major concat, and gradient only through the local slice."""
@@ -134,7 +177,9 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     for name in ("b32-yfcc-msclips", "b16-yfcc-msclips"):
-        run_config(name)
+        model, _ = run_config(name)
+        if name.startswith("b32"):
+            zeroshot_fixture(model, name)
     multirank_gather_fixture()
 
 
