@@ -103,6 +103,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true", help="do not bracket GEMM launches with HIP events")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic = null)")
+    ap.add_argument("--prefill-random", action="store_true",
+                    help="probe runs only: fill the workspace with random data first (timing ablation builds of the "
+                         "library whose kernels skip their stores; zero-filled operands would raise the clock)")
     ap.add_argument("--shapes", action="store_true", help="add the per-shape table of the dominant kernel to the record")
     args = ap.parse_args()
 
@@ -142,6 +145,11 @@ def main():
 
     for _ in range(args.warmup):
         loss = step()
+    if args.prefill_random:
+        for v in eng._workspace(B, B).values():
+            for t in (v if isinstance(v, (list, tuple)) else [v]):
+                if torch.is_tensor(t) and t.is_floating_point():
+                    t.normal_()
     probe = None if args.no_probe else hip.KernelProbe()
     hip.set_gemm_probe(DOMINANT["variant"], probe)
     fence()

@@ -51,12 +51,12 @@ typedef struct msclip_gemm_desc {
   int out_kind;
   float alpha;
   int rpg, radd, roff;   /* rpg > 0; use rpg = INT_MAX, radd = roff = 0 for the identity */
-  int tile;              /* 0 = auto, 1 = 128x128 (4 waves), 2 = 256x256 streaming ring (dense) / two-buffer (conv), 3 = 256x256 two-buffer, 4 = 256x256 ping-pong (dense; what auto picks for large problems), 5 = streaming kernel with LDS-resident weights (K <= 192, or the 3x3 convolutions with 48 input channels; M >= 4096; auto picks it there), 6 = 256x192 two-buffer (implicit conv with N % 192 == 0) */
+  int tile;              /* 0 = auto, 1 = 128x128 (4 waves), 2 = 256x256 streaming ring (dense) / two-buffer (conv), 3 = 256x256 two-buffer, 4 = 256x256 ping-pong (dense; what auto picks for large problems), 5 = streaming kernel with LDS-resident weights (K <= 192, or the 3x3 convolutions with 48 input channels; M >= 4096; auto picks it there), 6 = 256x192 two-buffer (implicit conv with N % 192 == 0), 7 = 4-wave 256x256 kernel with the epilogue carried under the next tile's K loop (dense X, bf16 output, no residual, N % 256 == 0, K >= 576, alpha 1; auto picks it for such problems when they fill the chip; EINVAL otherwise) */
 } msclip_gemm_desc;
 
 int msclip_gemm(const msclip_gemm_desc* desc, void* stream);
 
-/* Name of the kernel msclip_gemm would launch for this descriptor ("pp", "ppconv", "stream", "ring", "dense256",
+/* Name of the kernel msclip_gemm would launch for this descriptor ("w4", "pp", "ppconv", "stream", "ring", "dense256",
  * "dense128", "conv192", "conv256", "conv128"; "invalid" for rejected arguments): the library's own dispatch rule, so
  * that measurement code (bench.py's roofline leg) counts exactly the launches of one kernel.  No GPU work. */
 const char* msclip_gemm_variant(const msclip_gemm_desc* desc);

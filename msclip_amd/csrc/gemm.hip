@@ -1187,7 +1187,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
     {
       const int n = cn0 + wn + lane_s;
       const float* p = bsrc + (n < nlast ? n : nlast);
+#ifndef PP_NOEPI
       asm volatile("global_load_dword %0, %1, off" : "=&v"(bcol) : "v"(p));
+#else
+      bcol = 0.f; (void)p;
+#endif
     }
     float4 bias4[TN];
 #pragma unroll
@@ -1195,8 +1199,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
       int n = cn0 + wn + i * 32 + (lane_s & 7) * 4;
       n = n + 3 < nlast ? n : (nlast & ~3);
       const float* p = bsrc + (vec ? n : 0);
-      f32x4 v;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#ifndef PP_NOEPI
       asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(v) : "v"(p));
+#else
+      (void)p;
+#endif
       bias4[i] = make_float4(v[0], v[1], v[2], v[3]);
     }
     PP_STAMP(1);
@@ -1438,6 +1446,8 @@ extern "C" int msclip_pp_trace(unsigned long long* out) {
 
 bool msclip_gemm_small_try(const msclip_gemm_desc* d, hipStream_t st, int ncu);   // gemm_small.hip
 bool msclip_gemm_small_eligible(const msclip_gemm_desc* d);
+bool msclip_gemm_w4_eligible(const msclip_gemm_desc* d);                            // gemm_w4.hip
+void msclip_gemm_w4_launch(const msclip_gemm_desc* d, hipStream_t st);
 
 static int device_cus() {
   static int ncu = 0;
@@ -1451,9 +1461,9 @@ static int device_cus() {
 }
 
 // ---- kernel choice: ONE function decides, msclip_gemm launches what it says and msclip_gemm_variant reports it
-enum GemmVariant { GV_INVALID = 0, GV_STREAM, GV_PP, GV_RING, GV_DENSE256, GV_DENSE128, GV_PPCONV, GV_CONV192, GV_CONV256, GV_CONV128 };
+enum GemmVariant { GV_INVALID = 0, GV_STREAM, GV_PP, GV_RING, GV_DENSE256, GV_DENSE128, GV_PPCONV, GV_CONV192, GV_CONV256, GV_CONV128, GV_W4 };
 static const char* const kVariantName[] = {"invalid", "stream", "pp", "ring", "dense256", "dense128", "ppconv", "conv192",
-                                           "conv256", "conv128"};
+                                           "conv256", "conv128", "w4"};
 
 static GemmVariant pick_variant(const msclip_gemm_desc* d) {
   if (!d || !d->X || !d->W || !d->out || !d->zero) return GV_INVALID;
@@ -1467,6 +1477,9 @@ static GemmVariant pick_variant(const msclip_gemm_desc* d) {
   const long long big_tiles = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256);
   const bool big = d->tile >= 2 || (d->tile == 0 && d->N >= 192 && big_tiles >= 128);
   if ((d->tile == 0 || d->tile == 5) && msclip_gemm_small_eligible(d)) return GV_STREAM;
+  if (d->tile == 7) return msclip_gemm_w4_eligible(d) ? GV_W4 : GV_INVALID;
+  // bf16 outputs without residual (QKV, c_fc): the 4-wave kernel whose epilogue rides under the next tile's K loop
+  if (d->tile == 0 && big && msclip_gemm_w4_eligible(d)) return GV_W4;
   if (d->mode == 0) {
     // 256-row tile offsets must fit the 32-bit buffer offsets of the ping-pong kernel's loads
     // ... and tile id x (4 row-tile counts) below 2^32 for the kernel's reciprocal-multiply tile mapping
@@ -1500,6 +1513,7 @@ extern "C" int msclip_gemm(const msclip_gemm_desc* d, void* stream) {
   const int grid = tiles < ncu ? tiles : ncu;
   switch (v) {
     case GV_STREAM: if (!msclip_gemm_small_try(d, st, ncu)) return MSCLIP_EINVAL; break;
+    case GV_W4: msclip_gemm_w4_launch(d, st); break;
     case GV_PP: hipLaunchKernelGGL(gemm_pp_kernel<0>, dim3(grid), dim3(512), 0, st, *d); break;
     case GV_PPCONV: hipLaunchKernelGGL(gemm_pp_kernel<1>, dim3(grid), dim3(512), 0, st, *d); break;
     case GV_RING: hipLaunchKernelGGL(gemm_ring_kernel, dim3(grid), dim3(512), 0, st, *d); break;

@@ -190,6 +190,7 @@ def describe_gemm(mode, M, N, K, tile=0, conv=None, ldx=None, resid_kind=0, rpg=
     conv = (H, W, Cin, Ho, Wo, stride, pad) for mode 1."""
     d = GemmDesc()
     d.X = d.W = d.zero = d.out = 1
+    d.resid = 1 if resid_kind else None
     d.M, d.N, d.K, d.mode, d.tile = M, N, K, mode, tile
     d.ldx, d.ldw, d.ldo, d.ldr = (ldx if ldx is not None else K), K, N, N
     d.rpg, d.resid_kind, d.alpha = rpg, resid_kind, 1.0

@@ -604,3 +604,51 @@ def test_bad_arguments_are_rejected(gpu_device):
         hip.gemm(x, w, torch.empty(8, 8, dtype=BF, device="cuda"))
     with pytest.raises(hip.HipError):
         hip.attention(rnd(300, 2304, dtype=BF), torch.empty(300, 768, dtype=BF, device="cuda"), 1, 300, 12, False)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 2: the 4-wave GEMM whose epilogue is carried under the next tile's K loop (csrc/gemm_w4.hip, tile = 7)
+# ---------------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("act", [hip.ACT_NONE, hip.ACT_QUICKGELU, hip.ACT_RELU])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 576), (1000, 768, 768), (77, 512, 3072), (2051, 1024, 640), (5000, 2304, 768),
+                                    (300 * 256 - 19, 256, 576), (9 * 256, 9 * 256, 1024)])
+def test_gemm_w4_carried_epilogue(gpu_device, M, N, K, act):
+    """Every epilogue unit / row guard / tile hand-over of the 4-wave kernel: one tile, fewer and more tiles than
+    workgroups, ragged M (rows past M never written), 9 K-tiles (the minimum: units on K-tiles 1..8) and more, all
+    three activations, with and without bias.  Checked on EVERY output element against fp32 torch."""
+    x, w, b = rnd(M, K, seed=31, dtype=BF), rnd(N, K, seed=32, scale=0.05, dtype=BF), rnd(N, seed=33)
+    assert hip.gemm_variant(hip.describe_gemm(0, M, N, K, tile=7)) == "w4"
+    base = x.float() @ w.float().t()
+    for bias in (b, None):
+        ref = base + (bias if bias is not None else 0.0)
+        if act == hip.ACT_QUICKGELU:
+            ref = ref * torch.sigmoid(1.702 * ref)
+        elif act == hip.ACT_RELU:
+            ref = F.relu(ref)
+        out = torch.full((M + 5, N), float("nan"), dtype=BF, device="cuda")
+        for rep in range(2):                                                    # second launch: same result bit for bit
+            hip.gemm(x, w, out[:M], bias=bias, act=act, tile=7)
+            if rep == 0:
+                first = out[:M].clone()
+        assert torch.equal(first.view(torch.int16), out[:M].view(torch.int16))
+        # operands rounded to bf16 once more before the bias / activation (the packed carry): 2^-8 relative on |acc|
+        close(out[:M], ref, 3e-2, 1.5e-2)
+        assert bool(torch.isnan(out[M:].float()).all())                          # nothing written past M
+
+
+def test_gemm_w4_is_what_auto_picks_for_the_projections(gpu_device):
+    assert hip.gemm_variant(hip.describe_gemm(0, 65024, 2304, 768)) == "w4"      # QKV
+    assert hip.gemm_variant(hip.describe_gemm(0, 65024, 3072, 768)) == "w4"      # c_fc
+    assert hip.gemm_variant(hip.describe_gemm(0, 65024, 768, 3072, resid_kind=hip.RESID_F32)) == "pp"   # residual: ping-pong
+    assert hip.gemm_variant(hip.describe_gemm(0, 1000, 768, 768, tile=7, resid_kind=hip.RESID_F32)) == "invalid"
+    x, w = rnd(65024, 768, seed=41, dtype=BF), rnd(2304, 768, seed=42, scale=0.05, dtype=BF)
+    b = rnd(2304, seed=43)
+    out = torch.empty(65024, 2304, dtype=BF, device="cuda")
+    hip.gemm(x, w, out, bias=b)
+    ref = torch.empty_like(out)
+    hip.gemm(x, w, ref, bias=b, tile=4)                                          # the ping-pong kernel on the same data
+    d = (out.float() - ref.float()).abs()
+    assert d.max().item() <= 3e-2 * max(1.0, ref.float().abs().max().item())
+    rows = torch.tensor([0, 255, 256, 32767, 65023], device="cuda")
+    close(out[rows], x[rows].float() @ w.float().t() + b, 3e-2, 1.5e-2)

@@ -102,6 +102,9 @@ if __name__ == "__main__":
     for name, M, N, K, epi in SHAPES:
         line = f"{name} M={M} N={N} K={K} {epi:5s}"
         for t in args.tiles:
+            if t == 7 and epi == "resid":           # the 4-wave kernel takes bf16 outputs without residual only
+                line += " | tile7:      n/a"
+                continue
             us, tf = run(name, M, N, K, epi, t, check=True)
             if name.strip() in ("qkv", "out", "fc", "proj"):
                 tot[t] += us
