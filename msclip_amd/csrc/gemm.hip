@@ -1478,8 +1478,9 @@ static GemmVariant pick_variant(const msclip_gemm_desc* d) {
   const bool big = d->tile >= 2 || (d->tile == 0 && d->N >= 192 && big_tiles >= 128);
   if ((d->tile == 0 || d->tile == 5) && msclip_gemm_small_eligible(d)) return GV_STREAM;
   if (d->tile == 7) return msclip_gemm_w4_eligible(d) ? GV_W4 : GV_INVALID;
-  // bf16 outputs without residual (QKV, c_fc): the 4-wave kernel whose epilogue rides under the next tile's K loop
-  if (d->tile == 0 && big && msclip_gemm_w4_eligible(d)) return GV_W4;
+  // (the 4-wave kernel with the carried epilogue, gemm_w4.hip, is opt-in through tile = 7: its main loop matches the
+  //  ping-pong kernel's (QKV 153 vs 156 us, c_fc 203 vs 203 us in the model step without any epilogue), but with one
+  //  wave per SIMD the epilogue's VALU work has no second wave's issue slots to hide in: 200 / 291 us against 190 / 266)
   if (d->mode == 0) {
     // 256-row tile offsets must fit the 32-bit buffer offsets of the ping-pong kernel's loads
     // ... and tile id x (4 row-tile counts) below 2^32 for the kernel's reciprocal-multiply tile mapping
