@@ -153,6 +153,62 @@ int msclip_lse_rows(const float* logits, int ld, float* lse, int R, int N, void*
 int msclip_clip_loss_partial(const float* lse_img, const float* lse_txt, const float* img_rows, int ld, int label_off,
                              int R, float scale, float* out, void* stream);
 
+/* ---- backward pass of the transformer blocks and the contrastive head (first slice).  The
+ * reference ships no trainer: these differentiate the forward it defines and are pinned against autograd of the
+ * imported reference (tests/golden/b32-yfcc-msclips.grads.npz).  GEMM gradients go through msclip_gemm itself
+ * (dX = dY @ W with the transposed weight as W; dW = dY^T @ X with both operands transposed by
+ * msclip_transpose_bf16). ---- */
+
+/* out[c][m] = in[m][c] (bf16); columns m in [M, Mpad) are zero-filled (Mpad % 64 == 0: the K axis of a wgrad GEMM). */
+int msclip_transpose_bf16(const void* in, int ldi, void* out, int ldo, int M, int C, int Mpad, void* stream);
+
+/* y = bf16(x) for an fp32 matrix (C, ldx, ldy multiples of 4): gradient streams are fp32, GEMM operands bf16. */
+int msclip_cast_bf16(const float* x, int ldx, void* y, int ldy, int M, int C, void* stream);
+
+/* out[n] (+)= sum_m x[m][n] (x bf16 or fp32): bias gradients, LayerNorm parameter gradients' second stage. */
+int msclip_colsum(const void* x, int ld, int is_f32, float* out, int M, int N, int accumulate, void* stream);
+
+/* QuickGELU on a saved pre-activation and its backward (M.py:222-224): y = h sigma(1.702 h);
+ * dh = dy (sigma + 1.702 h sigma (1 - sigma)).  bf16, n % 8 == 0. */
+int msclip_quickgelu(const void* h, void* y, long long n, void* stream);
+int msclip_quickgelu_bwd(const void* h, const void* dy, void* dh, long long n, void* stream);
+
+/* LayerNorm backward (M.py:204-219).  Row m of the op reads x[src(m)], src(m) = row_idx ? row_idx[m] : m * row_mul;
+ * dy [M, C] bf16 or fp32; dx[src(m)] = (or +=) the input gradient.  part (optional) [part_blocks][2][C] receives per-block
+ * partial sums of dgamma (= sum dy * xhat) and dbeta (= sum dy): fold with msclip_colsum.  C in {512, 768}. */
+int msclip_layernorm_bwd(const float* x, int ldx, const int* row_idx, int row_mul, const void* dy, int lddy, int dy_is_f32,
+                         const float* gamma, float* dx, int lddx, int accumulate, float* part, int part_blocks, int M,
+                         int C, float eps, void* stream);
+
+/* Backward of msclip_attention for L <= 96: dqkv [q | k | v gradients] from qkv, the forward output o and its
+ * gradient dout (all bf16, same layouts as the forward). */
+int msclip_attention_bwd(const void* qkv, const void* o, const void* dout, void* dqkv, int nsamples, int L, int heads,
+                         int ldq, int ldo, int causal, void* stream);
+
+/* dx = (dy - y (y . dy)) / ||x||,  y = x / ||x||   (M.py:2983, :3076). */
+int msclip_l2norm_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, int M, int E, void* stream);
+
+/* dL/dS of the symmetric cross-entropy on this rank's row block: G[r][j] = w (exp(S - lse_row[r]) + exp(S - lse_col[j])
+ * - 2 [j == label_off + r]), S [R, N] fp32 = scale * A_loc @ B_all^T, w = 1 / (2 N_global); G bf16 [R, ldg] with columns
+ * [N, Npad) zeroed; dscale_part[r] = sum_j G S (optional). */
+int msclip_clip_loss_bwd_g(const float* S, int lds, const float* lse_row, const float* lse_col, int label_off, float w,
+                           void* G, int ldg, float* dscale_part, int R, int N, int Npad, void* stream);
+
+/* Token + positional embedding backward (M.py:3047-3048): dEmb[token] += dx row (fp32 atomics), dPos[l] += dx row. */
+int msclip_embed_tokens_bwd(const long long* tokens, const float* dx, int lddx, float* demb, float* dpos, int B, int L,
+                            int C, int vocab, void* stream);
+
+/* Lateral adapter (M.py:1752-1778): the pre-LayerNorm sum [cls; BN(dw3x3(grid))] + [usecls * cls; t] (saved by the
+ * training forward) and the gradient wrt the incoming tokens from the gradient of that sum. */
+int msclip_adapter_sum(const float* xin, int ldx, const float* t, int ldt, const float* dww, const float* dwb, float* out,
+                       int ldo, int B, int L, int g, int C, int usecls, void* stream);
+int msclip_adapter_dx(const float* dsum, int lds, const float* dww, float* dx, int lddx, int B, int L, int g, int C,
+                      int usecls, void* stream);
+
+/* AdamW with decoupled weight decay on one fp32 tensor (step >= 1 for the bias corrections). */
+int msclip_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                 float weight_decay, int step, void* stream);
+
 /* Library / device introspection (no GPU work). */
 int msclip_abi_version(void);
 const char* msclip_build_arch(void);

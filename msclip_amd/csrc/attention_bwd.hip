@@ -1,0 +1,195 @@
+// Backward of the fused softmax(q k^T [+ causal]) v attention (forward: attention.hip; reference M.py:707-738) for
+// sequences up to 96 tokens (the 50-token image grid of ViT-B/32 and the 77-token captions): one workgroup of 4 waves
+// per (sample, head), everything of that head resident in LDS, all five contractions on v_mfma_f32_16x16x32_bf16.
+//
+//   S  = Q K^T (q pre-scaled by the packed in_proj weight),  P = softmax(S),  O = P V            (recomputed / given)
+//   dV = P^T dO      dP = dO V^T      dS = P o (dP - delta),  delta_q = sum_d dO[q][d] O[q][d]
+//   dQ = dS K        dK = dS^T Q
+//
+// The MFMA computes D[i][j] = sum_k A[i][k] B[j][k] from two K-contiguous row operands, lane (j = lane % 16,
+// quad = lane / 16) holding D[4*quad + r][j].  So S, dP are formed TRANSPOSED (A = K / V rows, B = Q / dO rows): a lane
+// owns one query and 4 keys per tile, the softmax statistics of a query are an in-lane reduction plus two quad
+// exchanges, and dS^T = P^T o (dP^T - delta) is element-wise in registers.  The three gradients contract over tokens,
+// so their operands are the TRANSPOSED tensors: Q^T, K^T, dO^T are built while loading, P^T / dS / dS^T are written to
+// LDS from the accumulator layout; the outputs come out as dV^T, dK^T, dQ^T tiles, i.e. 4 consecutive head-dim elements
+// per lane and token: 8-byte global stores.
+#include "common.h"
+#include "../../include/msclip_hip.h"
+
+namespace {
+
+constexpr int RS = 72;                      // row stride (elements) of the [token][64] images: 144 B, 16-B aligned
+
+template <int NT16, bool CAUSAL>            // NT16 = padded length / 16 (4: 64 tokens, 6: 96 tokens)
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+                                                       const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqkv, int L,
+                                                       int H, int ldq, int ldo) {
+  constexpr int LP = NT16 * 16, LS = LP + 8;          // padded length, row stride of the [..][token] images
+  extern __shared__ __attribute__((aligned(16))) bf16_t sm[];
+  bf16_t* Q = sm;                                      // [LP][RS]
+  bf16_t* K = Q + LP * RS;
+  bf16_t* V = K + LP * RS;
+  bf16_t* dO = V + LP * RS;
+  bf16_t* QT = dO + LP * RS;                           // [64][LS]
+  bf16_t* KT = QT + 64 * LS;
+  bf16_t* dOT = KT + 64 * LS;
+  bf16_t* PT = dOT + 64 * LS;                          // [key][query]   (LP x LS)
+  bf16_t* dS = PT + LP * LS;                           // [query][key]
+  bf16_t* dST = dS + LP * LS;                          // [key][query]
+  float* delta = (float*)(dST + LP * LS);              // [LP]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const size_t row0 = (size_t)b * L;
+  const bf16_t* qb = qkv + row0 * ldq + h * 64;
+  const bf16_t* ob = o + row0 * ldo + h * 64;
+  const bf16_t* db = dout + row0 * ldo + h * 64;
+
+  // ---- load: thread -> (token r, 16-byte chunk c); row-major and transposed images, delta
+  for (int idx = tid; idx < LP * 8; idx += 256) {
+    const int r = idx >> 3, c = idx & 7;
+    uint4 q4 = make_uint4(0, 0, 0, 0), k4 = q4, v4 = q4, d4 = q4, o4 = q4;
+    if (r < L) {
+      q4 = *(const uint4*)(qb + (size_t)r * ldq + c * 8);
+      k4 = *(const uint4*)(qb + (size_t)r * ldq + H * 64 + c * 8);
+      v4 = *(const uint4*)(qb + (size_t)r * ldq + 2 * H * 64 + c * 8);
+      d4 = *(const uint4*)(db + (size_t)r * ldo + c * 8);
+      o4 = *(const uint4*)(ob + (size_t)r * ldo + c * 8);
+    }
+    *(uint4*)(Q + r * RS + c * 8) = q4;
+    *(uint4*)(K + r * RS + c * 8) = k4;
+    *(uint4*)(V + r * RS + c * 8) = v4;
+    *(uint4*)(dO + r * RS + c * 8) = d4;
+    const unsigned qw[4] = {q4.x, q4.y, q4.z, q4.w}, kw[4] = {k4.x, k4.y, k4.z, k4.w}, dw[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      QT[(c * 8 + 2 * e) * LS + r] = (bf16_t)(qw[e] & 0xffff);
+      QT[(c * 8 + 2 * e + 1) * LS + r] = (bf16_t)(qw[e] >> 16);
+      KT[(c * 8 + 2 * e) * LS + r] = (bf16_t)(kw[e] & 0xffff);
+      KT[(c * 8 + 2 * e + 1) * LS + r] = (bf16_t)(kw[e] >> 16);
+      dOT[(c * 8 + 2 * e) * LS + r] = (bf16_t)(dw[e] & 0xffff);
+      dOT[(c * 8 + 2 * e + 1) * LS + r] = (bf16_t)(dw[e] >> 16);
+    }
+    float fd[8], fo[8];
+    unpack_bf16x8(d4, fd);
+    unpack_bf16x8(o4, fo);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += fd[e] * fo[e];
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    if (c == 0) delta[r] = s;
+  }
+  // zero the padding columns [LP, LS) of the token-contiguous images is unnecessary: k-steps never read past LP.
+  __syncthreads();
+
+  const int r16 = lane & 15, quad = lane >> 4;
+  auto mma = [&](f32x4 acc, const bf16_t* pa, int sa, const bf16_t* pb, int sb, int ksteps) {
+    for (int ks = 0; ks < ksteps; ++ks) {
+      const bf16x8 a = *(const bf16x8*)(pa + r16 * sa + ks * 32 + quad * 8);
+      const bf16x8 bb = *(const bf16x8*)(pb + r16 * sb + ks * 32 + quad * 8);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bb, acc, 0, 0, 0);
+    }
+    return acc;
+  };
+
+  // ---- phase 1: per 16-query tile: S^T, softmax over keys, dP^T, dS^T -> P^T, dS, dS^T in LDS
+  for (int qt = wave; qt < NT16; qt += 4) {
+    const int query = qt * 16 + r16;
+    f32x4 st[NT16];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NT16; ++kt) {
+      st[kt] = mma(f32x4{0.f, 0.f, 0.f, 0.f}, K + kt * 16 * RS, RS, Q + qt * 16 * RS, RS, 2);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt * 16 + quad * 4 + r;
+        const bool ok = key < L && (!CAUSAL || key <= query);
+        st[kt][r] = ok ? st[kt][r] : -INFINITY;
+        mx = fmaxf(mx, st[kt][r]);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (mx == -INFINITY) mx = 0.f;                               // padded query row: every key masked
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT16; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        st[kt][r] = __expf(st[kt][r] - mx);
+        sum += st[kt][r];
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = sum > 0.f ? 1.f / sum : 0.f;
+    const float dl = delta[query];
+#pragma unroll
+    for (int kt = 0; kt < NT16; ++kt) {
+      const f32x4 dp = mma(f32x4{0.f, 0.f, 0.f, 0.f}, V + kt * 16 * RS, RS, dO + qt * 16 * RS, RS, 2);
+      float ds[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = st[kt][r] * inv;
+        ds[r] = p * (dp[r] - dl);
+        const int key = kt * 16 + quad * 4 + r;
+        PT[key * LS + query] = f32_to_bf16(p);
+        dST[key * LS + query] = f32_to_bf16(ds[r]);
+      }
+      uint2 u;
+      u.x = pack_bf16x2(ds[0], ds[1]);
+      u.y = pack_bf16x2(ds[2], ds[3]);
+      *(uint2*)(dS + query * LS + kt * 16 + quad * 4) = u;
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: dV^T = dO^T-rows x P^T-rows (over queries), dK^T = Q^T x dS^T (over queries), dQ^T = K^T x dS (over keys)
+  bf16_t* gb = dqkv + row0 * ldq + h * 64;
+  for (int t = wave; t < 3 * 4 * NT16; t += 4) {
+    const int which = t / (4 * NT16), rem = t - which * 4 * NT16;
+    const int dt = rem / NT16, tt = rem - dt * NT16;            // head-dim tile, token tile
+    const bf16_t* pa = which == 0 ? dOT : (which == 1 ? QT : KT);
+    const bf16_t* pb = which == 0 ? PT : (which == 1 ? dST : dS);
+    const f32x4 acc = mma(f32x4{0.f, 0.f, 0.f, 0.f}, pa + dt * 16 * LS, LS, pb + tt * 16 * LS, LS, LP / 32);
+    const int tok = tt * 16 + r16;
+    if (tok < L) {
+      uint2 u;
+      u.x = pack_bf16x2(acc[0], acc[1]);
+      u.y = pack_bf16x2(acc[2], acc[3]);
+      const int col = (which == 0 ? 2 * H * 64 : (which == 1 ? H * 64 : 0)) + dt * 16 + quad * 4;
+      *(uint2*)(gb + (size_t)tok * ldq + col) = u;
+    }
+  }
+}
+
+template <int NT16, bool CAUSAL>
+int launch_bwd(const void* qkv, const void* o, const void* dout, void* dqkv, int nsamples, int L, int H, int ldq, int ldo,
+               hipStream_t st) {
+  constexpr int LP = NT16 * 16, LS = LP + 8;
+  const size_t lds = (size_t)(4 * LP * RS + 3 * 64 * LS + 3 * LP * LS) * 2 + LP * 4;
+  static bool done = false;
+  if (!done && lds > 65536) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<NT16, CAUSAL>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    done = true;
+  }
+  hipLaunchKernelGGL((attn_bwd_kernel<NT16, CAUSAL>), dim3(nsamples * H), dim3(256), lds, st, (const bf16_t*)qkv,
+                     (const bf16_t*)o, (const bf16_t*)dout, (bf16_t*)dqkv, L, H, ldq, ldo);
+  return msclip_launch_status();
+}
+
+}  // namespace
+
+extern "C" int msclip_attention_bwd(const void* qkv, const void* o, const void* dout, void* dqkv, int nsamples, int L,
+                                    int heads, int ldq, int ldo, int causal, void* stream) {
+  if (!qkv || !o || !dout || !dqkv || nsamples <= 0 || L <= 0 || L > 96 || heads <= 0 || (ldq % 8) || (ldo % 8))
+    return MSCLIP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (L <= 64) return causal ? launch_bwd<4, true>(qkv, o, dout, dqkv, nsamples, L, heads, ldq, ldo, st)
+                             : launch_bwd<4, false>(qkv, o, dout, dqkv, nsamples, L, heads, ldq, ldo, st);
+  return causal ? launch_bwd<6, true>(qkv, o, dout, dqkv, nsamples, L, heads, ldq, ldo, st)
+                : launch_bwd<6, false>(qkv, o, dout, dqkv, nsamples, L, heads, ldq, ldo, st);
+}

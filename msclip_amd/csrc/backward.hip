@@ -1,0 +1,434 @@
+// Backward-pass kernels of the transformer blocks and the contrastive head (first slice).
+//
+// The reference release has no trainer; what these kernels differentiate is the forward the reference defines
+// (M.py = lib/models/clip_openai_pe_res_v1.py) plus the symmetric cross-entropy this build adds, and they are pinned
+// against autograd of the imported reference (tests/golden/*.grads.npz).  GEMM gradients reuse msclip_gemm:
+//   dX = dY @ W        -> msclip_gemm(X = dY, W = W^T)          (W^T packed by the host once per step)
+//   dW = dY^T @ X      -> msclip_gemm(X = dY^T, W = X^T)        (both transposed by msclip_transpose_bf16: the
+//                          contraction runs over the token rows, which must be the contiguous axis of both operands)
+// The shared attention / MLP tensors (M.py:2808-2830) get the SUM of both towers' gradients for free: the towers'
+// tokens are rows of one matrix, so one wgrad GEMM contracts over image and text rows together.
+// Everything here is HBM-bound elementwise / reduction work: 16-byte accesses, one wave per row where a row reduction
+// is needed, fp32 statistics and accumulation, bf16 only for tensors that feed an MFMA GEMM.
+#include "common.h"
+#include "../../include/msclip_hip.h"
+
+namespace {
+
+__device__ __forceinline__ float sigmoidf_fast(float z) { return 1.f / (1.f + __expf(-z)); }
+
+// ---- out[c][m] = in[m][c] (bf16), columns m in [M, Mpad) zero-filled: the K-contiguous operand of a wgrad GEMM.
+// 64 x 64 tiles through LDS (padded rows: conflict-free both ways).
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ in, int ldi, bf16_t* __restrict__ out,
+                                                        int ldo, int M, int C, int Mpad) {
+  __shared__ bf16_t tile[64][66];
+  const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {
+    const int m = m0 + r, c = c0 + tx;
+    tile[r][tx] = (m < M && c < C) ? in[(size_t)m * ldi + c] : (bf16_t)0;
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {
+    const int c = c0 + r, m = m0 + tx;
+    if (c < C && m < Mpad) out[(size_t)c * ldo + m] = tile[tx][r];
+  }
+}
+
+// ---- out[n] (+)= sum_m x[m][n]: bias gradients and the second stage of the LayerNorm parameter gradients.
+// One block per 64 columns; 4 waves stride the rows, lanes own columns; fixed summation order (deterministic).
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int ld, float* __restrict__ out, int M, int N,
+                                                     int accumulate) {
+  __shared__ float part[4][64];
+  const int n = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+  float s = 0.f;
+  if (n < N) {
+    for (int m = w; m < M; m += 4) {
+      if constexpr (sizeof(T) == 2) s += bf16_to_f32(x[(size_t)m * ld + n]);
+      else s += x[(size_t)m * ld + n];
+    }
+  }
+  part[w][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (w == 0 && n < N) {
+    const float t = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+    out[n] = accumulate ? out[n] + t : t;
+  }
+}
+
+// ---- fp32 -> bf16 copy of a gradient matrix (the operand of its dgrad / wgrad GEMMs).
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ x, int ldx, bf16_t* __restrict__ y, int ldy, int M,
+                                                   int C4) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)M * C4; i += (size_t)gridDim.x * 256) {
+    const size_t m = i / C4;
+    const int c = (int)(i - m * C4) * 4;
+    const float4 v = *(const float4*)(x + m * ldx + c);
+    uint2 o;
+    o.x = pack_bf16x2(v.x, v.y);
+    o.y = pack_bf16x2(v.z, v.w);
+    *(uint2*)(y + m * ldy + c) = o;
+  }
+}
+
+// ---- QuickGELU forward on a saved pre-activation (training keeps h for the backward) and its backward:
+// y = h * sigma(1.702 h)  (M.py:222-224);  dh = dy * (sigma + 1.702 h sigma (1 - sigma)).
+__global__ __launch_bounds__(256) void quickgelu_kernel(const bf16_t* __restrict__ h, bf16_t* __restrict__ y, size_t n8) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    const uint4 u = ((const uint4*)h)[i];
+    float f[8];
+    unpack_bf16x8(u, f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = f[k] * sigmoidf_fast(1.702f * f[k]);
+    uint4 o;
+    o.x = pack_bf16x2(f[0], f[1]); o.y = pack_bf16x2(f[2], f[3]); o.z = pack_bf16x2(f[4], f[5]); o.w = pack_bf16x2(f[6], f[7]);
+    ((uint4*)y)[i] = o;
+  }
+}
+__global__ __launch_bounds__(256) void quickgelu_bwd_kernel(const bf16_t* __restrict__ h, const bf16_t* __restrict__ dy,
+                                                            bf16_t* __restrict__ dh, size_t n8) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    const uint4 uh = ((const uint4*)h)[i], ud = ((const uint4*)dy)[i];
+    float fh[8], fd[8];
+    unpack_bf16x8(uh, fh);
+    unpack_bf16x8(ud, fd);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float s = sigmoidf_fast(1.702f * fh[k]);
+      fd[k] = fd[k] * (s + 1.702f * fh[k] * s * (1.f - s));
+    }
+    uint4 o;
+    o.x = pack_bf16x2(fd[0], fd[1]); o.y = pack_bf16x2(fd[2], fd[3]); o.z = pack_bf16x2(fd[4], fd[5]); o.w = pack_bf16x2(fd[6], fd[7]);
+    ((uint4*)dh)[i] = o;
+  }
+}
+
+// ---- LayerNorm backward (TF-style LN of M.py:204-219: biased variance, eps inside the sqrt, fp32 statistics).
+// One wave per row, C = 64 * V4 * 4 (768 -> V4 = 3, 512 -> 2).  x row m comes from x[src(m)], src(m) = row_idx ? row_idx[m]
+// : m * row_mul (the cls / EOT gathers of the heads); dy is bf16 or fp32 [M, C]; the result goes to dx[src(m)]
+// (overwrite or +=).  dgamma / dbeta: every block accumulates its rows in registers and writes ONE partial row
+// part[blockIdx][2][C]; msclip_colsum folds the partials (deterministic).  bf16 copy of dx optional (the operand of the
+// next wgrad / dgrad GEMM when the residual gradient stream itself is what feeds it).
+template <int V4, typename TDY>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, int ldx, const int* __restrict__ row_idx,
+                                                     int row_mul, const TDY* __restrict__ dy, int lddy,
+                                                     const float* __restrict__ gamma, float* __restrict__ dx, int lddx,
+                                                     int accumulate, float* __restrict__ part, int M, float eps) {
+  constexpr int C = 256 * V4;
+  __shared__ float red[4][2][C];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float4 g[V4], dg[V4], db[V4];
+#pragma unroll
+  for (int v = 0; v < V4; ++v) {
+    g[v] = *(const float4*)(gamma + v * 256 + lane * 4);
+    dg[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    db[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int m = blockIdx.x * 4 + wave; m < M; m += gridDim.x * 4) {
+    const size_t src = row_idx ? (size_t)row_idx[m] : (size_t)m * row_mul;
+    float4 xv[V4], dv[V4];
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < V4; ++v) {
+      xv[v] = *(const float4*)(x + src * ldx + v * 256 + lane * 4);
+      s += xv[v].x + xv[v].y + xv[v].z + xv[v].w;
+      if constexpr (sizeof(TDY) == 2) {
+        const uint2 u = *(const uint2*)((const bf16_t*)dy + (size_t)m * lddy + v * 256 + lane * 4);
+        dv[v] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                            __uint_as_float(u.y & 0xffff0000u));
+      } else {
+        dv[v] = *(const float4*)((const float*)dy + (size_t)m * lddy + v * 256 + lane * 4);
+      }
+    }
+    const float mu = wave_sum(s) * (1.f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int v = 0; v < V4; ++v) {
+      xv[v].x -= mu; xv[v].y -= mu; xv[v].z -= mu; xv[v].w -= mu;
+      q += xv[v].x * xv[v].x + xv[v].y * xv[v].y + xv[v].z * xv[v].z + xv[v].w * xv[v].w;
+    }
+    const float rstd = rsqrtf(wave_sum(q) * (1.f / C) + eps);
+    float a = 0.f, b = 0.f;                          // sum(dxhat), sum(dxhat * xhat)
+#pragma unroll
+    for (int v = 0; v < V4; ++v) {
+      xv[v].x *= rstd; xv[v].y *= rstd; xv[v].z *= rstd; xv[v].w *= rstd;      // xhat
+      dg[v].x += dv[v].x * xv[v].x; dg[v].y += dv[v].y * xv[v].y; dg[v].z += dv[v].z * xv[v].z; dg[v].w += dv[v].w * xv[v].w;
+      db[v].x += dv[v].x; db[v].y += dv[v].y; db[v].z += dv[v].z; db[v].w += dv[v].w;
+      dv[v].x *= g[v].x; dv[v].y *= g[v].y; dv[v].z *= g[v].z; dv[v].w *= g[v].w;   // dxhat
+      a += dv[v].x + dv[v].y + dv[v].z + dv[v].w;
+      b += dv[v].x * xv[v].x + dv[v].y * xv[v].y + dv[v].z * xv[v].z + dv[v].w * xv[v].w;
+    }
+    a = wave_sum(a) * (1.f / C);
+    b = wave_sum(b) * (1.f / C);
+#pragma unroll
+    for (int v = 0; v < V4; ++v) {
+      float4 r;
+      r.x = rstd * (dv[v].x - a - xv[v].x * b); r.y = rstd * (dv[v].y - a - xv[v].y * b);
+      r.z = rstd * (dv[v].z - a - xv[v].z * b); r.w = rstd * (dv[v].w - a - xv[v].w * b);
+      float4* dst = (float4*)(dx + src * lddx + v * 256 + lane * 4);
+      if (accumulate) {
+        const float4 o = *dst;
+        r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w;
+      }
+      *dst = r;
+    }
+  }
+  if (part) {
+#pragma unroll
+    for (int v = 0; v < V4; ++v) {
+      *(float4*)&red[wave][0][v * 256 + lane * 4] = dg[v];
+      *(float4*)&red[wave][1][v * 256 + lane * 4] = db[v];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+      const int which = i / C, c = i - which * C;
+      part[((size_t)blockIdx.x * 2 + which) * C + c] = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+    }
+  }
+}
+
+// ---- y = x / ||x||  backward:  dx = (dy - y (y . dy)) / ||x||   (M.py:2983, :3076).  One wave per row.
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dy,
+                                                         int lddy, float* __restrict__ dx, int lddx, int M, int E) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = blockIdx.x * 4 + wave;
+  if (m >= M) return;
+  float nn = 0.f, dot = 0.f;
+  for (int e = lane; e < E; e += 64) {
+    const float xv = x[(size_t)m * ldx + e];
+    nn += xv * xv;
+    dot += xv * dy[(size_t)m * lddy + e];
+  }
+  nn = wave_sum(nn);
+  dot = wave_sum(dot);
+  const float inv = rsqrtf(nn);
+  for (int e = lane; e < E; e += 64) {
+    const float xv = x[(size_t)m * ldx + e];
+    dx[(size_t)m * lddx + e] = inv * (dy[(size_t)m * lddy + e] - xv * dot * inv * inv);
+  }
+}
+
+// ---- contrastive head backward, elementwise part.  S [R, N] = scale * A_loc @ B_all^T (fp32, from msclip_gemm);
+// G[r][j] = w * (exp(S - lse_row[r]) + exp(S - lse_col[j]) - 2 [j == label_off + r]),  w = 1 / (2 N_global):
+// dL/dS of the symmetric cross-entropy restricted to this rank's rows (rank-major labels, reference
+// lib/utils/comm.py:150-153).  G is written as bf16 (operand of the dA = scale * G @ B_all GEMM); dscale_part[r] =
+// sum_j G[r][j] * S[r][j] (its sum over r and ranks, divided by scale, is dL/dscale).  One wave per row.
+__global__ __launch_bounds__(256) void clip_g_kernel(const float* __restrict__ S, int lds, const float* __restrict__ lse_row,
+                                                     const float* __restrict__ lse_col, int label_off, float w,
+                                                     bf16_t* __restrict__ G, int ldg, float* __restrict__ dscale_part, int R,
+                                                     int N, int Npad) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= R) return;
+  const float lr = lse_row[r];
+  const int label = label_off + r;
+  float acc = 0.f;
+  for (int j = lane; j < Npad; j += 64) {
+    float g = 0.f;
+    if (j < N) {
+      const float s = S[(size_t)r * lds + j];
+      g = w * (__expf(s - lr) + __expf(s - lse_col[j]) - (j == label ? 2.f : 0.f));
+      acc += g * s;
+    }
+    G[(size_t)r * ldg + j] = f32_to_bf16(g);
+  }
+  acc = wave_sum(acc);
+  if (dscale_part && lane == 0) dscale_part[r] = acc;
+}
+
+// ---- token embedding + positional embedding backward (M.py:3047-3048): dX rows of the text tokens scatter-add into
+// dEmb[token] (fp32 atomics: captions share ids, padding id 0 above all) and sum over the batch into dPos[l].
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* __restrict__ tokens, const float* __restrict__ dx,
+                                                        int lddx, float* __restrict__ demb, float* __restrict__ dpos, int B,
+                                                        int L, int C, int vocab) {
+  const int row = blockIdx.x;                        // b * L + l
+  const int l = row % L;
+  long long t = tokens[row];
+  t = t < 0 ? 0 : (t >= vocab ? vocab - 1 : t);
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float v = dx[(size_t)row * lddx + c];
+    atomicAdd(demb + (size_t)t * C + c, v);
+    atomicAdd(dpos + (size_t)l * C + c, v);
+  }
+}
+
+// ---- lateral adapter (M.py:1752-1778), the pieces the backward needs.
+// adapter_sum: pre-LayerNorm sum  [cls; BN(dw3x3(grid))] + [cls * usecls; t]  (fp32 [B*L, C]), saved by the training
+// forward;  adapter_dx: gradient wrt the incoming tokens from the gradient of that sum: cls row (1 + usecls) * d[0],
+// grid rows = transposed depthwise 3x3 (BN scale folded in dww, as in the forward).  One block per token, lanes = channels.
+__global__ __launch_bounds__(256) void adapter_sum_kernel(const float* __restrict__ xin, int ldx, const float* __restrict__ t,
+                                                          int ldt, const float* __restrict__ dww, const float* __restrict__ dwb,
+                                                          float* __restrict__ out, int ldo, int B, int L, int g, int C,
+                                                          int usecls) {
+  const int row = blockIdx.x, b = row / L, p = row - b * L;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float v;
+    if (p == 0) {
+      v = xin[(size_t)row * ldx + c] * (usecls ? 2.f : 1.f);
+    } else {
+      const int py = (p - 1) / g, px = (p - 1) - py * g;
+      float a = dwb[c];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int yy = py + ky - 1, xx = px + kx - 1;
+          if (yy >= 0 && yy < g && xx >= 0 && xx < g)
+            a += dww[(ky * 3 + kx) * C + c] * xin[((size_t)b * L + 1 + yy * g + xx) * ldx + c];
+        }
+      v = a + t[((size_t)b * g * g + (p - 1)) * ldt + c];
+    }
+    out[(size_t)row * ldo + c] = v;
+  }
+}
+__global__ __launch_bounds__(256) void adapter_dx_kernel(const float* __restrict__ dsum, int lds, const float* __restrict__ dww,
+                                                         float* __restrict__ dx, int lddx, int B, int L, int g, int C,
+                                                         int usecls) {
+  const int row = blockIdx.x, b = row / L, p = row - b * L;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float v;
+    if (p == 0) {
+      v = dsum[(size_t)row * lds + c] * (usecls ? 2.f : 1.f);
+    } else {
+      const int py = (p - 1) / g, px = (p - 1) - py * g;
+      v = 0.f;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int yy = py - (ky - 1), xx = px - (kx - 1);         // output pixel that saw this one through tap (ky, kx)
+          if (yy >= 0 && yy < g && xx >= 0 && xx < g)
+            v += dww[(ky * 3 + kx) * C + c] * dsum[((size_t)b * L + 1 + yy * g + xx) * lds + c];
+        }
+    }
+    dx[(size_t)row * lddx + c] = v;
+  }
+}
+
+// ---- AdamW (decoupled weight decay), one fused pass per parameter tensor; fp32 states.
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps,
+                                                    float wd, float c1, float c2) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float pi = p[i];
+    p[i] = pi - lr * (mi * c1 / (sqrtf(vi * c2) + eps) + wd * pi);
+  }
+}
+
+}  // namespace
+
+static int grid_for(size_t n, int per_block, int cap = 4096) {
+  size_t b = (n + per_block - 1) / per_block;
+  return (int)(b < 1 ? 1 : (b > (size_t)cap ? cap : b));
+}
+
+extern "C" int msclip_transpose_bf16(const void* in, int ldi, void* out, int ldo, int M, int C, int Mpad, void* stream) {
+  if (!in || !out || M <= 0 || C <= 0 || Mpad < M || ldo < Mpad || ldi < C) return MSCLIP_EINVAL;
+  hipLaunchKernelGGL(transpose_kernel, dim3((Mpad + 63) / 64, (C + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)in, ldi, (bf16_t*)out, ldo, M, C, Mpad);
+  return msclip_launch_status();
+}
+
+extern "C" int msclip_cast_bf16(const float* x, int ldx, void* y, int ldy, int M, int C, void* stream) {
+  if (!x || !y || M <= 0 || C <= 0 || (C & 3) || (ldx & 3) || (ldy & 3)) return MSCLIP_EINVAL;
+  hipLaunchKernelGGL(cast_kernel, dim3(grid_for((size_t)M * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                     (bf16_t*)y, ldy, M, C / 4);
+  return msclip_launch_status();
+}
+
+extern "C" int msclip_colsum(const void* x, int ld, int is_f32, float* out, int M, int N, int accumulate, void* stream) {
+  if (!x || !out || M <= 0 || N <= 0 || ld < N) return MSCLIP_EINVAL;
+  if (is_f32)
+    hipLaunchKernelGGL(colsum_kernel<float>, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const float*)x, ld, out,
+                       M, N, accumulate);
+  else
+    hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld,
+                       out, M, N, accumulate);
+  return msclip_launch_status();
+}
+
+extern "C" int msclip_quickgelu(const void* h, void* y, long long n, void* stream) {
+  if (!h || !y || n <= 0 || (n & 7)) return MSCLIP_EINVAL;
+  hipLaunchKernelGGL(quickgelu_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h,
+                     (bf16_t*)y, (size_t)(n / 8));
+  return msclip_launch_status();
+}
+
+extern "C" int msclip_quickgelu_bwd(const void* h, const void* dy, void* dh, long long n, void* stream) {
+  if (!h || !dy || !dh || n <= 0 || (n & 7)) return MSCLIP_EINVAL;
+  hipLaunchKernelGGL(quickgelu_bwd_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h,
+                     (const bf16_t*)dy, (bf16_t*)dh, (size_t)(n / 8));
+  return msclip_launch_status();
+}
+
+extern "C" int msclip_layernorm_bwd(const float* x, int ldx, const int* row_idx, int row_mul, const void* dy, int lddy,
+                                    int dy_is_f32, const float* gamma, float* dx, int lddx, int accumulate, float* part,
+                                    int part_blocks, int M, int C, float eps, void* stream) {
+  if (!x || !dy || !gamma || !dx || M <= 0 || (C != 512 && C != 768) || part_blocks < 1) return MSCLIP_EINVAL;
+  int blocks = (M + 3) / 4;
+  if (blocks > part_blocks) blocks = part_blocks;
+  if (part && blocks < part_blocks) {                // unused partial rows must not hold garbage
+    if (hipMemsetAsync(part + (size_t)blocks * 2 * C, 0, (size_t)(part_blocks - blocks) * 2 * C * sizeof(float),
+                       (hipStream_t)stream) != hipSuccess) return MSCLIP_ELAUNCH;
+  }
+  hipStream_t st = (hipStream_t)stream;
+#define LNB(V4, T) hipLaunchKernelGGL((ln_bwd_kernel<V4, T>), dim3(blocks), dim3(256), 0, st, x, ldx, row_idx, row_mul, \
+                                      (const T*)dy, lddy, gamma, dx, lddx, accumulate, part, M, eps)
+  if (C == 768) { if (dy_is_f32) LNB(3, float); else LNB(3, bf16_t); }
+  else { if (dy_is_f32) LNB(2, float); else LNB(2, bf16_t); }
+#undef LNB
+  return msclip_launch_status();
+}
+
+extern "C" int msclip_l2norm_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, int M, int E,
+                                 void* stream) {
+  if (!x || !dy || !dx || M <= 0 || E <= 0) return MSCLIP_EINVAL;
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, dy, lddy, dx, lddx, M, E);
+  return msclip_launch_status();
+}
+
+extern "C" int msclip_clip_loss_bwd_g(const float* S, int lds, const float* lse_row, const float* lse_col, int label_off,
+                                      float w, void* G, int ldg, float* dscale_part, int R, int N, int Npad, void* stream) {
+  if (!S || !lse_row || !lse_col || !G || R <= 0 || N <= 0 || Npad < N || ldg < Npad || lds < N) return MSCLIP_EINVAL;
+  hipLaunchKernelGGL(clip_g_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, S, lds, lse_row, lse_col, label_off,
+                     w, (bf16_t*)G, ldg, dscale_part, R, N, Npad);
+  return msclip_launch_status();
+}
+
+extern "C" int msclip_embed_tokens_bwd(const long long* tokens, const float* dx, int lddx, float* demb, float* dpos, int B,
+                                       int L, int C, int vocab, void* stream) {
+  if (!tokens || !dx || !demb || !dpos || B <= 0 || L <= 0 || C <= 0) return MSCLIP_EINVAL;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(B * L), dim3(256), 0, (hipStream_t)stream, tokens, dx, lddx, demb, dpos, B, L, C,
+                     vocab);
+  return msclip_launch_status();
+}
+
+extern "C" int msclip_adapter_sum(const float* xin, int ldx, const float* t, int ldt, const float* dww, const float* dwb,
+                                  float* out, int ldo, int B, int L, int g, int C, int usecls, void* stream) {
+  if (!xin || !t || !dww || !dwb || !out || B <= 0 || L != g * g + 1) return MSCLIP_EINVAL;
+  hipLaunchKernelGGL(adapter_sum_kernel, dim3(B * L), dim3(256), 0, (hipStream_t)stream, xin, ldx, t, ldt, dww, dwb, out, ldo,
+                     B, L, g, C, usecls);
+  return msclip_launch_status();
+}
+
+extern "C" int msclip_adapter_dx(const float* dsum, int lds, const float* dww, float* dx, int lddx, int B, int L, int g, int C,
+                                 int usecls, void* stream) {
+  if (!dsum || !dww || !dx || B <= 0 || L != g * g + 1) return MSCLIP_EINVAL;
+  hipLaunchKernelGGL(adapter_dx_kernel, dim3(B * L), dim3(256), 0, (hipStream_t)stream, dsum, lds, dww, dx, lddx, B, L, g, C,
+                     usecls);
+  return msclip_launch_status();
+}
+
+extern "C" int msclip_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                            float eps, float weight_decay, int step, void* stream) {
+  if (!p || !g || !m || !v || n <= 0 || step < 1) return MSCLIP_EINVAL;
+  const float c1 = 1.f / (1.f - powf(beta1, (float)step)), c2 = 1.f / (1.f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((size_t)n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (size_t)n, lr,
+                     beta1, beta2, eps, weight_decay, c1, c2);
+  return msclip_launch_status();
+}

@@ -243,7 +243,7 @@ class Engine:
         if taps is not None:
             taps[name] = t[:n * L].view(n, L, -1).float().clone()                            # batch-first [B, L, C]
 
-    def _vision_front(self, img, w, Bi, taps=None):
+    def _vision_front(self, img, w, Bi, taps=None, keep_pre=None):
         """Stem + tokenisation (M.py:2416-2426) and stage 0 of the parallel branch (M.py:2436)."""
         first = self.stem_specs[0]
         fused = (self.dual_w.shape[1] == 96 and self._fusable_3x3s2(first) and not hip.env_flag("MSCLIP_FRONT_UNFUSED")
@@ -270,6 +270,8 @@ class Engine:
         hip.gemm(x, self.w_last, w["X"], M=Bi * g2, resid=self.vpos, resid_kind=hip.RESID_TABLE, rpg=g2, radd=1, roff=1)
         hip.fill_cls(self.cls, self.vpos, w["X"], Bi, self.Lv)
         xv = w["X"][:w["Mv"]]
+        if keep_pre is not None:
+            keep_pre.append(xv.clone())                     # tokens before ln_pre (the training step's backward needs them)
         hip.layernorm(xv, self.ln_pre.g, self.ln_pre.b, xv, w["Mv"])
         self._tap_tokens(taps, "tokens_ln_pre", xv, Bi, self.Lv)
 

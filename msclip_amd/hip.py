@@ -20,6 +20,9 @@ EXPORTS = (
     "msclip_adapter_combine_ln", "msclip_l2norm", "msclip_stem_conv3x3s2_dual", "msclip_dwpool",
     "msclip_stem_dual_conv3x3s2", "msclip_conv1x1_conv3x3s2", "msclip_convresblock48_s2",
     "msclip_lse_rows", "msclip_clip_loss_partial", "msclip_clip_lse_fused", "msclip_clip_loss_from_partials",
+    "msclip_transpose_bf16", "msclip_cast_bf16", "msclip_colsum", "msclip_quickgelu", "msclip_quickgelu_bwd", "msclip_layernorm_bwd",
+    "msclip_attention_bwd", "msclip_l2norm_bwd", "msclip_clip_loss_bwd_g", "msclip_embed_tokens_bwd", "msclip_adapter_sum",
+    "msclip_adapter_dx", "msclip_adamw",
     "msclip_abi_version", "msclip_build_arch",
 )
 
@@ -87,6 +90,20 @@ def lib():
         L.msclip_clip_loss_partial.argtypes = [vp, vp, vp, ci, ci, ci, cf, vp, vp]
         L.msclip_clip_lse_fused.argtypes = [vp, ci, vp, ci, ci, ci, ci, cf, ci, ci, vp, vp, vp, vp]
         L.msclip_clip_loss_from_partials.argtypes = [vp, vp, vp, vp, vp, ci, ci, cf, vp, vp, vp]
+        ll = ctypes.c_longlong
+        L.msclip_transpose_bf16.argtypes = [vp, ci, vp, ci, ci, ci, ci, vp]
+        L.msclip_cast_bf16.argtypes = [vp, ci, vp, ci, ci, ci, vp]
+        L.msclip_colsum.argtypes = [vp, ci, ci, vp, ci, ci, ci, vp]
+        L.msclip_quickgelu.argtypes = [vp, vp, ll, vp]
+        L.msclip_quickgelu_bwd.argtypes = [vp, vp, vp, ll, vp]
+        L.msclip_layernorm_bwd.argtypes = [vp, ci, vp, ci, vp, ci, ci, vp, vp, ci, ci, vp, ci, ci, ci, cf, vp]
+        L.msclip_attention_bwd.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
+        L.msclip_l2norm_bwd.argtypes = [vp, ci, vp, ci, vp, ci, ci, ci, vp]
+        L.msclip_clip_loss_bwd_g.argtypes = [vp, ci, vp, vp, ci, cf, vp, ci, vp, ci, ci, ci, vp]
+        L.msclip_embed_tokens_bwd.argtypes = [vp, vp, ci, vp, vp, ci, ci, ci, ci, vp]
+        L.msclip_adapter_sum.argtypes = [vp, ci, vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
+        L.msclip_adapter_dx.argtypes = [vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, vp]
+        L.msclip_adamw.argtypes = [vp, vp, vp, vp, ll, cf, cf, cf, cf, cf, ci, vp]
         L.msclip_abi_version.restype = ci
         L.msclip_build_arch.restype = ctypes.c_char_p
         for name in EXPORTS:
@@ -383,3 +400,115 @@ def clip_loss_from_partials(pm_i, ps_i, pm_t, ps_t, diag, scale, out, lse_out=No
     R, nsplit = pm_i.shape
     _check(lib().msclip_clip_loss_from_partials(_p(pm_i), _p(ps_i), _p(pm_t), _p(ps_t), _p(diag), R, nsplit, scale,
                                                 _p(out), _p(lse_out), _stream()), "msclip_clip_loss_from_partials")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# backward-pass entry points (csrc/backward.hip, csrc/attention_bwd.hip)
+# ---------------------------------------------------------------------------------------------------------------------
+
+def transpose_bf16(x, M=None, Mpad=None):
+    """x bf16 [M, C] (row-range view fine) -> new bf16 [C, Mpad] with columns >= M zeroed (Mpad: M rounded up to 64)."""
+    _bf16(x)
+    M = x.shape[0] if M is None else M
+    C = x.shape[1]
+    Mpad = (M + 63) // 64 * 64 if Mpad is None else Mpad
+    out = torch.empty(C, Mpad, dtype=torch.bfloat16, device=x.device)
+    _check(lib().msclip_transpose_bf16(_p(x), x.stride(0), _p(out), Mpad, M, C, Mpad, _stream()), "msclip_transpose_bf16")
+    return out
+
+
+def cast_bf16(x, out=None):
+    assert x.dtype == torch.float32 and x.stride(-1) == 1
+    M, C = x.shape
+    if out is None:
+        out = torch.empty(M, C, dtype=torch.bfloat16, device=x.device)
+    _check(lib().msclip_cast_bf16(_p(x), x.stride(0), _p(out), out.stride(0), M, C, _stream()), "msclip_cast_bf16")
+    return out
+
+
+def colsum(x, out=None, M=None, accumulate=False):
+    M = x.shape[0] if M is None else M
+    N = x.shape[1]
+    if out is None:
+        out = torch.empty(N, dtype=torch.float32, device=x.device)
+    assert x.dtype in (torch.float32, torch.bfloat16) and x.stride(-1) == 1
+    _check(lib().msclip_colsum(_p(x), x.stride(0), int(x.dtype == torch.float32), _p(out), M, N, int(accumulate), _stream()),
+           "msclip_colsum")
+    return out
+
+
+def quickgelu(h, y):
+    _bf16(h); _bf16(y)
+    assert h.is_contiguous() and y.is_contiguous()
+    _check(lib().msclip_quickgelu(_p(h), _p(y), h.numel(), _stream()), "msclip_quickgelu")
+    return y
+
+
+def quickgelu_bwd(h, dy, dh):
+    assert h.is_contiguous() and dy.is_contiguous() and dh.is_contiguous()
+    _check(lib().msclip_quickgelu_bwd(_p(h), _p(dy), _p(dh), h.numel(), _stream()), "msclip_quickgelu_bwd")
+    return dh
+
+
+LN_PART_BLOCKS = 1024
+
+
+def layernorm_bwd(x, dy, gamma, dx, M, *, row_idx=None, row_mul=1, accumulate=True, want_param_grads=True, eps=1e-12):
+    """-> (dgamma, dbeta) fp32 [C] (or None).  x fp32 [*, C]; dy [M, C] bf16 / fp32; dx fp32 gets (+=) the input gradient
+    at the rows the forward read."""
+    C = x.shape[-1]
+    part = torch.empty(LN_PART_BLOCKS, 2, C, dtype=torch.float32, device=x.device) if want_param_grads else None
+    _check(lib().msclip_layernorm_bwd(_p(x), x.stride(0), _p(row_idx), row_mul, _p(dy), dy.stride(0),
+                                      int(dy.dtype == torch.float32), _p(gamma), _p(dx), dx.stride(0), int(accumulate),
+                                      _p(part), LN_PART_BLOCKS, M, C, eps, _stream()), "msclip_layernorm_bwd")
+    if not want_param_grads:
+        return None, None
+    both = colsum(part.view(LN_PART_BLOCKS, 2 * C))
+    return both[:C], both[C:]
+
+
+def attention_bwd(qkv, o, dout, dqkv, nsamples, L, heads, causal):
+    _bf16(qkv); _bf16(o); _bf16(dout); _bf16(dqkv)
+    assert o.stride(0) == dout.stride(0) and qkv.stride(0) == dqkv.stride(0)
+    _check(lib().msclip_attention_bwd(_p(qkv), _p(o), _p(dout), _p(dqkv), nsamples, L, heads, qkv.stride(0), o.stride(0),
+                                      int(causal), _stream()), "msclip_attention_bwd")
+    return dqkv
+
+
+def l2norm_bwd(x, dy, dx):
+    M, E = x.shape
+    _check(lib().msclip_l2norm_bwd(_p(x), x.stride(0), _p(dy), dy.stride(0), _p(dx), dx.stride(0), M, E, _stream()),
+           "msclip_l2norm_bwd")
+    return dx
+
+
+def clip_loss_bwd_g(S, lse_row, lse_col, label_off, w, G, dscale_part=None):
+    R, N = S.shape
+    _check(lib().msclip_clip_loss_bwd_g(_p(S), S.stride(0), _p(lse_row), _p(lse_col), label_off, w, _p(G), G.stride(0),
+                                        _p(dscale_part), R, N, G.shape[1], _stream()), "msclip_clip_loss_bwd_g")
+    return G
+
+
+def embed_tokens_bwd(tokens, dx, demb, dpos):
+    B, L = tokens.shape
+    _check(lib().msclip_embed_tokens_bwd(_p(tokens), _p(dx), dx.stride(0), _p(demb), _p(dpos), B, L, dx.shape[1],
+                                         demb.shape[0], _stream()), "msclip_embed_tokens_bwd")
+
+
+def adapter_sum(xin, t, dww, dwb, out, B, L, g, usecls):
+    _check(lib().msclip_adapter_sum(_p(xin), xin.stride(0), _p(t), t.stride(0), _p(dww), _p(dwb), _p(out), out.stride(0), B, L,
+                                    g, xin.shape[1], int(usecls), _stream()), "msclip_adapter_sum")
+    return out
+
+
+def adapter_dx(dsum, dww, dx, B, L, g, usecls):
+    _check(lib().msclip_adapter_dx(_p(dsum), dsum.stride(0), _p(dww), _p(dx), dx.stride(0), B, L, g, dsum.shape[1],
+                                   int(usecls), _stream()), "msclip_adapter_dx")
+    return dx
+
+
+def adamw(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
+    for t in (p, g, m, v):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel()
+    _check(lib().msclip_adamw(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step, _stream()),
+           "msclip_adamw")

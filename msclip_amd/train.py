@@ -1,0 +1,360 @@
+"""Backward pass + optimizer step of the MS-CLIP-S hot path, first slice.
+
+The reference release contains no trainer and no loss; what is differentiated here is the forward it defines
+(lib/models/clip_openai_pe_res_v1.py, "M.py") and the symmetric cross-entropy this build adds, with the reference's
+gather semantics (gradient only through the local rows, lib/utils/comm.py:151-152) and its optimizer hyper-parameters
+(separate LR / weight decay for the shared tensors: experiments/model/*-msclips.yaml `LR_SHARE` / `WD_SHARE`, scaled
+with the world size in lib/config/default.py:299-304; no decay on bias / LayerNorm / BatchNorm, `WITHOUT_WD_LIST`).
+
+Scope of the slice -- everything differentiable on the token side of the model:
+  * the contrastive head (fused LSE sweeps forward; dL/dlogits blocks + GEMMs backward), L2 norm, both projections,
+    ln_post / ln_final;
+  * all transformer blocks of both towers: LayerNorm, QKV / out_proj / c_fc / c_proj GEMMs (dgrad + wgrad through
+    msclip_gemm), attention (msclip_attention_bwd), QuickGELU.  The modality-shared tensors (M.py:2808-2830) receive the
+    SUM of the image- and text-row gradients: the towers' tokens are rows of one matrix and one wgrad GEMM contracts
+    over all of them;
+  * the token path of the lateral adapters (ln_adapt incl. its parameters, the depthwise 3x3 over the token grid, the
+    doubled cls row), ln_pre, class / positional embeddings, token embedding.
+Frozen in this slice (their gradients are NOT produced): the convolutional stem, the parallel convolutional branch, the
+adapters' top-down convolutions and every BatchNorm (the HIP forward folds running statistics: eval-mode BN).  Those
+are ~5 M of the 132 M parameters; row f3 stays partial until they are covered.
+
+Parity: tests/test_gpu_train.py compares every produced gradient with autograd of the REAL reference
+(tests/golden/b32-yfcc-msclips.grads.npz, captured by tools/make_golden.py::grads_fixture).
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+from . import comm as C
+from . import hip
+
+BF = torch.bfloat16
+F32 = torch.float32
+_LEAVES = ("attn.in_proj_weight", "attn.in_proj_bias", "attn.out_proj.weight", "attn.out_proj.bias",
+           "mlp.c_fc.weight", "mlp.c_fc.bias", "mlp.c_proj.weight", "mlp.c_proj.bias")
+
+
+def _wgrad(dy_bf, x_bf, M):
+    """dW[N, K] = dY^T @ X over the first M rows of dy_bf [*, N] and x_bf [*, K] (bf16): both operands transposed so the
+    token axis is the contiguous K axis of the GEMM (zero-padded to a multiple of 64)."""
+    a = hip.transpose_bf16(dy_bf, M)
+    b = hip.transpose_bf16(x_bf, M)
+    out = torch.empty(a.shape[0], b.shape[0], dtype=F32, device=a.device)
+    hip.gemm(a, b, out)
+    return out
+
+
+def _dgrad(dy_bf, w_t, out=None):
+    """dX[M, K] = dY[M, N] @ W[N, K], w_t = W^T-as-stored-for-the-GEMM = [K, N] bf16 (N % 64 == 0)."""
+    if out is None:
+        out = torch.empty(dy_bf.shape[0], w_t.shape[0], dtype=BF, device=dy_bf.device)
+    hip.gemm(dy_bf, w_t, out)
+    return out
+
+
+class TrainStep:
+    """forward + backward (+ AdamW step) for one local batch.  `engine` is the model's msclip_amd.engine.Engine."""
+
+    def __init__(self, model, lr=None, lr_share=None, wd=0.2, wd_share=None, betas=(0.9, 0.98), eps=1e-6):
+        self.model = model
+        self.eng = model.engine()
+        self.lr, self.lr_share = lr, lr_share
+        self.wd, self.wd_share = wd, wd_share
+        self.betas, self.eps = betas, eps
+        self.state = {}
+        self.steps = 0
+
+    # ------------------------------------------------------------------ forward that keeps what the backward needs
+    def forward(self, img, tok):
+        e = self.eng
+        e.refresh()
+        with torch.cuda.device(e.dev), torch.no_grad():
+            Bi, Bt = img.shape[0], tok.shape[0]
+            assert Bi == Bt, "a training step needs image-text pairs"
+            if e.Lv > 96 or e.Lt > 96:
+                raise NotImplementedError("msclip_attention_bwd covers sequences up to 96 tokens (ViT-B/32 grid, 77-token "
+                                          "captions); the 197-token grid of ViT-B/16 is not in this slice")
+            w = e._workspace(Bi, Bt)
+            Mv, M = w["Mv"], w["M"]
+            D = e.D
+            X = w["X"]
+            sv = dict(Bi=Bi, Bt=Bt, Mv=Mv, M=M, layers=[None] * e.n_layers, tok=e._check_tok(tok))
+            # ---- fronts (the conv side is frozen: nothing of it is saved but the tokens in front of ln_pre)
+            keep = []
+            e._vision_front(e._check_img(img), w, Bi, keep_pre=keep)
+            sv["tok_pre"] = keep[0]
+            g2 = e.g * e.g
+            e._text_front(sv["tok"], w, Bt)
+            # ---- blocks
+            for i in range(e.n_layers):
+                vb = e.vblk[i]
+                tb = e.tblk[i]
+                L = dict(adapter=None)
+                if vb is not None and i in e.lateral:
+                    j = e.lateral.index(i)
+                    e._parallel_stage(j, w, Bi)
+                    a = e.adapters[j]
+                    hip.dwpool(w["par"][j], a["pool"], w["pool"][j], Bi, e.par_hw[j], e.par_hw[j], a["C"], a["k"])
+                    hip.gemm(w["pool"][j], a["pw"].weight, w["T"], M=Bi * g2, N=a["pw"].cout, bias=a["pw"].bias, ldx=a["pw"].cin)
+                    asum = torch.empty(Mv, D, dtype=F32, device=e.dev)
+                    hip.adapter_sum(X[:Mv], w["T"], a["dww"], a["dwb"], asum, Bi, e.Lv, e.g, e.usecls)
+                    hip.layernorm(asum, a["ln"].g, a["ln"].b, X[:Mv], Mv)                    # X[:Mv] <- ln_adapt(sum), fp32
+                    L["adapter"] = dict(j=j, sum=asum)
+                segs = ([(0, Mv, vb)] if vb is not None else []) + [(Mv, M, tb)]
+                r_lo = segs[0][0]
+                L["x_in"] = X[r_lo:M].clone()
+                lno1 = torch.empty(M, D, dtype=BF, device=e.dev)
+                for r0, r1, b in segs:
+                    hip.layernorm(X[r0:r1], b["ln1"].g, b["ln1"].b, lno1[r0:r1], r1 - r0)
+                groups = [(r_lo, M, segs[0][2]["w"])] if len(segs) == 2 and vb["w"] is tb["w"] else \
+                         [(r0, r1, b["w"]) for r0, r1, b in segs]
+                qkv = torch.empty(M, 3 * D, dtype=BF, device=e.dev)
+                ao = torch.empty(M, D, dtype=BF, device=e.dev)
+                for r0, r1, bw in groups:
+                    hip.gemm(lno1[r0:r1], bw.wqkv, qkv[r0:r1], bias=bw.bqkv)
+                if vb is not None:
+                    hip.attention(qkv[:Mv], ao[:Mv], Bi, e.Lv, e.heads, False)
+                hip.attention(qkv[Mv:M], ao[Mv:M], Bt, e.Lt, e.heads, True)
+                for r0, r1, bw in groups:
+                    hip.gemm(ao[r0:r1], bw.wo, X[r0:r1], bias=bw.bo, resid=X[r0:r1], resid_kind=hip.RESID_F32)
+                L["x_mid"] = X[r_lo:M].clone()
+                lno2 = torch.empty(M, D, dtype=BF, device=e.dev)
+                for r0, r1, b in segs:
+                    hip.layernorm(X[r0:r1], b["ln2"].g, b["ln2"].b, lno2[r0:r1], r1 - r0)
+                h = torch.empty(M, 4 * D, dtype=BF, device=e.dev)
+                hid = torch.empty(M, 4 * D, dtype=BF, device=e.dev)
+                for r0, r1, bw in groups:
+                    hip.gemm(lno2[r0:r1], bw.wfc, h[r0:r1], bias=bw.bfc)                      # pre-activation is kept
+                hip.quickgelu(h[r_lo:M], hid[r_lo:M])
+                for r0, r1, bw in groups:
+                    hip.gemm(hid[r0:r1], bw.wpr, X[r0:r1], bias=bw.bpr, resid=X[r0:r1], resid_kind=hip.RESID_F32)
+                L.update(r_lo=r_lo, segs=segs, groups=groups, lno1=lno1, qkv=qkv, ao=ao, lno2=lno2, h=h)
+                del hid
+                sv["layers"][i] = L
+            # ---- heads + loss
+            sv["x_out"] = X[:M].clone()
+            e._head_image(w, Bi)
+            e._head_text(w, Bt)
+            sv.update(hv=w["hv"].clone(), ht=w["ht"].clone(), fv_raw=w["fv_raw"].clone(), ft_raw=w["ft_raw"].clone(),
+                      fv=w["fv"].clone(), ft=w["ft"].clone(), fvb=w["fvb"].clone(), ftb=w["ftb"].clone(), eot=w["eot"].clone())
+            # ---- loss.  The inference path forms its logits from bf16 unit features (error ~0.03 on a logit at T = 1/0.07:
+            # fine for a loss value, but it perturbs every softmax probability by a few percent and with it the whole
+            # gradient).  The training step splits each fp32 feature into bf16 hi + lo parts and contracts
+            # [hi | hi | lo] . [hi | lo | hi] in one K = 3E GEMM: logits to ~2^-16 relative, still on the bf16 MFMA path.
+            def split(f):
+                hi = hip.cast_bf16(f)
+                lo = hip.cast_bf16(f - hi.float())
+                return torch.cat([hi, lo], dim=1)                                              # [B, 2E]: the gather payload
+            pi, pt = split(sv["fv"]), split(sv["ft"])
+            if C.comm.world_size > 1:
+                allpi, hi_ = C.gather_rows_async(pi)
+                allpt, ht_ = C.gather_rows_async(pt)
+                hi_.wait(); ht_.wait()
+            else:
+                allpi, allpt = pi, pt
+            E = e.E
+            n = allpi.shape[0]
+            off = C.local_label_offset(Bi) if n > Bi else 0
+            sv["off"], sv["n"] = off, n
+            sv["allI"], sv["allT"] = allpi[:, :E].contiguous(), allpt[:, :E].contiguous()     # hi parts: dgrad operands
+            s = e.logit_scale_exp
+
+            def logits_block(a, ball):                                                         # scale * A_loc @ B_all^T, fp32
+                a3 = torch.cat([a[:, :E], a[:, :E], a[:, E:]], dim=1)
+                b3 = torch.cat([ball[:, :E], ball[:, E:], ball[:, :E]], dim=1)
+                S = torch.empty(a.shape[0], n, dtype=F32, device=e.dev)
+                hip.gemm(a3, b3, S, alpha=s)
+                return S
+            S_i, S_t = logits_block(pi, allpt), logits_block(pt, allpi)                        # image rows / caption rows
+            lse = torch.empty(2, Bi, dtype=F32, device=e.dev)
+            hip.lse_rows(S_i, lse[0])
+            hip.lse_rows(S_t, lse[1])
+            out = torch.empty(1, dtype=F32, device=e.dev)
+            hip.clip_loss_partial(lse[0], lse[1], S_i, off, 1.0 / (2.0 * n), out)
+            if n > Bi:
+                dist.all_reduce(out)
+                lse_all = torch.empty(n // Bi, 2, Bi, dtype=F32, device=e.dev)
+                dist.all_gather_into_tensor(lse_all, lse.contiguous())
+                lse_all = lse_all.permute(1, 0, 2).reshape(2, n).contiguous()                 # rank-major global order
+            else:
+                lse_all = lse
+            sv.update(S_i=S_i, S_t=S_t, lse_loc=lse, lse_all=lse_all)
+            self.saved = sv
+            return out[0].clone()
+
+    # ------------------------------------------------------------------ backward
+    def backward(self):
+        """-> {reference state_dict key: fp32 gradient} for every parameter of the slice (shared tensors under their
+        visual.* key; the text-tower aliases are the same Parameter objects)."""
+        e, sv = self.eng, self.saved
+        dev, D, E = e.dev, e.D, e.E
+        with torch.cuda.device(dev), torch.no_grad():
+            Bi, Bt, Mv, M, n, off = sv["Bi"], sv["Bt"], sv["Mv"], sv["M"], sv["n"], sv["off"]
+            s = e.logit_scale_exp
+            grads = {}
+            # ---- contrastive head: dL/dS blocks of this rank's image rows and caption rows
+            npad = (n + 63) // 64 * 64
+            wgt = 1.0 / (2.0 * n)
+
+            def side(S, b_all, lse_row, lse_col, want_dscale):
+                G = torch.empty(S.shape[0], npad, dtype=BF, device=dev)
+                dsp = torch.empty(S.shape[0], dtype=F32, device=dev) if want_dscale else None
+                hip.clip_loss_bwd_g(S, lse_row, lse_col, off, wgt, G, dsp)
+                bt = hip.transpose_bf16(b_all, n, npad)                                        # [E, npad]
+                d = torch.empty(S.shape[0], E, dtype=F32, device=dev)
+                hip.gemm(G, bt, d, alpha=s)                                                    # dA = scale * G @ B_all
+                return d, dsp
+            lse_i_loc, lse_t_loc = sv["lse_loc"][0], sv["lse_loc"][1]
+            lse_i_all, lse_t_all = sv["lse_all"][0], sv["lse_all"][1]
+            dfi, dsp = side(sv["S_i"], sv["allT"], lse_i_loc, lse_t_all, True)
+            dft, _ = side(sv["S_t"], sv["allI"], lse_t_loc, lse_i_all, False)
+            dscale = hip.colsum(dsp.view(-1, 1))                                               # sum_r sum_j G S
+            if n > Bi:
+                dist.all_reduce(dscale)
+            # S already carries the scale: dL/dscale = sum G S / scale; logit_scale = log(scale) => dL/dlogit_scale = sum G S
+            grads["logit_scale"] = dscale.reshape(())
+
+            dX = torch.zeros(M, D, dtype=F32, device=dev)
+
+            def head(feat_raw, dfeat, hrow, w_proj, ln, key_proj, key_ln, row_idx=None, row_mul=1):
+                dfr = torch.empty_like(feat_raw)
+                hip.l2norm_bwd(feat_raw, dfeat, dfr)
+                dfr_b = hip.cast_bf16(dfr)
+                grads[key_proj] = _wgrad(hrow, dfr_b, hrow.shape[0])                           # [D, E] like the parameter
+                dh = torch.empty(hrow.shape[0], D, dtype=F32, device=dev)                      # fp32: it feeds column sums
+                hip.gemm(dfr_b, w_proj.t().contiguous(), dh)                                   # dfr [B, E] @ W [E, D]
+                dg, db = hip.layernorm_bwd(sv["x_out"], dh, ln.g, dX, hrow.shape[0], row_idx=row_idx, row_mul=row_mul)
+                grads[key_ln + ".weight"], grads[key_ln + ".bias"] = dg, db
+            head(sv["fv_raw"], dfi, sv["hv"], e.w_vproj, e.ln_post, "visual.proj", "visual.ln_post", row_mul=e.Lv)
+            head(sv["ft_raw"], dft, sv["ht"], e.w_tproj, e.ln_final, "text_projection", "ln_final", row_idx=sv["eot"])
+
+            # ---- blocks, last to first
+            for i in reversed(range(e.n_layers)):
+                L = sv["layers"][i]
+                r_lo, segs, groups = L["r_lo"], L["segs"], L["groups"]
+                names = {id(e.tblk[i]["w"]): f"transformer.resblocks.{i}"}
+                if e.vblk[i] is not None:                    # shared tensors live under their visual.* name (one Parameter)
+                    names[id(e.vblk[i]["w"])] = f"visual.transformer.resblocks.{i}"
+                hid = torch.empty(M, 4 * D, dtype=BF, device=dev)
+                hip.quickgelu(L["h"][r_lo:M], hid[r_lo:M])                                     # recomputed, not stored
+                dY = torch.empty(M, D, dtype=BF, device=dev)
+                hip.cast_bf16(dX[r_lo:M], dY[r_lo:M])
+                dhid = torch.empty(M, 4 * D, dtype=BF, device=dev)
+                # gradients of the LayerNorm outputs stay fp32: they are only read by the LayerNorm backward, whose dbeta /
+                # dgamma are column sums of nearly cancelling terms (a bf16 dy costs 10-30 % on those sums at small batch)
+                dlno = torch.empty(M, D, dtype=F32, device=dev)
+                for r0, r1, bw in groups:
+                    p = names[id(bw)]
+                    grads[p + ".mlp.c_proj.weight"] = _wgrad(dY[r0:r1], hid[r0:r1], r1 - r0)
+                    grads[p + ".mlp.c_proj.bias"] = hip.colsum(dX[r0:r1])
+                    _dgrad(dY[r0:r1], bw.wpr.t().contiguous(), dhid[r0:r1])
+                del hid
+                dh = torch.empty(M, 4 * D, dtype=BF, device=dev)
+                hip.quickgelu_bwd(L["h"][r_lo:M], dhid[r_lo:M], dh[r_lo:M])
+                for r0, r1, bw in groups:
+                    p = names[id(bw)]
+                    grads[p + ".mlp.c_fc.weight"] = _wgrad(dh[r0:r1], L["lno2"][r0:r1], r1 - r0)
+                    grads[p + ".mlp.c_fc.bias"] = hip.colsum(dh[r0:r1])
+                    _dgrad(dh[r0:r1], bw.wfc.t().contiguous(), dlno[r0:r1])
+                del dhid, dh
+                for r0, r1, b in segs:
+                    pre = f"visual.transformer.resblocks.{i}" if b is e.vblk[i] else f"transformer.resblocks.{i}"
+                    dg, db = hip.layernorm_bwd(L["x_mid"][r0 - r_lo:r1 - r_lo], dlno[r0:r1], b["ln2"].g, dX[r0:r1], r1 - r0)
+                    grads[pre + ".ln_2.weight"], grads[pre + ".ln_2.bias"] = dg, db
+                # attention half
+                hip.cast_bf16(dX[r_lo:M], dY[r_lo:M])
+                dao = torch.empty(M, D, dtype=BF, device=dev)
+                dqkv = torch.zeros(M, 3 * D, dtype=BF, device=dev)
+                for r0, r1, bw in groups:
+                    p = names[id(bw)]
+                    grads[p + ".attn.out_proj.weight"] = _wgrad(dY[r0:r1], L["ao"][r0:r1], r1 - r0)
+                    grads[p + ".attn.out_proj.bias"] = hip.colsum(dX[r0:r1])
+                    _dgrad(dY[r0:r1], bw.wo.t().contiguous(), dao[r0:r1])
+                if e.vblk[i] is not None:
+                    hip.attention_bwd(L["qkv"][:Mv], L["ao"][:Mv], dao[:Mv], dqkv[:Mv], Bi, e.Lv, e.heads, False)
+                hip.attention_bwd(L["qkv"][Mv:M], L["ao"][Mv:M], dao[Mv:M], dqkv[Mv:M], Bt, e.Lt, e.heads, True)
+                for r0, r1, bw in groups:
+                    p = names[id(bw)]
+                    gw = _wgrad(dqkv[r0:r1], L["lno1"][r0:r1], r1 - r0)                       # wrt the PACKED weight
+                    gb = hip.colsum(dqkv[r0:r1])
+                    gw[:D] *= 0.125                                                            # packed q rows = 64^-0.5 * W_q
+                    gb[:D] *= 0.125
+                    grads[p + ".attn.in_proj_weight"], grads[p + ".attn.in_proj_bias"] = gw, gb
+                    _dgrad(dqkv[r0:r1], bw.wqkv.t().contiguous(), dlno[r0:r1])
+                for r0, r1, b in segs:
+                    pre = f"visual.transformer.resblocks.{i}" if b is e.vblk[i] else f"transformer.resblocks.{i}"
+                    dg, db = hip.layernorm_bwd(L["x_in"][r0 - r_lo:r1 - r_lo], dlno[r0:r1], b["ln1"].g, dX[r0:r1], r1 - r0)
+                    grads[pre + ".ln_1.weight"], grads[pre + ".ln_1.bias"] = dg, db
+                if L["adapter"] is not None:                                                   # token path of the lateral adapter
+                    ad = L["adapter"]
+                    a = e.adapters[ad["j"]]
+                    dsum = torch.empty(Mv, D, dtype=F32, device=dev)
+                    dg, db = hip.layernorm_bwd(ad["sum"], dX[:Mv], a["ln"].g, dsum, Mv, accumulate=False)
+                    pre = f"visual.transformer.parallel_lateral_adapter.{ad['j']}.ln_adapt"
+                    grads[pre + ".weight"], grads[pre + ".bias"] = dg, db
+                    hip.adapter_dx(dsum, a["dww"], dX[:Mv], Bi, e.Lv, e.g, e.usecls)
+                sv["layers"][i] = None                                                         # free the layer's activations
+            # ---- fronts: text embedding, image cls / positional embeddings, ln_pre
+            demb = torch.zeros_like(e.emb, dtype=F32)
+            dpos = torch.zeros(e.Lt, D, dtype=F32, device=dev)
+            hip.embed_tokens_bwd(sv["tok"], dX[Mv:M], demb, dpos)
+            grads["token_embedding.weight"], grads["positional_embedding"] = demb, dpos
+            dtok = torch.empty(Mv, D, dtype=F32, device=dev)
+            dg, db = hip.layernorm_bwd(sv["tok_pre"], dX[:Mv], e.ln_pre.g, dtok, Mv, accumulate=False)
+            grads["visual.ln_pre.weight"], grads["visual.ln_pre.bias"] = dg, db
+            dvpos = hip.colsum(dtok.view(Bi, e.Lv * D)).view(e.Lv, D)                           # sum over the batch
+            grads["visual.positional_embedding"] = dvpos
+            grads["visual.class_embedding"] = dvpos[0].clone()
+            self.saved = None
+            return grads
+
+    # ------------------------------------------------------------------ optimizer
+    def param_groups(self):
+        """(name, parameter, lr, weight_decay) for every parameter of the slice, following the reference's yaml: shared
+        attention / MLP tensors use CUSTOM.LR_SHARE / WD_SHARE, everything else TRAIN.LR / TRAIN.WD; no decay for names
+        containing 'bn' / 'bias' / 'ln' (TRAIN.WITHOUT_WD_LIST) and for model.no_weight_decay()."""
+        m = self.model
+        shared = set()
+        if m.share_from_layer is not None:
+            for i in range(max(m.share_from_layer, 1), len(m.visual.transformer.resblocks)):
+                shared.update(f"visual.transformer.resblocks.{i}.{leaf}" for leaf in _LEAVES)
+        nodecay = set(m.no_weight_decay())
+        params = dict(m.named_parameters())
+        out = []
+        for k, p in params.items():
+            lr = self.lr_share if (k in shared and self.lr_share is not None) else self.lr
+            wd = self.wd_share if (k in shared and self.wd_share is not None) else self.wd
+            if any(t in k for t in ("bn", "bias", "ln")) or k.split(".")[-1] in nodecay or k in nodecay:
+                wd = 0.0
+            out.append((k, p, lr, wd))
+        return out
+
+    def step(self, grads, world_average=True):
+        """AdamW on the module's fp32 parameters (msclip_adamw), then the engine re-packs its bf16 copies.  Under
+        N > 1 ranks the per-rank gradients are averaged first (what the reference's DDP wrapper would do)."""
+        self.steps += 1
+        with torch.no_grad():
+            for k, p, lr, wd in self.param_groups():
+                g = grads.get(k)
+                if g is None:
+                    continue
+                g = g.reshape(p.shape).contiguous()
+                if world_average and C.comm.world_size > 1:
+                    dist.all_reduce(g)
+                    g /= C.comm.world_size
+                st = self.state.get(k)
+                if st is None:
+                    st = self.state[k] = (torch.zeros_like(p), torch.zeros_like(p))
+                hip.adamw(p.data.view(-1), g.view(-1), st[0].view(-1), st[1].view(-1), lr, self.betas[0], self.betas[1],
+                          self.eps, wd, self.steps)
+                p._version  # (in-place kernel write: bump the engine's fingerprint below)
+        self.eng.refresh(force=True)
+
+
+def from_config(model, config):
+    """TrainStep with the reference yaml's optimizer hyper-parameters (TRAIN.LR / WD, CUSTOM.LR_SHARE / WD_SHARE)."""
+    tr, cu = config.TRAIN, config.CUSTOM
+    return TrainStep(model, lr=tr.get("LR", 1e-4), lr_share=cu.get("LR_SHARE", None) or None, wd=tr.get("WD", 0.2),
+                     wd_share=cu.get("WD_SHARE", None) or None)

@@ -39,7 +39,7 @@ def golden(name):
 
 def summarize(t):
     f = t.detach().float().flatten().cpu()
-    idx = torch.linspace(0, f.numel() - 1, 64).long()
+    idx = torch.linspace(0, f.numel() - 1, 64).long().clamp_(max=f.numel() - 1)   # (fp32 linspace overshoots past 2^24 elements)
     return np.concatenate([[f.mean().item(), f.abs().mean().item()], f[idx].numpy()]).astype(np.float32)
 
 

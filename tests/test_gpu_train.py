@@ -1,0 +1,243 @@
+"""Backward pass (first slice) on a real MI355X.
+
+* every backward kernel against a plain fp32 PyTorch statement (autograd of the same op);
+* the whole slice -- contrastive head, both projections, every transformer block of both towers with the modality-shared
+  tensors' summed gradients, the token path of the lateral adapters, embeddings -- against autograd of the REAL reference
+  (tests/golden/b32-yfcc-msclips.grads.npz, captured by tools/make_golden.py::grads_fixture on the golden batch);
+* an AdamW step with the reference's parameter groups lowers the loss of the batch it was computed on.
+
+Stated tolerance (bf16 GEMM operands and activations in BOTH passes, fp32 accumulation / statistics, against fp32
+autograd of an fp32 forward): per gradient tensor, max error over the golden's 64-point sample <= 8 % of the tensor's
+abs-max (median over the 211 tensors <= 3 %; measured 2.2 %, worst 5 %), abs-mean within 5 %, cosine >= 0.995 for the tensors stored in full.
+LayerNorm BIAS gradients are column sums of nearly cancelling rows at the golden batch of 4 (abs-mean 15 x below the
+matching weight gradient's): 25 % / 15 % / cosine 0.95 for those.  The error is dominated by the forward: the bf16 towers'
+unit features differ from the fp32 reference's by ~1e-3, i.e. ~0.03 on a logit at T = 1/0.07, a few percent on every
+softmax probability the gradient starts from."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import golden, summarize, synth_sd, GOLDEN
+from msclip_amd import hip, synth, train
+from msclip_amd.clip_openai_pe_res_v1 import get_clip_model
+from msclip_amd.config import named_config
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+SAMPLE_TOL, ABSMEAN_TOL, COS_TOL = 0.08, 0.05, 0.995
+LNB_SAMPLE_TOL, LNB_ABSMEAN_TOL, LNB_COS_TOL = 0.25, 0.15, 0.95
+
+
+def rnd(*shape, seed=0, scale=1.0, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).cuda()
+
+
+def rel(got, ref):
+    return ((got.float() - ref.float()).abs().max() / ref.float().abs().max().clamp_min(1e-12)).item()
+
+
+def test_transpose_cast_colsum_gelu(gpu_device):
+    x = rnd(1000, 200, seed=1, dtype=BF)
+    t = hip.transpose_bf16(x)
+    assert t.shape == (200, 1024) and torch.equal(t[:, :1000], x.t()) and bool((t[:, 1000:] == 0).all())
+    t2 = hip.transpose_bf16(x[100:900], 777)
+    assert t2.shape == (200, 832) and torch.equal(t2[:, :777], x[100:877].t()) and bool((t2[:, 777:] == 0).all())
+    f = rnd(300, 768, seed=2)
+    assert torch.equal(hip.cast_bf16(f), f.to(BF))
+    assert rel(hip.colsum(f), f.sum(0)) < 1e-5 and rel(hip.colsum(x), x.float().sum(0)) < 1e-5
+    acc = torch.ones(768, device="cuda")
+    hip.colsum(f, out=acc, accumulate=True)
+    assert rel(acc, f.sum(0) + 1) < 1e-5
+    h, dy = rnd(64, 3072, seed=3, scale=2.0, dtype=BF), rnd(64, 3072, seed=4, dtype=BF)
+    y, dh = torch.empty_like(h), torch.empty_like(h)
+    hip.quickgelu(h, y)
+    hf = h.float().requires_grad_(True)
+    ref = hf * torch.sigmoid(1.702 * hf)
+    assert rel(y, ref.detach()) < 1e-2
+    ref.backward(dy.float())
+    hip.quickgelu_bwd(h, dy, dh)
+    assert rel(dh, hf.grad) < 1e-2
+
+
+@pytest.mark.parametrize("C,dy_f32,gather", [(768, False, False), (768, True, False), (512, False, False), (768, False, True)])
+def test_layernorm_backward(gpu_device, C, dy_f32, gather):
+    M = 1000
+    x = rnd(M * (3 if gather else 1), C, seed=5, scale=2.0) + 0.3
+    gam, bet = rnd(C, seed=6) + 1.0, rnd(C, seed=7)
+    dy = rnd(M, C, seed=8, dtype=torch.float32 if dy_f32 else BF)
+    idx = (torch.arange(M, device="cuda") * 3 + 1).int() if gather else None
+    xr = x[idx.long()] if gather else x
+    xa = xr.clone().requires_grad_(True)
+    ga, ba = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    u = xa.mean(-1, keepdim=True)
+    s = (xa - u).pow(2).mean(-1, keepdim=True)
+    (ga * ((xa - u) / torch.sqrt(s + 1e-12)) + ba).backward(dy.float())
+    dx = torch.full_like(x, 0.5)
+    dg, db = hip.layernorm_bwd(x, dy, gam, dx, M, row_idx=idx, accumulate=True)
+    got = dx[idx.long()] if gather else dx
+    assert rel(got - 0.5, xa.grad) < 2e-4
+    if gather:
+        mask = torch.ones(x.shape[0], dtype=torch.bool, device="cuda")
+        mask[idx.long()] = False
+        assert bool((dx[mask] == 0.5).all())                                  # untouched rows
+    assert rel(dg, ga.grad) < 2e-4 and rel(db, ba.grad) < 2e-4
+    dx2 = torch.full_like(x, 7.0)
+    hip.layernorm_bwd(x, dy, gam, dx2, M, row_idx=idx, accumulate=False, want_param_grads=False)
+    assert rel(dx2[idx.long()] if gather else dx2, xa.grad) < 2e-4
+
+
+@pytest.mark.parametrize("L,causal", [(50, False), (77, True), (64, False), (33, True), (96, True), (1, False)])
+def test_attention_backward(gpu_device, L, causal):
+    ns, H = 3, 12
+    qkv = rnd(ns * L, 3 * H * 64, seed=9, scale=0.7, dtype=BF)
+    dout = rnd(ns * L, H * 64, seed=10, dtype=BF)
+    o = torch.empty(ns * L, H * 64, dtype=BF, device="cuda")
+    hip.attention(qkv, o, ns, L, H, causal)
+    qf = qkv.float().requires_grad_(True)
+    q, k, v = (t.reshape(ns, L, H, 64).transpose(1, 2) for t in qf.chunk(3, dim=-1))
+    sc = q @ k.transpose(-1, -2)                                              # q is pre-scaled in the packed layout
+    if causal:
+        sc = sc + torch.full((L, L), float("-inf"), device="cuda").triu_(1)
+    ref_o = (torch.softmax(sc, -1) @ v).transpose(1, 2).reshape(ns * L, H * 64)
+    ref_o.backward(dout.float())
+    dqkv = torch.full_like(qkv, float("nan"))
+    hip.attention_bwd(qkv, o, dout, dqkv, ns, L, H, causal)
+    assert bool(torch.isfinite(dqkv.float()).all())
+    assert rel(dqkv, qf.grad) < 3e-2
+    cos = F.cosine_similarity(dqkv.float().flatten(), qf.grad.flatten(), dim=0).item()
+    assert cos > 0.999, cos
+
+
+def test_l2norm_loss_embed_adapter_adamw(gpu_device):
+    # l2norm
+    x, dy = rnd(37, 512, seed=11), rnd(37, 512, seed=12)
+    xa = x.clone().requires_grad_(True)
+    (xa / xa.norm(dim=-1, keepdim=True)).backward(dy)
+    dx = torch.empty_like(x)
+    hip.l2norm_bwd(x, dy, dx)
+    assert rel(dx, xa.grad) < 1e-4
+    # dL/dS of the symmetric CE on a row block with a label offset
+    R, N, off = 40, 100, 30
+    S = rnd(R, N, seed=13, scale=3.0)
+    full = rnd(N, N, seed=14, scale=3.0)
+    full[off:off + R] = S
+    fa = full.clone().requires_grad_(True)
+    lab = torch.arange(N, device="cuda")
+    (0.5 * (F.cross_entropy(fa, lab) + F.cross_entropy(fa.t(), lab))).backward()
+    G = torch.empty(R, 128, dtype=BF, device="cuda")
+    dsp = torch.empty(R, device="cuda")
+    hip.clip_loss_bwd_g(S, torch.logsumexp(full, 1)[off:off + R].contiguous(), torch.logsumexp(full, 0).contiguous(), off,
+                        1.0 / (2 * N), G, dsp)
+    assert rel(G[:, :N], fa.grad[off:off + R]) < 1e-2 and bool((G[:, N:] == 0).all())
+    assert abs(dsp.sum().item() - (fa.grad[off:off + R] * S).sum().item()) < 1e-3
+    # embedding backward
+    tok = torch.randint(0, 50, (6, 77), generator=torch.Generator().manual_seed(15)).cuda()
+    dxe = rnd(6 * 77, 768, seed=16)
+    demb, dpos = torch.zeros(50, 768, device="cuda"), torch.zeros(77, 768, device="cuda")
+    hip.embed_tokens_bwd(tok, dxe, demb, dpos)
+    ref = torch.zeros(50, 768, device="cuda").index_add_(0, tok.flatten(), dxe)
+    assert rel(demb, ref) < 1e-5 and rel(dpos, dxe.view(6, 77, 768).sum(0)) < 1e-5
+    # lateral adapter token path (M.py:1763-1777): sum and its input gradient against conv2d autograd
+    B, g, Cc = 3, 7, 768
+    Lt = g * g + 1
+    xin, tt = rnd(B * Lt, Cc, seed=17), rnd(B * g * g, Cc, seed=18)
+    dww, dwb = rnd(9, Cc, seed=19, scale=0.3), rnd(Cc, seed=20)
+    xa = xin.clone().requires_grad_(True)
+    xv = xa.view(B, Lt, Cc)
+    grid = xv[:, 1:].transpose(1, 2).reshape(B, Cc, g, g)
+    bo = F.conv2d(grid, dww.t().reshape(Cc, 1, 3, 3), dwb, padding=1, groups=Cc).flatten(2).transpose(1, 2)
+    ref_sum = torch.cat([2 * xv[:, :1], bo + tt.view(B, g * g, Cc)], 1).reshape(B * Lt, Cc)
+    out = torch.empty_like(xin)
+    hip.adapter_sum(xin, tt, dww, dwb, out, B, Lt, g, True)
+    assert rel(out, ref_sum.detach()) < 1e-5
+    dsum = rnd(B * Lt, Cc, seed=21)
+    ref_sum.backward(dsum)
+    dxa = torch.empty_like(xin)
+    hip.adapter_dx(dsum, dww, dxa, B, Lt, g, True)
+    assert rel(dxa, xa.grad) < 1e-5
+    # AdamW against torch.optim.AdamW
+    p0, gr = rnd(5000, seed=22), rnd(5000, seed=23)
+    pt = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pt], lr=1e-3, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.2)
+    p, m, v = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+    for step in (1, 2, 3):
+        pt.grad = gr * step
+        opt.step()
+        hip.adamw(p, gr * step, m, v, 1e-3, 0.9, 0.98, 1e-6, 0.2, step)
+    assert rel(p, pt.detach()) < 1e-5
+
+
+def _fresh_model(name):
+    m = get_clip_model(named_config(name))
+    m.load_state_dict(synth_sd(name), strict=True)
+    return m.cuda().eval()
+
+
+def test_gradients_against_reference_autograd(gpu_device):
+    """The whole slice against autograd of the imported reference on the golden batch (fp32 CPU, eval-mode BatchNorm)."""
+    import os
+    name = "b32-yfcc-msclips"
+    g = np.load(os.path.join(GOLDEN, name + ".grads.npz"))
+    m = _fresh_model(name)
+    ts = train.TrainStep(m, lr=1e-4)
+    b = int(g["batch"])
+    img = synth.synth_images(b, seed=int(g["seed"])).cuda()
+    tok = synth.synth_tokens(b, seed=int(g["seed"]) + 1).cuda()
+    loss = ts.forward(img, tok)
+    assert abs(loss.item() - float(g["loss"])) <= 2e-2, (loss.item(), float(g["loss"]))
+    grads = ts.backward()
+    frozen = ("resblocks.0.conv1", "resblocks.0.bn1", "resblocks.0.resnet_stage", "resblocks.0.last_conv", "parallel_branch_v",
+              "top2bottom", "bottom_dw_conv")
+    ref_keys = [k[2:] for k in g.files if k.startswith("g_")]
+    expect = [k for k in ref_keys if not any(f in k for f in frozen)]
+    assert sorted(grads) == sorted(expect), (sorted(set(expect) - set(grads))[:5], sorted(set(grads) - set(expect))[:5])
+    worst, am, coss = {}, {}, {}
+    for k in expect:
+        got = grads[k]
+        ref = g["g_" + k]
+        sm = summarize(got)
+        scale = max(float(g["gmax_" + k]), 1e-12)                     # the tensor's abs-max in the reference
+        err = np.abs(sm[2:] - ref[2:]).max() / scale
+        worst[k] = float(err)
+        am[k] = abs(sm[1] - ref[1]) / (ref[1] + 1e-12)
+        if "gfull_" + k in g.files:
+            full = torch.from_numpy(g["gfull_" + k]).flatten()
+            coss[k] = F.cosine_similarity(got.float().cpu().flatten(), full, dim=0).item()
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:6]
+    print("gradient tensors checked:", len(expect), "worst sample errors:", top)
+    print("median sample error", float(np.median(list(worst.values()))), "worst abs-mean deviations",
+          sorted(am.items(), key=lambda kv: -kv[1])[:4], "lowest cosines", sorted(coss.items(), key=lambda kv: kv[1])[:4])
+    for k in expect:
+        lnb = k.endswith(("ln_1.bias", "ln_2.bias", "ln_final.bias", "ln_post.bias", "ln_pre.bias", "ln_adapt.bias"))
+        assert worst[k] <= (LNB_SAMPLE_TOL if lnb else SAMPLE_TOL), (k, worst[k])
+        assert am[k] <= (LNB_ABSMEAN_TOL if lnb else ABSMEAN_TOL), (k, am[k])
+        if k in coss:
+            assert coss[k] >= (LNB_COS_TOL if lnb else COS_TOL), (k, coss[k])
+    assert float(np.median(list(worst.values()))) <= 3e-2
+    # the shared tensors' gradients are sums over both towers: a text-only / image-only backward must give less
+    assert len([k for k in expect if "visual.transformer.resblocks" in k and ".attn." in k]) == 11 * 4
+
+
+def test_adamw_step_with_reference_param_groups_lowers_the_loss(gpu_device):
+    name = "b32-yfcc-msclips"
+    m = _fresh_model(name)
+    cfg = named_config(name)
+    ts = train.from_config(m, cfg)
+    groups = {k: (lr, wd) for k, _, lr, wd in ts.param_groups()}
+    assert groups["visual.transformer.resblocks.3.mlp.c_fc.weight"] == (cfg.CUSTOM.LR_SHARE, cfg.CUSTOM.WD_SHARE)
+    assert groups["visual.transformer.resblocks.3.mlp.c_fc.bias"][1] == 0.0                # WITHOUT_WD_LIST: bias
+    assert groups["transformer.resblocks.0.mlp.c_fc.weight"] == (cfg.TRAIN.LR, cfg.TRAIN.get("WD", 0.2))
+    assert groups["visual.transformer.resblocks.3.ln_1.weight"][1] == 0.0 and groups["logit_scale"][1] == 0.0
+    img, tok = synth.synth_images(8, seed=51).cuda(), synth.synth_tokens(8, seed=52).cuda()
+    ts.lr, ts.lr_share = 2e-5, 2e-5
+    l0 = ts.forward(img, tok).item()
+    before = m.visual.transformer.resblocks[5].mlp.c_fc.weight.detach().clone()
+    ts.step(ts.backward())
+    assert not torch.equal(before, m.visual.transformer.resblocks[5].mlp.c_fc.weight.detach())
+    assert m.transformer.resblocks[5].mlp.c_fc.weight.data_ptr() == m.visual.transformer.resblocks[5].mlp.c_fc.weight.data_ptr()
+    l1 = ts.forward(img, tok).item()
+    assert abs(l1 - m.contrastive_loss(img, tok).item()) <= 2e-2          # the inference path sees the updated weights
+    ts.saved = None
+    assert l1 < l0, (l0, l1)

@@ -32,7 +32,7 @@ def summarize(t):
     """Compact, order-sensitive summary of a big activation: mean, abs-mean and a
     strided 64-element slice of the flattened tensor."""
     f = t.detach().float().flatten()
-    idx = torch.linspace(0, f.numel() - 1, 64).long()
+    idx = torch.linspace(0, f.numel() - 1, 64).long().clamp_(max=f.numel() - 1)   # (fp32 linspace overshoots past 2^24 elements)
     return np.concatenate([[f.mean().item(), f.abs().mean().item()], f[idx].numpy()]).astype(np.float32)
 
 
@@ -146,6 +146,40 @@ def zeroshot_fixture(model, name):
     print(f"{name}: zero-shot fixture top1 {top1:.2f}% on 64 generated images, W {tuple(W.shape)}")
 
 
+def grads_fixture(model, name):
+    """f3 (backward) fixture: autograd of the REAL reference through forward(image, text) and the symmetric CE
+    0.5 * (CE(logits) + CE(logits^T)) (the loss itself is not in the reference), eval-mode BatchNorm,
+    fp32, the golden batch.  Stored per parameter: mean, abs-mean, abs-max and a 64-point strided sample of the gradient (the
+    shared tensors' gradients are the SUM over both towers: one Parameter object, M.py:2808-2830), plus the loss."""
+    img = synth.synth_images(BATCH, seed=SEED)
+    tok = synth.synth_tokens(BATCH, seed=SEED + 1)
+    R.ensure_single_rank_group()
+    for p in model.parameters():
+        p.grad = None
+        p.requires_grad_(True)
+    logits = model(img, tok)
+    lab = torch.arange(BATCH)
+    loss = 0.5 * (torch.nn.functional.cross_entropy(logits, lab) + torch.nn.functional.cross_entropy(logits.t(), lab))
+    loss.backward()
+    out = {"loss": np.float32(loss.item()), "batch": np.int64(BATCH), "seed": np.int64(SEED)}
+    seen = {}
+    for k, p in model.named_parameters(remove_duplicate=False):
+        if p.grad is None:
+            continue
+        if id(p) in seen:                      # aliases (text-tower names of the shared tensors): same gradient object
+            out["alias_" + k] = np.array(seen[id(p)])
+            continue
+        seen[id(p)] = k
+        out["g_" + k] = summarize(p.grad)
+        out["gmax_" + k] = np.float32(p.grad.abs().max().item())
+        if p.grad.numel() <= 4096:
+            out["gfull_" + k] = p.grad.detach().numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, f"{name}.grads.npz"), **out)
+    print(f"{name}: grads fixture, loss {loss.item():.5f}, {sum(k.startswith('g_') for k in out)} gradient tensors")
+    for p in model.parameters():
+        p.grad = None
+
+
 def multirank_gather_fixture():
     """Reference gather_tensors under 2-rank gloo (lib/utils/comm.py:140-154):
     rank-major concat, and gradient only through the local slice."""
@@ -180,6 +214,7 @@ def main():
         model, _ = run_config(name)
         if name.startswith("b32"):
             zeroshot_fixture(model, name)
+            grads_fixture(model, name)
     multirank_gather_fixture()
 
 
