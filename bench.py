@@ -106,6 +106,10 @@ def main():
     ap.add_argument("--prefill-random", action="store_true",
                     help="probe runs only: fill the workspace with random data first (timing ablation builds of the "
                          "library whose kernels skip their stores; zero-filled operands would raise the clock)")
+    ap.add_argument("--train-slice", action="store_true",
+                    help="time forward + backward + AdamW of the f3 slice (msclip_amd.train: every transformer block, heads, "
+                         "loss, embeddings; the convolutional branch is frozen) instead of the forward step -- a separate, "
+                         "clearly partial metric, never the headline")
     ap.add_argument("--shapes", action="store_true", help="add the per-shape table of the dominant kernel to the record")
     args = ap.parse_args()
 
@@ -134,7 +138,16 @@ def main():
     img = synth.synth_images(B, seed=10 + rank).to(dev)                      # fp32 pixels (reference API), resident in HBM
     tok = synth.synth_tokens(B, seed=100 + rank).to(dev)
 
+    ts = None
+    if args.train_slice:
+        from msclip_amd import train
+        ts = train.from_config(model, named_config(args.model))
+
     def step():
+        if ts is not None:
+            loss = ts.forward(img, tok)
+            ts.step(ts.backward())
+            return loss
         return eng.forward_loss(img, tok, gather=True)
 
     def fence():
@@ -179,10 +192,15 @@ def main():
                                    f"symmetric CE), per-GPU batch {B}, 224x224 images + 77-token captions, "
                                    f"random-init weights", "per_gpu_batch": B, "global_batch": B * world,
                        "parallelism": f"dp{world}", "bn": "eval (folded running statistics)"},
-            "step_tflops_per_gpu": round(pairs_s / world * gf / 1e3, 1),
+            "step_tflops_per_gpu": round(pairs_s / world * gf / 1e3 * (3 if ts is not None else 1), 1),
             "whole_step_mfma_frac": round(pairs_s / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4),
             "loss": round(loss_val, 5),
         }
+        if ts is not None:
+            rec["metric"] = "PARTIAL training step (f3 slice) pairs/sec " + args.model
+            rec["config"]["workload"] = ("forward (activations kept) + backward of the heads, loss, all transformer blocks, "
+                                         "adapters' token path, embeddings + AdamW; conv stem / parallel branch / BatchNorm "
+                                         "frozen (no gradients): NOT a complete training step; FLOPs counted as 3x forward")
         rec["config"]["rccl_ranks"] = dist.get_world_size() if world > 1 else 1
         n = probe.summary()[0] if probe is not None else 0
         if n > 0:                       # tiny batches never reach the ping-pong kernel: no roofline line then

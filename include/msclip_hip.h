@@ -51,13 +51,13 @@ typedef struct msclip_gemm_desc {
   int out_kind;
   float alpha;
   int rpg, radd, roff;   /* rpg > 0; use rpg = INT_MAX, radd = roff = 0 for the identity */
-  int tile;              /* 0 = auto, 1 = 128x128 (4 waves), 2 = 256x256 streaming ring (dense) / two-buffer (conv), 3 = 256x256 two-buffer, 4 = 256x256 ping-pong (dense; what auto picks for large problems), 5 = streaming kernel with LDS-resident weights (K <= 192, or the 3x3 convolutions with 48 input channels; M >= 4096; auto picks it there), 6 = 256x192 two-buffer (implicit conv with N % 192 == 0), 7 = 4-wave 256x256 kernel with the epilogue carried under the next tile's K loop (dense X, bf16 output, no residual, N % 256 == 0, K >= 576, alpha 1; auto picks it for such problems when they fill the chip; EINVAL otherwise) */
+  int tile;              /* 0 = auto, 1 = 128x128 (4 waves), 4 = 256x256 ping-pong (what auto picks for large problems; dense X, or implicit conv with Cin % 64 == 0), 5 = streaming kernel with LDS-resident weights (K <= 192, or the 3x3 convolutions with 48 input channels; M >= 4096; auto picks it there), 6 = 256x192 two-buffer (implicit conv with N % 192 == 0), 7 = 4-wave 256x256 kernel with the epilogue carried under the next tile's K loop (dense X, bf16 output, no residual, N % 256 == 0, K >= 576, alpha 1; auto picks it for such problems when they fill the chip; EINVAL otherwise) */
 } msclip_gemm_desc;
 
 int msclip_gemm(const msclip_gemm_desc* desc, void* stream);
 
-/* Name of the kernel msclip_gemm would launch for this descriptor ("w4", "pp", "ppconv", "stream", "ring", "dense256",
- * "dense128", "conv192", "conv256", "conv128"; "invalid" for rejected arguments): the library's own dispatch rule, so
+/* Name of the kernel msclip_gemm would launch for this descriptor ("w4", "pp", "ppconv", "stream", "dense128",
+ * "conv192", "conv128"; "invalid" for rejected arguments): the library's own dispatch rule, so
  * that measurement code (bench.py's roofline leg) counts exactly the launches of one kernel.  No GPU work. */
 const char* msclip_gemm_variant(const msclip_gemm_desc* desc);
 
@@ -165,8 +165,10 @@ int msclip_transpose_bf16(const void* in, int ldi, void* out, int ldo, int M, in
 /* y = bf16(x) for an fp32 matrix (C, ldx, ldy multiples of 4): gradient streams are fp32, GEMM operands bf16. */
 int msclip_cast_bf16(const float* x, int ldx, void* y, int ldy, int M, int C, void* stream);
 
-/* out[n] (+)= sum_m x[m][n] (x bf16 or fp32): bias gradients, LayerNorm parameter gradients' second stage. */
-int msclip_colsum(const void* x, int ld, int is_f32, float* out, int M, int N, int accumulate, void* stream);
+/* out[n] (+)= sum_m x[m][n] (x bf16 or fp32): bias gradients, LayerNorm parameter gradients' second stage.  chunks > 1:
+ * two deterministic stages through scratch [chunks, N] (row chunks in parallel, then folded); chunks == 1: one launch. */
+int msclip_colsum(const void* x, int ld, int is_f32, float* out, int M, int N, int accumulate, float* scratch, int chunks,
+                  void* stream);
 
 /* QuickGELU on a saved pre-activation and its backward (M.py:222-224): y = h sigma(1.702 h);
  * dh = dy (sigma + 1.702 h sigma (1 - sigma)).  bf16, n % 8 == 0. */

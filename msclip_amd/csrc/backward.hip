@@ -39,12 +39,16 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
 // One block per 64 columns; 4 waves stride the rows, lanes own columns; fixed summation order (deterministic).
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int ld, float* __restrict__ out, int M, int N,
-                                                     int accumulate) {
+                                                     int accumulate, int rows_per_chunk) {
+  // blockIdx.y = row chunk: chunk c sums rows [c * rows_per_chunk, ...) into out[c * N + n] (a [chunks, N] partial matrix
+  // that a second launch with one chunk folds); one chunk: out[n] directly.
   __shared__ float part[4][64];
   const int n = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+  const int m0 = blockIdx.y * rows_per_chunk;
+  const int m1 = min(M, m0 + rows_per_chunk);
   float s = 0.f;
   if (n < N) {
-    for (int m = w; m < M; m += 4) {
+    for (int m = m0 + w; m < m1; m += 4) {
       if constexpr (sizeof(T) == 2) s += bf16_to_f32(x[(size_t)m * ld + n]);
       else s += x[(size_t)m * ld + n];
     }
@@ -53,7 +57,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
   __syncthreads();
   if (w == 0 && n < N) {
     const float t = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
-    out[n] = accumulate ? out[n] + t : t;
+    float* o = out + (size_t)blockIdx.y * N + n;
+    *o = accumulate ? *o + t : t;
   }
 }
 
@@ -341,14 +346,21 @@ extern "C" int msclip_cast_bf16(const float* x, int ldx, void* y, int ldy, int M
   return msclip_launch_status();
 }
 
-extern "C" int msclip_colsum(const void* x, int ld, int is_f32, float* out, int M, int N, int accumulate, void* stream) {
-  if (!x || !out || M <= 0 || N <= 0 || ld < N) return MSCLIP_EINVAL;
+extern "C" int msclip_colsum(const void* x, int ld, int is_f32, float* out, int M, int N, int accumulate, float* scratch,
+                             int chunks, void* stream) {
+  if (!x || !out || M <= 0 || N <= 0 || ld < N || chunks < 1 || (chunks > 1 && !scratch)) return MSCLIP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int rpc = (M + chunks - 1) / chunks;
+  float* first = chunks > 1 ? scratch : out;         // [chunks, N] partials, or the result itself
   if (is_f32)
-    hipLaunchKernelGGL(colsum_kernel<float>, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const float*)x, ld, out,
-                       M, N, accumulate);
+    hipLaunchKernelGGL(colsum_kernel<float>, dim3((N + 63) / 64, chunks), dim3(256), 0, st, (const float*)x, ld, first, M, N,
+                       chunks > 1 ? 0 : accumulate, rpc);
   else
-    hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld,
-                       out, M, N, accumulate);
+    hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3((N + 63) / 64, chunks), dim3(256), 0, st, (const bf16_t*)x, ld, first, M,
+                       N, chunks > 1 ? 0 : accumulate, rpc);
+  if (chunks > 1)
+    hipLaunchKernelGGL(colsum_kernel<float>, dim3((N + 63) / 64, 1), dim3(256), 0, st, (const float*)scratch, N, out, chunks, N,
+                       accumulate, chunks);
   return msclip_launch_status();
 }
 

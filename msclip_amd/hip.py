@@ -93,7 +93,7 @@ def lib():
         ll = ctypes.c_longlong
         L.msclip_transpose_bf16.argtypes = [vp, ci, vp, ci, ci, ci, ci, vp]
         L.msclip_cast_bf16.argtypes = [vp, ci, vp, ci, ci, ci, vp]
-        L.msclip_colsum.argtypes = [vp, ci, ci, vp, ci, ci, ci, vp]
+        L.msclip_colsum.argtypes = [vp, ci, ci, vp, ci, ci, ci, vp, ci, vp]
         L.msclip_quickgelu.argtypes = [vp, vp, ll, vp]
         L.msclip_quickgelu_bwd.argtypes = [vp, vp, vp, ll, vp]
         L.msclip_layernorm_bwd.argtypes = [vp, ci, vp, ci, vp, ci, ci, vp, vp, ci, ci, vp, ci, ci, ci, cf, vp]
@@ -197,8 +197,8 @@ _gemm_probe = {}   # kernel variant -> KernelProbe
 def gemm_variant(desc):
     """Which kernel msclip_gemm dispatches this descriptor to -- asked from the library itself (msclip_gemm_variant):
     'pp' = gemm_pp_kernel<0> (dense 256x256 ping-pong, the default for large problems), 'ppconv' = gemm_pp_kernel<1>,
-    'stream' = gemm_stream_kernel (K <= 192), 'ring', 'dense256'/'dense128' = gemm_kernel<0,...>,
-    'conv192'/'conv256'/'conv128' = gemm_kernel<1,...>."""
+    'stream' = gemm_stream_kernel (K <= 192), 'dense128' = gemm_kernel<0,128,128>, 'conv192'/'conv128' = gemm_kernel<1,...>,
+    'w4' = gemm_w4_kernel (tile 7)."""
     return lib().msclip_gemm_variant(ctypes.byref(desc)).decode()
 
 
@@ -432,8 +432,10 @@ def colsum(x, out=None, M=None, accumulate=False):
     if out is None:
         out = torch.empty(N, dtype=torch.float32, device=x.device)
     assert x.dtype in (torch.float32, torch.bfloat16) and x.stride(-1) == 1
-    _check(lib().msclip_colsum(_p(x), x.stride(0), int(x.dtype == torch.float32), _p(out), M, N, int(accumulate), _stream()),
-           "msclip_colsum")
+    chunks = 1 if M <= 2048 else min(256, (M + 511) // 512)           # long matrices: row chunks in parallel, then folded
+    scratch = torch.empty(chunks, N, dtype=torch.float32, device=x.device) if chunks > 1 else None
+    _check(lib().msclip_colsum(_p(x), x.stride(0), int(x.dtype == torch.float32), _p(out), M, N, int(accumulate),
+                               _p(scratch), chunks, _stream()), "msclip_colsum")
     return out
 
 

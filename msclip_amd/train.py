@@ -36,14 +36,42 @@ _LEAVES = ("attn.in_proj_weight", "attn.in_proj_bias", "attn.out_proj.weight", "
            "mlp.c_fc.weight", "mlp.c_fc.bias", "mlp.c_proj.weight", "mlp.c_proj.bias")
 
 
+_SIDE = {}
+
+
 def _wgrad(dy_bf, x_bf, M):
     """dW[N, K] = dY^T @ X over the first M rows of dy_bf [*, N] and x_bf [*, K] (bf16): both operands transposed so the
-    token axis is the contiguous K axis of the GEMM (zero-padded to a multiple of 64)."""
-    a = hip.transpose_bf16(dy_bf, M)
-    b = hip.transpose_bf16(x_bf, M)
-    out = torch.empty(a.shape[0], b.shape[0], dtype=F32, device=a.device)
-    hip.gemm(a, b, out)
-    return out
+    token axis is the contiguous K axis of the GEMM (zero-padded).  A weight gradient has few output tiles (9-36 of
+    256 x 256) over a very deep contraction (65 024 tokens at batch 512): the contraction is cut into S slices whose
+    GEMMs run concurrently on S side streams into fp32 partials, folded in a fixed order (deterministic)."""
+    N, K = dy_bf.shape[1], x_bf.shape[1]
+    tiles = ((N + 255) // 256) * ((K + 255) // 256)
+    S = 1
+    while S < 16 and tiles * S * 2 <= 256 and M // (S * 2) >= 2048:
+        S *= 2
+    Mpad = (M + 64 * S - 1) // (64 * S) * (64 * S)
+    a = hip.transpose_bf16(dy_bf, M, Mpad)
+    b = hip.transpose_bf16(x_bf, M, Mpad)
+    if S == 1:
+        out = torch.empty(N, K, dtype=F32, device=a.device)
+        hip.gemm(a, b, out)
+        return out
+    kc = Mpad // S
+    part = torch.empty(S, N, K, dtype=F32, device=a.device)
+    cur = torch.cuda.current_stream(a.device)
+    pool = _SIDE.setdefault(a.device, [torch.cuda.Stream(device=a.device) for _ in range(16)])
+    ready = torch.cuda.Event()
+    ready.record(cur)
+    for sidx in range(S):
+        st = pool[sidx]
+        st.wait_event(ready)
+        with torch.cuda.stream(st):
+            hip.gemm(a[:, sidx * kc:(sidx + 1) * kc], b[:, sidx * kc:(sidx + 1) * kc], part[sidx], tile=4)
+        cur.wait_stream(st)
+    for t in (a, b, part):
+        for sidx in range(S):
+            t.record_stream(pool[sidx])
+    return hip.colsum(part.view(S, N * K)).view(N, K)
 
 
 def _dgrad(dy_bf, w_t, out=None):

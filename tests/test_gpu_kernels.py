@@ -34,10 +34,11 @@ def test_gemm_dense_bias_and_shapes(gpu_device, M, N, K):
     close(outf, 0.5 * (x.float() @ w.float().t()) + b, 2e-3, 1e-4)
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4])
+@pytest.mark.parametrize("tile", [1, 4])
 @pytest.mark.parametrize("M,N,K", [(1000, 768, 3072), (700, 520, 128), (256, 256, 64), (2051, 1096, 768)])
 def test_gemm_every_tile_config(gpu_device, tile, M, N, K):
-    """Each main-loop variant (128x128, streaming ring, two-buffer, ping-pong) on ragged edges, all three epilogue kinds."""
+    """Both dense main loops (128x128 two-buffer, 256x256 ping-pong) on ragged edges, all three epilogue kinds (the 4-wave
+    kernel, tile 7, has its own test below)."""
     x, w, b = rnd(M, K, seed=11, dtype=BF), rnd(N, K, seed=12, scale=0.05, dtype=BF), rnd(N, seed=13)
     base = x.float() @ w.float().t() + b
     out = torch.full((M + 3, N), float("nan"), dtype=BF, device="cuda")
@@ -201,7 +202,7 @@ def test_gemm_token_scatter_with_table(gpu_device):
     assert float(got[:, 0].abs().max()) == 0.0 and float(X[B * L:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("tile", [0, 1, 4])
 def test_gemm_token_scatter_every_tile_config(gpu_device, tile):
     """The stem -> token-row scatter with the positional table at a batch where the large-tile kernels take it."""
     B, g2, D, K = 700, 49, 768, 768                                # M = 34300: 134 row tiles of 256

@@ -223,7 +223,8 @@ def test_gemm_dispatch_rule_is_the_librarys_own():
     assert v(0, 65024, 2304, 0, 768) == "pp"            # QKV over image + text rows
     assert v(0, 65024, 768, 0, 3072) == "pp"            # c_proj
     assert v(0, 65024, 768, 4, 768) == "pp"
-    assert v(0, 65024, 768, 2, 768) == "ring"
+    assert v(0, 65024, 768, 2, 768) == "invalid"        # retired main loop
+    assert v(0, 65024, 2304, 7, 768) == "w4"            # opt-in 4-wave kernel with the carried epilogue
     assert v(0, 6422528, 48, 0, 64, ldx=48) == "stream"  # pointwise conv of the conv branch
     assert v(0, 25088, 768, 0, 192) == "stream"         # adapter 1x1
     assert v(0, 512, 512, 0, 768) == "dense128"         # heads
@@ -234,7 +235,7 @@ def test_gemm_dispatch_rule_is_the_librarys_own():
     assert v(1, 401408, 96, 0, 896, c3(512, 56, 96)) == "conv128"
     assert v(1, 1000, 64, 0, 576, (10, 10, 64, 10, 10, 1, 1)) == "conv128"
     assert v(0, 65024, 768, 0, 100) == "invalid"        # K % 64
-    assert v(0, 25088, 768, 0, 64, rpg=49) == "dense256" or v(0, 25088, 768, 0, 64, rpg=49) == "pp"   # row scatter never streams
+    assert v(0, 25088, 768, 0, 64, rpg=49) == "pp"      # row scatter never streams
 
 
 def test_reference_shim_layout_import(tmp_path):

@@ -1,3 +1,5 @@
+// PROBE SNAPSHOT (not built by build.sh, not shipped): the instrumented copy of the product kernel used for the
+// ablation / trace numbers quoted in DESIGN.md; build with tools/probes/build_ablations.sh.
 // bf16 MFMA GEMM for gfx950 with a gathering X-loader and fused epilogues.
 //
 //   out[row(m), n] = epilogue( alpha * sum_k X[m, k] * W[n, k] )
@@ -20,8 +22,8 @@
 //    columns of one row; interior tiles are transposed through the just-consumed LDS slab
 //    so every global store / residual load instruction moves full 128-byte lines.
 #include <type_traits>
-#include "common.h"
-#include "../../include/msclip_hip.h"
+#include "common.h"   // -I msclip_amd/csrc
+#include "../../include/msclip_hip.h"   // relative to msclip_amd/csrc (-I): include/msclip_hip.h
 
 namespace {
 
@@ -33,6 +35,22 @@ struct RowSrc {          // per staged X row (conv mode)
   int ok;
 };
 
+#ifdef PP_TRACE   // probe builds only: cycle stamps of workgroup 0 (waves 0 and 4) of the ping-pong kernel
+__device__ unsigned long long pp_trace_buf[2 * 512];
+struct PpTrace { bool on; int cnt; int grp; };
+__device__ __forceinline__ void pp_stamp(PpTrace& t, int id) {
+  if (t.on && t.cnt < 510) {
+    pp_trace_buf[t.grp * 512 + t.cnt] = ((unsigned long long)id << 56) | (__builtin_amdgcn_s_memtime() & 0xffffffffffffffull);
+    ++t.cnt;
+  }
+}
+#define PP_STAMP(id) pp_stamp(tr, id)
+#define EPI_STAMP(id) if (tr) pp_stamp(*tr, id)
+#else
+struct PpTrace {};
+#define PP_STAMP(id) (void)0
+#define EPI_STAMP(id) (void)0
+#endif
 
 constexpr int STG_BYTES = 4096;   // per-wave staging: 32 rows x 128 B, 16-byte chunks XOR-swizzled by (row & 7)
 
@@ -41,7 +59,7 @@ constexpr int STG_BYTES = 4096;   // per-wave staging: 32 rows x 128 B, 16-byte 
 // add / ReLU / conversion after the transpose (row-contiguous, full-line residual loads).
 template <int TM, int TN>
 __device__ __forceinline__ void epilogue_interior(f32x16 (&acc)[TN][TM], const msclip_gemm_desc& a, char* stg,
-                                                  int mw0, int nw0, int lane) {
+                                                  int mw0, int nw0, int lane, PpTrace* tr = nullptr) {
   const int fr = lane & 31, fhi = lane >> 5;
   const int srow = lane >> 3, sch = lane & 7;      // read-back mapping: row i*8 + srow, 16-byte chunk sch
   const float* __restrict__ bias = a.bias;
@@ -56,9 +74,11 @@ __device__ __forceinline__ void epilogue_interior(f32x16 (&acc)[TN][TM], const m
   char* wr = stg + fr * 128;
   const int wsw = fr & 7;
   const char* rd = stg + srow * 128 + ((sch ^ srow) << 4);      // + i * 1024 for row block i
+  EPI_STAMP(10);
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     const int mrow0 = mw0 + tm * 32;
+    EPI_STAMP(11);
     if (direct16) {                                  // 64 bf16 columns per staged row: TN == 2 only
 #pragma unroll
       for (int tn = 0; tn < (TN == 2 ? TN : 0); ++tn)
@@ -83,8 +103,12 @@ __device__ __forceinline__ void epilogue_interior(f32x16 (&acc)[TN][TM], const m
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const uint4 u = *(const uint4*)(rd + i * 1024);
+#ifndef MSCLIP_ABLATE_EPI
         if (nw0 + sch * 8 < a.N)   // N % 8 == 0 on this path
           *(uint4*)((bf16_t*)a.out + (size_t)(mrow0 + i * 8 + srow) * a.ldo + nw0 + sch * 8) = u;
+#else
+        asm volatile("" ::"v"(u.x), "v"(u.y), "v"(u.z), "v"(u.w));
+#endif
       }
     } else {
 #pragma unroll
@@ -127,6 +151,7 @@ __device__ __forceinline__ void epilogue_interior(f32x16 (&acc)[TN][TM], const m
           if (a.act == 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
           const size_t row = (size_t)(mrow0 + i * 8 + srow);
           const int n = nw0 + tn * 32 + sch * 4;
+#ifndef MSCLIP_ABLATE_EPI
           if (n >= a.N) {
           } else if (a.out_kind == 1) {
             *(float4*)((float*)a.out + row * a.ldo + n) = v;
@@ -136,6 +161,9 @@ __device__ __forceinline__ void epilogue_interior(f32x16 (&acc)[TN][TM], const m
             o.y = pack_bf16x2(v.z, v.w);
             *(uint2*)((bf16_t*)a.out + row * a.ldo + n) = o;
           }
+#else
+          asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w), "v"(row), "v"(n));
+#endif
         }
       }
     }
@@ -181,7 +209,8 @@ __device__ __forceinline__ uint2 ld_global_u2(const void* p) {
 
 template <int TM, int TN, int RK, int ACT, int OUTK>
 __device__ __forceinline__ void epilogue_rows(f32x4 (&acc)[2 * TN][2 * TM], const msclip_gemm_desc& a, unsigned stg,
-                                              int mw0, int nw0, int lane, const float4 (&bias4)[TN]) {
+                                              int mw0, int nw0, int lane, const float4 (&bias4)[TN],
+                                              PpTrace* tr = nullptr) {
   // accumulator layout of v_mfma_f32_16x16x32 with swapped operands: acc[ni][mi][r] = C[mi*16 + lane%16][ni*16 + 4*(lane/16) + r]
   const int r16 = lane & 15, quad = lane >> 4;
   const int srow = lane >> 3, sch = lane & 7;
@@ -213,6 +242,7 @@ __device__ __forceinline__ void epilogue_rows(f32x4 (&acc)[2 * TN][2 * TM], cons
 #pragma unroll
     for (int b = 0; b < RAHEAD; ++b) load_res(b, rv[b]);
   }
+  EPI_STAMP(10);
   f32x4 x[2][4];
   auto stage = [&](int b, f32x4 (&dst)[4]) {                     // block b = tm * TN + tn -> LDS -> row-major registers
     const int tm = b / TN, tn = b % TN;
@@ -230,6 +260,7 @@ __device__ __forceinline__ void epilogue_rows(f32x4 (&acc)[2 * TN][2 * TM], cons
 #pragma unroll
   for (int b = 0; b < TM * TN; ++b) {
     const int tm = b / TN, tn = b % TN;
+    if (tn == 0) { EPI_STAMP(11); }
     f32x4(&xb)[4] = x[b & 1];
     if (b + 1 < TM * TN) {
       stage(b + 1, x[(b + 1) & 1]);
@@ -255,6 +286,7 @@ __device__ __forceinline__ void epilogue_rows(f32x4 (&acc)[2 * TN][2 * TM], cons
       }
       if (act == 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
       const size_t row = (size_t)(mw0 + tm * 32 + i * 8 + srow);
+#ifndef MSCLIP_ABLATE_EPI
       if (n >= a.N) {
       } else if (outk == 1) {
         st_global((float*)a.out + row * a.ldo + n, v);
@@ -264,6 +296,9 @@ __device__ __forceinline__ void epilogue_rows(f32x4 (&acc)[2 * TN][2 * TM], cons
         o.y = pack_bf16x2(v.z, v.w);
         st_global((bf16_t*)a.out + row * a.ldo + n, o);
       }
+#else
+      asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w), "v"(row), "v"(n));
+#endif
     }
     if (rk && b + RAHEAD < TM * TN) load_res(b + RAHEAD, rv[b % RAHEAD]);
   }
@@ -288,7 +323,7 @@ __device__ __forceinline__ u32x4 stg_read16u(unsigned addr) {
 
 template <int TM, int TN, int ACT>
 __device__ __forceinline__ void epilogue_pack16(f32x4 (&acc)[2 * TN][2 * TM], const msclip_gemm_desc& a, unsigned stg,
-                                                int mw0, int nw0, int lane, float bcol) {
+                                                int mw0, int nw0, int lane, float bcol, PpTrace* tr = nullptr) {
   static_assert(TN == 2, "64 bf16 columns = one 128-byte staged row");
   const int r16 = lane & 15, quad = lane >> 4;
   const int srow = lane >> 3, sch = lane & 7;
@@ -314,6 +349,7 @@ __device__ __forceinline__ void epilogue_pack16(f32x4 (&acc)[2 * TN][2 * TM], co
                  :
                  : "memory");
   }
+  EPI_STAMP(10);
   u32x4 x[2][4];
   auto stage = [&](int tm, u32x4 (&dst)[4]) {                    // 32 rows x 64 columns of the wave, packed to bf16
 #pragma unroll
@@ -335,6 +371,7 @@ __device__ __forceinline__ void epilogue_pack16(f32x4 (&acc)[2 * TN][2 * TM], co
   stage(0, x[0]);
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
+    EPI_STAMP(11);
     u32x4(&xb)[4] = x[tm & 1];
     if (tm + 1 < TM) {
       stage(tm + 1, x[(tm + 1) & 1]);
@@ -346,9 +383,13 @@ __device__ __forceinline__ void epilogue_pack16(f32x4 (&acc)[2 * TN][2 * TM], co
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const size_t row = (size_t)(mw0 + tm * 32 + i * 8 + srow);
+#ifndef MSCLIP_ABLATE_EPI
       // non-temporal: the tile leaves faster (QKV 262 -> 249 us, c_fc 378 -> 365 us; +0.7 % on the step), the fp32
       // stream of out_proj / c_proj stays cacheable for the LayerNorm that follows
       if (n < a.N) __builtin_nontemporal_store(xb[i], (AS1 u32x4*)((bf16_t*)a.out + row * a.ldo + n));
+#else
+      asm volatile("" ::"v"(xb[i]), "v"(row), "v"(n));
+#endif
     }
   }
 }
@@ -672,7 +713,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const msclip_gemm
         for (int i = 0; i < TN; ++i)
 #pragma unroll
           for (int j = 0; j < TM; ++j) {
+#ifndef MSCLIP_ABLATE_MFMA
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk & 1][i], xf[kk & 1][j], acc[i][j], 0, 0, 0);
+#else
+            asm volatile("" ::"v"(wf[kk & 1][i]), "v"(xf[kk & 1][j]));
+#endif
           }
         // interleave: one memory instruction behind each MFMA (fragment reads first, then LDS-DMA pieces)
 #pragma unroll
@@ -697,6 +742,210 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const msclip_gemm
     else
       epilogue_generic<TM, TN>(acc, a, vec, cm0 + wm, cn0 + wn, lane);
   }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// Streaming kernel for the dense transformer projections: 256 x 256 tile, 8 waves (2 x 4), K-slabs of 32 in a
+// 4-slot LDS ring (4 x 32 KiB).  Three slabs are always in flight and the synchronisation is software-pipelined.
+// Iteration s (slab s in slot s & 3):
+//   [A] k-step 0 MFMAs  interleaved with  ds_reads of (s, k-step 1)    and 2 LDS-DMA pieces of slab s+3
+//   [B] s_waitcnt vmcnt(6) ; s_barrier                                  -> slab s+1 is published
+//   [C] k-step 1 MFMAs  interleaved with  ds_reads of (s+1, k-step 0)  and 2 LDS-DMA pieces of slab s+3
+// so a slab starts with its first fragments already in registers, and the LDS latency, the DMA latency and the
+// barrier skew sit under MFMAs.  vmcnt(6): younger than slab s+1 are slab s+2 (4 pieces) and the 2 pieces issued in
+// [A]; loads retire in order, so "<= 6 outstanding" implies slab s+1 landed (stores in the queue only make the wait
+// conservative).  Slot (s+3) & 3 == (s-1) & 3 was last read before barrier B(s-1).  The stream runs across tile
+// boundaries (three slabs of the next tile fly under the epilogue).  LDS image per slab: [512 rows][4 chunks of
+// 16 B], physical chunk = logical ^ ((row >> 3) & 3): conflict-free for the 32x32x16 fragment read (PMC: 0).
+//
+// Variants measured on MI355X (M 65024, shared-layer shapes, sum of the four GEMMs): 128x128 two-buffer 1780 us;
+// 256x256 two-buffer 1350 us; this kernel 1262 us; a ping-pong variant (memory / MFMA segments, waves 4-7 one
+// barrier behind) 1354 us.  Ceiling probes: MFMA-only streams clock down to ~1.5 GHz (~1650 TF); MFMA plus the
+// 7.8 GB/s-per-TF DMA stream this tile shape needs, issued from independent waves, reach ~945 TF.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int RBK = 32, RSLOTS = 4, RBM = 256, RBN = 256;
+#ifdef MSCLIP_ABLATE_BARRIER   // probe builds only (timing without workgroup synchronisation; results are garbage)
+#define RING_BARRIER() asm volatile("" ::: "memory")
+#else
+#define RING_BARRIER() __builtin_amdgcn_s_barrier()
+#endif
+
+__global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const msclip_gemm_desc a) {
+  constexpr int NW = 8, TM = 4, TN = 2;
+  static_assert((RBM + RBN) * RBK * 2 >= NW * STG_BYTES, "staging fits one ring slot");
+  __shared__ __attribute__((aligned(1024))) bf16_t smem[RSLOTS][(RBM + RBN) * RBK];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nt_n = (a.N + RBN - 1) / RBN;
+  const int nt_m = (a.M + RBM - 1) / RBM;
+  const int ntiles = nt_n * nt_m;
+  const int nk = a.K / RBK;
+
+  const bf16_t* __restrict__ X = (const bf16_t*)a.X;
+  const bf16_t* __restrict__ W = (const bf16_t*)a.W;
+  const bf16_t* __restrict__ Z = (const bf16_t*)a.zero;
+
+  auto tile_origin = [&](int t, int& m0, int& n0) {
+    const int q = ntiles >> 3, r = ntiles & 7, x = t & 7;
+    const int id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (t >> 3);
+    m0 = (id / nt_n) * RBM;
+    n0 = (id % nt_n) * RBN;
+  };
+
+  // ---- issue side: lane owns (row = (i*8 + wave)*16 + lane/4, physical chunk = lane%4), i = 0..1 per operand
+  const int lc = (lane & 3) ^ ((lane >> 5) | ((wave & 1) << 1));   // == pc ^ ((row >> 3) & 3)
+  const int rsub = lane >> 2;
+  const bf16_t* rowp[4];        // X piece 0, X piece 1, W piece 0, W piece 1 (nullptr = out of range -> zero page)
+  int ti = blockIdx.x, kti = 0, si = 0;
+  auto setup_rows = [&](int t) {
+    int m0, n0;
+    tile_origin(t, m0, n0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = m0 + (i * NW + wave) * 16 + rsub;
+      const int n = n0 + (i * NW + wave) * 16 + rsub;
+      rowp[i] = (m < a.M) ? X + (size_t)m * a.ldx + lc * 8 : nullptr;
+      rowp[2 + i] = (n < a.N) ? W + (size_t)n * a.ldw + lc * 8 : nullptr;
+    }
+  };
+  // sources + LDS slot of the NEXT slab to issue (consumed piece by piece inside the MFMA stream)
+  const bf16_t* src[4];
+  bf16_t* dst0 = nullptr;
+  auto plan_next = [&]() {
+    if (ti < ntiles) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) src[j] = rowp[j] ? rowp[j] + kti * RBK : Z;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) src[j] = Z;      // past the end of the tile list: dummy pieces keep the counts exact
+    }
+    dst0 = smem[si & (RSLOTS - 1)];
+  };
+  auto advance = [&]() {
+    ++si;
+    if (ti < ntiles && ++kti == nk) {
+      kti = 0;
+      ti += gridDim.x;
+      if (ti < ntiles) setup_rows(ti);
+    }
+  };
+  auto piece_dst = [&](int j) -> bf16_t* {
+    return dst0 + (j < 2 ? 0 : RBM * RBK) + ((j & 1) * NW + wave) * 16 * RBK;
+  };
+
+  // ---- compute side
+  const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
+  const int fr = lane & 31, fhi = lane >> 5;
+  const int fsw = (fr >> 3) & 3;
+  const bool vec = !((a.N | a.ldo | (a.resid_kind ? a.ldr : 0)) & 3);
+  const bool plain_rows = a.rpg == 0x7fffffff && a.resid_kind != 3;
+
+  if (ti < ntiles) setup_rows(ti);
+#pragma unroll 1
+  for (int p = 0; p < 3; ++p) {   // prologue: three slabs in flight
+    plan_next();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) glds16(src[j], piece_dst(j));
+    advance();
+  }
+
+  int sc = 0;
+  bf16x8 wf[2][TN], xf[2][TM];
+  auto read_frags = [&](int slot, int kk, int set) {
+    const bf16_t* xs = smem[slot] + (wm + fr) * RBK;
+    const bf16_t* ws = smem[slot] + RBM * RBK + (wn + fr) * RBK;
+    const int ph = ((kk * 2 + fhi) ^ fsw) * 8;
+#pragma unroll
+    for (int i = 0; i < TN; ++i) wf[set][i] = *(const bf16x8*)(ws + i * 32 * RBK + ph);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) xf[set][j] = *(const bf16x8*)(xs + j * 32 * RBK + ph);
+  };
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  RING_BARRIER();
+  asm volatile("" ::: "memory");
+  read_frags(0, 0, 0);
+
+  bool first_tile = true;
+  for (int tc = blockIdx.x; tc < ntiles; tc += gridDim.x) {
+    int cm0, cn0;
+    tile_origin(tc, cm0, cn0);
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    if (!first_tile) {
+      // every wave has finished reading its epilogue staging (slot (sc-1) & 3) before slab sc+3 is DMA'd into it
+      RING_BARRIER();
+      asm volatile("" ::: "memory");
+    }
+    first_tile = false;
+
+    for (int kt = 0; kt < nk; ++kt, ++sc) {
+      plan_next();
+      // ---- [A]
+      read_frags(sc & (RSLOTS - 1), 1, 1);
+      glds16(src[0], piece_dst(0));
+      glds16(src[1], piece_dst(1));
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+#ifndef MSCLIP_ABLATE_MFMA
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0][i], xf[0][j], acc[i][j], 0, 0, 0);
+#else
+          asm volatile("" ::"v"(wf[0][i]), "v"(xf[0][j]));
+#endif
+        }
+#pragma unroll
+      for (int q = 0; q < TM * TN; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   // MFMA
+        if (q < TM + TN) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                   // DS read
+        if (q >= TM * TN - 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);             // VMEM read
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- [B]
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      RING_BARRIER();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- [C]
+      read_frags((sc + 1) & (RSLOTS - 1), 0, 0);
+      glds16(src[2], piece_dst(2));
+      glds16(src[3], piece_dst(3));
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+#ifndef MSCLIP_ABLATE_MFMA
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1][i], xf[1][j], acc[i][j], 0, 0, 0);
+#else
+          asm volatile("" ::"v"(wf[1][i]), "v"(xf[1][j]));
+#endif
+        }
+#pragma unroll
+      for (int q = 0; q < TM * TN; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (q < TM + TN) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if (q >= TM * TN - 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      advance();
+    }
+
+    // Slot (sc-1) & 3 (the tile's last slab) is not read by anyone after the last [B]: it is the staging area.
+    if (vec && plain_rows && cm0 + RBM <= a.M && (cn0 + RBN <= a.N || !(a.N & 7)))
+      epilogue_interior<TM, TN>(acc, a, (char*)smem[(sc + RSLOTS - 1) & (RSLOTS - 1)] + wave * STG_BYTES, cm0 + wm,
+                                cn0 + wn, lane);
+    else
+      epilogue_generic<TM, TN>(acc, a, vec, cm0 + wm, cn0 + wn, lane);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // dummy tail pieces must land before the LDS is released
 }
 
 
@@ -726,7 +975,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const msclip_gemm
 // ------------------------------------------------------------------------------------------------------------
 constexpr int PSLOTS = 10, PREG = 128 * 64;   // ring regions, bf16 elements per region
 
+#ifdef PP_NODS   // probe builds only: fragments come from nowhere
+__device__ __forceinline__ bf16x8 pp_ld(const void* p) {
+  union { unsigned u[4]; bf16x8 v; } x;
+  asm volatile("" : "=v"(x.u[0]), "=v"(x.u[1]), "=v"(x.u[2]), "=v"(x.u[3]) : "v"(p));
+  return x.v;
+}
+#else
 __device__ __forceinline__ bf16x8 pp_ld(const void* p) { return *(const bf16x8*)p; }
+#endif
 
 // MODE 1: implicit GEMM of a convolution whose input-channel count is a multiple of 64 (a K-tile never straddles a
 // filter tap).  X rows are output pixels: the lane keeps the byte offset of its four pixels' window origin and their
@@ -741,6 +998,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2;                       // 0: leading group, 1: one barrier behind
+#ifdef PP_TRACE
+  PpTrace tr{blockIdx.x == 0 && (tid & 255) == 0, 0, grp};
+#endif
   const int nt_n = (a.N + 255) / 256;
   const int nt_m = (a.M + 255) / 256;
   const int ntiles = nt_n * nt_m;
@@ -823,10 +1083,19 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
   auto issue = [&](auto jc) {                      // region j of K-tile (ti, kti) -> ring slot islot
     constexpr int J = decltype(jc)::value;
     bf16_t* dst = smem + islot * PREG + wave * 512;
+#ifdef PP_HOTSRC
+    const unsigned ko = 0;
+#else
     const unsigned ko = (unsigned)kti * 128u;
+#endif
+#ifdef PP_NODMA
+    asm volatile("" ::"s"(ko), "v"(dst));
+#else
     if (J < 2) {
       blds16(rw, vw[0], ko + (J & 1) * whalf, dst);
+#ifndef PP_ONEDMA
       blds16(rw, vw[1], ko + (J & 1) * whalf, dst + 8 * 512);
+#endif
     } else if (MODE == 1) {
       const int kh = (ce >> 20) & 15, kw = (ce >> 24) & 15, doff = (ce & 0xfffff) * 2;
 #pragma unroll
@@ -837,8 +1106,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
       }
     } else {
       blds16(rx, vx[0], ko + (J & 1) * xhalf, dst);
+#ifndef PP_ONEDMA
       blds16(rx, vx[1], ko + (J & 1) * xhalf, dst + 8 * 512);
+#endif
     }
+#endif
     if (MODE == 1 && J == 1) {
       // entry for the X regions of this K-tile, issued two phases on.  A scalar load in inline asm (with its own wait,
       // so the value is valid wherever the compiler keeps or moves it): as a tracked vector load it would sit in the
@@ -875,6 +1147,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
   const int woff = (wave & 1) * 64 * 128;          // byte offset of its 64 rows inside that region
   const char* lds = (const char*)smem;
 
+#ifdef PP_DESYNC   // probe: spread the workgroups' epilogue bursts
+  for (int i = ((blockIdx.x >> 3) & 31) * PP_DESYNC; i > 0; --i) __builtin_amdgcn_s_sleep(8);   // 512-cycle steps
+#endif
   if (MODE == 1)                                   // one descriptor over the whole NHWC input (< 2 GiB, checked by the host)
     rx = make_rsrc(a.X, (unsigned)((long long)(a.M / (a.Ho * a.Wo)) * a.H * a.Wd * a.Cin * 2));
   set_tile(ti);
@@ -914,7 +1189,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
     {
       const int n = cn0 + wn + lane_s;
       const float* p = bsrc + (n < nlast ? n : nlast);
+#ifndef PP_NOEPI
       asm volatile("global_load_dword %0, %1, off" : "=&v"(bcol) : "v"(p));
+#else
+      bcol = 0.f; (void)p;
+#endif
     }
     float4 bias4[TN];
 #pragma unroll
@@ -923,11 +1202,17 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
       n = n + 3 < nlast ? n : (nlast & ~3);
       const float* p = bsrc + (vec ? n : 0);
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#ifndef PP_NOEPI
       asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(v) : "v"(p));
+#else
+      (void)p;
+#endif
       bias4[i] = make_float4(v[0], v[1], v[2], v[3]);
     }
+    PP_STAMP(1);
 
     for (int kt = 0; kt < nk; ++kt) {
+      if (kt) { PP_STAMP(2); }
       int s1 = cslot + wsub, s2 = cslot + 2 + grp;
       if (s1 >= PSLOTS) s1 -= PSLOTS;
       if (s2 >= PSLOTS) s2 -= PSLOTS;
@@ -935,8 +1220,16 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
       const char* xreg = lds + s2 * (PREG * 2);
       cslot = cslot + 4 >= PSLOTS ? cslot + 4 - PSLOTS : cslot + 4;
 
+#ifdef PP_NOPRIO
+#define PP_PRIO(x) (void)0
+#else
 #define PP_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#endif
+#ifdef PP_NOLGK
+#define PP_LGK() asm volatile("" ::: "memory")
+#else
 #define PP_LGK() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#endif
 #define PP_SYNC_IN()                                   \
   __builtin_amdgcn_sched_barrier(0);                   \
   __builtin_amdgcn_s_barrier();                        \
@@ -960,6 +1253,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) xf[j][ks] = pp_ld(xreg + j * 2048 + la[ks]);
+#ifndef PP_4PHASE
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -968,6 +1262,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
         issue(I0{});
         issue(I1{});
       }
+#endif
       PP_SYNC_IN();
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
@@ -976,6 +1271,18 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
 #pragma unroll
           for (int i = 0; i < 2; ++i)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[i][ks], xf[j][ks], acc[i][j], 0, 0, 0);
+#ifdef PP_4PHASE
+      PP_SYNC_OUT();
+
+      // ---- phase 1: W sub 1 -> quadrant (0, 1)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) w1[i][ks] = pp_ld(wreg + 4096 + i * 2048 + la[ks]);
+      issue(I0{});
+      issue(I1{});
+      PP_SYNC_IN();
+#endif
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -990,6 +1297,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) xf[j][ks] = pp_ld(xreg + 8192 + j * 2048 + la[ks]);
+#ifndef PP_4PHASE
       if (!kt) {
         issue(I0{});
         issue(I1{});
@@ -999,6 +1307,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
       if (kt == 0 && nk >= 3 && epi_stores == 16) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
       else if (kt == 0 && nk >= 3 && epi_stores == 32) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#endif
       PP_SYNC_IN();
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
@@ -1007,8 +1316,29 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
 #pragma unroll
           for (int i = 0; i < 2; ++i)
             acc[2 + i][4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[i][ks], xf[j][ks], acc[2 + i][4 + j], 0, 0, 0);
+#ifdef PP_4PHASE
+      PP_SYNC_OUT();
+#endif
 
       // ---- phase 3: nothing new to read -> quadrant (1, 0); the next K-tile's regions are waited for here
+#ifdef PP_4PHASE
+      issue(I2{});
+      issue(I3{});
+#ifndef PP_NOWAIT
+      // First K-tile after an epilogue: the regions this wait is for (K-tile 1's) were issued BEFORE the epilogue's
+      // stores, but the VM counter retires in order, so "at most 8 in flight" would also wait for the write
+      // acknowledgements of the whole output tile (+2 k cycles on the first K-tile of every c_fc tile in the phase
+      // trace).  The stores are younger than those regions and older than this K-tile's 8 pieces: leaving 8 + (a lower
+      // bound of their number) in flight asks for exactly the regions.  K-tile 1's wait is the strict one again.
+#ifndef PP_NORELAX
+      if (kt == 0 && nk >= 3 && epi_stores == 16) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+      else if (kt == 0 && nk >= 3 && epi_stores == 32) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+      else
+#endif
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#endif
+      PP_SYNC_IN();
+#endif
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -1022,12 +1352,23 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
     // Both groups run the epilogue together: the leading group waits one barrier, the trailing one re-staggers after.
     // Staging = the ring slots of the last K-tile's X regions (dead since its phase 2; re-issued in phase 1 of the
     // next tile, behind a barrier every wave reaches only after its epilogue).
+    PP_STAMP(3);
     if (!grp) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    PP_STAMP(4);
     {
       int ss = cslot + 8 + (wave >> 2);            // cslot already points 4 ahead: X regions of the last K-tile = cslot - 2, - 1
       while (ss >= PSLOTS) ss -= PSLOTS;
       const unsigned stg = (unsigned)(size_t)(AS3 bf16_t*)smem + ss * (PREG * 2) + (wave & 3) * STG_BYTES;
+#ifdef PP_NOEPI
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) asm volatile("" ::"v"(acc[i][j][r]));
+      asm volatile("" ::"v"(stg));
+#else
       // lane id recomputed from scratch: the epilogue's lane constants must not live (spilled) across the main loop
       int lane_e;
       asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
@@ -1035,26 +1376,46 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
       if (vec && plain_rows && cm0 + 256 <= a.M)
       {
         const bool full_n = cn0 + 256 <= a.N;      // no lane's store is predicated off
+#ifdef PP_TRACE
+        PpTrace* trp = &tr;
+#else
+        PpTrace* trp = nullptr;
+#endif
         const int mw0 = cm0 + wm, nw0 = cn0 + wn;
+#ifdef PP_OLDEPI
+        (void)trp;
+        epilogue_interior<TM, TN>(acc, a, (char*)smem + ss * (PREG * 2) + (wave & 3) * STG_BYTES, mw0, nw0, lane_e);
+#else
+#ifndef PP_ROWS16
         const bool pack16 = a.resid_kind == 0 && a.out_kind == 0 && !((a.N | a.ldo) & 7);
         if (full_n) epi_stores = pack16 && a.act <= 2 ? 4 * TM : 4 * TM * TN;   // 16 / 32 store instructions per wave
         if (pack16 && a.act == 0)
-          epilogue_pack16<TM, TN, 0>(acc, a, stg, mw0, nw0, lane_e, bcol);               // QKV
+          epilogue_pack16<TM, TN, 0>(acc, a, stg, mw0, nw0, lane_e, bcol, trp);               // QKV
         else if (pack16 && a.act == 1)
-          epilogue_pack16<TM, TN, 1>(acc, a, stg, mw0, nw0, lane_e, bcol);               // c_fc + QuickGELU
+          epilogue_pack16<TM, TN, 1>(acc, a, stg, mw0, nw0, lane_e, bcol, trp);               // c_fc + QuickGELU
         else if (pack16 && a.act == 2)
-          epilogue_pack16<TM, TN, 2>(acc, a, stg, mw0, nw0, lane_e, bcol);               // convolution + ReLU
+          epilogue_pack16<TM, TN, 2>(acc, a, stg, mw0, nw0, lane_e, bcol, trp);               // convolution + ReLU
+#else
+        if (a.resid_kind == 0 && a.act == 0 && a.out_kind == 0)
+          epilogue_rows<TM, TN, 0, 0, 0>(acc, a, stg, mw0, nw0, lane_e, bias4, trp);
+        else if (a.resid_kind == 0 && a.act == 1 && a.out_kind == 0)
+          epilogue_rows<TM, TN, 0, 1, 0>(acc, a, stg, mw0, nw0, lane_e, bias4, trp);
+#endif
         else if (a.resid_kind == 1 && a.act == 0 && a.out_kind == 1)
-          epilogue_rows<TM, TN, 1, 0, 1>(acc, a, stg, mw0, nw0, lane_e, bias4);          // out_proj / c_proj into the fp32 stream
+          epilogue_rows<TM, TN, 1, 0, 1>(acc, a, stg, mw0, nw0, lane_e, bias4, trp);          // out_proj / c_proj into the fp32 stream
         else
-          epilogue_rows<TM, TN, -1, -1, -1>(acc, a, stg, mw0, nw0, lane_e, bias4);       // pointwise convolutions, heads
+          epilogue_rows<TM, TN, -1, -1, -1>(acc, a, stg, mw0, nw0, lane_e, bias4, trp);       // pointwise convolutions, heads
+#endif
       }
       else
         epilogue_generic16<TM, TN>(acc, a, vec, cm0 + wm, cn0 + wn, lane_e);
+#endif
     }
+    PP_STAMP(5);
     if (grp) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   }
+  PP_STAMP(6);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing empty pieces must retire before the LDS is released
 #undef PP_SYNC_IN
 #undef PP_SYNC_OUT
@@ -1079,6 +1440,11 @@ static void launch_cfg(const msclip_gemm_desc* d, hipStream_t st, int blocks_per
   hipLaunchKernelGGL((gemm_kernel<MODE, BM, BN, WM, WN>), dim3(grid), dim3(WM * WN * 64), 0, st, *d);
 }
 
+#ifdef PP_TRACE
+extern "C" int msclip_pp_trace(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(pp_trace_buf), sizeof(unsigned long long) * 1024) == hipSuccess ? 0 : -1;
+}
+#endif
 
 bool msclip_gemm_small_try(const msclip_gemm_desc* d, hipStream_t st, int ncu);   // gemm_small.hip
 bool msclip_gemm_small_eligible(const msclip_gemm_desc* d);
@@ -1097,8 +1463,9 @@ static int device_cus() {
 }
 
 // ---- kernel choice: ONE function decides, msclip_gemm launches what it says and msclip_gemm_variant reports it
-enum GemmVariant { GV_INVALID = 0, GV_STREAM, GV_PP, GV_DENSE128, GV_PPCONV, GV_CONV192, GV_CONV128, GV_W4 };
-static const char* const kVariantName[] = {"invalid", "stream", "pp", "dense128", "ppconv", "conv192", "conv128", "w4"};
+enum GemmVariant { GV_INVALID = 0, GV_STREAM, GV_PP, GV_RING, GV_DENSE256, GV_DENSE128, GV_PPCONV, GV_CONV192, GV_CONV256, GV_CONV128, GV_W4 };
+static const char* const kVariantName[] = {"invalid", "stream", "pp", "ring", "dense256", "dense128", "ppconv", "conv192",
+                                           "conv256", "conv128", "w4"};
 
 static GemmVariant pick_variant(const msclip_gemm_desc* d) {
   if (!d || !d->X || !d->W || !d->out || !d->zero) return GV_INVALID;
@@ -1110,8 +1477,7 @@ static GemmVariant pick_variant(const msclip_gemm_desc* d) {
   if (d->rpg <= 0) return GV_INVALID;
   // tile choice: the 256x256 / 8-wave config whenever the problem fills the chip with it, else 128x128
   const long long big_tiles = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256);
-  if (d->tile < 0 || d->tile > 7 || d->tile == 2 || d->tile == 3) return GV_INVALID;   // 2, 3: retired main loops
-  const bool big = d->tile >= 4 || (d->tile == 0 && d->N >= 192 && big_tiles >= 128);
+  const bool big = d->tile >= 2 || (d->tile == 0 && d->N >= 192 && big_tiles >= 128);
   if ((d->tile == 0 || d->tile == 5) && msclip_gemm_small_eligible(d)) return GV_STREAM;
   if (d->tile == 7) return msclip_gemm_w4_eligible(d) ? GV_W4 : GV_INVALID;
   // (the 4-wave kernel with the carried epilogue, gemm_w4.hip, is opt-in through tile = 7: its main loop matches the
@@ -1124,7 +1490,8 @@ static GemmVariant pick_variant(const msclip_gemm_desc* d) {
                        (long long)d->ldw * 2 * 256 + (long long)d->K * 2 < (1ll << 31) &&
                        big_tiles * ((d->M + 255) / 256) * 4 < (1ll << 32);
     if (pp_ok && (d->tile == 4 || (d->tile == 0 && big))) return GV_PP;     // ping-pong kernel (default for the projections)
-    return GV_DENSE128;                        // small problems, heads, logits (and tile 1)
+    if (big && d->tile != 3) return GV_RING;   // streaming ring kernel (tile 2; tile 3 selects the two-buffer 256x256 kernel: A/B tests)
+    return big ? GV_DENSE256 : GV_DENSE128;
   }
   // input channels a multiple of 64 (a K-tile stays inside one filter tap): the ping-pong kernel gathers the rows itself
   const long long in_bytes = (long long)(d->M / (d->Ho * d->Wo)) * d->H * d->Wd * d->Cin * 2;
@@ -1135,7 +1502,7 @@ static GemmVariant pick_variant(const msclip_gemm_desc* d) {
   // N a multiple of 192 (192 / 384 / 768 output channels): 256 x 192 tiles leave no idle columns
   const long long t192 = (long long)((d->M + 255) / 256) * ((d->N + 191) / 192);
   if (d->tile == 6 || (d->tile == 0 && d->N % 192 == 0 && t192 >= 128)) return GV_CONV192;
-  return GV_CONV128;
+  return big ? GV_CONV256 : GV_CONV128;
 }
 
 extern "C" const char* msclip_gemm_variant(const msclip_gemm_desc* d) { return kVariantName[pick_variant(d)]; }
@@ -1152,8 +1519,11 @@ extern "C" int msclip_gemm(const msclip_gemm_desc* d, void* stream) {
     case GV_W4: msclip_gemm_w4_launch(d, st); break;
     case GV_PP: hipLaunchKernelGGL(gemm_pp_kernel<0>, dim3(grid), dim3(512), 0, st, *d); break;
     case GV_PPCONV: hipLaunchKernelGGL(gemm_pp_kernel<1>, dim3(grid), dim3(512), 0, st, *d); break;
+    case GV_RING: hipLaunchKernelGGL(gemm_ring_kernel, dim3(grid), dim3(512), 0, st, *d); break;
+    case GV_DENSE256: launch_cfg<0, 256, 256, 2, 4>(d, st, 1); break;
     case GV_DENSE128: launch_cfg<0, 128, 128, 2, 2>(d, st, 2); break;
     case GV_CONV192: launch_cfg<1, 256, 192, 4, 2>(d, st, 1); break;
+    case GV_CONV256: launch_cfg<1, 256, 256, 2, 4>(d, st, 1); break;
     case GV_CONV128: launch_cfg<1, 128, 128, 2, 2>(d, st, 2); break;
     default: return MSCLIP_EINVAL;
   }

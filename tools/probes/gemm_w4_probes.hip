@@ -1,3 +1,5 @@
+// PROBE SNAPSHOT (not built by build.sh, not shipped): the instrumented copy of the product kernel used for the
+// ablation / trace numbers quoted in DESIGN.md; build with tools/probes/build_ablations.sh.
 // bf16 MFMA GEMM for gfx950 whose epilogue runs UNDER the next tile's main loop.
 //
 //   out[m, n] = act( sum_k X[m, k] * W[n, k] + bias[n] )        bf16 output, dense row-major X [M, K], W [N, K]
@@ -32,8 +34,8 @@
 //  * VM counter (in order): per iteration W pieces (8), X pieces (8), then the unit's 4 stores; sync waits vmcnt(8 + 4):
 //    everything up to this iteration's W pieces has landed, the stores of an iteration get a whole K-tile to retire.
 #include <type_traits>
-#include "common.h"
-#include "../../include/msclip_hip.h"
+#include "common.h"   // -I msclip_amd/csrc
+#include "../../include/msclip_hip.h"   // relative to msclip_amd/csrc (-I): include/msclip_hip.h
 
 namespace {
 
@@ -224,6 +226,9 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const msclip_gemm_desc 
   // iteration, whose sync retires them; first used one iteration later.
   auto retarget_epilogue = [&](int m0, int n0, bool valid) {
     const unsigned long long ob = (unsigned long long)(a.M - m0) * (unsigned long long)a.ldo * 2ull - (unsigned long long)n0 * 2ull;
+#ifdef W4_PROBE_DROPSTORES   // timing probe: every store out of range (issued and counted, no memory traffic)
+    valid = false;
+#endif
     ro = valid ? make_rsrc((bf16_t*)a.out + (size_t)m0 * a.ldo + n0, ob > 0xffffffffull ? 0xffffffffu : (unsigned)ob)
                : make_rsrc(a.out, 0);
     const float* bp = a.bias ? a.bias + n0 + wc * 128 + quad * 32 + eb * 8 : (const float*)a.zero;
@@ -241,6 +246,14 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const msclip_gemm_desc 
   auto unit_slice = [&](auto uc, auto gc) {
     constexpr int U = decltype(uc)::value;
     constexpr int G = decltype(gc)::value;
+#ifdef W4_PROBE_RAWSTORE   // timing probe: the stores without the transposes / bias / activation
+    if constexpr (G >= 16 && ((G - 16) & 3) == 3) {
+      constexpr int sl = (G - 16) >> 2;
+      eo = u32x4{carry[U][sl * 4], carry[U][sl * 4 + 1], carry[U][sl * 4 + 2], carry[U][sl * 4 + 3]};
+      __builtin_amdgcn_raw_buffer_store_b128(eo, ro, (int)ovoff, (int)((unsigned)(U * 16 + sl) * ldo2), 2);
+    }
+    return;
+#endif
     if constexpr (G < 8) {
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
@@ -364,6 +377,11 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const msclip_gemm_desc 
   bool have_prev = false;
   for (int tc = blockIdx.x; tc < ntiles; tc += gridDim.x) {
     // first K-tile: G 0..3 finish the previous tile, then its accumulators are packed into the carry
+#ifdef W4_PROBE_NOEPI   // timing probe: main loop only (results are garbage)
+    for (int kt = 0; kt < 9; ++kt) iteration(MP{}, I0{});
+    for (int kt = 9; kt < nk; ++kt) iteration(MP{}, I0{});
+    continue;
+#endif
     retarget_epilogue(lm0, ln0, have_prev);
     iteration(MF{}, I0{});
     tile_origin(tc, lm0, ln0);
@@ -384,6 +402,10 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const msclip_gemm_desc 
   W4_TAIL(0, 2) W4_TAIL(1, 2) W4_TAIL(2, 2) W4_TAIL(3, 2)
 #undef W4_TAIL
   asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");     // last MFMA's D -> v_accvgpr_read: hipcc pads nothing around asm
+#ifdef W4_PROBE_NOEPI
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  return;
+#endif
   retarget_epilogue(lm0, ln0, true);
   w4_pack_all(carry);
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(biasv[0]), "+v"(biasv[1])::"memory");   // bias arrived; trailing dummy pieces retired
