@@ -452,3 +452,17 @@ def test_two_rank_rccl_gather_matches_single_process(gpu_device, tmp_path):
     assert got["logits"].shape == (12, 12)
     assert (got["logits"] - ref_logits).abs().max().item() <= 2e-2          # per-rank batch 6 vs 12: other tile grids
     assert abs(got["loss"] - ref_loss) <= 2e-3
+
+
+def test_conv_branch_on_side_stream_is_bitwise_the_inline_schedule(gpu_device, monkeypatch):
+    """MSCLIP_CONV_SIDE_STREAM=1 issues the parallel convolutional branch + the adapters' top-down halves on a side HIP
+    stream (they depend on the image only) with one event per adapter: same kernels, same data, bitwise the same result."""
+    m = model_for("b32-yfcc-msclips")
+    img = synth.synth_images(6, seed=91).cuda()
+    tok = synth.synth_tokens(6, seed=92).cuda()
+    a = m.engine().run(img, tok)
+    fi, ft = a["fv"].clone(), a["ft"].clone()
+    monkeypatch.setenv("MSCLIP_CONV_SIDE_STREAM", "1")
+    for _ in range(3):                                                 # back-to-back steps: buffer reuse across steps
+        b = m.engine().run(img, tok)
+        assert torch.equal(b["fv"], fi) and torch.equal(b["ft"], ft)
