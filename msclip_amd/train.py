@@ -213,15 +213,26 @@ class TrainStep:
             return out[0].clone()
 
     # ------------------------------------------------------------------ backward
-    def backward(self):
+    def backward(self, reduce=True, bucket_bytes=64 << 20):
         """-> {reference state_dict key: fp32 gradient} for every parameter of the slice (shared tensors under their
-        visual.* key; the text-tower aliases are the same Parameter objects)."""
+        visual.* key; the text-tower aliases are the same Parameter objects).  Under N > 1 ranks (and reduce=True) the
+        gradients are averaged over the ranks as the reference's DDP wrapper would: every gradient goes into a
+        comm.GradReducer bucket the moment it exists, and the buckets' RCCL all-reduces run on the side stream under
+        the rest of the backward (last block's bucket first)."""
         e, sv = self.eng, self.saved
         dev, D, E = e.dev, e.D, e.E
         with torch.cuda.device(dev), torch.no_grad():
             Bi, Bt, Mv, M, n, off = sv["Bi"], sv["Bt"], sv["Mv"], sv["M"], sv["n"], sv["off"]
             s = e.logit_scale_exp
-            grads = {}
+            reducer = C.GradReducer(bucket_bytes) if (reduce and C.comm.world_size > 1) else None
+            self.reducer = reducer
+
+            class _Grads(dict):
+                def __setitem__(self, k, v):
+                    dict.__setitem__(self, k, v)
+                    if reducer is not None:
+                        reducer.add(k, v)
+            grads = _Grads()
             # ---- contrastive head: dL/dS blocks of this rank's image rows and caption rows
             npad = (n + 63) // 64 * 64
             wgt = 1.0 / (2.0 * n)
@@ -336,7 +347,7 @@ class TrainStep:
             grads["visual.positional_embedding"] = dvpos
             grads["visual.class_embedding"] = dvpos[0].clone()
             self.saved = None
-            return grads
+            return reducer.finish() if reducer is not None else dict(grads)
 
     # ------------------------------------------------------------------ optimizer
     def param_groups(self):
@@ -359,9 +370,10 @@ class TrainStep:
             out.append((k, p, lr, wd))
         return out
 
-    def step(self, grads, world_average=True):
-        """AdamW on the module's fp32 parameters (msclip_adamw), then the engine re-packs its bf16 copies.  Under
-        N > 1 ranks the per-rank gradients are averaged first (what the reference's DDP wrapper would do)."""
+    def step(self, grads, world_average=False):
+        """AdamW on the module's fp32 parameters (msclip_adamw), then the engine re-packs its bf16 copies.  backward()
+        already returns rank-averaged gradients; world_average=True averages here instead, tensor by tensor (for
+        gradients produced with backward(reduce=False))."""
         self.steps += 1
         with torch.no_grad():
             for k, p, lr, wd in self.param_groups():

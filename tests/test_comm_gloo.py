@@ -45,6 +45,21 @@ def _worker(rank, world, port, q):
     dist.all_reduce(part)
     full = O.contrastive_loss(O.clip_logits(feats[:, 0], feats[:, 1], torch.tensor(s).log()))
     res["loss_sharded"], res["loss_full"] = float(part), float(full)
+    # bucketed gradient averaging (train.py backward): 7 tensors of mixed shapes, a bucket of 64 floats -> several
+    # collectives, the last one partial; every rank must end up with the rank mean under the original names / shapes
+    red = C.GradReducer(bucket_bytes=64 * 4)
+    shapes = [(5, 7), (3,), (40,), (2, 3, 4), (1,), (9, 9), ()]
+    mine = {}
+    for i, sh in enumerate(shapes):
+        gg = torch.Generator().manual_seed(1000 * rank + i)
+        mine[f"p{i}"] = torch.randn(sh, generator=gg)
+        red.add(f"p{i}", mine[f"p{i}"].clone())
+    avg = red.finish()
+    ok = list(avg.keys()) == [f"p{i}" for i in range(len(shapes))] and red.launched >= 3
+    for i, sh in enumerate(shapes):
+        both = [torch.randn(sh, generator=torch.Generator().manual_seed(1000 * r + i)) for r in range(world)]
+        ok = ok and avg[f"p{i}"].shape == torch.Size(sh) and torch.allclose(avg[f"p{i}"], sum(both) / world, atol=1e-6)
+    res["reducer_ok"], res["reducer_launched"] = bool(ok), red.launched
     if rank == 0:
         q.put(res)
     dist.barrier()
@@ -61,6 +76,7 @@ def test_two_rank_gather_and_sharded_loss():
     np.testing.assert_array_equal(res["gathered"], ref["gathered"])      # same values/order as the reference's gather
     np.testing.assert_array_equal(res["grad"], ref["grad_rank0"])        # gradient only through the local slice
     assert res["rank"] == 0 and res["world"] == 2 and res["off"] == 0 and res["packed_ok"] and res["async_ok"]
+    assert res["reducer_ok"], res["reducer_launched"]
     assert abs(res["loss_sharded"] - res["loss_full"]) < 1e-5
 
 
@@ -69,4 +85,7 @@ def test_single_process_is_world_one():
     t = torch.randn(2, 4)
     assert C.comm.world_size == 1 and C.comm.rank == 0 and C.comm.is_main_process()
     assert C.gather_tensors(t) is t and C.gather_features(t) is t
+    red = C.GradReducer()
+    red.add("a", t)
+    assert red.finish()["a"] is t and red.launched == 0          # world 1: pass-through, no collective
     C.comm.synchronize()
