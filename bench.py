@@ -107,9 +107,9 @@ def main():
                     help="probe runs only: fill the workspace with random data first (timing ablation builds of the "
                          "library whose kernels skip their stores; zero-filled operands would raise the clock)")
     ap.add_argument("--train-slice", action="store_true",
-                    help="time forward + backward + AdamW of the f3 slice (msclip_amd.train: every transformer block, heads, "
-                         "loss, embeddings; the convolutional branch is frozen) instead of the forward step -- a separate, "
-                         "clearly partial metric, never the headline")
+                    help="time forward + backward + AdamW of the training step (msclip_amd.train: every parameter gets a "
+                         "gradient; BatchNorm with frozen running statistics) instead of the forward step -- a separate "
+                         "metric, never the headline")
     ap.add_argument("--shapes", action="store_true", help="add the per-shape table of the dominant kernel to the record")
     args = ap.parse_args()
 
@@ -197,10 +197,12 @@ def main():
             "loss": round(loss_val, 5),
         }
         if ts is not None:
-            rec["metric"] = "PARTIAL training step (f3 slice) pairs/sec " + args.model
-            rec["config"]["workload"] = ("forward (activations kept) + backward of the heads, loss, all transformer blocks, "
-                                         "adapters' token path, embeddings + AdamW; conv stem / parallel branch / BatchNorm "
-                                         "frozen (no gradients): NOT a complete training step; FLOPs counted as 3x forward")
+            rec["metric"] = "training step (forward + backward + AdamW, frozen BatchNorm statistics) pairs/sec " + args.model
+            rec["config"]["workload"] = ("forward (activations kept) + backward of every parameter (heads, loss, all "
+                                         "transformer blocks, adapters, conv stem, parallel conv branch, embeddings) + AdamW + "
+                                         "bucketed gradient all-reduce at N > 1; BatchNorm uses its running statistics "
+                                         "(gamma / beta trained, statistics frozen); FLOPs counted as 3x forward")
+            rec["config"]["bn"] = "frozen running statistics (folded); gamma / beta receive gradients"
         rec["config"]["rccl_ranks"] = dist.get_world_size() if world > 1 else 1
         n = probe.summary()[0] if probe is not None else 0
         if n > 0:                       # tiny batches never reach the ping-pong kernel: no roofline line then

@@ -207,6 +207,28 @@ int msclip_adapter_sum(const float* xin, int ldx, const float* t, int ldt, const
 int msclip_adapter_dx(const float* dsum, int lds, const float* dww, float* dx, int lddx, int B, int L, int g, int C,
                       int usecls, void* stream);
 
+/* ---- convolutional side of the backward pass (csrc/backward_conv.hip).  The contractions run on msclip_gemm:
+ * dW = dY^T . im2col(X), dX = col2im(dY . W); reference forward: M.py:1898-2000 (stem), 1812-1895 (parallel branch),
+ * 1752-1778 (adapters).
+ * msclip_im2col: x_kind 0 = NHWC bf16 [B, H, W, C], 1 = NCHW fp32 image, 2 = NCHW bf16 image; col bf16 [B*Ho*Wo, Kp],
+ *   column (kh*KW + kw)*C + ci (the packed forward weights' K order), zero beyond KH*KW*C and outside the image.
+ * msclip_col2im: dcol bf16 [B*Ho*Wo, ld] -> dx NHWC bf16 (C % 8 == 0), optionally added to what dx holds.
+ * msclip_relu_bwd: out = (dy [+ dy2]) * (y > 0) over n bf16 elements (n % 8 == 0; dy2 may be null). */
+int msclip_im2col(const void* x, int x_kind, void* col, int B, int H, int W, int C, int KH, int KW, int stride, int pad,
+                  int Ho, int Wo, int Kp, void* stream);
+int msclip_col2im(const void* dcol, int ld, void* dx, int B, int H, int W, int C, int KH, int KW, int stride, int pad, int Ho,
+                  int Wo, int accumulate, void* stream);
+int msclip_relu_bwd(const void* dy, const void* dy2, const void* y, void* out, long long n, void* stream);
+/* Adapters' kernel == stride depthwise conv (msclip_dwpool): input gradient (dtop NHWC bf16, optionally accumulated) and
+ * filter gradient as `slabs` partial sums part[slabs][k*k][C] fp32 (fold with msclip_colsum: deterministic). */
+int msclip_dwpool_bwd(const void* dpool, int ldp, const float* w, void* dtop, int B, int H, int W, int C, int k,
+                      int accumulate, void* stream);
+int msclip_dwpool_wgrad(const void* dpool, int ldp, const void* top, float* part, int B, int H, int W, int C, int k,
+                        int slabs, void* stream);
+/* Filter gradient of the depthwise 3x3 over the token grid (msclip_adapter_sum's dww): part[slabs][9][C] fp32. */
+int msclip_dw3x3_wgrad(const float* dsum, int lds, const float* x, int ldx, float* part, int B, int L, int g, int C,
+                       int slabs, void* stream);
+
 /* AdamW with decoupled weight decay on one fp32 tensor (step >= 1 for the bias corrections). */
 int msclip_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
                  float weight_decay, int step, void* stream);

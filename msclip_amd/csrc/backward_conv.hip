@@ -1,0 +1,276 @@
+// Backward of the convolutional side of the vision tower: the EarlyconvRes stem, the parallel
+// convolutional branch and the top-down / depthwise halves of the lateral adapters (reference M.py:1898-2000,
+// 1812-1895, 1752-1778).  The contractions themselves run on the MFMA GEMM (msclip_gemm): a convolution's weight
+// gradient is dY^T . im2col(X) and its input gradient is col2im(dY . W), so what lives here is the data movement around
+// those GEMMs and the small depthwise reductions:
+//
+//   msclip_im2col          NHWC bf16 (or the NCHW fp32 / bf16 input image) -> patch matrix [pixels, Kp] bf16,
+//                          K index (kh*KW + kw)*C + ci like the packed forward weights (packing.conv_weight_matrix)
+//   msclip_col2im          patch-matrix gradient -> NHWC bf16 input gradient (gather form: no atomics, deterministic)
+//   msclip_relu_bwd        (dy [+ dy2]) * (y > 0)
+//   msclip_dwpool_bwd      input gradient of the adapters' kernel == stride depthwise conv
+//   msclip_dwpool_wgrad    its filter gradient, per-slab partial sums [S][k*k][C] (the caller folds them with msclip_colsum)
+//   msclip_dw3x3_wgrad     filter gradient of the depthwise 3x3 over the token grid, per-slab partials [S][9][C]
+//
+// All of them are HBM-bound streaming kernels: 16-byte accesses, consecutive lanes on consecutive channel chunks.
+#include "common.h"
+#include "../../include/msclip_hip.h"
+
+namespace {
+
+static int grid_for(size_t n, int per_block, int cap = 1 << 20) {
+  size_t b = (n + per_block - 1) / per_block;
+  return (int)(b < 1 ? 1 : (b > (size_t)cap ? cap : b));
+}
+
+// one thread = one (pixel, 8-wide K chunk); grid-stride over pixels*Kp/8
+template <int KIND>   // 0: NHWC bf16 with C % 8 == 0 (vector path), 1: NCHW fp32 image, 2: NCHW bf16 image, 3: NHWC bf16 any C
+__global__ __launch_bounds__(256) void im2col_kernel(const void* __restrict__ xin, bf16_t* __restrict__ col, int B, int H,
+                                                     int W, int C, int KH, int KW, int stride, int pad, int Ho, int Wo,
+                                                     int Kp) {
+  const int kc = Kp >> 3, K = KH * KW * C;
+  const size_t total = (size_t)B * Ho * Wo * kc;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int c8 = (int)(idx % kc);
+    const size_t pix = idx / kc;
+    const int b = (int)(pix / ((size_t)Ho * Wo));
+    const int rem = (int)(pix - (size_t)b * Ho * Wo);
+    const int oh = rem / Wo, ow = rem - oh * Wo;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (KIND == 0) {
+      const int k0 = c8 * 8;
+      if (k0 < K) {
+        const int tap = k0 / C, ci = k0 - tap * C;
+        const int kh = tap / KW, kw = tap - kh * KW;
+        const int ih = oh * stride - pad + kh, iw = ow * stride - pad + kw;
+        if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+          v = *(const uint4*)((const bf16_t*)xin + (((size_t)b * H + ih) * W + iw) * C + ci);
+      }
+    } else {
+      unsigned short e[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = c8 * 8 + j;
+        e[j] = 0;
+        if (k < K) {
+          const int tap = k / C, ci = k - tap * C;
+          const int kh = tap / KW, kw = tap - kh * KW;
+          const int ih = oh * stride - pad + kh, iw = ow * stride - pad + kw;
+          if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
+            if (KIND == 1) e[j] = f32_to_bf16(((const float*)xin)[(((size_t)b * C + ci) * H + ih) * W + iw]);
+            else if (KIND == 2) e[j] = ((const bf16_t*)xin)[(((size_t)b * C + ci) * H + ih) * W + iw];
+            else e[j] = ((const bf16_t*)xin)[(((size_t)b * H + ih) * W + iw) * C + ci];
+          }
+        }
+      }
+      v.x = e[0] | ((unsigned)e[1] << 16); v.y = e[2] | ((unsigned)e[3] << 16);
+      v.z = e[4] | ((unsigned)e[5] << 16); v.w = e[6] | ((unsigned)e[7] << 16);
+    }
+    *(uint4*)(col + pix * Kp + (size_t)c8 * 8) = v;
+  }
+}
+
+// one thread = one input pixel's 8-channel chunk; sums the patch-matrix entries of every (output pixel, tap) that read it
+__global__ __launch_bounds__(256) void col2im_kernel(const bf16_t* __restrict__ dcol, int ld, bf16_t* __restrict__ dx, int B,
+                                                     int H, int W, int C, int KH, int KW, int stride, int pad, int Ho, int Wo,
+                                                     int accumulate) {
+  const int nch = C >> 3;
+  const size_t total = (size_t)B * H * W * nch;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int cc = (int)(idx % nch);
+    const size_t ipix = idx / nch;
+    const int b = (int)(ipix / ((size_t)H * W));
+    const int rem = (int)(ipix - (size_t)b * H * W);
+    const int ih = rem / W, iw = rem - ih * W;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    if (accumulate) {
+      float f[8];
+      unpack_bf16x8(*(const uint4*)(dx + ipix * C + cc * 8), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = f[e];
+    }
+    for (int kh = 0; kh < KH; ++kh) {
+      const int th = ih + pad - kh;
+      if (th < 0 || th % stride) continue;
+      const int oh = th / stride;
+      if (oh >= Ho) continue;
+      for (int kw = 0; kw < KW; ++kw) {
+        const int tw = iw + pad - kw;
+        if (tw < 0 || tw % stride) continue;
+        const int ow = tw / stride;
+        if (ow >= Wo) continue;
+        float f[8];
+        unpack_bf16x8(*(const uint4*)(dcol + (((size_t)b * Ho + oh) * Wo + ow) * ld + (size_t)(kh * KW + kw) * C + cc * 8), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += f[e];
+      }
+    }
+    uint4 o;
+    o.x = pack_bf16x2(acc[0], acc[1]); o.y = pack_bf16x2(acc[2], acc[3]);
+    o.z = pack_bf16x2(acc[4], acc[5]); o.w = pack_bf16x2(acc[6], acc[7]);
+    *(uint4*)(dx + ipix * C + cc * 8) = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const uint4* __restrict__ dy, const uint4* __restrict__ dy2,
+                                                       const uint4* __restrict__ y, uint4* __restrict__ out, size_t n8) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    float d[8], yy[8];
+    unpack_bf16x8(dy[i], d);
+    unpack_bf16x8(y[i], yy);
+    if (dy2) {
+      float d2[8];
+      unpack_bf16x8(dy2[i], d2);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d[e] += d2[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) d[e] = yy[e] > 0.f ? d[e] : 0.f;
+    uint4 o;
+    o.x = pack_bf16x2(d[0], d[1]); o.y = pack_bf16x2(d[2], d[3]);
+    o.z = pack_bf16x2(d[4], d[5]); o.w = pack_bf16x2(d[6], d[7]);
+    out[i] = o;
+  }
+}
+
+// dtop[b, ih, iw, c] (+)= dpool[b, ih/k, iw/k, c] * w[(ih%k)*k + iw%k][c]    (windows do not overlap: k == stride)
+__global__ __launch_bounds__(256) void dwpool_bwd_kernel(const bf16_t* __restrict__ dpool, int ldp, const float* __restrict__ w,
+                                                         bf16_t* __restrict__ dtop, int B, int H, int W, int C, int k,
+                                                         int accumulate) {
+  const int nch = C >> 3, g = H / k;
+  const size_t total = (size_t)B * H * W * nch;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int cc = (int)(idx % nch);
+    const size_t ipix = idx / nch;
+    const int b = (int)(ipix / ((size_t)H * W));
+    const int rem = (int)(ipix - (size_t)b * H * W);
+    const int ih = rem / W, iw = rem - ih * W;
+    const int gy = ih / k, gx = iw / k, ky = ih - gy * k, kx = iw - gx * k;
+    float d[8], acc[8];
+    unpack_bf16x8(*(const uint4*)(dpool + (((size_t)b * g + gy) * g + gx) * ldp + cc * 8), d);
+    const float* wr = w + (size_t)(ky * k + kx) * C + cc * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = d[e] * wr[e];
+    if (accumulate) {
+      float f[8];
+      unpack_bf16x8(*(const uint4*)(dtop + ipix * C + cc * 8), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += f[e];
+    }
+    uint4 o;
+    o.x = pack_bf16x2(acc[0], acc[1]); o.y = pack_bf16x2(acc[2], acc[3]);
+    o.z = pack_bf16x2(acc[4], acc[5]); o.w = pack_bf16x2(acc[6], acc[7]);
+    *(uint4*)(dtop + ipix * C + cc * 8) = o;
+  }
+}
+
+// part[s][tap][c] = sum over the output positions of slab s of dpool[pos][c] * top[window(pos) + tap][c].
+// grid (k*k, S); a thread owns channels threadIdx.x, + 256, ... and walks the slab's positions (coalesced over c).
+__global__ __launch_bounds__(256) void dwpool_wgrad_kernel(const bf16_t* __restrict__ dpool, int ldp,
+                                                           const bf16_t* __restrict__ top, float* __restrict__ part, int B,
+                                                           int H, int W, int C, int k, int S) {
+  const int tap = blockIdx.x, s = blockIdx.y, ky = tap / k, kx = tap - ky * k, g = H / k;
+  const size_t npos = (size_t)B * g * g;
+  const size_t p0 = npos * s / S, p1 = npos * (s + 1) / S;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float acc = 0.f;
+    for (size_t p = p0; p < p1; ++p) {
+      const int b = (int)(p / ((size_t)g * g));
+      const int rem = (int)(p - (size_t)b * g * g);
+      const int gy = rem / g, gx = rem - gy * g;
+      acc += bf16_to_f32(dpool[p * ldp + c]) * bf16_to_f32(top[(((size_t)b * H + gy * k + ky) * W + gx * k + kx) * C + c]);
+    }
+    part[((size_t)s * k * k + tap) * C + c] = acc;
+  }
+}
+
+// part[s][tap][c] = sum over samples of slab s and grid positions of dsum[b, 1+pos, c] * x[b, 1 + neighbour(pos, tap), c]
+__global__ __launch_bounds__(256) void dw3x3_wgrad_kernel(const float* __restrict__ dsum, int lds, const float* __restrict__ x,
+                                                          int ldx, float* __restrict__ part, int B, int L, int g, int C, int S) {
+  const int tap = blockIdx.x, s = blockIdx.y, ky = tap / 3, kx = tap - ky * 3;
+  const int b0 = (int)((long long)B * s / S), b1 = (int)((long long)B * (s + 1) / S);
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float acc = 0.f;
+    for (int b = b0; b < b1; ++b)
+      for (int py = 0; py < g; ++py) {
+        const int yy = py + ky - 1;
+        if (yy < 0 || yy >= g) continue;
+        for (int px = 0; px < g; ++px) {
+          const int xx = px + kx - 1;
+          if (xx < 0 || xx >= g) continue;
+          acc += dsum[((size_t)b * L + 1 + py * g + px) * lds + c] * x[((size_t)b * L + 1 + yy * g + xx) * ldx + c];
+        }
+      }
+    part[((size_t)s * 9 + tap) * C + c] = acc;
+  }
+}
+
+}  // namespace
+
+extern "C" int msclip_im2col(const void* x, int x_kind, void* col, int B, int H, int W, int C, int KH, int KW, int stride,
+                             int pad, int Ho, int Wo, int Kp, void* stream) {
+  if (!x || !col || B <= 0 || H <= 0 || W <= 0 || C <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0 || Ho <= 0 || Wo <= 0)
+    return MSCLIP_EINVAL;
+  if ((Kp % 8) || Kp < KH * KW * C || x_kind < 0 || x_kind > 2) return MSCLIP_EINVAL;
+  const size_t total = (size_t)B * Ho * Wo * (Kp / 8);
+  const int grid = grid_for(total, 256);
+  hipStream_t st = (hipStream_t)stream;
+#define IM2COL(KIND)                                                                                                   \
+  hipLaunchKernelGGL(im2col_kernel<KIND>, dim3(grid), dim3(256), 0, st, x, (bf16_t*)col, B, H, W, C, KH, KW, stride, pad, \
+                     Ho, Wo, Kp)
+  if (x_kind == 1) IM2COL(1);
+  else if (x_kind == 2) IM2COL(2);
+  else if (C % 8 == 0) IM2COL(0);
+  else IM2COL(3);
+#undef IM2COL
+  return msclip_launch_status();
+}
+
+extern "C" int msclip_col2im(const void* dcol, int ld, void* dx, int B, int H, int W, int C, int KH, int KW, int stride,
+                             int pad, int Ho, int Wo, int accumulate, void* stream) {
+  if (!dcol || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0)
+    return MSCLIP_EINVAL;
+  if ((ld % 8) || ld < KH * KW * C || Ho <= 0 || Wo <= 0) return MSCLIP_EINVAL;
+  const size_t total = (size_t)B * H * W * (C / 8);
+  hipLaunchKernelGGL(col2im_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dcol, ld,
+                     (bf16_t*)dx, B, H, W, C, KH, KW, stride, pad, Ho, Wo, accumulate);
+  return msclip_launch_status();
+}
+
+extern "C" int msclip_relu_bwd(const void* dy, const void* dy2, const void* y, void* out, long long n, void* stream) {
+  if (!dy || !y || !out || n <= 0 || (n % 8)) return MSCLIP_EINVAL;
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for((size_t)n / 8, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint4*)dy, (const uint4*)dy2, (const uint4*)y, (uint4*)out, (size_t)n / 8);
+  return msclip_launch_status();
+}
+
+extern "C" int msclip_dwpool_bwd(const void* dpool, int ldp, const float* w, void* dtop, int B, int H, int W, int C, int k,
+                                 int accumulate, void* stream) {
+  if (!dpool || !w || !dtop || B <= 0 || k <= 0 || H <= 0 || H != W || (H % k) || (C % 8) || (ldp % 8) || ldp < C)
+    return MSCLIP_EINVAL;
+  const size_t total = (size_t)B * H * W * (C / 8);
+  hipLaunchKernelGGL(dwpool_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dpool,
+                     ldp, w, (bf16_t*)dtop, B, H, W, C, k, accumulate);
+  return msclip_launch_status();
+}
+
+extern "C" int msclip_dwpool_wgrad(const void* dpool, int ldp, const void* top, float* part, int B, int H, int W, int C,
+                                   int k, int slabs, void* stream) {
+  if (!dpool || !top || !part || B <= 0 || k <= 0 || H <= 0 || H != W || (H % k) || C <= 0 || ldp < C || slabs <= 0 ||
+      slabs > 65535)
+    return MSCLIP_EINVAL;
+  hipLaunchKernelGGL(dwpool_wgrad_kernel, dim3(k * k, slabs), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dpool, ldp,
+                     (const bf16_t*)top, part, B, H, W, C, k, slabs);
+  return msclip_launch_status();
+}
+
+extern "C" int msclip_dw3x3_wgrad(const float* dsum, int lds, const float* x, int ldx, float* part, int B, int L, int g, int C,
+                                  int slabs, void* stream) {
+  if (!dsum || !x || !part || B <= 0 || L != g * g + 1 || C <= 0 || lds < C || ldx < C || slabs <= 0 || slabs > 65535)
+    return MSCLIP_EINVAL;
+  hipLaunchKernelGGL(dw3x3_wgrad_kernel, dim3(9, slabs), dim3(256), 0, (hipStream_t)stream, dsum, lds, x, ldx, part, B, L, g, C,
+                     slabs);
+  return msclip_launch_status();
+}

@@ -56,6 +56,7 @@ class Engine:
         self.dev = ref.device
         self.model = model
         self._ws = {}
+        self.force_unfused = False      # the training step runs the conv side layer by layer: every map stays in the workspace
         with torch.cuda.device(self.dev), torch.no_grad():
             self._pack(model)
         self._stamp = self._fingerprint()
@@ -247,7 +248,7 @@ class Engine:
     def _vision_front(self, img, w, Bi, taps=None, keep_pre=None):
         """Stem + tokenisation (M.py:2416-2426) and stage 0 of the parallel branch (M.py:2436)."""
         first = self.stem_specs[0]
-        fused = (self.dual_w.shape[1] == 96 and self._fusable_3x3s2(first) and not hip.env_flag("MSCLIP_FRONT_UNFUSED")
+        fused = (self.dual_w.shape[1] == 96 and self._fusable_3x3s2(first) and not (hip.env_flag("MSCLIP_FRONT_UNFUSED") or self.force_unfused)
                  and img.numel() * img.element_size() < 2 ** 31
                  and Bi * self.h1 * self.h1 * (self.D // 16) * 2 < 2 ** 31)      # the kernel's own 32-bit offset limits
         if fused:
@@ -283,7 +284,7 @@ class Engine:
         t1, t2, tr = w["par_tmp"][j]
         src = w["par"][j - 1]
         lead = ((c1.kh, c1.kw, c1.stride, c1.pad, c1.cin, c1.cout) == (1, 1, 1, 0, 48, 48) and self._fusable_3x3s2(c2)
-                and not hip.env_flag("MSCLIP_FRONT_UNFUSED") and src.numel() * 2 < 2 ** 31)
+                and not (hip.env_flag("MSCLIP_FRONT_UNFUSED") or self.force_unfused) and src.numel() * 2 < 2 ** 31)
         if (lead and c2.cout == 48 and (cr.kh, cr.kw, cr.stride, cr.pad, cr.cin, cr.cout) == (1, 1, 2, 0, 48, 96)
                 and (c3.kh, c3.kw, c3.stride, c3.pad, c3.cin, c3.cout) == (1, 1, 1, 0, 48, 96)
                 and (cr.h_out, cr.w_out) == (c2.h_out, c2.w_out) and not hip.env_flag("MSCLIP_BLOCK_UNFUSED")):

@@ -22,7 +22,8 @@ EXPORTS = (
     "msclip_lse_rows", "msclip_clip_loss_partial", "msclip_clip_lse_fused", "msclip_clip_loss_from_partials",
     "msclip_transpose_bf16", "msclip_cast_bf16", "msclip_colsum", "msclip_quickgelu", "msclip_quickgelu_bwd", "msclip_layernorm_bwd",
     "msclip_attention_bwd", "msclip_l2norm_bwd", "msclip_clip_loss_bwd_g", "msclip_embed_tokens_bwd", "msclip_adapter_sum",
-    "msclip_adapter_dx", "msclip_adamw",
+    "msclip_adapter_dx", "msclip_adamw", "msclip_im2col", "msclip_col2im", "msclip_relu_bwd", "msclip_dwpool_bwd",
+    "msclip_dwpool_wgrad", "msclip_dw3x3_wgrad",
     "msclip_abi_version", "msclip_build_arch",
 )
 
@@ -104,6 +105,12 @@ def lib():
         L.msclip_adapter_sum.argtypes = [vp, ci, vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
         L.msclip_adapter_dx.argtypes = [vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, vp]
         L.msclip_adamw.argtypes = [vp, vp, vp, vp, ll, cf, cf, cf, cf, cf, ci, vp]
+        L.msclip_im2col.argtypes = [vp, ci, vp] + [ci] * 11 + [vp]
+        L.msclip_col2im.argtypes = [vp, ci, vp] + [ci] * 11 + [vp]
+        L.msclip_relu_bwd.argtypes = [vp, vp, vp, vp, ll, vp]
+        L.msclip_dwpool_bwd.argtypes = [vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, vp]
+        L.msclip_dwpool_wgrad.argtypes = [vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, vp]
+        L.msclip_dw3x3_wgrad.argtypes = [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp]
         L.msclip_abi_version.restype = ci
         L.msclip_build_arch.restype = ctypes.c_char_p
         for name in EXPORTS:
@@ -507,6 +514,67 @@ def adapter_dx(dsum, dww, dx, B, L, g, usecls):
     _check(lib().msclip_adapter_dx(_p(dsum), dsum.stride(0), _p(dww), _p(dx), dx.stride(0), B, L, g, dsum.shape[1],
                                    int(usecls), _stream()), "msclip_adapter_dx")
     return dx
+
+
+def im2col(x, B, H, W, C, KH, KW, stride, pad, image=False):
+    """Patch matrix [B*Ho*Wo, Kp] bf16 of an NHWC bf16 activation (or of the NCHW fp32 / bf16 input image), Kp = KH*KW*C
+    rounded up to 64, column (kh*KW + kw)*C + ci."""
+    Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    Kp = (KH * KW * C + 63) // 64 * 64
+    n = B * Ho * Wo * Kp
+    flat = torch.empty(n + 64, dtype=torch.bfloat16, device=x.device)      # 64 elements of slack behind the matrix
+    col = flat[:n].view(B * Ho * Wo, Kp)
+    kind = (1 if x.dtype == torch.float32 else 2) if image else 0
+    if not image:
+        _bf16(x)
+    _check(lib().msclip_im2col(_p(x), kind, _p(col), B, H, W, C, KH, KW, stride, pad, Ho, Wo, Kp, _stream()), "msclip_im2col")
+    return col
+
+
+def col2im(dcol, dx, B, H, W, C, KH, KW, stride, pad, accumulate=False):
+    Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    _bf16(dcol)
+    _bf16(dx)
+    _check(lib().msclip_col2im(_p(dcol), dcol.stride(0), _p(dx), B, H, W, C, KH, KW, stride, pad, Ho, Wo, int(accumulate),
+                               _stream()), "msclip_col2im")
+    return dx
+
+
+def relu_bwd(dy, y, out=None, dy2=None):
+    """(dy [+ dy2]) * (y > 0) on bf16 tensors of equal size."""
+    _bf16(dy)
+    _bf16(y)
+    if out is None:
+        out = torch.empty_like(dy)
+    assert dy.is_contiguous() and y.is_contiguous() and out.is_contiguous() and dy.numel() == y.numel() == out.numel()
+    _check(lib().msclip_relu_bwd(_p(dy), _p(dy2) if dy2 is not None else None, _p(y), _p(out), dy.numel(), _stream()),
+           "msclip_relu_bwd")
+    return out
+
+
+def dwpool_bwd(dpool, w, dtop, B, H, W, C, k, accumulate=False):
+    _check(lib().msclip_dwpool_bwd(_p(dpool), dpool.stride(0), _p(w), _p(dtop), B, H, W, C, k, int(accumulate), _stream()),
+           "msclip_dwpool_bwd")
+    return dtop
+
+
+def dwpool_wgrad(dpool, top, B, H, W, C, k):
+    """-> fp32 [k*k, C]: gradient of msclip_dwpool's filter table."""
+    S = max(1, min(64, 4096 // (k * k)))
+    part = torch.empty(S, k * k * C, dtype=torch.float32, device=dpool.device)
+    _check(lib().msclip_dwpool_wgrad(_p(dpool), dpool.stride(0), _p(top), _p(part), B, H, W, C, k, S, _stream()),
+           "msclip_dwpool_wgrad")
+    return colsum(part).view(k * k, C)
+
+
+def dw3x3_wgrad(dsum, x, B, L, g):
+    """-> fp32 [9, C]: gradient of the token-grid depthwise 3x3 filter of msclip_adapter_sum."""
+    C = dsum.shape[1]
+    S = max(1, min(64, B))
+    part = torch.empty(S, 9 * C, dtype=torch.float32, device=dsum.device)
+    _check(lib().msclip_dw3x3_wgrad(_p(dsum), dsum.stride(0), _p(x), x.stride(0), _p(part), B, L, g, C, S, _stream()),
+           "msclip_dw3x3_wgrad")
+    return colsum(part).view(9, C)
 
 
 def adamw(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):

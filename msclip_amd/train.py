@@ -29,6 +29,7 @@ import torch.distributed as dist
 
 from . import comm as C
 from . import hip
+from .train_conv import ConvSideBackward
 
 BF = torch.bfloat16
 F32 = torch.float32
@@ -96,6 +97,12 @@ class TrainStep:
 
     # ------------------------------------------------------------------ forward that keeps what the backward needs
     def forward(self, img, tok):
+        try:
+            return self._forward(img, tok)
+        finally:
+            self.eng.force_unfused = False
+
+    def _forward(self, img, tok):
         e = self.eng
         e.refresh()
         with torch.cuda.device(e.dev), torch.no_grad():
@@ -111,7 +118,9 @@ class TrainStep:
             sv = dict(Bi=Bi, Bt=Bt, Mv=Mv, M=M, layers=[None] * e.n_layers, tok=e._check_tok(tok))
             # ---- fronts (the conv side is frozen: nothing of it is saved but the tokens in front of ln_pre)
             keep = []
-            e._vision_front(e._check_img(img), w, Bi, keep_pre=keep)
+            sv["img"] = e._check_img(img)
+            e.force_unfused = True                   # layer-by-layer conv side: every map the backward reads stays in `w`
+            e._vision_front(sv["img"], w, Bi, keep_pre=keep)
             sv["tok_pre"] = keep[0]
             g2 = e.g * e.g
             e._text_front(sv["tok"], w, Bt)
@@ -128,8 +137,9 @@ class TrainStep:
                     hip.gemm(w["pool"][j], a["pw"].weight, w["T"], M=Bi * g2, N=a["pw"].cout, bias=a["pw"].bias, ldx=a["pw"].cin)
                     asum = torch.empty(Mv, D, dtype=F32, device=e.dev)
                     hip.adapter_sum(X[:Mv], w["T"], a["dww"], a["dwb"], asum, Bi, e.Lv, e.g, e.usecls)
+                    x_pre = X[:Mv].clone()                                                   # what the depthwise 3x3 read
                     hip.layernorm(asum, a["ln"].g, a["ln"].b, X[:Mv], Mv)                    # X[:Mv] <- ln_adapt(sum), fp32
-                    L["adapter"] = dict(j=j, sum=asum)
+                    L["adapter"] = dict(j=j, sum=asum, x_pre=x_pre)
                 segs = ([(0, Mv, vb)] if vb is not None else []) + [(Mv, M, tb)]
                 r_lo = segs[0][0]
                 L["x_in"] = X[r_lo:M].clone()
@@ -161,6 +171,7 @@ class TrainStep:
                 L.update(r_lo=r_lo, segs=segs, groups=groups, lno1=lno1, qkv=qkv, ao=ao, lno2=lno2, h=h)
                 del hid
                 sv["layers"][i] = L
+            e.force_unfused = False
             # ---- heads + loss
             sv["x_out"] = X[:M].clone()
             e._head_image(w, Bi)
@@ -256,6 +267,8 @@ class TrainStep:
             grads["logit_scale"] = dscale.reshape(())
 
             dX = torch.zeros(M, D, dtype=F32, device=dev)
+            conv = ConvSideBackward(self)
+            conv.begin(sv["img"], e._workspace(Bi, Bt), Bi)
 
             def head(feat_raw, dfeat, hrow, w_proj, ln, key_proj, key_ln, row_idx=None, row_mul=1):
                 dfr = torch.empty_like(feat_raw)
@@ -333,6 +346,7 @@ class TrainStep:
                     dg, db = hip.layernorm_bwd(ad["sum"], dX[:Mv], a["ln"].g, dsum, Mv, accumulate=False)
                     pre = f"visual.transformer.parallel_lateral_adapter.{ad['j']}.ln_adapt"
                     grads[pre + ".weight"], grads[pre + ".bias"] = dg, db
+                    conv.adapter(grads, ad["j"], dsum, ad["x_pre"])      # adapter convs + parallel stage j (train_conv.py)
                     hip.adapter_dx(dsum, a["dww"], dX[:Mv], Bi, e.Lv, e.g, e.usecls)
                 sv["layers"][i] = None                                                         # free the layer's activations
             # ---- fronts: text embedding, image cls / positional embeddings, ln_pre
@@ -346,6 +360,7 @@ class TrainStep:
             dvpos = hip.colsum(dtok.view(Bi, e.Lv * D)).view(e.Lv, D)                           # sum over the batch
             grads["visual.positional_embedding"] = dvpos
             grads["visual.class_embedding"] = dvpos[0].clone()
+            conv.stem(grads, dtok)
             self.saved = None
             return reducer.finish() if reducer is not None else dict(grads)
 

@@ -1,4 +1,4 @@
-"""Backward pass (first slice) on a real MI355X.
+"""Backward pass on a real MI355X.
 
 * every backward kernel against a plain fp32 PyTorch statement (autograd of the same op);
 * the whole slice -- contrastive head, both projections, every transformer block of both towers with the modality-shared
@@ -12,7 +12,13 @@ abs-max (median over the 211 tensors <= 3 %; measured 2.2 %, worst 5 %), abs-mea
 LayerNorm BIAS gradients are column sums of nearly cancelling rows at the golden batch of 4 (abs-mean 15 x below the
 matching weight gradient's): 25 % / 15 % / cosine 0.95 for those.  The error is dominated by the forward: the bf16 towers'
 unit features differ from the fp32 reference's by ~1e-3, i.e. ~0.03 on a logit at T = 1/0.07, a few percent on every
-softmax probability the gradient starts from."""
+softmax probability the gradient starts from.
+The convolutional side (stem, parallel branch, adapter convolutions, every BatchNorm's gamma / beta with FROZEN running
+statistics -- the fixture is eval-mode autograd) is a third class: its gradients pass through up to ten ReLU masks evaluated
+on bf16 activations and, at the golden batch of 4, its per-channel BatchNorm gradients are cancelling sums over few
+pixels: sample error <= 25 % of the tensor's abs-max (measured: median 4.7 %, worst 22 %), abs-mean within 6 % (measured
+worst 3.7 %), cosine >= 0.975 (measured lowest 0.980).  The kernels underneath (im2col / col2im / depthwise gradients) are
+pinned to 1e-5 against autograd of F.conv2d in the unit tests above."""
 import numpy as np
 import pytest
 import torch
@@ -27,6 +33,9 @@ pytestmark = pytest.mark.gpu
 BF = torch.bfloat16
 SAMPLE_TOL, ABSMEAN_TOL, COS_TOL = 0.08, 0.05, 0.995
 LNB_SAMPLE_TOL, LNB_ABSMEAN_TOL, LNB_COS_TOL = 0.25, 0.15, 0.95
+CONV_SAMPLE_TOL, CONV_ABSMEAN_TOL, CONV_COS_TOL = 0.25, 0.06, 0.975
+CONV_SIDE = ("resblocks.0.conv1", "resblocks.0.bn1", "resblocks.0.resnet_stage", "resblocks.0.last_conv", "parallel_branch_v",
+             "top2bottom", "bottom_dw_conv")
 
 
 def rnd(*shape, seed=0, scale=1.0, dtype=torch.float32):
@@ -169,6 +178,80 @@ def test_l2norm_loss_embed_adapter_adamw(gpu_device):
     assert rel(p, pt.detach()) < 1e-5
 
 
+@pytest.mark.parametrize("geom", [(2, 12, 16, 3, 2, 1), (3, 9, 8, 1, 2, 0), (2, 8, 24, 3, 1, 1), (2, 10, 3, 3, 2, 1)])
+def test_im2col_col2im_against_conv_autograd(gpu_device, geom):
+    """dW = dY^T . im2col(X) and dX = col2im(dY . W) against autograd of F.conv2d (fp32 on the same bf16 values);
+    the last geometry is the 3-channel NCHW image path (no input gradient)."""
+    B, H, C, k, s, pad = geom
+    co = 16
+    image = C == 3
+    Ho = (H + 2 * pad - k) // s + 1
+    x = rnd(B, C, H, H, seed=1).to(BF).float()                         # NCHW values exactly representable in bf16
+    wgt = rnd(co, C, k, k, seed=2, scale=0.3).to(BF).float()
+    dy = rnd(B, co, Ho, Ho, seed=3).to(BF).float()
+    xr = x.clone().requires_grad_(True)
+    wr = wgt.clone().requires_grad_(True)
+    F.conv2d(xr, wr, stride=s, padding=pad).backward(dy)
+    if image:
+        col = hip.im2col(x.contiguous(), B, H, H, C, k, k, s, pad, image=True)
+    else:
+        col = hip.im2col(x.permute(0, 2, 3, 1).contiguous().to(BF).view(B * H * H, C), B, H, H, C, k, k, s, pad)
+    K = k * k * C
+    assert col.shape == (B * Ho * Ho, (K + 63) // 64 * 64) and torch.all(col[:, K:] == 0)
+    dy2 = dy.permute(0, 2, 3, 1).reshape(B * Ho * Ho, co)
+    dw = (dy2.t() @ col.float()[:, :K]).view(co, k, k, C).permute(0, 3, 1, 2)
+    assert rel(dw, wr.grad) <= 1e-5
+    if not image:
+        wm = wgt.permute(0, 2, 3, 1).reshape(co, K)                     # packed forward layout
+        dcol = torch.zeros(B * Ho * Ho, col.shape[1], dtype=BF, device="cuda")
+        dcol[:, :K] = (dy2 @ wm).to(BF)
+        dx = torch.full((B * H * H, C), 7.0, dtype=BF, device="cuda")
+        hip.col2im(dcol, dx, B, H, H, C, k, k, s, pad)
+        ref = xr.grad.permute(0, 2, 3, 1).reshape(B * H * H, C)
+        assert rel(dx, ref) <= 2e-2                                     # dcol is rounded to bf16 before the tap sum
+        dx2 = dx.clone()
+        hip.col2im(dcol, dx2, B, H, H, C, k, k, s, pad, accumulate=True)
+        assert rel(dx2, 2 * ref) <= 2e-2
+
+
+def test_relu_dwpool_dw3x3_backward_kernels(gpu_device):
+    B, g, k, C, D = 3, 7, 4, 48, 64
+    H = g * k
+    # relu mask with a second addend
+    y = rnd(B * 49, C, seed=1).to(BF)
+    d1, d2 = rnd(B * 49, C, seed=2).to(BF), rnd(B * 49, C, seed=3).to(BF)
+    got = hip.relu_bwd(d1, y, dy2=d2)
+    assert rel(got, ((d1.float() + d2.float()) * (y.float() > 0)).to(BF)) == 0
+    assert torch.equal(hip.relu_bwd(d1, y), (d1.float() * (y.float() > 0)).to(BF))
+    # depthwise kernel == stride conv
+    top = rnd(B, C, H, H, seed=4).to(BF).float()
+    wd = rnd(C, 1, k, k, seed=5, scale=0.2)
+    dpool = rnd(B, C, g, g, seed=6).to(BF).float()
+    tr, wr = top.clone().requires_grad_(True), wd.clone().requires_grad_(True)
+    F.conv2d(tr, wr, stride=k, groups=C).backward(dpool)
+    top_n = top.permute(0, 2, 3, 1).contiguous().to(BF).view(B * H * H, C)
+    dp_n = dpool.permute(0, 2, 3, 1).contiguous().to(BF).view(B * g * g, C)
+    wtab = wd[:, 0].reshape(C, k * k).t().contiguous()                  # [k*k, C] like packing.adapter_weights
+    dw = hip.dwpool_wgrad(dp_n, top_n, B, H, H, C, k)
+    assert rel(dw.t().reshape(C, 1, k, k), wr.grad) <= 1e-5
+    dtop = torch.full((B * H * H, C), 3.0, dtype=BF, device="cuda")
+    hip.dwpool_bwd(dp_n, wtab, dtop, B, H, H, C, k)
+    ref = tr.grad.permute(0, 2, 3, 1).reshape(B * H * H, C)
+    assert rel(dtop, ref) <= 8e-3
+    hip.dwpool_bwd(dp_n, wtab, dtop, B, H, H, C, k, accumulate=True)
+    assert rel(dtop, 2 * ref) <= 1.2e-2
+    # depthwise 3x3 over the token grid (cls row excluded)
+    L = g * g + 1
+    x = rnd(B * L, D, seed=7)
+    dsum = rnd(B * L, D, seed=8)
+    wb = rnd(D, 1, 3, 3, seed=9).requires_grad_(True)
+    grid = x.view(B, L, D)[:, 1:].transpose(1, 2).reshape(B, D, g, g)
+    out = F.conv2d(grid, wb, padding=1, groups=D)
+    out.backward(dsum.view(B, L, D)[:, 1:].transpose(1, 2).reshape(B, D, g, g))
+    got = hip.dw3x3_wgrad(dsum, x, B, L, g)
+    assert rel(got.t().reshape(D, 1, 3, 3), wb.grad) <= 1e-5
+
+
 def _fresh_model(name):
     m = get_clip_model(named_config(name))
     m.load_state_dict(synth_sd(name), strict=True)
@@ -188,10 +271,7 @@ def test_gradients_against_reference_autograd(gpu_device):
     loss = ts.forward(img, tok)
     assert abs(loss.item() - float(g["loss"])) <= 2e-2, (loss.item(), float(g["loss"]))
     grads = ts.backward()
-    frozen = ("resblocks.0.conv1", "resblocks.0.bn1", "resblocks.0.resnet_stage", "resblocks.0.last_conv", "parallel_branch_v",
-              "top2bottom", "bottom_dw_conv")
-    ref_keys = [k[2:] for k in g.files if k.startswith("g_")]
-    expect = [k for k in ref_keys if not any(f in k for f in frozen)]
+    expect = [k[2:] for k in g.files if k.startswith("g_")]           # every parameter of the model
     assert sorted(grads) == sorted(expect), (sorted(set(expect) - set(grads))[:5], sorted(set(grads) - set(expect))[:5])
     worst, am, coss = {}, {}, {}
     for k in expect:
@@ -209,13 +289,21 @@ def test_gradients_against_reference_autograd(gpu_device):
     print("gradient tensors checked:", len(expect), "worst sample errors:", top)
     print("median sample error", float(np.median(list(worst.values()))), "worst abs-mean deviations",
           sorted(am.items(), key=lambda kv: -kv[1])[:4], "lowest cosines", sorted(coss.items(), key=lambda kv: kv[1])[:4])
+    conv_keys = [k for k in expect if any(f in k for f in CONV_SIDE)]
+    assert len(expect) == 325 and len(conv_keys) == 114
+    print("conv side: median sample error", float(np.median([worst[k] for k in conv_keys])), "worst",
+          max(worst[k] for k in conv_keys), "worst abs-mean", max(am[k] for k in conv_keys), "lowest cosine",
+          min(coss[k] for k in conv_keys if k in coss))
     for k in expect:
         lnb = k.endswith(("ln_1.bias", "ln_2.bias", "ln_final.bias", "ln_post.bias", "ln_pre.bias", "ln_adapt.bias"))
-        assert worst[k] <= (LNB_SAMPLE_TOL if lnb else SAMPLE_TOL), (k, worst[k])
-        assert am[k] <= (LNB_ABSMEAN_TOL if lnb else ABSMEAN_TOL), (k, am[k])
+        tol = (LNB_SAMPLE_TOL, LNB_ABSMEAN_TOL, LNB_COS_TOL) if lnb else \
+              (CONV_SAMPLE_TOL, CONV_ABSMEAN_TOL, CONV_COS_TOL) if k in conv_keys else (SAMPLE_TOL, ABSMEAN_TOL, COS_TOL)
+        assert worst[k] <= tol[0], (k, worst[k])
+        assert am[k] <= tol[1], (k, am[k])
         if k in coss:
-            assert coss[k] >= (LNB_COS_TOL if lnb else COS_TOL), (k, coss[k])
-    assert float(np.median(list(worst.values()))) <= 3e-2
+            assert coss[k] >= tol[2], (k, coss[k])
+    assert float(np.median([worst[k] for k in expect if k not in conv_keys])) <= 3e-2
+    assert float(np.median([worst[k] for k in conv_keys])) <= 6e-2
     # the shared tensors' gradients are sums over both towers: a text-only / image-only backward must give less
     assert len([k for k in expect if "visual.transformer.resblocks" in k and ".attn." in k]) == 11 * 4
 
