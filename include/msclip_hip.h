@@ -56,6 +56,11 @@ typedef struct msclip_gemm_desc {
 
 int msclip_gemm(const msclip_gemm_desc* desc, void* stream);
 
+/* Split-K form of the dense GEMM for deep, narrow contractions (weight gradients): out is fp32 [slices][M][ldo], slice s
+ * holds the contraction over K columns [s*K/slices, (s+1)*K/slices) (K % (64*slices) == 0); no bias / residual /
+ * activation / scatter.  The caller folds the slices (msclip_colsum over [slices, M*ldo]: fixed order). */
+int msclip_gemm_splitk(const msclip_gemm_desc* desc, int slices, void* stream);
+
 /* Name of the kernel msclip_gemm would launch for this descriptor ("w4", "pp", "ppconv", "stream", "dense128",
  * "conv192", "conv128"; "invalid" for rejected arguments): the library's own dispatch rule, so
  * that measurement code (bench.py's roofline leg) counts exactly the launches of one kernel.  No GPU work. */

@@ -498,7 +498,17 @@ __device__ __forceinline__ void epilogue_generic(f32x16 (&acc)[TN][TM], const ms
 //   big  : 256 x 256, 8 waves (2 x 4), 128 KiB LDS, one workgroup per CU  (transformer projections)
 //   small: 128 x 128, 4 waves (2 x 2),  64 KiB LDS, two workgroups per CU (narrow convolutions, tiny heads)
 template <int MODE, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const msclip_gemm_desc a) {
+__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const msclip_gemm_desc a_in) {
+  // Split-K launches (msclip_gemm_splitk): blockIdx.y = K slice; slice s contracts columns [s*K/S, (s+1)*K/S) of both
+  // operands into its own fp32 output matrix out[s][M][ldo] (the caller folds the S partials in a fixed order).
+  msclip_gemm_desc a = a_in;
+  if (MODE == 0 && gridDim.y > 1) {
+    const int kc = a.K / (int)gridDim.y;
+    a.X = (const bf16_t*)a.X + (size_t)blockIdx.y * kc;
+    a.W = (const bf16_t*)a.W + (size_t)blockIdx.y * kc;
+    a.out = (float*)a.out + (size_t)blockIdx.y * a.M * a.ldo;
+    a.K = kc;
+  }
   constexpr int NW = WM * WN;
   constexpr int NT = NW * 64;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -1139,6 +1149,20 @@ static GemmVariant pick_variant(const msclip_gemm_desc* d) {
 }
 
 extern "C" const char* msclip_gemm_variant(const msclip_gemm_desc* d) { return kVariantName[pick_variant(d)]; }
+
+// Split-K form for contractions that are deep and narrow (weight gradients: a few output tiles over 10^5 - 10^7 tokens or
+// pixels): `slices` workgroup rows, each contracting K / slices columns into out[slice][M][ldo] (fp32), 128 x 128 tiles.
+extern "C" int msclip_gemm_splitk(const msclip_gemm_desc* d, int slices, void* stream) {
+  if (!d || slices < 1 || slices > 65535 || pick_variant(d) == GV_INVALID) return MSCLIP_EINVAL;
+  if (d->mode != 0 || d->out_kind != 1 || d->bias || d->resid || d->resid_kind || d->act || d->rpg != 0x7fffffff || d->radd ||
+      d->roff || (d->K % (BK * slices)))
+    return MSCLIP_EINVAL;
+  const int tiles = ((d->M + 127) / 128) * ((d->N + 127) / 128);
+  const int cap = device_cus() * 2;
+  hipLaunchKernelGGL((gemm_kernel<0, 128, 128, 2, 2>), dim3(tiles < cap ? tiles : cap, slices), dim3(256), 0,
+                     (hipStream_t)stream, *d);
+  return msclip_launch_status();
+}
 
 extern "C" int msclip_gemm(const msclip_gemm_desc* d, void* stream) {
   const GemmVariant v = pick_variant(d);

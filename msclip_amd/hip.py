@@ -23,7 +23,7 @@ EXPORTS = (
     "msclip_transpose_bf16", "msclip_cast_bf16", "msclip_colsum", "msclip_quickgelu", "msclip_quickgelu_bwd", "msclip_layernorm_bwd",
     "msclip_attention_bwd", "msclip_l2norm_bwd", "msclip_clip_loss_bwd_g", "msclip_embed_tokens_bwd", "msclip_adapter_sum",
     "msclip_adapter_dx", "msclip_adamw", "msclip_im2col", "msclip_col2im", "msclip_relu_bwd", "msclip_dwpool_bwd",
-    "msclip_dwpool_wgrad", "msclip_dw3x3_wgrad",
+    "msclip_dwpool_wgrad", "msclip_dw3x3_wgrad", "msclip_gemm_splitk",
     "msclip_abi_version", "msclip_build_arch",
 )
 
@@ -73,6 +73,7 @@ def lib():
         L = ctypes.CDLL(LIB_PATH)
         vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
         L.msclip_gemm.argtypes = [ctypes.POINTER(GemmDesc), vp]
+        L.msclip_gemm_splitk.argtypes = [ctypes.POINTER(GemmDesc), ci, vp]
         L.msclip_gemm_variant.argtypes = [ctypes.POINTER(GemmDesc)]
         L.msclip_gemm_variant.restype = ctypes.c_char_p
         L.msclip_attention.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, vp]
@@ -274,6 +275,22 @@ def gemm(x, w, out, *, M=None, bias=None, resid=None, resid_kind=0, act=0, alpha
         return out
     _check(lib().msclip_gemm(ctypes.byref(d), _stream()), "msclip_gemm")
     return out
+
+
+def gemm_splitk(x, w, slices):
+    """fp32 [N_x, N_w] = x @ w^T for two K-contiguous bf16 operands x [M, K], w [N, K] with a deep K (K % (64*slices) == 0):
+    `slices` K ranges contracted by separate workgroup rows of ONE launch into fp32 partials, folded in a fixed order."""
+    _bf16(x)
+    _bf16(w)
+    M, N, K = x.shape[0], w.shape[0], x.shape[1]
+    assert w.shape[1] == K and K % (64 * slices) == 0
+    part = torch.empty(slices, M * N, dtype=torch.float32, device=x.device)
+    d = GemmDesc()
+    d.X, d.W, d.zero, d.out = x.data_ptr(), w.data_ptr(), zero_page(x.device).data_ptr(), part.data_ptr()
+    d.M, d.N, d.K, d.ldx, d.ldw, d.ldo = M, N, K, x.stride(0), w.stride(0), N
+    d.out_kind, d.alpha, d.rpg = 1, 1.0, INT_MAX
+    _check(lib().msclip_gemm_splitk(ctypes.byref(d), slices, _stream()), "msclip_gemm_splitk")
+    return colsum(part).view(M, N) if slices > 1 else part.view(M, N)
 
 
 _TAPS = {}

@@ -47,6 +47,13 @@ def _wgrad(dy_bf, x_bf, M):
     GEMMs run concurrently on S side streams into fp32 partials, folded in a fixed order (deterministic)."""
     N, K = dy_bf.shape[1], x_bf.shape[1]
     tiles = ((N + 255) // 256) * ((K + 255) // 256)
+    if tiles <= 4:
+        # narrow gradients (the convolutions: 48-192 channels over up to 6.4 M pixels): one split-K launch of 128 x 128
+        # tiles, enough slices to put ~2 workgroups on every CU, at least 1024 deep each
+        t128 = ((N + 127) // 128) * ((K + 127) // 128)
+        S = max(1, min(512 // t128, M // 1024))
+        Mpad = (M + 64 * S - 1) // (64 * S) * (64 * S)
+        return hip.gemm_splitk(hip.transpose_bf16(dy_bf, M, Mpad), hip.transpose_bf16(x_bf, M, Mpad), S)
     S = 1
     while S < 16 and tiles * S * 2 <= 256 and M // (S * 2) >= 2048:
         S *= 2

@@ -214,6 +214,17 @@ def test_im2col_col2im_against_conv_autograd(gpu_device, geom):
         assert rel(dx2, 2 * ref) <= 2e-2
 
 
+@pytest.mark.parametrize("shape", [(48, 64, 8192, 8), (96, 448, 4096, 4), (200, 130, 2048, 1), (768, 48, 1024, 16)])
+def test_gemm_splitk(gpu_device, shape):
+    """msclip_gemm_splitk: K slices contracted by separate workgroup rows of one launch, folded in a fixed order."""
+    M, N, K, S = shape
+    a, b = rnd(M, K, seed=1).to(BF), rnd(N, K, seed=2).to(BF)
+    got = hip.gemm_splitk(a, b, S)
+    ref = a.double() @ b.double().t()
+    assert rel(got, ref) <= 2e-6
+    assert torch.equal(got, hip.gemm_splitk(a, b, S))                  # deterministic
+
+
 def test_relu_dwpool_dw3x3_backward_kernels(gpu_device):
     B, g, k, C, D = 3, 7, 4, 48, 64
     H = g * k
