@@ -35,6 +35,38 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
   }
 }
 
+// The same with 16-byte global accesses (C % 8 == 0, ldi % 8 == 0, ldo % 8 == 0, Mpad % 64 == 0): 8 lanes read one
+// 128-byte row segment and, after the LDS turn, 8 lanes write one 128-byte segment of an output row; the tile's row stride
+// of 33 dwords makes the transposed 2-byte reads conflict-free (lanes with consecutive m-chunks sit 8 banks apart).
+__global__ __launch_bounds__(256) void transpose_vec_kernel(const bf16_t* __restrict__ in, int ldi, bf16_t* __restrict__ out,
+                                                            int ldo, int M, int C) {
+  __shared__ bf16_t tile[64][66];
+  const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int sub = threadIdx.x >> 3, ch = threadIdx.x & 7;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = sub + 32 * i, m = m0 + r, c = c0 + ch * 8;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (m < M && c < C) v = *(const uint4*)(in + (size_t)m * ldi + c);
+    unsigned* d = (unsigned*)&tile[r][ch * 8];
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = sub + 32 * i, c = c0 + r;
+    if (c < C) {
+      unsigned short e[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e[j] = tile[ch * 8 + j][r];
+      uint4 v;
+      v.x = e[0] | ((unsigned)e[1] << 16); v.y = e[2] | ((unsigned)e[3] << 16);
+      v.z = e[4] | ((unsigned)e[5] << 16); v.w = e[6] | ((unsigned)e[7] << 16);
+      *(uint4*)(out + (size_t)c * ldo + m0 + ch * 8) = v;
+    }
+  }
+}
+
 // ---- out[n] (+)= sum_m x[m][n]: bias gradients and the second stage of the LayerNorm parameter gradients.
 // One block per 64 columns; 4 waves stride the rows, lanes own columns; fixed summation order (deterministic).
 template <typename T>
@@ -334,8 +366,12 @@ static int grid_for(size_t n, int per_block, int cap = 4096) {
 
 extern "C" int msclip_transpose_bf16(const void* in, int ldi, void* out, int ldo, int M, int C, int Mpad, void* stream) {
   if (!in || !out || M <= 0 || C <= 0 || Mpad < M || ldo < Mpad || ldi < C) return MSCLIP_EINVAL;
-  hipLaunchKernelGGL(transpose_kernel, dim3((Mpad + 63) / 64, (C + 63) / 64), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)in, ldi, (bf16_t*)out, ldo, M, C, Mpad);
+  if (!(C % 8) && !(ldi % 8) && !(ldo % 8) && !(Mpad % 64) && !((size_t)in % 16) && !((size_t)out % 16))
+    hipLaunchKernelGGL(transpose_vec_kernel, dim3(Mpad / 64, (C + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)in, ldi, (bf16_t*)out, ldo, M, C);
+  else
+    hipLaunchKernelGGL(transpose_kernel, dim3((Mpad + 63) / 64, (C + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)in, ldi, (bf16_t*)out, ldo, M, C, Mpad);
   return msclip_launch_status();
 }
 

@@ -38,6 +38,7 @@ _LEAVES = ("attn.in_proj_weight", "attn.in_proj_bias", "attn.out_proj.weight", "
 
 
 _SIDE = {}
+_WGRAD_STREAMS = 28
 
 
 def _wgrad(dy_bf, x_bf, M):
@@ -54,9 +55,7 @@ def _wgrad(dy_bf, x_bf, M):
         S = max(1, min(512 // t128, M // 1024))
         Mpad = (M + 64 * S - 1) // (64 * S) * (64 * S)
         return hip.gemm_splitk(hip.transpose_bf16(dy_bf, M, Mpad), hip.transpose_bf16(x_bf, M, Mpad), S)
-    S = 1
-    while S < 16 and tiles * S * 2 <= 256 and M // (S * 2) >= 2048:
-        S *= 2
+    S = max(1, min(_WGRAD_STREAMS, 256 // tiles, M // 4096))           # one workgroup per CU across the S concurrent GEMMs
     Mpad = (M + 64 * S - 1) // (64 * S) * (64 * S)
     a = hip.transpose_bf16(dy_bf, M, Mpad)
     b = hip.transpose_bf16(x_bf, M, Mpad)
@@ -67,7 +66,7 @@ def _wgrad(dy_bf, x_bf, M):
     kc = Mpad // S
     part = torch.empty(S, N, K, dtype=F32, device=a.device)
     cur = torch.cuda.current_stream(a.device)
-    pool = _SIDE.setdefault(a.device, [torch.cuda.Stream(device=a.device) for _ in range(16)])
+    pool = _SIDE.setdefault(a.device, [torch.cuda.Stream(device=a.device) for _ in range(_WGRAD_STREAMS)])
     ready = torch.cuda.Event()
     ready.record(cur)
     for sidx in range(S):

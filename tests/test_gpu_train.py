@@ -53,6 +53,9 @@ def test_transpose_cast_colsum_gelu(gpu_device):
     assert t.shape == (200, 1024) and torch.equal(t[:, :1000], x.t()) and bool((t[:, 1000:] == 0).all())
     t2 = hip.transpose_bf16(x[100:900], 777)
     assert t2.shape == (200, 832) and torch.equal(t2[:, :777], x[100:877].t()) and bool((t2[:, 777:] == 0).all())
+    x3 = rnd(130, 27, seed=5, dtype=BF)                               # odd width: the scalar tile kernel
+    t3 = hip.transpose_bf16(x3)
+    assert t3.shape == (27, 192) and torch.equal(t3[:, :130], x3.t()) and bool((t3[:, 130:] == 0).all())
     f = rnd(300, 768, seed=2)
     assert torch.equal(hip.cast_bf16(f), f.to(BF))
     assert rel(hip.colsum(f), f.sum(0)) < 1e-5 and rel(hip.colsum(x), x.float().sum(0)) < 1e-5
