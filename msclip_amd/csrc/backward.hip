@@ -94,6 +94,42 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
   }
 }
 
+// bf16 matrices with 16-byte row pieces (N % 8 == 0, ld % 8 == 0): a lane owns 8 columns; `cpr` lanes (a power of two
+// <= 32) cover up to 256 columns of a row, the block's 256 / cpr row groups are folded through LDS.  Same chunking and
+// fixed summation order as the scalar kernel.
+__global__ __launch_bounds__(256) void colsum_bf16x8_kernel(const bf16_t* __restrict__ x, int ld, float* __restrict__ out,
+                                                            int M, int N, int accumulate, int rows_per_chunk, int cpr) {
+  __shared__ float part[256][9];
+  const int tx = threadIdx.x & (cpr - 1), ty = threadIdx.x / cpr, ngrp = 256 / cpr;
+  const int n = (blockIdx.x * cpr + tx) * 8;
+  const int m0 = blockIdx.y * rows_per_chunk;
+  const int m1 = min(M, m0 + rows_per_chunk);
+  float s[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = 0.f;
+  if (n < N) {
+    for (int m = m0 + ty; m < m1; m += ngrp) {
+      float f[8];
+      unpack_bf16x8(*(const uint4*)(x + (size_t)m * ld + n), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += f[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) part[threadIdx.x][e] = s[e];
+  __syncthreads();
+  const int col = threadIdx.x;                         // up to cpr * 8 columns of the block, one per thread
+  if (col < cpr * 8) {
+    const int cx = col >> 3, ce = col & 7, nn = blockIdx.x * cpr * 8 + col;
+    if (nn < N) {
+      float t = 0.f;
+      for (int r = 0; r < ngrp; ++r) t += part[r * cpr + cx][ce];
+      float* o = out + (size_t)blockIdx.y * N + nn;
+      *o = accumulate ? *o + t : t;
+    }
+  }
+}
+
 // ---- fp32 -> bf16 copy of a gradient matrix (the operand of its dgrad / wgrad GEMMs).
 __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ x, int ldx, bf16_t* __restrict__ y, int ldy, int M,
                                                    int C4) {
@@ -391,6 +427,12 @@ extern "C" int msclip_colsum(const void* x, int ld, int is_f32, float* out, int 
   if (is_f32)
     hipLaunchKernelGGL(colsum_kernel<float>, dim3((N + 63) / 64, chunks), dim3(256), 0, st, (const float*)x, ld, first, M, N,
                        chunks > 1 ? 0 : accumulate, rpc);
+  else if (!(N % 8) && !(ld % 8) && !((size_t)x % 16)) {
+    int cpr = 1;
+    while (cpr < 32 && cpr * 8 < N) cpr *= 2;
+    hipLaunchKernelGGL(colsum_bf16x8_kernel, dim3((N + cpr * 8 - 1) / (cpr * 8), chunks), dim3(256), 0, st, (const bf16_t*)x,
+                       ld, first, M, N, chunks > 1 ? 0 : accumulate, rpc, cpr);
+  }
   else
     hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3((N + 63) / 64, chunks), dim3(256), 0, st, (const bf16_t*)x, ld, first, M,
                        N, chunks > 1 ? 0 : accumulate, rpc);

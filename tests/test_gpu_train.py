@@ -59,6 +59,10 @@ def test_transpose_cast_colsum_gelu(gpu_device):
     f = rnd(300, 768, seed=2)
     assert torch.equal(hip.cast_bf16(f), f.to(BF))
     assert rel(hip.colsum(f), f.sum(0)) < 1e-5 and rel(hip.colsum(x), x.float().sum(0)) < 1e-5
+    for mm, nn in ((5000, 48), (3000, 3072), (2500, 8), (700, 27), (4100, 104)):     # 16-byte kernel (narrow / wide / chunked) and scalar kernel
+        xb = rnd(mm, nn, seed=6, dtype=BF)
+        assert rel(hip.colsum(xb), xb.float().sum(0)) < 1e-5, (mm, nn)
+        assert torch.equal(hip.colsum(xb), hip.colsum(xb))
     acc = torch.ones(768, device="cuda")
     hip.colsum(f, out=acc, accumulate=True)
     assert rel(acc, f.sum(0) + 1) < 1e-5
