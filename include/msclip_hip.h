@@ -187,8 +187,9 @@ int msclip_layernorm_bwd(const float* x, int ldx, const int* row_idx, int row_mu
                          const float* gamma, float* dx, int lddx, int accumulate, float* part, int part_blocks, int M,
                          int C, float eps, void* stream);
 
-/* Backward of msclip_attention for L <= 96: dqkv [q | k | v gradients] from qkv, the forward output o and its
- * gradient dout (all bf16, same layouts as the forward). */
+/* Backward of msclip_attention for L <= 208: dqkv [q | k | v gradients] from qkv, the forward output o and its
+ * gradient dout (all bf16, same layouts as the forward).  L <= 96: the whole head resident in LDS; 97-208 (the 197-token
+ * grid of ViT-B/16): query axis in blocks of 32, dK / dV accumulated in registers across the blocks. */
 int msclip_attention_bwd(const void* qkv, const void* o, const void* dout, void* dqkv, int nsamples, int L, int heads,
                          int ldq, int ldo, int causal, void* stream);
 

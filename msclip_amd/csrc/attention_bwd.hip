@@ -1,6 +1,8 @@
-// Backward of the fused softmax(q k^T [+ causal]) v attention (forward: attention.hip; reference M.py:707-738) for
-// sequences up to 96 tokens (the 50-token image grid of ViT-B/32 and the 77-token captions): one workgroup of 4 waves
-// per (sample, head), everything of that head resident in LDS, all five contractions on v_mfma_f32_16x16x32_bf16.
+// Backward of the fused softmax(q k^T [+ causal]) v attention (forward: attention.hip; reference M.py:707-738): one
+// workgroup of 4 waves per (sample, head), all five contractions on v_mfma_f32_16x16x32_bf16.  Up to 96 tokens (the
+// 50-token image grid of ViT-B/32 and the 77-token captions) everything of the head is resident in LDS
+// (attn_bwd_kernel, described here); 97-208 tokens (the 197-token grid of ViT-B/16) run the query-blocked form further
+// down (attn_bwd_qb_kernel).
 //
 //   S  = Q K^T (q pre-scaled by the packed in_proj weight),  P = softmax(S),  O = P V            (recomputed / given)
 //   dV = P^T dO      dP = dO V^T      dS = P o (dP - delta),  delta_q = sum_d dO[q][d] O[q][d]
@@ -181,13 +183,248 @@ int launch_bwd(const void* qkv, const void* o, const void* dout, void* dqkv, int
   return msclip_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Longer sequences (96 < L <= 208: the 197-token grid of ViT-B/16).  P^T, dS and dS^T of a whole head no longer fit the
+// LDS next to the operands (3 x 208 x 216 bf16 = 270 KB), so the QUERY axis is processed in blocks of 32:
+//   resident for the head:  K, V row-major, K^T                                     (87 KB at L = 197)
+//   per query block:        Q, dO rows and their transposes, delta, P^T / dS^T [key][32], dS [32][key]   (66 KB)
+// dQ of a block is complete after the block (it contracts over keys); dV^T and dK^T contract over queries and are
+// accumulated in registers across the blocks (2 * 4 * NT16 tiles of 16 x 16 over 4 waves: 2 * NT16 accumulators per
+// wave) and stored once at the end.  Phase 1 of a block has only two 16-query tiles, so a wave takes (query tile, half
+// of the key tiles) and the two halves exchange the row maximum and the row sum through LDS.
+// The key axis is padded to a multiple of 32 (one MFMA k-step) with zero columns in K^T and dS.
+// ------------------------------------------------------------------------------------------------------------
+template <int NT16, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_bwd_qb_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+                                                          const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqkv, int L,
+                                                          int H, int ldq, int ldo) {
+  constexpr int LP = NT16 * 16, LPK = (LP + 31) / 32 * 32, LS = LPK + 8;   // padded keys, k-step padded keys, [..][key] stride
+  constexpr int QB = 32, QS = QB + 8;                                       // queries per block, [..][query] stride
+  constexpr int NA = 2 * NT16;                                              // dV^T / dK^T accumulator tiles per wave
+  extern __shared__ __attribute__((aligned(16))) bf16_t sm[];
+  bf16_t* K = sm;                                      // [LP][RS]
+  bf16_t* V = K + LP * RS;
+  bf16_t* KT = V + LP * RS;                            // [64][LS]
+  bf16_t* Qb = KT + 64 * LS;                           // [QB][RS]
+  bf16_t* dOb = Qb + QB * RS;
+  bf16_t* QT = dOb + QB * RS;                          // [64][QS]
+  bf16_t* dOT = QT + 64 * QS;
+  bf16_t* PT = dOT + 64 * QS;                          // [LP][QS]   (key, query in block)
+  bf16_t* dST = PT + LP * QS;
+  bf16_t* dS = dST + LP * QS;                          // [QB][LS]
+  float* delta = (float*)(dS + QB * LS);               // [QB]
+  float* red = delta + QB;                             // [2 stats][2 key halves][QB]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const size_t row0 = (size_t)b * L;
+  const bf16_t* qb = qkv + row0 * ldq + h * 64;
+  const bf16_t* ob = o + row0 * ldo + h * 64;
+  const bf16_t* db = dout + row0 * ldo + h * 64;
+  bf16_t* gb = dqkv + row0 * ldq + h * 64;
+
+  // ---- resident operands: K, V rows, K^T (zero beyond L, and in the k-step padding columns)
+  for (int idx = tid; idx < LP * 8; idx += 256) {
+    const int r = idx >> 3, c = idx & 7;
+    uint4 k4 = make_uint4(0, 0, 0, 0), v4 = k4;
+    if (r < L) {
+      k4 = *(const uint4*)(qb + (size_t)r * ldq + H * 64 + c * 8);
+      v4 = *(const uint4*)(qb + (size_t)r * ldq + 2 * H * 64 + c * 8);
+    }
+    *(uint4*)(K + r * RS + c * 8) = k4;
+    *(uint4*)(V + r * RS + c * 8) = v4;
+    const unsigned kw[4] = {k4.x, k4.y, k4.z, k4.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      KT[(c * 8 + 2 * e) * LS + r] = (bf16_t)(kw[e] & 0xffff);
+      KT[(c * 8 + 2 * e + 1) * LS + r] = (bf16_t)(kw[e] >> 16);
+    }
+  }
+  if constexpr (LPK > LP) {
+    constexpr int PADC = LPK - LP;
+    for (int idx = tid; idx < 64 * PADC; idx += 256) KT[(idx / PADC) * LS + LP + idx % PADC] = 0;
+    for (int idx = tid; idx < QB * PADC; idx += 256) dS[(idx / PADC) * LS + LP + idx % PADC] = 0;
+  }
+
+  const int r16 = lane & 15, quad = lane >> 4;
+  auto mma = [&](f32x4 acc, const bf16_t* pa, int sa, const bf16_t* pb, int sb, int ksteps) {
+    for (int ks = 0; ks < ksteps; ++ks) {
+      const bf16x8 a = *(const bf16x8*)(pa + r16 * sa + ks * 32 + quad * 8);
+      const bf16x8 bb = *(const bf16x8*)(pb + r16 * sb + ks * 32 + quad * 8);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bb, acc, 0, 0, 0);
+    }
+    return acc;
+  };
+
+  f32x4 acc[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int NK0 = (NT16 + 1) / 2;                  // key tiles of half 0
+  const int qt = wave & 1, kh = wave >> 1;             // phase 1: this wave's query tile of the block and key half
+  const int kt0 = kh ? NK0 : 0, kt1 = kh ? NT16 : NK0;
+
+  for (int q0 = 0; q0 < L; q0 += QB) {
+    __syncthreads();                                   // previous block's phase 2 is done with the block buffers
+    {
+      const int r = tid >> 3, c = tid & 7, q = q0 + r;
+      uint4 q4 = make_uint4(0, 0, 0, 0), d4 = q4, o4 = q4;
+      if (q < L) {
+        q4 = *(const uint4*)(qb + (size_t)q * ldq + c * 8);
+        d4 = *(const uint4*)(db + (size_t)q * ldo + c * 8);
+        o4 = *(const uint4*)(ob + (size_t)q * ldo + c * 8);
+      }
+      *(uint4*)(Qb + r * RS + c * 8) = q4;
+      *(uint4*)(dOb + r * RS + c * 8) = d4;
+      const unsigned qw[4] = {q4.x, q4.y, q4.z, q4.w}, dw[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        QT[(c * 8 + 2 * e) * QS + r] = (bf16_t)(qw[e] & 0xffff);
+        QT[(c * 8 + 2 * e + 1) * QS + r] = (bf16_t)(qw[e] >> 16);
+        dOT[(c * 8 + 2 * e) * QS + r] = (bf16_t)(dw[e] & 0xffff);
+        dOT[(c * 8 + 2 * e + 1) * QS + r] = (bf16_t)(dw[e] >> 16);
+      }
+      float fd[8], fo[8];
+      unpack_bf16x8(d4, fd);
+      unpack_bf16x8(o4, fo);
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += fd[e] * fo[e];
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      s += __shfl_xor(s, 4, 64);
+      if (c == 0) delta[r] = s;
+    }
+    __syncthreads();
+
+    // ---- phase 1: S^T of (query tile qt, key half kh), softmax statistics shared with the other half, dP^T, dS
+    {
+      const int qi = qt * 16 + r16, query = q0 + qi;
+      f32x4 st[NK0];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < NK0; ++i) {
+        const int kt = kt0 + i;
+        if (kt < kt1) {
+          st[i] = mma(f32x4{0.f, 0.f, 0.f, 0.f}, K + kt * 16 * RS, RS, Qb + qt * 16 * RS, RS, 2);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = kt * 16 + quad * 4 + r;
+            const bool ok = key < L && (!CAUSAL || key <= query);
+            st[i][r] = ok ? st[i][r] : -INFINITY;
+            mx = fmaxf(mx, st[i][r]);
+          }
+        }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      if (quad == 0) red[kh * QB + qi] = mx;
+      __syncthreads();
+      mx = fmaxf(red[qi], red[QB + qi]);
+      if (mx == -INFINITY) mx = 0.f;                   // padded query row: every key masked
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < NK0; ++i)
+        if (kt0 + i < kt1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            st[i][r] = __expf(st[i][r] - mx);
+            sum += st[i][r];
+          }
+        }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      if (quad == 0) red[2 * QB + kh * QB + qi] = sum;
+      __syncthreads();
+      sum = red[2 * QB + qi] + red[3 * QB + qi];
+      const float inv = sum > 0.f ? 1.f / sum : 0.f;
+      const float dl = delta[qi];
+#pragma unroll
+      for (int i = 0; i < NK0; ++i) {
+        const int kt = kt0 + i;
+        if (kt < kt1) {
+          const f32x4 dp = mma(f32x4{0.f, 0.f, 0.f, 0.f}, V + kt * 16 * RS, RS, dOb + qt * 16 * RS, RS, 2);
+          float ds[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = st[i][r] * inv;
+            ds[r] = p * (dp[r] - dl);
+            const int key = kt * 16 + quad * 4 + r;
+            PT[key * QS + qi] = f32_to_bf16(p);
+            dST[key * QS + qi] = f32_to_bf16(ds[r]);
+          }
+          uint2 u;
+          u.x = pack_bf16x2(ds[0], ds[1]);
+          u.y = pack_bf16x2(ds[2], ds[3]);
+          *(uint2*)(dS + qi * LS + kt * 16 + quad * 4) = u;
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- phase 2: dV^T += dO^T . P^T, dK^T += Q^T . dS^T over the block's 32 queries (one k-step); dQ^T of the block
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int t = wave + 4 * i;                      // < 2 * 4 * NT16
+      const int which = t / (4 * NT16), rem = t - which * 4 * NT16;
+      const int dt = rem / NT16, kt = rem - dt * NT16;
+      acc[i] = mma(acc[i], (which ? QT : dOT) + dt * 16 * QS, QS, (which ? dST : PT) + kt * 16 * QS, QS, 1);
+    }
+    for (int t = wave; t < 4 * (QB / 16); t += 4) {
+      const int dt = t >> 1, tq = t & 1;
+      const f32x4 a = mma(f32x4{0.f, 0.f, 0.f, 0.f}, KT + dt * 16 * LS, LS, dS + tq * 16 * LS, LS, LPK / 32);
+      const int tok = q0 + tq * 16 + r16;
+      if (tok < L) {
+        uint2 u;
+        u.x = pack_bf16x2(a[0], a[1]);
+        u.y = pack_bf16x2(a[2], a[3]);
+        *(uint2*)(gb + (size_t)tok * ldq + dt * 16 + quad * 4) = u;
+      }
+    }
+  }
+  // ---- dV^T, dK^T tiles: 4 consecutive head-dim elements per lane and key
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int t = wave + 4 * i;
+    const int which = t / (4 * NT16), rem = t - which * 4 * NT16;
+    const int dt = rem / NT16, kt = rem - dt * NT16;
+    const int tok = kt * 16 + r16;
+    if (tok < L) {
+      uint2 u;
+      u.x = pack_bf16x2(acc[i][0], acc[i][1]);
+      u.y = pack_bf16x2(acc[i][2], acc[i][3]);
+      *(uint2*)(gb + (size_t)tok * ldq + (which ? H * 64 : 2 * H * 64) + dt * 16 + quad * 4) = u;
+    }
+  }
+}
+
+template <int NT16, bool CAUSAL>
+int launch_bwd_qb(const void* qkv, const void* o, const void* dout, void* dqkv, int nsamples, int L, int H, int ldq, int ldo,
+                  hipStream_t st) {
+  constexpr int LP = NT16 * 16, LPK = (LP + 31) / 32 * 32, LS = LPK + 8, QB = 32, QS = QB + 8;
+  const size_t lds = (size_t)(2 * LP * RS + 64 * LS + 2 * QB * RS + 2 * 64 * QS + 2 * LP * QS + QB * LS) * 2 + 5 * QB * 4;
+  static bool done = false;
+  if (!done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_qb_kernel<NT16, CAUSAL>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    done = true;
+  }
+  hipLaunchKernelGGL((attn_bwd_qb_kernel<NT16, CAUSAL>), dim3(nsamples * H), dim3(256), lds, st, (const bf16_t*)qkv,
+                     (const bf16_t*)o, (const bf16_t*)dout, (bf16_t*)dqkv, L, H, ldq, ldo);
+  return msclip_launch_status();
+}
+
 }  // namespace
 
 extern "C" int msclip_attention_bwd(const void* qkv, const void* o, const void* dout, void* dqkv, int nsamples, int L,
                                     int heads, int ldq, int ldo, int causal, void* stream) {
-  if (!qkv || !o || !dout || !dqkv || nsamples <= 0 || L <= 0 || L > 96 || heads <= 0 || (ldq % 8) || (ldo % 8))
+  if (!qkv || !o || !dout || !dqkv || nsamples <= 0 || L <= 0 || L > 208 || heads <= 0 || (ldq % 8) || (ldo % 8))
     return MSCLIP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  if (L > 160) return causal ? launch_bwd_qb<13, true>(qkv, o, dout, dqkv, nsamples, L, heads, ldq, ldo, st)
+                             : launch_bwd_qb<13, false>(qkv, o, dout, dqkv, nsamples, L, heads, ldq, ldo, st);
+  if (L > 96) return causal ? launch_bwd_qb<10, true>(qkv, o, dout, dqkv, nsamples, L, heads, ldq, ldo, st)
+                            : launch_bwd_qb<10, false>(qkv, o, dout, dqkv, nsamples, L, heads, ldq, ldo, st);
   if (L <= 64) return causal ? launch_bwd<4, true>(qkv, o, dout, dqkv, nsamples, L, heads, ldq, ldo, st)
                              : launch_bwd<4, false>(qkv, o, dout, dqkv, nsamples, L, heads, ldq, ldo, st);
   return causal ? launch_bwd<6, true>(qkv, o, dout, dqkv, nsamples, L, heads, ldq, ldo, st)

@@ -114,9 +114,8 @@ class TrainStep:
         with torch.cuda.device(e.dev), torch.no_grad():
             Bi, Bt = img.shape[0], tok.shape[0]
             assert Bi == Bt, "a training step needs image-text pairs"
-            if e.Lv > 96 or e.Lt > 96:
-                raise NotImplementedError("msclip_attention_bwd covers sequences up to 96 tokens (ViT-B/32 grid, 77-token "
-                                          "captions); the 197-token grid of ViT-B/16 is not in this slice")
+            if e.Lv > 208 or e.Lt > 208:
+                raise NotImplementedError("msclip_attention_bwd covers sequences up to 208 tokens")
             w = e._workspace(Bi, Bt)
             Mv, M = w["Mv"], w["M"]
             D = e.D

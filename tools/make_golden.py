@@ -214,7 +214,7 @@ def main():
         model, _ = run_config(name)
         if name.startswith("b32"):
             zeroshot_fixture(model, name)
-            grads_fixture(model, name)
+        grads_fixture(model, name)              # b16: the 197-token grid (query-blocked attention backward, k = 8 adapters)
     multirank_gather_fixture()
 
 
