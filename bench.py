@@ -106,7 +106,7 @@ def main():
     ap.add_argument("--prefill-random", action="store_true",
                     help="probe runs only: fill the workspace with random data first (timing ablation builds of the "
                          "library whose kernels skip their stores; zero-filled operands would raise the clock)")
-    ap.add_argument("--train-slice", action="store_true",
+    ap.add_argument("--train", "--train-slice", dest="train_slice", action="store_true",
                     help="time forward + backward + AdamW of the training step (msclip_amd.train: every parameter gets a "
                          "gradient; BatchNorm with frozen running statistics) instead of the forward step -- a separate "
                          "metric, never the headline")
