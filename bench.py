@@ -110,6 +110,9 @@ def main():
                     help="time forward + backward + AdamW of the training step (msclip_amd.train: every parameter gets a "
                          "gradient; BatchNorm with frozen running statistics) instead of the forward step -- a separate "
                          "metric, never the headline")
+    ap.add_argument("--bn", choices=("batch", "frozen"), default="batch",
+                    help="--train only: train-mode BatchNorm with per-GPU batch statistics (default, the reference's train() "
+                         "semantics) or frozen running statistics")
     ap.add_argument("--shapes", action="store_true", help="add the per-shape table of the dominant kernel to the record")
     args = ap.parse_args()
 
@@ -141,7 +144,7 @@ def main():
     ts = None
     if args.train_slice:
         from msclip_amd import train
-        ts = train.from_config(model, named_config(args.model))
+        ts = train.from_config(model, named_config(args.model), bn=args.bn)
 
     def step():
         if ts is not None:
@@ -197,12 +200,12 @@ def main():
             "loss": round(loss_val, 5),
         }
         if ts is not None:
-            rec["metric"] = "training step (forward + backward + AdamW, frozen BatchNorm statistics) pairs/sec " + args.model
+            rec["metric"] = f"training step (forward + backward + AdamW, BatchNorm: {args.bn} statistics) pairs/sec " + args.model
             rec["config"]["workload"] = ("forward (activations kept) + backward of every parameter (heads, loss, all "
                                          "transformer blocks, adapters, conv stem, parallel conv branch, embeddings) + AdamW + "
-                                         "bucketed gradient all-reduce at N > 1; BatchNorm uses its running statistics "
-                                         "(gamma / beta trained, statistics frozen); FLOPs counted as 3x forward")
-            rec["config"]["bn"] = "frozen running statistics (folded); gamma / beta receive gradients"
+                                         "bucketed gradient all-reduce at N > 1; FLOPs counted as 3x forward")
+            rec["config"]["bn"] = ("train mode: per-GPU batch statistics, running statistics updated (momentum 0.1)"
+                                   if args.bn == "batch" else "frozen running statistics (folded); gamma / beta receive gradients")
         rec["config"]["rccl_ranks"] = dist.get_world_size() if world > 1 else 1
         n = probe.summary()[0] if probe is not None else 0
         if n > 0:                       # tiny batches never reach the ping-pong kernel: no roofline line then

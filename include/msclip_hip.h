@@ -235,6 +235,21 @@ int msclip_dwpool_wgrad(const void* dpool, int ldp, const void* top, float* part
 int msclip_dw3x3_wgrad(const float* dsum, int lds, const float* x, int ldx, float* part, int B, int L, int g, int C,
                        int slabs, void* stream);
 
+/* ---- train-mode BatchNorm on a raw convolution output x [M, C] (per-GPU batch statistics; reference nn.BatchNorm2d in
+ * train(), M.py:1825-1861, 1920-1936).  x_f32 / dy_f32 / y_f32: 0 = bf16, 1 = fp32 matrices (dx has dy's type).
+ * msclip_bn_stats: part[chunks][2][C] = per-row-chunk (sum x, sum x^2); fold with msclip_colsum.
+ * msclip_bn_apply: y = act(x * scale[c] + shift[c] [+ resid (bf16)]).
+ * msclip_bn_bwd_reduce: part[chunks][2][C] = (sum dy, sum dy * xhat), xhat = (x - mean) * rstd.
+ * msclip_bn_bwd_dx: dx = gamma * rstd * (dy - dbeta / M - xhat * dgamma / M). */
+int msclip_bn_stats(const void* x, int ld, int x_f32, float* part, int M, int C, int chunks, void* stream);
+int msclip_bn_apply(const void* x, int ld, int x_f32, const float* scale, const float* shift, const void* resid, int ldr,
+                    void* y, int ldy, int y_f32, int M, int C, int relu, void* stream);
+int msclip_bn_bwd_reduce(const void* dy, int lddy, int dy_f32, const void* x, int ld, int x_f32, const float* mean,
+                         const float* rstd, float* part, int M, int C, int chunks, void* stream);
+int msclip_bn_bwd_dx(const void* dy, int lddy, int dy_f32, const void* x, int ld, int x_f32, const float* mean,
+                     const float* rstd, const float* gamma, const float* dbeta, const float* dgamma, void* dx, int lddx, int M,
+                     int C, void* stream);
+
 /* AdamW with decoupled weight decay on one fp32 tensor (step >= 1 for the bias corrections). */
 int msclip_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
                  float weight_decay, int step, void* stream);

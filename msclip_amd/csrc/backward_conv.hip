@@ -207,6 +207,99 @@ __global__ __launch_bounds__(256) void dw3x3_wgrad_kernel(const float* __restric
   }
 }
 
+// ---- train-mode BatchNorm (per-GPU batch statistics; reference nn.BatchNorm2d in train(), M.py:1825-1861, 1920-1936) ----
+// x is the RAW convolution output [M, C] (bf16 activation matrix, or the fp32 token-grid matrix of the adapters' depthwise
+// 3x3).  Statistics and both backward reductions are produced as per-chunk partial rows [chunks][2][C] that the caller
+// folds with msclip_colsum (fixed order: deterministic).
+template <typename T>
+__device__ __forceinline__ float ld_f(const T* p) {
+  if constexpr (sizeof(T) == 2) return bf16_to_f32(*p);
+  else return *p;
+}
+// part[chunk][0][c] = sum x, part[chunk][1][c] = sum x^2 over the chunk's rows.  block = 256 threads = 4 row groups x 64 columns
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, int ld, float* __restrict__ part, int M, int C,
+                                                       int rows_per_chunk) {
+  __shared__ float red[2][4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+  const int m0 = blockIdx.y * rows_per_chunk, m1 = min(M, m0 + rows_per_chunk);
+  float s = 0.f, q = 0.f;
+  if (c < C)
+    for (int m = m0 + w; m < m1; m += 4) {
+      const float v = ld_f(x + (size_t)m * ld + c);
+      s += v;
+      q = fmaf(v, v, q);
+    }
+  red[0][w][threadIdx.x & 63] = s;
+  red[1][w][threadIdx.x & 63] = q;
+  __syncthreads();
+  if (w == 0 && c < C) {
+    const int l = threadIdx.x;
+    part[((size_t)blockIdx.y * 2 + 0) * C + c] = red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l];
+    part[((size_t)blockIdx.y * 2 + 1) * C + c] = red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l];
+  }
+}
+// part[chunk][0][c] = sum dy, part[chunk][1][c] = sum dy * xhat,  xhat = (x - mean) * rstd
+template <typename T, typename TD>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const TD* __restrict__ dy, int lddy, const T* __restrict__ x, int ld,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            float* __restrict__ part, int M, int C, int rows_per_chunk) {
+  __shared__ float red[2][4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+  const int m0 = blockIdx.y * rows_per_chunk, m1 = min(M, m0 + rows_per_chunk);
+  float s = 0.f, q = 0.f;
+  if (c < C) {
+    const float mu = mean[c], rs = rstd[c];
+    for (int m = m0 + w; m < m1; m += 4) {
+      const float d = ld_f(dy + (size_t)m * lddy + c);
+      s += d;
+      q = fmaf(d, (ld_f(x + (size_t)m * ld + c) - mu) * rs, q);
+    }
+  }
+  red[0][w][threadIdx.x & 63] = s;
+  red[1][w][threadIdx.x & 63] = q;
+  __syncthreads();
+  if (w == 0 && c < C) {
+    const int l = threadIdx.x;
+    part[((size_t)blockIdx.y * 2 + 0) * C + c] = red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l];
+    part[((size_t)blockIdx.y * 2 + 1) * C + c] = red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l];
+  }
+}
+// y = act(x * scale[c] + shift[c] [+ resid]) -> bf16 or fp32 (TO)
+template <typename T, typename TO>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, int ld, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, const bf16_t* __restrict__ resid,
+                                                       int ldr, TO* __restrict__ y, int ldy, int M, int C, int relu) {
+  const size_t total = (size_t)M * C;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t m = i / C;
+    const int c = (int)(i - m * C);
+    float v = fmaf(ld_f(x + m * ld + c), scale[c], shift[c]);
+    if (resid) v += bf16_to_f32(resid[m * ldr + c]);
+    if (relu) v = fmaxf(v, 0.f);
+    if constexpr (sizeof(TO) == 2) y[m * ldy + c] = f32_to_bf16(v);
+    else y[m * ldy + c] = v;
+  }
+}
+// dx = gamma * rstd * (dy - dbeta / M - xhat * dgamma / M)
+template <typename T, typename TD>
+__global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const TD* __restrict__ dy, int lddy, const T* __restrict__ x, int ld,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        const float* __restrict__ gamma, const float* __restrict__ dbeta,
+                                                        const float* __restrict__ dgamma, TD* __restrict__ dx, int lddx, int M,
+                                                        int C) {
+  const size_t total = (size_t)M * C;
+  const float inv = 1.f / (float)M;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t m = i / C;
+    const int c = (int)(i - m * C);
+    const float xh = (ld_f(x + m * ld + c) - mean[c]) * rstd[c];
+    const float v = gamma[c] * rstd[c] * (ld_f(dy + m * lddy + c) - dbeta[c] * inv - xh * dgamma[c] * inv);
+    if constexpr (sizeof(TD) == 2) dx[m * lddx + c] = f32_to_bf16(v);
+    else dx[m * lddx + c] = v;
+  }
+}
+
 }  // namespace
 
 extern "C" int msclip_im2col(const void* x, int x_kind, void* col, int B, int H, int W, int C, int KH, int KW, int stride,
@@ -272,5 +365,66 @@ extern "C" int msclip_dw3x3_wgrad(const float* dsum, int lds, const float* x, in
     return MSCLIP_EINVAL;
   hipLaunchKernelGGL(dw3x3_wgrad_kernel, dim3(9, slabs), dim3(256), 0, (hipStream_t)stream, dsum, lds, x, ldx, part, B, L, g, C,
                      slabs);
+  return msclip_launch_status();
+}
+
+// ---- train-mode BatchNorm entry points.  x_f32 / dy_f32: 0 = bf16, 1 = fp32 matrices.
+extern "C" int msclip_bn_stats(const void* x, int ld, int x_f32, float* part, int M, int C, int chunks, void* stream) {
+  if (!x || !part || M <= 0 || C <= 0 || ld < C || chunks < 1 || chunks > 65535) return MSCLIP_EINVAL;
+  const int rpc = (M + chunks - 1) / chunks;
+  const dim3 grid((C + 63) / 64, chunks);
+  if (x_f32) hipLaunchKernelGGL(bn_stats_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ld, part, M, C, rpc);
+  else hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld, part, M, C, rpc);
+  return msclip_launch_status();
+}
+
+extern "C" int msclip_bn_apply(const void* x, int ld, int x_f32, const float* scale, const float* shift, const void* resid,
+                               int ldr, void* y, int ldy, int y_f32, int M, int C, int relu, void* stream) {
+  if (!x || !scale || !shift || !y || M <= 0 || C <= 0 || ld < C || ldy < C || (resid && ldr < C)) return MSCLIP_EINVAL;
+  const int grid = grid_for((size_t)M * C, 256 * 8, 16384);
+  hipStream_t st = (hipStream_t)stream;
+  const bf16_t* r = (const bf16_t*)resid;
+#define BN_APPLY(T, TO) \
+  hipLaunchKernelGGL((bn_apply_kernel<T, TO>), dim3(grid), dim3(256), 0, st, (const T*)x, ld, scale, shift, r, ldr, (TO*)y, ldy, M, C, relu)
+  if (x_f32 && y_f32) BN_APPLY(float, float);
+  else if (x_f32) BN_APPLY(float, bf16_t);
+  else if (y_f32) BN_APPLY(bf16_t, float);
+  else BN_APPLY(bf16_t, bf16_t);
+#undef BN_APPLY
+  return msclip_launch_status();
+}
+
+extern "C" int msclip_bn_bwd_reduce(const void* dy, int lddy, int dy_f32, const void* x, int ld, int x_f32, const float* mean,
+                                    const float* rstd, float* part, int M, int C, int chunks, void* stream) {
+  if (!dy || !x || !mean || !rstd || !part || M <= 0 || C <= 0 || ld < C || lddy < C || chunks < 1 || chunks > 65535)
+    return MSCLIP_EINVAL;
+  const int rpc = (M + chunks - 1) / chunks;
+  const dim3 grid((C + 63) / 64, chunks);
+  hipStream_t st = (hipStream_t)stream;
+#define BN_RED(T, TD) \
+  hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, TD>), grid, dim3(256), 0, st, (const TD*)dy, lddy, (const T*)x, ld, mean, rstd, part, M, C, rpc)
+  if (x_f32 && dy_f32) BN_RED(float, float);
+  else if (x_f32) BN_RED(float, bf16_t);
+  else if (dy_f32) BN_RED(bf16_t, float);
+  else BN_RED(bf16_t, bf16_t);
+#undef BN_RED
+  return msclip_launch_status();
+}
+
+extern "C" int msclip_bn_bwd_dx(const void* dy, int lddy, int dy_f32, const void* x, int ld, int x_f32, const float* mean,
+                                const float* rstd, const float* gamma, const float* dbeta, const float* dgamma, void* dx,
+                                int lddx, int M, int C, void* stream) {
+  if (!dy || !x || !mean || !rstd || !gamma || !dbeta || !dgamma || !dx || M <= 0 || C <= 0 || ld < C || lddy < C || lddx < C)
+    return MSCLIP_EINVAL;
+  const int grid = grid_for((size_t)M * C, 256 * 8, 16384);
+  hipStream_t st = (hipStream_t)stream;
+#define BN_DX(T, TD)                                                                                                        \
+  hipLaunchKernelGGL((bn_bwd_dx_kernel<T, TD>), dim3(grid), dim3(256), 0, st, (const TD*)dy, lddy, (const T*)x, ld, mean, rstd, \
+                     gamma, dbeta, dgamma, (TD*)dx, lddx, M, C)
+  if (x_f32 && dy_f32) BN_DX(float, float);
+  else if (x_f32) BN_DX(float, bf16_t);
+  else if (dy_f32) BN_DX(bf16_t, float);
+  else BN_DX(bf16_t, bf16_t);
+#undef BN_DX
   return msclip_launch_status();
 }

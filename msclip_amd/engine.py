@@ -245,8 +245,11 @@ class Engine:
         if taps is not None:
             taps[name] = t[:n * L].view(n, L, -1).float().clone()                            # batch-first [B, L, C]
 
-    def _vision_front(self, img, w, Bi, taps=None, keep_pre=None):
-        """Stem + tokenisation (M.py:2416-2426) and stage 0 of the parallel branch (M.py:2436)."""
+    def _vision_front(self, img, w, Bi, taps=None, keep_pre=None, convs_done=False):
+        """Stem + tokenisation (M.py:2416-2426) and stage 0 of the parallel branch (M.py:2436).  convs_done: the stem's maps
+        are already in the workspace (the training step's train-mode BatchNorm chain), only the tokenisation runs."""
+        if convs_done:
+            return self._tokenise(w["stem"][-1], w, Bi, taps, keep_pre)
         first = self.stem_specs[0]
         fused = (self.dual_w.shape[1] == 96 and self._fusable_3x3s2(first) and not (hip.env_flag("MSCLIP_FRONT_UNFUSED") or self.force_unfused)
                  and img.numel() * img.element_size() < 2 ** 31
@@ -267,6 +270,9 @@ class Engine:
             for i, (spec, out) in enumerate(zip(self.stem_specs, w["stem"])):
                 self._tap_nhwc(taps, f"stem_stage{i}", out, Bi, spec.h_out, spec.cout)
             self._tap_nhwc(taps, "parallel0", w["P0"], Bi, self.h1, self.D // 16)
+        self._tokenise(x, w, Bi, taps, keep_pre)
+
+    def _tokenise(self, x, w, Bi, taps=None, keep_pre=None):
         g2 = self.g * self.g
         # last_conv (1x1, no BN/ReLU) fused with "+ positional_embedding" and the scatter to token rows b*L + 1 + p
         hip.gemm(x, self.w_last, w["X"], M=Bi * g2, resid=self.vpos, resid_kind=hip.RESID_TABLE, rpg=g2, radd=1, roff=1)

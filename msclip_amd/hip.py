@@ -23,7 +23,8 @@ EXPORTS = (
     "msclip_transpose_bf16", "msclip_cast_bf16", "msclip_colsum", "msclip_quickgelu", "msclip_quickgelu_bwd", "msclip_layernorm_bwd",
     "msclip_attention_bwd", "msclip_l2norm_bwd", "msclip_clip_loss_bwd_g", "msclip_embed_tokens_bwd", "msclip_adapter_sum",
     "msclip_adapter_dx", "msclip_adamw", "msclip_im2col", "msclip_col2im", "msclip_relu_bwd", "msclip_dwpool_bwd",
-    "msclip_dwpool_wgrad", "msclip_dw3x3_wgrad", "msclip_gemm_splitk",
+    "msclip_dwpool_wgrad", "msclip_dw3x3_wgrad", "msclip_gemm_splitk", "msclip_bn_stats", "msclip_bn_apply",
+    "msclip_bn_bwd_reduce", "msclip_bn_bwd_dx",
     "msclip_abi_version", "msclip_build_arch",
 )
 
@@ -112,6 +113,10 @@ def lib():
         L.msclip_dwpool_bwd.argtypes = [vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, vp]
         L.msclip_dwpool_wgrad.argtypes = [vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, vp]
         L.msclip_dw3x3_wgrad.argtypes = [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp]
+        L.msclip_bn_stats.argtypes = [vp, ci, ci, vp, ci, ci, ci, vp]
+        L.msclip_bn_apply.argtypes = [vp, ci, ci, vp, vp, vp, ci, vp, ci, ci, ci, ci, ci, vp]
+        L.msclip_bn_bwd_reduce.argtypes = [vp, ci, ci, vp, ci, ci, vp, vp, vp, ci, ci, ci, vp]
+        L.msclip_bn_bwd_dx.argtypes = [vp, ci, ci, vp, ci, ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]
         L.msclip_abi_version.restype = ci
         L.msclip_build_arch.restype = ctypes.c_char_p
         for name in EXPORTS:
@@ -592,6 +597,52 @@ def dw3x3_wgrad(dsum, x, B, L, g):
     _check(lib().msclip_dw3x3_wgrad(_p(dsum), dsum.stride(0), _p(x), x.stride(0), _p(part), B, L, g, C, S, _stream()),
            "msclip_dw3x3_wgrad")
     return colsum(part).view(9, C)
+
+
+def _bn_chunks(M):
+    return 1 if M <= 2048 else min(512, (M + 1023) // 1024)
+
+
+def bn_stats(x, M=None):
+    """x [M, C] bf16 or fp32 -> (mean [C], biased variance [C]) over the rows (fp32)."""
+    M = x.shape[0] if M is None else M
+    C = x.shape[1]
+    ch = _bn_chunks(M)
+    part = torch.empty(ch, 2 * C, dtype=torch.float32, device=x.device)
+    _check(lib().msclip_bn_stats(_p(x), x.stride(0), int(x.dtype == torch.float32), _p(part), M, C, ch, _stream()),
+           "msclip_bn_stats")
+    s = (colsum(part) if ch > 1 else part[0]).view(2, C)
+    mean = s[0] / M
+    var = (s[1] / M - mean * mean).clamp_min_(0.0)
+    return mean, var
+
+
+def bn_apply(x, scale, shift, out, M=None, relu=False, resid=None):
+    M = x.shape[0] if M is None else M
+    C = x.shape[1]
+    _check(lib().msclip_bn_apply(_p(x), x.stride(0), int(x.dtype == torch.float32), _p(scale), _p(shift),
+                                 _p(resid) if resid is not None else None, resid.stride(0) if resid is not None else 0,
+                                 _p(out), out.stride(0), int(out.dtype == torch.float32), M, C, int(relu), _stream()),
+           "msclip_bn_apply")
+    return out
+
+
+def bn_bwd(dy, x, mean, rstd, gamma, dx, M=None):
+    """Train-mode BatchNorm backward on matrices [M, C] (x: bf16 or fp32; dy and dx: one dtype, bf16 or fp32):
+    -> (dgamma, dbeta); dx is filled."""
+    M = x.shape[0] if M is None else M
+    C = x.shape[1]
+    assert dy.dtype == dx.dtype
+    xf, df = int(x.dtype == torch.float32), int(dy.dtype == torch.float32)
+    ch = _bn_chunks(M)
+    part = torch.empty(ch, 2 * C, dtype=torch.float32, device=x.device)
+    _check(lib().msclip_bn_bwd_reduce(_p(dy), dy.stride(0), df, _p(x), x.stride(0), xf, _p(mean), _p(rstd), _p(part), M, C, ch,
+                                      _stream()), "msclip_bn_bwd_reduce")
+    s = (colsum(part) if ch > 1 else part[0]).view(2, C)
+    dbeta, dgamma = s[0].contiguous(), s[1].contiguous()
+    _check(lib().msclip_bn_bwd_dx(_p(dy), dy.stride(0), df, _p(x), x.stride(0), xf, _p(mean), _p(rstd), _p(gamma), _p(dbeta),
+                                  _p(dgamma), _p(dx), dx.stride(0), M, C, _stream()), "msclip_bn_bwd_dx")
+    return dgamma, dbeta
 
 
 def adamw(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):

@@ -29,7 +29,7 @@ import torch.distributed as dist
 
 from . import comm as C
 from . import hip
-from .train_conv import ConvSideBackward
+from .train_conv import ConvSideBackward, ConvSideBatchNorm
 
 BF = torch.bfloat16
 F32 = torch.float32
@@ -92,7 +92,13 @@ def _dgrad(dy_bf, w_t, out=None):
 class TrainStep:
     """forward + backward (+ AdamW step) for one local batch.  `engine` is the model's msclip_amd.engine.Engine."""
 
-    def __init__(self, model, lr=None, lr_share=None, wd=0.2, wd_share=None, betas=(0.9, 0.98), eps=1e-6):
+    def __init__(self, model, lr=None, lr_share=None, wd=0.2, wd_share=None, betas=(0.9, 0.98), eps=1e-6, bn="frozen"):
+        """bn = "frozen": BatchNorm with its running statistics (gamma / beta trained; the inference kernels' folded
+        form); bn = "batch": train-mode BatchNorm -- per-GPU batch statistics in the forward, their backward, running
+        statistics updated with momentum 0.1 (what the reference's modules do in train())."""
+        assert bn in ("frozen", "batch")
+        self.bn = bn
+        self.convbn = None
         self.model = model
         self.eng = model.engine()
         self.lr, self.lr_share = lr, lr_share
@@ -125,7 +131,14 @@ class TrainStep:
             keep = []
             sv["img"] = e._check_img(img)
             e.force_unfused = True                   # layer-by-layer conv side: every map the backward reads stays in `w`
-            e._vision_front(sv["img"], w, Bi, keep_pre=keep)
+            cb = None
+            if self.bn == "batch":
+                if self.convbn is None:
+                    self.convbn = ConvSideBatchNorm(self)
+                cb = self.convbn
+                cb.begin(sv["img"], w, Bi)
+                cb.front()
+            e._vision_front(sv["img"], w, Bi, keep_pre=keep, convs_done=cb is not None)
             sv["tok_pre"] = keep[0]
             g2 = e.g * e.g
             e._text_front(sv["tok"], w, Bt)
@@ -136,12 +149,17 @@ class TrainStep:
                 L = dict(adapter=None)
                 if vb is not None and i in e.lateral:
                     j = e.lateral.index(i)
-                    e._parallel_stage(j, w, Bi)
                     a = e.adapters[j]
-                    hip.dwpool(w["par"][j], a["pool"], w["pool"][j], Bi, e.par_hw[j], e.par_hw[j], a["C"], a["k"])
-                    hip.gemm(w["pool"][j], a["pw"].weight, w["T"], M=Bi * g2, N=a["pw"].cout, bias=a["pw"].bias, ldx=a["pw"].cin)
                     asum = torch.empty(Mv, D, dtype=F32, device=e.dev)
-                    hip.adapter_sum(X[:Mv], w["T"], a["dww"], a["dwb"], asum, Bi, e.Lv, e.g, e.usecls)
+                    if cb is not None:
+                        cb.stage(j)
+                        cb.adapter_top(j, w["T"])
+                        cb.adapter_sum(j, X[:Mv], w["T"], asum)
+                    else:
+                        e._parallel_stage(j, w, Bi)
+                        hip.dwpool(w["par"][j], a["pool"], w["pool"][j], Bi, e.par_hw[j], e.par_hw[j], a["C"], a["k"])
+                        hip.gemm(w["pool"][j], a["pw"].weight, w["T"], M=Bi * g2, N=a["pw"].cout, bias=a["pw"].bias, ldx=a["pw"].cin)
+                        hip.adapter_sum(X[:Mv], w["T"], a["dww"], a["dwb"], asum, Bi, e.Lv, e.g, e.usecls)
                     x_pre = X[:Mv].clone()                                                   # what the depthwise 3x3 read
                     hip.layernorm(asum, a["ln"].g, a["ln"].b, X[:Mv], Mv)                    # X[:Mv] <- ln_adapt(sum), fp32
                     L["adapter"] = dict(j=j, sum=asum, x_pre=x_pre)
@@ -177,6 +195,8 @@ class TrainStep:
                 del hid
                 sv["layers"][i] = L
             e.force_unfused = False
+            if cb is not None:
+                cb.update_running_stats()
             # ---- heads + loss
             sv["x_out"] = X[:M].clone()
             e._head_image(w, Bi)
@@ -272,8 +292,11 @@ class TrainStep:
             grads["logit_scale"] = dscale.reshape(())
 
             dX = torch.zeros(M, D, dtype=F32, device=dev)
-            conv = ConvSideBackward(self)
-            conv.begin(sv["img"], e._workspace(Bi, Bt), Bi)
+            if self.bn == "batch":
+                conv = self.convbn                       # holds the raw conv outputs / batch statistics of this forward
+            else:
+                conv = ConvSideBackward(self)
+                conv.begin(sv["img"], e._workspace(Bi, Bt), Bi)
 
             def head(feat_raw, dfeat, hrow, w_proj, ln, key_proj, key_ln, row_idx=None, row_mul=1):
                 dfr = torch.empty_like(feat_raw)
@@ -351,8 +374,12 @@ class TrainStep:
                     dg, db = hip.layernorm_bwd(ad["sum"], dX[:Mv], a["ln"].g, dsum, Mv, accumulate=False)
                     pre = f"visual.transformer.parallel_lateral_adapter.{ad['j']}.ln_adapt"
                     grads[pre + ".weight"], grads[pre + ".bias"] = dg, db
-                    conv.adapter(grads, ad["j"], dsum, ad["x_pre"])      # adapter convs + parallel stage j (train_conv.py)
-                    hip.adapter_dx(dsum, a["dww"], dX[:Mv], Bi, e.Lv, e.g, e.usecls)
+                    if self.bn == "batch":                               # adapter convs + parallel stage j (train_conv.py)
+                        dgrid, dww = conv.adapter(grads, ad["j"], dsum, ad["x_pre"])
+                    else:
+                        conv.adapter(grads, ad["j"], dsum, ad["x_pre"])
+                        dgrid, dww = dsum, a["dww"]
+                    hip.adapter_dx(dgrid, dww, dX[:Mv], Bi, e.Lv, e.g, e.usecls)
                 sv["layers"][i] = None                                                         # free the layer's activations
             # ---- fronts: text embedding, image cls / positional embeddings, ln_pre
             demb = torch.zeros_like(e.emb, dtype=F32)
@@ -413,8 +440,9 @@ class TrainStep:
         self.eng.refresh(force=True)
 
 
-def from_config(model, config):
-    """TrainStep with the reference yaml's optimizer hyper-parameters (TRAIN.LR / WD, CUSTOM.LR_SHARE / WD_SHARE)."""
+def from_config(model, config, bn="batch"):
+    """TrainStep with the reference yaml's optimizer hyper-parameters (TRAIN.LR / WD, CUSTOM.LR_SHARE / WD_SHARE).
+    bn = "batch" (default): train-mode BatchNorm as the reference's modules run in train(); "frozen": running statistics."""
     tr, cu = config.TRAIN, config.CUSTOM
     return TrainStep(model, lr=tr.get("LR", 1e-4), lr_share=cu.get("LR_SHARE", None) or None, wd=tr.get("WD", 0.2),
-                     wd_share=cu.get("WD_SHARE", None) or None)
+                     wd_share=cu.get("WD_SHARE", None) or None, bn=bn)

@@ -2,10 +2,12 @@
 stem (M.py:1898-2000), the parallel convolutional branch (M.py:1812-1895) and the convolutional halves of the lateral
 adapters (M.py:1752-1778).
 
-BatchNorm semantics: FROZEN statistics.  The HIP forward folds every BatchNorm's running mean / variance into the
-adjacent convolution (packing.py), and this backward differentiates exactly that function: gamma, beta and the
-convolution weights receive gradients, the running statistics are constants (what autograd of the reference gives in
-eval() mode -- the mode tests/golden/*.grads.npz was captured in).  Train-mode batch statistics are not implemented.
+Two BatchNorm semantics.  ConvSideBackward (first half of this file): FROZEN statistics -- the HIP forward folds every
+BatchNorm's running mean / variance into the adjacent convolution (packing.py) and the backward differentiates exactly
+that function: gamma, beta and the convolution weights receive gradients, the running statistics are constants (what
+autograd of the reference gives in eval() mode; fixture tests/golden/*.grads.npz).  ConvSideBatchNorm (second half):
+train-mode BatchNorm with per-GPU batch statistics, their backward and the running-statistics update (the reference in
+train() mode; fixture tests/golden/b32-yfcc-msclips.grads_trainbn.npz).
 
 Every convolution is a GEMM in the forward (implicit im2col gather); here
     dWf = dY^T . im2col(X)      msclip_im2col + the split-K wgrad GEMM of train._wgrad
@@ -224,3 +226,285 @@ class ConvSideBackward:
         dpre = self._relu_bwd(dy, w["S1"])
         self._first_conv(grads, sp + ".conv1.weight", sp + ".bn1", dpre)
         self.col_img = None
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Train-mode BatchNorm (per-GPU batch statistics): what nn.BatchNorm2d does in train() (M.py:1825-1861, 1920-1936).
+# Forward: every convolution runs with its RAW weights (no fold), the batch mean / biased variance of its output are
+# reduced on the GPU (msclip_bn_stats), normalise + affine (+ residual, ReLU) is one element-wise pass (msclip_bn_apply),
+# and the running statistics get the reference's update (momentum 0.1, unbiased variance).  Backward: dgamma / dbeta and
+# the gradient of the raw convolution output (msclip_bn_bwd_reduce / _dx), then the same GEMM-based convolution backward
+# as above on the raw weights (no fold chain rule).  The stem's 3x3 and its 1x1 shortcut are separate convolutions here:
+# their two BatchNorms see different statistics, the centre-tap merge only holds for frozen statistics.
+# ----------------------------------------------------------------------------------------------------------------------
+from . import packing as P
+
+
+class _RawSpecs:
+    """Raw-weight ConvSpecs (geometry and chunk tables built once; weights refreshed from the module every step)."""
+
+    def __init__(self, e):
+        self.e = e
+        sd = {k: t.detach() for k, t in e.model.state_dict().items()}
+        dev = e.dev
+        sp = "visual.transformer.resblocks.0"
+
+        def spec(key, h, s, pad):
+            wt = sd[key + ".weight"].float()
+            return P.ConvSpec(wt, torch.zeros(wt.shape[0]), h, h, s, pad).to(dev), key + ".weight"
+        self.items = []                                  # (spec, state_dict key)
+        self.stem = []
+        for i, fs in enumerate(e.stem_specs):
+            q = f"{sp}.resnet_stage.conv_{i}"
+            main, short = spec(q + ".conv1", fs.h_in, fs.stride, 1), spec(q + ".downsample.0", fs.h_in, fs.stride, 0)
+            self.stem.append((main[0], short[0], q))
+            self.items += [main, short]
+        self.par = [None]
+        for j in range(1, 5):
+            q = f"visual.transformer.parallel_branch_v.{j}.resnet_stage.conv_0"
+            c1f, c2f, crf, c3f = e.par_specs[j]
+            quad = [spec(q + ".conv1", c1f.h_in, 1, 0), spec(q + ".conv2", c2f.h_in, c2f.stride, c2f.pad),
+                    spec(q + ".residual_conv", crf.h_in, crf.stride, 0), spec(q + ".conv3", c3f.h_in, 1, 0)]
+            self.par.append(tuple(x[0] for x in quad) + (q,))
+            self.items += quad
+        self.pw = []
+        for j in range(5):
+            p = f"visual.transformer.parallel_lateral_adapter.{j}"
+            pw = spec(p + ".top2bottom_pw_conv.conv", e.g, 1, 0)
+            self.pw.append(pw[0])
+            self.items.append(pw)
+        self.refresh()
+
+    def refresh(self):
+        e = self.e
+        sd = {k: t.detach() for k, t in e.model.state_dict().items()}
+        for sp_, key in self.items:
+            sp_.weight.copy_(P.pad_k(P.conv_weight_matrix(sd[key].float())).to(BF))
+        sp = "visual.transformer.resblocks.0"
+
+        def first(key):                                  # [48, 3, 3, 3] -> [48, 64] bf16 in the patch matrix's (kh, kw, ci) order
+            return P.pad_k(P.conv_weight_matrix(sd[key].float())).to(BF).contiguous()
+        self.w_conv1 = first(sp + ".conv1.weight")
+        self.w_par0 = first("visual.transformer.parallel_branch_v.0.conv.weight")
+        self.pool, self.dww = [], []
+        for j in range(5):
+            p = f"visual.transformer.parallel_lateral_adapter.{j}"
+            wd = sd[p + ".top2bottom_dw_conv.conv.weight"].float()
+            c, _, k, _ = wd.shape
+            self.pool.append(wd[:, 0].reshape(c, k * k).t().contiguous())                      # [k*k, C]
+            wb = sd[p + ".bottom_dw_conv.conv.weight"].float()
+            self.dww.append(wb[:, 0].reshape(wb.shape[0], 9).t().contiguous())                 # [9, D]
+        self.sd = sd
+
+
+class ConvSideBatchNorm:
+    """Forward and backward of the conv side with train-mode BatchNorm.  One instance per TrainStep."""
+    MOMENTUM = 0.1
+
+    def __init__(self, train_step):
+        self.ts = train_step
+        self.e = train_step.eng
+        self.raw = _RawSpecs(self.e)
+        self.bw = ConvSideBackward(train_step)           # its generic pieces (_conv_bwd, _relu_bwd, patch matrix) are reused
+
+    # ------------------------------------------------------------------ forward
+    def _bn(self, x_raw, prefix, eps, out, M, relu=False, resid=None):
+        sd = self.raw.sd
+        mean, var = hip.bn_stats(x_raw, M)
+        rstd = torch.rsqrt(var + eps)
+        g, b = sd[prefix + ".weight"].float(), sd[prefix + ".bias"].float()
+        scale = (g * rstd).contiguous()
+        shift = (b - mean * scale).contiguous()
+        hip.bn_apply(x_raw, scale, shift, out, M, relu=relu, resid=resid)
+        self.saved[prefix] = (x_raw, mean.contiguous(), rstd.contiguous(), g.contiguous(), M)
+        self.stats[prefix] = (mean, var, M)
+        return out
+
+    def begin(self, img, w, Bi):
+        self.raw.refresh()
+        self.saved, self.stats = {}, {}
+        self.w, self.Bi, self.img = w, Bi, img
+        self.bw.begin(img, w, Bi)
+        self.bw.sd = self.raw.sd
+        self.bw._wt = {}                                 # transposed dgrad weights of the previous step are stale
+
+    def front(self):
+        """conv1 / parallel stage 0 (both from one patch matrix of the image) and the four stem stages -> w["S1"], w["P0"],
+        w["stem"][i]."""
+        e, w, Bi = self.e, self.w, self.Bi
+        sp = "visual.transformer.resblocks.0"
+        col = self.bw._image_cols()
+        pix = Bi * e.h1 * e.h1
+        for wt, prefix, out in ((self.raw.w_conv1, sp + ".bn1", e._s1(w, Bi)),
+                                (self.raw.w_par0, "visual.transformer.parallel_branch_v.0.bn", w["P0"])):
+            r = torch.empty(pix, wt.shape[0], dtype=F32, device=e.dev)      # raw conv outputs stay fp32 until normalised
+            hip.gemm(col, wt, r)
+            self._bn(r, prefix, 1e-5, out, pix, relu=True)
+        x = w["S1"]
+        for i, (main, short, q) in enumerate(self.raw.stem):
+            M = Bi * main.h_out * main.w_out
+            rm = torch.empty(M, main.cout, dtype=F32, device=e.dev)
+            rs = torch.empty(M, short.cout, dtype=F32, device=e.dev)
+            e._conv(x, main, rm, Bi)
+            e._conv(x, short, rs, Bi)
+            tmp = _zbuf(M, main.cout, e.dev)
+            self._bn(rm, q + ".bn1", 1e-5, tmp, M)
+            self._bn(rs, q + ".downsample.1", 1e-5, w["stem"][i], M, relu=True, resid=tmp)
+            x = w["stem"][i]
+
+    def stage(self, j):
+        if j == 0:
+            return
+        e, w, Bi = self.e, self.w, self.Bi
+        c1, c2, cr, c3, q = self.raw.par[j]
+        t1, t2, tr = w["par_tmp"][j]
+        src = w["par"][j - 1]
+
+        def run(spec, x, bn, out, relu, resid=None):
+            M = Bi * spec.h_out * spec.w_out
+            r = torch.empty(M, spec.cout, dtype=F32, device=e.dev)
+            e._conv(x, spec, r, Bi)
+            self._bn(r, f"{q}.{bn}", 1e-6, out, M, relu=relu, resid=resid)
+        run(c1, src, "bn1", t1, True)
+        run(c2, t1, "bn2", t2, True)
+        run(cr, src, "residual_bn", tr, False)
+        run(c3, t2, "bn3", w["par"][j], True, resid=tr)
+
+    def adapter_top(self, j, out):
+        """pool = BN(dwconv_{k=s}(par[j])) -> w["pool"][j]; out = pw(pool)."""
+        e, w, Bi = self.e, self.w, self.Bi
+        a = e.adapters[j]
+        hw, g2 = e.par_hw[j], e.g * e.g
+        p = f"visual.transformer.parallel_lateral_adapter.{j}"
+        r = _zbuf(Bi * g2, a["C"], e.dev)
+        hip.dwpool(w["par"][j], self.raw.pool[j], r, Bi, hw, hw, a["C"], a["k"])
+        self._bn(r, p + ".top2bottom_dw_conv.bn", 1e-5, w["pool"][j], Bi * g2)
+        pw = self.raw.pw[j]
+        hip.gemm(w["pool"][j], pw.weight, out, M=Bi * g2, N=pw.cout, ldx=pw.cin)
+
+    def adapter_sum(self, j, X, t, out):
+        """out = [2 cls; BN(dw3x3(grid)) + t] with batch statistics of the depthwise output over the grid rows."""
+        e, Bi = self.e, self.Bi
+        D, g, L = e.D, e.g, e.Lv
+        p = f"visual.transformer.parallel_lateral_adapter.{j}.bottom_dw_conv.bn"
+        zero_t = torch.zeros(Bi * g * g, D, dtype=F32, device=e.dev)
+        zero_b = torch.zeros(D, dtype=F32, device=e.dev)
+        raw_full = torch.empty(Bi * L, D, dtype=F32, device=e.dev)
+        hip.adapter_sum(X, zero_t, self.raw.dww[j], zero_b, raw_full, Bi, L, g, e.usecls)
+        graw = raw_full.view(Bi, L, D)[:, 1:].reshape(Bi * g * g, D)
+        sd = self.raw.sd
+        mean, var = hip.bn_stats(graw)
+        rstd = torch.rsqrt(var + 1e-5)
+        gam, bet = sd[p + ".weight"].float(), sd[p + ".bias"].float()
+        scale = gam * rstd
+        hip.adapter_sum(X, t, (self.raw.dww[j] * scale).contiguous(), (bet - mean * scale).contiguous(), out, Bi, L, g, e.usecls)
+        self.saved[p] = (graw, mean.contiguous(), rstd.contiguous(), gam.contiguous(), Bi * g * g)
+        self.stats[p] = (mean, var, Bi * g * g)
+
+    def update_running_stats(self):
+        """running = (1 - m) running + m batch (unbiased variance), num_batches_tracked += 1: in place on the module's buffers."""
+        bufs = dict(self.e.model.named_buffers())
+        m = self.MOMENTUM
+        with torch.no_grad():
+            for prefix, (mean, var, n) in self.stats.items():
+                bufs[prefix + ".running_mean"].mul_(1 - m).add_(mean, alpha=m)
+                bufs[prefix + ".running_var"].mul_(1 - m).add_(var * (n / max(n - 1, 1)), alpha=m)
+                bufs[prefix + ".num_batches_tracked"].add_(1)
+
+    # ------------------------------------------------------------------ backward
+    def _bn_bwd(self, grads, prefix, dy):
+        x_raw, mean, rstd, gam, M = self.saved[prefix]
+        dx = torch.empty_like(dy) if dy.dtype == F32 else _zbuf(x_raw.shape[0], x_raw.shape[1], x_raw.device)
+        dg, db = hip.bn_bwd(dy, x_raw, mean, rstd, gam, dx, M)
+        grads[prefix + ".weight"], grads[prefix + ".bias"] = dg, db
+        return dx
+
+    def _conv(self, grads, key, spec, wkey, x_in, draw, need_dx=True):
+        G, _, dx = self.bw._conv_bwd(key, spec, x_in, draw, self.Bi, need_dx=need_dx)
+        grads[wkey] = G
+        return dx
+
+    def _first(self, grads, wkey, prefix, dpre):
+        from .train import _wgrad
+        draw = self._bn_bwd(grads, prefix, dpre)
+        pix = self.Bi * self.e.h1 * self.e.h1
+        dwf = _wgrad(draw, self.bw._image_cols(), pix)[:, :27]
+        grads[wkey] = dwf.reshape(draw.shape[1], 3, 3, 3).permute(0, 3, 1, 2).contiguous()
+
+    def adapter(self, grads, j, dsum, x_pre):
+        """-> the gradient matrix to hand to msclip_adapter_dx together with the RAW depthwise filter."""
+        from .train import _wgrad
+        e, w, Bi = self.e, self.w, self.Bi
+        a = e.adapters[j]
+        g, D, C, k, hw, L = e.g, e.D, a["C"], a["k"], e.par_hw[j], e.Lv
+        g2 = g * g
+        p = f"visual.transformer.parallel_lateral_adapter.{j}"
+        dT = dsum.view(Bi, L, D)[:, 1:].reshape(Bi * g2, D)
+        # bottom: BN(dw3x3(grid)) with batch statistics
+        draw = self._bn_bwd(grads, p + ".bottom_dw_conv.bn", dT)
+        dfull = dsum.clone()
+        dfull.view(Bi, L, D)[:, 1:] = draw.view(Bi, g2, D)
+        grads[p + ".bottom_dw_conv.conv.weight"] = hip.dw3x3_wgrad(dfull, x_pre, Bi, L, g).t().reshape(D, 1, 3, 3)
+        # top-down: T = Wp . BN(dwpool(par[j]))
+        dT_bf = hip.cast_bf16(dT)
+        pw = self.raw.pw[j]
+        grads[p + ".top2bottom_pw_conv.conv.weight"] = _wgrad(dT_bf, w["pool"][j], Bi * g2).reshape(D, C, 1, 1)
+        wt = pw.weight[:, :C].t().contiguous()
+        dt = _zbuf(Bi * g2, C, e.dev)
+        hip.gemm(dT_bf, wt, dt)
+        dpool = self._bn_bwd(grads, p + ".top2bottom_dw_conv.bn", dt)
+        grads[p + ".top2bottom_dw_conv.conv.weight"] = hip.dwpool_wgrad(dpool, w["par"][j], Bi, hw, hw, C, k).t().reshape(C, 1, k, k)
+        if self.bw.dpar[0] is None:
+            self.bw.dpar[0] = _zbuf(Bi * hw * hw, C, e.dev)
+            hip.dwpool_bwd(dpool, self.raw.pool[j], self.bw.dpar[0], Bi, hw, hw, C, k)
+        else:
+            hip.dwpool_bwd(dpool, self.raw.pool[j], self.bw.dpar[0], Bi, hw, hw, C, k, accumulate=True)
+        self._stage_bwd(grads, j)
+        return dfull, self.raw.dww[j]
+
+    def _stage_bwd(self, grads, j):
+        e, w = self.e, self.w
+        da, db_ = self.bw.dpar
+        dpre = self.bw._relu_bwd(da, w["par"][j], dy2=db_)
+        self.bw.dpar = [None, None]
+        if j == 0:
+            self._first(grads, "visual.transformer.parallel_branch_v.0.conv.weight", "visual.transformer.parallel_branch_v.0.bn", dpre)
+            return
+        c1, c2, cr, c3, q = self.raw.par[j]
+        t1, t2, _ = w["par_tmp"][j]
+        src = w["par"][j - 1]
+        d3 = self._bn_bwd(grads, q + ".bn3", dpre)
+        dr = self._bn_bwd(grads, q + ".residual_bn", dpre)
+        del dpre
+        dt2 = self._conv(grads, ("par", j, 3), c3, q + ".conv3.weight", t2, d3)
+        dsrc_a = self._conv(grads, ("par", j, "r"), cr, q + ".residual_conv.weight", src, dr)
+        del d3, dr
+        d2 = self._bn_bwd(grads, q + ".bn2", self.bw._relu_bwd(dt2, t2))
+        dt1 = self._conv(grads, ("par", j, 2), c2, q + ".conv2.weight", t1, d2)
+        del d2, dt2
+        d1 = self._bn_bwd(grads, q + ".bn1", self.bw._relu_bwd(dt1, t1))
+        dsrc_b = self._conv(grads, ("par", j, 1), c1, q + ".conv1.weight", src, d1)
+        self.bw.dpar = [dsrc_a, dsrc_b]
+
+    def stem(self, grads, dtok):
+        from .train import _wgrad
+        e, w, Bi = self.e, self.w, self.Bi
+        g2, D = e.g * e.g, e.D
+        sp = "visual.transformer.resblocks.0"
+        dlast = hip.cast_bf16(dtok.view(Bi, e.Lv, D)[:, 1:].reshape(Bi * g2, D))
+        x = w["stem"][-1]
+        grads[sp + ".last_conv.weight"] = _wgrad(dlast, x[:Bi * g2], Bi * g2).reshape(D, x.shape[1], 1, 1)
+        dy = _zbuf(Bi * g2, x.shape[1], e.dev)
+        hip.gemm(dlast, e.w_last.t().contiguous(), dy)
+        dy2 = None
+        for i in reversed(range(len(self.raw.stem))):
+            main, short, q = self.raw.stem[i]
+            x_in = w["stem"][i - 1] if i else w["S1"]
+            dpre = self.bw._relu_bwd(dy, w["stem"][i], dy2=dy2)
+            dm = self._bn_bwd(grads, q + ".bn1", dpre)
+            ds = self._bn_bwd(grads, q + ".downsample.1", dpre)
+            del dpre
+            dy = self._conv(grads, ("stem", i, "m"), main, q + ".conv1.weight", x_in, dm)
+            dy2 = self._conv(grads, ("stem", i, "s"), short, q + ".downsample.0.weight", x_in, ds)
+        self._first(grads, sp + ".conv1.weight", sp + ".bn1", self.bw._relu_bwd(dy, w["S1"], dy2=dy2))
+        self.bw.col_img = None

@@ -271,6 +271,39 @@ def test_relu_dwpool_dw3x3_backward_kernels(gpu_device):
     assert rel(got.t().reshape(D, 1, 3, 3), wb.grad) <= 1e-5
 
 
+@pytest.mark.parametrize("dtype,M,C", [(BF, 5000, 48), (torch.float32, 3000, 768), (BF, 300, 96)])
+def test_batchnorm_train_kernels(gpu_device, dtype, M, C):
+    """msclip_bn_stats / _apply / _bwd_reduce / _bwd_dx against autograd of F.batch_norm(training=True)."""
+    x = (rnd(M, C, seed=1) * 1.5 + 0.3).to(dtype)
+    gam, bet = rnd(C, seed=2) * 0.5 + 1.0, rnd(C, seed=3)
+    dy = rnd(M, C, seed=4).to(dtype)
+    res = rnd(M, C, seed=5, dtype=BF)
+    xr, gr, br = x.float().requires_grad_(True), gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    ref = F.batch_norm(xr, None, None, gr, br, training=True, eps=1e-5)
+    ref.backward(dy.float())
+    mean, var = hip.bn_stats(x)
+    assert rel(mean, x.float().mean(0)) <= 1e-5 and rel(var, x.float().var(0, unbiased=False)) <= 1e-4
+    rstd = torch.rsqrt(var + 1e-5)
+    scale, shift = (gam * rstd).contiguous(), (bet - mean * gam * rstd).contiguous()
+    out = torch.empty(M, C, dtype=BF, device="cuda")
+    hip.bn_apply(x, scale, shift, out)
+    assert rel(out, ref.detach().to(BF)) <= 8e-3
+    out2 = torch.empty(M, C, dtype=torch.float32, device="cuda")
+    hip.bn_apply(x, scale, shift, out2, relu=True, resid=res)
+    assert rel(out2, torch.relu(ref.detach() + res.float())) <= 1e-4
+    dx = torch.empty_like(x)
+    dg, db = hip.bn_bwd(dy, x, mean.contiguous(), rstd.contiguous(), gam, dx)
+    assert rel(dg, gr.grad) <= 1e-4 and rel(db, br.grad) <= 1e-4
+    assert rel(dx, xr.grad) <= (1e-4 if dtype == torch.float32 else 1e-2)
+    if dtype == torch.float32:                                        # fp32 raw conv output with a bf16 gradient (the stem / branch case)
+        dyb = dy.to(BF)
+        dxb = torch.empty_like(dyb)
+        hip.bn_bwd(dyb, x, mean.contiguous(), rstd.contiguous(), gam, dxb)
+        xr2 = x.detach().clone().requires_grad_(True)
+        F.batch_norm(xr2, None, None, gam, bet, training=True, eps=1e-5).backward(dyb.float())
+        assert rel(dxb, xr2.grad) <= 1e-2
+
+
 def _fresh_model(name):
     m = get_clip_model(named_config(name))
     m.load_state_dict(synth_sd(name), strict=True)
@@ -326,6 +359,56 @@ def test_gradients_against_reference_autograd(gpu_device, name):
     assert float(np.median([worst[k] for k in conv_keys])) <= 6e-2
     # the shared tensors' gradients are sums over both towers: a text-only / image-only backward must give less
     assert len([k for k in expect if "visual.transformer.resblocks" in k and ".attn." in k]) == 11 * 4
+
+
+def test_gradients_with_train_mode_batchnorm(gpu_device):
+    """bn="batch": per-GPU batch statistics in every BatchNorm, their backward, the running-statistics update -- against
+    autograd of the reference in train() mode (tests/golden/b32-yfcc-msclips.grads_trainbn.npz).  Same tolerance classes as
+    the frozen-statistics test; the running statistics after one forward to 1e-2 of their largest entry (measured 2e-3:
+    the batch statistics of maps behind bf16 transformer blocks, entering with momentum 0.1)."""
+    import os
+    name = "b32-yfcc-msclips"
+    g = np.load(os.path.join(GOLDEN, name + ".grads_trainbn.npz"))
+    m = _fresh_model(name)
+    ts = train.TrainStep(m, lr=1e-4, bn="batch")
+    b = int(g["batch"])
+    img = synth.synth_images(b, seed=int(g["seed"])).cuda()
+    tok = synth.synth_tokens(b, seed=int(g["seed"]) + 1).cuda()
+    nbt0 = {k: int(v) for k, v in m.state_dict().items() if k.endswith("num_batches_tracked")}
+    loss = ts.forward(img, tok)
+    assert abs(loss.item() - float(g["loss"])) <= 2e-2, (loss.item(), float(g["loss"]))
+    sd = m.state_dict()
+    runs = [k[4:] for k in g.files if k.startswith("run_")]
+    assert len(runs) == 2 * 36                                        # running mean / variance of the 36 BatchNorms
+    run_err = {}
+    for k in runs:
+        ref = torch.from_numpy(g["run_" + k])
+        run_err[k] = rel(sd[k].cpu(), ref)
+        nk = k.rsplit(".", 1)[0] + ".num_batches_tracked"
+        assert int(sd[nk]) == nbt0[nk] + 1
+    print("running statistics after one forward: worst deviation", max(run_err.values()), max(run_err, key=run_err.get))
+    assert max(run_err.values()) <= 1e-2                              # of the tensor's largest entry (0.1 x the batch statistic's error)
+    grads = ts.backward()
+    expect = [k[2:] for k in g.files if k.startswith("g_")]
+    assert sorted(grads) == sorted(expect)
+    worst, am, coss = {}, {}, {}
+    for k in expect:
+        sm, ref = summarize(grads[k]), g["g_" + k]
+        worst[k] = float(np.abs(sm[2:] - ref[2:]).max() / max(float(g["gmax_" + k]), 1e-12))
+        am[k] = abs(sm[1] - ref[1]) / (ref[1] + 1e-12)
+        if "gfull_" + k in g.files:
+            coss[k] = F.cosine_similarity(grads[k].float().cpu().flatten(), torch.from_numpy(g["gfull_" + k]).flatten(), dim=0).item()
+    conv_keys = [k for k in expect if any(f in k for f in CONV_SIDE)]
+    print("train-mode BN: conv side median sample error", float(np.median([worst[k] for k in conv_keys])), "worst",
+          max(worst[k] for k in conv_keys), "worst abs-mean", max(am[k] for k in conv_keys), "lowest cosine",
+          min(coss[k] for k in conv_keys if k in coss), "| token side median", float(np.median([worst[k] for k in expect if k not in conv_keys])))
+    for k in expect:
+        lnb = k.endswith(("ln_1.bias", "ln_2.bias", "ln_final.bias", "ln_post.bias", "ln_pre.bias", "ln_adapt.bias"))
+        tol = (LNB_SAMPLE_TOL, LNB_ABSMEAN_TOL, LNB_COS_TOL) if lnb else (0.40, 0.10, 0.95) if k in conv_keys else (0.10, 0.08, 0.99)
+        assert worst[k] <= tol[0], (k, worst[k])
+        assert am[k] <= tol[1], (k, am[k])
+        if k in coss:
+            assert coss[k] >= tol[2], (k, coss[k])
 
 
 def test_adamw_step_with_reference_param_groups_lowers_the_loss(gpu_device):

@@ -146,22 +146,28 @@ def zeroshot_fixture(model, name):
     print(f"{name}: zero-shot fixture top1 {top1:.2f}% on 64 generated images, W {tuple(W.shape)}")
 
 
-def grads_fixture(model, name):
+def grads_fixture(model, name, train_bn=False, batch=None):
     """f3 (backward) fixture: autograd of the REAL reference through forward(image, text) and the symmetric CE
     0.5 * (CE(logits) + CE(logits^T)) (the loss itself is not in the reference), eval-mode BatchNorm,
     fp32, the golden batch.  Stored per parameter: mean, abs-mean, abs-max and a 64-point strided sample of the gradient (the
     shared tensors' gradients are the SUM over both towers: one Parameter object, M.py:2808-2830), plus the loss."""
-    img = synth.synth_images(BATCH, seed=SEED)
-    tok = synth.synth_tokens(BATCH, seed=SEED + 1)
+    nb = batch or BATCH                      # train-mode BN: 16 (statistics over 4 images are ill-conditioned in any precision)
+    img = synth.synth_images(nb, seed=SEED)
+    tok = synth.synth_tokens(nb, seed=SEED + 1)
     R.ensure_single_rank_group()
     for p in model.parameters():
         p.grad = None
         p.requires_grad_(True)
+    if train_bn:
+        # train(): every BatchNorm normalises with the batch statistics of this (per-GPU) batch and updates its running
+        # statistics (momentum 0.1, unbiased variance); dropout / drop-path are 0 in the released configs
+        model.train()
+        before = {k: v.clone() for k, v in model.state_dict().items() if "running_" in k}
     logits = model(img, tok)
-    lab = torch.arange(BATCH)
+    lab = torch.arange(nb)
     loss = 0.5 * (torch.nn.functional.cross_entropy(logits, lab) + torch.nn.functional.cross_entropy(logits.t(), lab))
     loss.backward()
-    out = {"loss": np.float32(loss.item()), "batch": np.int64(BATCH), "seed": np.int64(SEED)}
+    out = {"loss": np.float32(loss.item()), "batch": np.int64(nb), "seed": np.int64(SEED)}
     seen = {}
     for k, p in model.named_parameters(remove_duplicate=False):
         if p.grad is None:
@@ -174,8 +180,15 @@ def grads_fixture(model, name):
         out["gmax_" + k] = np.float32(p.grad.abs().max().item())
         if p.grad.numel() <= 4096:
             out["gfull_" + k] = p.grad.detach().numpy().astype(np.float32)
-    np.savez_compressed(os.path.join(OUT, f"{name}.grads.npz"), **out)
-    print(f"{name}: grads fixture, loss {loss.item():.5f}, {sum(k.startswith('g_') for k in out)} gradient tensors")
+    if train_bn:
+        after = model.state_dict()
+        for k in before:                                   # the running statistics after ONE forward in train()
+            out["run_" + k] = after[k].detach().numpy().astype(np.float32)
+        model.load_state_dict({**after, **before})         # put the statistics back: later fixtures start from the same model
+        model.eval()
+    np.savez_compressed(os.path.join(OUT, f"{name}.grads{'_trainbn' if train_bn else ''}.npz"), **out)
+    print(f"{name}: grads fixture{' (train-mode BN)' if train_bn else ''}, loss {loss.item():.5f}, "
+          f"{sum(k.startswith('g_') for k in out)} gradient tensors")
     for p in model.parameters():
         p.grad = None
 
@@ -215,6 +228,8 @@ def main():
         if name.startswith("b32"):
             zeroshot_fixture(model, name)
         grads_fixture(model, name)              # b16: the 197-token grid (query-blocked attention backward, k = 8 adapters)
+        if name.startswith("b32"):
+            grads_fixture(model, name, train_bn=True, batch=16)
     multirank_gather_fixture()
 
 

@@ -8,9 +8,10 @@ from msclip_amd import synth, train
 from msclip_amd.clip_openai_pe_res_v1 import get_clip_model
 from msclip_amd.config import named_config
 name = "b32-yfcc-msclips"
-g = np.load(os.path.join(GOLDEN, name + ".grads.npz"))
+BN = os.environ.get("BN", "frozen")
+g = np.load(os.path.join(GOLDEN, name + (".grads_trainbn.npz" if BN == "batch" else ".grads.npz")))
 m = get_clip_model(named_config(name)); m.load_state_dict(synth_sd(name), strict=True); m = m.cuda().eval()
-ts = train.TrainStep(m, lr=1e-4)
+ts = train.TrainStep(m, lr=1e-4, bn=BN)
 b = int(g["batch"])
 img = synth.synth_images(b, seed=int(g["seed"])).cuda(); tok = synth.synth_tokens(b, seed=int(g["seed"]) + 1).cuda()
 print("loss", ts.forward(img, tok).item(), float(g["loss"]))
