@@ -319,9 +319,9 @@ class CLIP(nn.Module):
     def train(self, mode=True):
         if mode:
             logging.getLogger(__name__).warning(
-                "msclip_amd: the HIP forward runs eval-mode BatchNorm (folded running statistics) and the backward "
-                "slice (msclip_amd.train) covers the transformer blocks and the contrastive head only; "
-                "train(True) flips the module flags and nothing else")
+                "msclip_amd: forward() / encode_*() are the inference path (no autograd, BatchNorm folded with its running "
+                "statistics) whatever the module flags say; the training step -- forward with train-mode BatchNorm, backward "
+                "of every parameter, AdamW -- is msclip_amd.train.TrainStep / from_config(model, config)")
         return super().train(mode)
 
     def engine(self):

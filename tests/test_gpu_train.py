@@ -411,11 +411,13 @@ def test_gradients_with_train_mode_batchnorm(gpu_device):
             assert coss[k] >= tol[2], (k, coss[k])
 
 
-def test_adamw_step_with_reference_param_groups_lowers_the_loss(gpu_device):
+@pytest.mark.parametrize("bn", ["frozen", "batch"])
+def test_adamw_step_with_reference_param_groups_lowers_the_loss(gpu_device, bn):
     name = "b32-yfcc-msclips"
     m = _fresh_model(name)
     cfg = named_config(name)
-    ts = train.from_config(m, cfg)
+    ts = train.from_config(m, cfg, bn=bn)
+    assert train.from_config(m, cfg).bn == "batch"                     # the reference's train() semantics are the default
     groups = {k: (lr, wd) for k, _, lr, wd in ts.param_groups()}
     assert groups["visual.transformer.resblocks.3.mlp.c_fc.weight"] == (cfg.CUSTOM.LR_SHARE, cfg.CUSTOM.WD_SHARE)
     assert groups["visual.transformer.resblocks.3.mlp.c_fc.bias"][1] == 0.0                # WITHOUT_WD_LIST: bias
@@ -428,7 +430,17 @@ def test_adamw_step_with_reference_param_groups_lowers_the_loss(gpu_device):
     ts.step(ts.backward())
     assert not torch.equal(before, m.visual.transformer.resblocks[5].mlp.c_fc.weight.detach())
     assert m.transformer.resblocks[5].mlp.c_fc.weight.data_ptr() == m.visual.transformer.resblocks[5].mlp.c_fc.weight.data_ptr()
+    inf0 = None
+    if bn == "batch":
+        inf0 = m.contrastive_loss(img, tok).item()
     l1 = ts.forward(img, tok).item()
-    assert abs(l1 - m.contrastive_loss(img, tok).item()) <= 2e-2          # the inference path sees the updated weights
+    if bn == "frozen":
+        assert abs(l1 - m.contrastive_loss(img, tok).item()) <= 2e-2      # the inference path sees the updated weights
+    else:
+        # two train-mode forwards: every BatchNorm's counter moved twice and the inference path (running statistics,
+        # re-folded by the engine) changed with them
+        nbt = m.state_dict()["visual.transformer.parallel_branch_v.2.resnet_stage.conv_0.bn2.num_batches_tracked"]
+        assert int(nbt) == 1002
+        assert abs(m.contrastive_loss(img, tok).item() - inf0) > 1e-4
     ts.saved = None
     assert l1 < l0, (l0, l1)
