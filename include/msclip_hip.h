@@ -240,7 +240,8 @@ int msclip_dw3x3_wgrad(const float* dsum, int lds, const float* x, int ldx, floa
  * msclip_bn_stats: part[chunks][2][C] = per-row-chunk (sum x, sum x^2); fold with msclip_colsum.
  * msclip_bn_apply: y = act(x * scale[c] + shift[c] [+ resid (bf16)]).
  * msclip_bn_bwd_reduce: part[chunks][2][C] = (sum dy, sum dy * xhat), xhat = (x - mean) * rstd.
- * msclip_bn_bwd_dx: dx = gamma * rstd * (dy - dbeta / M - xhat * dgamma / M). */
+ * msclip_bn_bwd_dx: dx = gamma * rstd * (dy - dbeta / n_stat - xhat * dgamma / n_stat), n_stat = rows the statistics cover
+ *   (= M unless the caller passes r consecutive rows as one row of r*C columns with r-fold repeated channel vectors). */
 int msclip_bn_stats(const void* x, int ld, int x_f32, float* part, int M, int C, int chunks, void* stream);
 int msclip_bn_apply(const void* x, int ld, int x_f32, const float* scale, const float* shift, const void* resid, int ldr,
                     void* y, int ldy, int y_f32, int M, int C, int relu, void* stream);
@@ -248,7 +249,7 @@ int msclip_bn_bwd_reduce(const void* dy, int lddy, int dy_f32, const void* x, in
                          const float* rstd, float* part, int M, int C, int chunks, void* stream);
 int msclip_bn_bwd_dx(const void* dy, int lddy, int dy_f32, const void* x, int ld, int x_f32, const float* mean,
                      const float* rstd, const float* gamma, const float* dbeta, const float* dgamma, void* dx, int lddx, int M,
-                     int C, void* stream);
+                     int C, long long n_stat, void* stream);
 
 /* AdamW with decoupled weight decay on one fp32 tensor (step >= 1 for the bias corrections). */
 int msclip_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,

@@ -265,38 +265,41 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const TD* __restrict
     part[((size_t)blockIdx.y * 2 + 1) * C + c] = red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l];
   }
 }
-// y = act(x * scale[c] + shift[c] [+ resid]) -> bf16 or fp32 (TO)
+// y = act(x * scale[c] + shift[c] [+ resid]) -> bf16 or fp32 (TO).  thread = one column, blockIdx.y = row chunk: the
+// per-channel constants are loaded once, consecutive lanes read consecutive columns, no index division per element.
 template <typename T, typename TO>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, int ld, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const bf16_t* __restrict__ resid,
-                                                       int ldr, TO* __restrict__ y, int ldy, int M, int C, int relu) {
-  const size_t total = (size_t)M * C;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const size_t m = i / C;
-    const int c = (int)(i - m * C);
-    float v = fmaf(ld_f(x + m * ld + c), scale[c], shift[c]);
-    if (resid) v += bf16_to_f32(resid[m * ldr + c]);
+                                                       int ldr, TO* __restrict__ y, int ldy, int M, int C, int relu,
+                                                       int rows_per_chunk) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float sc = scale[c], sh = shift[c];
+  const int m0 = blockIdx.y * rows_per_chunk, m1 = min(M, m0 + rows_per_chunk);
+  for (int m = m0; m < m1; ++m) {
+    float v = fmaf(ld_f(x + (size_t)m * ld + c), sc, sh);
+    if (resid) v += bf16_to_f32(resid[(size_t)m * ldr + c]);
     if (relu) v = fmaxf(v, 0.f);
-    if constexpr (sizeof(TO) == 2) y[m * ldy + c] = f32_to_bf16(v);
-    else y[m * ldy + c] = v;
+    if constexpr (sizeof(TO) == 2) y[(size_t)m * ldy + c] = f32_to_bf16(v);
+    else y[(size_t)m * ldy + c] = v;
   }
 }
-// dx = gamma * rstd * (dy - dbeta / M - xhat * dgamma / M)
+// dx = gamma * rstd * (dy - dbeta / n - xhat * dgamma / n), n = the number of rows the statistics were taken over
 template <typename T, typename TD>
 __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const TD* __restrict__ dy, int lddy, const T* __restrict__ x, int ld,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ gamma, const float* __restrict__ dbeta,
                                                         const float* __restrict__ dgamma, TD* __restrict__ dx, int lddx, int M,
-                                                        int C) {
-  const size_t total = (size_t)M * C;
-  const float inv = 1.f / (float)M;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const size_t m = i / C;
-    const int c = (int)(i - m * C);
-    const float xh = (ld_f(x + m * ld + c) - mean[c]) * rstd[c];
-    const float v = gamma[c] * rstd[c] * (ld_f(dy + m * lddy + c) - dbeta[c] * inv - xh * dgamma[c] * inv);
-    if constexpr (sizeof(TD) == 2) dx[m * lddx + c] = f32_to_bf16(v);
-    else dx[m * lddx + c] = v;
+                                                        int C, float inv_n, int rows_per_chunk) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float mu = mean[c], rs = rstd[c], g = gamma[c] * rs, kb = dbeta[c] * inv_n, kg = dgamma[c] * inv_n;
+  const int m0 = blockIdx.y * rows_per_chunk, m1 = min(M, m0 + rows_per_chunk);
+  for (int m = m0; m < m1; ++m) {
+    const float xh = (ld_f(x + (size_t)m * ld + c) - mu) * rs;
+    const float v = g * (ld_f(dy + (size_t)m * lddy + c) - kb - xh * kg);
+    if constexpr (sizeof(TD) == 2) dx[(size_t)m * lddx + c] = f32_to_bf16(v);
+    else dx[(size_t)m * lddx + c] = v;
   }
 }
 
@@ -381,11 +384,15 @@ extern "C" int msclip_bn_stats(const void* x, int ld, int x_f32, float* part, in
 extern "C" int msclip_bn_apply(const void* x, int ld, int x_f32, const float* scale, const float* shift, const void* resid,
                                int ldr, void* y, int ldy, int y_f32, int M, int C, int relu, void* stream) {
   if (!x || !scale || !shift || !y || M <= 0 || C <= 0 || ld < C || ldy < C || (resid && ldr < C)) return MSCLIP_EINVAL;
-  const int grid = grid_for((size_t)M * C, 256 * 8, 16384);
+  int chunks = (M + 63) / 64;                          // >= 64 rows per block, at most ~4096 blocks
+  const int cb = (C + 255) / 256;
+  if (chunks * cb > 4096) chunks = 4096 / cb > 0 ? 4096 / cb : 1;
+  const int rpc = (M + chunks - 1) / chunks;
+  const dim3 grid(cb, (M + rpc - 1) / rpc);
   hipStream_t st = (hipStream_t)stream;
   const bf16_t* r = (const bf16_t*)resid;
 #define BN_APPLY(T, TO) \
-  hipLaunchKernelGGL((bn_apply_kernel<T, TO>), dim3(grid), dim3(256), 0, st, (const T*)x, ld, scale, shift, r, ldr, (TO*)y, ldy, M, C, relu)
+  hipLaunchKernelGGL((bn_apply_kernel<T, TO>), grid, dim3(256), 0, st, (const T*)x, ld, scale, shift, r, ldr, (TO*)y, ldy, M, C, relu, rpc)
   if (x_f32 && y_f32) BN_APPLY(float, float);
   else if (x_f32) BN_APPLY(float, bf16_t);
   else if (y_f32) BN_APPLY(bf16_t, float);
@@ -413,14 +420,20 @@ extern "C" int msclip_bn_bwd_reduce(const void* dy, int lddy, int dy_f32, const 
 
 extern "C" int msclip_bn_bwd_dx(const void* dy, int lddy, int dy_f32, const void* x, int ld, int x_f32, const float* mean,
                                 const float* rstd, const float* gamma, const float* dbeta, const float* dgamma, void* dx,
-                                int lddx, int M, int C, void* stream) {
-  if (!dy || !x || !mean || !rstd || !gamma || !dbeta || !dgamma || !dx || M <= 0 || C <= 0 || ld < C || lddy < C || lddx < C)
+                                int lddx, int M, int C, long long n_stat, void* stream) {
+  if (!dy || !x || !mean || !rstd || !gamma || !dbeta || !dgamma || !dx || M <= 0 || C <= 0 || ld < C || lddy < C || lddx < C ||
+      n_stat <= 0)
     return MSCLIP_EINVAL;
-  const int grid = grid_for((size_t)M * C, 256 * 8, 16384);
+  int chunks = (M + 63) / 64;
+  const int cb = (C + 255) / 256;
+  if (chunks * cb > 4096) chunks = 4096 / cb > 0 ? 4096 / cb : 1;
+  const int rpc = (M + chunks - 1) / chunks;
+  const dim3 grid(cb, (M + rpc - 1) / rpc);
+  const float inv_n = 1.f / (float)n_stat;
   hipStream_t st = (hipStream_t)stream;
-#define BN_DX(T, TD)                                                                                                        \
-  hipLaunchKernelGGL((bn_bwd_dx_kernel<T, TD>), dim3(grid), dim3(256), 0, st, (const TD*)dy, lddy, (const T*)x, ld, mean, rstd, \
-                     gamma, dbeta, dgamma, (TD*)dx, lddx, M, C)
+#define BN_DX(T, TD)                                                                                                      \
+  hipLaunchKernelGGL((bn_bwd_dx_kernel<T, TD>), grid, dim3(256), 0, st, (const TD*)dy, lddy, (const T*)x, ld, mean, rstd, gamma, \
+                     dbeta, dgamma, (TD*)dx, lddx, M, C, inv_n, rpc)
   if (x_f32 && dy_f32) BN_DX(float, float);
   else if (x_f32) BN_DX(float, bf16_t);
   else if (dy_f32) BN_DX(bf16_t, float);

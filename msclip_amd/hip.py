@@ -116,7 +116,7 @@ def lib():
         L.msclip_bn_stats.argtypes = [vp, ci, ci, vp, ci, ci, ci, vp]
         L.msclip_bn_apply.argtypes = [vp, ci, ci, vp, vp, vp, ci, vp, ci, ci, ci, ci, ci, vp]
         L.msclip_bn_bwd_reduce.argtypes = [vp, ci, ci, vp, ci, ci, vp, vp, vp, ci, ci, ci, vp]
-        L.msclip_bn_bwd_dx.argtypes = [vp, ci, ci, vp, ci, ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]
+        L.msclip_bn_bwd_dx.argtypes = [vp, ci, ci, vp, ci, ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ll, vp]
         L.msclip_abi_version.restype = ci
         L.msclip_build_arch.restype = ctypes.c_char_p
         for name in EXPORTS:
@@ -603,15 +603,30 @@ def _bn_chunks(M):
     return 1 if M <= 2048 else min(512, (M + 1023) // 1024)
 
 
+def _bn_fold_rows(M, C, *mats):
+    """Column reductions over a narrow matrix waste lanes (48 channels = 48 of a wave's 64 lanes, 192-byte rows).  r
+    consecutive rows are read as ONE row of r*C columns (contiguous matrices only): every lane works on full cache lines,
+    and the r partial results per channel are added afterwards."""
+    r = 1
+    if all(m.is_contiguous() and m.shape[1] == C for m in mats):
+        while C * r < 768 and M % (r * 2) == 0 and M // (r * 2) >= 64:
+            r *= 2
+    return r
+
+
 def bn_stats(x, M=None):
     """x [M, C] bf16 or fp32 -> (mean [C], biased variance [C]) over the rows (fp32)."""
     M = x.shape[0] if M is None else M
     C = x.shape[1]
-    ch = _bn_chunks(M)
-    part = torch.empty(ch, 2 * C, dtype=torch.float32, device=x.device)
-    _check(lib().msclip_bn_stats(_p(x), x.stride(0), int(x.dtype == torch.float32), _p(part), M, C, ch, _stream()),
+    x = x[:M]
+    r = _bn_fold_rows(M, C, x)
+    xw = x.view(M // r, C * r) if r > 1 else x
+    Mw, Cw = xw.shape
+    ch = _bn_chunks(Mw)
+    part = torch.empty(ch, 2 * Cw, dtype=torch.float32, device=x.device)
+    _check(lib().msclip_bn_stats(_p(xw), xw.stride(0), int(x.dtype == torch.float32), _p(part), Mw, Cw, ch, _stream()),
            "msclip_bn_stats")
-    s = (colsum(part) if ch > 1 else part[0]).view(2, C)
+    s = (colsum(part) if ch > 1 else part[0]).view(2, r, C).sum(1)
     mean = s[0] / M
     var = (s[1] / M - mean * mean).clamp_min_(0.0)
     return mean, var
@@ -620,9 +635,15 @@ def bn_stats(x, M=None):
 def bn_apply(x, scale, shift, out, M=None, relu=False, resid=None):
     M = x.shape[0] if M is None else M
     C = x.shape[1]
-    _check(lib().msclip_bn_apply(_p(x), x.stride(0), int(x.dtype == torch.float32), _p(scale), _p(shift),
-                                 _p(resid) if resid is not None else None, resid.stride(0) if resid is not None else 0,
-                                 _p(out), out.stride(0), int(out.dtype == torch.float32), M, C, int(relu), _stream()),
+    xs, os_, rs = x[:M], out[:M], (resid[:M] if resid is not None else None)
+    r = _bn_fold_rows(M, C, *([xs, os_] + ([rs] if rs is not None else [])))
+    if r > 1:                                            # narrow maps: r rows as one row of r*C columns (full cache lines per wave)
+        xs, os_ = xs.view(M // r, C * r), os_.view(M // r, C * r)
+        rs = rs.view(M // r, C * r) if rs is not None else None
+        scale, shift = scale.repeat(r), shift.repeat(r)
+    _check(lib().msclip_bn_apply(_p(xs), xs.stride(0), int(x.dtype == torch.float32), _p(scale), _p(shift),
+                                 _p(rs) if rs is not None else None, rs.stride(0) if rs is not None else 0,
+                                 _p(os_), os_.stride(0), int(out.dtype == torch.float32), M // r, C * r, int(relu), _stream()),
            "msclip_bn_apply")
     return out
 
@@ -634,14 +655,26 @@ def bn_bwd(dy, x, mean, rstd, gamma, dx, M=None):
     C = x.shape[1]
     assert dy.dtype == dx.dtype
     xf, df = int(x.dtype == torch.float32), int(dy.dtype == torch.float32)
-    ch = _bn_chunks(M)
-    part = torch.empty(ch, 2 * C, dtype=torch.float32, device=x.device)
-    _check(lib().msclip_bn_bwd_reduce(_p(dy), dy.stride(0), df, _p(x), x.stride(0), xf, _p(mean), _p(rstd), _p(part), M, C, ch,
-                                      _stream()), "msclip_bn_bwd_reduce")
-    s = (colsum(part) if ch > 1 else part[0]).view(2, C)
+    x, dy = x[:M], dy[:M]
+    r = _bn_fold_rows(M, C, x, dy)
+    xw, dyw = (x.view(M // r, C * r), dy.view(M // r, C * r)) if r > 1 else (x, dy)
+    mw, rw = (mean.repeat(r), rstd.repeat(r)) if r > 1 else (mean, rstd)
+    Mw, Cw = xw.shape
+    ch = _bn_chunks(Mw)
+    part = torch.empty(ch, 2 * Cw, dtype=torch.float32, device=x.device)
+    _check(lib().msclip_bn_bwd_reduce(_p(dyw), dyw.stride(0), df, _p(xw), xw.stride(0), xf, _p(mw), _p(rw), _p(part), Mw, Cw,
+                                      ch, _stream()), "msclip_bn_bwd_reduce")
+    s = (colsum(part) if ch > 1 else part[0]).view(2, r, C).sum(1)
     dbeta, dgamma = s[0].contiguous(), s[1].contiguous()
-    _check(lib().msclip_bn_bwd_dx(_p(dy), dy.stride(0), df, _p(x), x.stride(0), xf, _p(mean), _p(rstd), _p(gamma), _p(dbeta),
-                                  _p(dgamma), _p(dx), dx.stride(0), M, C, _stream()), "msclip_bn_bwd_dx")
+    dxs = dx[:M]
+    if r > 1 and dxs.is_contiguous():
+        dxw = dxs.view(M // r, C * r)
+        gw, bw_, dgw = gamma.repeat(r), dbeta.repeat(r), dgamma.repeat(r)     # named: a dropped temporary's block is re-used at once
+        _check(lib().msclip_bn_bwd_dx(_p(dyw), dyw.stride(0), df, _p(xw), xw.stride(0), xf, _p(mw), _p(rw), _p(gw), _p(bw_),
+                                      _p(dgw), _p(dxw), dxw.stride(0), Mw, Cw, M, _stream()), "msclip_bn_bwd_dx")
+    else:
+        _check(lib().msclip_bn_bwd_dx(_p(dy), dy.stride(0), df, _p(x), x.stride(0), xf, _p(mean), _p(rstd), _p(gamma),
+                                      _p(dbeta), _p(dgamma), _p(dx), dx.stride(0), M, C, M, _stream()), "msclip_bn_bwd_dx")
     return dgamma, dbeta
 
 

@@ -32,7 +32,9 @@ def _zbuf(rows, cols, dev):
     """bf16 [rows, cols] with 64 zero elements of slack behind it (GEMM operands whose K is padded to 64 read past a
     row's end against zero weights: the bytes must be finite)."""
     n = rows * cols
-    return torch.zeros(n + 64, dtype=BF, device=dev)[:n].view(rows, cols)
+    flat = torch.empty(n + 64, dtype=BF, device=dev)
+    flat[n:].zero_()                                     # only the slack needs a defined value: the matrix itself is overwritten
+    return flat[:n].view(rows, cols)
 
 
 class _Fold:
