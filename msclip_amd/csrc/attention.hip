@@ -316,23 +316,34 @@ __global__ __launch_bounds__(256, 2) void attn_wg_kernel(const bf16_t* __restric
   bf16x8 qcur[4], qnext[4];
   if (wave * 32 < L) load_q(wave, qcur);
 
-  // ---- K rows and V^T into LDS (8 threads per row, 16 B each; padded keys are zero)
+  // ---- K rows and V^T into LDS (8 threads per row, 16 B each; padded keys are zero).  Every global load of the pass is
+  // issued before the first LDS write: one memory round trip per workgroup instead of one per 32 keys (the loop form
+  // -- load, write, load, write -- made this pass 7 dependent round trips at L = 197 and the kernel latency-bound:
+  // 121 us per layer at B = 256 against ~40 us of VALU work).
   {
     const int c = tid & 7;
-    for (int key = tid >> 3; key < KP; key += 32) {
-      uint4 ku = make_uint4(0, 0, 0, 0), vu = make_uint4(0, 0, 0, 0);
+    uint4 ku[NT], vu[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int key = (tid >> 3) + 32 * i;
+      ku[i] = make_uint4(0, 0, 0, 0);
+      vu[i] = make_uint4(0, 0, 0, 0);
       if (key < L) {
-        ku = *(const uint4*)(kbase + (size_t)key * ldq + c * 8);
-        vu = *(const uint4*)(vbase + (size_t)key * ldq + c * 8);
+        ku[i] = *(const uint4*)(kbase + (size_t)key * ldq + c * 8);
+        vu[i] = *(const uint4*)(vbase + (size_t)key * ldq + c * 8);
       }
-      *(uint4*)(kl + key * KROW + c * 8) = ku;
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int key = (tid >> 3) + 32 * i;
+      *(uint4*)(kl + key * KROW + c * 8) = ku[i];
       const int w = key & 15;
       const int slot = (key & ~15) + (((w >> 2) & 1) << 3) + (w & 3) + ((w >> 3) << 2);
       bf16_t* dst = vt + (c * 8) * KPS + slot;
-      dst[0 * KPS] = (bf16_t)(vu.x & 0xffff); dst[1 * KPS] = (bf16_t)(vu.x >> 16);
-      dst[2 * KPS] = (bf16_t)(vu.y & 0xffff); dst[3 * KPS] = (bf16_t)(vu.y >> 16);
-      dst[4 * KPS] = (bf16_t)(vu.z & 0xffff); dst[5 * KPS] = (bf16_t)(vu.z >> 16);
-      dst[6 * KPS] = (bf16_t)(vu.w & 0xffff); dst[7 * KPS] = (bf16_t)(vu.w >> 16);
+      dst[0 * KPS] = (bf16_t)(vu[i].x & 0xffff); dst[1 * KPS] = (bf16_t)(vu[i].x >> 16);
+      dst[2 * KPS] = (bf16_t)(vu[i].y & 0xffff); dst[3 * KPS] = (bf16_t)(vu[i].y >> 16);
+      dst[4 * KPS] = (bf16_t)(vu[i].z & 0xffff); dst[5 * KPS] = (bf16_t)(vu[i].z >> 16);
+      dst[6 * KPS] = (bf16_t)(vu[i].w & 0xffff); dst[7 * KPS] = (bf16_t)(vu[i].w >> 16);
     }
   }
   __syncthreads();
