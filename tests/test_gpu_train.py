@@ -444,3 +444,20 @@ def test_adamw_step_with_reference_param_groups_lowers_the_loss(gpu_device, bn):
         assert abs(m.contrastive_loss(img, tok).item() - inf0) > 1e-4
     ts.saved = None
     assert l1 < l0, (l0, l1)
+
+
+def test_training_loop_memorises_two_batches(gpu_device):
+    """Twelve optimizer steps over two fixed batches with train-mode BatchNorm (what tools/train_synthetic.py runs): the
+    loss stays finite and falls by more than half, and the inference path (running statistics after 12 updates) agrees."""
+    name = "b32-yfcc-msclips"
+    m = _fresh_model(name)
+    ts = train.from_config(m, named_config(name))
+    ts.lr = ts.lr_share = 2e-5
+    data = [(synth.synth_images(16, seed=10 + i).cuda(), synth.synth_tokens(16, seed=100 + i).cuda()) for i in range(2)]
+    losses = []
+    for step in range(12):
+        losses.append(ts.forward(*data[step % 2]).item())
+        ts.step(ts.backward())
+    assert all(np.isfinite(losses)), losses
+    assert max(losses[-2:]) < 0.5 * min(losses[:2]), losses
+    assert np.isfinite(m.contrastive_loss(*data[0]).item())
