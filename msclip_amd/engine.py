@@ -100,7 +100,14 @@ class Engine:
         self.S = v.input_resolution
         self.n_layers = len(m.transformer.resblocks)
         assert len(vt.resblocks) == self.n_layers, "vision and text depth must match for the batched layer loop"
-        self.logit_scale_exp = float(m.logit_scale.detach().exp())
+        # exp(logit_scale) is a HOST scalar for the logits kernels (GEMM alpha / LSE scale).  Reading it here would block the
+        # host until everything queued before the re-pack has finished -- after an optimizer step that is the whole
+        # training step, and the next step's launches would start against an empty GPU queue.  So: an asynchronous copy into
+        # pinned memory now, the wait when the value is first used (the logits stage, at the end of a forward).
+        self._ls_host = torch.empty(1, dtype=torch.float32).pin_memory()
+        self._ls_host.copy_(m.logit_scale.detach().exp().reshape(1), non_blocking=True)
+        self._ls_event = torch.cuda.Event()
+        self._ls_event.record(torch.cuda.current_stream(dev))
 
         # --- stem
         sp = "visual.transformer.resblocks.0"
@@ -163,6 +170,14 @@ class Engine:
         self.tpos = sd["positional_embedding"].float().contiguous()
         self.ln_final = _LN(m.ln_final)
         self.w_tproj = sd["text_projection"].t().to(torch.bfloat16).contiguous()      # [E, D]
+
+    @property
+    def logit_scale_exp(self):
+        if self._ls_event is not None:
+            self._ls_event.synchronize()
+            self._ls_val = float(self._ls_host[0])
+            self._ls_event = None
+        return self._ls_val
 
     # ------------------------------------------------------------------ workspace
     def _workspace(self, Bi, Bt):

@@ -56,6 +56,19 @@ def ktab(kh, kw, cin, w_in):
     return tab
 
 
+_KTAB_ON_DEVICE = {}
+
+
+def ktab_on(device, kh, kw, cin, w_in):
+    """The chunk table of a geometry, built and uploaded once per device: re-packing after an optimizer step must not
+    issue host-to-device copies (a pageable upload blocks the host until the stream has drained)."""
+    key = (str(device), kh, kw, cin, w_in)
+    t = _KTAB_ON_DEVICE.get(key)
+    if t is None:
+        t = _KTAB_ON_DEVICE[key] = ktab(kh, kw, cin, w_in).to(device)
+    return t
+
+
 class ConvSpec:
     """One convolution lowered to the gathering GEMM: packed weight, bias, chunk table, geometry."""
 
@@ -67,10 +80,11 @@ class ConvSpec:
         self.w_out = (w_in + 2 * pad - kw) // stride + 1
         self.weight = pad_k(conv_weight_matrix(w_oihw.float())).to(torch.bfloat16)
         self.bias = bias.float().contiguous()
-        self.ktab = ktab(kh, kw, ci, w_in)
+        self.ktab = ktab_on(self.weight.device, kh, kw, ci, w_in)
 
     def to(self, device):
-        self.weight, self.bias, self.ktab = self.weight.to(device), self.bias.to(device), self.ktab.to(device)
+        self.weight, self.bias = self.weight.to(device), self.bias.to(device)
+        self.ktab = ktab_on(device, self.kh, self.kw, self.cin, self.w_in)
         return self
 
     def geometry(self):
