@@ -446,10 +446,11 @@ def test_adamw_step_with_reference_param_groups_lowers_the_loss(gpu_device, bn):
     assert l1 < l0, (l0, l1)
 
 
-def test_training_loop_memorises_two_batches(gpu_device):
+@pytest.mark.parametrize("name", ["b32-yfcc-msclips", "b16-yfcc-msclips"])
+def test_training_loop_memorises_two_batches(gpu_device, name):
     """Twelve optimizer steps over two fixed batches with train-mode BatchNorm (what tools/train_synthetic.py runs): the
-    loss stays finite and falls by more than half, and the inference path (running statistics after 12 updates) agrees."""
-    name = "b32-yfcc-msclips"
+    loss stays finite and falls by more than half, and the inference path (running statistics after 12 updates) agrees.
+    b16: the 14 x 14 grid (k = 8 / 4 / 2 / 1 / 1 adapters, query-blocked attention backward) in train-mode BatchNorm."""
     m = _fresh_model(name)
     ts = train.from_config(m, named_config(name))
     ts.lr = ts.lr_share = 2e-5
