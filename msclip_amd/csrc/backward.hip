@@ -130,6 +130,20 @@ __global__ __launch_bounds__(256) void colsum_bf16x8_kernel(const bf16_t* __rest
   }
 }
 
+// Few rows, very many columns (the S <= 32 fp32 partials of a split-K weight gradient, 0.6-2.4 M columns): one thread per
+// 4 columns walks the rows in order -- 16-byte loads, the same fixed summation order.
+__global__ __launch_bounds__(256) void fold_rows_kernel(const float* __restrict__ x, size_t ld, float* __restrict__ out, int M,
+                                                        size_t N4, int accumulate) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < N4; i += (size_t)gridDim.x * 256) {
+    float4 s = accumulate ? ((const float4*)out)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int m = 0; m < M; ++m) {
+      const float4 v = *(const float4*)(x + (size_t)m * ld + i * 4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    ((float4*)out)[i] = s;
+  }
+}
+
 // ---- fp32 -> bf16 copy of a gradient matrix (the operand of its dgrad / wgrad GEMMs).
 __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ x, int ldx, bf16_t* __restrict__ y, int ldy, int M,
                                                    int C4) {
@@ -422,6 +436,11 @@ extern "C" int msclip_colsum(const void* x, int ld, int is_f32, float* out, int 
                              int chunks, void* stream) {
   if (!x || !out || M <= 0 || N <= 0 || ld < N || chunks < 1 || (chunks > 1 && !scratch)) return MSCLIP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  if (is_f32 && M <= 32 && N >= 16384 && !(N % 4) && !(ld % 4) && !((size_t)x % 16) && !((size_t)out % 16)) {
+    hipLaunchKernelGGL(fold_rows_kernel, dim3(grid_for((size_t)N / 4, 256, 8192)), dim3(256), 0, st, (const float*)x, (size_t)ld,
+                       out, M, (size_t)N / 4, accumulate);
+    return msclip_launch_status();
+  }
   const int rpc = (M + chunks - 1) / chunks;
   float* first = chunks > 1 ? scratch : out;         // [chunks, N] partials, or the result itself
   if (is_f32)

@@ -225,6 +225,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
   const int m0 = blockIdx.y * rows_per_chunk, m1 = min(M, m0 + rows_per_chunk);
   float s = 0.f, q = 0.f;
   if (c < C)
+#pragma unroll 4
     for (int m = m0 + w; m < m1; m += 4) {
       const float v = ld_f(x + (size_t)m * ld + c);
       s += v;
@@ -250,6 +251,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const TD* __restrict
   float s = 0.f, q = 0.f;
   if (c < C) {
     const float mu = mean[c], rs = rstd[c];
+#pragma unroll 4
     for (int m = m0 + w; m < m1; m += 4) {
       const float d = ld_f(dy + (size_t)m * lddy + c);
       s += d;
@@ -276,6 +278,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
   if (c >= C) return;
   const float sc = scale[c], sh = shift[c];
   const int m0 = blockIdx.y * rows_per_chunk, m1 = min(M, m0 + rows_per_chunk);
+#pragma unroll 4
   for (int m = m0; m < m1; ++m) {
     float v = fmaf(ld_f(x + (size_t)m * ld + c), sc, sh);
     if (resid) v += bf16_to_f32(resid[(size_t)m * ldr + c]);
@@ -295,6 +298,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const TD* __restrict__ d
   if (c >= C) return;
   const float mu = mean[c], rs = rstd[c], g = gamma[c] * rs, kb = dbeta[c] * inv_n, kg = dgamma[c] * inv_n;
   const int m0 = blockIdx.y * rows_per_chunk, m1 = min(M, m0 + rows_per_chunk);
+#pragma unroll 4
   for (int m = m0; m < m1; ++m) {
     const float xh = (ld_f(x + (size_t)m * ld + c) - mu) * rs;
     const float v = g * (ld_f(dy + (size_t)m * lddy + c) - kb - xh * kg);

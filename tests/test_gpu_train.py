@@ -63,6 +63,8 @@ def test_transpose_cast_colsum_gelu(gpu_device):
         xb = rnd(mm, nn, seed=6, dtype=BF)
         assert rel(hip.colsum(xb), xb.float().sum(0)) < 1e-5, (mm, nn)
         assert torch.equal(hip.colsum(xb), hip.colsum(xb))
+    part = rnd(7, 65536 + 64, seed=8)                                   # split-K partials: few rows, very wide -> the fold kernel
+    assert rel(hip.colsum(part), part.double().sum(0).float()) < 1e-6 and torch.equal(hip.colsum(part), hip.colsum(part))
     acc = torch.ones(768, device="cuda")
     hip.colsum(f, out=acc, accumulate=True)
     assert rel(acc, f.sum(0) + 1) < 1e-5
