@@ -124,10 +124,15 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # MSCLIP_TEST_SHARED_GPU=1 (tests only, tests/test_gpu_model.py): all ranks on GPU 0 over gloo, so the N > 1 plumbing of
+    # this script (rendezvous, barriers, max-over-ranks timing, rank-0 record) runs on a one-GPU box.  Never a measurement.
+    shared = os.environ.get("MSCLIP_TEST_SHARED_GPU", "0") == "1"
+    if shared:
+        local = 0
     torch.cuda.set_device(local)
-    C.init_distributed("nccl")
+    C.init_distributed("gloo" if shared else "nccl")
     rank = C.comm.rank
-    if world > 1:                                     # the collectives really are RCCL over all N ranks
+    if world > 1 and not shared:                      # the collectives really are RCCL over all N ranks
         assert dist.is_initialized() and dist.get_backend() == "nccl" and dist.get_world_size() == args.gpus, \
             (dist.get_backend(), dist.get_world_size(), args.gpus)
     dev = torch.device("cuda", local)
@@ -207,6 +212,8 @@ def main():
             rec["config"]["bn"] = ("train mode: per-GPU batch statistics, running statistics updated (momentum 0.1)"
                                    if args.bn == "batch" else "frozen running statistics (folded); gamma / beta receive gradients")
         rec["config"]["rccl_ranks"] = dist.get_world_size() if world > 1 else 1
+        if shared:
+            rec["config"]["TEST_ONLY"] = "all ranks share GPU 0 over gloo (MSCLIP_TEST_SHARED_GPU): not a measurement"
         n = probe.summary()[0] if probe is not None else 0
         if n > 0:                       # tiny batches never reach the ping-pong kernel: no roofline line then
             n, kms, flops = probe.summary()

@@ -239,9 +239,9 @@ class TrainStep:
             hip.clip_loss_partial(lse[0], lse[1], S_i, off, 1.0 / (2.0 * n), out)
             if n > Bi:
                 dist.all_reduce(out)
-                lse_all = torch.empty(n // Bi, 2, Bi, dtype=F32, device=e.dev)
-                dist.all_gather_into_tensor(lse_all, lse.contiguous())
-                lse_all = lse_all.permute(1, 0, 2).reshape(2, n).contiguous()                 # rank-major global order
+                lse_flat = torch.empty((n // Bi) * 2, Bi, dtype=F32, device=e.dev)            # concatenated along dim 0: every backend's form
+                dist.all_gather_into_tensor(lse_flat, lse.contiguous())
+                lse_all = lse_flat.view(n // Bi, 2, Bi).permute(1, 0, 2).reshape(2, n).contiguous()   # rank-major global order
             else:
                 lse_all = lse
             sv.update(S_i=S_i, S_t=S_t, lse_loc=lse, lse_all=lse_all)

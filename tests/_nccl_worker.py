@@ -1,4 +1,7 @@
-"""Worker of tests/test_gpu_model.py::test_two_rank_rccl_*: one process per GPU, backend nccl (= RCCL)."""
+"""Worker of tests/test_gpu_model.py::test_two_rank_*: one process per rank.  argv[2] = "nccl" (default; RCCL, one GPU per
+rank) or "gloo" (both ranks on GPU 0: everything of the N > 1 path except RCCL itself runs on a one-GPU box -- rank-major
+gathers issued from the side stream, label offsets, the sharded loss with its scalar all-reduce, the bucketed gradient
+all-reduce of the training step)."""
 import json
 import os
 import sys
@@ -13,13 +16,14 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def main():
     rank, world, out = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), sys.argv[1]
-    torch.cuda.set_device(rank)
+    backend = sys.argv[2] if len(sys.argv) > 2 else "nccl"
+    torch.cuda.set_device(rank if backend == "nccl" else 0)
     from conftest import synth_sd
     from msclip_amd import comm as C, synth
     from msclip_amd.clip_openai_pe_res_v1 import get_clip_model
     from msclip_amd.config import named_config
-    C.init_distributed("nccl")
-    assert dist.get_backend() == "nccl" and C.comm.world_size == world
+    C.init_distributed(backend)
+    assert dist.get_backend() == backend and C.comm.world_size == world
     name = "b32-yfcc-msclips"
     m = get_clip_model(named_config(name))
     m.load_state_dict(synth_sd(name), strict=True)
@@ -29,9 +33,17 @@ def main():
     mine = slice(rank * B, (rank + 1) * B)
     logits = m(img[mine].cuda(), tok[mine].cuda())                    # gather=True from the yaml (GATHER_TENSORS)
     loss = m.contrastive_loss(img[mine].cuda(), tok[mine].cuda())
+    # training step: gradients averaged over the ranks through comm.GradReducer (small buckets: several collectives)
+    from msclip_amd import train
+    ts = train.TrainStep(m, lr=1e-4, bn="frozen")
+    tl = ts.forward(img[mine].cuda(), tok[mine].cuda())
+    grads = ts.backward(bucket_bytes=8 << 20)
+    keys = ["visual.transformer.resblocks.5.mlp.c_fc.weight", "visual.proj", "logit_scale", "ln_final.weight",
+            "visual.transformer.parallel_branch_v.2.resnet_stage.conv_0.conv2.weight", "token_embedding.weight"]
     torch.cuda.synchronize()
     if rank == 0:
-        torch.save({"logits": logits.cpu(), "loss": float(loss)}, out)
+        torch.save({"logits": logits.cpu(), "loss": float(loss), "train_loss": float(tl), "launched": ts.reducer.launched,
+                    "grads": {k: grads[k].float().cpu() for k in keys}, "n_grads": len(grads)}, out)
     dist.barrier()
     dist.destroy_process_group()
 

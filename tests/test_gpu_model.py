@@ -454,6 +454,68 @@ def test_two_rank_rccl_gather_matches_single_process(gpu_device, tmp_path):
     assert abs(got["loss"] - ref_loss) <= 2e-3
 
 
+def test_two_ranks_on_one_gpu_over_gloo(gpu_device, tmp_path):
+    """The N > 1 path on a one-GPU box: two processes share GPU 0 and talk over gloo, so everything but RCCL itself runs --
+    rank-major feature gathers issued from the side stream, label offsets, the sharded loss + scalar all-reduce, and the
+    training step's bucketed gradient all-reduce.  Against the single-process run on the concatenated batch: same
+    logits / loss; the rank-averaged gradients times the world size are the full-batch gradients (each rank differentiates
+    the global loss through its local rows only, lib/utils/comm.py:151-152)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    from msclip_amd import train
+    out = tmp_path / "r0.pt"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29613",
+                        os.path.join(ROOT, "tests", "_nccl_worker.py"), str(out), "gloo"], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = torch.load(out)
+    m = model_for("b32-yfcc-msclips")
+    img, tok = synth.synth_images(12, seed=91).cuda(), synth.synth_tokens(12, seed=92).cuda()
+    ref_logits = m(img, tok).cpu()
+    ref_loss = float(m.contrastive_loss(img, tok))
+    assert (got["logits"] - ref_logits).abs().max().item() <= 2e-2
+    assert abs(got["loss"] - ref_loss) <= 2e-3
+    ts = train.TrainStep(m, lr=1e-4, bn="frozen")
+    full_loss = float(ts.forward(img, tok))
+    full = ts.backward()
+    assert abs(got["train_loss"] - full_loss) <= 2e-3 and got["n_grads"] == len(full) and got["launched"] >= 8
+    for k, g in got["grads"].items():
+        ref = full[k].float().cpu()
+        # logit_scale multiplies the whole logits matrix, which every rank holds in full (reference: all_I @ all_T^T on every
+        # rank): its per-rank gradient already is the global one and the DDP average leaves it unchanged
+        mul = 1.0 if k == "logit_scale" else 2.0
+        err = ((mul * g - ref).abs().max() / ref.abs().max().clamp_min(1e-12)).item()
+        cos = torch.nn.functional.cosine_similarity((mul * g).flatten(), ref.flatten(), dim=0).item()
+        assert err <= 6e-2 and cos >= 0.998, (k, err, cos)            # batch 6 + 6 vs 12: other tile grids / split counts
+
+
+@pytest.mark.parametrize("extra", [[], ["--train"]])
+def test_bench_multi_rank_plumbing_on_one_gpu(gpu_device, extra):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per process), with both ranks on GPU 0
+    over gloo (MSCLIP_TEST_SHARED_GPU=1): rendezvous, warm-up, barrier-fenced timed region, max over ranks, ONE JSON line
+    from rank 0 with the whole-job value."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, MSCLIP_TEST_SHARED_GPU="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29615", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8", "--no-pmc", "--no-cpu-baseline"] + extra,
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["warmup"] == 1 and rec["value"] > 0 and rec["scaling"] == "weak"
+    assert rec["config"]["global_batch"] == 16 and rec["config"]["rccl_ranks"] == 2 and "TEST_ONLY" in rec["config"]
+    assert abs(rec["value"] - 16 * 2 / (rec["ms_per_step"] * 2e-3)) / rec["value"] < 1e-2      # whole-job pairs / max-rank time
+
+
 def test_conv_branch_on_side_stream_is_bitwise_the_inline_schedule(gpu_device, monkeypatch):
     """MSCLIP_CONV_SIDE_STREAM=1 issues the parallel convolutional branch + the adapters' top-down halves on a side HIP
     stream (they depend on the image only) with one event per adapter: same kernels, same data, bitwise the same result."""
