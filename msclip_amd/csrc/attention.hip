@@ -104,24 +104,30 @@ __global__ __launch_bounds__(WPB * 64) void attn_kernel(const bf16_t* __restrict
         }
         const int q = qt * 32 + fr;
         float mx = -INFINITY;
+        // key tiles above the causal diagonal (kt >= nkt: a compile-time bound here) are skipped in the softmax as well,
+        // not only in the MFMAs: a third of the text tower's softmax VALU work at 3 x 3 tiles
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)
+          if (kt < nkt) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
-            const bool ok = key < L && (!CAUSAL || key <= q) && kt < nkt;
-            s[kt][r] = ok ? s[kt][r] : -INFINITY;
-            mx = fmaxf(mx, s[kt][r]);
+            for (int r = 0; r < 16; ++r) {
+              const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
+              const bool ok = key < L && (!CAUSAL || key <= q);
+              s[kt][r] = ok ? s[kt][r] : -INFINITY;
+              mx = fmaxf(mx, s[kt][r]);
+            }
           }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)
+          if (kt < nkt) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float p = __expf(s[kt][r] - mx);
-            s[kt][r] = p;
-            sum += p;
+            for (int r = 0; r < 16; ++r) {
+              const float p = __expf(s[kt][r] - mx);
+              s[kt][r] = p;
+              sum += p;
+            }
           }
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.f / sum;
