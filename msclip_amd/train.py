@@ -1,4 +1,5 @@
-"""Backward pass + optimizer step of the MS-CLIP-S hot path, first slice.
+"""Training step of the MS-CLIP-S hot path: forward that keeps what the backward needs, backward of every parameter,
+AdamW.
 
 The reference release contains no trainer and no loss; what is differentiated here is the forward it defines
 (lib/models/clip_openai_pe_res_v1.py, "M.py") and the symmetric cross-entropy this build adds, with the reference's
@@ -6,21 +7,18 @@ gather semantics (gradient only through the local rows, lib/utils/comm.py:151-15
 (separate LR / weight decay for the shared tensors: experiments/model/*-msclips.yaml `LR_SHARE` / `WD_SHARE`, scaled
 with the world size in lib/config/default.py:299-304; no decay on bias / LayerNorm / BatchNorm, `WITHOUT_WD_LIST`).
 
-Scope of the slice -- everything differentiable on the token side of the model:
-  * the contrastive head (fused LSE sweeps forward; dL/dlogits blocks + GEMMs backward), L2 norm, both projections,
-    ln_post / ln_final;
-  * all transformer blocks of both towers: LayerNorm, QKV / out_proj / c_fc / c_proj GEMMs (dgrad + wgrad through
-    msclip_gemm), attention (msclip_attention_bwd), QuickGELU.  The modality-shared tensors (M.py:2808-2830) receive the
-    SUM of the image- and text-row gradients: the towers' tokens are rows of one matrix and one wgrad GEMM contracts
-    over all of them;
-  * the token path of the lateral adapters (ln_adapt incl. its parameters, the depthwise 3x3 over the token grid, the
-    doubled cls row), ln_pre, class / positional embeddings, token embedding.
-Frozen in this slice (their gradients are NOT produced): the convolutional stem, the parallel convolutional branch, the
-adapters' top-down convolutions and every BatchNorm (the HIP forward folds running statistics: eval-mode BN).  Those
-are ~5 M of the 132 M parameters; row f3 stays partial until they are covered.
+This file: the token side -- the contrastive head (fused LSE sweeps forward; dL/dlogits blocks + GEMMs backward), L2
+norm, both projections, ln_post / ln_final; all transformer blocks of both towers (LayerNorm, QKV / out_proj / c_fc /
+c_proj dgrad + wgrad through msclip_gemm, msclip_attention_bwd, QuickGELU), where the modality-shared tensors
+(M.py:2808-2830) receive the SUM of the image- and text-row gradients because the towers' tokens are rows of one matrix
+and one wgrad GEMM contracts over all of them; the token path of the lateral adapters, ln_pre, class / positional /
+token embeddings; the AdamW step and the rank averaging (comm.GradReducer).  train_conv.py: the convolutional side
+(stem, parallel branch, adapter convolutions) with train-mode BatchNorm (bn="batch": per-GPU batch statistics, running
+statistics updated) or frozen statistics (bn="frozen").  Together: all 325 gradient tensors of both released configs.
 
-Parity: tests/test_gpu_train.py compares every produced gradient with autograd of the REAL reference
-(tests/golden/b32-yfcc-msclips.grads.npz, captured by tools/make_golden.py::grads_fixture).
+Parity: tests/test_gpu_train.py compares every gradient with autograd of the REAL reference
+(tests/golden/*.grads.npz in eval() mode, b32-yfcc-msclips.grads_trainbn.npz in train() mode; captured by
+tools/make_golden.py::grads_fixture).
 """
 import math
 
@@ -127,7 +125,7 @@ class TrainStep:
             D = e.D
             X = w["X"]
             sv = dict(Bi=Bi, Bt=Bt, Mv=Mv, M=M, layers=[None] * e.n_layers, tok=e._check_tok(tok))
-            # ---- fronts (the conv side is frozen: nothing of it is saved but the tokens in front of ln_pre)
+            # ---- fronts (the conv side's maps stay in the workspace `w`; the tokens in front of ln_pre are cloned)
             keep = []
             sv["img"] = e._check_img(img)
             e.force_unfused = True                   # layer-by-layer conv side: every map the backward reads stays in `w`
