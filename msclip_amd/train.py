@@ -438,6 +438,52 @@ class TrainStep:
         self.eng.refresh(force=True)
 
 
+def _optimizer_state_dict(ts):
+    """TrainStep's AdamW state in torch.optim.AdamW's state_dict layout (parameter indices in named_parameters order, one
+    param_group per distinct (lr, weight_decay)): what the reference's `save_checkpoint_on_master` stores under
+    'optimizer' (lib/utils/utils.py:177-183)."""
+    groups, index = {}, {}
+    state = {}
+    for i, (k, p, lr, wd) in enumerate(ts.param_groups()):
+        index[k] = i
+        groups.setdefault((lr, wd), []).append(i)
+        st = ts.state.get(k)
+        if st is not None:
+            state[i] = {"step": torch.tensor(float(ts.steps)), "exp_avg": st[0].detach().cpu(), "exp_avg_sq": st[1].detach().cpu()}
+    pgs = [{"lr": lr, "weight_decay": wd, "betas": tuple(ts.betas), "eps": ts.eps, "amsgrad": False, "params": idx}
+           for (lr, wd), idx in groups.items()]
+    return {"state": state, "param_groups": pgs, "msclip": {"steps": ts.steps, "bn": ts.bn, "names": list(index)}}
+
+
+def save_checkpoint(model, ts, path, step, model_name="", perf=0.0):
+    """The reference's resumable checkpoint dict (lib/utils/utils.py:157-200): 'step', 'model', 'state_dict', 'perf',
+    'optimizer'.  Rank 0 only under N > 1."""
+    if not C.comm.is_main_process():
+        return
+    torch.save({"step": step + 1, "model": model_name, "perf": perf,
+                "state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
+                "optimizer": _optimizer_state_dict(ts)}, path)
+
+
+def resume_checkpoint(model, ts, path):
+    """-> the step to continue from.  Loads the module (strict, aliases checked), the AdamW moments and the step count."""
+    from .checkpoint import check_aliases, extract_state_dict
+    obj = torch.load(path, map_location="cpu", weights_only=False)
+    sd = extract_state_dict(obj)
+    model.load_state_dict(sd, strict=True)
+    check_aliases(model, sd)
+    opt = obj["optimizer"]
+    names = opt["msclip"]["names"]
+    params = dict(model.named_parameters())
+    ts.state = {}
+    for i, st in opt["state"].items():
+        p = params[names[int(i)]]
+        ts.state[names[int(i)]] = (st["exp_avg"].to(p.device).contiguous(), st["exp_avg_sq"].to(p.device).contiguous())
+    ts.steps = int(opt["msclip"]["steps"])
+    ts.eng.refresh(force=True)
+    return int(obj.get("step", ts.steps))
+
+
 def from_config(model, config, bn="batch"):
     """TrainStep with the reference yaml's optimizer hyper-parameters (TRAIN.LR / WD, CUSTOM.LR_SHARE / WD_SHARE).
     bn = "batch" (default): train-mode BatchNorm as the reference's modules run in train(); "frozen": running statistics."""

@@ -464,3 +464,56 @@ def test_training_loop_memorises_two_batches(gpu_device, name):
     assert all(np.isfinite(losses)), losses
     assert max(losses[-2:]) < 0.5 * min(losses[:2]), losses
     assert np.isfinite(m.contrastive_loss(*data[0]).item())
+
+
+def test_checkpoint_resume_continues_the_run(gpu_device, tmp_path):
+    """save_checkpoint / resume_checkpoint (the reference's 'step' / 'model' / 'state_dict' / 'perf' / 'optimizer' dict,
+    lib/utils/utils.py:157-200): two steps, save, then the third step once in the running process and once in a fresh
+    model + TrainStep resumed from the file.  Every kernel but the embedding gradient's fp32 atomics is deterministic, so
+    all parameters, running statistics and AdamW moments agree bitwise except the two embedding tables (1e-5).
+    The stored optimizer state loads into torch.optim.AdamW built over the same groups."""
+    name = "b32-yfcc-msclips"
+    cfg = named_config(name)
+    data = [(synth.synth_images(8, seed=20 + i).cuda(), synth.synth_tokens(8, seed=120 + i).cuda()) for i in range(3)]
+
+    def run(m, ts, steps):
+        for i in steps:
+            ts.forward(*data[i])
+            ts.step(ts.backward())
+    mb = _fresh_model(name)
+    tb = train.from_config(mb, cfg)
+    run(mb, tb, range(2))
+    path = tmp_path / "checkpoint.pth"
+    train.save_checkpoint(mb, tb, path, step=1, model_name=name)
+    obj = torch.load(path, weights_only=False)
+    assert set(obj) == {"step", "model", "state_dict", "perf", "optimizer"} and obj["step"] == 2
+    run(mb, tb, [2])
+    mc = _fresh_model(name)
+    tc = train.from_config(mc, cfg)
+    assert train.resume_checkpoint(mc, tc, path) == 2 and tc.steps == 2
+    run(mc, tc, [2])
+    sb, sc = mb.state_dict(), mc.state_dict()
+    atomics = ("token_embedding.weight", "positional_embedding")
+    for k in sb:
+        if k in atomics:
+            assert rel(sc[k], sb[k]) <= 1e-5, (k, rel(sc[k], sb[k]))
+        else:
+            assert torch.equal(sb[k], sc[k]), (k, rel(sc[k].float(), sb[k].float()))
+    k = "visual.transformer.resblocks.4.mlp.c_fc.weight"
+    assert torch.equal(tc.state[k][0], tb.state[k][0]) and torch.equal(tc.state[k][1], tb.state[k][1]) and tc.steps == tb.steps == 3
+    # torch.optim.AdamW accepts the stored state (same parameter order / groups)
+    params = dict(mc.named_parameters())
+    names = obj["optimizer"]["msclip"]["names"]
+    opt = torch.optim.AdamW([{"params": [params[names[i]] for i in g["params"]], "lr": g["lr"], "weight_decay": g["weight_decay"]}
+                             for g in obj["optimizer"]["param_groups"]], betas=(0.9, 0.98), eps=1e-6)
+    remap, n = {}, 0
+    for g in obj["optimizer"]["param_groups"]:
+        for i in g["params"]:
+            remap[i] = n
+            n += 1
+    sd = {"state": {remap[i]: v for i, v in obj["optimizer"]["state"].items()},
+          "param_groups": [dict(g, params=[remap[i] for i in g["params"]]) for g in obj["optimizer"]["param_groups"]]}
+    opt.load_state_dict({"state": sd["state"], "param_groups": [dict(pg, **{k: v for k, v in g.items() if k != "params"},
+                                                                      params=g["params"])
+                                                                 for pg, g in zip(opt.state_dict()["param_groups"], sd["param_groups"])]})
+    assert len(opt.state_dict()["state"]) == len(obj["optimizer"]["state"])
