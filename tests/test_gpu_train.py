@@ -517,3 +517,23 @@ def test_checkpoint_resume_continues_the_run(gpu_device, tmp_path):
                                                                       params=g["params"])
                                                                  for pg, g in zip(opt.state_dict()["param_groups"], sd["param_groups"])]})
     assert len(opt.state_dict()["state"]) == len(obj["optimizer"]["state"])
+
+
+@pytest.mark.parametrize("bn,batch", [("batch", 5), ("frozen", 3), ("batch", 1)])
+def test_training_step_odd_batches(gpu_device, bn, batch):
+    """Batches that are not multiples of anything (row counts 635 / 381 / 127: ragged GEMM tiles, padded wgrad
+    contractions, un-foldable BatchNorm maps; batch 1: the loss is 0 and BatchNorm sees one image): finite gradients for
+    every parameter, parameters move."""
+    name = "b32-yfcc-msclips"
+    m = _fresh_model(name)
+    ts = train.from_config(m, named_config(name), bn=bn)
+    img, tok = synth.synth_images(batch, seed=7).cuda(), synth.synth_tokens(batch, seed=8).cuda()
+    loss = ts.forward(img, tok)
+    grads = ts.backward()
+    assert np.isfinite(loss.item()) and len(grads) == 325
+    for k, g in grads.items():
+        assert bool(torch.isfinite(g).all()), k
+    before = m.visual.transformer.resblocks[0].resnet_stage.conv_1.conv1.weight.detach().clone()
+    ts.step(grads)
+    if batch > 1:
+        assert not torch.equal(before, m.visual.transformer.resblocks[0].resnet_stage.conv_1.conv1.weight.detach())
