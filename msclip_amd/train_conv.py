@@ -510,3 +510,4 @@ class ConvSideBatchNorm:
             dy2 = self._conv(grads, ("stem", i, "s"), short, q + ".downsample.0.weight", x_in, ds)
         self._first(grads, sp + ".conv1.weight", sp + ".bn1", self.bw._relu_bwd(dy, w["S1"], dy2=dy2))
         self.bw.col_img = None
+        self.saved = {}                                  # the raw maps (several GB at batch 512) are not kept between steps
