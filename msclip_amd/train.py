@@ -27,64 +27,13 @@ import torch.distributed as dist
 
 from . import comm as C
 from . import hip
+from .gradgemm import dgrad as _dgrad, wgrad as _wgrad
 from .train_conv import ConvSideBackward, ConvSideBatchNorm
 
 BF = torch.bfloat16
 F32 = torch.float32
 _LEAVES = ("attn.in_proj_weight", "attn.in_proj_bias", "attn.out_proj.weight", "attn.out_proj.bias",
            "mlp.c_fc.weight", "mlp.c_fc.bias", "mlp.c_proj.weight", "mlp.c_proj.bias")
-
-
-_SIDE = {}
-_WGRAD_STREAMS = 28
-
-
-def _wgrad(dy_bf, x_bf, M):
-    """dW[N, K] = dY^T @ X over the first M rows of dy_bf [*, N] and x_bf [*, K] (bf16): both operands transposed so the
-    token axis is the contiguous K axis of the GEMM (zero-padded).  A weight gradient has few output tiles (9-36 of
-    256 x 256) over a very deep contraction (65 024 tokens at batch 512): the contraction is cut into S slices whose
-    GEMMs run concurrently on S side streams into fp32 partials, folded in a fixed order (deterministic)."""
-    N, K = dy_bf.shape[1], x_bf.shape[1]
-    tiles = ((N + 255) // 256) * ((K + 255) // 256)
-    if tiles <= 4:
-        # narrow gradients (the convolutions: 48-192 channels over up to 6.4 M pixels): one split-K launch of 128 x 128
-        # tiles, enough slices to put ~2 workgroups on every CU, at least 1024 deep each
-        t128 = ((N + 127) // 128) * ((K + 127) // 128)
-        S = max(1, min(512 // t128, M // 1024))
-        Mpad = (M + 64 * S - 1) // (64 * S) * (64 * S)
-        return hip.gemm_splitk(hip.transpose_bf16(dy_bf, M, Mpad), hip.transpose_bf16(x_bf, M, Mpad), S)
-    S = max(1, min(_WGRAD_STREAMS, 256 // tiles, M // 4096))           # one workgroup per CU across the S concurrent GEMMs
-    Mpad = (M + 64 * S - 1) // (64 * S) * (64 * S)
-    a = hip.transpose_bf16(dy_bf, M, Mpad)
-    b = hip.transpose_bf16(x_bf, M, Mpad)
-    if S == 1:
-        out = torch.empty(N, K, dtype=F32, device=a.device)
-        hip.gemm(a, b, out)
-        return out
-    kc = Mpad // S
-    part = torch.empty(S, N, K, dtype=F32, device=a.device)
-    cur = torch.cuda.current_stream(a.device)
-    pool = _SIDE.setdefault(a.device, [torch.cuda.Stream(device=a.device) for _ in range(_WGRAD_STREAMS)])
-    ready = torch.cuda.Event()
-    ready.record(cur)
-    for sidx in range(S):
-        st = pool[sidx]
-        st.wait_event(ready)
-        with torch.cuda.stream(st):
-            hip.gemm(a[:, sidx * kc:(sidx + 1) * kc], b[:, sidx * kc:(sidx + 1) * kc], part[sidx], tile=4)
-        cur.wait_stream(st)
-    for t in (a, b, part):
-        for sidx in range(S):
-            t.record_stream(pool[sidx])
-    return hip.colsum(part.view(S, N * K)).view(N, K)
-
-
-def _dgrad(dy_bf, w_t, out=None):
-    """dX[M, K] = dY[M, N] @ W[N, K], w_t = W^T-as-stored-for-the-GEMM = [K, N] bf16 (N % 64 == 0)."""
-    if out is None:
-        out = torch.empty(dy_bf.shape[0], w_t.shape[0], dtype=BF, device=dy_bf.device)
-    hip.gemm(dy_bf, w_t, out)
-    return out
 
 
 class TrainStep:

@@ -10,7 +10,7 @@ train-mode BatchNorm with per-GPU batch statistics, their backward and the runni
 train() mode; fixture tests/golden/b32-yfcc-msclips.grads_trainbn.npz).
 
 Every convolution is a GEMM in the forward (implicit im2col gather); here
-    dWf = dY^T . im2col(X)      msclip_im2col + the split-K wgrad GEMM of train._wgrad
+    dWf = dY^T . im2col(X)      msclip_im2col + the split-K wgrad GEMM (gradgemm.wgrad)
     dX  = col2im(dY . Wf)       msclip_gemm + msclip_col2im (pointwise convs: the GEMM writes dX directly)
     dbf = column sums of dY
 on the FOLDED weight Wf = W * s, bf = beta - mean * s, s = gamma / sqrt(var + eps); the chain rule back to the module's
@@ -23,6 +23,7 @@ engine.force_unfused, so every intermediate map is there): valid until the next 
 import torch
 
 from . import hip
+from .gradgemm import wgrad as _wgrad
 
 BF = torch.bfloat16
 F32 = torch.float32
@@ -77,7 +78,6 @@ class ConvSideBackward:
     def _conv_bwd(self, key, spec, x_in, dpre, B, need_dx=True, col=None):
         """dpre: bf16 [B*Ho*Wo, cout] (with slack) -> (G [cout, cin, kh, kw] fp32 wrt the folded filter, dbias [cout],
         dx NHWC bf16 [B*H*W, cin] or None)."""
-        from .train import _wgrad
         co, ci, kh, kw = spec.cout, spec.cin, spec.kh, spec.kw
         pix = B * spec.h_out * spec.w_out
         K = kh * kw * ci
@@ -123,7 +123,6 @@ class ConvSideBackward:
 
     def _first_conv(self, grads, conv_key, bn_prefix, dpre):
         """wgrad of a 3x3 / stride 2 convolution on the input image (no input gradient)."""
-        from .train import _wgrad
         pix = self.Bi * self.e.h1 * self.e.h1
         co = dpre.shape[1]
         dwf = _wgrad(dpre, self._image_cols(), pix)[:, :27]
@@ -147,7 +146,6 @@ class ConvSideBackward:
         fb.grads(grads, p + ".bottom_dw_conv.conv.weight", ddww.t().reshape(D, 1, 3, 3),
                  sd[p + ".bottom_dw_conv.conv.weight"].float(), cs)
         # pointwise conv: T = Wp (pool_out + shift)
-        from .train import _wgrad
         ft = _Fold(sd, p + ".top2bottom_dw_conv.bn", 1e-5)
         pool_out = w["pool"][j]
         wp = sd[p + ".top2bottom_pw_conv.conv.weight"].float()[:, :, 0, 0]        # [D, C]
@@ -204,7 +202,6 @@ class ConvSideBackward:
     # ------------------------------------------------------------------ stem
     def stem(self, grads, dtok):
         """dtok: fp32 [Mv, D] gradient of the token matrix in front of ln_pre (cls row included)."""
-        from .train import _wgrad
         e, w, Bi, sd = self.e, self.w, self.Bi, self.sd
         g2, D = e.g * e.g, e.D
         sp = "visual.transformer.resblocks.0"
@@ -427,7 +424,6 @@ class ConvSideBatchNorm:
         return dx
 
     def _first(self, grads, wkey, prefix, dpre):
-        from .train import _wgrad
         draw = self._bn_bwd(grads, prefix, dpre)
         pix = self.Bi * self.e.h1 * self.e.h1
         dwf = _wgrad(draw, self.bw._image_cols(), pix)[:, :27]
@@ -435,7 +431,6 @@ class ConvSideBatchNorm:
 
     def adapter(self, grads, j, dsum, x_pre):
         """-> the gradient matrix to hand to msclip_adapter_dx together with the RAW depthwise filter."""
-        from .train import _wgrad
         e, w, Bi = self.e, self.w, self.Bi
         a = e.adapters[j]
         g, D, C, k, hw, L = e.g, e.D, a["C"], a["k"], e.par_hw[j], e.Lv
@@ -489,7 +484,6 @@ class ConvSideBatchNorm:
         self.bw.dpar = [dsrc_a, dsrc_b]
 
     def stem(self, grads, dtok):
-        from .train import _wgrad
         e, w, Bi = self.e, self.w, self.Bi
         g2, D = e.g * e.g, e.D
         sp = "visual.transformer.resblocks.0"
