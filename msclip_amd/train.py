@@ -20,7 +20,6 @@ Parity: tests/test_gpu_train.py compares every gradient with autograd of the REA
 (tests/golden/*.grads.npz in eval() mode, b32-yfcc-msclips.grads_trainbn.npz in train() mode; captured by
 tools/make_golden.py::grads_fixture).
 """
-import math
 
 import torch
 import torch.distributed as dist
