@@ -372,22 +372,33 @@ __global__ __launch_bounds__(256, 2) void attn_wg_kernel(const bf16_t* __restric
     }
     const int q = qt * 32 + fr;
     float mx = -INFINITY;
+    // The softmax is this kernel's VALU budget (112 values per lane and query tile).  Key tiles that lie completely
+    // inside the sequence (and below the causal diagonal) need no mask: the compare + select pair runs only on the
+    // boundary tiles (a wave-uniform choice per tile); p = 2^(s*log2e - max*log2e) is one FMA + v_exp per value.
 #pragma unroll
-    for (int kt = 0; kt < NT; ++kt)
+    for (int kt = 0; kt < NT; ++kt) {
+      const bool inside = kt * 32 + 32 <= L && (!CAUSAL || kt < qt) && kt < nkt;
+      if (inside) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
-        const bool ok = key < L && (!CAUSAL || key <= q) && kt < nkt;
-        s[kt][r] = ok ? s[kt][r] : -INFINITY;
-        mx = fmaxf(mx, s[kt][r]);
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
+          const bool ok = key < L && (!CAUSAL || key <= q) && kt < nkt;
+          s[kt][r] = ok ? s[kt][r] : -INFINITY;
+          mx = fmaxf(mx, s[kt][r]);
+        }
       }
+    }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mxl = mx * 1.44269504f;
     float sum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = __expf(s[kt][r] - mx);
+        const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], 1.44269504f, -mxl));
         s[kt][r] = p;
         sum += p;
       }
