@@ -165,6 +165,9 @@ class GradReducer:
         if not self.pending:
             return
         dev = self.pending[0][1].device
+        if dev.type == "cuda":
+            from .gradgemm import join
+            join(dev)                                        # weight gradients still running on the wgrad lane stream
         flat = torch.empty(self.open_elems, dtype=torch.float32, device=dev)
         layout, o = [], 0
         for name, g in self.pending:

@@ -59,3 +59,40 @@ def dgrad(dy_bf, w_t, out=None):
         out = torch.empty(dy_bf.shape[0], w_t.shape[0], dtype=BF, device=dy_bf.device)
     hip.gemm(dy_bf, w_t, out)
     return out
+
+
+# ---- weight gradients off the critical path.  The backward's dependency chain is the dgrad GEMMs; a weight gradient is
+# only needed by the optimizer (or the gradient all-reduce).  wgrad_async runs the whole weight-gradient job -- the two
+# operand transposes (HBM-bound), the split-K GEMMs and the fold -- on a side "lane" stream behind an event, so it overlaps
+# the MFMA-bound dgrad GEMMs of the main stream; join() makes the current stream wait for everything queued on the lane.
+_LANE = {}
+
+
+def lane(device):
+    s = _LANE.get(device)
+    if s is None:
+        s = _LANE[device] = torch.cuda.Stream(device=device)
+    return s
+
+
+def wgrad_async(dy_bf, x_bf, M, post=None):
+    """wgrad(dy_bf, x_bf, M) on the lane stream.  The operands must not be overwritten in place afterwards (their memory
+    may be freed: the caching allocator is told about the lane's use); the result may only be touched after join()."""
+    dev = dy_bf.device
+    cur, ln = torch.cuda.current_stream(dev), lane(dev)
+    ready = torch.cuda.Event()
+    ready.record(cur)
+    ln.wait_event(ready)
+    with torch.cuda.stream(ln):
+        out = wgrad(dy_bf, x_bf, M)
+        if post is not None:
+            out = post(out)
+    dy_bf.record_stream(ln)
+    x_bf.record_stream(ln)
+    out.record_stream(cur)
+    return out
+
+
+def join(device):
+    if device in _LANE:
+        torch.cuda.current_stream(device).wait_stream(_LANE[device])

@@ -26,7 +26,8 @@ import torch.distributed as dist
 
 from . import comm as C
 from . import hip
-from .gradgemm import dgrad as _dgrad, wgrad as _wgrad
+from . import gradgemm
+from .gradgemm import dgrad as _dgrad, wgrad as _wgrad, wgrad_async as _wgrad_async
 from .train_conv import ConvSideBackward, ConvSideBatchNorm
 
 BF = torch.bfloat16
@@ -273,7 +274,7 @@ class TrainStep:
                 dlno = torch.empty(M, D, dtype=F32, device=dev)
                 for r0, r1, bw in groups:
                     p = names[id(bw)]
-                    grads[p + ".mlp.c_proj.weight"] = _wgrad(dY[r0:r1], hid[r0:r1], r1 - r0)
+                    grads[p + ".mlp.c_proj.weight"] = _wgrad_async(dY[r0:r1], hid[r0:r1], r1 - r0)
                     grads[p + ".mlp.c_proj.bias"] = hip.colsum(dX[r0:r1])
                     _dgrad(dY[r0:r1], bw.wpr.t().contiguous(), dhid[r0:r1])
                 del hid
@@ -281,7 +282,7 @@ class TrainStep:
                 hip.quickgelu_bwd(L["h"][r_lo:M], dhid[r_lo:M], dh[r_lo:M])
                 for r0, r1, bw in groups:
                     p = names[id(bw)]
-                    grads[p + ".mlp.c_fc.weight"] = _wgrad(dh[r0:r1], L["lno2"][r0:r1], r1 - r0)
+                    grads[p + ".mlp.c_fc.weight"] = _wgrad_async(dh[r0:r1], L["lno2"][r0:r1], r1 - r0)
                     grads[p + ".mlp.c_fc.bias"] = hip.colsum(dh[r0:r1])
                     _dgrad(dh[r0:r1], bw.wfc.t().contiguous(), dlno[r0:r1])
                 del dhid, dh
@@ -290,22 +291,25 @@ class TrainStep:
                     dg, db = hip.layernorm_bwd(L["x_mid"][r0 - r_lo:r1 - r_lo], dlno[r0:r1], b["ln2"].g, dX[r0:r1], r1 - r0)
                     grads[pre + ".ln_2.weight"], grads[pre + ".ln_2.bias"] = dg, db
                 # attention half
-                hip.cast_bf16(dX[r_lo:M], dY[r_lo:M])
+                dY2 = torch.empty(M, D, dtype=BF, device=dev)          # not dY again: the lane stream may still read it (c_proj wgrad)
+                hip.cast_bf16(dX[r_lo:M], dY2[r_lo:M])
                 dao = torch.empty(M, D, dtype=BF, device=dev)
                 dqkv = torch.zeros(M, 3 * D, dtype=BF, device=dev)
                 for r0, r1, bw in groups:
                     p = names[id(bw)]
-                    grads[p + ".attn.out_proj.weight"] = _wgrad(dY[r0:r1], L["ao"][r0:r1], r1 - r0)
+                    grads[p + ".attn.out_proj.weight"] = _wgrad_async(dY2[r0:r1], L["ao"][r0:r1], r1 - r0)
                     grads[p + ".attn.out_proj.bias"] = hip.colsum(dX[r0:r1])
-                    _dgrad(dY[r0:r1], bw.wo.t().contiguous(), dao[r0:r1])
+                    _dgrad(dY2[r0:r1], bw.wo.t().contiguous(), dao[r0:r1])
                 if e.vblk[i] is not None:
                     hip.attention_bwd(L["qkv"][:Mv], L["ao"][:Mv], dao[:Mv], dqkv[:Mv], Bi, e.Lv, e.heads, False)
                 hip.attention_bwd(L["qkv"][Mv:M], L["ao"][Mv:M], dao[Mv:M], dqkv[Mv:M], Bt, e.Lt, e.heads, True)
                 for r0, r1, bw in groups:
                     p = names[id(bw)]
-                    gw = _wgrad(dqkv[r0:r1], L["lno1"][r0:r1], r1 - r0)                       # wrt the PACKED weight
+                    def unscale_q(g):                                                          # packed q rows = 64^-0.5 * W_q
+                        g[:D] *= 0.125
+                        return g
+                    gw = _wgrad_async(dqkv[r0:r1], L["lno1"][r0:r1], r1 - r0, post=unscale_q)   # wrt the PACKED weight
                     gb = hip.colsum(dqkv[r0:r1])
-                    gw[:D] *= 0.125                                                            # packed q rows = 64^-0.5 * W_q
                     gb[:D] *= 0.125
                     grads[p + ".attn.in_proj_weight"], grads[p + ".attn.in_proj_bias"] = gw, gb
                     _dgrad(dqkv[r0:r1], bw.wqkv.t().contiguous(), dlno[r0:r1])
@@ -339,6 +343,7 @@ class TrainStep:
             grads["visual.positional_embedding"] = dvpos
             grads["visual.class_embedding"] = dvpos[0].clone()
             conv.stem(grads, dtok)
+            gradgemm.join(dev)                                   # the weight gradients queued on the lane stream
             self.saved = None
             return reducer.finish() if reducer is not None else dict(grads)
 

@@ -23,7 +23,7 @@ engine.force_unfused, so every intermediate map is there): valid until the next 
 import torch
 
 from . import hip
-from .gradgemm import wgrad as _wgrad
+from .gradgemm import wgrad as _wgrad, wgrad_async as _wgrad_async
 
 BF = torch.bfloat16
 F32 = torch.float32
@@ -75,18 +75,23 @@ class ConvSideBackward:
             self._wt[key] = t
         return t
 
-    def _conv_bwd(self, key, spec, x_in, dpre, B, need_dx=True, col=None):
+    def _conv_bwd(self, key, spec, x_in, dpre, B, need_dx=True, col=None, lane=False):
         """dpre: bf16 [B*Ho*Wo, cout] (with slack) -> (G [cout, cin, kh, kw] fp32 wrt the folded filter, dbias [cout],
-        dx NHWC bf16 [B*H*W, cin] or None)."""
+        dx NHWC bf16 [B*H*W, cin] or None).  lane=True: the weight gradient runs on gradgemm's lane stream (G may only be
+        read after gradgemm.join) and no bias gradient is formed."""
         co, ci, kh, kw = spec.cout, spec.cin, spec.kh, spec.kw
         pix = B * spec.h_out * spec.w_out
         K = kh * kw * ci
         pointwise = (kh, kw, spec.stride, spec.pad) == (1, 1, 1, 0)
         if col is None:
             col = x_in[:pix] if pointwise else hip.im2col(x_in, B, spec.h_in, spec.w_in, ci, kh, kw, spec.stride, spec.pad)
-        dwf = _wgrad(dpre, col, pix)[:, :K]
-        G = dwf.reshape(co, kh, kw, ci).permute(0, 3, 1, 2).contiguous()
-        db = hip.colsum(dpre, M=pix)
+
+        def to_filter(dwf):
+            return dwf[:, :K].reshape(co, kh, kw, ci).permute(0, 3, 1, 2).contiguous()
+        if lane:
+            G, db = _wgrad_async(dpre, col, pix, post=to_filter), None
+        else:
+            G, db = to_filter(_wgrad(dpre, col, pix)), hip.colsum(dpre, M=pix)
         dx = None
         if need_dx:
             if pointwise:
@@ -419,15 +424,16 @@ class ConvSideBatchNorm:
         return dx
 
     def _conv(self, grads, key, spec, wkey, x_in, draw, need_dx=True):
-        G, _, dx = self.bw._conv_bwd(key, spec, x_in, draw, self.Bi, need_dx=need_dx)
-        grads[wkey] = G
+        G, _, dx = self.bw._conv_bwd(key, spec, x_in, draw, self.Bi, need_dx=need_dx, lane=True)
+        grads[wkey] = G                                  # final after gradgemm.join (end of the backward / bucket flush)
         return dx
 
     def _first(self, grads, wkey, prefix, dpre):
         draw = self._bn_bwd(grads, prefix, dpre)
         pix = self.Bi * self.e.h1 * self.e.h1
-        dwf = _wgrad(draw, self.bw._image_cols(), pix)[:, :27]
-        grads[wkey] = dwf.reshape(draw.shape[1], 3, 3, 3).permute(0, 3, 1, 2).contiguous()
+        co = draw.shape[1]
+        grads[wkey] = _wgrad_async(draw, self.bw._image_cols(), pix,
+                                   post=lambda d: d[:, :27].reshape(co, 3, 3, 3).permute(0, 3, 1, 2).contiguous())
 
     def adapter(self, grads, j, dsum, x_pre):
         """-> the gradient matrix to hand to msclip_adapter_dx together with the RAW depthwise filter."""
@@ -445,7 +451,8 @@ class ConvSideBatchNorm:
         # top-down: T = Wp . BN(dwpool(par[j]))
         dT_bf = hip.cast_bf16(dT)
         pw = self.raw.pw[j]
-        grads[p + ".top2bottom_pw_conv.conv.weight"] = _wgrad(dT_bf, w["pool"][j], Bi * g2).reshape(D, C, 1, 1)
+        grads[p + ".top2bottom_pw_conv.conv.weight"] = _wgrad_async(dT_bf, w["pool"][j], Bi * g2,
+                                                                    post=lambda d: d.reshape(D, C, 1, 1))
         wt = pw.weight[:, :C].t().contiguous()
         dt = _zbuf(Bi * g2, C, e.dev)
         hip.gemm(dT_bf, wt, dt)
@@ -489,7 +496,8 @@ class ConvSideBatchNorm:
         sp = "visual.transformer.resblocks.0"
         dlast = hip.cast_bf16(dtok.view(Bi, e.Lv, D)[:, 1:].reshape(Bi * g2, D))
         x = w["stem"][-1]
-        grads[sp + ".last_conv.weight"] = _wgrad(dlast, x[:Bi * g2], Bi * g2).reshape(D, x.shape[1], 1, 1)
+        cin = x.shape[1]
+        grads[sp + ".last_conv.weight"] = _wgrad_async(dlast, x[:Bi * g2], Bi * g2, post=lambda d: d.reshape(D, cin, 1, 1))
         dy = _zbuf(Bi * g2, x.shape[1], e.dev)
         hip.gemm(dlast, e.w_last.t().contiguous(), dy)
         dy2 = None
