@@ -104,6 +104,24 @@ def wgrad_async(dy_bf, x_bf, M, post=None):
     return out
 
 
+def on_lane(fn, *operands):
+    """fn() on the lane stream behind an event (same contract as wgrad_async: operands read-only afterwards, result valid
+    after join).  For the other HBM-bound by-products of the backward that nothing on the critical path reads (bias sums)."""
+    dev = operands[0].device
+    if hip.env_flag("MSCLIP_WGRAD_SYNC") or _ranks_share_a_gpu():
+        return fn()
+    cur, ln = torch.cuda.current_stream(dev), lane(dev)
+    ready = torch.cuda.Event()
+    ready.record(cur)
+    ln.wait_event(ready)
+    with torch.cuda.stream(ln):
+        out = fn()
+    for t in operands:
+        t.record_stream(ln)
+    out.record_stream(cur)
+    return out
+
+
 def join(device):
     if device in _LANE:
         torch.cuda.current_stream(device).wait_stream(_LANE[device])

@@ -283,7 +283,7 @@ class TrainStep:
                 for r0, r1, bw in groups:
                     p = names[id(bw)]
                     grads[p + ".mlp.c_fc.weight"] = _wgrad_async(dh[r0:r1], L["lno2"][r0:r1], r1 - r0)
-                    grads[p + ".mlp.c_fc.bias"] = hip.colsum(dh[r0:r1])
+                    grads[p + ".mlp.c_fc.bias"] = gradgemm.on_lane(lambda a=dh[r0:r1]: hip.colsum(a), dh)
                     _dgrad(dh[r0:r1], bw.wfc.t().contiguous(), dlno[r0:r1])
                 del dhid, dh
                 for r0, r1, b in segs:
@@ -309,8 +309,11 @@ class TrainStep:
                         g[:D] *= 0.125
                         return g
                     gw = _wgrad_async(dqkv[r0:r1], L["lno1"][r0:r1], r1 - r0, post=unscale_q)   # wrt the PACKED weight
-                    gb = hip.colsum(dqkv[r0:r1])
-                    gb[:D] *= 0.125
+                    def bias_q(a=dqkv[r0:r1]):
+                        g = hip.colsum(a)
+                        g[:D] *= 0.125
+                        return g
+                    gb = gradgemm.on_lane(bias_q, dqkv)
                     grads[p + ".attn.in_proj_weight"], grads[p + ".attn.in_proj_bias"] = gw, gb
                     _dgrad(dqkv[r0:r1], bw.wqkv.t().contiguous(), dlno[r0:r1])
                 for r0, r1, b in segs:
