@@ -202,7 +202,10 @@ class TrainStep:
         gradients are averaged over the ranks as the reference's DDP wrapper would: every gradient goes into a
         comm.GradReducer bucket the moment it exists, and the buckets' RCCL all-reduces run on the side stream under
         the rest of the backward (last block's bucket first)."""
-        e, sv = self.eng, self.saved
+        e, sv = self.eng, getattr(self, "saved", None)
+        if sv is None:
+            raise RuntimeError("TrainStep.backward() needs the activations of a TrainStep.forward() that has not been "
+                               "differentiated yet (call forward first; one backward per forward)")
         dev, D, E = e.dev, e.D, e.E
         with torch.cuda.device(dev), torch.no_grad():
             Bi, Bt, Mv, M, n, off = sv["Bi"], sv["Bt"], sv["Mv"], sv["M"], sv["n"], sv["off"]

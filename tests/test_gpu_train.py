@@ -533,6 +533,8 @@ def test_training_step_odd_batches(gpu_device, bn, batch):
     assert np.isfinite(loss.item()) and len(grads) == 325
     for k, g in grads.items():
         assert bool(torch.isfinite(g).all()), k
+    with pytest.raises(RuntimeError, match="forward"):
+        ts.backward()                                                  # one backward per forward
     before = m.visual.transformer.resblocks[0].resnet_stage.conv_1.conv1.weight.detach().clone()
     ts.step(grads)
     if batch > 1:
