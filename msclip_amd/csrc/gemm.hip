@@ -314,41 +314,60 @@ __device__ __forceinline__ void epilogue_pack16(f32x4 (&acc)[2 * TN][2 * TM], co
                  :
                  : "memory");
   }
+  // Block tm = 32 rows x 64 columns of the wave.  Its values are computed in four QUARTERS (8 values + one 16-byte staging
+  // write pair each); between the quarters of block tm+1 the four 1-KiB store instructions of block tm go out one at a
+  // time instead of back to back.  Measured same-box against the back-to-back form: QKV 226.6 -> 223.1 us, c_fc unchanged
+  // (334 -> 333 us), ping-pong launches in the model step 187.0 -> 185.6 us on average.  (The probe builds say the c_fc
+  // epilogue is 57 us of activation math + staging and 32 us that vanish without the stores, nearly additive; spreading
+  // the stores does not recover them, so they are not lost to a blocked store queue at issue.)
   u32x4 x[2][4];
-  auto stage = [&](int tm, u32x4 (&dst)[4]) {                    // 32 rows x 64 columns of the wave, packed to bf16
+  auto quarter = [&](int tm, int q) {                            // (mi, ni) = (q >> 1, 2 * (q & 1) + {0, 1})
+    const int mi = q >> 1;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int h = 0; h < 2; ++h) {
+      const int ni = 2 * (q & 1) + h;
+      float v[4];
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] = acc[ni][2 * tm + mi][e] * a.alpha + b[ni][e];
-          if (ACT == 1) v[e] = v[e] / (1.f + __expf(-1.702f * v[e]));
-          if (ACT == 2) v[e] = fmaxf(v[e], 0.f);
-        }
-        stg_write8(wr + mi * 2048 + (((ni * 2 + (quad >> 1)) ^ wsw) << 4), pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+      for (int e = 0; e < 4; ++e) {
+        v[e] = acc[ni][2 * tm + mi][e] * a.alpha + b[ni][e];
+        if (ACT == 1) v[e] = v[e] / (1.f + __expf(-1.702f * v[e]));
+        if (ACT == 2) v[e] = fmaxf(v[e], 0.f);
       }
+      stg_write8(wr + mi * 2048 + (((ni * 2 + (quad >> 1)) ^ wsw) << 4), pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+    }
+  };
+  auto fetch = [&](u32x4 (&dst)[4]) {                            // the staged block, 4 rows of 128 B per lane group
     dst[0] = stg_read16u<0>(rd); dst[1] = stg_read16u<1024>(rd);
     dst[2] = stg_read16u<2048>(rd); dst[3] = stg_read16u<3072>(rd);
   };
-  stage(0, x[0]);
+  auto store = [&](int tm, int i, const u32x4& v) {
+    const int n = nw0 + sch * 8;
+    const size_t row = (size_t)(mw0 + tm * 32 + i * 8 + srow);
+    // non-temporal: the tile leaves faster (QKV 262 -> 249 us, c_fc 378 -> 365 us; +0.7 % on the step), the fp32
+    // stream of out_proj / c_proj stays cacheable for the LayerNorm that follows
+    if (n < a.N) __builtin_nontemporal_store(v, (AS1 u32x4*)((bf16_t*)a.out + row * a.ldo + n));
+  };
+#pragma unroll
+  for (int q = 0; q < 4; ++q) quarter(0, q);
+  fetch(x[0]);
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     u32x4(&xb)[4] = x[tm & 1];
     if (tm + 1 < TM) {
-      stage(tm + 1, x[(tm + 1) & 1]);
-      asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(xb[0]), "+v"(xb[1]), "+v"(xb[2]), "+v"(xb[3])::"memory");
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        quarter(tm + 1, q);
+        // the 4 reads of block tm are older than the 2 staging writes of this quarter (LDS returns in order)
+        if (q == 0) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(xb[0]), "+v"(xb[1]), "+v"(xb[2]), "+v"(xb[3])::"memory");
+        __builtin_amdgcn_sched_barrier(0);
+        store(tm, q, xb[q]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      fetch(x[(tm + 1) & 1]);
     } else {
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xb[0]), "+v"(xb[1]), "+v"(xb[2]), "+v"(xb[3])::"memory");
-    }
-    const int n = nw0 + sch * 8;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const size_t row = (size_t)(mw0 + tm * 32 + i * 8 + srow);
-      // non-temporal: the tile leaves faster (QKV 262 -> 249 us, c_fc 378 -> 365 us; +0.7 % on the step), the fp32
-      // stream of out_proj / c_proj stays cacheable for the LayerNorm that follows
-      if (n < a.N) __builtin_nontemporal_store(xb[i], (AS1 u32x4*)((bf16_t*)a.out + row * a.ldo + n));
+      for (int i = 0; i < 4; ++i) store(tm, i, xb[i]);
     }
   }
 }

@@ -1529,3 +1529,7 @@ extern "C" int msclip_gemm(const msclip_gemm_desc* d, void* stream) {
   }
   return msclip_launch_status();
 }
+
+// The product library's split-K entry point (msclip_amd/csrc/gemm.hip) is not part of this instrumented snapshot; the symbol
+// exists so that msclip_amd/hip.py can load a probe build.
+extern "C" int msclip_gemm_splitk(const msclip_gemm_desc*, int, void*) { return MSCLIP_EINVAL; }
