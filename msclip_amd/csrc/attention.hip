@@ -313,13 +313,21 @@ __global__ __launch_bounds__(256, 2) void attn_wg_kernel(const bf16_t* __restric
   const bf16_t* vbase = qbase + 2 * H * 64;
   const int fr = lane & 31, fhi = lane >> 5;
 
-  // ---- this wave's first Q tile is requested before the cooperative K / V pass
+  // ---- this wave's first Q tile is requested before the cooperative K / V pass.  The Q loads are inline asm with a
+  // COUNTED wait: as compiler-tracked loads the next tile's prefetch was waited for with vmcnt(0) at the top of the
+  // loop, i.e. behind the write acknowledgements of the previous tile's output stores (the VM counter retires in order);
+  // the prefetch is issued before those four stores, so vmcnt(4) is its exact wait.
   auto load_q = [&](int qt, bf16x8 (&qf)[4]) {
     const int qrow = min(qt * 32 + fr, L - 1);
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const bf16x8*)(qbase + (size_t)qrow * ldq + (kk * 2 + fhi) * 8);
+    for (int kk = 0; kk < 4; ++kk) {
+      const bf16_t* p = qbase + (size_t)qrow * ldq + (kk * 2 + fhi) * 8;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(qf[kk]) : "v"(p));
+    }
   };
   bf16x8 qcur[4], qnext[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) qcur[kk] = qnext[kk] = bf16x8{};
   if (wave * 32 < L) load_q(wave, qcur);
 
   // ---- K rows and V^T into LDS (8 threads per row, 16 B each; padded keys are zero).  Every global load of the pass is
@@ -332,13 +340,13 @@ __global__ __launch_bounds__(256, 2) void attn_wg_kernel(const bf16_t* __restric
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
       const int key = (tid >> 3) + 32 * i;
-      ku[i] = make_uint4(0, 0, 0, 0);
-      vu[i] = make_uint4(0, 0, 0, 0);
-      if (key < L) {
-        ku[i] = *(const uint4*)(kbase + (size_t)key * ldq + c * 8);
-        vu[i] = *(const uint4*)(vbase + (size_t)key * ldq + c * 8);
-      }
+      const int kc = min(key, L - 1);                  // unconditional (clamped) loads: no exec-mask branch between them
+      ku[i] = *(const uint4*)(kbase + (size_t)kc * ldq + c * 8);
+      vu[i] = *(const uint4*)(vbase + (size_t)kc * ldq + c * 8);
     }
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+      if ((tid >> 3) + 32 * i >= L) ku[i] = vu[i] = make_uint4(0, 0, 0, 0);
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
       const int key = (tid >> 3) + 32 * i;
@@ -352,21 +360,48 @@ __global__ __launch_bounds__(256, 2) void attn_wg_kernel(const bf16_t* __restric
       dst[6 * KPS] = (bf16_t)(vu[i].w & 0xffff); dst[7 * KPS] = (bf16_t)(vu[i].w >> 16);
     }
   }
+  // the first Q tile was requested before the K / V loads above, whose (compiler-tracked) wait also covers it
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(qcur[0]), "+v"(qcur[1]), "+v"(qcur[2]), "+v"(qcur[3])::"memory");
   __syncthreads();
 
   for (int qt = wave; qt < NT && qt * 32 < L; qt += 4) {
-    if ((qt + 4) < NT && (qt + 4) * 32 < L) load_q(qt + 4, qnext);
+    const bool more = (qt + 4) < NT && (qt + 4) * 32 < L;
+    if (more) load_q(qt + 4, qnext);
     const int nkt = CAUSAL ? (qt + 1) : NT;
     f32x16 s[NT];
+    if constexpr (!CAUSAL) {
+      // Straight-line and software-pipelined: the K fragments of key tile kt + 1 are requested before the four MFMAs of
+      // tile kt (padded keys are zero in LDS and masked below, so no tile is skipped).  As "read, wait, MFMA" per fragment
+      // -- what the guarded per-tile form compiled to -- every one of the 56 MFMAs of a query tile exposed a full LDS
+      // round trip: the kernel was LDS-latency-bound (removing the softmax's exp or either MFMA group changed nothing).
+      bf16x8 kf[2][4];
 #pragma unroll
-    for (int kt = 0; kt < NT; ++kt) {
+      for (int kk = 0; kk < 4; ++kk) kf[0][kk] = *(const bf16x8*)(kl + fr * KROW + (kk * 2 + fhi) * 8);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
-      if (kt < nkt && kt * 32 < L) {
+      for (int kt = 0; kt < NT; ++kt) {
+        if (kt + 1 < NT) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          const bf16x8 kf = *(const bf16x8*)(kl + (kt * 32 + fr) * KROW + (kk * 2 + fhi) * 8);
-          s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qcur[kk], s[kt], 0, 0, 0);
+          for (int kk = 0; kk < 4; ++kk)
+            kf[(kt + 1) & 1][kk] = *(const bf16x8*)(kl + ((kt + 1) * 32 + fr) * KROW + (kk * 2 + fhi) * 8);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+        __builtin_amdgcn_sched_barrier(0);             // (the scheduler otherwise sinks every read back in front of its MFMA)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt & 1][kk], qcur[kk], s[kt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+        if (kt < nkt && kt * 32 < L) {
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            const bf16x8 kf = *(const bf16x8*)(kl + (kt * 32 + fr) * KROW + (kk * 2 + fhi) * 8);
+            s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qcur[kk], s[kt], 0, 0, 0);
+          }
         }
       }
     }
@@ -409,19 +444,41 @@ __global__ __launch_bounds__(256, 2) void attn_wg_kernel(const bf16_t* __restric
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    if constexpr (!CAUSAL) {
+      // the same for O^T = V^T . P^T: the two V^T fragments of k-step st + 1 are requested before the MFMAs of k-step st
+      bf16x8 vf[2][2];
 #pragma unroll
-    for (int kt = 0; kt < NT; ++kt) {
-      if (kt < nkt && kt * 32 < L) {
+      for (int dt = 0; dt < 2; ++dt) vf[0][dt] = *(const bf16x8*)(vt + (dt * 32 + fr) * KPS + fhi * 8);
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          bf16x8 pf;
+      for (int st = 0; st < 2 * NT; ++st) {
+        if (st + 1 < 2 * NT) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) pf[e] = (__bf16)s[kt][half * 8 + e];
-          const int st = kt * 2 + half;
+          for (int dt = 0; dt < 2; ++dt)
+            vf[(st + 1) & 1][dt] = *(const bf16x8*)(vt + (dt * 32 + fr) * KPS + (st + 1) * 16 + fhi * 8);
+        }
+        bf16x8 pf;
 #pragma unroll
-          for (int dt = 0; dt < 2; ++dt) {
-            const bf16x8 vf = *(const bf16x8*)(vt + (dt * 32 + fr) * KPS + st * 16 + fhi * 8);
-            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
+        for (int e = 0; e < 8; ++e) pf[e] = (__bf16)s[st >> 1][(st & 1) * 8 + e];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[st & 1][dt], pf, o[dt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt) {
+        if (kt < nkt && kt * 32 < L) {
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            bf16x8 pf;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pf[e] = (__bf16)s[kt][half * 8 + e];
+            const int st = kt * 2 + half;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+              const bf16x8 vf = *(const bf16x8*)(vt + (dt * 32 + fr) * KPS + st * 16 + fhi * 8);
+              o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
+            }
           }
         }
       }
@@ -444,8 +501,11 @@ __global__ __launch_bounds__(256, 2) void attn_wg_kernel(const bf16_t* __restric
         }
       }
     }
+    if (more) {   // younger than the prefetch: exactly this tile's four output stores (row qt * 32 is a real query: none is skipped)
+      asm volatile("s_waitcnt vmcnt(4)" : "+v"(qnext[0]), "+v"(qnext[1]), "+v"(qnext[2]), "+v"(qnext[3])::"memory");
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) qcur[kk] = qnext[kk];
+      for (int kk = 0; kk < 4; ++kk) qcur[kk] = qnext[kk];
+    }
   }
 }
 
