@@ -15,6 +15,7 @@
 // so their operands are the TRANSPOSED tensors: Q^T, K^T, dO^T are built while loading, P^T / dS / dS^T are written to
 // LDS from the accumulator layout; the outputs come out as dV^T, dK^T, dQ^T tiles, i.e. 4 consecutive head-dim elements
 // per lane and token: 8-byte global stores.
+#include <type_traits>
 #include "common.h"
 #include "../../include/msclip_hip.h"
 
@@ -88,12 +89,21 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
   __syncthreads();
 
   const int r16 = lane & 15, quad = lane >> 4;
-  auto mma = [&](f32x4 acc, const bf16_t* pa, int sa, const bf16_t* pb, int sb, int ksteps) {
-    for (int ks = 0; ks < ksteps; ++ks) {
-      const bf16x8 a = *(const bf16x8*)(pa + r16 * sa + ks * 32 + quad * 8);
-      const bf16x8 bb = *(const bf16x8*)(pb + r16 * sb + ks * 32 + quad * 8);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bb, acc, 0, 0, 0);
+  // Fragment reads are issued as a batch in front of the MFMAs that use them (and pinned there: the scheduler otherwise
+  // sinks every ds_read to its MFMA with an lgkmcnt(0) in between, one exposed LDS round trip per MFMA -- what made the
+  // 197-token forward kernel latency-bound).
+  auto frag = [&](const bf16_t* p, int stride, int ks) { return *(const bf16x8*)(p + r16 * stride + ks * 32 + quad * 8); };
+  auto mma = [&](f32x4 acc, const bf16_t* pa, int sa, const bf16_t* pb, int sb, auto ksc) {
+    constexpr int KS = decltype(ksc)::value;
+    bf16x8 a[KS], bb[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      a[ks] = frag(pa, sa, ks);
+      bb[ks] = frag(pb, sb, ks);
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks], bb[ks], acc, 0, 0, 0);
     return acc;
   };
 
@@ -102,9 +112,24 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
     const int query = qt * 16 + r16;
     f32x4 st[NT16];
     float mx = -INFINITY;
+    {   // S^T tiles of all key tiles: every K fragment (and the two Q fragments) requested before the first MFMA
+      bf16x8 kf[NT16][2];
+      const bf16x8 q0 = frag(Q + qt * 16 * RS, RS, 0), q1 = frag(Q + qt * 16 * RS, RS, 1);
+#pragma unroll
+      for (int kt = 0; kt < NT16; ++kt) {
+        kf[kt][0] = frag(K + kt * 16 * RS, RS, 0);
+        kf[kt][1] = frag(K + kt * 16 * RS, RS, 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kt = 0; kt < NT16; ++kt) {
+        st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][0], q0, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][1], q1, st[kt], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int kt = 0; kt < NT16; ++kt) {
-      st[kt] = mma(f32x4{0.f, 0.f, 0.f, 0.f}, K + kt * 16 * RS, RS, Q + qt * 16 * RS, RS, 2);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = kt * 16 + quad * 4 + r;
@@ -128,9 +153,26 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
     sum += __shfl_xor(sum, 32, 64);
     const float inv = sum > 0.f ? 1.f / sum : 0.f;
     const float dl = delta[query];
+    f32x4 dpt[NT16];
+    {   // dP^T tiles the same way
+      bf16x8 vf[NT16][2];
+      const bf16x8 d0 = frag(dO + qt * 16 * RS, RS, 0), d1 = frag(dO + qt * 16 * RS, RS, 1);
+#pragma unroll
+      for (int kt = 0; kt < NT16; ++kt) {
+        vf[kt][0] = frag(V + kt * 16 * RS, RS, 0);
+        vf[kt][1] = frag(V + kt * 16 * RS, RS, 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kt = 0; kt < NT16; ++kt) {
+        dpt[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[kt][0], d0, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        dpt[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[kt][1], d1, dpt[kt], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int kt = 0; kt < NT16; ++kt) {
-      const f32x4 dp = mma(f32x4{0.f, 0.f, 0.f, 0.f}, V + kt * 16 * RS, RS, dO + qt * 16 * RS, RS, 2);
+      const f32x4 dp = dpt[kt];
       float ds[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -155,7 +197,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
     const int dt = rem / NT16, tt = rem - dt * NT16;            // head-dim tile, token tile
     const bf16_t* pa = which == 0 ? dOT : (which == 1 ? QT : KT);
     const bf16_t* pb = which == 0 ? PT : (which == 1 ? dST : dS);
-    const f32x4 acc = mma(f32x4{0.f, 0.f, 0.f, 0.f}, pa + dt * 16 * LS, LS, pb + tt * 16 * LS, LS, LP / 32);
+    const f32x4 acc = mma(f32x4{0.f, 0.f, 0.f, 0.f}, pa + dt * 16 * LS, LS, pb + tt * 16 * LS, LS, std::integral_constant<int, LP / 32>{});
     const int tok = tt * 16 + r16;
     if (tok < L) {
       uint2 u;
