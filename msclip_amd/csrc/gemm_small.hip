@@ -115,13 +115,32 @@ __global__ __launch_bounds__(SWV * 64) void gemm_stream_kernel(const msclip_gemm
       constexpr int kc = decltype(kcc)::value;
       if (kc + 1 < NKC) load_chunk(xp, std::integral_constant<int, (kc + 1 < NKC ? kc + 1 : 0)>{}, xq[(kc + 1) & 1]);
       else load_chunk(xn, std::integral_constant<int, 0>{}, xq[(kc + 1) & 1]);
+      if constexpr (NT <= 3) {
+        // narrow outputs: the chunk's 4 * NT weight fragments are requested from LDS before its MFMAs (and pinned there:
+        // the scheduler otherwise sinks each ds_read to its MFMA behind an lgkmcnt(0), one exposed LDS round trip per MFMA)
+        bf16x8 wf[4][NT];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(&xq[kc & 1][ks]);
+        for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const bf16x8 wf = *(const bf16x8*)(wl + (t * 32 + fr) * wstride + (kc * 8 + ks * 2 + fhi) * 16);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[t], 0, 0, 0);
+          for (int t = 0; t < NT; ++t)
+            wf[ks][t] = *(const bf16x8*)(wl + (t * 32 + fr) * wstride + (kc * 8 + ks * 2 + fhi) * 16);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const bf16x8 xf = *reinterpret_cast<const bf16x8*>(&xq[kc & 1][ks]);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][t], xf, acc[t], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const bf16x8 xf = *reinterpret_cast<const bf16x8*>(&xq[kc & 1][ks]);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const bf16x8 wf = *(const bf16x8*)(wl + (t * 32 + fr) * wstride + (kc * 8 + ks * 2 + fhi) * 16);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[t], 0, 0, 0);
+          }
         }
       }
     };
