@@ -244,14 +244,27 @@ __global__ __launch_bounds__(256) void dwpool_rows_kernel(const bf16_t* __restri
     float a0[8], a1[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) a0[e] = a1[e] = 0.f;
-#pragma unroll 4
-    for (int ky = 0; ky < k; ++ky) {
-      const bf16_t* row = base + (size_t)ky * W * C;
+    // window rows in groups of four: the eight 16-byte loads of a group are issued together (unconditional, clamped
+    // chunk index: no exec-mask branch between them) before the group's multiply-adds
+    const int c0 = one ? lane * 8 : 0, c1 = two ? (lane + 64) * 8 : 0;
+    for (int ky0 = 0; ky0 < k; ky0 += 4) {
+      uint4 q0[4], q1[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        q0[j] = q1[j] = make_uint4(0, 0, 0, 0);
+        if (ky0 + j < k) {                             // wave-uniform (k = 1 and 2 have shorter groups)
+          const bf16_t* row = base + (size_t)(ky0 + j) * W * C;
+          q0[j] = *(const uint4*)(row + c0);
+          q1[j] = *(const uint4*)(row + c1);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+      if (ky0 + j < k) {
+      const int ky = ky0 + j;
       const float* wr = wl + ky * RL;
-      uint4 u0 = make_uint4(0, 0, 0, 0);
-      if (one) u0 = *(const uint4*)(row + lane * 8);
-      uint4 u1 = make_uint4(0, 0, 0, 0);
-      if (two) u1 = *(const uint4*)(row + (lane + 64) * 8);
+      const uint4 u0 = one ? q0[j] : make_uint4(0, 0, 0, 0);
+      const uint4 u1 = q1[j];
       float f[8];
       unpack_bf16x8(u0, f);
       const int wo = one ? lane * 8 : 0;
@@ -265,6 +278,8 @@ __global__ __launch_bounds__(256) void dwpool_rows_kernel(const bf16_t* __restri
         a1[0] = fmaf(f[0], x0.x, a1[0]); a1[1] = fmaf(f[1], x0.y, a1[1]); a1[2] = fmaf(f[2], x0.z, a1[2]);
         a1[3] = fmaf(f[3], x0.w, a1[3]); a1[4] = fmaf(f[4], x1.x, a1[4]); a1[5] = fmaf(f[5], x1.y, a1[5]);
         a1[6] = fmaf(f[6], x1.z, a1[6]); a1[7] = fmaf(f[7], x1.w, a1[7]);
+      }
+      }
       }
     }
     if (one) {
