@@ -387,13 +387,13 @@ def test_gradients_against_reference_autograd(gpu_device, name):
     assert len([k for k in expect if "visual.transformer.resblocks" in k and ".attn." in k]) == 11 * 4
 
 
-def test_gradients_with_train_mode_batchnorm(gpu_device):
+@pytest.mark.parametrize("name", ["b32-yfcc-msclips", "b16-yfcc-msclips"])
+def test_gradients_with_train_mode_batchnorm(gpu_device, name):
     """bn="batch": per-GPU batch statistics in every BatchNorm, their backward, the running-statistics update -- against
     autograd of the reference in train() mode (tests/golden/b32-yfcc-msclips.grads_trainbn.npz).  Same tolerance classes as
     the frozen-statistics test; the running statistics after one forward to 1e-2 of their largest entry (measured 2e-3:
     the batch statistics of maps behind bf16 transformer blocks, entering with momentum 0.1)."""
     import os
-    name = "b32-yfcc-msclips"
     g = np.load(os.path.join(GOLDEN, name + ".grads_trainbn.npz"))
     m = _fresh_model(name)
     ts = train.TrainStep(m, lr=1e-4, bn="batch")
@@ -435,6 +435,8 @@ def test_gradients_with_train_mode_batchnorm(gpu_device):
         assert am[k] <= tol[1], (k, am[k])
         if k in coss:
             assert coss[k] >= tol[2], (k, coss[k])
+    if not name.startswith("b32"):
+        return
     # ... and no further from the fp32 reference than the reference's own bf16-autocast run in train() mode on this batch
     # (median 3.9 % token side / 11.7 % conv side, worst conv-side tensor 31 %, lowest conv-side cosine 0.959)
     dev = _reference_bf16_deviation("train_bn_batch16")

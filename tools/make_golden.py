@@ -228,8 +228,7 @@ def main():
         if name.startswith("b32"):
             zeroshot_fixture(model, name)
         grads_fixture(model, name)              # b16: the 197-token grid (query-blocked attention backward, k = 8 adapters)
-        if name.startswith("b32"):
-            grads_fixture(model, name, train_bn=True, batch=16)
+        grads_fixture(model, name, train_bn=True, batch=16 if name.startswith("b32") else 8)
     multirank_gather_fixture()
 
 
