@@ -574,3 +574,15 @@ def test_training_step_odd_batches(gpu_device, bn, batch):
     ts.step(grads)
     if batch > 1:
         assert not torch.equal(before, m.visual.transformer.resblocks[0].resnet_stage.conv_1.conv1.weight.detach())
+
+
+def test_train_synthetic_script(gpu_device):
+    """tools/train_synthetic.py end to end (its exit code is the loss check)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train_synthetic.py"), "--batch", "8", "--steps", "6"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert "OK" in r.stdout and r.stdout.count("step ") == 6
