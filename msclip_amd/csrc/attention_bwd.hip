@@ -290,14 +290,23 @@ __global__ __launch_bounds__(256) void attn_bwd_qb_kernel(const bf16_t* __restri
   }
 
   const int r16 = lane & 15, quad = lane >> 4;
-  auto mma = [&](f32x4 acc, const bf16_t* pa, int sa, const bf16_t* pb, int sb, int ksteps) {
-    for (int ks = 0; ks < ksteps; ++ks) {
-      const bf16x8 a = *(const bf16x8*)(pa + r16 * sa + ks * 32 + quad * 8);
-      const bf16x8 bb = *(const bf16x8*)(pb + r16 * sb + ks * 32 + quad * 8);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bb, acc, 0, 0, 0);
+  // fragment reads batched in front of their MFMAs (see attn_bwd_kernel)
+  auto mma = [&](f32x4 acc, const bf16_t* pa, int sa, const bf16_t* pb, int sb, auto ksc) {
+    constexpr int KS = decltype(ksc)::value;
+    bf16x8 a[KS], bb[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      a[ks] = *(const bf16x8*)(pa + r16 * sa + ks * 32 + quad * 8);
+      bb[ks] = *(const bf16x8*)(pb + r16 * sb + ks * 32 + quad * 8);
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks], bb[ks], acc, 0, 0, 0);
     return acc;
   };
+  using K1 = std::integral_constant<int, 1>;
+  using K2 = std::integral_constant<int, 2>;
+  using KL = std::integral_constant<int, LPK / 32>;
 
   f32x4 acc[NA];
 #pragma unroll
@@ -348,7 +357,7 @@ __global__ __launch_bounds__(256) void attn_bwd_qb_kernel(const bf16_t* __restri
       for (int i = 0; i < NK0; ++i) {
         const int kt = kt0 + i;
         if (kt < kt1) {
-          st[i] = mma(f32x4{0.f, 0.f, 0.f, 0.f}, K + kt * 16 * RS, RS, Qb + qt * 16 * RS, RS, 2);
+          st[i] = mma(f32x4{0.f, 0.f, 0.f, 0.f}, K + kt * 16 * RS, RS, Qb + qt * 16 * RS, RS, K2{});
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int key = kt * 16 + quad * 4 + r;
@@ -385,7 +394,7 @@ __global__ __launch_bounds__(256) void attn_bwd_qb_kernel(const bf16_t* __restri
       for (int i = 0; i < NK0; ++i) {
         const int kt = kt0 + i;
         if (kt < kt1) {
-          const f32x4 dp = mma(f32x4{0.f, 0.f, 0.f, 0.f}, V + kt * 16 * RS, RS, dOb + qt * 16 * RS, RS, 2);
+          const f32x4 dp = mma(f32x4{0.f, 0.f, 0.f, 0.f}, V + kt * 16 * RS, RS, dOb + qt * 16 * RS, RS, K2{});
           float ds[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -410,11 +419,11 @@ __global__ __launch_bounds__(256) void attn_bwd_qb_kernel(const bf16_t* __restri
       const int t = wave + 4 * i;                      // < 2 * 4 * NT16
       const int which = t / (4 * NT16), rem = t - which * 4 * NT16;
       const int dt = rem / NT16, kt = rem - dt * NT16;
-      acc[i] = mma(acc[i], (which ? QT : dOT) + dt * 16 * QS, QS, (which ? dST : PT) + kt * 16 * QS, QS, 1);
+      acc[i] = mma(acc[i], (which ? QT : dOT) + dt * 16 * QS, QS, (which ? dST : PT) + kt * 16 * QS, QS, K1{});
     }
     for (int t = wave; t < 4 * (QB / 16); t += 4) {
       const int dt = t >> 1, tq = t & 1;
-      const f32x4 a = mma(f32x4{0.f, 0.f, 0.f, 0.f}, KT + dt * 16 * LS, LS, dS + tq * 16 * LS, LS, LPK / 32);
+      const f32x4 a = mma(f32x4{0.f, 0.f, 0.f, 0.f}, KT + dt * 16 * LS, LS, dS + tq * 16 * LS, LS, KL{});
       const int tok = q0 + tq * 16 + r16;
       if (tok < L) {
         uint2 u;
