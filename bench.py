@@ -136,6 +136,9 @@ def main():
         assert dist.is_initialized() and dist.get_backend() == "nccl" and dist.get_world_size() == args.gpus, \
             (dist.get_backend(), dist.get_world_size(), args.gpus)
     dev = torch.device("cuda", local)
+    # a process group also exists at N = 1 under MSCLIP_COLLECTIVES_AT_WORLD_1=1 (one rank, every collective through RCCL as an
+    # identity: what the collectives cost a step before any wire time; tests/test_gpu_model.py)
+    grouped = dist.is_initialized()
 
     sd = synth.synth_state_dict(load_schema(args.model), seed=0)
     model = get_clip_model(named_config(args.model))
@@ -160,10 +163,16 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
+    if grouped:
+        # with a communicator in the process the legacy default stream synchronises implicitly with RCCL's streams on every
+        # launch (hip.off_default_stream): the whole run goes to one non-default stream instead of switching per call
+        compute = hip.compute_stream(dev)
+        compute.wait_stream(torch.cuda.current_stream(dev))
+        torch.cuda.set_stream(compute)
     for _ in range(args.warmup):
         loss = step()
     if args.prefill_random:
@@ -181,7 +190,7 @@ def main():
     dt = time.perf_counter() - t0
     hip.set_gemm_probe(DOMINANT["variant"], None)
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if grouped:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     loss_val = float(loss)
@@ -212,6 +221,8 @@ def main():
             rec["config"]["bn"] = ("train mode: per-GPU batch statistics, running statistics updated (momentum 0.1)"
                                    if args.bn == "batch" else "frozen running statistics (folded); gamma / beta receive gradients")
         rec["config"]["rccl_ranks"] = dist.get_world_size() if world > 1 else 1
+        if grouped and world == 1:
+            rec["config"]["collectives"] = f"one-rank {dist.get_backend()} group: every collective issued (identity)"
         if shared:
             rec["config"]["TEST_ONLY"] = "all ranks share GPU 0 over gloo (MSCLIP_TEST_SHARED_GPU): not a measurement"
         n = probe.summary()[0] if probe is not None else 0
@@ -254,8 +265,11 @@ def main():
             rec["mfma_util_pct"] = rec["roofline"]["mfma_busy_pct_whole_step"]   # BASELINE metric's second half (all kernels of a step)
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(args.model, sd)
+        if grouped:                     # RCCL's version banner sits in libc's stdout buffer: out with it BEFORE the record, so
+            import ctypes               # that the JSON line is the last line of the run
+            ctypes.CDLL(None).fflush(None)
         print(json.dumps(rec), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -255,6 +255,15 @@ int msclip_bn_bwd_dx(const void* dy, int lddy, int dy_f32, const void* x, int ld
 int msclip_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
                  float weight_decay, int step, void* stream);
 
+/* HIP streams with an explicit priority on the current device.  The training step runs its weight-gradient jobs beside the
+ * dgrad chain (the role torch DDP's / autograd's side streams play under the reference's lib/core/function.py:66-77
+ * backward); streams of the LOWEST priority draw their hardware queue from a pool of their own, so the overlap does not
+ * depend on which other streams (RCCL's, the caller's) the runtime happens to map onto the compute stream's queue.
+ * priority_range: numerically greatest = least urgent (HIP's convention).  Return value: hipError_t. */
+int msclip_stream_priority_range(int* least, int* greatest);
+int msclip_stream_create(int priority, void** stream);
+int msclip_stream_destroy(void* stream);
+
 /* Library / device introspection (no GPU work). */
 int msclip_abi_version(void);
 const char* msclip_build_arch(void);

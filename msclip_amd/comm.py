@@ -24,6 +24,16 @@ class Comm(object):
         return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
     @property
+    def collectives(self):
+        """True when the data path has to run its collectives: more than one rank -- or ONE rank of an initialised group
+        with MSCLIP_COLLECTIVES_AT_WORLD_1=1 (the one-GPU RCCL test: every collective then goes through the backend as an
+        identity instead of being skipped)."""
+        import os
+        if not (dist.is_available() and dist.is_initialized()):
+            return False
+        return dist.get_world_size() > 1 or os.environ.get("MSCLIP_COLLECTIVES_AT_WORLD_1") == "1"
+
+    @property
     def rank(self):
         return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
@@ -43,7 +53,7 @@ class Comm(object):
         return self.rank == 0
 
     def synchronize(self):
-        if self.world_size == 1:
+        if not self.collectives:
             return
         dist.barrier()
 
@@ -64,7 +74,7 @@ def _all_gather_rows(t):
 
 def gather_tensors(tensor):
     """[B, ...] on every rank -> [B*world, ...], rank-major; gradient only through the local rows."""
-    if comm.world_size == 1:
+    if not comm.collectives:
         return tensor
     out = _all_gather_rows(tensor.detach())
     if tensor.requires_grad:
@@ -75,7 +85,7 @@ def gather_tensors(tensor):
 
 def gather_features(packed):
     """packed [B, 2, E] (image | text features of the local batch) -> [world*B, 2, E] in ONE collective."""
-    if comm.world_size == 1:
+    if not comm.collectives:
         return packed
     return _all_gather_rows(packed)
 
@@ -115,7 +125,7 @@ def gather_rows_async(t):
     """Start the rank-major all-gather of t [B, ...]; returns (out, handle).  On a HIP device the collective is issued
     from the side stream behind an event recorded now on the compute stream ("t is final"), so it overlaps whatever
     the compute stream runs next.  handle is None at world size 1 (out is t itself)."""
-    if comm.world_size == 1:
+    if not comm.collectives:
         return t, None
     t = t.contiguous()
     out = torch.empty((comm.world_size * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
@@ -153,8 +163,8 @@ class GradReducer:
         self.launched = 0            # collectives issued (tests / bench read it)
 
     def add(self, name, grad):
-        if comm.world_size == 1:
-            self.flights.append((None, None, None, [(name, grad)]))
+        if not comm.collectives:
+            self.flights.append((None, None, None, [(name, grad)], None))
             return
         self.pending.append((name, grad))
         self.open_elems += grad.numel()
@@ -165,38 +175,54 @@ class GradReducer:
         if not self.pending:
             return
         dev = self.pending[0][1].device
-        if dev.type == "cuda":
-            from .gradgemm import join
-            join(dev)                                        # weight gradients still running on the wgrad lane stream
         flat = torch.empty(self.open_elems, dtype=torch.float32, device=dev)
         layout, o = [], 0
         for name, g in self.pending:
             n = g.numel()
-            flat[o:o + n].copy_(g.reshape(-1))
             layout.append((name, tuple(g.shape), o, n))
             o += n
+        grads = [g for _, g in self.pending]
         self.pending, self.open_elems = [], 0
-        if self.average:
-            flat.mul_(1.0 / comm.world_size)                 # pre-scaled: the reduced sum is the mean
+
+        def pack():
+            if all(g.dtype == torch.float32 for g in grads):
+                torch.cat([g.reshape(-1) for g in grads], out=flat)          # batched: a few launches per bucket
+            else:
+                for g, (_, _, o, n) in zip(grads, layout):
+                    flat[o:o + n].copy_(g.reshape(-1))
+            if self.average and comm.world_size > 1:
+                flat.mul_(1.0 / comm.world_size)                              # pre-scaled: the reduced sum is the mean
+
         side = None
         if flat.is_cuda:
+            # pack + all-reduce both on the side stream, behind "everything queued so far" on the compute stream AND on the
+            # wgrad lane stream (gradgemm.wgrad_async): the compute stream itself waits for neither and goes on with the
+            # backward pass
+            from .gradgemm import lane_stream
             side = side_stream(dev)
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream(dev))
             side.wait_event(ready)
+            lane = lane_stream(dev)
+            if lane is not None:
+                side.wait_stream(lane)
             with torch.cuda.stream(side):
+                pack()
                 work = dist.all_reduce(flat, async_op=True)
             flat.record_stream(side)
+            for g in grads:
+                g.record_stream(side)
         else:
+            pack()
             work = dist.all_reduce(flat, async_op=True)
         self.launched += 1
-        self.flights.append((flat, work, side, layout))
+        self.flights.append((flat, work, side, layout, grads))               # grads: alive until the side stream has read them
 
     def finish(self):
         """-> {name: averaged gradient}; the current stream is ordered behind every collective."""
         self.flush()
         out = {}
-        for flat, work, side, layout in self.flights:
+        for flat, work, side, layout, _ in self.flights:
             if flat is None:
                 out[layout[0][0]] = layout[0][1]
                 continue
@@ -221,7 +247,9 @@ def init_distributed(backend=None):
     """env:// initialisation used by bench.py (reference lib/utils/utils.py:61-73: nccl == RCCL on ROCm)."""
     import datetime
     import os
-    if dist.is_initialized() or int(os.environ.get("WORLD_SIZE", "1")) == 1:
+    if dist.is_initialized():
+        return
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and os.environ.get("MSCLIP_COLLECTIVES_AT_WORLD_1") != "1":
         return
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"

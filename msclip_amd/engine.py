@@ -483,6 +483,7 @@ class Engine:
             raise ValueError(f"expected tokens [B, {self.Lt}], got {tuple(tok.shape)}")
         return tok.to(torch.int64).contiguous()
 
+    @hip.off_default_stream
     def run(self, img=None, tok=None, norm=True, gather=False, taps=None):
         """Both towers (either may be None) up to the (optionally L2-normalised) features; returns the workspace
         (plus the gathered bf16 features under "allI"/"allT" when gather=True).  `taps` (a dict) receives fp32 copies
@@ -548,10 +549,12 @@ class Engine:
         self._ws[key] = replay
         return replay
 
+    @hip.off_default_stream
     def encode_image(self, img, norm=True):
         w = self.run(img=img, norm=norm)
         return (w["fv"] if norm else w["fv_raw"]).clone()
 
+    @hip.off_default_stream
     def encode_text(self, tok, norm=True):
         w = self.run(tok=tok, norm=norm)
         return (w["ft"] if norm else w["ft_raw"]).clone()
@@ -564,6 +567,7 @@ class Engine:
             return w, w["allI"], w["allT"]
         return w, w["fvb"], w["ftb"]
 
+    @hip.off_default_stream
     def forward_logits(self, img, tok, gather=True):
         """Reference-faithful full N x N logits on every rank (M.py:3136-3141)."""
         w, allI, allT = self._gathered(img, tok, gather)
@@ -572,6 +576,7 @@ class Engine:
         hip.gemm(allI, allT, out, alpha=self.logit_scale_exp)
         return out
 
+    @hip.off_default_stream
     def forward_loss(self, img, tok, gather=True):
         """Symmetric CE over the global batch from the LOCAL row and column blocks only (SURVEY.md s8e option B),
         each as one fused MFMA GEMM + online log-sum-exp sweep (no logits block is written): image rows against all
@@ -581,7 +586,7 @@ class Engine:
         B, n = w["fvb"].shape[0], allI.shape[0]
         world = n // B
         loss = self.loss_from_features(w["fvb"], w["ftb"], allI, allT, C.local_label_offset(B) if world > 1 else 0)
-        if world > 1:
+        if world > 1 or (gather and C.comm.collectives):
             dist.all_reduce(loss)
         return loss[0]
 

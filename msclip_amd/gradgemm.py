@@ -10,7 +10,13 @@ BF = torch.bfloat16
 F32 = torch.float32
 
 _SIDE = {}
-_WGRAD_STREAMS = 28
+import os
+# Cap on the concurrent K-slices of a wide weight gradient.  Each slice is a persistent GEMM of `tiles` workgroups (9-36)
+# on its own stream, and the whole job runs beside the main stream's dgrad GEMMs (wgrad_async): TWO slices (18-72 CUs
+# for the gradient, the rest for the critical path) measured best -- ViT-B/32 batch 512 step 142.5 / 126.1 / 129.3 / 132.0 /
+# 138.3 ms at caps 1 / 2 / 4 / 8 / 28 -- and is the only setting that does not depend on how many hardware queues the
+# runtime maps streams to (GPU_MAX_HW_QUEUES 4 -> 8: cap 2 127 -> 127 ms, cap 3 131 -> 168 ms, cap 28 139 -> 186 ms).
+_WGRAD_STREAMS = int(os.environ.get("MSCLIP_WGRAD_STREAMS", "2"))
 
 
 def wgrad(dy_bf, x_bf, M):
@@ -27,7 +33,7 @@ def wgrad(dy_bf, x_bf, M):
         S = max(1, min(512 // t128, M // 1024))
         Mpad = (M + 64 * S - 1) // (64 * S) * (64 * S)
         return hip.gemm_splitk(hip.transpose_bf16(dy_bf, M, Mpad), hip.transpose_bf16(x_bf, M, Mpad), S)
-    S = max(1, min(_WGRAD_STREAMS, 256 // tiles, M // 4096))           # one workgroup per CU across the S concurrent GEMMs
+    S = max(1, min(_WGRAD_STREAMS, 256 // tiles, M // 4096))
     Mpad = (M + 64 * S - 1) // (64 * S) * (64 * S)
     a = hip.transpose_bf16(dy_bf, M, Mpad)
     b = hip.transpose_bf16(x_bf, M, Mpad)
@@ -38,7 +44,9 @@ def wgrad(dy_bf, x_bf, M):
     kc = Mpad // S
     part = torch.empty(S, N, K, dtype=F32, device=a.device)
     cur = torch.cuda.current_stream(a.device)
-    pool = _SIDE.setdefault(a.device, [torch.cuda.Stream(device=a.device) for _ in range(_WGRAD_STREAMS)])
+    pool = _SIDE.get(a.device)
+    if pool is None:
+        pool = _SIDE[a.device] = [hip.background_stream(a.device) for _ in range(_WGRAD_STREAMS)]
     ready = torch.cuda.Event()
     ready.record(cur)
     for sidx in range(S):
@@ -71,8 +79,13 @@ _LANE = {}
 def lane(device):
     s = _LANE.get(device)
     if s is None:
-        s = _LANE[device] = torch.cuda.Stream(device=device)
+        s = _LANE[device] = hip.background_stream(device)
     return s
+
+
+def lane_stream(device):
+    """The lane stream of `device` if anything has used it yet, else None (comm.GradReducer orders its buckets behind it)."""
+    return _LANE.get(device)
 
 
 def _ranks_share_a_gpu():

@@ -48,6 +48,7 @@ class TrainStep:
         self.convbn = None
         self.model = model
         self.eng = model.engine()
+        self.dev = self.eng.dev
         self.lr, self.lr_share = lr, lr_share
         self.wd, self.wd_share = wd, wd_share
         self.betas, self.eps = betas, eps
@@ -55,6 +56,7 @@ class TrainStep:
         self.steps = 0
 
     # ------------------------------------------------------------------ forward that keeps what the backward needs
+    @hip.off_default_stream
     def forward(self, img, tok):
         try:
             return self._forward(img, tok)
@@ -159,7 +161,7 @@ class TrainStep:
                 lo = hip.cast_bf16(f - hi.float())
                 return torch.cat([hi, lo], dim=1)                                              # [B, 2E]: the gather payload
             pi, pt = split(sv["fv"]), split(sv["ft"])
-            if C.comm.world_size > 1:
+            if C.comm.collectives:
                 allpi, hi_ = C.gather_rows_async(pi)
                 allpt, ht_ = C.gather_rows_async(pt)
                 hi_.wait(); ht_.wait()
@@ -184,7 +186,8 @@ class TrainStep:
             hip.lse_rows(S_t, lse[1])
             out = torch.empty(1, dtype=F32, device=e.dev)
             hip.clip_loss_partial(lse[0], lse[1], S_i, off, 1.0 / (2.0 * n), out)
-            if n > Bi:
+            sv["coll"] = n > Bi or C.comm.collectives
+            if sv["coll"]:
                 dist.all_reduce(out)
                 lse_flat = torch.empty((n // Bi) * 2, Bi, dtype=F32, device=e.dev)            # concatenated along dim 0: every backend's form
                 dist.all_gather_into_tensor(lse_flat, lse.contiguous())
@@ -196,6 +199,7 @@ class TrainStep:
             return out[0].clone()
 
     # ------------------------------------------------------------------ backward
+    @hip.off_default_stream
     def backward(self, reduce=True, bucket_bytes=64 << 20):
         """-> {reference state_dict key: fp32 gradient} for every parameter of the slice (shared tensors under their
         visual.* key; the text-tower aliases are the same Parameter objects).  Under N > 1 ranks (and reduce=True) the
@@ -210,7 +214,7 @@ class TrainStep:
         with torch.cuda.device(dev), torch.no_grad():
             Bi, Bt, Mv, M, n, off = sv["Bi"], sv["Bt"], sv["Mv"], sv["M"], sv["n"], sv["off"]
             s = e.logit_scale_exp
-            reducer = C.GradReducer(bucket_bytes) if (reduce and C.comm.world_size > 1) else None
+            reducer = C.GradReducer(bucket_bytes) if (reduce and C.comm.collectives) else None
             self.reducer = reducer
 
             class _Grads(dict):
@@ -236,7 +240,7 @@ class TrainStep:
             dfi, dsp = side(sv["S_i"], sv["allT"], lse_i_loc, lse_t_all, True)
             dft, _ = side(sv["S_t"], sv["allI"], lse_t_loc, lse_i_all, False)
             dscale = hip.colsum(dsp.view(-1, 1))                                               # sum_r sum_j G S
-            if n > Bi:
+            if sv["coll"]:
                 dist.all_reduce(dscale)
             # S already carries the scale: dL/dscale = sum G S / scale; logit_scale = log(scale) => dL/dlogit_scale = sum G S
             grads["logit_scale"] = dscale.reshape(())
@@ -374,6 +378,7 @@ class TrainStep:
             out.append((k, p, lr, wd))
         return out
 
+    @hip.off_default_stream
     def step(self, grads, world_average=False):
         """AdamW on the module's fp32 parameters (msclip_adamw), then the engine re-packs its bf16 copies.  backward()
         already returns rank-averaged gradients; world_average=True averages here instead, tensor by tensor (for

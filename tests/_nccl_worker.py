@@ -22,6 +22,8 @@ def main():
     from msclip_amd import comm as C, synth
     from msclip_amd.clip_openai_pe_res_v1 import get_clip_model
     from msclip_amd.config import named_config
+    if world == 1:
+        os.environ["MSCLIP_COLLECTIVES_AT_WORLD_1"] = "1"             # one rank, but every collective goes through the backend
     C.init_distributed(backend)
     assert dist.get_backend() == backend and C.comm.world_size == world
     name = "b32-yfcc-msclips"

@@ -454,6 +454,39 @@ def test_two_rank_rccl_gather_matches_single_process(gpu_device, tmp_path):
     assert abs(got["loss"] - ref_loss) <= 2e-3
 
 
+def test_one_rank_rccl_collectives(gpu_device, tmp_path):
+    """RCCL itself on a one-GPU box: a world of ONE rank over the `nccl` backend runs every collective of the N > 1 path
+    through librccl (communicator creation, `all_gather_into_tensor` of the features from the side stream, the scalar
+    all-reduce of the sharded loss, the bucketed async gradient all-reduce) -- with one rank they are identities, so the
+    results must equal the plain single-process run on the same batch."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    from msclip_amd import train
+    out = tmp_path / "r0.pt"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", "29617",
+                        os.path.join(ROOT, "tests", "_nccl_worker.py"), str(out), "nccl"], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = torch.load(out)
+    m = model_for("b32-yfcc-msclips")
+    img, tok = synth.synth_images(6, seed=91).cuda(), synth.synth_tokens(6, seed=92).cuda()
+    assert torch.equal(got["logits"], m(img, tok).cpu())
+    assert got["loss"] == float(m.contrastive_loss(img, tok))
+    ts = train.TrainStep(m, lr=1e-4, bn="frozen")
+    assert got["train_loss"] == float(ts.forward(img, tok))
+    full = ts.backward()
+    assert got["n_grads"] == len(full) and got["launched"] >= 8
+    for k, g in got["grads"].items():
+        if k == "token_embedding.weight":                              # atomics: order-dependent last bits
+            assert torch.allclose(g, full[k].float().cpu(), rtol=1e-3, atol=1e-6), k
+        else:
+            assert torch.equal(g, full[k].float().cpu()), k
+
+
 def test_two_ranks_on_one_gpu_over_gloo(gpu_device, tmp_path):
     """The N > 1 path on a one-GPU box: two processes share GPU 0 and talk over gloo, so everything but RCCL itself runs --
     rank-major feature gathers issued from the side stream, label offsets, the sharded loss + scalar all-reduce, and the
