@@ -167,7 +167,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if grouped:
+    if grouped and not hip.env_flag("MSCLIP_KEEP_DEFAULT_STREAM"):
         # with a communicator in the process the legacy default stream synchronises implicitly with RCCL's streams on every
         # launch (hip.off_default_stream): the whole run goes to one non-default stream instead of switching per call
         compute = hip.compute_stream(dev)
