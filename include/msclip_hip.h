@@ -251,9 +251,26 @@ int msclip_bn_bwd_dx(const void* dy, int lddy, int dy_f32, const void* x, int ld
                      const float* rstd, const float* gamma, const float* dbeta, const float* dgamma, void* dx, int lddx, int M,
                      int C, long long n_stat, void* stream);
 
+/* One parameter tensor of msclip_adamw_multi (host-side array; lr / weight_decay per tensor = the reference's parameter
+ * groups, lib/optim/build.py via CUSTOM.LR_SHARE / WD_SHARE and TRAIN.WITHOUT_WD_LIST). */
+typedef struct msclip_adamw_tensor {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  long long n;
+  float lr;
+  float weight_decay;
+} msclip_adamw_tensor;
+
 /* AdamW with decoupled weight decay on one fp32 tensor (step >= 1 for the bias corrections). */
 int msclip_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
                  float weight_decay, int step, void* stream);
+/* The same update for `count` tensors in a handful of launches (32 K-element chunks of up to 48 tensors per launch, the
+ * tensor table travels in the kernel arguments): bitwise the result of `count` msclip_adamw calls.  `tensors` is a HOST
+ * array, read before the call returns. */
+int msclip_adamw_multi(const msclip_adamw_tensor* tensors, int count, float beta1, float beta2, float eps, int step,
+                       void* stream);
 
 /* HIP streams with an explicit priority on the current device.  The training step runs its weight-gradient jobs beside the
  * dgrad chain (the role torch DDP's / autograd's side streams play under the reference's lib/core/function.py:66-77

@@ -392,18 +392,69 @@ __global__ __launch_bounds__(256) void adapter_dx_kernel(const float* __restrict
   }
 }
 
-// ---- AdamW (decoupled weight decay), one fused pass per parameter tensor; fp32 states.
+// ---- AdamW (decoupled weight decay), one fused pass per parameter tensor; fp32 states.  One statement of the update with
+// the contractions written out, shared by both kernels: their results are bitwise the same.
+__device__ __forceinline__ void adamw_update(float gi, float& mi, float& vi, float& pi, float lr, float b1, float b2, float eps,
+                                             float wd, float c1, float c2) {
+  mi = __fmaf_rn(b1, mi, (1.f - b1) * gi);
+  vi = __fmaf_rn(b2, vi, (1.f - b2) * gi * gi);
+  const float upd = __fmaf_rn(wd, pi, mi * c1 / (sqrtf(vi * c2) + eps));
+  pi = __fmaf_rn(-lr, upd, pi);
+}
+
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps,
                                                     float wd, float c1, float c2) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-    const float gi = g[i];
-    const float mi = b1 * m[i] + (1.f - b1) * gi;
-    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    float mi = m[i], vi = v[i], pi = p[i];
+    adamw_update(g[i], mi, vi, pi, lr, b1, b2, eps, wd, c1, c2);
     m[i] = mi;
     v[i] = vi;
-    const float pi = p[i];
-    p[i] = pi - lr * (mi * c1 / (sqrtf(vi * c2) + eps) + wd * pi);
+    p[i] = pi;
+  }
+}
+
+// ---- the same update over many tensors per launch: block b works on chunk (map[b] >> 8) of tensor (map[b] & 255).
+constexpr int AW_TENSORS = 48, AW_BLOCKS = 400, AW_CHUNK = 32768;
+struct AdamwBatch {
+  msclip_adamw_tensor t[AW_TENSORS];
+  unsigned map[AW_BLOCKS];
+};
+
+__global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamwBatch a, float b1, float b2, float eps, float c1, float c2) {
+  const unsigned e = a.map[blockIdx.x];
+  const msclip_adamw_tensor& t = a.t[e & 255u];
+  const size_t lo = (size_t)(e >> 8) * AW_CHUNK;
+  const size_t left = (size_t)t.n - lo;
+  const int cnt = left < (size_t)AW_CHUNK ? (int)left : AW_CHUNK;
+  float* __restrict__ p = t.p + lo;
+  const float* __restrict__ g = t.g + lo;
+  float* __restrict__ m = t.m + lo;
+  float* __restrict__ v = t.v + lo;
+  const float lr = t.lr, wd = t.weight_decay;
+  auto upd = [&](float gi, float& mi, float& vi, float& pi) { adamw_update(gi, mi, vi, pi, lr, b1, b2, eps, wd, c1, c2); };
+  int i0 = 0;
+  if (!(((size_t)p | (size_t)g | (size_t)m | (size_t)v) & 15)) {
+    const int n4 = cnt >> 2;
+    for (int i = threadIdx.x; i < n4; i += 256) {
+      const float4 g4 = ((const float4*)g)[i];
+      float4 m4 = ((float4*)m)[i], v4 = ((float4*)v)[i], p4 = ((float4*)p)[i];
+      upd(g4.x, m4.x, v4.x, p4.x);
+      upd(g4.y, m4.y, v4.y, p4.y);
+      upd(g4.z, m4.z, v4.z, p4.z);
+      upd(g4.w, m4.w, v4.w, p4.w);
+      ((float4*)m)[i] = m4;
+      ((float4*)v)[i] = v4;
+      ((float4*)p)[i] = p4;
+    }
+    i0 = n4 << 2;
+  }
+  for (int i = i0 + threadIdx.x; i < cnt; i += 256) {
+    float mi = m[i], vi = v[i], pi = p[i];
+    upd(g[i], mi, vi, pi);
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = pi;
   }
 }
 
@@ -539,5 +590,42 @@ extern "C" int msclip_adamw(float* p, const float* g, float* m, float* v, long l
   const float c1 = 1.f / (1.f - powf(beta1, (float)step)), c2 = 1.f / (1.f - powf(beta2, (float)step));
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((size_t)n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (size_t)n, lr,
                      beta1, beta2, eps, weight_decay, c1, c2);
+  return msclip_launch_status();
+}
+
+extern "C" int msclip_adamw_multi(const msclip_adamw_tensor* tensors, int count, float beta1, float beta2, float eps, int step,
+                                  void* stream) {
+  if (!tensors || count < 0 || step < 1) return MSCLIP_EINVAL;
+  for (int i = 0; i < count; ++i)
+    if (!tensors[i].p || !tensors[i].g || !tensors[i].m || !tensors[i].v || tensors[i].n <= 0) return MSCLIP_EINVAL;
+  const float c1 = 1.f / (1.f - powf(beta1, (float)step)), c2 = 1.f / (1.f - powf(beta2, (float)step));
+  AdamwBatch b;
+  int nt = 0, nb = 0;
+  auto flush = [&]() {
+    if (nb) hipLaunchKernelGGL(adamw_multi_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, b, beta1, beta2, eps, c1, c2);
+    nt = nb = 0;
+  };
+  for (int i = 0; i < count; ++i) {
+    const long long chunks = (tensors[i].n + AW_CHUNK - 1) / AW_CHUNK;
+    long long c = 0;
+    while (c < chunks) {
+      if (nt == AW_TENSORS || nb == AW_BLOCKS) flush();
+      b.t[nt] = tensors[i];
+      // a tensor that continues in the next launch restarts there at chunk c: shift its base instead of carrying an offset
+      b.t[nt].p += c * AW_CHUNK;
+      b.t[nt].g += c * AW_CHUNK;
+      b.t[nt].m += c * AW_CHUNK;
+      b.t[nt].v += c * AW_CHUNK;
+      b.t[nt].n -= c * AW_CHUNK;
+      long long local = 0;
+      while (c < chunks && nb < AW_BLOCKS) {
+        b.map[nb++] = (unsigned)nt | ((unsigned)local << 8);
+        ++local;
+        ++c;
+      }
+      ++nt;
+    }
+  }
+  flush();
   return msclip_launch_status();
 }

@@ -22,7 +22,7 @@ EXPORTS = (
     "msclip_lse_rows", "msclip_clip_loss_partial", "msclip_clip_lse_fused", "msclip_clip_loss_from_partials",
     "msclip_transpose_bf16", "msclip_cast_bf16", "msclip_colsum", "msclip_quickgelu", "msclip_quickgelu_bwd", "msclip_layernorm_bwd",
     "msclip_attention_bwd", "msclip_l2norm_bwd", "msclip_clip_loss_bwd_g", "msclip_embed_tokens_bwd", "msclip_adapter_sum",
-    "msclip_adapter_dx", "msclip_adamw", "msclip_im2col", "msclip_col2im", "msclip_relu_bwd", "msclip_dwpool_bwd",
+    "msclip_adapter_dx", "msclip_adamw", "msclip_adamw_multi", "msclip_im2col", "msclip_col2im", "msclip_relu_bwd", "msclip_dwpool_bwd",
     "msclip_dwpool_wgrad", "msclip_dw3x3_wgrad", "msclip_gemm_splitk", "msclip_bn_stats", "msclip_bn_apply",
     "msclip_bn_bwd_reduce", "msclip_bn_bwd_dx",
     "msclip_abi_version", "msclip_build_arch",
@@ -108,6 +108,7 @@ def lib():
         L.msclip_adapter_sum.argtypes = [vp, ci, vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
         L.msclip_adapter_dx.argtypes = [vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, vp]
         L.msclip_adamw.argtypes = [vp, vp, vp, vp, ll, cf, cf, cf, cf, cf, ci, vp]
+        L.msclip_adamw_multi.argtypes = [ctypes.POINTER(AdamwTensor), ci, cf, cf, cf, ci, vp]
         L.msclip_im2col.argtypes = [vp, ci, vp] + [ci] * 11 + [vp]
         L.msclip_col2im.argtypes = [vp, ci, vp] + [ci] * 11 + [vp]
         L.msclip_relu_bwd.argtypes = [vp, vp, vp, vp, ll, vp]
@@ -739,6 +740,27 @@ def bn_bwd(dy, x, mean, rstd, gamma, dx, M=None):
         _check(lib().msclip_bn_bwd_dx(_p(dy), dy.stride(0), df, _p(x), x.stride(0), xf, _p(mean), _p(rstd), _p(gamma),
                                       _p(dbeta), _p(dgamma), _p(dx), dx.stride(0), M, C, M, _stream()), "msclip_bn_bwd_dx")
     return dgamma, dbeta
+
+
+class AdamwTensor(ctypes.Structure):
+    """msclip_adamw_tensor (include/msclip_hip.h)."""
+    _fields_ = [("p", ctypes.c_void_p), ("g", ctypes.c_void_p), ("m", ctypes.c_void_p), ("v", ctypes.c_void_p),
+                ("n", ctypes.c_longlong), ("lr", ctypes.c_float), ("weight_decay", ctypes.c_float)]
+
+
+def adamw_multi(items, beta1, beta2, eps, step):
+    """items: [(p, g, m, v, lr, weight_decay)] of contiguous fp32 tensors: one msclip_adamw_multi call (a handful of
+    launches for the model's 325 tensors instead of one each)."""
+    n = len(items)
+    if not n:
+        return
+    arr = (AdamwTensor * n)()
+    for a, (p, g, m, v, lr, wd) in zip(arr, items):
+        for t in (p, g, m, v):
+            assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel() and t.device == p.device
+        a.p, a.g, a.m, a.v, a.n, a.lr, a.weight_decay = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, wd
+    with torch.cuda.device(items[0][0].device):
+        _check(lib().msclip_adamw_multi(arr, n, beta1, beta2, eps, step, _stream()), "msclip_adamw_multi")
 
 
 def adamw(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):

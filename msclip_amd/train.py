@@ -385,6 +385,7 @@ class TrainStep:
         gradients produced with backward(reduce=False))."""
         self.steps += 1
         with torch.no_grad():
+            items = []
             for k, p, lr, wd in self.param_groups():
                 g = grads.get(k)
                 if g is None:
@@ -396,9 +397,8 @@ class TrainStep:
                 st = self.state.get(k)
                 if st is None:
                     st = self.state[k] = (torch.zeros_like(p), torch.zeros_like(p))
-                hip.adamw(p.data.view(-1), g.view(-1), st[0].view(-1), st[1].view(-1), lr, self.betas[0], self.betas[1],
-                          self.eps, wd, self.steps)
-                p._version  # (in-place kernel write: bump the engine's fingerprint below)
+                items.append((p.data.view(-1), g.view(-1), st[0].view(-1), st[1].view(-1), lr, wd))
+            hip.adamw_multi(items, self.betas[0], self.betas[1], self.eps, self.steps)     # in-place: refresh below re-packs
         self.eng.refresh(force=True)
 
 

@@ -192,6 +192,35 @@ def test_l2norm_loss_embed_adapter_adamw(gpu_device):
     assert rel(p, pt.detach()) < 1e-5
 
 
+def test_adamw_multi_equals_per_tensor_calls(gpu_device):
+    """msclip_adamw_multi over a ragged list (1 element ... 20 M: tensors that span several launches, more tensors than one
+    launch's table, an unaligned gradient view as the bucketed all-reduce hands them out) = msclip_adamw tensor by tensor,
+    bit for bit, over three steps; guard elements behind every tensor stay untouched."""
+    sizes = [1, 3, 768, 5000, 32768, 32769, 65536 + 5, 768 * 768, 20_000_003] + [100 + 7 * i for i in range(60)]
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    flat = torch.randn(sum(sizes) + len(sizes) + 1, device="cuda", generator=gen)          # gradients as views at odd offsets
+    ps, offs, o = [], [], 1
+    for n in sizes:
+        ps.append(torch.randn(n + 4, device="cuda", generator=gen))
+        offs.append(o)
+        o += n + 1
+    one = [(p.clone(), torch.zeros_like(p), torch.zeros_like(p)) for p in ps]
+    many = [(p.clone(), torch.zeros_like(p), torch.zeros_like(p)) for p in ps]
+    for step in (1, 2, 3):
+        fs = flat * step
+        gs = [fs[o:o + n] for o, n in zip(offs, sizes)]
+        assert any(g.data_ptr() % 16 for g in gs)
+        for (p, m, v), g, n in zip(one, gs, sizes):
+            hip.adamw(p[:n], g, m[:n], v[:n], 1e-3 * (1 + n % 3), 0.9, 0.98, 1e-6, 0.2 * (n % 2), step)
+        hip.adamw_multi([(p[:n], g, m[:n], v[:n], 1e-3 * (1 + n % 3), 0.2 * (n % 2))
+                         for (p, m, v), g, n in zip(many, gs, sizes)], 0.9, 0.98, 1e-6, step)
+    for (p1, m1, v1), (p2, m2, v2), p0, n in zip(one, many, ps, sizes):
+        assert torch.equal(p1, p2) and torch.equal(m1, m2) and torch.equal(v1, v2), (n, (p1 - p2).abs().max().item(), (m1 - m2).abs().max().item())
+        assert torch.equal(p2[n:], p0[n:]) and not torch.equal(p2[:n], p0[:n])
+    with pytest.raises(hip.HipError):
+        hip.adamw_multi([(one[0][0], one[0][0], one[0][1], one[0][2], 1e-3, 0.0)], 0.9, 0.98, 1e-6, 0)
+
+
 @pytest.mark.parametrize("geom", [(2, 12, 16, 3, 2, 1), (3, 9, 8, 1, 2, 0), (2, 8, 24, 3, 1, 1), (2, 10, 3, 3, 2, 1)])
 def test_im2col_col2im_against_conv_autograd(gpu_device, geom):
     """dW = dY^T . im2col(X) and dX = col2im(dY . W) against autograd of F.conv2d (fp32 on the same bf16 values);
