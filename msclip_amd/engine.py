@@ -91,6 +91,7 @@ class Engine:
         dev = self.dev
         v, vt = m.visual, m.visual.transformer
         sd = {k: t.detach() for k, t in m.state_dict().items()}
+        P.bn_fold_all(sd)
         self.D = m.transformer_width
         self.E = m.embed_dim
         self.heads = m.heads
