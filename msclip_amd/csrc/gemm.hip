@@ -319,9 +319,11 @@ __device__ __forceinline__ void epilogue_pack16(f32x4 (&acc)[2 * TN][2 * TM], co
   // time instead of back to back.  Measured same-box against the back-to-back form: QKV 226.6 -> 223.1 us, c_fc unchanged
   // (334 -> 333 us), ping-pong launches in the model step 187.0 -> 185.6 us on average.  (The probe builds say the c_fc
   // epilogue is 57 us of activation math + staging and 32 us that vanish without the stores, nearly additive; spreading
-  // the stores does not recover them, so they are not lost to a blocked store queue at issue.  The likelier mechanism: the
-  // VM counter retires in order, so the SECOND K-tile's wait of the next tile -- for regions issued after these stores --
-  // also waits for the stores' acknowledgements, ~128 KiB per CU draining at ~16 B/clk.)
+  // the stores within the epilogue does not recover them.  Nor are they lost in the next tile's counted waits: a timing-only
+  // probe whose K-tile 1 / K-tile 2 waits also leave the epilogue's stores in flight -- wrong results, -DPP_RELAX2 / 3 of
+  // tools/probes/gemm_pp_probes.hip -- runs every shape within noise of the shipped kernel.  What is left is the CU's
+  // store path itself: ~128 KiB per tile at ~16 B/clk is ~8 k cycles during which all eight waves sit in the epilogue and
+  // nobody issues MFMAs.)
   u32x4 x[2][4];
   auto quarter = [&](int tm, int q) {                            // (mi, ni) = (q >> 1, 2 * (q & 1) + {0, 1})
     const int mi = q >> 1;

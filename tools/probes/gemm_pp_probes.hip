@@ -1306,6 +1306,16 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
       issue(I3{});
       if (kt == 0 && nk >= 3 && epi_stores == 16) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
       else if (kt == 0 && nk >= 3 && epi_stores == 32) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+#if defined(PP_RELAX2) || defined(PP_RELAX3)
+      // TIMING ONLY (results are wrong: K-tile 2 / 3 may not have landed): also K-tile 1's (and 2's) wait leaves the
+      // epilogue's stores in flight -- what the tile would cost if those regions were older than the stores
+      else if (kt == 1 && nk >= 5 && epi_stores == 16) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+      else if (kt == 1 && nk >= 5 && epi_stores == 32) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+#endif
+#ifdef PP_RELAX3
+      else if (kt == 2 && nk >= 5 && epi_stores == 16) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+      else if (kt == 2 && nk >= 5 && epi_stores == 32) asm volatile("s_waitcnt vmcnt(56)" ::: "memory");
+#endif
       else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 #endif
       PP_SYNC_IN();
