@@ -22,6 +22,7 @@ engine.force_unfused, so every intermediate map is there): valid until the next 
 """
 import torch
 
+from . import gradgemm
 from . import hip
 from .gradgemm import wgrad as _wgrad, wgrad_async as _wgrad_async
 
@@ -108,6 +109,23 @@ class ConvSideBackward:
                 del dcol
         return G, db, dx
 
+    def _fold_on_lane(self, grads, fold, conv_key, G, w_raw, dshift, also=None):
+        """fold.grads(...) on gradgemm's lane stream, behind the weight gradient G it consumes (G comes from
+        _conv_bwd(lane=True)); `also` = (fold2, key2, w_raw2) reads the centre tap of the same G (the stem's merged 1x1
+        shortcut).  The results may only be touched after gradgemm.join, like every lane product."""
+        def fn():
+            fold.grads(grads, conv_key, G, w_raw, dshift)
+            if also is not None:
+                f2, k2, w2 = also
+                f2.grads(grads, k2, G[:, :, 1:2, 1:2].contiguous(), w2, dshift)
+            return grads[conv_key]
+        gradgemm.on_lane(fn, G, dshift)
+        if G.is_cuda:
+            cur = torch.cuda.current_stream(G.device)
+            for f, k in ((fold, conv_key),) + (((also[0], also[1]),) if also is not None else ()):
+                for key in (k, f.prefix + ".weight", f.prefix + ".bias"):
+                    grads[key].record_stream(cur)
+
     def _relu_bwd(self, dy, y, dy2=None):
         out = _zbuf(dy.shape[0], dy.shape[1], dy.device)
         hip.relu_bwd(dy, y[:dy.shape[0]], out, dy2=dy2)
@@ -188,20 +206,22 @@ class ConvSideBackward:
         t1, t2, _ = w["par_tmp"][j]
         src = w["par"][j - 1]
 
-        def fold(conv, bn, G, dbias):
-            _Fold(sd, f"{q}.{bn}", 1e-6).grads(grads, f"{q}.{conv}.weight", G, sd[f"{q}.{conv}.weight"].float(), dbias)
-        G, dbias, dt2 = self._conv_bwd(("par", j, 3), c3, t2, dpre, Bi)
-        fold("conv3", "bn3", G, dbias)
-        G, dbias, dsrc_a = self._conv_bwd(("par", j, "r"), cr, src, dpre, Bi)
-        fold("residual_conv", "residual_bn", G, dbias)
+        def fold(conv, bn, G, dpre_, spec):
+            # weight gradient + the fold's chain rule on the lane stream; the bias sum (main stream) feeds the latter
+            dbias = hip.colsum(dpre_, M=Bi * spec.h_out * spec.w_out)
+            self._fold_on_lane(grads, _Fold(sd, f"{q}.{bn}", 1e-6), f"{q}.{conv}.weight", G, sd[f"{q}.{conv}.weight"].float(), dbias)
+        G, _, dt2 = self._conv_bwd(("par", j, 3), c3, t2, dpre, Bi, lane=True)
+        fold("conv3", "bn3", G, dpre, c3)
+        G, _, dsrc_a = self._conv_bwd(("par", j, "r"), cr, src, dpre, Bi, lane=True)
+        fold("residual_conv", "residual_bn", G, dpre, cr)
         del dpre
         dt2 = self._relu_bwd(dt2, t2)
-        G, dbias, dt1 = self._conv_bwd(("par", j, 2), c2, t1, dt2, Bi)
-        fold("conv2", "bn2", G, dbias)
+        G, _, dt1 = self._conv_bwd(("par", j, 2), c2, t1, dt2, Bi, lane=True)
+        fold("conv2", "bn2", G, dt2, c2)
         del dt2
         dt1 = self._relu_bwd(dt1, t1)
-        G, dbias, dsrc_b = self._conv_bwd(("par", j, 1), c1, src, dt1, Bi)
-        fold("conv1", "bn1", G, dbias)
+        G, _, dsrc_b = self._conv_bwd(("par", j, 1), c1, src, dt1, Bi, lane=True)
+        fold("conv1", "bn1", G, dt1, c1)
         self.dpar = [dsrc_a, dsrc_b]
 
     # ------------------------------------------------------------------ stem
@@ -223,10 +243,11 @@ class ConvSideBackward:
             q = f"{sp}.resnet_stage.conv_{i}"
             x_in = w["stem"][i - 1] if i else w["S1"]
             dpre = self._relu_bwd(dy, w["stem"][i])
-            G, dbias, dy = self._conv_bwd(("stem", i), spec, x_in, dpre, Bi)
-            _Fold(sd, q + ".bn1", 1e-5).grads(grads, q + ".conv1.weight", G, sd[q + ".conv1.weight"].float(), dbias)
-            _Fold(sd, q + ".downsample.1", 1e-5).grads(grads, q + ".downsample.0.weight", G[:, :, 1:2, 1:2].contiguous(),
-                                                        sd[q + ".downsample.0.weight"].float(), dbias)
+            G, _, dy = self._conv_bwd(("stem", i), spec, x_in, dpre, Bi, lane=True)
+            dbias = hip.colsum(dpre, M=Bi * spec.h_out * spec.w_out)
+            self._fold_on_lane(grads, _Fold(sd, q + ".bn1", 1e-5), q + ".conv1.weight", G, sd[q + ".conv1.weight"].float(), dbias,
+                               also=(_Fold(sd, q + ".downsample.1", 1e-5), q + ".downsample.0.weight",
+                                     sd[q + ".downsample.0.weight"].float()))
         dpre = self._relu_bwd(dy, w["S1"])
         self._first_conv(grads, sp + ".conv1.weight", sp + ".bn1", dpre)
         self.col_img = None
