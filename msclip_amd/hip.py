@@ -646,7 +646,7 @@ def dwpool_bwd(dpool, w, dtop, B, H, W, C, k, accumulate=False):
 
 def dwpool_wgrad(dpool, top, B, H, W, C, k):
     """-> fp32 [k*k, C]: gradient of msclip_dwpool's filter table."""
-    S = max(1, min(64, 4096 // (k * k)))
+    S = max(1, min(1024, 4096 // k, B * (H // k) * (W // k)))          # grid (k, S): one block per window row and slab
     part = torch.empty(S, k * k * C, dtype=torch.float32, device=dpool.device)
     _check(lib().msclip_dwpool_wgrad(_p(dpool), dpool.stride(0), _p(top), _p(part), B, H, W, C, k, S, _stream()),
            "msclip_dwpool_wgrad")
@@ -656,7 +656,7 @@ def dwpool_wgrad(dpool, top, B, H, W, C, k):
 def dw3x3_wgrad(dsum, x, B, L, g):
     """-> fp32 [9, C]: gradient of the token-grid depthwise 3x3 filter of msclip_adapter_sum."""
     C = dsum.shape[1]
-    S = max(1, min(64, B))
+    S = max(1, min(256, B))
     part = torch.empty(S, 9 * C, dtype=torch.float32, device=dsum.device)
     _check(lib().msclip_dw3x3_wgrad(_p(dsum), dsum.stride(0), _p(x), x.stride(0), _p(part), B, L, g, C, S, _stream()),
            "msclip_dw3x3_wgrad")

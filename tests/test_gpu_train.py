@@ -306,6 +306,37 @@ def test_relu_dwpool_dw3x3_backward_kernels(gpu_device):
     assert rel(got.t().reshape(D, 1, 3, 3), wb.grad) <= 1e-5
 
 
+@pytest.mark.parametrize("B,g,k,C", [(5, 7, 16, 48), (4, 7, 2, 384), (6, 7, 1, 768), (2, 14, 8, 48), (3, 5, 3, 200)])
+def test_dwpool_wgrad_geometries(gpu_device, B, g, k, C):
+    """msclip_dwpool_wgrad over the adapters' real geometries (k = 16 ... 1, 48 ... 768 channels: several positions side by
+    side per block below 129 channels, several channel passes above 256) against autograd of the strided depthwise conv."""
+    H = g * k
+    top = rnd(B, C, H, H, seed=4).to(BF).float()
+    wd = rnd(C, 1, k, k, seed=5, scale=0.2).requires_grad_(True)
+    dpool = rnd(B, C, g, g, seed=6).to(BF).float()
+    F.conv2d(top, wd, stride=k, groups=C).backward(dpool)
+    top_n = top.permute(0, 2, 3, 1).contiguous().to(BF).view(B * H * H, C)
+    dp_n = dpool.permute(0, 2, 3, 1).contiguous().to(BF).view(B * g * g, C)
+    dw = hip.dwpool_wgrad(dp_n, top_n, B, H, H, C, k)
+    assert rel(dw.t().reshape(C, 1, k, k), wd.grad) <= 1e-5
+    assert torch.equal(dw, hip.dwpool_wgrad(dp_n, top_n, B, H, H, C, k))          # deterministic
+
+
+@pytest.mark.parametrize("B,g,D", [(5, 7, 768), (300, 7, 64), (3, 14, 768), (4, 5, 100), (2, 14, 300)])
+def test_dw3x3_wgrad_geometries(gpu_device, B, g, D):
+    """msclip_dw3x3_wgrad: the row form of the 7 x 7 and 14 x 14 token grids (all nine taps per thread) and the generic
+    form, more samples than slabs, channel counts that are no multiple of the block."""
+    L = g * g + 1
+    x = rnd(B * L, D, seed=7)
+    dsum = rnd(B * L, D, seed=8)
+    wb = rnd(D, 1, 3, 3, seed=9).requires_grad_(True)
+    grid = x.view(B, L, D)[:, 1:].transpose(1, 2).reshape(B, D, g, g)
+    F.conv2d(grid, wb, padding=1, groups=D).backward(dsum.view(B, L, D)[:, 1:].transpose(1, 2).reshape(B, D, g, g))
+    got = hip.dw3x3_wgrad(dsum, x, B, L, g)
+    assert rel(got.t().reshape(D, 1, 3, 3), wb.grad) <= 2e-5
+    assert torch.equal(got, hip.dw3x3_wgrad(dsum, x, B, L, g))
+
+
 @pytest.mark.parametrize("dtype,M,C", [(BF, 5000, 48), (torch.float32, 3000, 768), (BF, 300, 96)])
 def test_batchnorm_train_kernels(gpu_device, dtype, M, C):
     """msclip_bn_stats / _apply / _bwd_reduce / _bwd_dx against autograd of F.batch_norm(training=True)."""
