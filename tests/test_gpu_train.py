@@ -133,6 +133,25 @@ def test_attention_backward(gpu_device, L, causal):
     assert cos > 0.999, cos
 
 
+def _adapter_token_path_case(B, g, Cc, usecls):
+    Lt = g * g + 1
+    xin, tt = rnd(B * Lt, Cc, seed=17), rnd(B * g * g, Cc, seed=18)
+    dww, dwb = rnd(9, Cc, seed=19, scale=0.3), rnd(Cc, seed=20)
+    xa = xin.clone().requires_grad_(True)
+    xv = xa.view(B, Lt, Cc)
+    grid = xv[:, 1:].transpose(1, 2).reshape(B, Cc, g, g)
+    bo = F.conv2d(grid, dww.t().reshape(Cc, 1, 3, 3), dwb, padding=1, groups=Cc).flatten(2).transpose(1, 2)
+    ref_sum = torch.cat([(2 if usecls else 1) * xv[:, :1], bo + tt.view(B, g * g, Cc)], 1).reshape(B * Lt, Cc)
+    out = torch.empty_like(xin)
+    hip.adapter_sum(xin, tt, dww, dwb, out, B, Lt, g, usecls)
+    assert rel(out, ref_sum.detach()) < 1e-5, (B, g, Cc)
+    dsum = rnd(B * Lt, Cc, seed=21)
+    ref_sum.backward(dsum)
+    dxa = torch.empty_like(xin)
+    hip.adapter_dx(dsum, dww, dxa, B, Lt, g, usecls)
+    assert rel(dxa, xa.grad) < 1e-5, (B, g, Cc)
+
+
 def test_l2norm_loss_embed_adapter_adamw(gpu_device):
     # l2norm
     x, dy = rnd(37, 512, seed=11), rnd(37, 512, seed=12)
@@ -163,6 +182,8 @@ def test_l2norm_loss_embed_adapter_adamw(gpu_device):
     ref = torch.zeros(50, 768, device="cuda").index_add_(0, tok.flatten(), dxe)
     assert rel(demb, ref) < 1e-5 and rel(dpos, dxe.view(6, 77, 768).sum(0)) < 1e-5
     # lateral adapter token path (M.py:1763-1777): sum and its input gradient against conv2d autograd
+    for B, g, Cc, usecls in ((3, 7, 768, True), (2, 14, 1100, False), (2, 5, 50, True)):   # 16-byte form, > 1024 channels, 4-byte form
+        _adapter_token_path_case(B, g, Cc, usecls)
     B, g, Cc = 3, 7, 768
     Lt = g * g + 1
     xin, tt = rnd(B * Lt, Cc, seed=17), rnd(B * g * g, Cc, seed=18)
