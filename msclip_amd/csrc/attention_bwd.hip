@@ -23,8 +23,14 @@ namespace {
 
 constexpr int RS = 72;                      // row stride (elements) of the [token][64] images: 144 B, 16-B aligned
 
+// Waves per workgroup of attn_bwd_kernel.  The head's images fill 92-155 KB of LDS, so a CU holds ONE workgroup: with 4
+// waves that is one wave per SIMD -- nothing to overlap the LDS round trips of the 72 three-MFMA tile jobs with, and the six
+// query tiles of a 77-token caption took two rounds with half the waves idle in the second.  Eight waves: two per SIMD,
+// one round (text 522 -> see DESIGN.md s8).
+constexpr int BWD_WAVES = 8;
+
 template <int NT16, bool CAUSAL>            // NT16 = padded length / 16 (4: 64 tokens, 6: 96 tokens)
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+__global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                        const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqkv, int L,
                                                        int H, int ldq, int ldo) {
   constexpr int LP = NT16 * 16, LS = LP + 8;          // padded length, row stride of the [..][token] images
@@ -50,7 +56,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
   const bf16_t* db = dout + row0 * ldo + h * 64;
 
   // ---- load: thread -> (token r, 16-byte chunk c); row-major and transposed images, delta
-  for (int idx = tid; idx < LP * 8; idx += 256) {
+  for (int idx = tid; idx < LP * 8; idx += 64 * BWD_WAVES) {
     const int r = idx >> 3, c = idx & 7;
     uint4 q4 = make_uint4(0, 0, 0, 0), k4 = q4, v4 = q4, d4 = q4, o4 = q4;
     if (r < L) {
@@ -108,7 +114,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
   };
 
   // ---- phase 1: per 16-query tile: S^T, softmax over keys, dP^T, dS^T -> P^T, dS, dS^T in LDS
-  for (int qt = wave; qt < NT16; qt += 4) {
+  for (int qt = wave; qt < NT16; qt += BWD_WAVES) {
     const int query = qt * 16 + r16;
     f32x4 st[NT16];
     float mx = -INFINITY;
@@ -192,7 +198,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
 
   // ---- phase 2: dV^T = dO^T-rows x P^T-rows (over queries), dK^T = Q^T x dS^T (over queries), dQ^T = K^T x dS (over keys)
   bf16_t* gb = dqkv + row0 * ldq + h * 64;
-  for (int t = wave; t < 3 * 4 * NT16; t += 4) {
+  for (int t = wave; t < 3 * 4 * NT16; t += BWD_WAVES) {
     const int which = t / (4 * NT16), rem = t - which * 4 * NT16;
     const int dt = rem / NT16, tt = rem - dt * NT16;            // head-dim tile, token tile
     const bf16_t* pa = which == 0 ? dOT : (which == 1 ? QT : KT);
@@ -220,7 +226,7 @@ int launch_bwd(const void* qkv, const void* o, const void* dout, void* dqkv, int
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     done = true;
   }
-  hipLaunchKernelGGL((attn_bwd_kernel<NT16, CAUSAL>), dim3(nsamples * H), dim3(256), lds, st, (const bf16_t*)qkv,
+  hipLaunchKernelGGL((attn_bwd_kernel<NT16, CAUSAL>), dim3(nsamples * H), dim3(64 * BWD_WAVES), lds, st, (const bf16_t*)qkv,
                      (const bf16_t*)o, (const bf16_t*)dout, (bf16_t*)dqkv, L, H, ldq, ldo);
   return msclip_launch_status();
 }
