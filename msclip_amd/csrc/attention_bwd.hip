@@ -26,7 +26,8 @@ constexpr int RS = 72;                      // row stride (elements) of the [tok
 // Waves per workgroup of attn_bwd_kernel.  The head's images fill 92-155 KB of LDS, so a CU holds ONE workgroup: with 4
 // waves that is one wave per SIMD -- nothing to overlap the LDS round trips of the 72 three-MFMA tile jobs with, and the six
 // query tiles of a 77-token caption took two rounds with half the waves idle in the second.  Eight waves: two per SIMD,
-// one round (text 522 -> see DESIGN.md s8).
+// one round: isolated 195 us (77 tokens, causal) / 130 us (50 tokens) at batch 512; inside the training step, beside the
+// weight-gradient lane, 537 -> 352 us and 303 -> 256 us.
 constexpr int BWD_WAVES = 8;
 
 template <int NT16, bool CAUSAL>            // NT16 = padded length / 16 (4: 64 tokens, 6: 96 tokens)
