@@ -238,18 +238,22 @@ int launch_bwd(const void* qkv, const void* o, const void* dout, void* dqkv, int
 //   resident for the head:  K, V row-major, K^T                                     (87 KB at L = 197)
 //   per query block:        Q, dO rows and their transposes, delta, P^T / dS^T [key][32], dS [32][key]   (66 KB)
 // dQ of a block is complete after the block (it contracts over keys); dV^T and dK^T contract over queries and are
-// accumulated in registers across the blocks (2 * 4 * NT16 tiles of 16 x 16 over 4 waves: 2 * NT16 accumulators per
-// wave) and stored once at the end.  Phase 1 of a block has only two 16-query tiles, so a wave takes (query tile, half
-// of the key tiles) and the two halves exchange the row maximum and the row sum through LDS.
+// accumulated in registers across the blocks (2 * 4 * NT16 tiles of 16 x 16 over the QB_WAVES waves: NT16 accumulators
+// per wave at eight) and stored once at the end.  Phase 1 of a block has only two 16-query tiles, so a wave takes (query
+// tile, one of QB_WAVES / 2 parts of the key tiles) and the parts exchange the row maximum and the row sum through LDS.
 // The key axis is padded to a multiple of 32 (one MFMA k-step) with zero columns in K^T and dS.
 // ------------------------------------------------------------------------------------------------------------
+// Waves per workgroup of the query-blocked kernel: its 153 KB of LDS also mean one workgroup per CU (see BWD_WAVES).
+constexpr int QB_WAVES = 8;
+
 template <int NT16, bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_bwd_qb_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+__global__ __launch_bounds__(64 * QB_WAVES) void attn_bwd_qb_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                           const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqkv, int L,
                                                           int H, int ldq, int ldo) {
   constexpr int LP = NT16 * 16, LPK = (LP + 31) / 32 * 32, LS = LPK + 8;   // padded keys, k-step padded keys, [..][key] stride
   constexpr int QB = 32, QS = QB + 8;                                       // queries per block, [..][query] stride
-  constexpr int NA = 2 * NT16;                                              // dV^T / dK^T accumulator tiles per wave
+  constexpr int NW = QB_WAVES, KH = NW / 2;                                 // waves; key parts of phase 1 (two query tiles x KH)
+  constexpr int NA = (2 * 4 * NT16 + NW - 1) / NW;                          // dV^T / dK^T accumulator tiles per wave
   extern __shared__ __attribute__((aligned(16))) bf16_t sm[];
   bf16_t* K = sm;                                      // [LP][RS]
   bf16_t* V = K + LP * RS;
@@ -262,7 +266,7 @@ __global__ __launch_bounds__(256) void attn_bwd_qb_kernel(const bf16_t* __restri
   bf16_t* dST = PT + LP * QS;
   bf16_t* dS = dST + LP * QS;                          // [QB][LS]
   float* delta = (float*)(dS + QB * LS);               // [QB]
-  float* red = delta + QB;                             // [2 stats][2 key halves][QB]
+  float* red = delta + QB;                             // [2 stats][KH key parts][QB]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -274,7 +278,7 @@ __global__ __launch_bounds__(256) void attn_bwd_qb_kernel(const bf16_t* __restri
   bf16_t* gb = dqkv + row0 * ldq + h * 64;
 
   // ---- resident operands: K, V rows, K^T (zero beyond L, and in the k-step padding columns)
-  for (int idx = tid; idx < LP * 8; idx += 256) {
+  for (int idx = tid; idx < LP * 8; idx += 64 * NW) {
     const int r = idx >> 3, c = idx & 7;
     uint4 k4 = make_uint4(0, 0, 0, 0), v4 = k4;
     if (r < L) {
@@ -292,8 +296,8 @@ __global__ __launch_bounds__(256) void attn_bwd_qb_kernel(const bf16_t* __restri
   }
   if constexpr (LPK > LP) {
     constexpr int PADC = LPK - LP;
-    for (int idx = tid; idx < 64 * PADC; idx += 256) KT[(idx / PADC) * LS + LP + idx % PADC] = 0;
-    for (int idx = tid; idx < QB * PADC; idx += 256) dS[(idx / PADC) * LS + LP + idx % PADC] = 0;
+    for (int idx = tid; idx < 64 * PADC; idx += 64 * NW) KT[(idx / PADC) * LS + LP + idx % PADC] = 0;
+    for (int idx = tid; idx < QB * PADC; idx += 64 * NW) dS[(idx / PADC) * LS + LP + idx % PADC] = 0;
   }
 
   const int r16 = lane & 15, quad = lane >> 4;
@@ -318,13 +322,13 @@ __global__ __launch_bounds__(256) void attn_bwd_qb_kernel(const bf16_t* __restri
   f32x4 acc[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  constexpr int NK0 = (NT16 + 1) / 2;                  // key tiles of half 0
-  const int qt = wave & 1, kh = wave >> 1;             // phase 1: this wave's query tile of the block and key half
-  const int kt0 = kh ? NK0 : 0, kt1 = kh ? NT16 : NK0;
+  constexpr int NK0 = (NT16 + KH - 1) / KH;            // key tiles per part (the last part may be short)
+  const int qt = wave & 1, kh = wave >> 1;             // phase 1: this wave's query tile of the block and key part
+  const int kt0 = kh * NK0, kt1 = kt0 + NK0 < NT16 ? kt0 + NK0 : NT16;
 
   for (int q0 = 0; q0 < L; q0 += QB) {
     __syncthreads();                                   // previous block's phase 2 is done with the block buffers
-    {
+    if (tid < QB * 8) {
       const int r = tid >> 3, c = tid & 7, q = q0 + r;
       uint4 q4 = make_uint4(0, 0, 0, 0), d4 = q4, o4 = q4;
       if (q < L) {
@@ -378,7 +382,9 @@ __global__ __launch_bounds__(256) void attn_bwd_qb_kernel(const bf16_t* __restri
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       if (quad == 0) red[kh * QB + qi] = mx;
       __syncthreads();
-      mx = fmaxf(red[qi], red[QB + qi]);
+      mx = red[qi];
+#pragma unroll
+      for (int p = 1; p < KH; ++p) mx = fmaxf(mx, red[p * QB + qi]);
       if (mx == -INFINITY) mx = 0.f;                   // padded query row: every key masked
       float sum = 0.f;
 #pragma unroll
@@ -392,9 +398,11 @@ __global__ __launch_bounds__(256) void attn_bwd_qb_kernel(const bf16_t* __restri
         }
       sum += __shfl_xor(sum, 16, 64);
       sum += __shfl_xor(sum, 32, 64);
-      if (quad == 0) red[2 * QB + kh * QB + qi] = sum;
+      if (quad == 0) red[(KH + kh) * QB + qi] = sum;
       __syncthreads();
-      sum = red[2 * QB + qi] + red[3 * QB + qi];
+      sum = red[KH * QB + qi];
+#pragma unroll
+      for (int p = 1; p < KH; ++p) sum += red[(KH + p) * QB + qi];
       const float inv = sum > 0.f ? 1.f / sum : 0.f;
       const float dl = delta[qi];
 #pragma unroll
@@ -423,12 +431,14 @@ __global__ __launch_bounds__(256) void attn_bwd_qb_kernel(const bf16_t* __restri
     // ---- phase 2: dV^T += dO^T . P^T, dK^T += Q^T . dS^T over the block's 32 queries (one k-step); dQ^T of the block
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const int t = wave + 4 * i;                      // < 2 * 4 * NT16
-      const int which = t / (4 * NT16), rem = t - which * 4 * NT16;
-      const int dt = rem / NT16, kt = rem - dt * NT16;
-      acc[i] = mma(acc[i], (which ? QT : dOT) + dt * 16 * QS, QS, (which ? dST : PT) + kt * 16 * QS, QS, K1{});
+      const int t = wave + NW * i;
+      if (t < 2 * 4 * NT16) {
+        const int which = t / (4 * NT16), rem = t - which * 4 * NT16;
+        const int dt = rem / NT16, kt = rem - dt * NT16;
+        acc[i] = mma(acc[i], (which ? QT : dOT) + dt * 16 * QS, QS, (which ? dST : PT) + kt * 16 * QS, QS, K1{});
+      }
     }
-    for (int t = wave; t < 4 * (QB / 16); t += 4) {
+    for (int t = wave; t < 4 * (QB / 16); t += NW) {
       const int dt = t >> 1, tq = t & 1;
       const f32x4 a = mma(f32x4{0.f, 0.f, 0.f, 0.f}, KT + dt * 16 * LS, LS, dS + tq * 16 * LS, LS, KL{});
       const int tok = q0 + tq * 16 + r16;
@@ -443,11 +453,11 @@ __global__ __launch_bounds__(256) void attn_bwd_qb_kernel(const bf16_t* __restri
   // ---- dV^T, dK^T tiles: 4 consecutive head-dim elements per lane and key
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
-    const int t = wave + 4 * i;
+    const int t = wave + NW * i;
     const int which = t / (4 * NT16), rem = t - which * 4 * NT16;
     const int dt = rem / NT16, kt = rem - dt * NT16;
     const int tok = kt * 16 + r16;
-    if (tok < L) {
+    if (t < 2 * 4 * NT16 && tok < L) {
       uint2 u;
       u.x = pack_bf16x2(acc[i][0], acc[i][1]);
       u.y = pack_bf16x2(acc[i][2], acc[i][3]);
@@ -460,14 +470,14 @@ template <int NT16, bool CAUSAL>
 int launch_bwd_qb(const void* qkv, const void* o, const void* dout, void* dqkv, int nsamples, int L, int H, int ldq, int ldo,
                   hipStream_t st) {
   constexpr int LP = NT16 * 16, LPK = (LP + 31) / 32 * 32, LS = LPK + 8, QB = 32, QS = QB + 8;
-  const size_t lds = (size_t)(2 * LP * RS + 64 * LS + 2 * QB * RS + 2 * 64 * QS + 2 * LP * QS + QB * LS) * 2 + 5 * QB * 4;
+  const size_t lds = (size_t)(2 * LP * RS + 64 * LS + 2 * QB * RS + 2 * 64 * QS + 2 * LP * QS + QB * LS) * 2 + (1 + QB_WAVES) * QB * 4;
   static bool done = false;
   if (!done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_qb_kernel<NT16, CAUSAL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     done = true;
   }
-  hipLaunchKernelGGL((attn_bwd_qb_kernel<NT16, CAUSAL>), dim3(nsamples * H), dim3(256), lds, st, (const bf16_t*)qkv,
+  hipLaunchKernelGGL((attn_bwd_qb_kernel<NT16, CAUSAL>), dim3(nsamples * H), dim3(64 * QB_WAVES), lds, st, (const bf16_t*)qkv,
                      (const bf16_t*)o, (const bf16_t*)dout, (bf16_t*)dqkv, L, H, ldq, ldo);
   return msclip_launch_status();
 }

@@ -1,7 +1,7 @@
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from msclip_amd import hip
-for (B, L, causal) in [(512, 50, False), (512, 77, True)]:
+for (B, L, causal) in [(512, 50, False), (512, 77, True), (256, 197, False)]:
     qkv = torch.randn(B * L, 2304, device="cuda").to(torch.bfloat16)
     o = torch.empty(B * L, 768, dtype=torch.bfloat16, device="cuda")
     hip.attention(qkv, o, B, L, 12, causal)
