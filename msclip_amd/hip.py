@@ -522,9 +522,25 @@ def cast_bf16(x, out=None):
 def colsum(x, out=None, M=None, accumulate=False):
     M = x.shape[0] if M is None else M
     N = x.shape[1]
+    assert x.dtype in (torch.float32, torch.bfloat16) and x.stride(-1) == 1
+    if N <= 384 and M >= 65536 and x.stride(0) == N and x.dtype == torch.bfloat16 and not (N % 8):
+        # narrow, long, contiguous (the convolutions' bias sums: 48-384 channels over up to 6.4 M pixels): r consecutive rows
+        # are read as ONE row of r*N columns, so every lane works on full cache lines (1.6 -> 4+ TB/s), and the r partial
+        # vectors are added at the end
+        r = 1
+        while r * 2 * N <= 1536 and M % (r * 2) == 0:
+            r *= 2
+        if r > 1:
+            wide = colsum(x[:M].view(M // r, r * N)).view(r, N).sum(0)
+            if out is None:
+                return wide
+            if accumulate:
+                out += wide
+            else:
+                out.copy_(wide)
+            return out
     if out is None:
         out = torch.empty(N, dtype=torch.float32, device=x.device)
-    assert x.dtype in (torch.float32, torch.bfloat16) and x.stride(-1) == 1
     chunks = 1 if M <= 2048 else min(256, (M + 511) // 512)           # long matrices: row chunks in parallel, then folded
     scratch = torch.empty(chunks, N, dtype=torch.float32, device=x.device) if chunks > 1 else None
     _check(lib().msclip_colsum(_p(x), x.stride(0), int(x.dtype == torch.float32), _p(out), M, N, int(accumulate),

@@ -67,6 +67,14 @@ def test_transpose_cast_colsum_gelu(gpu_device):
         xb = rnd(mm, nn, seed=6, dtype=BF)
         assert rel(hip.colsum(xb), xb.float().sum(0)) < 1e-5, (mm, nn)
         assert torch.equal(hip.colsum(xb), hip.colsum(xb))
+    for mm, nn, take in ((70000 * 4, 48, None), (65536 + 32, 192, 65536), (66000, 384, 65600), (65536 * 2 + 2, 48, None)):
+        xb = rnd(mm, nn, seed=9, dtype=BF)                              # narrow + long: r rows read as one wide row (with row slack)
+        got = hip.colsum(xb, M=take)
+        ref = xb[:take].double().sum(0).float() if take else xb.double().sum(0).float()
+        assert rel(got, ref) < 2e-6, (mm, nn)
+        acc2 = torch.ones(nn, device="cuda")
+        hip.colsum(xb, out=acc2, M=take, accumulate=True)
+        assert rel(acc2, ref + 1) < 2e-6
     part = rnd(7, 65536 + 64, seed=8)                                   # split-K partials: few rows, very wide -> the fold kernel
     assert rel(hip.colsum(part), part.double().sum(0).float()) < 1e-6 and torch.equal(hip.colsum(part), hip.colsum(part))
     acc = torch.ones(768, device="cuda")
