@@ -80,10 +80,22 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
   const int m1 = min(M, m0 + rows_per_chunk);
   float s = 0.f;
   if (n < N) {
-    for (int m = m0 + w; m < m1; m += 4) {
-      if constexpr (sizeof(T) == 2) s += bf16_to_f32(x[(size_t)m * ld + n]);
-      else s += x[(size_t)m * ld + n];
+    auto ld1 = [&](int m) -> float {
+      if constexpr (sizeof(T) == 2) return bf16_to_f32(x[(size_t)m * ld + n]);
+      else return x[(size_t)m * ld + n];
+    };
+    // four rows in flight per wave (independent partial sums, folded in a fixed order): the short matrices this kernel
+    // mostly sees (1024 partial rows of the LayerNorm parameter gradients, split-K partials) are latency-bound
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int m = m0 + w;
+    for (; m + 12 < m1; m += 16) {
+      s0 += ld1(m);
+      s1 += ld1(m + 4);
+      s2 += ld1(m + 8);
+      s3 += ld1(m + 12);
     }
+    for (; m < m1; m += 4) s0 += ld1(m);
+    s = (s0 + s1) + (s2 + s3);
   }
   part[w][threadIdx.x & 63] = s;
   __syncthreads();
