@@ -104,6 +104,13 @@ int msclip_adapter_combine_ln(const float* xin, int ldx, const float* t, int ldt
 int msclip_l2norm(const float* x, int ldx, float* out_f32, int ldf, void* out_bf16, int ldb, int M, int E,
                   void* stream);
 
+/* out[m] = x[src(m)], rows as raw bytes (row_bytes, both leading dimensions and both pointers multiples of 16).
+ * src(m) = row_idx ? row_idx[m] : m*row_mul + row_add.  Moves the rows that are still read after the last block's
+ * attention -- x[:, 0, :] of the image tower (M.py:2685) and the EOT row of every caption (M.py:3057-3060) -- into a compact
+ * matrix, so that the block's out_proj / ln_2 / MLP run on 2 B rows instead of all tokens. */
+int msclip_gather_rows(const void* x, long long ldx_bytes, const int* row_idx, int row_mul, int row_add, void* out,
+                       long long ldo_bytes, int M, int row_bytes, void* stream);
+
 /* Both Cin=3 3x3/s2/p1 convs (stem conv1+bn1+relu, M.py:1993-1995; parallel stage 0, M.py:2260-2273)
  * in one pass over the NCHW image.  w: fp32 [27][2*C1] (BN folded), bias [2*C1]; outputs NHWC bf16. */
 int msclip_stem_conv3x3s2_dual(const void* img, int img_is_bf16, const float* w, const float* bias, void* out_a,

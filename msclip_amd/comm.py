@@ -64,11 +64,8 @@ comm = Comm()
 def _all_gather_rows(t):
     world = comm.world_size
     out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    try:
-        dist.all_gather_into_tensor(out, t.contiguous())
-    except (RuntimeError, NotImplementedError):            # backends without the flat primitive
-        parts = list(out.chunk(world, dim=0))
-        dist.all_gather(parts, t.contiguous())
+    # ncclAllGather on RCCL; gloo implements the flat form too (torch >= 2.0).  No fallback: a failing collective surfaces.
+    dist.all_gather_into_tensor(out, t.contiguous())
     return out
 
 
@@ -142,56 +139,99 @@ def gather_rows_async(t):
     return out, GatherHandle(work, out, side)
 
 
+_ARENA = {}       # (device, bucket_elems) -> [persistent flat fp32 buckets]: allocated once, re-used by every step
+
+
 class GradReducer:
     """Gradient averaging over the data-parallel ranks (what the reference's DDP wrapper does for its trainer), as a few
     large all-reduces that overlap the rest of the backward pass.
 
-    The backward hands over gradients in the order it produces them (last block first).  They are copied into flat fp32
-    buckets of ~`bucket_bytes`; a full bucket is all-reduced asynchronously from the side stream behind an event
-    recorded on the compute stream ("bucket is final"), so RCCL's ring runs under the remaining GEMMs.  Bucket size:
-    xGMI is point-to-point (7 links x ~153 GB/s per GPU) and a ring all-reduce is bound by ONE link's bandwidth, so the
-    collectives should be few and tens of MB each (the ~1 ms ring latency of an 8-GPU node amortised to a few percent),
-    not one per tensor: the 132 M-parameter model makes eight 64 MiB buckets.  finish() waits for every collective and
-    returns views into the averaged buckets under the original names.  World size 1: a pass-through."""
+    The backward hands over gradients in the order it produces them (last block first).  They live in flat fp32 buckets of
+    ~`bucket_bytes` that persist across steps (no per-step allocation): a producer that can write to a given address asks
+    for its slot first (`reserve`) and the gradient is born inside the bucket -- the transformer's weight gradients, ~340 of
+    the model's 530 MB; the remaining tensors are copied in by one multi-tensor copy per bucket.  A full bucket is all-reduced asynchronously from the side stream behind an event recorded on the compute
+    stream ("bucket is final"), so RCCL's ring runs under the remaining GEMMs.  Bucket size: xGMI is point-to-point
+    (7 links x ~153 GB/s per GPU) and a ring all-reduce is bound by ONE link's bandwidth, so the collectives should be few
+    and tens of MB each (the ~1 ms ring latency of an 8-GPU node amortised to a few percent), not one per tensor: the
+    132 M-parameter model makes eight 64 MiB buckets.  finish() waits for every collective and returns views into the
+    averaged buckets under the original names; they stay valid until the next reducer of the same bucket size on this
+    device starts filling its buckets (i.e. until the next backward).  World size 1: a pass-through."""
 
     def __init__(self, bucket_bytes=64 << 20, average=True):
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.average = average
-        self.pending = []            # [(name, tensor)] of the open bucket
-        self.open_elems = 0
-        self.flights = []            # [(flat, work, side, [(name, shape, offset, numel)])]
+        self.flat = None             # the open bucket
+        self.fill = 0                # elements handed out in it
+        self.layout = []             # [(name, shape, offset, numel)] of the open bucket
+        self.copies = []             # [(view, source)] still to be copied into the open bucket
+        self.reserved = {}           # name -> view handed out by reserve() and not yet add()ed
+        self.used = 0                # buckets of the arena taken by this reducer
+        self.flights = []            # [(flat, work, side, layout, keepalive)]
         self.launched = 0            # collectives issued (tests / bench read it)
+
+    def _bucket(self, device, need):
+        """Open bucket with room for `need` elements (a tensor larger than a bucket gets one of its own size)."""
+        if self.flat is not None and self.fill + need > self.flat.numel() and self.fill:
+            self.flush()
+        if self.flat is None:
+            size = max(self.bucket_elems, need)
+            arena = _ARENA.setdefault((device, self.bucket_elems), [])
+            while len(arena) <= self.used:
+                arena.append(None)
+            if arena[self.used] is None or arena[self.used].numel() < size:
+                arena[self.used] = torch.empty(size, dtype=torch.float32, device=device)
+            self.flat, self.fill = arena[self.used], 0
+            self.used += 1
+        return self.flat
+
+    def reserve(self, name, shape, device):
+        """-> an fp32 view of `shape` inside the open bucket for a producer that writes its result in place (None at world
+        size 1).  The producer's add(name, view) must follow before any other gradient is handed over."""
+        if not comm.collectives:
+            return None
+        n = 1
+        for d in shape:
+            n *= int(d)
+        flat = self._bucket(device, n)
+        view = flat[self.fill:self.fill + n].view(tuple(shape))
+        self.reserved[name] = (view, self.fill, n)
+        return view
 
     def add(self, name, grad):
         if not comm.collectives:
             self.flights.append((None, None, None, [(name, grad)], None))
             return
-        self.pending.append((name, grad))
-        self.open_elems += grad.numel()
-        if self.open_elems >= self.bucket_elems:
+        r = self.reserved.pop(name, None)
+        if r is not None and r[0].data_ptr() == grad.data_ptr() and tuple(r[0].shape) == tuple(grad.shape):
+            o, n = r[1], r[2]                                  # born in the bucket: nothing to copy
+        else:
+            n = grad.numel()
+            flat = self._bucket(grad.device, n)
+            o = self.fill
+            self.copies.append((flat[o:o + n], grad.reshape(-1)))
+        self.layout.append((name, tuple(grad.shape), o, n))
+        self.fill = o + n
+        if self.fill >= self.bucket_elems:
             self.flush()
 
     def flush(self):
-        if not self.pending:
+        if self.flat is None or not self.layout:
             return
-        dev = self.pending[0][1].device
-        flat = torch.empty(self.open_elems, dtype=torch.float32, device=dev)
-        layout, o = [], 0
-        for name, g in self.pending:
-            n = g.numel()
-            layout.append((name, tuple(g.shape), o, n))
-            o += n
-        grads = [g for _, g in self.pending]
-        self.pending, self.open_elems = [], 0
+        flat, fill, layout, copies = self.flat, self.fill, self.layout, self.copies
+        self.flat, self.fill, self.layout, self.copies = None, 0, [], []
+        dev = flat.device
+        payload = flat[:fill]
 
         def pack():
-            if all(g.dtype == torch.float32 for g in grads):
-                torch.cat([g.reshape(-1) for g in grads], out=flat)          # batched: a few launches per bucket
-            else:
-                for g, (_, _, o, n) in zip(grads, layout):
-                    flat[o:o + n].copy_(g.reshape(-1))
+            if copies:
+                dsts, srcs = [d for d, _ in copies], [g for _, g in copies]
+                if all(g.dtype == torch.float32 for g in srcs):
+                    torch._foreach_copy_(dsts, srcs)                          # one multi-tensor launch per bucket
+                else:
+                    for d, g in copies:
+                        d.copy_(g)
             if self.average and comm.world_size > 1:
-                flat.mul_(1.0 / comm.world_size)                              # pre-scaled: the reduced sum is the mean
+                payload.mul_(1.0 / comm.world_size)                           # pre-scaled: the reduced sum is the mean
 
         side = None
         if flat.is_cuda:
@@ -208,15 +248,14 @@ class GradReducer:
                 side.wait_stream(lane)
             with torch.cuda.stream(side):
                 pack()
-                work = dist.all_reduce(flat, async_op=True)
-            flat.record_stream(side)
-            for g in grads:
+                work = dist.all_reduce(payload, async_op=True)
+            for _, g in copies:
                 g.record_stream(side)
         else:
             pack()
-            work = dist.all_reduce(flat, async_op=True)
+            work = dist.all_reduce(payload, async_op=True)
         self.launched += 1
-        self.flights.append((flat, work, side, layout, grads))               # grads: alive until the side stream has read them
+        self.flights.append((flat, work, side, layout, [g for _, g in copies]))   # sources: alive until the side stream has read them
 
     def finish(self):
         """-> {name: averaged gradient}; the current stream is ordered behind every collective."""
@@ -229,7 +268,7 @@ class GradReducer:
             try:
                 work.wait()
             except RuntimeError as exc:
-                raise RuntimeError(f"{comm.head} gradient all-reduce of {flat.numel()} elements failed: {exc}") from exc
+                raise RuntimeError(f"{comm.head} gradient all-reduce of a {flat.numel()}-element bucket failed: {exc}") from exc
             if side is not None:
                 torch.cuda.current_stream(flat.device).wait_stream(side)
             for name, shape, o, n in layout:

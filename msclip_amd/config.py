@@ -86,7 +86,8 @@ def default_config():
     c.MODEL = CfgNode({"NAME": "clip_openai_pe_res_v1", "PRETRAINED_MODEL": "", "SPEC": {}})
     # trainer keys the optimizer set-up of the (unreleased) trainer reads (default.py:126-133, 189-190)
     c.TRAIN = CfgNode({"IMAGE_SIZE": [224, 224], "BATCH_SIZE_PER_GPU": 256, "LR": 1e-3, "SCALE_LR": True,
-                       "OPTIMIZER": "sgd", "MOMENTUM": 0.9, "WD": 1e-4, "WITHOUT_WD_LIST": []})
+                       "OPTIMIZER": "sgd", "OPTIMIZER_ARGS": {}, "MOMENTUM": 0.9, "WD": 1e-4, "WITHOUT_WD_LIST": [],
+                       "LR_SCHEDULER": {}})
     c.TEST = CfgNode({"IMAGE_SIZE": [224, 224], "BATCH_SIZE_PER_GPU": 32, "MODEL_FILE": "", "CENTER_CROP": True,
                       "INTERPOLATION": 3})
     c.INPUT = CfgNode({"MEAN": [0.485, 0.456, 0.406], "STD": [0.229, 0.224, 0.225]})  # default.py:84-85

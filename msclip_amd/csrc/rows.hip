@@ -454,3 +454,27 @@ extern "C" int msclip_l2norm(const float* x, int ldx, float* out_f32, int ldf, v
                      (bf16_t*)out_bf16, ldb, M, E);
   return msclip_launch_status();
 }
+
+namespace {
+// out[m] = x[src(m)] as raw bytes (16-byte pieces): the last block's live rows (cls / EOT) moved to a compact matrix.
+__global__ __launch_bounds__(256) void gather_rows_kernel(const char* __restrict__ x, long long ldx_bytes, const int* __restrict__ row_idx,
+                                                          int row_mul, int row_add, char* __restrict__ out, long long ldo_bytes,
+                                                          int M, int pieces) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * WPB + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const size_t src = row_idx ? (size_t)row_idx[m] : (size_t)m * row_mul + row_add;
+  const uint4* s = (const uint4*)(x + src * ldx_bytes);
+  uint4* d = (uint4*)(out + (size_t)m * ldo_bytes);
+  for (int i = lane; i < pieces; i += 64) d[i] = s[i];
+}
+}  // namespace
+
+extern "C" int msclip_gather_rows(const void* x, long long ldx_bytes, const int* row_idx, int row_mul, int row_add, void* out,
+                                  long long ldo_bytes, int M, int row_bytes, void* stream) {
+  if (!x || !out || M <= 0 || row_bytes <= 0 || (row_bytes % 16) || (ldx_bytes % 16) || (ldo_bytes % 16)) return MSCLIP_EINVAL;
+  if (((uintptr_t)x | (uintptr_t)out) & 15) return MSCLIP_EINVAL;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((M + WPB - 1) / WPB), dim3(256), 0, (hipStream_t)stream, (const char*)x, ldx_bytes,
+                     row_idx, row_mul, row_add, (char*)out, ldo_bytes, M, row_bytes / 16);
+  return msclip_launch_status();
+}

@@ -17,6 +17,8 @@ Control flow follows Transformer.forward (M.py:2388-2459): stem -> tokens ->
 for i in 1..11: [parallel stage + lateral adapter before blocks 2,4,6,8,10] ->
 block i; text block 0 is text-only.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -181,16 +183,22 @@ class Engine:
         return self._ls_val
 
     # ------------------------------------------------------------------ workspace
-    def _workspace(self, Bi, Bt):
+    def _workspace(self, Bi, Bt, inference=False):
         key = (Bi, Bt)
         w = self._ws.get(key)
+        if w is not None and inference and w.get("held"):
+            # a training forward's conv maps live in this workspace until its backward has run (train.TrainStep): an
+            # inference call of the same shape in between gets a workspace of its own
+            key = (Bi, Bt, "inference")
+            w = self._ws.get(key)
         if w is not None:
             self._ws[key] = self._ws.pop(key)                  # most recently used last
             return w
         if not torch.cuda.is_current_stream_capturing():
             # keep at most two eager workspaces (e.g. the steady batch and a ragged last batch): a third shape evicts the
             # least recently used one instead of growing without bound (graph captures own theirs)
-            eager = [k for k in self._ws if isinstance(k, tuple) and len(k) == 2 and not self._ws[k].get("pinned")]
+            eager = [k for k in self._ws if isinstance(k, tuple) and len(k) in (2, 3) and k[0] != "graph"
+                     and not self._ws[k].get("pinned") and not self._ws[k].get("held")]
             for k in eager[:-1] if len(eager) >= 2 else []:
                 del self._ws[k]
         dev, D, E = self.dev, self.D, self.E
@@ -229,6 +237,10 @@ class Engine:
             w["eot"] = torch.empty(Bt, dtype=torch.int32, device=dev)
             w["ht"] = buf(Bt, D)
             w["ft_raw"], w["ft"] = buf(Bt, E, dtype=f32), buf(Bt, E, dtype=f32)
+        # compact matrices of the rows that are still read after the last block's attention (cls / EOT rows, _last_block_tail)
+        nc = Bi + Bt
+        w["XC"] = buf(nc, D, dtype=f32)
+        w["AOC"], w["LNC"], w["HIDC"] = buf(nc, D), buf(nc, D), buf(nc, 4 * D)
         if Bi:
             w["fvb"] = buf(Bi, E)                            # bf16 unit features: gather payload / logits operand
         if Bt:
@@ -364,6 +376,9 @@ class Engine:
                 events.append(ev)
         return events
 
+    def lateral_on_last(self):
+        return (self.n_layers - 1) in self.lateral
+
     def _s1(self, w, Bi):
         if "S1" not in w:
             n = Bi * self.h1 * self.h1 * (self.D // 16)
@@ -373,7 +388,34 @@ class Engine:
     def _text_front(self, tok, w, Bt):
         hip.embed_tokens(tok, self.emb, self.tpos, w["X"], w["eot"], w["Mv"])
 
-    def _blocks(self, w, Bi, Bt, taps=None, conv_events=None):
+    def _last_block_tail(self, w, Bi, Bt, vb, tb):
+        """After the last block's attention only x[:, 0, :] of every image (M.py:2685) and the EOT row of every caption
+        (M.py:3057-3060) are read again, and out_proj / ln_2 / c_fc / c_proj are row-wise: they run on those Bi + Bt rows,
+        moved to the compact matrices XC (fp32 stream) / AOC (attention output), instead of on all tokens.  Same results
+        for encode_image / encode_text / forward / the loss; the other rows of X keep their pre-out_proj values."""
+        XC, AOC, LNC, HIDC = w["XC"], w["AOC"], w["LNC"], w["HIDC"]
+        X, AO = w["X"], w["AO"]
+        if Bi:
+            hip.gather_rows(X, XC[:Bi], Bi, row_mul=self.Lv)
+            hip.gather_rows(AO, AOC[:Bi], Bi, row_mul=self.Lv)
+        if Bt:
+            hip.gather_rows(X, XC[Bi:], Bt, row_idx=w["eot"])
+            hip.gather_rows(AO, AOC[Bi:], Bt, row_idx=w["eot"])
+        n = Bi + Bt
+        segs = ([(0, Bi, vb)] if Bi else []) + ([(Bi, n, tb)] if Bt else [])
+        groups = [(0, n, vb["w"])] if len(segs) == 2 and vb["w"] is tb["w"] else [(r0, r1, b["w"]) for r0, r1, b in segs]
+        for r0, r1, bw in groups:
+            hip.gemm(AOC[r0:r1], bw.wo, XC[r0:r1], bias=bw.bo, resid=XC[r0:r1], resid_kind=hip.RESID_F32)
+        if len(segs) == 2:
+            hip.layernorm_split(XC[:n], vb["ln2"].g, vb["ln2"].b, tb["ln2"].g, tb["ln2"].b, Bi, LNC[:n], n)
+        else:
+            for r0, r1, b in segs:
+                hip.layernorm(XC[r0:r1], b["ln2"].g, b["ln2"].b, LNC[r0:r1], r1 - r0)
+        for r0, r1, bw in groups:
+            hip.gemm(LNC[r0:r1], bw.wfc, HIDC[r0:r1], bias=bw.bfc, act=hip.ACT_QUICKGELU)
+            hip.gemm(HIDC[r0:r1], bw.wpr, XC[r0:r1], bias=bw.bpr, resid=XC[r0:r1], resid_kind=hip.RESID_F32)
+
+    def _blocks(self, w, Bi, Bt, taps=None, conv_events=None, compact=False):
         Mv, M = w["Mv"], w["M"]
         X, LNO, QKV, AO, HID = w["X"], w["LNO"], w["QKV"], w["AO"], w["HID"]
         for i in range(self.n_layers):
@@ -422,6 +464,9 @@ class Engine:
                 hip.attention(QKV[:Mv], AO[:Mv], Bi, self.Lv, self.heads, False)
             if tb is not None:
                 hip.attention(QKV[Mv:M], AO[Mv:M], Bt, self.Lt, self.heads, True)
+            if i == self.n_layers - 1 and compact:
+                self._last_block_tail(w, Bi, Bt, vb, tb)
+                continue
             for r0, r1, bw in groups:
                 hip.gemm(AO[r0:r1], bw.wo, X[r0:r1], bias=bw.bo, resid=X[r0:r1], resid_kind=hip.RESID_F32)
             if len(segs) == 2:
@@ -438,28 +483,34 @@ class Engine:
                 if tb is not None:
                     self._tap_tokens(taps, f"tblock{i}", X[Mv:M], Bt, self.Lt)
 
-    def _head_image(self, w, Bi, norm=True):                              # M.py:2685-2690, 2983
-        hip.layernorm(w["X"], self.ln_post.g, self.ln_post.b, w["hv"], Bi, row_mul=self.Lv)
+    def _head_image(self, w, Bi, norm=True, compact=False):               # M.py:2685-2690, 2983
+        if compact:                                                       # cls rows already sit in XC[:Bi] (_last_block_tail)
+            hip.layernorm(w["XC"], self.ln_post.g, self.ln_post.b, w["hv"], Bi)
+        else:
+            hip.layernorm(w["X"], self.ln_post.g, self.ln_post.b, w["hv"], Bi, row_mul=self.Lv)
         hip.gemm(w["hv"], self.w_vproj, w["fv_raw"])
         if norm:
             hip.l2norm(w["fv_raw"], w["fv"], w["fvb"])
 
-    def _head_text(self, w, Bt, norm=True):                               # M.py:3057-3077
-        hip.layernorm(w["X"], self.ln_final.g, self.ln_final.b, w["ht"], Bt, row_idx=w["eot"])
+    def _head_text(self, w, Bt, norm=True, compact=False, Bi=0):          # M.py:3057-3077
+        if compact:                                                       # EOT rows already sit in XC[Bi:]
+            hip.layernorm(w["XC"][Bi:], self.ln_final.g, self.ln_final.b, w["ht"], Bt)
+        else:
+            hip.layernorm(w["X"], self.ln_final.g, self.ln_final.b, w["ht"], Bt, row_idx=w["eot"])
         hip.gemm(w["ht"], self.w_tproj, w["ft_raw"])
         if norm:
             hip.l2norm(w["ft_raw"], w["ft"], w["ftb"])
 
-    def _heads(self, w, Bi, Bt, norm=True, gather=False):
+    def _heads(self, w, Bi, Bt, norm=True, gather=False, compact=False):
         """Projection heads.  With gather=True the image features' all-gather is started as soon as they exist and
         runs on RCCL's stream while the text head computes (returns the gathered operands and the work handles)."""
         allI = allT = wi = wt = None
         if Bi:
-            self._head_image(w, Bi, norm)
+            self._head_image(w, Bi, norm, compact)
             if gather:
                 allI, wi = C.gather_rows_async(w["fvb"])
         if Bt:
-            self._head_text(w, Bt, norm)
+            self._head_text(w, Bt, norm, compact, Bi)
             if gather:
                 allT, wt = C.gather_rows_async(w["ftb"])
         for h in (wi, wt):
@@ -494,19 +545,22 @@ class Engine:
                 self.refresh()
             Bi = img.shape[0] if img is not None else 0
             Bt = tok.shape[0] if tok is not None else 0
-            w = self._workspace(Bi, Bt)
+            w = self._workspace(Bi, Bt, inference=True)
             conv_events = None
             if Bi:
                 self._vision_front(self._check_img(img), w, Bi, taps)
-                # opt-in (MSCLIP_CONV_SIDE_STREAM=1): +1.6 % pairs/s on B/32, +2.2 % on B/16 same-box, but the GEMM launches
-                # it overlaps then measure 11 % longer each -- the per-kernel roofline of the bench stays clean by default
-                if (taps is None and hip.env_flag("MSCLIP_CONV_SIDE_STREAM") and self.lateral == sorted(self.lateral)
+                # default (MSCLIP_CONV_SIDE_STREAM=0 turns it off): +1.6 % pairs/s on B/32, +2.2 % on B/16 same-box.  The GEMM
+                # launches it overlaps measure ~11 % longer each, so bench.py takes its per-kernel roofline from a probe
+                # pass with the inline schedule and reports the overlapped figure beside it.
+                if (taps is None and os.environ.get("MSCLIP_CONV_SIDE_STREAM", "1") != "0" and self.lateral == sorted(self.lateral)
                         and not torch.cuda.is_current_stream_capturing()):
                     conv_events = self._conv_branch_on_side_stream(w, Bi)
             if Bt:
                 self._text_front(self._check_tok(tok), w, Bt)
-            self._blocks(w, Bi, Bt, taps, conv_events)
-            allI, allT = self._heads(w, Bi, Bt, norm, gather)
+            # the last block's row-wise tail on the live rows only (MSCLIP_FULL_LAST_BLOCK=1: every row, as the taps need it)
+            compact = taps is None and not hip.env_flag("MSCLIP_FULL_LAST_BLOCK") and not self.lateral_on_last()
+            self._blocks(w, Bi, Bt, taps, conv_events, compact)
+            allI, allT = self._heads(w, Bi, Bt, norm, gather, compact)
             if gather:
                 w["allI"], w["allT"] = allI, allT
             return w

@@ -19,11 +19,12 @@ import os
 _WGRAD_STREAMS = int(os.environ.get("MSCLIP_WGRAD_STREAMS", "2"))
 
 
-def wgrad(dy_bf, x_bf, M):
+def wgrad(dy_bf, x_bf, M, out=None):
     """dW[N, K] = dY^T @ X over the first M rows of dy_bf [*, N] and x_bf [*, K] (bf16): both operands transposed so the
     token axis is the contiguous K axis of the GEMM (zero-padded).  A weight gradient has few output tiles (9-36 of
     256 x 256) over a very deep contraction (65 024 tokens at batch 512): the contraction is cut into S slices whose
-    GEMMs run concurrently on S side streams into fp32 partials, folded in a fixed order (deterministic)."""
+    GEMMs run concurrently on S side streams into fp32 partials, folded in a fixed order (deterministic).  `out` (fp32
+    [N, K], contiguous): where the gradient is written (a slot of a gradient bucket, comm.GradReducer.reserve)."""
     N, K = dy_bf.shape[1], x_bf.shape[1]
     tiles = ((N + 255) // 256) * ((K + 255) // 256)
     if tiles <= 4:
@@ -32,13 +33,14 @@ def wgrad(dy_bf, x_bf, M):
         t128 = ((N + 127) // 128) * ((K + 127) // 128)
         S = max(1, min(512 // t128, M // 1024))
         Mpad = (M + 64 * S - 1) // (64 * S) * (64 * S)
-        return hip.gemm_splitk(hip.transpose_bf16(dy_bf, M, Mpad), hip.transpose_bf16(x_bf, M, Mpad), S)
+        return hip.gemm_splitk(hip.transpose_bf16(dy_bf, M, Mpad), hip.transpose_bf16(x_bf, M, Mpad), S, out=out)
     S = max(1, min(_WGRAD_STREAMS, 256 // tiles, M // 4096))
     Mpad = (M + 64 * S - 1) // (64 * S) * (64 * S)
     a = hip.transpose_bf16(dy_bf, M, Mpad)
     b = hip.transpose_bf16(x_bf, M, Mpad)
-    if S == 1:
+    if out is None:
         out = torch.empty(N, K, dtype=F32, device=a.device)
+    if S == 1:
         hip.gemm(a, b, out)
         return out
     kc = Mpad // S
@@ -58,7 +60,8 @@ def wgrad(dy_bf, x_bf, M):
     for t in (a, b, part):
         for sidx in range(S):
             t.record_stream(pool[sidx])
-    return hip.colsum(part.view(S, N * K)).view(N, K)
+    hip.colsum(part.view(S, N * K), out=out.view(-1))
+    return out
 
 
 def dgrad(dy_bf, w_t, out=None):
@@ -96,19 +99,19 @@ def _ranks_share_a_gpu():
     return dist.is_available() and dist.is_initialized() and dist.get_backend() == "gloo"
 
 
-def wgrad_async(dy_bf, x_bf, M, post=None):
+def wgrad_async(dy_bf, x_bf, M, post=None, out=None):
     """wgrad(dy_bf, x_bf, M) on the lane stream.  The operands must not be overwritten in place afterwards (their memory
     may be freed: the caching allocator is told about the lane's use); the result may only be touched after join()."""
     dev = dy_bf.device
     if hip.env_flag("MSCLIP_WGRAD_SYNC") or _ranks_share_a_gpu():
-        out = wgrad(dy_bf, x_bf, M)                      # everything on the calling stream (A/B knob; gloo test setups)
+        out = wgrad(dy_bf, x_bf, M, out)                 # everything on the calling stream (A/B knob; gloo test setups)
         return post(out) if post is not None else out
     cur, ln = torch.cuda.current_stream(dev), lane(dev)
     ready = torch.cuda.Event()
     ready.record(cur)
     ln.wait_event(ready)
     with torch.cuda.stream(ln):
-        out = wgrad(dy_bf, x_bf, M)
+        out = wgrad(dy_bf, x_bf, M, out)
         if post is not None:
             out = post(out)
     dy_bf.record_stream(ln)

@@ -17,7 +17,7 @@ INT_MAX = 2 ** 31 - 1
 
 EXPORTS = (
     "msclip_gemm", "msclip_gemm_variant", "msclip_attention", "msclip_layernorm", "msclip_layernorm_split", "msclip_embed_tokens", "msclip_fill_cls",
-    "msclip_adapter_combine_ln", "msclip_l2norm", "msclip_stem_conv3x3s2_dual", "msclip_dwpool",
+    "msclip_adapter_combine_ln", "msclip_l2norm", "msclip_gather_rows", "msclip_stem_conv3x3s2_dual", "msclip_dwpool",
     "msclip_stem_dual_conv3x3s2", "msclip_conv1x1_conv3x3s2", "msclip_convresblock48_s2",
     "msclip_lse_rows", "msclip_clip_loss_partial", "msclip_clip_lse_fused", "msclip_clip_loss_from_partials",
     "msclip_transpose_bf16", "msclip_cast_bf16", "msclip_colsum", "msclip_quickgelu", "msclip_quickgelu_bwd", "msclip_layernorm_bwd",
@@ -85,6 +85,7 @@ def lib():
         L.msclip_fill_cls.argtypes = [vp, vp, vp, ci, ci, ci, ci, vp]
         L.msclip_adapter_combine_ln.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, vp]
         L.msclip_l2norm.argtypes = [vp, ci, vp, ci, vp, ci, ci, ci, vp]
+        L.msclip_gather_rows.argtypes = [vp, ctypes.c_longlong, vp, ci, ci, vp, ctypes.c_longlong, ci, ci, vp]
         L.msclip_stem_conv3x3s2_dual.argtypes = [vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, vp]
         L.msclip_dwpool.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
         L.msclip_stem_dual_conv3x3s2.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
@@ -199,6 +200,16 @@ def off_default_stream(fn):
                 torch.cuda.set_stream(cs)
         return fn(self, *args, **kwargs)
     return wrapped
+
+
+def use_compute_stream(device=None):
+    """Explicit, once-at-start-up form of what off_default_stream does implicitly: make the per-device compute stream the
+    calling thread's current stream (ordered behind whatever the previous current stream has queued).  Returns it."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    cs = compute_stream(device)
+    cs.wait_stream(torch.cuda.current_stream(device))
+    torch.cuda.set_stream(cs)
+    return cs
 
 
 def priority_stream(device, urgent):
@@ -346,7 +357,7 @@ def gemm(x, w, out, *, M=None, bias=None, resid=None, resid_kind=0, act=0, alpha
     return out
 
 
-def gemm_splitk(x, w, slices):
+def gemm_splitk(x, w, slices, out=None):
     """fp32 [N_x, N_w] = x @ w^T for two K-contiguous bf16 operands x [M, K], w [N, K] with a deep K (K % (64*slices) == 0):
     `slices` K ranges contracted by separate workgroup rows of ONE launch into fp32 partials, folded in a fixed order."""
     _bf16(x)
@@ -359,7 +370,12 @@ def gemm_splitk(x, w, slices):
     d.M, d.N, d.K, d.ldx, d.ldw, d.ldo = M, N, K, x.stride(0), w.stride(0), N
     d.out_kind, d.alpha, d.rpg = 1, 1.0, INT_MAX
     _check(lib().msclip_gemm_splitk(ctypes.byref(d), slices, _stream()), "msclip_gemm_splitk")
-    return colsum(part).view(M, N) if slices > 1 else part.view(M, N)
+    if slices > 1:
+        return colsum(part, out=out.view(-1) if out is not None else None).view(M, N)
+    if out is not None:
+        out.view(-1).copy_(part.view(-1))
+        return out
+    return part.view(M, N)
 
 
 _TAPS = {}
@@ -427,6 +443,15 @@ def l2norm(x, out_f32=None, out_bf16=None):
     _check(lib().msclip_l2norm(_p(x), x.stride(0), _p(out_f32), out_f32.stride(0) if out_f32 is not None else 0,
                                _p(out_bf16), out_bf16.stride(0) if out_bf16 is not None else 0, M, E, _stream()),
            "msclip_l2norm")
+
+
+def gather_rows(x, out, M, *, row_idx=None, row_mul=1, row_add=0):
+    """out[m] = x[row_idx[m] or m*row_mul + row_add] for 2-D tensors of one dtype (rows moved as 16-byte pieces)."""
+    assert x.dtype == out.dtype and x.stride(-1) == 1 and out.stride(-1) == 1 and x.shape[1] == out.shape[1]
+    es = x.element_size()
+    _check(lib().msclip_gather_rows(_p(x), x.stride(0) * es, _p(row_idx), row_mul, row_add, _p(out), out.stride(0) * es, M,
+                                    x.shape[1] * es, _stream()), "msclip_gather_rows")
+    return out
 
 
 def stem_conv_dual(img, w, bias, out_a, out_b):

@@ -39,11 +39,20 @@ _LEAVES = ("attn.in_proj_weight", "attn.in_proj_bias", "attn.out_proj.weight", "
 class TrainStep:
     """forward + backward (+ AdamW step) for one local batch.  `engine` is the model's msclip_amd.engine.Engine."""
 
-    def __init__(self, model, lr=None, lr_share=None, wd=0.2, wd_share=None, betas=(0.9, 0.98), eps=1e-6, bn="frozen"):
+    def __init__(self, model, lr=None, lr_share=None, wd=0.05, wd_share=None, betas=(0.9, 0.999), eps=1e-8, bn="frozen",
+                 without_wd=("bn", "bias", "ln")):
         """bn = "frozen": BatchNorm with its running statistics (gamma / beta trained; the inference kernels' folded
         form); bn = "batch": train-mode BatchNorm -- per-GPU batch statistics in the forward, their backward, running
-        statistics updated with momentum 0.1 (what the reference's modules do in train())."""
+        statistics updated with momentum 0.1 (what the reference's modules do in train()).
+        Optimizer defaults are the reference yaml's (experiments/model/b32.yaml:39-50: adamW, WD 0.05, no decay on
+        'bn' / 'bias' / 'ln'; no OPTIMIZER_ARGS => torch.optim.AdamW's betas (0.9, 0.999) and eps 1e-8).
+        `without_wd`: TRAIN.WITHOUT_WD_LIST keywords ('bn': BatchNorm parameters, 'ln': LayerNorm parameters, 'bias': names
+        ending in 'bias')."""
         assert bn in ("frozen", "batch")
+        unknown = set(without_wd) - {"bn", "bias", "ln", "gn", "dw"}
+        if unknown:
+            raise NotImplementedError(f"TRAIN.WITHOUT_WD_LIST keywords {sorted(unknown)} are not implemented")
+        self.without_wd = tuple(without_wd)
         self.bn = bn
         self.convbn = None
         self.model = model
@@ -71,11 +80,18 @@ class TrainStep:
             assert Bi == Bt, "a training step needs image-text pairs"
             if e.Lv > 208 or e.Lt > 208:
                 raise NotImplementedError("msclip_attention_bwd covers sequences up to 208 tokens")
+            prev = getattr(self, "saved", None)
+            if prev is not None:                                   # a forward that was never differentiated: release its maps
+                prev["w"].pop("held", None)
+                self.saved = None
             w = e._workspace(Bi, Bt)
+            # the conv side's maps (w["stem"], w["par"], w["pool"], S1, P0) are read again by backward(): until then the
+            # engine's inference entry points (an eval / logging call of the same shape in between) get another workspace
+            w["held"] = True
             Mv, M = w["Mv"], w["M"]
             D = e.D
             X = w["X"]
-            sv = dict(Bi=Bi, Bt=Bt, Mv=Mv, M=M, layers=[None] * e.n_layers, tok=e._check_tok(tok))
+            sv = dict(Bi=Bi, Bt=Bt, Mv=Mv, M=M, layers=[None] * e.n_layers, tok=e._check_tok(tok), w=w)
             # ---- fronts (the conv side's maps stay in the workspace `w`; the tokens in front of ln_pre are cloned)
             keep = []
             sv["img"] = e._check_img(img)
@@ -226,6 +242,10 @@ class TrainStep:
                     dict.__setitem__(self, k, v)
                     if reducer is not None:
                         reducer.add(k, v)
+
+                def slot(self, k, shape):
+                    """Where gradient k should be written if it can be born inside its all-reduce bucket (else None)."""
+                    return reducer.reserve(k, shape, dev) if reducer is not None else None
             grads = _Grads()
             # ---- contrastive head: dL/dS blocks of this rank's image rows and caption rows
             npad = (n + 63) // 64 * 64
@@ -255,7 +275,7 @@ class TrainStep:
                 conv = self.convbn                       # holds the raw conv outputs / batch statistics of this forward
             else:
                 conv = ConvSideBackward(self)
-                conv.begin(sv["img"], e._workspace(Bi, Bt), Bi)
+                conv.begin(sv["img"], sv["w"], Bi)
 
             def head(feat_raw, dfeat, hrow, w_proj, ln, key_proj, key_ln, row_idx=None, row_mul=1):
                 dfr = torch.empty_like(feat_raw)
@@ -286,7 +306,8 @@ class TrainStep:
                 dlno = torch.empty(M, D, dtype=F32, device=dev)
                 for r0, r1, bw in groups:
                     p = names[id(bw)]
-                    grads[p + ".mlp.c_proj.weight"] = _wgrad_async(dY[r0:r1], hid[r0:r1], r1 - r0)
+                    k = p + ".mlp.c_proj.weight"
+                    grads[k] = _wgrad_async(dY[r0:r1], hid[r0:r1], r1 - r0, out=grads.slot(k, (D, 4 * D)))
                     grads[p + ".mlp.c_proj.bias"] = hip.colsum(dX[r0:r1])
                     _dgrad(dY[r0:r1], bw.wpr.t().contiguous(), dhid[r0:r1])
                 del hid
@@ -294,7 +315,8 @@ class TrainStep:
                 hip.quickgelu_bwd(L["h"][r_lo:M], dhid[r_lo:M], dh[r_lo:M])
                 for r0, r1, bw in groups:
                     p = names[id(bw)]
-                    grads[p + ".mlp.c_fc.weight"] = _wgrad_async(dh[r0:r1], L["lno2"][r0:r1], r1 - r0)
+                    k = p + ".mlp.c_fc.weight"
+                    grads[k] = _wgrad_async(dh[r0:r1], L["lno2"][r0:r1], r1 - r0, out=grads.slot(k, (4 * D, D)))
                     grads[p + ".mlp.c_fc.bias"] = gradgemm.on_lane(lambda a=dh[r0:r1]: hip.colsum(a), dh)
                     _dgrad(dh[r0:r1], bw.wfc.t().contiguous(), dlno[r0:r1])
                 del dhid, dh
@@ -309,7 +331,8 @@ class TrainStep:
                 dqkv = torch.zeros(M, 3 * D, dtype=BF, device=dev)
                 for r0, r1, bw in groups:
                     p = names[id(bw)]
-                    grads[p + ".attn.out_proj.weight"] = _wgrad_async(dY2[r0:r1], L["ao"][r0:r1], r1 - r0)
+                    k = p + ".attn.out_proj.weight"
+                    grads[k] = _wgrad_async(dY2[r0:r1], L["ao"][r0:r1], r1 - r0, out=grads.slot(k, (D, D)))
                     grads[p + ".attn.out_proj.bias"] = hip.colsum(dX[r0:r1])
                     _dgrad(dY2[r0:r1], bw.wo.t().contiguous(), dao[r0:r1])
                 if e.vblk[i] is not None:
@@ -320,13 +343,14 @@ class TrainStep:
                     def unscale_q(g):                                                          # packed q rows = 64^-0.5 * W_q
                         g[:D] *= 0.125
                         return g
-                    gw = _wgrad_async(dqkv[r0:r1], L["lno1"][r0:r1], r1 - r0, post=unscale_q)   # wrt the PACKED weight
+                    k = p + ".attn.in_proj_weight"
+                    grads[k] = _wgrad_async(dqkv[r0:r1], L["lno1"][r0:r1], r1 - r0, post=unscale_q,
+                                            out=grads.slot(k, (3 * D, D)))              # wrt the PACKED weight, scaled back
                     def bias_q(a=dqkv[r0:r1]):
                         g = hip.colsum(a)
                         g[:D] *= 0.125
                         return g
-                    gb = gradgemm.on_lane(bias_q, dqkv)
-                    grads[p + ".attn.in_proj_weight"], grads[p + ".attn.in_proj_bias"] = gw, gb
+                    grads[p + ".attn.in_proj_bias"] = gradgemm.on_lane(bias_q, dqkv)
                     _dgrad(dqkv[r0:r1], bw.wqkv.t().contiguous(), dlno[r0:r1])
                 for r0, r1, b in segs:
                     pre = f"visual.transformer.resblocks.{i}" if b is e.vblk[i] else f"transformer.resblocks.{i}"
@@ -367,35 +391,22 @@ class TrainStep:
             grads["visual.class_embedding"] = dvpos[0].clone()
             conv.stem(grads, dtok)
             gradgemm.join(dev)                                   # the weight gradients queued on the lane stream
+            sv["w"].pop("held", None)
             self.saved = None
             return reducer.finish() if reducer is not None else dict(grads)
 
     # ------------------------------------------------------------------ optimizer
     def param_groups(self):
-        """(name, parameter, lr, weight_decay) for every parameter of the slice, following the reference's yaml: shared
-        attention / MLP tensors use CUSTOM.LR_SHARE / WD_SHARE, everything else TRAIN.LR / TRAIN.WD; no decay for names
-        containing 'bn' / 'bias' / 'ln' (TRAIN.WITHOUT_WD_LIST) and for model.no_weight_decay()."""
-        m = self.model
-        shared = set()
-        if m.share_from_layer is not None:
-            for i in range(max(m.share_from_layer, 1), len(m.visual.transformer.resblocks)):
-                shared.update(f"visual.transformer.resblocks.{i}.{leaf}" for leaf in _LEAVES)
-        nodecay = set(m.no_weight_decay())
-        params = dict(m.named_parameters())
-        out = []
-        for k, p in params.items():
-            lr = self.lr_share if (k in shared and self.lr_share is not None) else self.lr
-            wd = self.wd_share if (k in shared and self.wd_share is not None) else self.wd
-            if any(t in k for t in ("bn", "bias", "ln")) or k.split(".")[-1] in nodecay or k in nodecay:
-                wd = 0.0
-            out.append((k, p, lr, wd))
-        return out
+        """(name, parameter, lr, weight_decay) for every parameter: module-level param_groups() with this step's settings."""
+        return param_groups(self.model, self.lr, self.lr_share, self.wd, self.wd_share, self.without_wd)
 
     @hip.off_default_stream
     def step(self, grads, world_average=False):
         """AdamW on the module's fp32 parameters (msclip_adamw), then the engine re-packs its bf16 copies.  backward()
         already returns rank-averaged gradients; world_average=True averages here instead, tensor by tensor (for
         gradients produced with backward(reduce=False))."""
+        if self.lr is None:
+            raise ValueError("TrainStep.step() needs a learning rate: TrainStep(model, lr=...) or train.from_config(model, config)")
         self.steps += 1
         with torch.no_grad():
             items = []
@@ -413,6 +424,35 @@ class TrainStep:
                 items.append((p.data.view(-1), g.view(-1), st[0].view(-1), st[1].view(-1), lr, wd))
             hip.adamw_multi(items, self.betas[0], self.betas[1], self.eps, self.steps)     # in-place: refresh below re-packs
         self.eng.refresh(force=True)
+
+
+def param_groups(model, lr, lr_share, wd, wd_share, without_wd=("bn", "bias", "ln")):
+    """(name, parameter, lr, weight_decay) for every parameter of the slice, following the reference's yaml: shared
+    attention / MLP tensors use CUSTOM.LR_SHARE / WD_SHARE, everything else TRAIN.LR / TRAIN.WD; no decay for the
+    TRAIN.WITHOUT_WD_LIST keywords -- 'bn' = parameters of BatchNorm modules (whatever their name: the stem's
+    `downsample.1` is one), 'ln' = parameters of LayerNorm modules, 'bias' = names ending in 'bias' -- and for every
+    name that CONTAINS an entry of model.no_weight_decay() (M.py:2950-2956: 'positional_embedding' covers
+    visual.positional_embedding, 'token_embedding' covers token_embedding.weight)."""
+    m = model
+    norm_params = set()
+    for mod in m.modules():
+        if (isinstance(mod, torch.nn.BatchNorm2d) and "bn" in without_wd) or \
+           (isinstance(mod, torch.nn.LayerNorm) and "ln" in without_wd):
+            norm_params.update(id(p) for p in mod.parameters(recurse=False))
+    shared = set()
+    if m.share_from_layer is not None:
+        for i in range(max(m.share_from_layer, 1), len(m.visual.transformer.resblocks)):
+            shared.update(f"visual.transformer.resblocks.{i}.{leaf}" for leaf in _LEAVES)
+    nodecay = set(m.no_weight_decay())
+    params = dict(m.named_parameters())
+    out = []
+    for k, p in params.items():
+        plr = lr_share if (k in shared and lr_share is not None) else lr
+        pwd = wd_share if (k in shared and wd_share is not None) else wd
+        if id(p) in norm_params or ("bias" in without_wd and k.endswith("bias")) or any(t in k for t in nodecay):
+            pwd = 0.0
+        out.append((k, p, plr, pwd))
+    return out
 
 
 def _optimizer_state_dict(ts):
@@ -462,8 +502,27 @@ def resume_checkpoint(model, ts, path):
 
 
 def from_config(model, config, bn="batch"):
-    """TrainStep with the reference yaml's optimizer hyper-parameters (TRAIN.LR / WD, CUSTOM.LR_SHARE / WD_SHARE).
+    """TrainStep with the reference yaml's optimizer block (experiments/model/b32.yaml:32-52 + the msclips overlays):
+    TRAIN.OPTIMIZER (only adamW is implemented: anything else raises), TRAIN.LR / WD / WITHOUT_WD_LIST, TRAIN.OPTIMIZER_ARGS
+    (betas / eps; absent => torch.optim.AdamW's defaults, what `AdamW(params, lr=..., weight_decay=..., **{})` gives),
+    CUSTOM.LR_SHARE / WD_SHARE for the modality-shared tensors (already scaled with the world size by update_config,
+    lib/config/default.py:299-304).
     bn = "batch" (default): train-mode BatchNorm as the reference's modules run in train(); "frozen": running statistics."""
+    return TrainStep(model, bn=bn, **optimizer_settings(config))
+
+
+def optimizer_settings(config):
+    """The optimizer block of a reference config as TrainStep keyword arguments (needs no GPU)."""
     tr, cu = config.TRAIN, config.CUSTOM
-    return TrainStep(model, lr=tr.get("LR", 1e-4), lr_share=cu.get("LR_SHARE", None) or None, wd=tr.get("WD", 0.2),
-                     wd_share=cu.get("WD_SHARE", None) or None, bn=bn)
+    opt = str(tr.get("OPTIMIZER", "sgd"))
+    if opt.lower() != "adamw":
+        raise NotImplementedError(f"TRAIN.OPTIMIZER = {opt!r}: this build implements adamW only (the released MS-CLIP-S "
+                                  "configs' optimizer, experiments/model/b32.yaml:48)")
+    oa = dict(tr.get("OPTIMIZER_ARGS", None) or {})
+    betas = tuple(oa.pop("betas", (0.9, 0.999)))
+    eps = float(oa.pop("eps", 1e-8))
+    oa.pop("lr", None)
+    if oa:
+        raise NotImplementedError(f"TRAIN.OPTIMIZER_ARGS keys {sorted(oa)} are not implemented")
+    return dict(lr=tr.LR, lr_share=cu.get("LR_SHARE", None) or None, wd=tr.WD, wd_share=cu.get("WD_SHARE", None) or None,
+                betas=betas, eps=eps, without_wd=tuple(tr.get("WITHOUT_WD_LIST", ()) or ()))

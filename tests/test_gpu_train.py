@@ -545,9 +545,11 @@ def test_adamw_step_with_reference_param_groups_lowers_the_loss(gpu_device, bn):
     ts = train.from_config(m, cfg, bn=bn)
     assert train.from_config(m, cfg).bn == "batch"                     # the reference's train() semantics are the default
     groups = {k: (lr, wd) for k, _, lr, wd in ts.param_groups()}
-    assert groups["visual.transformer.resblocks.3.mlp.c_fc.weight"] == (cfg.CUSTOM.LR_SHARE, cfg.CUSTOM.WD_SHARE)
+    # literals of the reference yaml (experiments/model/b32.yaml:34,49; b32-yfcc-msclips.yaml:13-14), world size 1
+    assert groups["visual.transformer.resblocks.3.mlp.c_fc.weight"] == (0.0001, 0.2)
     assert groups["visual.transformer.resblocks.3.mlp.c_fc.bias"][1] == 0.0                # WITHOUT_WD_LIST: bias
-    assert groups["transformer.resblocks.0.mlp.c_fc.weight"] == (cfg.TRAIN.LR, cfg.TRAIN.get("WD", 0.2))
+    assert groups["transformer.resblocks.0.mlp.c_fc.weight"] == (0.0001, 0.05)
+    assert ts.betas == (0.9, 0.999) and ts.eps == 1e-8                                      # no OPTIMIZER_ARGS: torch defaults
     assert groups["visual.transformer.resblocks.3.ln_1.weight"][1] == 0.0 and groups["logit_scale"][1] == 0.0
     img, tok = synth.synth_images(8, seed=51).cuda(), synth.synth_tokens(8, seed=52).cuda()
     ts.lr, ts.lr_share = 2e-5, 2e-5

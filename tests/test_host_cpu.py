@@ -299,3 +299,41 @@ def test_update_config_follows_reference_naming_and_lr_scaling():
     c = named_config("b32-yfcc-msclips")
     assert c.NAME == "b32-yfcc-msclips"
     assert abs(c.TRAIN.LR - 1e-4) < 1e-12 and abs(c.CUSTOM.LR_SHARE - 1e-4) < 1e-12 and c.CUSTOM.WD_SHARE == 0.2
+
+
+def test_optimizer_block_matches_reference_yaml_literals():
+    """TRAIN / CUSTOM optimizer keys as the reference yaml spells them (experiments/model/b32.yaml:32-52,
+    b32-yfcc-msclips.yaml:13-14).  Expected values are LITERALS copied from those files, not read back from the config."""
+    from msclip_amd import train
+    from msclip_amd.clip_openai_pe_res_v1 import get_clip_model
+    cfg = named_config("b32-yfcc-msclips")
+    assert cfg.TRAIN.OPTIMIZER == "adamW" and cfg.TRAIN.WD == 0.05 and cfg.TRAIN.LR == 0.0001
+    assert list(cfg.TRAIN.WITHOUT_WD_LIST) == ["bn", "bias", "ln"]
+    assert cfg.TRAIN.LR_SCHEDULER.METHOD == "timm" and cfg.TRAIN.LR_SCHEDULER.ARGS.sched == "cosine"
+    assert cfg.TRAIN.LR_SCHEDULER.ARGS.warmup_epochs == 5 and cfg.TRAIN.LR_SCHEDULER.ARGS.min_lr == 0.00001
+    st = train.optimizer_settings(cfg)
+    assert st == dict(lr=0.0001, lr_share=0.0001, wd=0.05, wd_share=0.2, betas=(0.9, 0.999), eps=1e-8,
+                      without_wd=("bn", "bias", "ln"))
+    m = get_clip_model(cfg)
+    g = {k: (lr, wd) for k, _, lr, wd in train.param_groups(m, st["lr"], st["lr_share"], st["wd"], st["wd_share"], st["without_wd"])}
+    assert g["visual.transformer.resblocks.3.mlp.c_fc.weight"] == (0.0001, 0.2)          # shared: LR_SHARE / WD_SHARE
+    assert g["visual.transformer.resblocks.3.attn.in_proj_weight"] == (0.0001, 0.2)
+    assert g["transformer.resblocks.0.mlp.c_fc.weight"] == (0.0001, 0.05)                # text block 0 is not shared: TRAIN.WD
+    assert g["visual.transformer.resblocks.0.conv1.weight"] == (0.0001, 0.05)
+    assert g["visual.proj"] == (0.0001, 0.05) and g["text_projection"] == (0.0001, 0.05)
+    for k in ("visual.transformer.resblocks.3.mlp.c_fc.bias", "visual.transformer.resblocks.3.attn.in_proj_bias",     # 'bias'
+              "visual.transformer.resblocks.3.ln_1.weight", "ln_final.weight", "visual.ln_pre.weight",                # 'ln'
+              "visual.transformer.parallel_lateral_adapter.2.ln_adapt.weight",
+              "visual.transformer.resblocks.0.bn1.weight",                                                            # 'bn'
+              "visual.transformer.resblocks.0.resnet_stage.conv_1.downsample.1.weight",        # a BatchNorm without 'bn' in its name
+              "visual.transformer.parallel_branch_v.2.resnet_stage.conv_0.residual_bn.weight",
+              "visual.positional_embedding", "positional_embedding", "token_embedding.weight", "logit_scale"):        # no_weight_decay()
+        assert g[k][1] == 0.0, k
+    # an optimizer this build does not implement is an error, not a silent AdamW
+    sgd = named_config("b32-yfcc-msclips", ["TRAIN.OPTIMIZER", "sgd"])
+    with pytest.raises(NotImplementedError):
+        train.optimizer_settings(sgd)
+    # OPTIMIZER_ARGS override betas / eps
+    oa = named_config("b32-yfcc-msclips", ["TRAIN.OPTIMIZER_ARGS.betas", "[0.9, 0.98]", "TRAIN.OPTIMIZER_ARGS.eps", "1e-6"])
+    st2 = train.optimizer_settings(oa)
+    assert st2["betas"] == (0.9, 0.98) and st2["eps"] == 1e-6

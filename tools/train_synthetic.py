@@ -53,12 +53,17 @@ def main():
         losses.append(float(loss))
         if rank == 0:
             print(f"step {step:3d}  loss {losses[-1]:.4f}  {1e3 * (time.perf_counter() - t0):7.1f} ms", flush=True)
+    # the inference-path loss gathers features and all-reduces its partial sums (GATHER_TENSORS: True): EVERY rank runs it,
+    # rank 0 prints it
+    inf = float(model.contrastive_loss(*data[0]))
+    ok = all(l == l for l in losses) and min(losses[-args.nbatches:]) < losses[0]
     if rank == 0:
-        inf = float(model.contrastive_loss(*data[0]))
         print(f"first batch through the inference path (running statistics): loss {inf:.4f}")
-        ok = all(l == l for l in losses) and min(losses[-args.nbatches:]) < losses[0]
         print("OK" if ok else "FAILED: the loss did not fall")
-        sys.exit(0 if ok else 1)
+    if torch.distributed.is_initialized():
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    sys.exit(0 if ok else 1)
 
 
 if __name__ == "__main__":
