@@ -654,3 +654,19 @@ def test_gemm_w4_against_the_pingpong_kernel_on_the_qkv_shape(gpu_device):
     assert d.max().item() <= 3e-2 * max(1.0, ref.float().abs().max().item())
     rows = torch.tensor([0, 255, 256, 32767, 65023], device="cuda")
     close(out[rows], x[rows].float() @ w.float().t() + b, 3e-2, 1.5e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gather_rows(gpu_device, dtype):
+    """msclip_gather_rows: rows by stride or by index, fp32 and bf16, out of a wider parent (row-range / column views)."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1000, 768, generator=g).to(dtype).cuda()
+    out = torch.zeros(20, 768, dtype=dtype, device="cuda")
+    hip.gather_rows(x, out, 20, row_mul=50)
+    assert torch.equal(out, x[::50])
+    idx = torch.randint(0, 1000, (33,), generator=g).to(torch.int32).cuda()
+    out2 = torch.zeros(40, 768, dtype=dtype, device="cuda")
+    hip.gather_rows(x, out2[3:36], 33, row_idx=idx)
+    assert torch.equal(out2[3:36], x[idx.long()]) and not out2[:3].any() and not out2[36:].any()
+    hip.gather_rows(x, out[:10], 10, row_mul=7, row_add=2)
+    assert torch.equal(out[:10], x[2::7][:10])

@@ -545,19 +545,69 @@ def test_bench_multi_rank_plumbing_on_one_gpu(gpu_device, extra):
     assert len(lines) == 1, r.stdout[-2000:]
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["warmup"] == 1 and rec["value"] > 0 and rec["scaling"] == "weak"
-    assert rec["config"]["global_batch"] == 16 and rec["config"]["rccl_ranks"] == 2 and "TEST_ONLY" in rec["config"]
+    assert rec["config"]["global_batch"] == 16 and rec["config"]["gloo_ranks"] == 2 and "rccl_ranks" not in rec["config"]
+    assert "TEST_ONLY" in rec["config"]
     assert abs(rec["value"] - 16 * 2 / (rec["ms_per_step"] * 2e-3)) / rec["value"] < 1e-2      # whole-job pairs / max-rank time
 
 
 def test_conv_branch_on_side_stream_is_bitwise_the_inline_schedule(gpu_device, monkeypatch):
-    """MSCLIP_CONV_SIDE_STREAM=1 issues the parallel convolutional branch + the adapters' top-down halves on a side HIP
-    stream (they depend on the image only) with one event per adapter: same kernels, same data, bitwise the same result."""
+    """The default schedule issues the parallel convolutional branch + the adapters' top-down halves on a side HIP stream
+    (they depend on the image only) with one event per adapter; MSCLIP_CONV_SIDE_STREAM=0 runs them inline: same kernels,
+    same data, bitwise the same result."""
     m = model_for("b32-yfcc-msclips")
     img = synth.synth_images(6, seed=91).cuda()
     tok = synth.synth_tokens(6, seed=92).cuda()
+    monkeypatch.setenv("MSCLIP_CONV_SIDE_STREAM", "0")
     a = m.engine().run(img, tok)
     fi, ft = a["fv"].clone(), a["ft"].clone()
-    monkeypatch.setenv("MSCLIP_CONV_SIDE_STREAM", "1")
+    monkeypatch.delenv("MSCLIP_CONV_SIDE_STREAM")
     for _ in range(3):                                                 # back-to-back steps: buffer reuse across steps
         b = m.engine().run(img, tok)
         assert torch.equal(b["fv"], fi) and torch.equal(b["ft"], ft)
+
+
+@pytest.mark.parametrize("name", ["b32-yfcc-msclips", "b16-yfcc-msclips"])
+def test_last_block_on_live_rows_only_matches_the_full_block(gpu_device, monkeypatch, name):
+    """After the last block's attention only x[:, 0] (M.py:2685) and the EOT rows (M.py:3057-3060) are read: the engine runs
+    out_proj / ln_2 / c_fc / c_proj of that block on those rows (engine._last_block_tail).  Features, logits and loss against
+    the same engine with MSCLIP_FULL_LAST_BLOCK=1 (every row, the reference's schedule): same arithmetic per row, another
+    GEMM tile shape -- agreement to bf16-operand rounding of the MLP hidden (far inside the stated tolerance, which both
+    also meet against the reference goldens in test_against_reference_golden).  Also image-only / text-only calls and
+    ragged batch sizes (compact row ranges)."""
+    m = model_for(name)
+    img = synth.synth_images(5, seed=71).cuda()
+    tok = synth.synth_tokens(7, seed=72, min_len=1, max_len=75).cuda()
+    monkeypatch.setenv("MSCLIP_FULL_LAST_BLOCK", "1")
+    fi, ft = m.encode_image(img), m.encode_text(tok)
+    lg = m(img, tok[:5])
+    loss = m.contrastive_loss(img, tok[:5]).item()
+    monkeypatch.delenv("MSCLIP_FULL_LAST_BLOCK")
+    ci, ct = m.encode_image(img), m.encode_text(tok)
+    assert (ci - fi).abs().max().item() <= 1e-3 and (ct - ft).abs().max().item() <= 1e-3
+    assert torch.nn.functional.cosine_similarity(ci, fi, dim=-1).min().item() >= 0.99999
+    assert torch.nn.functional.cosine_similarity(ct, ft, dim=-1).min().item() >= 0.99999
+    assert (m(img, tok[:5]) - lg).abs().max().item() <= 2e-2
+    assert abs(m.contrastive_loss(img, tok[:5]).item() - loss) <= 5e-3
+    w = m.engine().run(img, tok[:5])
+    assert w["XC"].shape[0] == 10 and torch.isfinite(w["XC"]).all()
+
+
+def test_inference_between_training_forward_and_backward_keeps_the_gradients(gpu_device):
+    """The conv side's activations the backward reads live in the engine's workspace: an inference call of the same shape
+    between TrainStep.forward and .backward (an eval / logging call) must not overwrite them -- it gets its own workspace."""
+    from msclip_amd import train
+    m = get_clip_model(named_config("b32-yfcc-msclips"))
+    m.load_state_dict(synth_sd("b32-yfcc-msclips"), strict=True)
+    m = m.cuda().eval()
+    img, tok = synth.synth_images(4, seed=81).cuda(), synth.synth_tokens(4, seed=82).cuda()
+    other = synth.synth_images(4, seed=83).cuda()
+    ts = train.TrainStep(m, lr=1e-4, bn="frozen")
+    ts.forward(img, tok)
+    ref = ts.backward()
+    ts.forward(img, tok)
+    m.contrastive_loss(other, tok)                    # same shape, other pixels: would overwrite the stem / branch maps
+    m.encode_image(other)
+    got = ts.backward()
+    for k in ("visual.transformer.resblocks.0.conv1.weight", "visual.transformer.parallel_branch_v.2.resnet_stage.conv_0.conv2.weight",
+              "visual.transformer.parallel_lateral_adapter.1.top2bottom_pw_conv.conv.weight"):
+        assert torch.equal(ref[k], got[k]), k

@@ -112,6 +112,11 @@ def test_entry_points_reject_bad_arguments_before_launching():
     assert lib.msclip_adapter_combine_ln(p, 768, p, 768, p, p, p, p, p, 768, 1, 50, 7, 768, 1, 1e-12, None) == EINVAL   # in place
     lib.msclip_dwpool.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
     assert lib.msclip_dwpool(p, p, p, 48, 1, 112, 112, 48, 5, None) == EINVAL                      # H % k
+    lib.msclip_gather_rows.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                       ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    assert lib.msclip_gather_rows(None, 3072, None, 1, 0, p, 3072, 4, 3072, None) == EINVAL        # null input
+    assert lib.msclip_gather_rows(p, 3072, None, 1, 0, p, 3072, 4, 3000, None) == EINVAL           # rows not 16-byte pieces
+    assert lib.msclip_gather_rows(p, 3072, None, 1, 0, p, 3072, 0, 3072, None) == EINVAL           # no rows
     lib.msclip_gemm.argtypes = [vp, vp]
     assert lib.msclip_gemm(None, None) == EINVAL
 

@@ -219,10 +219,32 @@ def _gather_worker(rank, world, path):
     dist.destroy_process_group()
 
 
+def refresh_prompt_features(name="b32-yfcc-msclips"):
+    """`--prompt-features-only`: re-capture ONLY prompt_text_features of <name>.zeroshot.npz from the reference for the
+    current tests/golden/tokenizer.json (after prompts were added there); every other array of the file is kept."""
+    model, _ = R.build_reference_model(name)
+    model.load_state_dict(synth.synth_state_dict(synth.schema_of(model), seed=SEED), strict=True)
+    model.eval()
+    g = json.load(open(os.path.join(OUT, "tokenizer.json")))
+    from dataset.languages.simple_tokenizer import SimpleTokenizer
+    assert SimpleTokenizer()(g["prompts"]).tolist() == g["ids"]
+    with torch.no_grad():
+        ft = model.encode_text(torch.tensor(g["ids"], dtype=torch.long))
+    path = os.path.join(OUT, f"{name}.zeroshot.npz")
+    z = dict(np.load(path))
+    n_old = z["prompt_text_features"].shape[0]
+    assert np.abs(ft.numpy()[:n_old] - z["prompt_text_features"]).max() < 1e-5      # the old prompts still give the old rows
+    z["prompt_text_features"] = ft.numpy()
+    np.savez_compressed(path, **z)
+    print(f"{name}: prompt_text_features {n_old} -> {ft.shape[0]} rows")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    if "--prompt-features-only" in sys.argv:
+        return refresh_prompt_features()
     for name in ("b32-yfcc-msclips", "b16-yfcc-msclips"):
         model, _ = run_config(name)
         if name.startswith("b32"):

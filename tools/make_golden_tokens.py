@@ -12,7 +12,12 @@ templates = ["a photo of a {}.", "a bad photo of a {}.", "itap of the {}.", "a {
 prompts = [t.format(c) for c in classes[:3] for t in templates[:3]] + [
     "A photo of   many  words, with punctuation!!! and numbers 12345 & symbols #@$", "it's the dog's ball; they're here, we've won",
     "&lt;html&gt; &amp;amp; entities", "naïve café façade ünïcödé", "", "x", " ".join(["word"] * 100),
-    "a photo of a " + classes[5] + ".", "a photo of a " + classes[6] + ".", "UPPER lower MiXeD"]
+    "a photo of a " + classes[5] + ".", "a photo of a " + classes[6] + ".", "UPPER lower MiXeD",
+    # well-formed NFC text that ftfy.fix_text leaves unchanged (the reference's cleaner, simple_tokenizer.py:54-57; the
+    # build container has no ftfy, its stub is the identity): byte-level BPE of multi-byte UTF-8
+    "ein Foto von einem Bären im Schnee, ganz nah", "una foto de un niño pequeño en la playa", "фото собаки на пляже",
+    "Ελληνικά γράμματα σε μια πινακίδα", "犬の写真、公園で", "صورة قطة صغيرة", "crème brûlée & piña colada",
+    "a photo of a dog 😀 smiling", "Smørrebrød på Åre ÆØÅ"]
 ids = tok(prompts).tolist()
 json.dump({"prompts": prompts, "ids": ids, "sot": tok.get_sot_token(), "eot": tok.get_eot_token()},
           open(os.path.join(ROOT, "tests", "golden", "tokenizer.json"), "w"))

@@ -67,24 +67,37 @@ def compare(ref, got):
     return res
 
 
-def main():
-    torch.manual_seed(0)
-    torch.set_num_threads(16)
-    R.ensure_single_rank_group()
-    name = "b32-yfcc-msclips"
+def run_model(name, cases):
     model, _ = R.build_reference_model(name)
     model.load_state_dict(synth.synth_state_dict(synth.schema_of(model), seed=SEED), strict=True)
     for p in model.parameters():
         p.requires_grad_(True)
-    out = {"what": "reference gradients under torch.autocast(bfloat16) against the same reference in fp32 (CPU), metrics of "
-                   "tests/test_gpu_train.py", "model": name}
-    for tag, batch, train_bn in (("eval_bn_batch4", 4, False), ("train_bn_batch16", 16, True)):
+    out = {}
+    for tag, batch, train_bn in cases:
         img, tok = synth.synth_images(batch, seed=SEED), synth.synth_tokens(batch, seed=SEED + 1)
         l32, g32 = grads(model, img, tok, train_bn, False)
         l16, g16 = grads(model, img, tok, train_bn, True)
         out[tag] = dict(loss_fp32=l32, loss_bf16=l16, **compare(g32, g16))
-        print(tag, json.dumps(out[tag], indent=1))
-    with open(os.path.join(ROOT, "tests", "golden", "ref_bf16_gradient_deviation.json"), "w") as f:
+        print(name, tag, json.dumps(out[tag], indent=1), flush=True)
+    return out
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(16)
+    R.ensure_single_rank_group()
+    path = os.path.join(ROOT, "tests", "golden", "ref_bf16_gradient_deviation.json")
+    only = sys.argv[1] if len(sys.argv) > 1 else None
+    out = json.load(open(path)) if only and os.path.exists(path) else {}
+    out["what"] = ("reference gradients under torch.autocast(bfloat16) against the same reference in fp32 (CPU), metrics of "
+                   "tests/test_gpu_train.py; top-level tags: b32-yfcc-msclips, other models under their name; the batches "
+                   "are the gradient fixtures' (tools/make_golden.py::grads_fixture)")
+    out["model"] = "b32-yfcc-msclips"
+    if only in (None, "b32-yfcc-msclips"):
+        out.update(run_model("b32-yfcc-msclips", (("eval_bn_batch4", 4, False), ("train_bn_batch16", 16, True))))
+    if only in (None, "b16-yfcc-msclips"):
+        out["b16-yfcc-msclips"] = run_model("b16-yfcc-msclips", (("eval_bn_batch4", 4, False), ("train_bn_batch8", 8, True)))
+    with open(path, "w") as f:
         json.dump(out, f, indent=1)
 
 
