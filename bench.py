@@ -188,6 +188,7 @@ def main():
                     t.normal_()
     probe = None if args.no_probe else hip.KernelProbe()
     hip.set_gemm_probe(DOMINANT["variant"], probe)
+    hip.set_gemm_probe("pp2", probe)                   # the same launches when the two-workgroups-per-CU kernel takes them
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -195,6 +196,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     hip.set_gemm_probe(DOMINANT["variant"], None)
+    hip.set_gemm_probe("pp2", None)
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if grouped:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -211,6 +213,7 @@ def main():
         step()
         probe = hip.KernelProbe()
         hip.set_gemm_probe(DOMINANT["variant"], probe)
+        hip.set_gemm_probe("pp2", probe)
         fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -218,6 +221,7 @@ def main():
         fence()
         dt_probe = time.perf_counter() - t0
         hip.set_gemm_probe(DOMINANT["variant"], None)
+        hip.set_gemm_probe("pp2", None)
         del os.environ["MSCLIP_CONV_SIDE_STREAM"]
 
     if rank == 0:

@@ -19,9 +19,11 @@
 //  * MFMA operands are swapped (A = W rows, B = X rows): a lane owns 4 consecutive output
 //    columns of one row; interior tiles are transposed through the just-consumed LDS slab
 //    so every global store / residual load instruction moves full 128-byte lines.
+#include <stdlib.h>
 #include <type_traits>
 #include "common.h"
 #include "../../include/msclip_hip.h"
+#include "gemm_epilogue.h"
 
 namespace {
 
@@ -34,7 +36,6 @@ struct RowSrc {          // per staged X row (conv mode)
 };
 
 
-constexpr int STG_BYTES = 4096;   // per-wave staging: 32 rows x 128 B, 16-byte chunks XOR-swizzled by (row & 7)
 
 // Interior tile (no guards): transpose the wave's TM x TN 32x32 accumulator tiles through LDS so that 8 lanes
 // cover one 128-byte line of one output row; bias/QuickGELU are applied in accumulator layout, the residual
@@ -136,309 +137,6 @@ __device__ __forceinline__ void epilogue_interior(f32x16 (&acc)[TN][TM], const m
             o.y = pack_bf16x2(v.z, v.w);
             *(uint2*)((bf16_t*)a.out + row * a.ldo + n) = o;
           }
-        }
-      }
-    }
-  }
-}
-
-// Interior tile of the ping-pong kernel.  Every 32x32 accumulator tile goes through the wave's 4-KiB staging block
-// as fp32 (32 rows x 128 B, chunks XOR-swizzled by row & 7) so that afterwards lane (srow = lane/8, sch = lane%8)
-// owns 4 consecutive columns sch*4.. of rows srow, srow+8, ...: bias (8 registers, loaded at tile start by the
-// caller), activation and residual are applied there.  Nothing is loaded in the epilogue for the bf16 outputs
-// (a load would sit behind the in-flight LDS-DMA of the next tile: the VM counter retires in order), the fp32
-// residual rows of two 32-row blocks are requested up front and re-requested two blocks ahead.
-// fp32 outputs leave as full 128-byte lines, bf16 outputs as aligned 64-byte half lines.
-// RK / ACT / OUTK: resid_kind / act / out_kind known at compile time, or -1 = read the descriptor.
-// The staging traffic is inline asm: a compiler-visible LDS access after an LDS-DMA gets an s_waitcnt vmcnt(0) in front of
-// it (the DMA is a pending LDS write), i.e. a stall on the next tile's in-flight prefetch.  A wave's DS instructions
-// execute in issue order, so block b+1 may be written over block b as soon as b's reads are issued.
-__device__ __forceinline__ void stg_write16(unsigned addr, f32x4 v) {
-  asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
-}
-template <int OFF>
-__device__ __forceinline__ f32x4 stg_read16(unsigned addr) {
-  f32x4 v;
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
-  return v;
-}
-
-// Global-memory accesses of these epilogues carry address space 1 explicitly: a store through a generic pointer "may
-// alias LDS", and while it is pending the compiler guards the K loop's fragment reads with s_waitcnt vmcnt(0).
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-__device__ __forceinline__ void st_global(void* p, float4 v) { *(AS1 f32x4*)p = f32x4{v.x, v.y, v.z, v.w}; }
-__device__ __forceinline__ void st_global(void* p, uint4 v) { *(AS1 u32x4*)p = u32x4{v.x, v.y, v.z, v.w}; }
-__device__ __forceinline__ void st_global(void* p, uint2 v) { *(AS1 u32x2*)p = u32x2{v.x, v.y}; }
-__device__ __forceinline__ float4 ld_global_f4(const void* p) {
-  const f32x4 v = *(const AS1 f32x4*)p;
-  return make_float4(v[0], v[1], v[2], v[3]);
-}
-__device__ __forceinline__ uint2 ld_global_u2(const void* p) {
-  const u32x2 v = *(const AS1 u32x2*)p;
-  return make_uint2(v[0], v[1]);
-}
-
-template <int TM, int TN, int RK, int ACT, int OUTK>
-__device__ __forceinline__ void epilogue_rows(f32x4 (&acc)[2 * TN][2 * TM], const msclip_gemm_desc& a, unsigned stg,
-                                              int mw0, int nw0, int lane, const float4 (&bias4)[TN]) {
-  // accumulator layout of v_mfma_f32_16x16x32 with swapped operands: acc[ni][mi][r] = C[mi*16 + lane%16][ni*16 + 4*(lane/16) + r]
-  const int r16 = lane & 15, quad = lane >> 4;
-  const int srow = lane >> 3, sch = lane & 7;
-  const unsigned wr = stg + r16 * 128;
-  const int wsw = r16 & 7;
-  const unsigned rd = stg + srow * 128 + ((sch ^ srow) << 4);    // + i * 1024 for rows i*8 + srow
-  const int rk = RK >= 0 ? RK : a.resid_kind;
-  const int act = ACT >= 0 ? ACT : a.act;
-  const int outk = OUTK >= 0 ? OUTK : a.out_kind;
-  constexpr int RAHEAD = 2;                                      // residual blocks (32 x 32) requested ahead
-  float4 rv[RAHEAD][4];                                          // raw: fp32 x 4, or bf16 x 4 in .x/.y (unpacked at use)
-  auto load_res = [&](int b, float4 (&dst)[4]) {
-    const int tm = b / TN, tn = b % TN;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const size_t row = (size_t)(mw0 + tm * 32 + i * 8 + srow);
-      const int n = nw0 + tn * 32 + sch * 4;
-      if (n >= a.N) {
-        dst[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      } else if (rk == 1) {
-        dst[i] = ld_global_f4((const float*)a.resid + row * a.ldr + n);
-      } else {
-        const uint2 u = ld_global_u2((const bf16_t*)a.resid + row * a.ldr + n);
-        dst[i] = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), 0.f, 0.f);
-      }
-    }
-  };
-  if (rk) {
-#pragma unroll
-    for (int b = 0; b < RAHEAD; ++b) load_res(b, rv[b]);
-  }
-  f32x4 x[2][4];
-  auto stage = [&](int b, f32x4 (&dst)[4]) {                     // block b = tm * TN + tn -> LDS -> row-major registers
-    const int tm = b / TN, tn = b % TN;
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {                              // the four 16 x 16 tiles of this 32 x 32 block
-        const f32x4 v = acc[2 * tn + ni][2 * tm + mi] * a.alpha;
-        stg_write16(wr + mi * 2048 + (((ni * 4 + quad) ^ wsw) << 4), v);
-      }
-    dst[0] = stg_read16<0>(rd); dst[1] = stg_read16<1024>(rd);
-    dst[2] = stg_read16<2048>(rd); dst[3] = stg_read16<3072>(rd);
-  };
-  stage(0, x[0]);
-#pragma unroll
-  for (int b = 0; b < TM * TN; ++b) {
-    const int tm = b / TN, tn = b % TN;
-    f32x4(&xb)[4] = x[b & 1];
-    if (b + 1 < TM * TN) {
-      stage(b + 1, x[(b + 1) & 1]);
-      asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(xb[0]), "+v"(xb[1]), "+v"(xb[2]), "+v"(xb[3])::"memory");
-    } else {
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xb[0]), "+v"(xb[1]), "+v"(xb[2]), "+v"(xb[3])::"memory");
-    }
-    const int n = nw0 + tn * 32 + sch * 4;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float4 v = make_float4(xb[i][0] + bias4[tn].x, xb[i][1] + bias4[tn].y, xb[i][2] + bias4[tn].z, xb[i][3] + bias4[tn].w);
-      if (act == 1) {
-        v.x = v.x / (1.f + __expf(-1.702f * v.x)); v.y = v.y / (1.f + __expf(-1.702f * v.y));
-        v.z = v.z / (1.f + __expf(-1.702f * v.z)); v.w = v.w / (1.f + __expf(-1.702f * v.w));
-      }
-      if (rk == 1) {
-        const float4 r = rv[b % RAHEAD][i];
-        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-      } else if (rk) {
-        const unsigned ux = __float_as_uint(rv[b % RAHEAD][i].x), uy = __float_as_uint(rv[b % RAHEAD][i].y);
-        v.x += __uint_as_float(ux << 16); v.y += __uint_as_float(ux & 0xffff0000u);
-        v.z += __uint_as_float(uy << 16); v.w += __uint_as_float(uy & 0xffff0000u);
-      }
-      if (act == 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      const size_t row = (size_t)(mw0 + tm * 32 + i * 8 + srow);
-      if (n >= a.N) {
-      } else if (outk == 1) {
-        st_global((float*)a.out + row * a.ldo + n, v);
-      } else {
-        uint2 o;
-        o.x = pack_bf16x2(v.x, v.y);
-        o.y = pack_bf16x2(v.z, v.w);
-        st_global((bf16_t*)a.out + row * a.ldo + n, o);
-      }
-    }
-    if (rk && b + RAHEAD < TM * TN) load_res(b + RAHEAD, rv[b % RAHEAD]);
-  }
-}
-
-// bf16 outputs without a residual (QKV, c_fc).  The staged fp32 epilogue above is bound by its LDS-write and
-// store-instruction issue (8-byte stores, 16-byte LDS writes), so here bias and activation are applied in the
-// accumulator layout, the tile is packed to bf16 BEFORE staging (8-byte LDS writes, half the bytes) and a whole
-// 32-row x 64-column block of the wave is staged at once: the read-back hands every lane 16 bytes and a store
-// instruction writes 8 full 128-byte lines.  The wave's 64 bias values live in ONE register (lane j: column j,
-// requested at tile start) and reach the accumulator layout through v_readlane.
-__device__ __forceinline__ void stg_write8(unsigned addr, unsigned lo, unsigned hi) {
-  u32x2 v = {lo, hi};
-  asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
-}
-template <int OFF>
-__device__ __forceinline__ u32x4 stg_read16u(unsigned addr) {
-  u32x4 v;
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
-  return v;
-}
-
-template <int TM, int TN, int ACT>
-__device__ __forceinline__ void epilogue_pack16(f32x4 (&acc)[2 * TN][2 * TM], const msclip_gemm_desc& a, unsigned stg,
-                                                int mw0, int nw0, int lane, float bcol) {
-  static_assert(TN == 2, "64 bf16 columns = one 128-byte staged row");
-  const int r16 = lane & 15, quad = lane >> 4;
-  const int srow = lane >> 3, sch = lane & 7;
-  const unsigned wr = stg + r16 * 128 + (quad & 1) * 8;
-  const int wsw = r16 & 7;
-  const unsigned rd = stg + srow * 128 + ((sch ^ srow) << 4);    // + i * 1024 for rows i*8 + srow
-  // bias of columns ni*16 + 4*quad + r: lane c of bcol holds column c's bias; 16 lane-crossbar reads (ds_bpermute
-  // touches no LDS memory).  The v_readlane + three-way select this replaces compiled into divergent control flow
-  // (one exec-mask branch nest per value: ~400 scalar-heavy instructions, 3-4 k cycles per tile in the phase trace).
-  float b[4][4];
-  {
-    const int src = __float_as_int(bcol), base = quad * 16;
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        b[ni][r] = __int_as_float(__builtin_amdgcn_ds_bpermute(base + (ni * 16 + r) * 4, src));
-    // all sixteen are back before the first hand-counted LDS operation of the staging code is issued
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][2]), "+v"(b[0][3]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[1][2]),
-                   "+v"(b[1][3]), "+v"(b[2][0]), "+v"(b[2][1]), "+v"(b[2][2]), "+v"(b[2][3]), "+v"(b[3][0]), "+v"(b[3][1]),
-                   "+v"(b[3][2]), "+v"(b[3][3])
-                 :
-                 : "memory");
-  }
-  // Block tm = 32 rows x 64 columns of the wave.  Its values are computed in four QUARTERS (8 values + one 16-byte staging
-  // write pair each); between the quarters of block tm+1 the four 1-KiB store instructions of block tm go out one at a
-  // time instead of back to back.  Measured same-box against the back-to-back form: QKV 226.6 -> 223.1 us, c_fc unchanged
-  // (334 -> 333 us), ping-pong launches in the model step 187.0 -> 185.6 us on average.  (The probe builds say the c_fc
-  // epilogue is 57 us of activation math + staging and 32 us that vanish without the stores, nearly additive; spreading
-  // the stores within the epilogue does not recover them.  Nor are they lost in the next tile's counted waits: a timing-only
-  // probe whose K-tile 1 / K-tile 2 waits also leave the epilogue's stores in flight -- wrong results, -DPP_RELAX2 / 3 of
-  // tools/probes/gemm_pp_probes.hip -- runs every shape within noise of the shipped kernel.  What is left is the CU's
-  // store path itself: ~128 KiB per tile at ~16 B/clk is ~8 k cycles during which all eight waves sit in the epilogue and
-  // nobody issues MFMAs.)
-  u32x4 x[2][4];
-  auto quarter = [&](int tm, int q) {                            // (mi, ni) = (q >> 1, 2 * (q & 1) + {0, 1})
-    const int mi = q >> 1;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int ni = 2 * (q & 1) + h;
-      float v[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        v[e] = acc[ni][2 * tm + mi][e] * a.alpha + b[ni][e];
-        if (ACT == 1) v[e] = v[e] / (1.f + __expf(-1.702f * v[e]));
-        if (ACT == 2) v[e] = fmaxf(v[e], 0.f);
-      }
-      stg_write8(wr + mi * 2048 + (((ni * 2 + (quad >> 1)) ^ wsw) << 4), pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-    }
-  };
-  auto fetch = [&](u32x4 (&dst)[4]) {                            // the staged block, 4 rows of 128 B per lane group
-    dst[0] = stg_read16u<0>(rd); dst[1] = stg_read16u<1024>(rd);
-    dst[2] = stg_read16u<2048>(rd); dst[3] = stg_read16u<3072>(rd);
-  };
-  auto store = [&](int tm, int i, const u32x4& v) {
-    const int n = nw0 + sch * 8;
-    const size_t row = (size_t)(mw0 + tm * 32 + i * 8 + srow);
-    // non-temporal: the tile leaves faster (QKV 262 -> 249 us, c_fc 378 -> 365 us; +0.7 % on the step), the fp32
-    // stream of out_proj / c_proj stays cacheable for the LayerNorm that follows
-    if (n < a.N) __builtin_nontemporal_store(v, (AS1 u32x4*)((bf16_t*)a.out + row * a.ldo + n));
-  };
-#pragma unroll
-  for (int q = 0; q < 4; ++q) quarter(0, q);
-  fetch(x[0]);
-#pragma unroll
-  for (int tm = 0; tm < TM; ++tm) {
-    u32x4(&xb)[4] = x[tm & 1];
-    if (tm + 1 < TM) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        quarter(tm + 1, q);
-        // the 4 reads of block tm are older than the 2 staging writes of this quarter (LDS returns in order)
-        if (q == 0) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(xb[0]), "+v"(xb[1]), "+v"(xb[2]), "+v"(xb[3])::"memory");
-        __builtin_amdgcn_sched_barrier(0);
-        store(tm, q, xb[q]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      fetch(x[(tm + 1) & 1]);
-    } else {
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xb[0]), "+v"(xb[1]), "+v"(xb[2]), "+v"(xb[3])::"memory");
-#pragma unroll
-      for (int i = 0; i < 4; ++i) store(tm, i, xb[i]);
-    }
-  }
-}
-
-// Edge tiles of the ping-pong kernel (rows past M, ragged N, unaligned leading dimensions): guarded, straight from the
-// 16 x 16 accumulator layout (lane owns row mi*16 + lane%16, columns ni*16 + 4*(lane/16) + 0..3).
-template <int TM, int TN>
-__device__ __forceinline__ void epilogue_generic16(f32x4 (&acc)[2 * TN][2 * TM], const msclip_gemm_desc& a, bool vec,
-                                                   int mw0, int nw0, int lane) {
-  const int r16 = lane & 15, quad = lane >> 4;
-  const float* __restrict__ bias = a.bias;
-#pragma unroll
-  for (int mi = 0; mi < 2 * TM; ++mi) {
-    const int m = mw0 + mi * 16 + r16;
-    if (m >= a.M) continue;
-    const int grp = m / a.rpg;
-    const size_t orow = (size_t)(m + grp * a.radd + a.roff);       // row scatter (stem -> token rows)
-    size_t row = (size_t)m;                                         // residual row
-    if (a.resid_kind == 3) row = (size_t)(m - grp * a.rpg + a.roff);
-#pragma unroll
-    for (int ni = 0; ni < 2 * TN; ++ni) {
-      const int n = nw0 + ni * 16 + quad * 4;
-      if (n >= a.N) continue;
-      float v[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][j] * a.alpha;
-      if (vec) {
-        if (bias) {
-          const float4 bv = *(const float4*)(bias + n);
-          v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-        }
-        if (a.act == 1) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = v[j] / (1.f + __expf(-1.702f * v[j]));
-        }
-        if (a.resid_kind == 1 || a.resid_kind == 3) {
-          const float4 rv = *(const float4*)((const float*)a.resid + row * a.ldr + n);
-          v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
-        } else if (a.resid_kind == 2) {
-          const uint2 rv = *(const uint2*)((const bf16_t*)a.resid + row * a.ldr + n);
-          v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
-          v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
-        }
-        if (a.act == 2) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-        }
-        if (a.out_kind == 1) {
-          *(float4*)((float*)a.out + orow * a.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-          uint2 o;
-          o.x = pack_bf16x2(v[0], v[1]);
-          o.y = pack_bf16x2(v[2], v[3]);
-          *(uint2*)((bf16_t*)a.out + orow * a.ldo + n) = o;
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (n + j >= a.N) break;
-          float y = v[j];
-          if (bias) y += bias[n + j];
-          if (a.act == 1) y = y / (1.f + __expf(-1.702f * y));
-          if (a.resid_kind == 1 || a.resid_kind == 3) y += ((const float*)a.resid)[row * a.ldr + n + j];
-          else if (a.resid_kind == 2) y += bf16_to_f32(((const bf16_t*)a.resid)[row * a.ldr + n + j]);
-          if (a.act == 2) y = fmaxf(y, 0.f);
-          if (a.out_kind == 1) ((float*)a.out)[orow * a.ldo + n + j] = y;
-          else ((bf16_t*)a.out)[orow * a.ldo + n + j] = f32_to_bf16(y);
         }
       }
     }
@@ -1117,6 +815,8 @@ bool msclip_gemm_small_try(const msclip_gemm_desc* d, hipStream_t st, int ncu); 
 bool msclip_gemm_small_eligible(const msclip_gemm_desc* d);
 bool msclip_gemm_w4_eligible(const msclip_gemm_desc* d);                            // gemm_w4.hip
 void msclip_gemm_w4_launch(const msclip_gemm_desc* d, hipStream_t st);
+bool msclip_gemm_pp2_eligible(const msclip_gemm_desc* d);                           // gemm_pp2.hip
+void msclip_gemm_pp2_launch(const msclip_gemm_desc* d, hipStream_t st, int ncu);
 
 static int device_cus() {
   static int ncu = 0;
@@ -1130,8 +830,19 @@ static int device_cus() {
 }
 
 // ---- kernel choice: ONE function decides, msclip_gemm launches what it says and msclip_gemm_variant reports it
-enum GemmVariant { GV_INVALID = 0, GV_STREAM, GV_PP, GV_DENSE128, GV_PPCONV, GV_CONV192, GV_CONV128, GV_W4 };
-static const char* const kVariantName[] = {"invalid", "stream", "pp", "dense128", "ppconv", "conv192", "conv128", "w4"};
+enum GemmVariant { GV_INVALID = 0, GV_STREAM, GV_PP, GV_DENSE128, GV_PPCONV, GV_CONV192, GV_CONV128, GV_W4, GV_PP2 };
+static const char* const kVariantName[] = {"invalid", "stream", "pp", "dense128", "ppconv", "conv192", "conv128", "w4", "pp2"};
+
+// MSCLIP_GEMM_PP2=1: the auto-dispatch takes gemm_pp2_kernel (two 4-wave workgroups per CU, 256 x 128 tiles) wherever it
+// would take the ping-pong kernel; 0: never; unset: the measured default below.
+static int pp2_auto() {
+  static int v = -2;
+  if (v == -2) {
+    const char* e = getenv("MSCLIP_GEMM_PP2");
+    v = e ? atoi(e) : -1;
+  }
+  return v;
+}
 
 static GemmVariant pick_variant(const msclip_gemm_desc* d) {
   if (!d || !d->X || !d->W || !d->out || !d->zero) return GV_INVALID;
@@ -1143,10 +854,11 @@ static GemmVariant pick_variant(const msclip_gemm_desc* d) {
   if (d->rpg <= 0) return GV_INVALID;
   // tile choice: the 256x256 / 8-wave config whenever the problem fills the chip with it, else 128x128
   const long long big_tiles = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256);
-  if (d->tile < 0 || d->tile > 7 || d->tile == 2 || d->tile == 3) return GV_INVALID;   // 2, 3: retired main loops
+  if (d->tile < 0 || d->tile > 8 || d->tile == 2 || d->tile == 3) return GV_INVALID;   // 2, 3: retired main loops
   const bool big = d->tile >= 4 || (d->tile == 0 && d->N >= 192 && big_tiles >= 128);
   if ((d->tile == 0 || d->tile == 5) && msclip_gemm_small_eligible(d)) return GV_STREAM;
   if (d->tile == 7) return msclip_gemm_w4_eligible(d) ? GV_W4 : GV_INVALID;
+  if (d->tile == 8) return msclip_gemm_pp2_eligible(d) ? GV_PP2 : GV_INVALID;
   // (the 4-wave kernel with the carried epilogue, gemm_w4.hip, is opt-in through tile = 7: its main loop matches the
   //  ping-pong kernel's (QKV 153 vs 156 us, c_fc 203 vs 203 us in the model step without any epilogue), but with one
   //  wave per SIMD the epilogue's VALU work has no second wave's issue slots to hide in: 200 / 291 us against 190 / 266)
@@ -1156,6 +868,7 @@ static GemmVariant pick_variant(const msclip_gemm_desc* d) {
     const bool pp_ok = (long long)d->ldx * 2 * 256 + (long long)d->K * 2 < (1ll << 31) &&
                        (long long)d->ldw * 2 * 256 + (long long)d->K * 2 < (1ll << 31) &&
                        big_tiles * ((d->M + 255) / 256) * 4 < (1ll << 32);
+    if (pp_ok && d->tile == 0 && big && pp2_auto() == 1 && msclip_gemm_pp2_eligible(d)) return GV_PP2;
     if (pp_ok && (d->tile == 4 || (d->tile == 0 && big))) return GV_PP;     // ping-pong kernel (default for the projections)
     return GV_DENSE128;                        // small problems, heads, logits (and tile 1)
   }
@@ -1197,6 +910,7 @@ extern "C" int msclip_gemm(const msclip_gemm_desc* d, void* stream) {
   switch (v) {
     case GV_STREAM: if (!msclip_gemm_small_try(d, st, ncu)) return MSCLIP_EINVAL; break;
     case GV_W4: msclip_gemm_w4_launch(d, st); break;
+    case GV_PP2: msclip_gemm_pp2_launch(d, st, ncu); break;
     case GV_PP: hipLaunchKernelGGL(gemm_pp_kernel<0>, dim3(grid), dim3(512), 0, st, *d); break;
     case GV_PPCONV: hipLaunchKernelGGL(gemm_pp_kernel<1>, dim3(grid), dim3(512), 0, st, *d); break;
     case GV_DENSE128: launch_cfg<0, 128, 128, 2, 2>(d, st, 2); break;

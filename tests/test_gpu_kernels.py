@@ -34,11 +34,11 @@ def test_gemm_dense_bias_and_shapes(gpu_device, M, N, K):
     close(outf, 0.5 * (x.float() @ w.float().t()) + b, 2e-3, 1e-4)
 
 
-@pytest.mark.parametrize("tile", [1, 4])
+@pytest.mark.parametrize("tile", [1, 4, 8])
 @pytest.mark.parametrize("M,N,K", [(1000, 768, 3072), (700, 520, 128), (256, 256, 64), (2051, 1096, 768)])
 def test_gemm_every_tile_config(gpu_device, tile, M, N, K):
-    """Both dense main loops (128x128 two-buffer, 256x256 ping-pong) on ragged edges, all three epilogue kinds (the 4-wave
-    kernel, tile 7, has its own test below)."""
+    """The dense main loops (128x128 two-buffer, 256x256 ping-pong, 256x128 two-workgroups-per-CU) on ragged edges, all three
+    epilogue kinds (the 4-wave kernel, tile 7, has its own test below)."""
     x, w, b = rnd(M, K, seed=11, dtype=BF), rnd(N, K, seed=12, scale=0.05, dtype=BF), rnd(N, seed=13)
     base = x.float() @ w.float().t() + b
     out = torch.full((M + 3, N), float("nan"), dtype=BF, device="cuda")
@@ -53,19 +53,21 @@ def test_gemm_every_tile_config(gpu_device, tile, M, N, K):
         close(xres, r32 + base, 4e-3, 1e-4)
 
 
-@pytest.mark.parametrize("nt_m,nt_n", [(1, 1), (3, 2), (5, 3), (2, 4), (7, 5), (4, 6), (3, 7), (9, 9), (40, 3), (300, 1)])
-def test_gemm_pingpong_tile_map_covers_every_tile(gpu_device, nt_m, nt_n):
-    """The ping-pong kernel's tile-id -> origin map (XCD remap, column groups of four, reciprocal-multiply divisions):
-    every 256 x 256 tile is computed exactly once for full, ragged and single-column group layouts, with fewer and
-    with more tiles than workgroups."""
-    M, N, K = nt_m * 256 - 19, nt_n * 256 - 40, 64
+@pytest.mark.parametrize("tile", [4, 8])
+@pytest.mark.parametrize("nt_m,nt_n", [(1, 1), (3, 2), (5, 3), (2, 4), (7, 5), (4, 6), (3, 7), (9, 9), (40, 3), (300, 1), (5, 17), (70, 9), (3, 24)])
+def test_gemm_pingpong_tile_map_covers_every_tile(gpu_device, tile, nt_m, nt_n):
+    """The ping-pong kernels' tile-id -> origin maps (XCD remap, column groups of four 256-column / eight 128-column tiles,
+    reciprocal-multiply divisions): every tile is computed exactly once for full, ragged and single-column group layouts,
+    with fewer and with more tiles than workgroups."""
+    tn = 256 if tile == 4 else 128
+    M, N, K = nt_m * 256 - 19, nt_n * tn - 40, 64
     x, w = rnd(M, K, seed=21, dtype=BF), rnd(N, K, seed=22, scale=0.1, dtype=BF)
     out = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
     acc = torch.zeros(M, N, dtype=torch.float32, device="cuda")
-    hip.gemm(x, w, out, tile=4)
+    hip.gemm(x, w, out, tile=tile)
     ref = x.float() @ w.float().t()
     close(out, ref, 2e-3, 1e-3)
-    hip.gemm(x, w, acc, resid=acc, resid_kind=hip.RESID_F32, tile=4)                 # a tile done twice would add twice
+    hip.gemm(x, w, acc, resid=acc, resid_kind=hip.RESID_F32, tile=tile)              # a tile done twice would add twice
     close(acc, ref, 2e-3, 1e-3)
 
 
@@ -95,8 +97,9 @@ def test_gemm_streaming_small_k(gpu_device, M, N, K, ldx):
     close(out[:M], ref1, 2e-2, 1e-2)                                             # agrees with the 128x128 kernel
 
 
-def test_gemm_pingpong_race_screen(gpu_device):
-    """The ping-pong kernel orders LDS-DMA writes, fragment reads and ring-slot reuse by counted waits and barriers only;
+@pytest.mark.parametrize("tile", [4, 8])
+def test_gemm_pingpong_race_screen(gpu_device, tile):
+    """The ping-pong kernels order LDS-DMA writes, fragment reads and ring-slot reuse by counted waits and barriers only;
     a misplaced one shows up as rare wrong tiles.  Many launches, every output element, bitwise-equal results."""
     M, N, K = 8192 + 77, 1024, 1536                                            # 33 x 4 tiles, ragged last row block
     x, w, b = rnd(M, K, seed=51, dtype=BF), rnd(N, K, seed=52, scale=0.04, dtype=BF), rnd(N, seed=53)
@@ -105,7 +108,7 @@ def test_gemm_pingpong_race_screen(gpu_device):
     out = torch.empty(M, N, dtype=BF, device="cuda")
     for it in range(25):
         out.fill_(float("nan"))
-        hip.gemm(x, w, out, bias=b, tile=4)
+        hip.gemm(x, w, out, bias=b, tile=tile)
         if first is None:
             close(out, ref, 2e-2, 1e-2)
             first = out.clone()
@@ -115,7 +118,7 @@ def test_gemm_pingpong_race_screen(gpu_device):
     acc = r32.clone()
     for it in range(10):
         acc.copy_(r32)
-        hip.gemm(x, w, acc, bias=b, resid=acc, resid_kind=hip.RESID_F32, tile=4)
+        hip.gemm(x, w, acc, bias=b, resid=acc, resid_kind=hip.RESID_F32, tile=tile)
         if it == 0:
             close(acc, r32 + ref, 4e-3, 1e-4)
             first = acc.clone()
@@ -123,8 +126,9 @@ def test_gemm_pingpong_race_screen(gpu_device):
             assert torch.equal(acc, first), f"launch {it} differs from launch 0"
 
 
+@pytest.mark.parametrize("tile", [4, 8])
 @pytest.mark.parametrize("act", [hip.ACT_NONE, hip.ACT_QUICKGELU])
-def test_gemm_pingpong_race_screen_multi_tile(gpu_device, act):
+def test_gemm_pingpong_race_screen_multi_tile(gpu_device, act, tile):
     """Same screen with several tiles per workgroup (768 tiles on <= 256 workgroups, 12 K-tiles each): the DMA stream
     crossing tile boundaries under the epilogue, and the first wait of a tile that leaves the previous tile's stores
     in flight, both epilogue families."""
@@ -137,7 +141,7 @@ def test_gemm_pingpong_race_screen_multi_tile(gpu_device, act):
     first = None
     for it in range(12):
         out.fill_(float("nan"))
-        hip.gemm(x, w, out, bias=b, act=act, tile=4)
+        hip.gemm(x, w, out, bias=b, act=act, tile=tile)
         if first is None:
             close(out, ref, 2e-2, 1e-2)
             first = out.clone()
@@ -149,7 +153,7 @@ def test_gemm_pingpong_race_screen_multi_tile(gpu_device, act):
         acc = r32.clone()
         for it in range(6):
             acc.copy_(r32)
-            hip.gemm(x, w, acc, bias=b, resid=acc, resid_kind=hip.RESID_F32, tile=4)
+            hip.gemm(x, w, acc, bias=b, resid=acc, resid_kind=hip.RESID_F32, tile=tile)
             if it == 0:
                 close(acc, r32 + ref, 4e-3, 1e-4)
                 first = acc.clone()
@@ -202,7 +206,7 @@ def test_gemm_token_scatter_with_table(gpu_device):
     assert float(got[:, 0].abs().max()) == 0.0 and float(X[B * L:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("tile", [0, 1, 4])
+@pytest.mark.parametrize("tile", [0, 1, 4, 8])
 def test_gemm_token_scatter_every_tile_config(gpu_device, tile):
     """The stem -> token-row scatter with the positional table at a batch where the large-tile kernels take it."""
     B, g2, D, K = 700, 49, 768, 768                                # M = 34300: 134 row tiles of 256
@@ -670,3 +674,23 @@ def test_gather_rows(gpu_device, dtype):
     assert torch.equal(out2[3:36], x[idx.long()]) and not out2[:3].any() and not out2[36:].any()
     hip.gather_rows(x, out[:10], 10, row_mul=7, row_add=2)
     assert torch.equal(out[:10], x[2::7][:10])
+
+
+def test_gemm_pp2_against_the_pingpong_kernel_on_the_projection_shapes(gpu_device):
+    """gemm_pp2_kernel (tile 8: two 4-wave workgroups per CU, 256 x 128 tiles) and gemm_pp_kernel (tile 4) run the same
+    K order per output element with the same MFMA shape and the same epilogue code: bitwise-equal outputs on the model's
+    four projection shapes at a batch-64 token count, bias / QuickGELU / fp32 residual epilogues."""
+    M = 64 * 127
+    for N, K, kind in ((2304, 768, "bias"), (3072, 768, "gelu"), (768, 768, "resid"), (768, 3072, "resid")):
+        x, w, b = rnd(M, K, seed=61, dtype=BF), rnd(N, K, seed=62, scale=0.04, dtype=BF), rnd(N, seed=63)
+        outs = []
+        for tile in (4, 8):
+            assert hip.gemm_variant(hip.describe_gemm(0, M, N, K, tile=tile)) == ("pp" if tile == 4 else "pp2")
+            if kind == "resid":
+                o = rnd(M, N, seed=64)
+                hip.gemm(x, w, o, bias=b, resid=o, resid_kind=hip.RESID_F32, tile=tile)
+            else:
+                o = torch.empty(M, N, dtype=BF, device="cuda")
+                hip.gemm(x, w, o, bias=b, act=hip.ACT_QUICKGELU if kind == "gelu" else hip.ACT_NONE, tile=tile)
+            outs.append(o)
+        assert torch.equal(outs[0], outs[1]), (N, K, kind, (outs[0].float() - outs[1].float()).abs().max().item())

@@ -225,15 +225,18 @@ def test_gemm_dispatch_rule_is_the_librarys_own():
 
     def v(mode, M, N, tile, K, conv=None, **kw):
         return hip.gemm_variant(hip.describe_gemm(mode, M, N, K, tile, conv, **kw))
+    c3 = lambda B, H, C: (H, H, C, H // 2, H // 2, 2, 1)
     assert v(0, 65024, 2304, 0, 768) == "pp"            # QKV over image + text rows
     assert v(0, 65024, 768, 0, 3072) == "pp"            # c_proj
     assert v(0, 65024, 768, 4, 768) == "pp"
     assert v(0, 65024, 768, 2, 768) == "invalid"        # retired main loop
     assert v(0, 65024, 2304, 7, 768) == "w4"            # opt-in 4-wave kernel with the carried epilogue
+    assert v(0, 65024, 2304, 8, 768) == "pp2"           # two 4-wave workgroups per CU, 256 x 128 tiles
+    assert v(1, 100352, 384, 8, 1728, c3(512, 28, 192)) == "invalid"      # ... dense operands only
+    assert v(0, 65024, 2304, 9, 768) == "invalid"
     assert v(0, 6422528, 48, 0, 64, ldx=48) == "stream"  # pointwise conv of the conv branch
     assert v(0, 25088, 768, 0, 192) == "stream"         # adapter 1x1
     assert v(0, 512, 512, 0, 768) == "dense128"         # heads
-    c3 = lambda B, H, C: (H, H, C, H // 2, H // 2, 2, 1)
     assert v(1, 1605632, 96, 0, 448, c3(512, 112, 48)) == "stream"        # 3x3 stride 2, 48 input channels
     assert v(1, 401408, 192, 0, 896, c3(512, 56, 96)) == "conv192"        # 3x3 stride 2, 96 -> 192
     assert v(1, 100352, 384, 0, 1728, c3(512, 28, 192)) == "ppconv"       # 3x3 stride 2, 192 -> 384 (K-tile inside one tap)
