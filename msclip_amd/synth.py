@@ -38,8 +38,8 @@ def _is_bn(key):
     return owner.startswith("bn") or owner == "residual_bn" or (owner == "1" and parts[-3] == "downsample")
 
 
-def synth_tensor(key, shape, dtype=torch.float32, seed=0, share_from_layer=1):
-    key = canonical_key(key, share_from_layer)
+def synth_tensor(key, shape, dtype=torch.float32, seed=0, share_from_layer=1, vision_layers=12):
+    key = canonical_key(key, share_from_layer, vision_layers)
     r = _rng(seed, key)
     leaf = key.split(".")[-1]
     shape = tuple(shape)
@@ -79,8 +79,11 @@ def synth_tensor(key, shape, dtype=torch.float32, seed=0, share_from_layer=1):
 def synth_state_dict(schema, seed=0, share_from_layer=1):
     """schema: iterable of (key, shape, dtype) in state_dict order."""
     out = {}
+    schema = list(schema)
+    vl = re.compile(r"^visual\.transformer\.resblocks\.(\d+)\.")
+    vision_layers = 1 + max([int(m.group(1)) for m in (vl.match(k) for k, _, _ in schema) if m] or [11])
     for key, shape, dtype in schema:
-        out[key] = synth_tensor(key, shape, dtype, seed, share_from_layer)
+        out[key] = synth_tensor(key, shape, dtype, seed, share_from_layer, vision_layers)
     return out
 
 

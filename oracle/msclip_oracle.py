@@ -64,6 +64,14 @@ def arch_b32():
     return Arch()
 
 
+def arch_l16():
+    """experiments/model/l16-fp8-msclips.yaml of this build (BASELINE config C5's stand-in; the reference builds it from the
+    same yaml, tests/golden/l16-fp8-msclips.npz): ViT-L width / depth / heads on the 14 x 14 grid of the B/16 configs."""
+    a = arch_b16()
+    a.embed_dim, a.width, a.heads, a.vision_layers, a.text_layers = 768, 1024, 16, 24, 24
+    return a
+
+
 def arch_b16():
     return Arch(patch_size=16, stem_strides=(2, 2, 2, 1), parallel_strides=(2, 2, 2, 2, 1),
                 t2b_kernels=(8, 4, 2, 1, 1), t2b_strides=(8, 4, 2, 1, 1))

@@ -26,18 +26,18 @@ def test_config_base_inheritance_and_opts():
         c.NAME = "frozen"
 
 
-@pytest.mark.parametrize("name", ["b32-yfcc-msclips", "b16-yfcc-msclips"])
+@pytest.mark.parametrize("name", ["b32-yfcc-msclips", "b16-yfcc-msclips", "l16-fp8-msclips"])
 def test_state_dict_abi_matches_reference_schema(name):
     model = get_clip_model(named_config(name))
     mine = [(k, tuple(v.shape), v.dtype) for k, v in model.state_dict().items()]
-    assert mine == load_schema(name)                       # same 521 keys, order, shapes, dtypes
+    assert mine == load_schema(name)                       # same 521 keys (l16: 809), order, shapes, dtypes
     # aliases: text block i >= 1 shares attn/mlp tensors with vision block i; LayerNorms never shared
-    for i in range(1, 12):
+    for i in range(1, len(model.transformer.resblocks)):
         v, t = model.visual.transformer.resblocks[i], model.transformer.resblocks[i]
         assert v.attn.in_proj_weight is t.attn.in_proj_weight and v.attn.in_proj_bias is t.attn.in_proj_bias
         assert v.attn.out_proj is t.attn.out_proj and v.mlp is t.mlp
         assert v.ln_1 is not t.ln_1 and v.ln_2 is not t.ln_2
-    assert sum(p.numel() for p in model.parameters()) == (132408001 if name.startswith("b32") else 132503617)
+    assert sum(p.numel() for p in model.parameters()) == {"b32": 132408001, "b16": 132503617, "l16": 369877761}[name[:3]]
 
 
 def test_strict_load_keeps_aliases_and_build_model_alias():

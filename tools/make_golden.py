@@ -239,12 +239,36 @@ def refresh_prompt_features(name="b32-yfcc-msclips"):
     print(f"{name}: prompt_text_features {n_old} -> {ft.shape[0]} rows")
 
 
+def l16_fixture(name="l16-fp8-msclips", batch=2):
+    """`--l16`: BASELINE config C5's stand-in (experiments/model/l16-fp8-msclips.yaml) is an ordinary model for the
+    reference (width 1024, 24 layers, 14 x 14 grid): build it THERE from that yaml, synthetic weights, and capture the
+    state_dict schema, features and logits of a small batch -- the pin of this build's bf16 path for that model (the fp8
+    path has no reference semantics)."""
+    model, _ = R.build_reference_model(name)
+    schema = synth.schema_of(model)
+    model.load_state_dict(synth.synth_state_dict(schema, seed=SEED), strict=True)
+    model.eval()
+    with open(os.path.join(OUT, name + ".schema.json"), "w") as f:
+        json.dump([(k, list(s), str(d).replace("torch.", "")) for k, s, d in schema], f)
+    img, tok = synth.synth_images(batch, seed=SEED), synth.synth_tokens(batch, seed=SEED + 1)
+    R.ensure_single_rank_group()
+    with torch.no_grad():
+        fi, ft = model.encode_image(img), model.encode_text(tok)
+        fir = model.encode_image(img, norm=False)
+        logits = model(img, tok)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), image_features=fi.numpy(), text_features=ft.numpy(),
+                        image_features_raw=fir.numpy(), logits=logits.numpy(), batch=np.int64(batch), seed=np.int64(SEED))
+    print(f"{name}: {len(schema)} keys, features {tuple(fi.shape)}, logits {logits.numpy().round(3).tolist()}")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
     if "--prompt-features-only" in sys.argv:
         return refresh_prompt_features()
+    if "--l16" in sys.argv:
+        return l16_fixture()
     for name in ("b32-yfcc-msclips", "b16-yfcc-msclips"):
         model, _ = run_config(name)
         if name.startswith("b32"):

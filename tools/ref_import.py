@@ -56,7 +56,10 @@ def _merge(a, b):
 def load_reference_config(name):
     """name: 'b32-yfcc-msclips' | 'b16-yfcc-msclips' | 'b32-laion-msclips'."""
     d = os.path.join(REF_ROOT, "experiments", "model")
-    with open(os.path.join(d, name + ".yaml")) as f:
+    path = os.path.join(d, name + ".yaml")
+    if not os.path.exists(path):       # a config of this build the reference can express (l16-fp8-msclips): its BASE is still the reference's
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "experiments", "model", name + ".yaml")
+    with open(path) as f:
         top = yaml.safe_load(f)
     cfg = {}
     for base in top.pop("BASE", []):
