@@ -21,14 +21,16 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-GFLOP_PER_PAIR = {"b32-yfcc-msclips": 23.549, "b16-yfcc-msclips": 49.617}   # SURVEY.md s8(d), counted on the reference
+GFLOP_PER_PAIR = {"b32-yfcc-msclips": 23.549, "b16-yfcc-msclips": 49.617,    # SURVEY.md s8(d), counted on the reference
+                  "l16-fp8-msclips": 172.436}   # torch.utils.flop_counter on the reference built from experiments/model/l16-fp8-msclips.yaml (image 125.345 + text 47.091)
+WIDTH = {"b32-yfcc-msclips": 768, "b16-yfcc-msclips": 768, "l16-fp8-msclips": 1024}
 # The reference computes out_proj / c_fc / c_proj of the LAST block on every token although only x[:, 0] (M.py:2685) and the
 # EOT row (M.py:3057-3060) are read afterwards; the engine runs them on those rows only (engine._last_block_tail).  FLOPs it
 # does not execute are not credited: 18 d^2 per skipped row (2 d^2 out_proj + 8 d^2 c_fc + 8 d^2 c_proj), d = 768.
-SKIPPED_ROWS_PER_PAIR = {"b32-yfcc-msclips": 50 + 77 - 2, "b16-yfcc-msclips": 197 + 77 - 2}
-GFLOP_PER_SKIPPED_ROW = 18 * 768 * 768 / 1e9
+SKIPPED_ROWS_PER_PAIR = {"b32-yfcc-msclips": 50 + 77 - 2, "b16-yfcc-msclips": 197 + 77 - 2, "l16-fp8-msclips": 197 + 77 - 2}
+PEAK_FP8_TFLOPS = 5000.0                                                       # MI355X_MICROARCH.md: dense fp8 (MX K = 128) MFMA
 PEAK_BF16_TFLOPS = 2500.0                                                      # MI355X_MICROARCH.md: dense bf16 MFMA
-DOMINANT = {"variant": "pp", "kernel": "gemm_pp_kernel<0>",                    # what hip.gemm_variant calls it / rocprof's name
+DOMINANT = {"variant": "pp", "kernel": "gemm_pp_kernel<0, false>",             # what hip.gemm_variant calls it / rocprof's name
             "what": "dense bf16 MFMA GEMM: all transformer projections + wide pointwise convs"}
 N_SIMD, N_XCD = 1024, 8                                                        # 256 CUs x 4 SIMDs; GRBM counters sum over XCDs
 
@@ -89,7 +91,7 @@ def cpu_baseline(name, sd, batch=32, iters=3):
     from oracle import msclip_oracle as O
     cores = min(os.cpu_count() or 1, 32)     # more intra-op threads than this only adds barrier overhead on these op sizes
     torch.set_num_threads(cores)
-    arch = O.arch_b32() if name.startswith("b32") else O.arch_b16()
+    arch = O.arch_b32() if name.startswith("b32") else O.arch_l16() if name.startswith("l16") else O.arch_b16()
     img, tok = synth.synth_images(batch, seed=3), synth.synth_tokens(batch, seed=4)
     with torch.no_grad():
         O.contrastive_loss(O.forward(img[:2], tok[:2], sd, arch))            # warm-up
@@ -187,8 +189,10 @@ def main():
                 if torch.is_tensor(t) and t.is_floating_point():
                     t.normal_()
     probe = None if args.no_probe else hip.KernelProbe()
+    probe8 = None if args.no_probe else hip.KernelProbe()                   # the fp8 launches of PRECISION fp8 models
     hip.set_gemm_probe(DOMINANT["variant"], probe)
     hip.set_gemm_probe("pp2", probe)                   # the same launches when the two-workgroups-per-CU kernel takes them
+    hip.set_gemm_f8_probe(probe8)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -197,6 +201,7 @@ def main():
     dt = time.perf_counter() - t0
     hip.set_gemm_probe(DOMINANT["variant"], None)
     hip.set_gemm_probe("pp2", None)
+    hip.set_gemm_f8_probe(None)
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if grouped:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -211,9 +216,10 @@ def main():
     if probe is not None and overlapped:
         os.environ["MSCLIP_CONV_SIDE_STREAM"] = "0"
         step()
-        probe = hip.KernelProbe()
+        probe, probe8 = hip.KernelProbe(), hip.KernelProbe()
         hip.set_gemm_probe(DOMINANT["variant"], probe)
         hip.set_gemm_probe("pp2", probe)
+        hip.set_gemm_f8_probe(probe8)
         fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -222,6 +228,7 @@ def main():
         dt_probe = time.perf_counter() - t0
         hip.set_gemm_probe(DOMINANT["variant"], None)
         hip.set_gemm_probe("pp2", None)
+        hip.set_gemm_f8_probe(None)
         del os.environ["MSCLIP_CONV_SIDE_STREAM"]
 
     if rank == 0:
@@ -229,15 +236,17 @@ def main():
         pairs_s = B * world * args.steps / dt
         gf_ref = GFLOP_PER_PAIR[args.model]
         skipped = 0.0 if (ts is not None or hip.env_flag("MSCLIP_FULL_LAST_BLOCK")) else \
-            SKIPPED_ROWS_PER_PAIR[args.model] * GFLOP_PER_SKIPPED_ROW
+            SKIPPED_ROWS_PER_PAIR[args.model] * 18 * WIDTH[args.model] ** 2 / 1e9
         gf = gf_ref - skipped                      # executed algorithmic FLOPs per pair
         fmul = 3 if ts is not None else 1          # backward counted as 2x forward
         rec = {
-            "metric": "image-text pairs/sec ViT-B/32 bf16" if args.model.startswith("b32") else "image-text pairs/sec ViT-B/16 bf16",
+            "metric": {"b32": "image-text pairs/sec ViT-B/32 bf16", "b16": "image-text pairs/sec ViT-B/16 bf16",
+                       "l16": "image-text pairs/sec ViT-L/16-width stand-in of config C5 (L/14 is inexpressible), fp8 + bf16"}[args.model[:3]],
             "mfma_util_pct": None,
             "value": round(pairs_s, 1), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": "bf16" if model.precision == "bf16" else "fp8 e4m3 operands (QKV, c_fc) + bf16 (everything else), fp32 accumulation",
+            "data": "synthetic",
             "config": {"workload": f"MS-CLIP-S {args.model} fwd + contrastive step (both towers, gather, logits, "
                                    f"symmetric CE), per-GPU batch {B}, 224x224 images + 77-token captions, "
                                    f"random-init weights", "per_gpu_batch": B, "global_batch": B * world,
@@ -308,8 +317,22 @@ def main():
                     errs = {k: v for k, v in pmc.items() if k.startswith("error_")}
                     if errs:
                         rec["roofline"]["pmc_errors"] = errs
-        if "roofline" in rec and "mfma_busy_pct_whole_step" in rec["roofline"]:
-            rec["mfma_util_pct"] = rec["roofline"]["mfma_busy_pct_whole_step"]   # BASELINE metric's second half (all kernels of a step)
+        n8 = probe8.summary()[0] if probe8 is not None else 0
+        if n8 > 0:                      # PRECISION fp8: the config's own kernel gets the headline roofline, the bf16 GEMM moves beside it
+            n8, kms8, flops8 = probe8.summary()
+            ach8 = flops8 / (kms8 * 1e-3) / 1e12
+            r8 = {"kernel": "gemm_pp_kernel<0, true> (dense fp8 e4m3 MX-MFMA GEMM: QKV and c_fc of every block)", "bound": "mfma",
+                  "achieved": round(ach8, 1), "peak": PEAK_FP8_TFLOPS, "unit": "TFLOP/s", "frac": round(ach8 / PEAK_FP8_TFLOPS, 4),
+                  "traffic": None, "launches_per_step": n8 // args.steps, "avg_launch_us": round(kms8 / n8 * 1e3, 2),
+                  "flops_per_launch_avg": round(flops8 / n8 / 1e9, 3), "flops_unit": "GFLOP",
+                  "algorithmic_bytes_per_launch": round(sum(probe8.bytes) / n8),
+                  "time_share_of_step": round(kms8 / (dt_probe * 1e3), 4)}
+            if "roofline" in rec:
+                rec["roofline_bf16_gemm"] = rec["roofline"]
+            rec["roofline"] = r8
+        for key in ("roofline", "roofline_bf16_gemm"):
+            if key in rec and "mfma_busy_pct_whole_step" in rec[key]:
+                rec["mfma_util_pct"] = rec[key]["mfma_busy_pct_whole_step"]      # BASELINE metric's second half (all kernels of a step)
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(args.model, sd)
         if grouped:                     # RCCL's version banner sits in libc's stdout buffer: out with it BEFORE the record, so

@@ -51,7 +51,7 @@ typedef struct msclip_gemm_desc {
   int out_kind;
   float alpha;
   int rpg, radd, roff;   /* rpg > 0; use rpg = INT_MAX, radd = roff = 0 for the identity */
-  int tile;              /* 0 = auto, 1 = 128x128 (4 waves), 4 = 256x256 ping-pong (what auto picks for large problems; dense X, or implicit conv with Cin % 64 == 0), 5 = streaming kernel with LDS-resident weights (K <= 192, or the 3x3 convolutions with 48 input channels; M >= 4096; auto picks it there), 6 = 256x192 two-buffer (implicit conv with N % 192 == 0), 7 = 4-wave 256x256 kernel with the epilogue carried under the next tile's K loop (dense X, bf16 output, no residual, N % 256 == 0, K >= 576, alpha 1; auto picks it for such problems when they fill the chip; EINVAL otherwise) */
+  int tile;              /* 0 = auto, 1 = 128x128 (4 waves), 4 = 256x256 ping-pong (what auto picks for large problems; dense X, or implicit conv with Cin % 64 == 0), 5 = streaming kernel with LDS-resident weights (K <= 192, or the 3x3 convolutions with 48 input channels; M >= 4096; auto picks it there), 6 = 256x192 two-buffer (implicit conv with N % 192 == 0), 7 = 4-wave 256x256 kernel with the epilogue carried under the next tile's K loop (dense X, bf16 output, no residual, N % 256 == 0, K >= 576, alpha 1; opt-in: measured slower than 4; EINVAL otherwise), 8 = two 4-wave workgroups per CU on 256x128 tiles (gemm_pp2.hip; dense X; opt-in: measured slower than 4, profiles/r03_gemm_pp2_ab.md) */
 } msclip_gemm_desc;
 
 int msclip_gemm(const msclip_gemm_desc* desc, void* stream);
@@ -61,7 +61,22 @@ int msclip_gemm(const msclip_gemm_desc* desc, void* stream);
  * activation / scatter.  The caller folds the slices (msclip_colsum over [slices, M*ldo]: fixed order). */
 int msclip_gemm_splitk(const msclip_gemm_desc* desc, int slices, void* stream);
 
-/* Name of the kernel msclip_gemm would launch for this descriptor ("w4", "pp", "ppconv", "stream", "dense128",
+/* The dense ping-pong GEMM on OCP e4m3 (fp8) operands, CDNA4's MX matrix instruction v_mfma_scale_f32_16x16x128_f8f6f4 with
+ * unit block scales (BASELINE config C5; the reference has no fp8 semantics).  desc->X [M, K] and desc->W [N, K] are e4m3 BYTES
+ * (ldx / ldw in bytes, multiples of 16; K a multiple of 128; mode 0 only); row_scale [M] and col_scale [N] are the fp32
+ * per-row scales of X and W: out = epilogue(alpha * row_scale[m] * col_scale[n] * sum_k X[m, k] W[n, k]), same bias /
+ * activation / residual / output kinds as msclip_gemm.  Replaces F.linear (M.py:612, 794) when MODEL.SPEC.PRECISION is fp8. */
+int msclip_gemm_f8(const msclip_gemm_desc* desc, const float* row_scale, const float* col_scale, void* stream);
+
+/* LayerNorm (M.py:204-219; parameters (gamma, beta) for rows < split, (gamma2, beta2) from there on) straight to e4m3 with one
+ * fp32 scale per row: q[m][c] = fp8(y / s[m]), s[m] = max_c |y| / 448.  The quantising producer of msclip_gemm_f8's X operand. */
+int msclip_layernorm_f8(const float* x, int ldx, const float* gamma, const float* beta, const float* gamma2, const float* beta2,
+                        int split, void* q, int ldq, float* row_scale, int M, int C, float eps, void* stream);
+
+/* bf16 [M, C] rows -> e4m3 + per-row scale (same convention).  C % 8 == 0. */
+int msclip_quant_f8_rows(const void* x, int ldx, void* q, int ldq, float* row_scale, int M, int C, void* stream);
+
+/* Name of the kernel msclip_gemm would launch for this descriptor ("w4", "pp", "pp2", "ppconv", "stream", "dense128",
  * "conv192", "conv128"; "invalid" for rejected arguments): the library's own dispatch rule, so
  * that measurement code (bench.py's roofline leg) counts exactly the launches of one kernel.  No GPU work. */
 const char* msclip_gemm_variant(const msclip_gemm_desc* desc);

@@ -225,8 +225,12 @@ class CLIP(nn.Module):
 
     def __init__(self, embed_dim, image_resolution, vision_layers, vision_width, vision_patch_size, context_length,
                  vocab_size, transformer_width, transformer_heads, transformer_layers, gather_tensors=False,
-                 custom_config=None):
+                 custom_config=None, precision="bf16"):
         super().__init__()
+        if precision not in ("bf16", "fp8"):
+            raise NotImplementedError(f"MODEL.SPEC.PRECISION = {precision!r}: 'bf16' (default) or 'fp8' (BASELINE config C5: the "
+                                      "LayerNorm-fed projections on the MX fp8 MFMA; no reference semantics)")
+        self.precision = precision
         for key in _UNSUPPORTED_TRUTHY:
             if _get(custom_config, key, False):
                 raise NotImplementedError(f"CUSTOM.{key} selects an experimental branch of the reference that no "
@@ -366,7 +370,8 @@ def get_clip_model(config, vocab_size=None, eot_token=None, **kwargs):
         raise NotImplementedError("POOL_TYPE/SKIP_CLS variants are not part of the released configs")
     return CLIP(spec.EMBED_DIM, config.TRAIN.IMAGE_SIZE[0], vis.LAYERS, vis.WIDTH, vis.PATCH_SIZE,
                 txt.CONTEXT_LENGTH, vocab_size if vocab_size is not None else txt.VOCAB_SIZE, txt.WIDTH, txt.HEADS,
-                txt.LAYERS, gather_tensors=_get(spec, "GATHER_TENSORS", False), custom_config=config.CUSTOM)
+                txt.LAYERS, gather_tensors=_get(spec, "GATHER_TENSORS", False), custom_config=config.CUSTOM,
+                precision=_get(spec, "PRECISION", "bf16"))
 
 
 build_model = get_clip_model     # the name BASELINE.json's north_star uses; the reference only has get_clip_model

@@ -312,10 +312,20 @@ __global__ __launch_bounds__(256) void dwpool_rows_kernel(const bf16_t* __restri
 
 extern "C" int msclip_stem_conv3x3s2_dual(const void* img, int img_is_bf16, const float* w, const float* bias,
                                           void* out_a, void* out_b, int B, int H, int W, int C1, void* stream) {
-  if (!img || !w || !bias || !out_a || !out_b || B <= 0 || C1 != 48 || H < 2 || W < 2 || (H & 1) || (W & 1)) return MSCLIP_EINVAL;
+  if (!img || !w || !bias || !out_a || !out_b || B <= 0 || (C1 != 48 && C1 != 64) || H < 2 || W < 2 || (H & 1) || (W & 1)) return MSCLIP_EINVAL;
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const long long total = (long long)B * Ho * Wo;
   hipStream_t st = (hipStream_t)stream;
+  if (C1 == 64) {                                               // width 1024 (the ViT-L-width stand-in): 2 x 64 channels on the VALU kernel
+    const dim3 grid((unsigned)((total + 255) / 256)), blk(256);
+    if (img_is_bf16)
+      hipLaunchKernelGGL((stem_dual_kernel<bf16_t, 64>), grid, blk, 0, st, (const bf16_t*)img, w, bias, (bf16_t*)out_a,
+                         (bf16_t*)out_b, B, H, W, Ho, Wo);
+    else
+      hipLaunchKernelGGL((stem_dual_kernel<float, 64>), grid, blk, 0, st, (const float*)img, w, bias, (bf16_t*)out_a,
+                         (bf16_t*)out_b, B, H, W, Ho, Wo);
+    return msclip_launch_status();
+  }
   const char* scalar = getenv("MSCLIP_STEM_SCALAR");            // the VALU kernel, for cross-checks only
   if (scalar && scalar[0] == '1') {
     const dim3 grid((unsigned)((total + 255) / 256)), blk(256);

@@ -459,12 +459,35 @@ constexpr int PSLOTS = 10, PREG = 128 * 64;   // ring regions, bf16 elements per
 
 __device__ __forceinline__ bf16x8 pp_ld(const void* p) { return *(const bf16x8*)p; }
 
+// one 16 x 16 accumulator tile += W fragment x X fragment.  bf16: k-step ks of the K-tile (16x16x32); fp8: the two 16-byte
+// halves of a fragment form ONE 32-byte e4m3 operand of the MX instruction (block scales 2^0 = E8M0 127), ks is always 0.
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+template <bool F8>
+__device__ __forceinline__ f32x4 pp_mma(const bf16x8 (&w)[2], const bf16x8 (&x)[2], int ks, f32x4 c) {
+  if constexpr (F8) {
+    i32x8 a, b;
+    __builtin_memcpy(&a, &w[0], 32);
+    __builtin_memcpy(&b, &x[0], 32);
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+  } else {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ks], x[ks], c, 0, 0, 0);
+  }
+}
+
 // MODE 1: implicit GEMM of a convolution whose input-channel count is a multiple of 64 (a K-tile never straddles a
 // filter tap).  X rows are output pixels: the lane keeps the byte offset of its four pixels' window origin and their
 // (ih0, iw0); a K-tile adds the tap's offset (chunk table entry 8*kti, fetched a phase ahead as a scalar load) and taps
 // outside the image -- or rows past M -- get an offset beyond the descriptor's range (read as zero).
-template <int MODE>
-__global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) {
+// F8 (msclip_gemm_f8, dense operands only): X and W are OCP e4m3 bytes, a K-tile is 128 elements -- the same 128-byte LDS
+// rows, regions, ring and LDS-DMA stream -- contracted by ONE v_mfma_scale_f32_16x16x128_f8f6f4 per 16 x 16 tile and K-tile
+// (twice the bf16 rate; block scales 2^0: the operands carry per-row scales instead, row_scale[m] for X rows and col_scale[n]
+// for W rows, fp32, applied to the accumulators in front of the epilogue).
+template <int MODE, bool F8 = false>
+__global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a, const float* __restrict__ row_scale,
+                                                      const float* __restrict__ col_scale) {
+  static_assert(!(F8 && MODE == 1), "fp8 operands: dense GEMM only");
+  constexpr unsigned ES = F8 ? 1u : 2u;            // operand element size in bytes
+  constexpr int KT = F8 ? 128 : 64;                // elements per K-tile (128 bytes)
   constexpr int TM = 4, TN = 2;
   __shared__ __attribute__((aligned(1024))) bf16_t smem[PSLOTS * PREG];
 
@@ -475,7 +498,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
   const int nt_n = (a.N + 255) / 256;
   const int nt_m = (a.M + 255) / 256;
   const int ntiles = nt_n * nt_m;
-  const int nk = a.K / 64;
+  const int nk = a.K / KT;
 
   // Tile id -> origin runs twice per tile in every wave (issue side and compute side).  Its two divisions by launch
   // constants go through multiply-high with reciprocals made once here (exact while id * divisor < 2^32; the host
@@ -507,10 +530,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
   for (int i = 0; i < 2; ++i) {
     const int row = (wave + 8 * i) * 8 + (lane >> 3);
     const unsigned ch = (unsigned)((lane & 7) ^ ((row >> 1) & 7)) << 4;
-    vx[i] = (unsigned)row * (unsigned)a.ldx * 2u + ch;
-    vw[i] = (unsigned)row * (unsigned)a.ldw * 2u + ch;
+    vx[i] = (unsigned)row * (unsigned)a.ldx * ES + ch;
+    vw[i] = (unsigned)row * (unsigned)a.ldw * ES + ch;
   }
-  const unsigned xhalf = 128u * (unsigned)a.ldx * 2u, whalf = 128u * (unsigned)a.ldw * 2u;
+  const unsigned xhalf = 128u * (unsigned)a.ldx * ES, whalf = 128u * (unsigned)a.ldw * ES;
   int ti = blockIdx.x, kti = 0, islot = 0;
   __amdgpu_buffer_rsrc_t rx, rw;
   // conv mode: window origin of this lane's pixel rows [half][piece]: byte offset + 16-byte chunk, and (ih0, iw0)
@@ -534,18 +557,18 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
           chw[h][i] = (ihs & 0xffff) | (iw0 << 16);
           cpix[h][i] = (((b * a.H + ih0) * a.Wd + iw0) * a.Cin) * 2 + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
         }
-      const unsigned long long wb = (unsigned long long)(a.N - n0) * (unsigned long long)a.ldw * 2ull;
-      rw = t < ntiles ? make_rsrc((const bf16_t*)a.W + (size_t)n0 * a.ldw, wb > 0xffffffffull ? 0xffffffffu : (unsigned)wb)
+      const unsigned long long wb = (unsigned long long)(a.N - n0) * (unsigned long long)a.ldw * ES;
+      rw = t < ntiles ? make_rsrc((const char*)a.W + (size_t)n0 * a.ldw * ES, wb > 0xffffffffull ? 0xffffffffu : (unsigned)wb)
                       : make_rsrc(a.W, 0);
       return;
     }
     if (t < ntiles) {
       int m0, n0;
       tile_origin(t, m0, n0);
-      const unsigned long long xb = (unsigned long long)(a.M - m0) * (unsigned long long)a.ldx * 2ull;
-      const unsigned long long wb = (unsigned long long)(a.N - n0) * (unsigned long long)a.ldw * 2ull;
-      rx = make_rsrc((const bf16_t*)a.X + (size_t)m0 * a.ldx, xb > 0xffffffffull ? 0xffffffffu : (unsigned)xb);
-      rw = make_rsrc((const bf16_t*)a.W + (size_t)n0 * a.ldw, wb > 0xffffffffull ? 0xffffffffu : (unsigned)wb);
+      const unsigned long long xb = (unsigned long long)(a.M - m0) * (unsigned long long)a.ldx * ES;
+      const unsigned long long wb = (unsigned long long)(a.N - n0) * (unsigned long long)a.ldw * ES;
+      rx = make_rsrc((const char*)a.X + (size_t)m0 * a.ldx * ES, xb > 0xffffffffull ? 0xffffffffu : (unsigned)xb);
+      rw = make_rsrc((const char*)a.W + (size_t)n0 * a.ldw * ES, wb > 0xffffffffull ? 0xffffffffu : (unsigned)wb);
     } else {                                       // past the tile list: empty descriptors, the counts stay exact
       rx = make_rsrc(a.X, 0);
       rw = make_rsrc(a.W, 0);
@@ -599,9 +622,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
   const int r16 = lane & 15, quad = lane >> 4;
   const bool vec = !((a.N | a.ldo | (a.resid_kind ? a.ldr : 0)) & 3);
   const bool plain_rows = a.rpg == 0x7fffffff && a.resid_kind != 3;
+  // bf16: la[ks] = k-step ks (16-byte chunk ks*4 + quad of the 128-byte row); fp8: the lane's 32 bytes of the one k-step are
+  // chunks 2*quad (la[0]) and 2*quad + 1 (la[1]) -- A and B use the same lane -> k assignment, so the contraction is exact
   int la[2];
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) la[ks] = r16 * 128 + ((((ks << 2) | quad) ^ ((r16 >> 1) & 7)) << 4);
+  for (int ks = 0; ks < 2; ++ks)
+    la[ks] = r16 * 128 + (((F8 ? (quad << 1) | ks : (ks << 2) | quad) ^ ((r16 >> 1) & 7)) << 4);
   const int wsub = ((wave >> 1) & 1);              // W half-region of this wave
   const int woff = (wave & 1) * 64 * 128;          // byte offset of its 64 rows inside that region
   const char* lds = (const char*)smem;
@@ -701,19 +727,19 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
       }
       PP_SYNC_IN();
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
+      for (int ks = 0; ks < (F8 ? 1 : 2); ++ks)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
           for (int i = 0; i < 2; ++i)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[i][ks], xf[j][ks], acc[i][j], 0, 0, 0);
+            acc[i][j] = pp_mma<F8>(w0[i], xf[j], ks, acc[i][j]);
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
+      for (int ks = 0; ks < (F8 ? 1 : 2); ++ks)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
           for (int i = 0; i < 2; ++i)
-            acc[2 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[i][ks], xf[j][ks], acc[2 + i][j], 0, 0, 0);
+            acc[2 + i][j] = pp_mma<F8>(w1[i], xf[j], ks, acc[2 + i][j]);
       PP_SYNC_OUT();
 
       // ---- phase 2: X sub 1 -> quadrant (1, 1)
@@ -732,21 +758,21 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
       else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       PP_SYNC_IN();
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
+      for (int ks = 0; ks < (F8 ? 1 : 2); ++ks)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
           for (int i = 0; i < 2; ++i)
-            acc[2 + i][4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[i][ks], xf[j][ks], acc[2 + i][4 + j], 0, 0, 0);
+            acc[2 + i][4 + j] = pp_mma<F8>(w1[i], xf[j], ks, acc[2 + i][4 + j]);
 
       // ---- phase 3: nothing new to read -> quadrant (1, 0); the next K-tile's regions are waited for here
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
+      for (int ks = 0; ks < (F8 ? 1 : 2); ++ks)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
           for (int i = 0; i < 2; ++i)
-            acc[i][4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[i][ks], xf[j][ks], acc[i][4 + j], 0, 0, 0);
+            acc[i][4 + j] = pp_mma<F8>(w0[i], xf[j], ks, acc[i][4 + j]);
       PP_SYNC_OUT();
     }
 
@@ -763,6 +789,28 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a) 
       int lane_e;
       asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
       epi_stores = 0;
+      if (F8) {
+        // per-row operand scales: acc[ni][mi][r] = C[row mi*16 + lane%16][column ni*16 + 4*(lane/16) + r]
+        const int er = lane_e & 15, eq = lane_e >> 4;
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+          const int m = cm0 + wm + mi * 16 + er;
+          const float sx = row_scale[m < a.M ? m : a.M - 1];
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[ni][mi][r] *= sx;
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int n = cn0 + wn + ni * 16 + eq * 4 + r;
+            const float sw = col_scale[n < a.N ? n : a.N - 1];
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) acc[ni][mi][r] *= sw;
+          }
+      }
       if (vec && plain_rows && cm0 + 256 <= a.M)
       {
         const bool full_n = cn0 + 256 <= a.N;      // no lane's store is predicated off
@@ -900,6 +948,24 @@ extern "C" int msclip_gemm_splitk(const msclip_gemm_desc* d, int slices, void* s
   return msclip_launch_status();
 }
 
+// fp8 (OCP e4m3) operands on the ping-pong kernel: X [M, K] and W [N, K] bytes (ldx / ldw in elements = bytes, multiples of 16),
+// K a multiple of 128; out = epilogue(alpha * row_scale[m] * col_scale[n] * sum_k X[m, k] W[n, k]) with the usual bias /
+// activation / residual epilogues.  Dense operands only.
+extern "C" int msclip_gemm_f8(const msclip_gemm_desc* d, const float* row_scale, const float* col_scale, void* stream) {
+  if (!d || !d->X || !d->W || !d->out || !d->zero || !row_scale || !col_scale) return MSCLIP_EINVAL;
+  if (d->mode != 0 || d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->K % 128) || (d->ldx % 16) || (d->ldw % 16) || d->ldx < d->K ||
+      d->ldw < d->K || d->rpg <= 0)
+    return MSCLIP_EINVAL;
+  const long long tiles = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256);
+  if ((long long)d->ldx * 256 + d->K >= (1ll << 31) || (long long)d->ldw * 256 + d->K >= (1ll << 31) ||
+      tiles * ((d->M + 255) / 256) * 4 >= (1ll << 32))
+    return MSCLIP_EINVAL;
+  const int ncu = device_cus();
+  hipLaunchKernelGGL((gemm_pp_kernel<0, true>), dim3(tiles < ncu ? (int)tiles : ncu), dim3(512), 0, (hipStream_t)stream, *d,
+                     row_scale, col_scale);
+  return msclip_launch_status();
+}
+
 extern "C" int msclip_gemm(const msclip_gemm_desc* d, void* stream) {
   const GemmVariant v = pick_variant(d);
   if (v == GV_INVALID) return MSCLIP_EINVAL;
@@ -911,8 +977,8 @@ extern "C" int msclip_gemm(const msclip_gemm_desc* d, void* stream) {
     case GV_STREAM: if (!msclip_gemm_small_try(d, st, ncu)) return MSCLIP_EINVAL; break;
     case GV_W4: msclip_gemm_w4_launch(d, st); break;
     case GV_PP2: msclip_gemm_pp2_launch(d, st, ncu); break;
-    case GV_PP: hipLaunchKernelGGL(gemm_pp_kernel<0>, dim3(grid), dim3(512), 0, st, *d); break;
-    case GV_PPCONV: hipLaunchKernelGGL(gemm_pp_kernel<1>, dim3(grid), dim3(512), 0, st, *d); break;
+    case GV_PP: hipLaunchKernelGGL((gemm_pp_kernel<0, false>), dim3(grid), dim3(512), 0, st, *d, nullptr, nullptr); break;
+    case GV_PPCONV: hipLaunchKernelGGL((gemm_pp_kernel<1, false>), dim3(grid), dim3(512), 0, st, *d, nullptr, nullptr); break;
     case GV_DENSE128: launch_cfg<0, 128, 128, 2, 2>(d, st, 2); break;
     case GV_CONV192: launch_cfg<1, 256, 192, 4, 2>(d, st, 1); break;
     case GV_CONV128: launch_cfg<1, 128, 128, 2, 2>(d, st, 2); break;

@@ -13,8 +13,9 @@
 
 namespace {
 
-constexpr int EMAX = 512;   // feature width handled in registers (E % 16 == 0, E <= 512)
-
+// feature width handled in registers (E % 16 == 0): EMAX = 512 (the released configs' EMBED_DIM) or 768 (the ViT-L-width
+// stand-in of config C5: 192 fragment registers)
+template <int EMAX>
 __global__ __launch_bounds__(256) void lse_fused_kernel(const bf16_t* __restrict__ A, int lda,
                                                         const bf16_t* __restrict__ Bm, int ldb, int R, int N, int E,
                                                         float scale, int label_off, int nsplit,
@@ -186,11 +187,15 @@ extern "C" int msclip_clip_lse_fused(const void* A, int lda, const void* Bm, int
                                      int label_off, int nsplit, float* part_max, float* part_sum, float* diag,
                                      void* stream) {
   if (!A || !Bm || !part_max || !part_sum || !diag || R <= 0 || N <= 0 || nsplit <= 0) return MSCLIP_EINVAL;
-  if (E <= 0 || E > EMAX || (E % 16) || (lda % 8) || (ldb % 8)) return MSCLIP_EINVAL;
+  if (E <= 0 || E > 768 || (E % 16) || (lda % 8) || (ldb % 8)) return MSCLIP_EINVAL;
   if (label_off < 0 || label_off + R > N) return MSCLIP_EINVAL;
   const dim3 grid((R + 31) / 32, (nsplit + 3) / 4);
-  hipLaunchKernelGGL(lse_fused_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)A, lda,
-                     (const bf16_t*)Bm, ldb, R, N, E, scale, label_off, nsplit, part_max, part_sum, diag);
+  if (E <= 512)
+    hipLaunchKernelGGL(lse_fused_kernel<512>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)A, lda,
+                       (const bf16_t*)Bm, ldb, R, N, E, scale, label_off, nsplit, part_max, part_sum, diag);
+  else
+    hipLaunchKernelGGL(lse_fused_kernel<768>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)A, lda,
+                       (const bf16_t*)Bm, ldb, R, N, E, scale, label_off, nsplit, part_max, part_sum, diag);
   return msclip_launch_status();
 }
 

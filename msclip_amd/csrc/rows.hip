@@ -356,10 +356,12 @@ __global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ x
 
 }  // namespace
 
-#define NV_DISPATCH(C, CALL3, CALL2, CALL1)        \
-  if ((C) == 768) { CALL3; }                        \
-  else if ((C) == 512) { CALL2; }                   \
-  else if ((C) == 256) { CALL1; }                   \
+// row width -> float4 pieces per lane (NV = C / 256): 768 (ViT-B), 1024 (the ViT-L-width stand-in of config C5), 512, 256
+#define NV_LAUNCH(C, KERNEL, GRID, BLK, ST, ...)                                                  \
+  if ((C) == 768) { hipLaunchKernelGGL(KERNEL<3>, GRID, BLK, 0, ST, __VA_ARGS__); }               \
+  else if ((C) == 1024) { hipLaunchKernelGGL(KERNEL<4>, GRID, BLK, 0, ST, __VA_ARGS__); }         \
+  else if ((C) == 512) { hipLaunchKernelGGL(KERNEL<2>, GRID, BLK, 0, ST, __VA_ARGS__); }          \
+  else if ((C) == 256) { hipLaunchKernelGGL(KERNEL<1>, GRID, BLK, 0, ST, __VA_ARGS__); }          \
   else return MSCLIP_EINVAL;
 
 static int launch_ln(const float* x, int ldx, const int* row_idx, int row_mul, int row_add, const float* gamma,
@@ -368,17 +370,11 @@ static int launch_ln(const float* x, int ldx, const int* row_idx, int row_mul, i
   const char* single = getenv("MSCLIP_LN_SINGLE_ROW");            // the wave-per-row kernel, for cross-checks only
   if (!row_idx && row_mul == 1 && row_add == 0 && !raw_out && M >= 4096 && !(single && single[0] == '1')) {
     const dim3 grid2(((M + 1) / 2 + WPB - 1) / WPB), blk2(256);
-    NV_DISPATCH(C,
-                hipLaunchKernelGGL(ln_pair_kernel<3>, grid2, blk2, 0, st, x, ldx, gamma, beta, out, ldo, out_kind, M, eps, gamma2, beta2, split),
-                hipLaunchKernelGGL(ln_pair_kernel<2>, grid2, blk2, 0, st, x, ldx, gamma, beta, out, ldo, out_kind, M, eps, gamma2, beta2, split),
-                hipLaunchKernelGGL(ln_pair_kernel<1>, grid2, blk2, 0, st, x, ldx, gamma, beta, out, ldo, out_kind, M, eps, gamma2, beta2, split))
+    NV_LAUNCH(C, ln_pair_kernel, grid2, blk2, st, x, ldx, gamma, beta, out, ldo, out_kind, M, eps, gamma2, beta2, split)
     return msclip_launch_status();
   }
   const dim3 grid((M + WPB - 1) / WPB), blk(256);
-  NV_DISPATCH(C,
-              hipLaunchKernelGGL(ln_kernel<3>, grid, blk, 0, st, x, ldx, row_idx, row_mul, row_add, gamma, beta, out, ldo, out_kind, raw_out, ld_raw, M, eps, gamma2, beta2, split),
-              hipLaunchKernelGGL(ln_kernel<2>, grid, blk, 0, st, x, ldx, row_idx, row_mul, row_add, gamma, beta, out, ldo, out_kind, raw_out, ld_raw, M, eps, gamma2, beta2, split),
-              hipLaunchKernelGGL(ln_kernel<1>, grid, blk, 0, st, x, ldx, row_idx, row_mul, row_add, gamma, beta, out, ldo, out_kind, raw_out, ld_raw, M, eps, gamma2, beta2, split))
+  NV_LAUNCH(C, ln_kernel, grid, blk, st, x, ldx, row_idx, row_mul, row_add, gamma, beta, out, ldo, out_kind, raw_out, ld_raw, M, eps, gamma2, beta2, split)
   return msclip_launch_status();
 }
 
@@ -406,9 +402,7 @@ extern "C" int msclip_embed_tokens(const long long* tokens, const float* emb, co
   const int rows = B * L;
   const dim3 grid((rows + WPB - 1) / WPB), blk(256);
   float* xb = x + (size_t)row_base * ldx;
-  NV_DISPATCH(C, hipLaunchKernelGGL(embed_kernel<3>, grid, blk, 0, st, tokens, emb, pos, xb, ldx, rows, L, vocab),
-              hipLaunchKernelGGL(embed_kernel<2>, grid, blk, 0, st, tokens, emb, pos, xb, ldx, rows, L, vocab),
-              hipLaunchKernelGGL(embed_kernel<1>, grid, blk, 0, st, tokens, emb, pos, xb, ldx, rows, L, vocab))
+  NV_LAUNCH(C, embed_kernel, grid, blk, st, tokens, emb, pos, xb, ldx, rows, L, vocab)
   if (eot_row) hipLaunchKernelGGL(eot_kernel, dim3(B), dim3(64), 0, st, tokens, eot_row, B, L, row_base);
   return msclip_launch_status();
 }
@@ -418,9 +412,7 @@ extern "C" int msclip_fill_cls(const float* cls, const float* pos, float* x, int
   if (!cls || !pos || !x || B <= 0 || (ldx % 4)) return MSCLIP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((B + WPB - 1) / WPB), blk(256);
-  NV_DISPATCH(C, hipLaunchKernelGGL(cls_kernel<3>, grid, blk, 0, st, cls, pos, x, ldx, B, L),
-              hipLaunchKernelGGL(cls_kernel<2>, grid, blk, 0, st, cls, pos, x, ldx, B, L),
-              hipLaunchKernelGGL(cls_kernel<1>, grid, blk, 0, st, cls, pos, x, ldx, B, L))
+  NV_LAUNCH(C, cls_kernel, grid, blk, st, cls, pos, x, ldx, B, L)
   return msclip_launch_status();
 }
 
@@ -432,18 +424,12 @@ extern "C" int msclip_adapter_combine_ln(const float* xin, int ldx, const float*
   const char* perrow = getenv("MSCLIP_ADAPTER_PER_TOKEN");       // the wave-per-token kernel, for cross-checks only
   if (!(perrow && perrow[0] == '1')) {
     const dim3 grid((B * g + WPB - 1) / WPB), blk(256);
-    NV_DISPATCH(C,
-                hipLaunchKernelGGL(adapter_gridrow_kernel<3>, grid, blk, 0, st, xin, ldx, t, ldt, dww, dwb, gamma, beta, xout, ldo, B, L, g, usecls, eps),
-                hipLaunchKernelGGL(adapter_gridrow_kernel<2>, grid, blk, 0, st, xin, ldx, t, ldt, dww, dwb, gamma, beta, xout, ldo, B, L, g, usecls, eps),
-                hipLaunchKernelGGL(adapter_gridrow_kernel<1>, grid, blk, 0, st, xin, ldx, t, ldt, dww, dwb, gamma, beta, xout, ldo, B, L, g, usecls, eps))
+    NV_LAUNCH(C, adapter_gridrow_kernel, grid, blk, st, xin, ldx, t, ldt, dww, dwb, gamma, beta, xout, ldo, B, L, g, usecls, eps)
     return msclip_launch_status();
   }
   const int rows = B * L;
   const dim3 grid((rows + WPB - 1) / WPB), blk(256);
-  NV_DISPATCH(C,
-              hipLaunchKernelGGL(adapter_kernel<3>, grid, blk, 0, st, xin, ldx, t, ldt, dww, dwb, gamma, beta, xout, ldo, B, L, g, usecls, eps),
-              hipLaunchKernelGGL(adapter_kernel<2>, grid, blk, 0, st, xin, ldx, t, ldt, dww, dwb, gamma, beta, xout, ldo, B, L, g, usecls, eps),
-              hipLaunchKernelGGL(adapter_kernel<1>, grid, blk, 0, st, xin, ldx, t, ldt, dww, dwb, gamma, beta, xout, ldo, B, L, g, usecls, eps))
+  NV_LAUNCH(C, adapter_kernel, grid, blk, st, xin, ldx, t, ldt, dww, dwb, gamma, beta, xout, ldo, B, L, g, usecls, eps)
   return msclip_launch_status();
 }
 
@@ -476,5 +462,88 @@ extern "C" int msclip_gather_rows(const void* x, long long ldx_bytes, const int*
   if (((uintptr_t)x | (uintptr_t)out) & 15) return MSCLIP_EINVAL;
   hipLaunchKernelGGL(gather_rows_kernel, dim3((M + WPB - 1) / WPB), dim3(256), 0, (hipStream_t)stream, (const char*)x, ldx_bytes,
                      row_idx, row_mul, row_add, (char*)out, ldo_bytes, M, row_bytes / 16);
+  return msclip_launch_status();
+}
+
+namespace {
+// LayerNorm -> OCP e4m3 with one scale per row: q[m][c] = fp8(y[m][c] / s[m]), s[m] = max_c |y[m][c]| / 448 (the format's
+// largest finite value), y = LN(x[m]) with (gamma, beta) for m < split and (gamma2, beta2) from there on.  The producer
+// half of the fp8 projections (msclip_gemm_f8 multiplies s[m] back in its epilogue).  One wave per row.
+template <int NV>
+__global__ __launch_bounds__(256) void ln_f8_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, const float* __restrict__ gamma2,
+                                                    const float* __restrict__ beta2, int split, unsigned char* __restrict__ q,
+                                                    int ldq, float* __restrict__ row_scale, int M, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * WPB + (threadIdx.x >> 6);
+  if (m >= M) return;
+  if (m >= split) {
+    gamma = gamma2;
+    beta = beta2;
+  }
+  float4 v[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = *(const float4*)(x + (size_t)m * ldx + i * 256 + lane * 4);
+  ln_core<NV>(v, gamma, beta, eps, lane);
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[i].x), fabsf(v[i].y)), fmaxf(fabsf(v[i].z), fabsf(v[i].w))));
+  amax = wave_max(amax);
+  const float s = amax > 0.f ? amax * (1.f / 448.f) : 1.f;
+  const float inv = 1.f / s;
+  if (lane == 0) row_scale[m] = s;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    int p = __builtin_amdgcn_cvt_pk_fp8_f32(v[i].x * inv, v[i].y * inv, 0, false);
+    p = __builtin_amdgcn_cvt_pk_fp8_f32(v[i].z * inv, v[i].w * inv, p, true);
+    *(int*)(q + (size_t)m * ldq + i * 256 + lane * 4) = p;
+  }
+}
+
+// bf16 rows -> e4m3 + per-row scale (same convention); C % 8 == 0, one wave per row, 16-byte loads.
+__global__ __launch_bounds__(256) void quant_f8_rows_kernel(const bf16_t* __restrict__ x, int ldx, unsigned char* __restrict__ q,
+                                                            int ldq, float* __restrict__ row_scale, int M, int C) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * WPB + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const bf16_t* xr = x + (size_t)m * ldx;
+  float amax = 0.f;
+  for (int c = lane * 8; c < C; c += 512) {
+    float f[8];
+    unpack_bf16x8(*(const uint4*)(xr + c), f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(f[e]));
+  }
+  amax = wave_max(amax);
+  const float s = amax > 0.f ? amax * (1.f / 448.f) : 1.f;
+  const float inv = 1.f / s;
+  if (lane == 0) row_scale[m] = s;
+  for (int c = lane * 8; c < C; c += 512) {
+    float f[8];
+    unpack_bf16x8(*(const uint4*)(xr + c), f);
+    int lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0] * inv, f[1] * inv, 0, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2] * inv, f[3] * inv, lo, true);
+    int hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4] * inv, f[5] * inv, 0, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6] * inv, f[7] * inv, hi, true);
+    *(int2*)(q + (size_t)m * ldq + c) = make_int2(lo, hi);
+  }
+}
+}  // namespace
+
+extern "C" int msclip_layernorm_f8(const float* x, int ldx, const float* gamma, const float* beta, const float* gamma2,
+                                   const float* beta2, int split, void* q, int ldq, float* row_scale, int M, int C, float eps,
+                                   void* stream) {
+  if (!x || !gamma || !beta || !gamma2 || !beta2 || !q || !row_scale || M <= 0 || split < 0 || split > M || (ldx % 4) || (ldq % 4))
+    return MSCLIP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((M + WPB - 1) / WPB), blk(256);
+  NV_LAUNCH(C, ln_f8_kernel, grid, blk, st, x, ldx, gamma, beta, gamma2, beta2, split, (unsigned char*)q, ldq, row_scale, M, eps)
+  return msclip_launch_status();
+}
+
+extern "C" int msclip_quant_f8_rows(const void* x, int ldx, void* q, int ldq, float* row_scale, int M, int C, void* stream) {
+  if (!x || !q || !row_scale || M <= 0 || C <= 0 || (C % 8) || (ldx % 8) || (ldq % 8)) return MSCLIP_EINVAL;
+  hipLaunchKernelGGL(quant_f8_rows_kernel, dim3((M + WPB - 1) / WPB), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
+                     (unsigned char*)q, ldq, row_scale, M, C);
   return msclip_launch_status();
 }

@@ -30,8 +30,16 @@ from . import packing as P
 class _BlockW:
     """Packed weights of one ResidualAttentionBlock's shareable part."""
 
-    def __init__(self, blk, heads):
+    def __init__(self, blk, heads, fp8=False):
         self.wqkv, self.bqkv = P.qkv_weights(blk.attn.in_proj_weight.detach(), blk.attn.in_proj_bias.detach(), heads)
+        if fp8:
+            # MODEL.SPEC.PRECISION fp8 (BASELINE config C5): the LayerNorm-fed projections' weights as OCP e4m3 with one
+            # scale per output channel, quantised from the fp32 parameters (q rows carry 64^-0.5 like the bf16 copy)
+            d = blk.attn.in_proj_weight.shape[1]
+            wq = blk.attn.in_proj_weight.detach().float().clone()
+            wq[:d] *= 0.125
+            self.wqkv_q, self.wqkv_s = hip.quantize_rows_f8(wq)
+            self.wfc_q, self.wfc_s = hip.quantize_rows_f8(blk.mlp.c_fc.weight.detach())
         bf = torch.bfloat16
         self.wo = blk.attn.out_proj.weight.detach().to(bf).contiguous()
         self.bo = blk.attn.out_proj.bias.detach().float().contiguous()
@@ -102,6 +110,9 @@ class Engine:
         self.Lt = m.context_length
         self.S = v.input_resolution
         self.n_layers = len(m.transformer.resblocks)
+        self.fp8 = getattr(m, "precision", "bf16") == "fp8"
+        if self.fp8 and self.D % 128:
+            raise NotImplementedError("PRECISION fp8 needs a width that is a multiple of 128 (one K-tile of the MX MFMA)")
         assert len(vt.resblocks) == self.n_layers, "vision and text depth must match for the batched layer loop"
         # exp(logit_scale) is a HOST scalar for the logits kernels (GEMM alpha / LSE scale).  Reading it here would block the
         # host until everything queued before the re-pack has finished -- after an optimizer step that is the whole
@@ -156,7 +167,7 @@ class Engine:
             key = (blk.attn.in_proj_weight.data_ptr(), blk.attn.out_proj.weight.data_ptr(),
                    blk.mlp.c_fc.weight.data_ptr(), blk.mlp.c_proj.weight.data_ptr())
             if key not in cache:
-                cache[key] = _BlockW(blk, self.heads)
+                cache[key] = _BlockW(blk, self.heads, self.fp8)
             return cache[key]
 
         self.vblk, self.tblk = [None] * self.n_layers, [None] * self.n_layers
@@ -216,6 +227,9 @@ class Engine:
         w = dict(Mv=Mv, Mt=Mt, M=M)
         w["X"] = buf(M, D, dtype=f32)
         w["LNO"], w["QKV"], w["AO"], w["HID"] = buf(M, D), buf(M, 3 * D), buf(M, D), buf(M, 4 * D)
+        if self.fp8:                                         # e4m3 LayerNorm output + its per-token scales
+            w["LNQ"] = torch.zeros(M * D + 256, dtype=torch.uint8, device=dev)[:M * D].view(M, D)
+            w["RS"] = torch.empty(M, dtype=f32, device=dev)
         if Bi:
             w["XA"] = buf(Mv, D, dtype=f32)
             h1 = self.h1
@@ -415,6 +429,17 @@ class Engine:
             hip.gemm(LNC[r0:r1], bw.wfc, HIDC[r0:r1], bias=bw.bfc, act=hip.ACT_QUICKGELU)
             hip.gemm(HIDC[r0:r1], bw.wpr, XC[r0:r1], bias=bw.bpr, resid=XC[r0:r1], resid_kind=hip.RESID_F32)
 
+    def _ln_f8(self, w, segs, which):
+        """LayerNorm of the token rows straight to e4m3 + per-token scales (w["LNQ"], w["RS"]): one launch over both towers'
+        rows (own gamma / beta per modality), or one per tower when only one runs."""
+        X = w["X"]
+        if len(segs) == 2:
+            (r0, rs, vb), (_, r1, tb) = segs
+            hip.layernorm_f8(X[r0:r1], vb[which].g, vb[which].b, tb[which].g, tb[which].b, rs - r0, w["LNQ"][r0:r1], w["RS"][r0:r1], r1 - r0)
+        else:
+            for r0, r1, b in segs:
+                hip.layernorm_f8(X[r0:r1], b[which].g, b[which].b, b[which].g, b[which].b, r1 - r0, w["LNQ"][r0:r1], w["RS"][r0:r1], r1 - r0)
+
     def _blocks(self, w, Bi, Bt, taps=None, conv_events=None, compact=False):
         Mv, M = w["Mv"], w["M"]
         X, LNO, QKV, AO, HID = w["X"], w["LNO"], w["QKV"], w["AO"], w["HID"]
@@ -447,7 +472,11 @@ class Engine:
                 vis_src, raw = w["XA"], X[:Mv]          # ln_1 reads the adapter output and moves it back into X
             # --- ln_1 (modality specific parameters; one launch over both towers' rows unless the adapter output
             #     has to be picked up from its own buffer)
-            if len(segs) == 2 and raw is None:
+            if self.fp8:
+                if raw is not None:                          # the adapter's output moves back into the residual matrix first
+                    hip.gather_rows(vis_src, raw, Mv)
+                self._ln_f8(w, segs, "ln1")
+            elif len(segs) == 2 and raw is None:
                 hip.layernorm_split(X[:M], vb["ln1"].g, vb["ln1"].b, tb["ln1"].g, tb["ln1"].b, Mv, LNO[:M], M)
             else:
                 for r0, r1, b in segs:
@@ -459,7 +488,10 @@ class Engine:
             groups = [(segs[0][0], segs[-1][1], segs[0][2]["w"])] if len(segs) == 2 and vb["w"] is tb["w"] else \
                      [(r0, r1, b["w"]) for r0, r1, b in segs]
             for r0, r1, bw in groups:
-                hip.gemm(LNO[r0:r1], bw.wqkv, QKV[r0:r1], bias=bw.bqkv)
+                if self.fp8:
+                    hip.gemm_f8(w["LNQ"][r0:r1], bw.wqkv_q, QKV[r0:r1], w["RS"][r0:r1], bw.wqkv_s, bias=bw.bqkv)
+                else:
+                    hip.gemm(LNO[r0:r1], bw.wqkv, QKV[r0:r1], bias=bw.bqkv)
             if vb is not None:
                 hip.attention(QKV[:Mv], AO[:Mv], Bi, self.Lv, self.heads, False)
             if tb is not None:
@@ -469,13 +501,18 @@ class Engine:
                 continue
             for r0, r1, bw in groups:
                 hip.gemm(AO[r0:r1], bw.wo, X[r0:r1], bias=bw.bo, resid=X[r0:r1], resid_kind=hip.RESID_F32)
-            if len(segs) == 2:
+            if self.fp8:
+                self._ln_f8(w, segs, "ln2")
+            elif len(segs) == 2:
                 hip.layernorm_split(X[:M], vb["ln2"].g, vb["ln2"].b, tb["ln2"].g, tb["ln2"].b, Mv, LNO[:M], M)
             else:
                 for r0, r1, b in segs:
                     hip.layernorm(X[r0:r1], b["ln2"].g, b["ln2"].b, LNO[r0:r1], r1 - r0)
             for r0, r1, bw in groups:
-                hip.gemm(LNO[r0:r1], bw.wfc, HID[r0:r1], bias=bw.bfc, act=hip.ACT_QUICKGELU)
+                if self.fp8:
+                    hip.gemm_f8(w["LNQ"][r0:r1], bw.wfc_q, HID[r0:r1], w["RS"][r0:r1], bw.wfc_s, bias=bw.bfc, act=hip.ACT_QUICKGELU)
+                else:
+                    hip.gemm(LNO[r0:r1], bw.wfc, HID[r0:r1], bias=bw.bfc, act=hip.ACT_QUICKGELU)
                 hip.gemm(HID[r0:r1], bw.wpr, X[r0:r1], bias=bw.bpr, resid=X[r0:r1], resid_kind=hip.RESID_F32)
             if taps is not None:
                 if vb is not None:

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("MSCLIP_HIP_LIB") or os.path.join(_HERE, "csrc", "libm
 INT_MAX = 2 ** 31 - 1
 
 EXPORTS = (
-    "msclip_gemm", "msclip_gemm_variant", "msclip_attention", "msclip_layernorm", "msclip_layernorm_split", "msclip_embed_tokens", "msclip_fill_cls",
+    "msclip_gemm", "msclip_gemm_f8", "msclip_layernorm_f8", "msclip_quant_f8_rows", "msclip_gemm_variant", "msclip_attention", "msclip_layernorm", "msclip_layernorm_split", "msclip_embed_tokens", "msclip_fill_cls",
     "msclip_adapter_combine_ln", "msclip_l2norm", "msclip_gather_rows", "msclip_stem_conv3x3s2_dual", "msclip_dwpool",
     "msclip_stem_dual_conv3x3s2", "msclip_conv1x1_conv3x3s2", "msclip_convresblock48_s2",
     "msclip_lse_rows", "msclip_clip_loss_partial", "msclip_clip_lse_fused", "msclip_clip_loss_from_partials",
@@ -76,6 +76,9 @@ def lib():
         vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
         L.msclip_gemm.argtypes = [ctypes.POINTER(GemmDesc), vp]
         L.msclip_gemm_splitk.argtypes = [ctypes.POINTER(GemmDesc), ci, vp]
+        L.msclip_gemm_f8.argtypes = [ctypes.POINTER(GemmDesc), vp, vp, vp]
+        L.msclip_layernorm_f8.argtypes = [vp, ci, vp, vp, vp, vp, ci, vp, ci, vp, ci, ci, cf, vp]
+        L.msclip_quant_f8_rows.argtypes = [vp, ci, vp, ci, vp, ci, ci, vp]
         L.msclip_gemm_variant.argtypes = [ctypes.POINTER(GemmDesc)]
         L.msclip_gemm_variant.restype = ctypes.c_char_p
         L.msclip_attention.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, vp]
@@ -355,6 +358,67 @@ def gemm(x, w, out, *, M=None, bias=None, resid=None, resid_kind=0, act=0, alpha
         return out
     _check(lib().msclip_gemm(ctypes.byref(d), _stream()), "msclip_gemm")
     return out
+
+
+F8 = torch.float8_e4m3fn
+_f8_probe = [None]
+
+
+def set_gemm_f8_probe(probe):
+    _f8_probe[0] = probe
+
+
+def quantize_rows_f8(w):
+    """Host-side (pack-time) per-row e4m3 quantisation of an fp32 / bf16 matrix [N, K]: -> (uint8 [N, K], fp32 scale [N])
+    with w ~= q * scale[:, None]; scale = max |row| / 448 (the format's largest finite value)."""
+    wf = w.detach().float()
+    s = wf.abs().amax(dim=1).clamp_min(1e-30) / 448.0
+    q = (wf / s[:, None]).to(F8)
+    return q.view(torch.uint8).contiguous(), s.contiguous()
+
+
+def gemm_f8(xq, wq, out, row_scale, col_scale, *, M=None, bias=None, resid=None, resid_kind=0, act=0, alpha=1.0):
+    """out = epilogue(alpha * row_scale[m] * col_scale[n] * xq @ wq^T) on the fp8 MX MFMA; xq uint8 [M, K] / wq uint8 [N, K]
+    hold OCP e4m3 bytes, K % 128 == 0."""
+    assert xq.dtype == torch.uint8 and wq.dtype == torch.uint8 and xq.stride(-1) == 1 and wq.stride(-1) == 1
+    _f32(col_scale)
+    assert row_scale.dtype == torch.float32
+    d = GemmDesc()
+    d.X, d.W, d.zero, d.out = xq.data_ptr(), wq.data_ptr(), zero_page(xq.device).data_ptr(), out.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.resid = resid.data_ptr() if resid is not None else None
+    d.M = M if M is not None else xq.shape[0]
+    d.N, d.K = wq.shape[0], wq.shape[1]
+    d.ldx, d.ldw, d.ldo = xq.stride(0), wq.stride(0), out.stride(0)
+    d.ldr = resid.stride(0) if resid is not None and resid.dim() == 2 else d.ldo
+    d.mode, d.act, d.resid_kind, d.alpha, d.rpg = 0, act, resid_kind, alpha, INT_MAX
+    d.out_kind = 1 if out.dtype == torch.float32 else 0
+    assert row_scale.numel() >= d.M and col_scale.numel() >= d.N
+    probe = _f8_probe[0]
+    t0 = probe.begin() if probe is not None else None
+    _check(lib().msclip_gemm_f8(ctypes.byref(d), _p(row_scale), _p(col_scale), _stream()), "msclip_gemm_f8")
+    if probe is not None:
+        esz = 4 if d.out_kind else 2
+        r_bytes = {RESID_NONE: 0, RESID_F32: d.M * d.N * 4, RESID_BF16: d.M * d.N * 2}[resid_kind]
+        nbytes = d.M * d.K + d.N * d.K + d.M * d.N * esz + r_bytes + (d.M + d.N) * 4 + (d.N * 4 if bias is not None else 0)
+        probe.end(t0, 2.0 * d.M * d.N * d.K, (d.M, d.N, d.K, d.K, False, act, resid_kind, d.out_kind), nbytes)
+    return out
+
+
+def layernorm_f8(x, gamma, beta, gamma2, beta2, split, q, row_scale, M, eps=1e-12):
+    """q[m] = e4m3(LN(x[m]) / s[m]), row_scale[m] = s[m]; (gamma, beta) for m < split, (gamma2, beta2) from there on."""
+    assert x.dtype == torch.float32 and x.stride(-1) == 1 and q.dtype == torch.uint8 and q.stride(-1) == 1
+    _check(lib().msclip_layernorm_f8(_p(x), x.stride(0), _p(gamma), _p(beta), _p(gamma2), _p(beta2), split, _p(q), q.stride(0),
+                                     _p(row_scale), M, x.shape[-1], eps, _stream()), "msclip_layernorm_f8")
+    return q
+
+
+def quant_f8_rows(x, q, row_scale, M=None):
+    _bf16(x)
+    M = x.shape[0] if M is None else M
+    _check(lib().msclip_quant_f8_rows(_p(x), x.stride(0), _p(q), q.stride(0), _p(row_scale), M, x.shape[1], _stream()),
+           "msclip_quant_f8_rows")
+    return q
 
 
 def gemm_splitk(x, w, slices, out=None):

@@ -694,3 +694,59 @@ def test_gemm_pp2_against_the_pingpong_kernel_on_the_projection_shapes(gpu_devic
                 hip.gemm(x, w, o, bias=b, act=hip.ACT_QUICKGELU if kind == "gelu" else hip.ACT_NONE, tile=tile)
             outs.append(o)
         assert torch.equal(outs[0], outs[1]), (N, K, kind, (outs[0].float() - outs[1].float()).abs().max().item())
+
+
+def _dq(q, s):
+    return q.view(hip.F8).float() * s[:, None]
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 768, 768), (1000, 2304, 1024), (2051, 1096, 768), (256 * 40 - 7, 3072, 1024), (512, 1024, 4096)])
+def test_gemm_f8(gpu_device, M, N, K):
+    """msclip_gemm_f8 (the ping-pong kernel on e4m3 operands, v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales, per-row
+    scales in the epilogue) against fp32 matmul of the DEQUANTISED operands: products of two e4m3 values are exact in fp32, so
+    only the accumulation order differs.  Ragged M / N, bias, QuickGELU, fp32 residual, repeated launches bitwise equal."""
+    xq, sx = hip.quantize_rows_f8(rnd(M, K, seed=81))
+    wq, sw = hip.quantize_rows_f8(rnd(N, K, seed=82, scale=0.05))
+    b = rnd(N, seed=83)
+    ref = _dq(xq, sx) @ _dq(wq, sw).t() + b
+    out = torch.full((M + 2, N), float("nan"), dtype=BF, device="cuda")
+    hip.gemm_f8(xq, wq, out[:M], sx, sw, bias=b)
+    close(out[:M], ref, 2e-2, 1e-2)
+    assert bool(torch.isnan(out[M:].float()).all())
+    o32 = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    hip.gemm_f8(xq, wq, o32, sx, sw, bias=b)
+    close(o32, ref, 1e-3 * float(ref.abs().max()), 1e-4)
+    hip.gemm_f8(xq, wq, out[:M], sx, sw, bias=b, act=hip.ACT_QUICKGELU)
+    close(out[:M], ref * torch.sigmoid(1.702 * ref), 2e-2, 1e-2)
+    r32 = rnd(M, N, seed=84)
+    first = None
+    for it in range(3):
+        acc = r32.clone()
+        hip.gemm_f8(xq, wq, acc, sx, sw, bias=b, resid=acc, resid_kind=hip.RESID_F32)
+        if first is None:
+            close(acc, r32 + ref, 1e-3 * float(ref.abs().max()), 1e-4)
+            first = acc
+        else:
+            assert torch.equal(acc, first)
+
+
+@pytest.mark.parametrize("C", [768, 1024])
+def test_layernorm_f8_and_row_quant(gpu_device, C):
+    """msclip_layernorm_f8: LayerNorm -> e4m3 + per-token scale (two parameter sets split by row) against torch; the scale is
+    max |y| / 448 and the dequantised row is within e4m3's half-ulp (2^-4 relative; 2^-10 * 448 * s absolute near zero)."""
+    M, split = 777, 300
+    x = rnd(M, C, seed=91, scale=2.0)
+    g1, b1, g2, b2 = rnd(C, seed=92) * 0.1 + 1, rnd(C, seed=93) * 0.1, rnd(C, seed=94) * 0.1 + 1, rnd(C, seed=95) * 0.1
+    y = torch.cat([F.layer_norm(x[:split], (C,), g1, b1, 1e-12), F.layer_norm(x[split:], (C,), g2, b2, 1e-12)])
+    q = torch.zeros(M, C, dtype=torch.uint8, device="cuda")
+    s = torch.zeros(M, device="cuda")
+    hip.layernorm_f8(x, g1, b1, g2, b2, split, q, s, M)
+    close(s, y.abs().amax(1) / 448.0, 0.0, 1e-4)
+    dq = _dq(q, s)
+    tol = 0.0626 * y.abs() + (2.0 ** -9) * 448 * s[:, None]
+    assert bool(((dq - y).abs() <= tol).all()), float(((dq - y).abs() - tol).max())
+    xb = rnd(M, C, seed=96, dtype=BF)
+    hip.quant_f8_rows(xb, q, s)
+    close(s, xb.float().abs().amax(1) / 448.0, 0.0, 1e-5)
+    ref_q, _ = hip.quantize_rows_f8(xb)                                          # torch's own e4m3 rounding of the same scaled values
+    assert (q != ref_q).float().mean().item() < 1e-3                              # (1/s vs division: a rare last-bit tie)
