@@ -27,6 +27,17 @@ from . import hip
 from . import packing as P
 
 
+_TEXT0 = {}
+
+
+def _text0_stream(device):
+    """The side stream of the text front + text block 0 (one per device)."""
+    s = _TEXT0.get(device)
+    if s is None:
+        s = _TEXT0[device] = torch.cuda.Stream(device=device)
+    return s
+
+
 class _BlockW:
     """Packed weights of one ResidualAttentionBlock's shareable part."""
 
@@ -440,10 +451,10 @@ class Engine:
             for r0, r1, b in segs:
                 hip.layernorm_f8(X[r0:r1], b[which].g, b[which].b, b[which].g, b[which].b, r1 - r0, w["LNQ"][r0:r1], w["RS"][r0:r1], r1 - r0)
 
-    def _blocks(self, w, Bi, Bt, taps=None, conv_events=None, compact=False):
+    def _blocks(self, w, Bi, Bt, taps=None, conv_events=None, compact=False, layers=None):
         Mv, M = w["Mv"], w["M"]
         X, LNO, QKV, AO, HID = w["X"], w["LNO"], w["QKV"], w["AO"], w["HID"]
-        for i in range(self.n_layers):
+        for i in (range(self.n_layers) if layers is None else layers):
             vb = self.vblk[i] if Bi else None
             tb = self.tblk[i] if Bt else None
             if vb is None and tb is None:
@@ -584,19 +595,41 @@ class Engine:
             Bt = tok.shape[0] if tok is not None else 0
             w = self._workspace(Bi, Bt, inference=True)
             conv_events = None
+            side_ok = (taps is None and os.environ.get("MSCLIP_CONV_SIDE_STREAM", "1") != "0"
+                       and not torch.cuda.is_current_stream_capturing())
+            text0 = None
+            if Bi and Bt and side_ok and self.vblk[0] is None:
+                # Text block 0 is text-only (vision slot 0 is the conv stem, M.py:2040-2051) and depends on the captions only:
+                # the text front and that block run on a second side stream beside the image front (HBM-bound conv passes
+                # beside MFMA-bound projections on disjoint rows / buffers of the workspace); the layer loop waits for it.
+                cur = torch.cuda.current_stream(self.dev)
+                ts = _text0_stream(self.dev)
+                start = torch.cuda.Event()
+                start.record(cur)                               # the workspace is free: the previous step's work is queued
+                ts.wait_event(start)
+                tokc = self._check_tok(tok)
+                with torch.cuda.stream(ts):
+                    self._text_front(tokc, w, Bt)
+                    self._blocks(w, 0, Bt, layers=(0,))
+                    text0 = torch.cuda.Event()
+                    text0.record(ts)
+                tokc.record_stream(ts)
             if Bi:
                 self._vision_front(self._check_img(img), w, Bi, taps)
                 # default (MSCLIP_CONV_SIDE_STREAM=0 turns it off): +1.6 % pairs/s on B/32, +2.2 % on B/16 same-box.  The GEMM
                 # launches it overlaps measure ~11 % longer each, so bench.py takes its per-kernel roofline from a probe
                 # pass with the inline schedule and reports the overlapped figure beside it.
-                if (taps is None and os.environ.get("MSCLIP_CONV_SIDE_STREAM", "1") != "0" and self.lateral == sorted(self.lateral)
-                        and not torch.cuda.is_current_stream_capturing()):
+                if side_ok and self.lateral == sorted(self.lateral):
                     conv_events = self._conv_branch_on_side_stream(w, Bi)
-            if Bt:
+            if Bt and text0 is None:
                 self._text_front(self._check_tok(tok), w, Bt)
             # the last block's row-wise tail on the live rows only (MSCLIP_FULL_LAST_BLOCK=1: every row, as the taps need it)
             compact = taps is None and not hip.env_flag("MSCLIP_FULL_LAST_BLOCK") and not self.lateral_on_last()
-            self._blocks(w, Bi, Bt, taps, conv_events, compact)
+            if text0 is not None:
+                torch.cuda.current_stream(self.dev).wait_event(text0)
+                self._blocks(w, Bi, Bt, taps, conv_events, compact, layers=range(1, self.n_layers))
+            else:
+                self._blocks(w, Bi, Bt, taps, conv_events, compact)
             allI, allT = self._heads(w, Bi, Bt, norm, gather, compact)
             if gather:
                 w["allI"], w["allT"] = allI, allT
