@@ -53,12 +53,30 @@ def _worker(rank, world, port, q):
     for i, sh in enumerate(shapes):
         gg = torch.Generator().manual_seed(1000 * rank + i)
         mine[f"p{i}"] = torch.randn(sh, generator=gg)
-        red.add(f"p{i}", mine[f"p{i}"].clone())
+        if i in (0, 5):                                    # born inside the bucket (train.py's wgrad slots): reserve, fill, add
+            slot = red.reserve(f"p{i}", sh, torch.device("cpu"))
+            slot.copy_(mine[f"p{i}"])
+            red.add(f"p{i}", slot)
+        else:
+            red.add(f"p{i}", mine[f"p{i}"].clone())
     avg = red.finish()
     ok = list(avg.keys()) == [f"p{i}" for i in range(len(shapes))] and red.launched >= 3
     for i, sh in enumerate(shapes):
         both = [torch.randn(sh, generator=torch.Generator().manual_seed(1000 * r + i)) for r in range(world)]
         ok = ok and avg[f"p{i}"].shape == torch.Size(sh) and torch.allclose(avg[f"p{i}"], sum(both) / world, atol=1e-6)
+    # a second reducer of the same bucket size re-uses the arena's buckets (no new allocation) and still averages correctly
+    red2 = C.GradReducer(bucket_bytes=64 * 4)
+    ptrs = {b.data_ptr() for b in C._ARENA[(torch.device("cpu"), 64)] if b is not None}
+    for i, sh in enumerate(shapes):
+        red2.add(f"p{i}", mine[f"p{i}"].clone())
+    avg2 = red2.finish()
+    res["arena_reused"] = \
+        len({b.data_ptr() for b in C._ARENA[(torch.device("cpu"), 64)] if b is not None} - ptrs) == 0
+    ok2 = True
+    for i, sh in enumerate(shapes):                        # (avg's views alias the re-used buckets: compare with the expectation)
+        both = [torch.randn(sh, generator=torch.Generator().manual_seed(1000 * r + i)) for r in range(world)]
+        ok2 = ok2 and torch.allclose(avg2[f"p{i}"], sum(both) / world, atol=1e-6)
+    res["second_ok"] = bool(ok2)
     res["reducer_ok"], res["reducer_launched"] = bool(ok), red.launched
     if rank == 0:
         q.put(res)
@@ -77,6 +95,7 @@ def test_two_rank_gather_and_sharded_loss():
     np.testing.assert_array_equal(res["grad"], ref["grad_rank0"])        # gradient only through the local slice
     assert res["rank"] == 0 and res["world"] == 2 and res["off"] == 0 and res["packed_ok"] and res["async_ok"]
     assert res["reducer_ok"], res["reducer_launched"]
+    assert res["arena_reused"] and res["second_ok"]
     assert abs(res["loss_sharded"] - res["loss_full"]) < 1e-5
 
 
