@@ -483,9 +483,20 @@ __device__ __forceinline__ f32x4 pp_mma(const bf16x8 (&w)[2], const bf16x8 (&x)[
 // (twice the bf16 rate; block scales 2^0: the operands carry per-row scales instead, row_scale[m] for X rows and col_scale[n]
 // for W rows, fp32, applied to the accumulators in front of the epilogue).
 template <int MODE, bool F8 = false>
-__global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a, const float* __restrict__ row_scale,
+__global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a_in, const float* __restrict__ row_scale,
                                                       const float* __restrict__ col_scale) {
   static_assert(!(F8 && MODE == 1), "fp8 operands: dense GEMM only");
+  // Split-K launches (msclip_gemm_splitk with tile = 4; the weight gradients of the training step): blockIdx.y = K slice;
+  // slice s contracts columns [s*K/S, (s+1)*K/S) of both operands into its own fp32 matrix out[s][M][ldo].  A weight
+  // gradient is 9-36 output tiles over a 65 024-deep contraction: tiles x slices workgroups of ONE launch fill the chip.
+  msclip_gemm_desc a = a_in;
+  if (MODE == 0 && !F8 && gridDim.y > 1) {
+    const int kc = a.K / (int)gridDim.y;
+    a.X = (const bf16_t*)a.X + (size_t)blockIdx.y * kc;
+    a.W = (const bf16_t*)a.W + (size_t)blockIdx.y * kc;
+    a.out = (float*)a.out + (size_t)blockIdx.y * a.M * a.ldo;
+    a.K = kc;
+  }
   constexpr unsigned ES = F8 ? 1u : 2u;            // operand element size in bytes
   constexpr int KT = F8 ? 128 : 64;                // elements per K-tile (128 bytes)
   constexpr int TM = 4, TN = 2;
@@ -941,6 +952,14 @@ extern "C" int msclip_gemm_splitk(const msclip_gemm_desc* d, int slices, void* s
   if (d->mode != 0 || d->out_kind != 1 || d->bias || d->resid || d->resid_kind || d->act || d->rpg != 0x7fffffff || d->radd ||
       d->roff || (d->K % (BK * slices)))
     return MSCLIP_EINVAL;
+  if (d->tile == 4) {                                    // the ping-pong kernel, one 256 x 256 tile list per slice
+    if (pick_variant(d) != GV_PP) return MSCLIP_EINVAL;
+    const int t256 = ((d->M + 255) / 256) * ((d->N + 255) / 256);
+    const int ncu = device_cus();
+    hipLaunchKernelGGL((gemm_pp_kernel<0, false>), dim3(t256 < ncu ? t256 : ncu, slices), dim3(512), 0, (hipStream_t)stream, *d,
+                       nullptr, nullptr);
+    return msclip_launch_status();
+  }
   const int tiles = ((d->M + 127) / 128) * ((d->N + 127) / 128);
   const int cap = device_cus() * 2;
   hipLaunchKernelGGL((gemm_kernel<0, 128, 128, 2, 2>), dim3(tiles < cap ? tiles : cap, slices), dim3(256), 0,

@@ -120,6 +120,61 @@ def wgrad_async(dy_bf, x_bf, M, post=None, out=None):
     return out
 
 
+class WgradJob:
+    """dW[N, K] = dY^T @ X for a WIDE weight gradient (the transformer's projections: 9-36 output tiles of 256 x 256 over a
+    65 024-deep contraction), in two halves:
+
+    * now: the two operand transposes (HBM-bound) on the lane stream, behind an event of the calling stream;
+    * finish(), a few kernels later on the calling stream: ONE split-K launch of the ping-pong GEMM -- tiles x slices ~ 250
+      workgroups, one tile each, so the launch fills the chip and nothing of it lingers on a few CUs beside the next
+      kernels -- and the fold of the fp32 partials (fixed order: deterministic).
+
+    Why not K-slices on side streams (wgrad above, what round 2 shipped for these): a slice is a persistent GEMM of 9-36
+    workgroups that holds its CUs for ~0.6 ms; the main stream's GEMMs launch 256 persistent workgroups with a STATIC tile
+    list each, so while slices hold 18-72 CUs that many of them start only after another has finished its whole list --
+    up to two rounds instead of one.  One full-chip launch in the main stream's own order has neither problem, and the
+    lane keeps only bandwidth-bound work, which shares the chip with MFMA-bound GEMMs far better."""
+
+    def __init__(self, dy_bf, x_bf, M, post=None):
+        self.N, self.K, self.M, self.post = dy_bf.shape[1], x_bf.shape[1], M, post
+        tiles = ((self.N + 255) // 256) * ((self.K + 255) // 256)
+        self.S = S = max(1, min(256 // tiles, M // 2048))
+        Mpad = (M + 64 * S - 1) // (64 * S) * (64 * S)
+        dev = dy_bf.device
+        self.sync = hip.env_flag("MSCLIP_WGRAD_SYNC") or _ranks_share_a_gpu()
+        if self.sync:
+            self.a, self.b, self.done = hip.transpose_bf16(dy_bf, M, Mpad), hip.transpose_bf16(x_bf, M, Mpad), None
+            return
+        cur, ln = torch.cuda.current_stream(dev), lane(dev)
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        ln.wait_event(ready)
+        with torch.cuda.stream(ln):
+            self.a = hip.transpose_bf16(dy_bf, M, Mpad)
+            self.b = hip.transpose_bf16(x_bf, M, Mpad)
+            self.done = torch.cuda.Event()
+            self.done.record(ln)
+        dy_bf.record_stream(ln)
+        x_bf.record_stream(ln)
+
+    def finish(self, out=None):
+        """-> fp32 [N, K] (written into `out` when given, e.g. a gradient bucket's slot) on the calling stream."""
+        dev = self.a.device
+        cur = torch.cuda.current_stream(dev)
+        if self.done is not None:
+            cur.wait_event(self.done)
+            self.a.record_stream(cur)
+            self.b.record_stream(cur)
+        if out is None:
+            out = torch.empty(self.N, self.K, dtype=F32, device=dev)
+        if self.S == 1:
+            hip.gemm(self.a, self.b, out, tile=4)
+        else:
+            hip.gemm_splitk(self.a, self.b, self.S, out=out, tile=4)
+        self.a = self.b = None
+        return self.post(out) if self.post is not None else out
+
+
 def on_lane(fn, *operands):
     """fn() on the lane stream behind an event (same contract as wgrad_async: operands read-only afterwards, result valid
     after join).  For the other HBM-bound by-products of the backward that nothing on the critical path reads (bias sums)."""

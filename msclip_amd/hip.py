@@ -421,9 +421,11 @@ def quant_f8_rows(x, q, row_scale, M=None):
     return q
 
 
-def gemm_splitk(x, w, slices, out=None):
+def gemm_splitk(x, w, slices, out=None, tile=0):
     """fp32 [N_x, N_w] = x @ w^T for two K-contiguous bf16 operands x [M, K], w [N, K] with a deep K (K % (64*slices) == 0):
-    `slices` K ranges contracted by separate workgroup rows of ONE launch into fp32 partials, folded in a fixed order."""
+    `slices` K ranges contracted by separate workgroup rows of ONE launch into fp32 partials, folded in a fixed order.
+    tile = 0: 128 x 128 tiles (narrow outputs); tile = 4: the 256 x 256 ping-pong kernel (wide outputs: 9-36 tiles x slices
+    workgroups fill the chip)."""
     _bf16(x)
     _bf16(w)
     M, N, K = x.shape[0], w.shape[0], x.shape[1]
@@ -432,7 +434,7 @@ def gemm_splitk(x, w, slices, out=None):
     d = GemmDesc()
     d.X, d.W, d.zero, d.out = x.data_ptr(), w.data_ptr(), zero_page(x.device).data_ptr(), part.data_ptr()
     d.M, d.N, d.K, d.ldx, d.ldw, d.ldo = M, N, K, x.stride(0), w.stride(0), N
-    d.out_kind, d.alpha, d.rpg = 1, 1.0, INT_MAX
+    d.out_kind, d.alpha, d.rpg, d.tile = 1, 1.0, INT_MAX, tile
     _check(lib().msclip_gemm_splitk(ctypes.byref(d), slices, _stream()), "msclip_gemm_splitk")
     if slices > 1:
         return colsum(part, out=out.view(-1) if out is not None else None).view(M, N)

@@ -247,6 +247,18 @@ class TrainStep:
                     """Where gradient k should be written if it can be born inside its all-reduce bucket (else None)."""
                     return reducer.reserve(k, shape, dev) if reducer is not None else None
             grads = _Grads()
+            # the four wide weight gradients of a block: operand transposes on the lane at once, the split-K GEMM of job k
+            # on THIS stream when job k + 1 is created (its transposes have run under the kernels issued in between)
+            pending = []
+
+            def flush_wgrads():
+                while pending:
+                    k, job, shape = pending.pop(0)
+                    grads[k] = job.finish(grads.slot(k, shape))
+
+            def wide_wgrad(k, dy, x, rows, shape, post=None):
+                flush_wgrads()
+                pending.append((k, gradgemm.WgradJob(dy, x, rows, post=post), shape))
             # ---- contrastive head: dL/dS blocks of this rank's image rows and caption rows
             npad = (n + 63) // 64 * 64
             wgt = 1.0 / (2.0 * n)
@@ -306,8 +318,7 @@ class TrainStep:
                 dlno = torch.empty(M, D, dtype=F32, device=dev)
                 for r0, r1, bw in groups:
                     p = names[id(bw)]
-                    k = p + ".mlp.c_proj.weight"
-                    grads[k] = _wgrad_async(dY[r0:r1], hid[r0:r1], r1 - r0, out=grads.slot(k, (D, 4 * D)))
+                    wide_wgrad(p + ".mlp.c_proj.weight", dY[r0:r1], hid[r0:r1], r1 - r0, (D, 4 * D))
                     grads[p + ".mlp.c_proj.bias"] = hip.colsum(dX[r0:r1])
                     _dgrad(dY[r0:r1], bw.wpr.t().contiguous(), dhid[r0:r1])
                 del hid
@@ -315,8 +326,7 @@ class TrainStep:
                 hip.quickgelu_bwd(L["h"][r_lo:M], dhid[r_lo:M], dh[r_lo:M])
                 for r0, r1, bw in groups:
                     p = names[id(bw)]
-                    k = p + ".mlp.c_fc.weight"
-                    grads[k] = _wgrad_async(dh[r0:r1], L["lno2"][r0:r1], r1 - r0, out=grads.slot(k, (4 * D, D)))
+                    wide_wgrad(p + ".mlp.c_fc.weight", dh[r0:r1], L["lno2"][r0:r1], r1 - r0, (4 * D, D))
                     grads[p + ".mlp.c_fc.bias"] = gradgemm.on_lane(lambda a=dh[r0:r1]: hip.colsum(a), dh)
                     _dgrad(dh[r0:r1], bw.wfc.t().contiguous(), dlno[r0:r1])
                 del dhid, dh
@@ -331,8 +341,7 @@ class TrainStep:
                 dqkv = torch.zeros(M, 3 * D, dtype=BF, device=dev)
                 for r0, r1, bw in groups:
                     p = names[id(bw)]
-                    k = p + ".attn.out_proj.weight"
-                    grads[k] = _wgrad_async(dY2[r0:r1], L["ao"][r0:r1], r1 - r0, out=grads.slot(k, (D, D)))
+                    wide_wgrad(p + ".attn.out_proj.weight", dY2[r0:r1], L["ao"][r0:r1], r1 - r0, (D, D))
                     grads[p + ".attn.out_proj.bias"] = hip.colsum(dX[r0:r1])
                     _dgrad(dY2[r0:r1], bw.wo.t().contiguous(), dao[r0:r1])
                 if e.vblk[i] is not None:
@@ -343,9 +352,8 @@ class TrainStep:
                     def unscale_q(g):                                                          # packed q rows = 64^-0.5 * W_q
                         g[:D] *= 0.125
                         return g
-                    k = p + ".attn.in_proj_weight"
-                    grads[k] = _wgrad_async(dqkv[r0:r1], L["lno1"][r0:r1], r1 - r0, post=unscale_q,
-                                            out=grads.slot(k, (3 * D, D)))              # wrt the PACKED weight, scaled back
+                    wide_wgrad(p + ".attn.in_proj_weight", dqkv[r0:r1], L["lno1"][r0:r1], r1 - r0, (3 * D, D),
+                               post=unscale_q)                                          # wrt the PACKED weight, scaled back
                     def bias_q(a=dqkv[r0:r1]):
                         g = hip.colsum(a)
                         g[:D] *= 0.125
@@ -390,7 +398,8 @@ class TrainStep:
             grads["visual.positional_embedding"] = dvpos
             grads["visual.class_embedding"] = dvpos[0].clone()
             conv.stem(grads, dtok)
-            gradgemm.join(dev)                                   # the weight gradients queued on the lane stream
+            flush_wgrads()
+            gradgemm.join(dev)                                   # the gradients queued on the lane stream
             sv["w"].pop("held", None)
             self.saved = None
             return reducer.finish() if reducer is not None else dict(grads)
