@@ -33,7 +33,11 @@ extern "C" {
  *   epilogue: v = alpha*acc + bias[n]; act 1 = QuickGELU (M.py:222-224); then
  *   + resid (1: fp32 [m][n], 2: bf16 [m][n], 3: fp32 table row (m % rpg + roff), e.g.
  *   positional embedding); act 2 = ReLU (after the residual); store to row
- *   m + (m / rpg) * radd + roff (token scatter of M.py:2418-2425). */
+ *   m + (m / rpg) * radd + roff (token scatter of M.py:2418-2425).
+ *   Training-step forms (ping-pong kernel only, dense X, N % 8 == 0): out2 != NULL additionally stores v BEFORE the
+ *   activation (bf16, leading dimension ldo) -- c_fc writes the pre-activation the backward needs and QuickGELU(v) in one
+ *   launch; resid_kind 4: v *= QuickGELU'(resid) with resid bf16 [m][n] -- the dgrad GEMM of c_proj applies the activation's
+ *   derivative (d/dh h sigma(1.702 h)) on the saved pre-activation in its epilogue. */
 typedef struct msclip_gemm_desc {
   const void* X;
   const void* W;
@@ -51,6 +55,7 @@ typedef struct msclip_gemm_desc {
   int out_kind;
   float alpha;
   int rpg, radd, roff;   /* rpg > 0; use rpg = INT_MAX, radd = roff = 0 for the identity */
+  void* out2;            /* optional second bf16 output: the epilogue value before the activation (NULL: none) */
   int tile;              /* 0 = auto, 1 = 128x128 (4 waves), 4 = 256x256 ping-pong (what auto picks for large problems; dense X, or implicit conv with Cin % 64 == 0), 5 = streaming kernel with LDS-resident weights (K <= 192, or the 3x3 convolutions with 48 input channels; M >= 4096; auto picks it there), 6 = 256x192 two-buffer (implicit conv with N % 192 == 0), 7 = 4-wave 256x256 kernel with the epilogue carried under the next tile's K loop (dense X, bf16 output, no residual, N % 256 == 0, K >= 576, alpha 1; opt-in: measured slower than 4; EINVAL otherwise), 8 = two 4-wave workgroups per CU on 256x128 tiles (gemm_pp2.hip; dense X; opt-in: measured slower than 4, profiles/r03_gemm_pp2_ab.md) */
 } msclip_gemm_desc;
 

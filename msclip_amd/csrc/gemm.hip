@@ -500,6 +500,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a_i
   constexpr unsigned ES = F8 ? 1u : 2u;            // operand element size in bytes
   constexpr int KT = F8 ? 128 : 64;                // elements per K-tile (128 bytes)
   constexpr int TM = 4, TN = 2;
+  constexpr bool TE = MODE == 0 && !F8;                          // training-step epilogue forms (out2, resid_kind 4) compiled in
   __shared__ __attribute__((aligned(1024))) bf16_t smem[PSLOTS * PREG];
 
   const int tid = threadIdx.x;
@@ -827,17 +828,19 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a_i
         const bool full_n = cn0 + 256 <= a.N;      // no lane's store is predicated off
         const int mw0 = cm0 + wm, nw0 = cn0 + wn;
         const bool pack16 = a.resid_kind == 0 && a.out_kind == 0 && !((a.N | a.ldo) & 7);
-        if (full_n) epi_stores = pack16 && a.act <= 2 ? 4 * TM : 4 * TM * TN;   // 16 / 32 store instructions per wave
+        if (full_n) epi_stores = pack16 && a.act <= 2 ? (a.out2 ? 8 * TM : 4 * TM) : 4 * TM * TN;   // 16 / 32 store instructions per wave
+        if (TE && pack16 && a.out2)                // training forward of c_fc: the pre-activation first, then the activation
+          epilogue_pack16<TM, TN, 0>(acc, a, stg, mw0, nw0, lane_e, bcol, a.out2);
         if (pack16 && a.act == 0)
-          epilogue_pack16<TM, TN, 0>(acc, a, stg, mw0, nw0, lane_e, bcol);               // QKV
+          epilogue_pack16<TM, TN, 0>(acc, a, stg, mw0, nw0, lane_e, bcol, a.out);        // QKV
         else if (pack16 && a.act == 1)
-          epilogue_pack16<TM, TN, 1>(acc, a, stg, mw0, nw0, lane_e, bcol);               // c_fc + QuickGELU
+          epilogue_pack16<TM, TN, 1>(acc, a, stg, mw0, nw0, lane_e, bcol, a.out);        // c_fc + QuickGELU
         else if (pack16 && a.act == 2)
-          epilogue_pack16<TM, TN, 2>(acc, a, stg, mw0, nw0, lane_e, bcol);               // convolution + ReLU
+          epilogue_pack16<TM, TN, 2>(acc, a, stg, mw0, nw0, lane_e, bcol, a.out);        // convolution + ReLU
         else if (a.resid_kind == 1 && a.act == 0 && a.out_kind == 1)
           epilogue_rows<TM, TN, 1, 0, 1>(acc, a, stg, mw0, nw0, lane_e, bias4);          // out_proj / c_proj into the fp32 stream
         else
-          epilogue_rows<TM, TN, -1, -1, -1>(acc, a, stg, mw0, nw0, lane_e, bias4);       // pointwise convolutions, heads
+          epilogue_rows<TM, TN, -1, -1, -1, TE>(acc, a, stg, mw0, nw0, lane_e, bias4);   // pointwise convolutions, heads, training forms
       }
       else
         epilogue_generic16<TM, TN>(acc, a, vec, cm0 + wm, cn0 + wn, lane_e);
@@ -911,11 +914,19 @@ static GemmVariant pick_variant(const msclip_gemm_desc* d) {
   if (d->mode == 1 && (!d->ktab || (d->Cin % 8))) return GV_INVALID;
   if (d->mode != 0 && d->mode != 1) return GV_INVALID;
   if (d->rpg <= 0) return GV_INVALID;
+  if (d->resid_kind < 0 || d->resid_kind > 4) return GV_INVALID;
+  // training-step epilogue forms (second pre-activation output; multiply by QuickGELU'(resid)): ping-pong kernels only,
+  // whole 256-row tiles only (the guarded edge-tile epilogue does not carry them)
+  const bool train_epi = d->out2 || d->resid_kind == 4;
+  if (train_epi && (d->mode != 0 || d->out_kind != 0 || ((d->N | d->ldo) & 7) || (d->M % 256) || (d->out2 && d->resid_kind) ||
+                    (d->resid_kind == 4 && (!d->resid || (d->ldr & 3))) || d->rpg != 0x7fffffff))
+    return GV_INVALID;
+  if (train_epi && d->tile != 4 && d->tile != 8 && d->tile != 0) return GV_INVALID;
   // tile choice: the 256x256 / 8-wave config whenever the problem fills the chip with it, else 128x128
   const long long big_tiles = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256);
   if (d->tile < 0 || d->tile > 8 || d->tile == 2 || d->tile == 3) return GV_INVALID;   // 2, 3: retired main loops
-  const bool big = d->tile >= 4 || (d->tile == 0 && d->N >= 192 && big_tiles >= 128);
-  if ((d->tile == 0 || d->tile == 5) && msclip_gemm_small_eligible(d)) return GV_STREAM;
+  const bool big = d->tile >= 4 || (d->tile == 0 && ((d->N >= 192 && big_tiles >= 128) || train_epi));
+  if ((d->tile == 0 || d->tile == 5) && !train_epi && msclip_gemm_small_eligible(d)) return GV_STREAM;
   if (d->tile == 7) return msclip_gemm_w4_eligible(d) ? GV_W4 : GV_INVALID;
   if (d->tile == 8) return msclip_gemm_pp2_eligible(d) ? GV_PP2 : GV_INVALID;
   // (the 4-wave kernel with the carried epilogue, gemm_w4.hip, is opt-in through tile = 7: its main loop matches the
@@ -929,6 +940,7 @@ static GemmVariant pick_variant(const msclip_gemm_desc* d) {
                        big_tiles * ((d->M + 255) / 256) * 4 < (1ll << 32);
     if (pp_ok && d->tile == 0 && big && pp2_auto() == 1 && msclip_gemm_pp2_eligible(d)) return GV_PP2;
     if (pp_ok && (d->tile == 4 || (d->tile == 0 && big))) return GV_PP;     // ping-pong kernel (default for the projections)
+    if (train_epi) return GV_INVALID;          // (offsets beyond the ping-pong kernel's 32-bit addressing)
     return GV_DENSE128;                        // small problems, heads, logits (and tile 1)
   }
   // input channels a multiple of 64 (a K-tile stays inside one filter tap): the ping-pong kernel gathers the rows itself

@@ -46,7 +46,13 @@ __device__ __forceinline__ uint2 ld_global_u2(const void* p) {
   return make_uint2(v[0], v[1]);
 }
 
-template <int TM, int TN, int RK, int ACT, int OUTK>
+// d/dh [h sigma(1.702 h)] = s + 1.702 h s (1 - s), s = sigma(1.702 h)   (M.py:222-224)
+__device__ __forceinline__ float quickgelu_grad(float h) {
+  const float s = 1.f / (1.f + __expf(-1.702f * h));
+  return s + 1.702f * h * s * (1.f - s);
+}
+
+template <int TM, int TN, int RK, int ACT, int OUTK, bool TE = false>     // TE: the training-step forms are compiled in
 __device__ __forceinline__ void epilogue_rows(f32x4 (&acc)[2 * TN][2 * TM], const msclip_gemm_desc& a, unsigned stg,
                                               int mw0, int nw0, int lane, const float4 (&bias4)[TN]) {
   // accumulator layout of v_mfma_f32_16x16x32 with swapped operands: acc[ni][mi][r] = C[mi*16 + lane%16][ni*16 + 4*(lane/16) + r]
@@ -115,6 +121,10 @@ __device__ __forceinline__ void epilogue_rows(f32x4 (&acc)[2 * TN][2 * TM], cons
       if (rk == 1) {
         const float4 r = rv[b % RAHEAD][i];
         v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+      } else if (TE && rk == 4) {                                    // v *= QuickGELU'(h), h = the bf16 "residual" (training dgrad)
+        const unsigned ux = __float_as_uint(rv[b % RAHEAD][i].x), uy = __float_as_uint(rv[b % RAHEAD][i].y);
+        v.x *= quickgelu_grad(__uint_as_float(ux << 16)); v.y *= quickgelu_grad(__uint_as_float(ux & 0xffff0000u));
+        v.z *= quickgelu_grad(__uint_as_float(uy << 16)); v.w *= quickgelu_grad(__uint_as_float(uy & 0xffff0000u));
       } else if (rk) {
         const unsigned ux = __float_as_uint(rv[b % RAHEAD][i].x), uy = __float_as_uint(rv[b % RAHEAD][i].y);
         v.x += __uint_as_float(ux << 16); v.y += __uint_as_float(ux & 0xffff0000u);
@@ -155,7 +165,7 @@ __device__ __forceinline__ u32x4 stg_read16u(unsigned addr) {
 
 template <int TM, int TN, int ACT>
 __device__ __forceinline__ void epilogue_pack16(f32x4 (&acc)[2 * TN][2 * TM], const msclip_gemm_desc& a, unsigned stg,
-                                                int mw0, int nw0, int lane, float bcol) {
+                                                int mw0, int nw0, int lane, float bcol, void* outp) {
   static_assert(TN == 2, "64 bf16 columns = one 128-byte staged row");
   const int r16 = lane & 15, quad = lane >> 4;
   const int srow = lane >> 3, sch = lane & 7;
@@ -216,7 +226,7 @@ __device__ __forceinline__ void epilogue_pack16(f32x4 (&acc)[2 * TN][2 * TM], co
     const size_t row = (size_t)(mw0 + tm * 32 + i * 8 + srow);
     // non-temporal: the tile leaves faster (QKV 262 -> 249 us, c_fc 378 -> 365 us; +0.7 % on the step), the fp32
     // stream of out_proj / c_proj stays cacheable for the LayerNorm that follows
-    if (n < a.N) __builtin_nontemporal_store(v, (AS1 u32x4*)((bf16_t*)a.out + row * a.ldo + n));
+    if (n < a.N) __builtin_nontemporal_store(v, (AS1 u32x4*)((bf16_t*)outp + row * a.ldo + n));
   };
 #pragma unroll
   for (int q = 0; q < 4; ++q) quarter(0, q);

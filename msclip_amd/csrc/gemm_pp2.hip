@@ -52,6 +52,7 @@ __device__ unsigned long long p2_trace_buf[1024 * P2_TRACE_N];
 
 __global__ __launch_bounds__(256, 2) void gemm_pp2_kernel(const msclip_gemm_desc a, const int delay_mode, const int delay_unit) {
   constexpr int TM = 4, TN = 2;
+  constexpr bool TE = true;                          // training-step epilogue forms (out2, resid_kind 4) compiled in
   __shared__ __attribute__((aligned(1024))) bf16_t smem[P2_SLOTS * P2_REG];   // 80 KiB: two workgroups per CU
 
   const int tid = threadIdx.x;
@@ -323,17 +324,19 @@ __global__ __launch_bounds__(256, 2) void gemm_pp2_kernel(const msclip_gemm_desc
       if (vec && plain_rows && cm0 + 256 <= a.M) {
         const bool full_n = cn0 + 128 <= a.N;      // no lane's store is predicated off
         const bool pack16 = a.resid_kind == 0 && a.out_kind == 0 && !((a.N | a.ldo) & 7);
-        if (full_n) stores = pack16 && a.act <= 2 ? 4 * TM : 4 * TM * TN;   // 16 / 32 store instructions per wave
+        if (full_n) stores = pack16 && a.act <= 2 ? (a.out2 ? 8 * TM : 4 * TM) : 4 * TM * TN;   // 16 / 32 store instructions per wave
+        if (TE && pack16 && a.out2)
+          epilogue_pack16<TM, TN, 0>(acc, a, stg, mw0, nw0, lane_e, bcol, a.out2);
         if (pack16 && a.act == 0)
-          epilogue_pack16<TM, TN, 0>(acc, a, stg, mw0, nw0, lane_e, bcol);               // QKV
+          epilogue_pack16<TM, TN, 0>(acc, a, stg, mw0, nw0, lane_e, bcol, a.out);        // QKV
         else if (pack16 && a.act == 1)
-          epilogue_pack16<TM, TN, 1>(acc, a, stg, mw0, nw0, lane_e, bcol);               // c_fc + QuickGELU
+          epilogue_pack16<TM, TN, 1>(acc, a, stg, mw0, nw0, lane_e, bcol, a.out);        // c_fc + QuickGELU
         else if (pack16 && a.act == 2)
-          epilogue_pack16<TM, TN, 2>(acc, a, stg, mw0, nw0, lane_e, bcol);
+          epilogue_pack16<TM, TN, 2>(acc, a, stg, mw0, nw0, lane_e, bcol, a.out);
         else if (a.resid_kind == 1 && a.act == 0 && a.out_kind == 1)
           epilogue_rows<TM, TN, 1, 0, 1>(acc, a, stg, mw0, nw0, lane_e, bias4);          // out_proj / c_proj into the fp32 stream
         else
-          epilogue_rows<TM, TN, -1, -1, -1>(acc, a, stg, mw0, nw0, lane_e, bias4);
+          epilogue_rows<TM, TN, -1, -1, -1, TE>(acc, a, stg, mw0, nw0, lane_e, bias4);
       } else {
         epilogue_generic16<TM, TN>(acc, a, vec, mw0, nw0, lane_e);
       }

@@ -51,7 +51,7 @@ class GemmDesc(ctypes.Structure):
         ("ktab", ctypes.c_void_p),
         ("act", ctypes.c_int), ("resid_kind", ctypes.c_int), ("out_kind", ctypes.c_int),
         ("alpha", ctypes.c_float),
-        ("rpg", ctypes.c_int), ("radd", ctypes.c_int), ("roff", ctypes.c_int), ("tile", ctypes.c_int),
+        ("rpg", ctypes.c_int), ("radd", ctypes.c_int), ("roff", ctypes.c_int), ("out2", ctypes.c_void_p), ("tile", ctypes.c_int),
     ]
 
 
@@ -314,13 +314,14 @@ def set_gemm_probe(variant, probe):
 
 
 ACT_NONE, ACT_QUICKGELU, ACT_RELU = 0, 1, 2
-RESID_NONE, RESID_F32, RESID_BF16, RESID_TABLE = 0, 1, 2, 3
+RESID_NONE, RESID_F32, RESID_BF16, RESID_TABLE, RESID_GELUGRAD = 0, 1, 2, 3, 4
 
 
 def gemm(x, w, out, *, M=None, bias=None, resid=None, resid_kind=0, act=0, alpha=1.0, conv=None, ktab=None,
-         ldx=None, ldo=None, ldr=None, rpg=INT_MAX, radd=0, roff=0, N=None, tile=0):
+         ldx=None, ldo=None, ldr=None, rpg=INT_MAX, radd=0, roff=0, N=None, tile=0, out2=None):
     """out = epilogue(alpha * x @ w^T).  x: bf16 [M, K] (or NHWC activation when conv=(H, W, Cin, Ho, Wo, stride, pad)),
-    w: bf16 [N, Kpad]; out: bf16 or fp32 2-D buffer."""
+    w: bf16 [N, Kpad]; out: bf16 or fp32 2-D buffer.  Training-step forms (ping-pong kernel): out2 = second bf16 output that
+    receives the value before the activation; resid_kind = RESID_GELUGRAD multiplies by QuickGELU'(resid) (resid bf16)."""
     _bf16(w)
     d = GemmDesc()
     d.X, d.W, d.zero, d.out = x.data_ptr(), w.data_ptr(), zero_page(x.device).data_ptr(), out.data_ptr()
@@ -345,6 +346,9 @@ def gemm(x, w, out, *, M=None, bias=None, resid=None, resid_kind=0, act=0, alpha
     d.alpha = alpha
     d.rpg, d.radd, d.roff = rpg, radd, roff
     d.tile = tile
+    if out2 is not None:
+        assert out2.dtype == torch.bfloat16 and out2.stride(0) == d.ldo and out.dtype == torch.bfloat16
+        d.out2 = out2.data_ptr()
     probe = (_gemm_probe.get(d.mode) or _gemm_probe.get(gemm_variant(d))) if _gemm_probe else None
     if probe is not None:
         k_alg = d.K if conv is None else conv[2] * (ktab_taps(ktab) if ktab is not None else 1)
@@ -352,8 +356,8 @@ def gemm(x, w, out, *, M=None, bias=None, resid=None, resid_kind=0, act=0, alpha
         _check(lib().msclip_gemm(ctypes.byref(d), _stream()), "msclip_gemm")
         esz = 4 if d.out_kind else 2
         x_bytes = d.M * d.K * 2 if conv is None else (d.M // (conv[3] * conv[4])) * conv[0] * conv[1] * conv[2] * 2
-        r_bytes = {RESID_NONE: 0, RESID_F32: d.M * d.N * 4, RESID_BF16: d.M * d.N * 2, RESID_TABLE: 0}[resid_kind]
-        nbytes = x_bytes + d.N * d.K * 2 + d.M * d.N * esz + r_bytes + (d.N * 4 if bias is not None else 0)
+        r_bytes = {RESID_NONE: 0, RESID_F32: d.M * d.N * 4, RESID_BF16: d.M * d.N * 2, RESID_TABLE: 0, RESID_GELUGRAD: d.M * d.N * 2}[resid_kind]
+        nbytes = x_bytes + d.N * d.K * 2 + d.M * d.N * esz * (2 if out2 is not None else 1) + r_bytes + (d.N * 4 if bias is not None else 0)
         probe.end(t0, 2.0 * d.M * d.N * k_alg, (d.M, d.N, d.K, k_alg, conv is not None, act, resid_kind, d.out_kind), nbytes)
         return out
     _check(lib().msclip_gemm(ctypes.byref(d), _stream()), "msclip_gemm")

@@ -152,12 +152,16 @@ class TrainStep:
                 h = torch.empty(M, 4 * D, dtype=BF, device=e.dev)
                 hid = torch.empty(M, 4 * D, dtype=BF, device=e.dev)
                 for r0, r1, bw in groups:
-                    hip.gemm(lno2[r0:r1], bw.wfc, h[r0:r1], bias=bw.bfc)                      # pre-activation is kept
-                hip.quickgelu(h[r_lo:M], hid[r_lo:M])
+                    if (r1 - r0) % 256 == 0:
+                        # ONE launch writes the pre-activation (the backward's QuickGELU' needs it) and the activation
+                        # (the ping-pong kernel's training forms cover whole 256-row tiles: any other row count takes two launches)
+                        hip.gemm(lno2[r0:r1], bw.wfc, hid[r0:r1], bias=bw.bfc, act=hip.ACT_QUICKGELU, out2=h[r0:r1])
+                    else:
+                        hip.gemm(lno2[r0:r1], bw.wfc, h[r0:r1], bias=bw.bfc)
+                        hip.quickgelu(h[r0:r1], hid[r0:r1])
                 for r0, r1, bw in groups:
                     hip.gemm(hid[r0:r1], bw.wpr, X[r0:r1], bias=bw.bpr, resid=X[r0:r1], resid_kind=hip.RESID_F32)
-                L.update(r_lo=r_lo, segs=segs, groups=groups, lno1=lno1, qkv=qkv, ao=ao, lno2=lno2, h=h)
-                del hid
+                L.update(r_lo=r_lo, segs=segs, groups=groups, lno1=lno1, qkv=qkv, ao=ao, lno2=lno2, h=h, hid=hid)
                 sv["layers"][i] = L
             e.force_unfused = False
             if cb is not None:
@@ -308,11 +312,9 @@ class TrainStep:
                 names = {id(e.tblk[i]["w"]): f"transformer.resblocks.{i}"}
                 if e.vblk[i] is not None:                    # shared tensors live under their visual.* name (one Parameter)
                     names[id(e.vblk[i]["w"])] = f"visual.transformer.resblocks.{i}"
-                hid = torch.empty(M, 4 * D, dtype=BF, device=dev)
-                hip.quickgelu(L["h"][r_lo:M], hid[r_lo:M])                                     # recomputed, not stored
+                hid = L["hid"]
                 dY = torch.empty(M, D, dtype=BF, device=dev)
                 hip.cast_bf16(dX[r_lo:M], dY[r_lo:M])
-                dhid = torch.empty(M, 4 * D, dtype=BF, device=dev)
                 # gradients of the LayerNorm outputs stay fp32: they are only read by the LayerNorm backward, whose dbeta /
                 # dgamma are column sums of nearly cancelling terms (a bf16 dy costs 10-30 % on those sums at small batch)
                 dlno = torch.empty(M, D, dtype=F32, device=dev)
@@ -320,16 +322,21 @@ class TrainStep:
                     p = names[id(bw)]
                     wide_wgrad(p + ".mlp.c_proj.weight", dY[r0:r1], hid[r0:r1], r1 - r0, (D, 4 * D))
                     grads[p + ".mlp.c_proj.bias"] = hip.colsum(dX[r0:r1])
-                    _dgrad(dY[r0:r1], bw.wpr.t().contiguous(), dhid[r0:r1])
-                del hid
                 dh = torch.empty(M, 4 * D, dtype=BF, device=dev)
-                hip.quickgelu_bwd(L["h"][r_lo:M], dhid[r_lo:M], dh[r_lo:M])
+                for r0, r1, bw in groups:
+                    if (r1 - r0) % 256 == 0:
+                        # dh = (dY . W_proj) * QuickGELU'(h): the activation's derivative in the dgrad GEMM's epilogue
+                        hip.gemm(dY[r0:r1], bw.wpr.t().contiguous(), dh[r0:r1], resid=L["h"][r0:r1], resid_kind=hip.RESID_GELUGRAD)
+                    else:
+                        dhid = _dgrad(dY[r0:r1], bw.wpr.t().contiguous())
+                        hip.quickgelu_bwd(L["h"][r0:r1], dhid, dh[r0:r1])
+                del hid
                 for r0, r1, bw in groups:
                     p = names[id(bw)]
                     wide_wgrad(p + ".mlp.c_fc.weight", dh[r0:r1], L["lno2"][r0:r1], r1 - r0, (4 * D, D))
                     grads[p + ".mlp.c_fc.bias"] = gradgemm.on_lane(lambda a=dh[r0:r1]: hip.colsum(a), dh)
                     _dgrad(dh[r0:r1], bw.wfc.t().contiguous(), dlno[r0:r1])
-                del dhid, dh
+                del dh
                 for r0, r1, b in segs:
                     pre = f"visual.transformer.resblocks.{i}" if b is e.vblk[i] else f"transformer.resblocks.{i}"
                     dg, db = hip.layernorm_bwd(L["x_mid"][r0 - r_lo:r1 - r_lo], dlno[r0:r1], b["ln2"].g, dX[r0:r1], r1 - r0)

@@ -750,3 +750,28 @@ def test_layernorm_f8_and_row_quant(gpu_device, C):
     close(s, xb.float().abs().amax(1) / 448.0, 0.0, 1e-5)
     ref_q, _ = hip.quantize_rows_f8(xb)                                          # torch's own e4m3 rounding of the same scaled values
     assert (q != ref_q).float().mean().item() < 1e-3                              # (1/s vs division: a rare last-bit tie)
+
+
+@pytest.mark.parametrize("tile", [0, 4, 8])
+@pytest.mark.parametrize("M,N,K", [(768, 520, 128), (2048, 1096, 768), (256 * 9, 3072, 768)])
+def test_gemm_training_epilogue_forms(gpu_device, tile, M, N, K):
+    """The ping-pong kernels' training-step epilogues: out2 = the value BEFORE the activation beside QuickGELU(value) from one
+    launch (c_fc's forward), and resid_kind 4 = multiply by QuickGELU'(h) (c_proj's dgrad); whole 256-row tiles (any other
+    M is rejected: the guarded edge epilogue does not carry these forms), ragged N."""
+    x, w, b = rnd(M, K, seed=31, dtype=BF), rnd(N, K, seed=32, scale=0.05, dtype=BF), rnd(N, seed=33)
+    pre = x.float() @ w.float().t() + b
+    out = torch.full((M + 1, N), float("nan"), dtype=BF, device="cuda")
+    out2 = torch.full((M + 1, N), float("nan"), dtype=BF, device="cuda")
+    hip.gemm(x, w, out[:M], bias=b, act=hip.ACT_QUICKGELU, out2=out2[:M], tile=tile)
+    close(out2[:M], pre, 2e-2, 1e-2)
+    close(out[:M], pre * torch.sigmoid(1.702 * pre), 2e-2, 1e-2)
+    assert bool(torch.isnan(out[M:].float()).all()) and bool(torch.isnan(out2[M:].float()).all())
+    h = rnd(M, N, seed=34, scale=1.5, dtype=BF)
+    s = torch.sigmoid(1.702 * h.float())
+    ref = (x.float() @ w.float().t()) * (s + 1.702 * h.float() * s * (1 - s))
+    dh = torch.full((M + 1, N), float("nan"), dtype=BF, device="cuda")
+    hip.gemm(x, w, dh[:M], resid=h, resid_kind=hip.RESID_GELUGRAD, tile=tile)
+    close(dh[:M], ref, 2e-2, 1e-2)
+    assert bool(torch.isnan(dh[M:].float()).all())
+    assert hip.gemm_variant(hip.describe_gemm(0, M, N, K, tile=1, resid_kind=hip.RESID_GELUGRAD)) == "invalid"   # other kernels reject it
+    assert hip.gemm_variant(hip.describe_gemm(0, M + 8, N, K, resid_kind=hip.RESID_GELUGRAD)) == "invalid"       # ... and so do ragged M
