@@ -107,7 +107,10 @@ class TrainStep:
             sv["tok_pre"] = keep[0]
             g2 = e.g * e.g
             e._text_front(sv["tok"], w, Bt)
-            # ---- blocks
+            # ---- blocks.  Xc = the residual matrix the next layer reads: the workspace's X at first; every layer that runs over
+            # all rows writes its two residual updates into fresh matrices (the backward needs the layer's input and its
+            # post-attention state: they stay where they are instead of being cloned), so Xc moves on.
+            Xc = X
             for i in range(e.n_layers):
                 vb = e.vblk[i]
                 tb = e.tblk[i]
@@ -119,21 +122,23 @@ class TrainStep:
                     if cb is not None:
                         cb.stage(j)
                         cb.adapter_top(j, w["T"])
-                        cb.adapter_sum(j, X[:Mv], w["T"], asum)
+                        cb.adapter_sum(j, Xc[:Mv], w["T"], asum)
                     else:
                         e._parallel_stage(j, w, Bi)
                         hip.dwpool(w["par"][j], a["pool"], w["pool"][j], Bi, e.par_hw[j], e.par_hw[j], a["C"], a["k"])
                         hip.gemm(w["pool"][j], a["pw"].weight, w["T"], M=Bi * g2, N=a["pw"].cout, bias=a["pw"].bias, ldx=a["pw"].cin)
-                        hip.adapter_sum(X[:Mv], w["T"], a["dww"], a["dwb"], asum, Bi, e.Lv, e.g, e.usecls)
-                    x_pre = X[:Mv].clone()                                                   # what the depthwise 3x3 read
-                    hip.layernorm(asum, a["ln"].g, a["ln"].b, X[:Mv], Mv)                    # X[:Mv] <- ln_adapt(sum), fp32
+                        hip.adapter_sum(Xc[:Mv], w["T"], a["dww"], a["dwb"], asum, Bi, e.Lv, e.g, e.usecls)
+                    x_pre = Xc[:Mv].clone()                                                   # what the depthwise 3x3 read
+                    hip.layernorm(asum, a["ln"].g, a["ln"].b, Xc[:Mv], Mv)                    # X[:Mv] <- ln_adapt(sum), fp32
                     L["adapter"] = dict(j=j, sum=asum, x_pre=x_pre)
                 segs = ([(0, Mv, vb)] if vb is not None else []) + [(Mv, M, tb)]
                 r_lo = segs[0][0]
-                L["x_in"] = X[r_lo:M].clone()
+                fresh = r_lo == 0                         # (text block 0 leaves the image rows alone: in place, cloned)
+                L["x_in"] = Xc if fresh else Xc[r_lo:M].clone()
+                XM = torch.empty(M, D, dtype=F32, device=e.dev) if fresh else Xc
                 lno1 = torch.empty(M, D, dtype=BF, device=e.dev)
                 for r0, r1, b in segs:
-                    hip.layernorm(X[r0:r1], b["ln1"].g, b["ln1"].b, lno1[r0:r1], r1 - r0)
+                    hip.layernorm(Xc[r0:r1], b["ln1"].g, b["ln1"].b, lno1[r0:r1], r1 - r0)
                 groups = [(r_lo, M, segs[0][2]["w"])] if len(segs) == 2 and vb["w"] is tb["w"] else \
                          [(r0, r1, b["w"]) for r0, r1, b in segs]
                 qkv = torch.empty(M, 3 * D, dtype=BF, device=e.dev)
@@ -144,11 +149,12 @@ class TrainStep:
                     hip.attention(qkv[:Mv], ao[:Mv], Bi, e.Lv, e.heads, False)
                 hip.attention(qkv[Mv:M], ao[Mv:M], Bt, e.Lt, e.heads, True)
                 for r0, r1, bw in groups:
-                    hip.gemm(ao[r0:r1], bw.wo, X[r0:r1], bias=bw.bo, resid=X[r0:r1], resid_kind=hip.RESID_F32)
-                L["x_mid"] = X[r_lo:M].clone()
+                    hip.gemm(ao[r0:r1], bw.wo, XM[r0:r1], bias=bw.bo, resid=Xc[r0:r1], resid_kind=hip.RESID_F32)
+                L["x_mid"] = XM if fresh else XM[r_lo:M].clone()
+                XN = torch.empty(M, D, dtype=F32, device=e.dev) if fresh else Xc
                 lno2 = torch.empty(M, D, dtype=BF, device=e.dev)
                 for r0, r1, b in segs:
-                    hip.layernorm(X[r0:r1], b["ln2"].g, b["ln2"].b, lno2[r0:r1], r1 - r0)
+                    hip.layernorm(XM[r0:r1], b["ln2"].g, b["ln2"].b, lno2[r0:r1], r1 - r0)
                 h = torch.empty(M, 4 * D, dtype=BF, device=e.dev)
                 hid = torch.empty(M, 4 * D, dtype=BF, device=e.dev)
                 for r0, r1, bw in groups:
@@ -160,16 +166,21 @@ class TrainStep:
                         hip.gemm(lno2[r0:r1], bw.wfc, h[r0:r1], bias=bw.bfc)
                         hip.quickgelu(h[r0:r1], hid[r0:r1])
                 for r0, r1, bw in groups:
-                    hip.gemm(hid[r0:r1], bw.wpr, X[r0:r1], bias=bw.bpr, resid=X[r0:r1], resid_kind=hip.RESID_F32)
+                    hip.gemm(hid[r0:r1], bw.wpr, XN[r0:r1], bias=bw.bpr, resid=XM[r0:r1], resid_kind=hip.RESID_F32)
                 L.update(r_lo=r_lo, segs=segs, groups=groups, lno1=lno1, qkv=qkv, ao=ao, lno2=lno2, h=h, hid=hid)
                 sv["layers"][i] = L
+                Xc = XN
             e.force_unfused = False
             if cb is not None:
                 cb.update_running_stats()
             # ---- heads + loss
-            sv["x_out"] = X[:M].clone()
-            e._head_image(w, Bi)
-            e._head_text(w, Bt)
+            sv["x_out"] = Xc if Xc is not X else X[:M].clone()
+            w["X"] = Xc                              # the heads read the final residual matrix
+            try:
+                e._head_image(w, Bi)
+                e._head_text(w, Bt)
+            finally:
+                w["X"] = X
             sv.update(hv=w["hv"].clone(), ht=w["ht"].clone(), fv_raw=w["fv_raw"].clone(), ft_raw=w["ft_raw"].clone(),
                       fv=w["fv"].clone(), ft=w["ft"].clone(), fvb=w["fvb"].clone(), ftb=w["ftb"].clone(), eot=w["eot"].clone())
             # ---- loss.  The inference path forms its logits from bf16 unit features (error ~0.03 on a logit at T = 1/0.07:
