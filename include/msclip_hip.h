@@ -56,6 +56,7 @@ typedef struct msclip_gemm_desc {
   float alpha;
   int rpg, radd, roff;   /* rpg > 0; use rpg = INT_MAX, radd = roff = 0 for the identity */
   void* out2;            /* optional second bf16 output: the epilogue value before the activation (NULL: none) */
+  float out_scale;       /* out_kind 2 (e4m3 output, msclip_gemm_f8 only): stored value = fp8(epilogue value * out_scale), saturating */
   int tile;              /* 0 = auto, 1 = 128x128 (4 waves), 4 = 256x256 ping-pong (what auto picks for large problems; dense X, or implicit conv with Cin % 64 == 0), 5 = streaming kernel with LDS-resident weights (K <= 192, or the 3x3 convolutions with 48 input channels; M >= 4096; auto picks it there), 6 = 256x192 two-buffer (implicit conv with N % 192 == 0), 7 = 4-wave 256x256 kernel with the epilogue carried under the next tile's K loop (dense X, bf16 output, no residual, N % 256 == 0, K >= 576, alpha 1; opt-in: measured slower than 4; EINVAL otherwise), 8 = two 4-wave workgroups per CU on 256x128 tiles (gemm_pp2.hip; dense X; opt-in: measured slower than 4, profiles/r03_gemm_pp2_ab.md) */
 } msclip_gemm_desc;
 
@@ -70,7 +71,9 @@ int msclip_gemm_splitk(const msclip_gemm_desc* desc, int slices, void* stream);
  * unit block scales (BASELINE config C5; the reference has no fp8 semantics).  desc->X [M, K] and desc->W [N, K] are e4m3 BYTES
  * (ldx / ldw in bytes, multiples of 16; K a multiple of 128; mode 0 only); row_scale [M] and col_scale [N] are the fp32
  * per-row scales of X and W: out = epilogue(alpha * row_scale[m] * col_scale[n] * sum_k X[m, k] W[n, k]), same bias /
- * activation / residual / output kinds as msclip_gemm.  Replaces F.linear (M.py:612, 794) when MODEL.SPEC.PRECISION is fp8. */
+ * activation / residual / output kinds as msclip_gemm, plus out_kind 2: an e4m3 output scaled by desc->out_scale (no residual;
+ * M % 256 == 0, N and ldo multiples of 16) -- c_fc writes the MLP hidden matrix as the fp8 operand of c_proj with one static,
+ * calibrated scale per tensor.  Replaces F.linear (M.py:612, 794, 798) when MODEL.SPEC.PRECISION is fp8. */
 int msclip_gemm_f8(const msclip_gemm_desc* desc, const float* row_scale, const float* col_scale, void* stream);
 
 /* LayerNorm (M.py:204-219; parameters (gamma, beta) for rows < split, (gamma2, beta2) from there on) straight to e4m3 with one

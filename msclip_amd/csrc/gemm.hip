@@ -828,6 +828,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a_i
         const bool full_n = cn0 + 256 <= a.N;      // no lane's store is predicated off
         const int mw0 = cm0 + wm, nw0 = cn0 + wn;
         const bool pack16 = a.resid_kind == 0 && a.out_kind == 0 && !((a.N | a.ldo) & 7);
+        if (F8 && a.out_kind == 2) {               // e4m3 output with a static scale (c_fc -> the fp8 operand of c_proj)
+          if (full_n) epi_stores = 2 * TM;
+          if (a.act == 1) epilogue_pack8<TM, TN, 1>(acc, a, stg, mw0, nw0, lane_e, bcol, a.out_scale);
+          else epilogue_pack8<TM, TN, 0>(acc, a, stg, mw0, nw0, lane_e, bcol, a.out_scale);
+        } else {
         if (full_n) epi_stores = pack16 && a.act <= 2 ? (a.out2 ? 8 * TM : 4 * TM) : 4 * TM * TN;   // 16 / 32 store instructions per wave
         if (TE && pack16 && a.out2)                // training forward of c_fc: the pre-activation first, then the activation
           epilogue_pack16<TM, TN, 0>(acc, a, stg, mw0, nw0, lane_e, bcol, a.out2);
@@ -841,6 +846,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a_i
           epilogue_rows<TM, TN, 1, 0, 1>(acc, a, stg, mw0, nw0, lane_e, bias4);          // out_proj / c_proj into the fp32 stream
         else
           epilogue_rows<TM, TN, -1, -1, -1, TE>(acc, a, stg, mw0, nw0, lane_e, bias4);   // pointwise convolutions, heads, training forms
+        }
       }
       else
         epilogue_generic16<TM, TN>(acc, a, vec, cm0 + wm, cn0 + wn, lane_e);
@@ -914,7 +920,7 @@ static GemmVariant pick_variant(const msclip_gemm_desc* d) {
   if (d->mode == 1 && (!d->ktab || (d->Cin % 8))) return GV_INVALID;
   if (d->mode != 0 && d->mode != 1) return GV_INVALID;
   if (d->rpg <= 0) return GV_INVALID;
-  if (d->resid_kind < 0 || d->resid_kind > 4) return GV_INVALID;
+  if (d->resid_kind < 0 || d->resid_kind > 4 || d->out_kind < 0 || d->out_kind > 1) return GV_INVALID;   // (e4m3 outputs: msclip_gemm_f8)
   // training-step epilogue forms (second pre-activation output; multiply by QuickGELU'(resid)): ping-pong kernels only,
   // whole 256-row tiles only (the guarded edge-tile epilogue does not carry them)
   const bool train_epi = d->out2 || d->resid_kind == 4;
@@ -985,7 +991,9 @@ extern "C" int msclip_gemm_splitk(const msclip_gemm_desc* d, int slices, void* s
 extern "C" int msclip_gemm_f8(const msclip_gemm_desc* d, const float* row_scale, const float* col_scale, void* stream) {
   if (!d || !d->X || !d->W || !d->out || !d->zero || !row_scale || !col_scale) return MSCLIP_EINVAL;
   if (d->mode != 0 || d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->K % 128) || (d->ldx % 16) || (d->ldw % 16) || d->ldx < d->K ||
-      d->ldw < d->K || d->rpg <= 0)
+      d->ldw < d->K || d->rpg != 0x7fffffff || d->out2 || d->out_kind < 0 || d->out_kind > 2 || d->resid_kind < 0 || d->resid_kind > 2)
+    return MSCLIP_EINVAL;
+  if (d->out_kind == 2 && ((d->M % 256) || (d->N % 16) || (d->ldo % 16) || d->resid_kind || !(d->out_scale > 0.f)))
     return MSCLIP_EINVAL;
   const long long tiles = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256);
   if ((long long)d->ldx * 256 + d->K >= (1ll << 31) || (long long)d->ldw * 256 + d->K >= (1ll << 31) ||

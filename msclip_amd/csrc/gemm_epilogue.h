@@ -253,6 +253,66 @@ __device__ __forceinline__ void epilogue_pack16(f32x4 (&acc)[2 * TN][2 * TM], co
   }
 }
 
+// e4m3 outputs (the fp8 instantiation only: c_fc under MODEL.SPEC.PRECISION fp8 writes the MLP hidden matrix as the fp8 operand
+// of c_proj).  out[m][n] = fp8(act(alpha acc + bias) * qscale) with ONE static scale per tensor (calibrated, engine.py); values
+// beyond the calibrated range saturate at the format's largest finite value.  A 32-row x 64-column block of the wave is 2 KiB of
+// bytes: staged with an 80-byte row stride (16-byte aligned read-back, 2-way bank aliasing on the 4-byte writes costs nothing),
+// read back as 16 bytes per lane, stored as 64-byte row segments (the wave's 64 columns of a row).
+__device__ __forceinline__ void stg_write4(unsigned addr, int v) {
+  asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+template <int TM, int TN, int ACT>
+__device__ __forceinline__ void epilogue_pack8(f32x4 (&acc)[2 * TN][2 * TM], const msclip_gemm_desc& a, unsigned stg,
+                                               int mw0, int nw0, int lane, float bcol, float qscale) {
+  static_assert(TN == 2, "64 e4m3 columns = one 64-byte staged row");
+  const int r16 = lane & 15, quad = lane >> 4;
+  const unsigned wr = stg + r16 * 80 + quad * 4;                 // + mi * 1280 + ni * 16
+  const int srow = lane >> 2, sch = lane & 3;                    // read-back: rows srow, srow + 16; 16-byte chunk sch
+  const unsigned rd = stg + srow * 80 + sch * 16;
+  float b[4][4];
+  {
+    const int src = __float_as_int(bcol), base = quad * 16;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        b[ni][r] = __int_as_float(__builtin_amdgcn_ds_bpermute(base + (ni * 16 + r) * 4, src));
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][2]), "+v"(b[0][3]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[1][2]),
+                   "+v"(b[1][3]), "+v"(b[2][0]), "+v"(b[2][1]), "+v"(b[2][2]), "+v"(b[2][3]), "+v"(b[3][0]), "+v"(b[3][1]),
+                   "+v"(b[3][2]), "+v"(b[3][3])
+                 :
+                 : "memory");
+  }
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = acc[ni][2 * tm + mi][e] * a.alpha + b[ni][e];
+          if (ACT == 1) v[e] = v[e] / (1.f + __expf(-1.702f * v[e]));
+          if (ACT == 2) v[e] = fmaxf(v[e], 0.f);
+          v[e] = fminf(fmaxf(v[e] * qscale, -448.f), 448.f);
+        }
+        int p = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+        p = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], p, true);
+        stg_write4(wr + mi * 1280 + ni * 16, p);
+      }
+    u32x4 x0 = stg_read16u<0>(rd), x1 = stg_read16u<1280>(rd);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0), "+v"(x1)::"memory");
+    const int n = nw0 + sch * 16;
+    if (n < a.N) {
+      const size_t row = (size_t)(mw0 + tm * 32 + srow);
+      __builtin_nontemporal_store(x0, (AS1 u32x4*)((unsigned char*)a.out + row * a.ldo + n));
+      __builtin_nontemporal_store(x1, (AS1 u32x4*)((unsigned char*)a.out + (row + 16) * a.ldo + n));
+    }
+  }
+}
+
 // Edge tiles of the ping-pong kernel (rows past M, ragged N, unaligned leading dimensions): guarded, straight from the
 // 16 x 16 accumulator layout (lane owns row mi*16 + lane%16, columns ni*16 + 4*(lane/16) + 0..3).
 template <int TM, int TN>

@@ -51,6 +51,11 @@ class _BlockW:
             wq[:d] *= 0.125
             self.wqkv_q, self.wqkv_s = hip.quantize_rows_f8(wq)
             self.wfc_q, self.wfc_s = hip.quantize_rows_f8(blk.mlp.c_fc.weight.detach())
+            self.wpr_q, self.wpr_s = hip.quantize_rows_f8(blk.mlp.c_proj.weight.detach())
+            # static scale of the MLP hidden matrix (c_fc's e4m3 output = c_proj's operand): calibrated on the first batch
+            # this layer sees (Engine._mlp_f8), None until then
+            self.hid_scale = None
+            self.wpr_cs = None
         bf = torch.bfloat16
         self.wo = blk.attn.out_proj.weight.detach().to(bf).contiguous()
         self.bo = blk.attn.out_proj.bias.detach().float().contiguous()
@@ -238,9 +243,11 @@ class Engine:
         w = dict(Mv=Mv, Mt=Mt, M=M)
         w["X"] = buf(M, D, dtype=f32)
         w["LNO"], w["QKV"], w["AO"], w["HID"] = buf(M, D), buf(M, 3 * D), buf(M, D), buf(M, 4 * D)
-        if self.fp8:                                         # e4m3 LayerNorm output + its per-token scales
+        if self.fp8:                                         # e4m3 LayerNorm output + its per-token scales; e4m3 MLP hidden
             w["LNQ"] = torch.zeros(M * D + 256, dtype=torch.uint8, device=dev)[:M * D].view(M, D)
             w["RS"] = torch.empty(M, dtype=f32, device=dev)
+            w["HIDQ"] = torch.zeros(M * 4 * D + 256, dtype=torch.uint8, device=dev)[:M * 4 * D].view(M, 4 * D)
+            w["ONES"] = torch.ones(M, dtype=f32, device=dev)
         if Bi:
             w["XA"] = buf(Mv, D, dtype=f32)
             h1 = self.h1
@@ -440,6 +447,27 @@ class Engine:
             hip.gemm(LNC[r0:r1], bw.wfc, HIDC[r0:r1], bias=bw.bfc, act=hip.ACT_QUICKGELU)
             hip.gemm(HIDC[r0:r1], bw.wpr, XC[r0:r1], bias=bw.bpr, resid=XC[r0:r1], resid_kind=hip.RESID_F32)
 
+    def _mlp_f8(self, w, r0, r1, bw):
+        """c_fc + QuickGELU + c_proj of the rows [r0, r1) under PRECISION fp8.  c_fc (e4m3 LayerNorm output x e4m3 weight) writes
+        the hidden matrix as e4m3 with ONE static scale per layer, which makes it the fp8 operand of c_proj without another pass
+        (its row maximum spans 16-32 column tiles: a per-token scale cannot come out of a tile's epilogue; a static, calibrated
+        per-tensor scale is the usual recipe for such activations).  Calibration: the first batch a layer sees runs c_fc with a
+        bf16 output and c_proj in bf16, and fixes the scale at 1.25 x its max |hidden| / 448 (one host read per layer, once);
+        later values beyond that range saturate.  Row counts that are not whole 256-row tiles keep the bf16 hidden matrix."""
+        X, HID, LNQ, RS = w["X"], w["HID"], w["LNQ"], w["RS"]
+        if bw.hid_scale is None or (r1 - r0) % 256:
+            hip.gemm_f8(LNQ[r0:r1], bw.wfc_q, HID[r0:r1], RS[r0:r1], bw.wfc_s, bias=bw.bfc, act=hip.ACT_QUICKGELU)
+            if bw.hid_scale is None and not torch.cuda.is_current_stream_capturing():
+                amax = float(HID[r0:r1].abs().amax())
+                bw.hid_scale = max(amax, 1e-6) * 1.25 / 448.0
+                bw.wpr_cs = (bw.wpr_s * bw.hid_scale).contiguous()
+            hip.gemm(HID[r0:r1], bw.wpr, X[r0:r1], bias=bw.bpr, resid=X[r0:r1], resid_kind=hip.RESID_F32)
+            return
+        HQ = w["HIDQ"]
+        hip.gemm_f8(LNQ[r0:r1], bw.wfc_q, HQ[r0:r1], RS[r0:r1], bw.wfc_s, bias=bw.bfc, act=hip.ACT_QUICKGELU,
+                    out_scale=1.0 / bw.hid_scale)
+        hip.gemm_f8(HQ[r0:r1], bw.wpr_q, X[r0:r1], w["ONES"][r0:r1], bw.wpr_cs, bias=bw.bpr, resid=X[r0:r1], resid_kind=hip.RESID_F32)
+
     def _ln_f8(self, w, segs, which):
         """LayerNorm of the token rows straight to e4m3 + per-token scales (w["LNQ"], w["RS"]): one launch over both towers'
         rows (own gamma / beta per modality), or one per tower when only one runs."""
@@ -521,10 +549,10 @@ class Engine:
                     hip.layernorm(X[r0:r1], b["ln2"].g, b["ln2"].b, LNO[r0:r1], r1 - r0)
             for r0, r1, bw in groups:
                 if self.fp8:
-                    hip.gemm_f8(w["LNQ"][r0:r1], bw.wfc_q, HID[r0:r1], w["RS"][r0:r1], bw.wfc_s, bias=bw.bfc, act=hip.ACT_QUICKGELU)
+                    self._mlp_f8(w, r0, r1, bw)
                 else:
                     hip.gemm(LNO[r0:r1], bw.wfc, HID[r0:r1], bias=bw.bfc, act=hip.ACT_QUICKGELU)
-                hip.gemm(HID[r0:r1], bw.wpr, X[r0:r1], bias=bw.bpr, resid=X[r0:r1], resid_kind=hip.RESID_F32)
+                    hip.gemm(HID[r0:r1], bw.wpr, X[r0:r1], bias=bw.bpr, resid=X[r0:r1], resid_kind=hip.RESID_F32)
             if taps is not None:
                 if vb is not None:
                     self._tap_tokens(taps, f"vblock{i}", X[:Mv], Bi, self.Lv)

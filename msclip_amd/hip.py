@@ -51,7 +51,7 @@ class GemmDesc(ctypes.Structure):
         ("ktab", ctypes.c_void_p),
         ("act", ctypes.c_int), ("resid_kind", ctypes.c_int), ("out_kind", ctypes.c_int),
         ("alpha", ctypes.c_float),
-        ("rpg", ctypes.c_int), ("radd", ctypes.c_int), ("roff", ctypes.c_int), ("out2", ctypes.c_void_p), ("tile", ctypes.c_int),
+        ("rpg", ctypes.c_int), ("radd", ctypes.c_int), ("roff", ctypes.c_int), ("out2", ctypes.c_void_p), ("out_scale", ctypes.c_float), ("tile", ctypes.c_int),
     ]
 
 
@@ -381,9 +381,9 @@ def quantize_rows_f8(w):
     return q.view(torch.uint8).contiguous(), s.contiguous()
 
 
-def gemm_f8(xq, wq, out, row_scale, col_scale, *, M=None, bias=None, resid=None, resid_kind=0, act=0, alpha=1.0):
+def gemm_f8(xq, wq, out, row_scale, col_scale, *, M=None, bias=None, resid=None, resid_kind=0, act=0, alpha=1.0, out_scale=1.0):
     """out = epilogue(alpha * row_scale[m] * col_scale[n] * xq @ wq^T) on the fp8 MX MFMA; xq uint8 [M, K] / wq uint8 [N, K]
-    hold OCP e4m3 bytes, K % 128 == 0."""
+    hold OCP e4m3 bytes, K % 128 == 0.  out uint8: an e4m3 output, stored value = fp8(epilogue value * out_scale)."""
     assert xq.dtype == torch.uint8 and wq.dtype == torch.uint8 and xq.stride(-1) == 1 and wq.stride(-1) == 1
     _f32(col_scale)
     assert row_scale.dtype == torch.float32
@@ -396,13 +396,14 @@ def gemm_f8(xq, wq, out, row_scale, col_scale, *, M=None, bias=None, resid=None,
     d.ldx, d.ldw, d.ldo = xq.stride(0), wq.stride(0), out.stride(0)
     d.ldr = resid.stride(0) if resid is not None and resid.dim() == 2 else d.ldo
     d.mode, d.act, d.resid_kind, d.alpha, d.rpg = 0, act, resid_kind, alpha, INT_MAX
-    d.out_kind = 1 if out.dtype == torch.float32 else 0
+    d.out_kind = 1 if out.dtype == torch.float32 else 2 if out.dtype == torch.uint8 else 0
+    d.out_scale = out_scale
     assert row_scale.numel() >= d.M and col_scale.numel() >= d.N
     probe = _f8_probe[0]
     t0 = probe.begin() if probe is not None else None
     _check(lib().msclip_gemm_f8(ctypes.byref(d), _p(row_scale), _p(col_scale), _stream()), "msclip_gemm_f8")
     if probe is not None:
-        esz = 4 if d.out_kind else 2
+        esz = {0: 2, 1: 4, 2: 1}[d.out_kind]
         r_bytes = {RESID_NONE: 0, RESID_F32: d.M * d.N * 4, RESID_BF16: d.M * d.N * 2}[resid_kind]
         nbytes = d.M * d.K + d.N * d.K + d.M * d.N * esz + r_bytes + (d.M + d.N) * 4 + (d.N * 4 if bias is not None else 0)
         probe.end(t0, 2.0 * d.M * d.N * d.K, (d.M, d.N, d.K, d.K, False, act, resid_kind, d.out_kind), nbytes)

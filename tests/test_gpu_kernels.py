@@ -775,3 +775,27 @@ def test_gemm_training_epilogue_forms(gpu_device, tile, M, N, K):
     assert bool(torch.isnan(dh[M:].float()).all())
     assert hip.gemm_variant(hip.describe_gemm(0, M, N, K, tile=1, resid_kind=hip.RESID_GELUGRAD)) == "invalid"   # other kernels reject it
     assert hip.gemm_variant(hip.describe_gemm(0, M + 8, N, K, resid_kind=hip.RESID_GELUGRAD)) == "invalid"       # ... and so do ragged M
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 1024, 768), (256 * 5, 4096, 1024)])
+def test_gemm_f8_e4m3_output(gpu_device, M, N, K):
+    """msclip_gemm_f8 with an e4m3 OUTPUT (c_fc -> the fp8 operand of c_proj): out = fp8(QuickGELU(acc + bias) * out_scale),
+    saturating.  Against torch's own e4m3 rounding of the fp32 reference: equal up to one fp8 ulp where the fp32 accumulation
+    order moves a value across a rounding boundary, saturation at +-448."""
+    xq, sx = hip.quantize_rows_f8(rnd(M, K, seed=85))
+    wq, sw = hip.quantize_rows_f8(rnd(N, K, seed=86, scale=0.05))
+    b = rnd(N, seed=87)
+    pre = _dq(xq, sx) @ _dq(wq, sw).t() + b
+    ref = pre * torch.sigmoid(1.702 * pre)
+    s = float(ref.abs().max()) / 448.0 * 2.0                       # half of the range: the top values saturate
+    out = torch.zeros(M, N, dtype=torch.uint8, device="cuda")
+    hip.gemm_f8(xq, wq, out, sx, sw, bias=b, act=hip.ACT_QUICKGELU, out_scale=1.0 / (s / 2.0))
+    got = out.view(hip.F8).float() * (s / 2.0)
+    want = (ref / (s / 2.0)).clamp(-448, 448).to(hip.F8).float() * (s / 2.0)
+    err = (got - want).abs()
+    tol = 0.126 * want.abs() + (2.0 ** -9) * 448 * (s / 2.0) + 1e-3 * float(ref.abs().max())     # one e4m3 ulp is 1/16 .. 1/8 of the value
+    print("e4m3 output: elements differing from torch's rounding of the fp32 reference:", (got != want).float().mean().item(),
+          "worst err / tol", float((err / tol).max()))
+    assert bool((err <= tol).all()), float((err - tol).max())
+    assert (got != want).float().mean().item() < 0.02               # nearly all elements bit-equal
+    assert float(got.abs().max()) <= 448 * (s / 2.0) + 1e-6 and bool((got.abs() >= 447 * (s / 2.0)).any())    # saturated, no NaN
