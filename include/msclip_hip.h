@@ -312,6 +312,12 @@ int msclip_stream_create(int priority, void** stream);
 int msclip_stream_destroy(void* stream);
 
 /* Library / device introspection (no GPU work). */
+/* Chain rule of a frozen-statistics BatchNorm folded into its convolution (W_f = W gamma rstd, shift = beta - mean gamma rstd)
+ * back to the module's parameters: dW = G s, dgamma = (sum_k G W - mean dshift) rstd, dbeta = dshift; G = dL/dW_f [cout, ldg >= K]
+ * fp32, w_raw [cout, K] the raw filter, one block per output channel (M.py:1825-1861, 1920-1936 differentiated in eval() mode). */
+int msclip_bn_fold_bwd(const float* G, long long ldg, const float* w_raw, int cout, int K, const float* dshift, const float* gamma,
+                       const float* mean, const float* var, float eps, float* dW, float* dgamma, float* dbeta, void* stream);
+
 int msclip_abi_version(void);
 const char* msclip_build_arch(void);
 

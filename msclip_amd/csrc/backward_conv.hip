@@ -596,3 +596,44 @@ extern "C" int msclip_bn_bwd_dx(const void* dy, int lddy, int dy_f32, const void
 #undef BN_DX
   return msclip_launch_status();
 }
+
+namespace {
+// Chain rule of a folded (frozen-statistics) BatchNorm back to the module's own parameters, one block per output channel c:
+//   s = gamma rstd, rstd = 1 / sqrt(var + eps);  W_f = W s, shift = beta - mean s
+//   dW[c][k] = G[c][k] s[c];  dgamma[c] = (sum_k G[c][k] W[c][k] - mean[c] dshift[c]) rstd[c];  dbeta[c] = dshift[c]
+// (G = dL/dW_f, dshift = dL/dshift).  Replaces a dozen per-channel ATen launches per BatchNorm of the frozen-statistics backward.
+__global__ __launch_bounds__(256) void bn_fold_bwd_kernel(const float* __restrict__ G, long long ldg, const float* __restrict__ w,
+                                                          int K, const float* __restrict__ dshift, const float* __restrict__ gamma,
+                                                          const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                                                          float* __restrict__ dW, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float red[4];
+  const int c = blockIdx.x;
+  const float rstd = 1.f / sqrtf(var[c] + eps);
+  const float sc = gamma[c] * rstd;
+  const float* g = G + (size_t)c * ldg;
+  const float* wr = w + (size_t)c * K;
+  float acc = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    const float gv = g[k];
+    acc += gv * wr[k];
+    dW[(size_t)c * K + k] = gv * sc;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float ds = (red[0] + red[1]) + (red[2] + red[3]) - mean[c] * dshift[c];
+    dgamma[c] = ds * rstd;
+    dbeta[c] = dshift[c];
+  }
+}
+}  // namespace
+
+extern "C" int msclip_bn_fold_bwd(const float* G, long long ldg, const float* w_raw, int cout, int K, const float* dshift,
+                                  const float* gamma, const float* mean, const float* var, float eps, float* dW, float* dgamma,
+                                  float* dbeta, void* stream) {
+  if (!G || !w_raw || !dshift || !gamma || !mean || !var || !dW || !dgamma || !dbeta || cout <= 0 || K <= 0 || ldg < K) return MSCLIP_EINVAL;
+  hipLaunchKernelGGL(bn_fold_bwd_kernel, dim3(cout), dim3(256), 0, (hipStream_t)stream, G, ldg, w_raw, K, dshift, gamma, mean, var,
+                     eps, dW, dgamma, dbeta);
+  return msclip_launch_status();
+}

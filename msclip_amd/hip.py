@@ -24,7 +24,7 @@ EXPORTS = (
     "msclip_attention_bwd", "msclip_l2norm_bwd", "msclip_clip_loss_bwd_g", "msclip_embed_tokens_bwd", "msclip_adapter_sum",
     "msclip_adapter_dx", "msclip_adamw", "msclip_adamw_multi", "msclip_im2col", "msclip_col2im", "msclip_relu_bwd", "msclip_dwpool_bwd",
     "msclip_dwpool_wgrad", "msclip_dw3x3_wgrad", "msclip_gemm_splitk", "msclip_bn_stats", "msclip_bn_apply",
-    "msclip_bn_bwd_reduce", "msclip_bn_bwd_dx",
+    "msclip_bn_bwd_reduce", "msclip_bn_bwd_dx", "msclip_bn_fold_bwd",
     "msclip_abi_version", "msclip_build_arch",
     "msclip_stream_priority_range", "msclip_stream_create", "msclip_stream_destroy",
 )
@@ -123,6 +123,7 @@ def lib():
         L.msclip_bn_apply.argtypes = [vp, ci, ci, vp, vp, vp, ci, vp, ci, ci, ci, ci, ci, vp]
         L.msclip_bn_bwd_reduce.argtypes = [vp, ci, ci, vp, ci, ci, vp, vp, vp, ci, ci, ci, vp]
         L.msclip_bn_bwd_dx.argtypes = [vp, ci, ci, vp, ci, ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ll, vp]
+        L.msclip_bn_fold_bwd.argtypes = [vp, ll, vp, ci, ci, vp, vp, vp, vp, cf, vp, vp, vp, vp]
         L.msclip_abi_version.restype = ci
         L.msclip_build_arch.restype = ctypes.c_char_p
         for name in EXPORTS:
@@ -852,6 +853,22 @@ def bn_bwd(dy, x, mean, rstd, gamma, dx, M=None):
         _check(lib().msclip_bn_bwd_dx(_p(dy), dy.stride(0), df, _p(x), x.stride(0), xf, _p(mean), _p(rstd), _p(gamma),
                                       _p(dbeta), _p(dgamma), _p(dx), dx.stride(0), M, C, M, _stream()), "msclip_bn_bwd_dx")
     return dgamma, dbeta
+
+
+def bn_fold_bwd(G, w_raw, dshift, gamma, mean, var, eps):
+    """Frozen-statistics BatchNorm fold, backward: G = dL/d(folded filter) [cout, ...] (fp32, rows contiguous), w_raw the raw
+    filter of the same shape -> (dW like w_raw, dgamma [cout], dbeta [cout])."""
+    cout = w_raw.shape[0]
+    K = w_raw.numel() // cout
+    Gm = G.reshape(cout, -1)
+    if Gm.shape[1] > 1 and Gm.stride(1) != 1:
+        Gm = Gm.contiguous()
+    assert Gm.dtype == torch.float32 and Gm.shape[1] == K and w_raw.dtype == torch.float32 and w_raw.is_contiguous()
+    dW = torch.empty_like(w_raw)
+    dgb = torch.empty(2, cout, dtype=torch.float32, device=w_raw.device)
+    _check(lib().msclip_bn_fold_bwd(_p(Gm), Gm.stride(0), _p(w_raw), cout, K, _p(dshift), _p(gamma), _p(mean), _p(var), eps, _p(dW),
+                                    _p(dgb[0]), _p(dgb[1]), _stream()), "msclip_bn_fold_bwd")
+    return dW, dgb[0], dgb[1]
 
 
 class AdamwTensor(ctypes.Structure):

@@ -40,23 +40,26 @@ def _zbuf(rows, cols, dev):
 
 
 class _Fold:
-    """One BatchNorm's frozen statistics: s = gamma * rstd, shift = beta - mean * s."""
+    """One BatchNorm's frozen statistics: s = gamma * rstd, shift = beta - mean * s (formed lazily: only the adapters' pointwise
+    conv needs `shift` on the host side of a launch)."""
 
     def __init__(self, sd, prefix, eps):
-        self.prefix = prefix
-        g, b = sd[prefix + ".weight"].float(), sd[prefix + ".bias"].float()
-        self.mean = sd[prefix + ".running_mean"].float()
-        self.rstd = torch.rsqrt(sd[prefix + ".running_var"].float() + eps)
-        self.s = g * self.rstd
-        self.shift = b - self.mean * self.s
+        self.prefix, self.eps = prefix, eps
+        self.gamma, self.beta = sd[prefix + ".weight"], sd[prefix + ".bias"]
+        self.mean, self.var = sd[prefix + ".running_mean"], sd[prefix + ".running_var"]
+
+    @property
+    def shift(self):
+        return self.beta.float() - self.mean.float() * self.gamma.float() * torch.rsqrt(self.var.float() + self.eps)
 
     def grads(self, out, conv_key, G, w_raw, dshift):
-        """G = dL/d(folded filter) in the raw filter's shape, dshift = dL/d(shift) -> raw conv / gamma / beta gradients."""
-        sh = (-1,) + (1,) * (G.dim() - 1)
-        out[conv_key] = G * self.s.view(sh)
-        ds = (G * w_raw).flatten(1).sum(1) - self.mean * dshift
-        out[self.prefix + ".weight"] = ds * self.rstd
-        out[self.prefix + ".bias"] = dshift.clone()
+        """G = dL/d(folded filter) in the raw filter's shape, dshift = dL/d(shift) -> raw conv / gamma / beta gradients
+        (one launch: msclip_bn_fold_bwd)."""
+        Gc = G if G.is_contiguous() else G.contiguous()
+        dW, dg, db = hip.bn_fold_bwd(Gc, w_raw.contiguous(), dshift.contiguous(), self.gamma, self.mean, self.var, self.eps)
+        out[conv_key] = dW
+        out[self.prefix + ".weight"] = dg
+        out[self.prefix + ".bias"] = db
 
 
 class ConvSideBackward:
