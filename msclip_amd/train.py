@@ -113,6 +113,24 @@ class TrainStep:
             if (cb is None and not gradgemm._ranks_share_a_gpu() and not hip.env_flag("MSCLIP_WGRAD_SYNC")
                     and e.lateral == sorted(e.lateral)):
                 conv_events = e._conv_branch_on_side_stream(w, Bi)
+            if (cb is not None and conv_events is None and not gradgemm._ranks_share_a_gpu() and not hip.env_flag("MSCLIP_WGRAD_SYNC")
+                    and e.lateral == sorted(e.lateral)):
+                # train-mode BatchNorm: the same for the raw-conv -> statistics -> normalise chains of the parallel branch and
+                # the adapters' top-down halves (they depend on the image only)
+                if w["Ts"] is None:
+                    w["Ts"] = [torch.empty(Bi * g2, D, dtype=F32, device=e.dev) for _ in e.adapters]
+                cur, side = torch.cuda.current_stream(e.dev), C.side_stream(e.dev)
+                ready = torch.cuda.Event()
+                ready.record(cur)
+                side.wait_event(ready)
+                conv_events = []
+                with torch.cuda.stream(side):
+                    for j in range(len(e.adapters)):
+                        cb.stage(j)
+                        cb.adapter_top(j, w["Ts"][j])
+                        ev = torch.cuda.Event()
+                        ev.record(side)
+                        conv_events.append(ev)
             e._text_front(sv["tok"], w, Bt)
             # ---- blocks.  Xc = the residual matrix the next layer reads: the workspace's X at first; every layer that runs over
             # all rows writes its two residual updates into fresh matrices (the backward needs the layer's input and its
@@ -126,7 +144,10 @@ class TrainStep:
                     j = e.lateral.index(i)
                     a = e.adapters[j]
                     asum = torch.empty(Mv, D, dtype=F32, device=e.dev)
-                    if cb is not None:
+                    if cb is not None and conv_events is not None:
+                        torch.cuda.current_stream(e.dev).wait_event(conv_events[j])
+                        cb.adapter_sum(j, Xc[:Mv], w["Ts"][j], asum)
+                    elif cb is not None:
                         cb.stage(j)
                         cb.adapter_top(j, w["T"])
                         cb.adapter_sum(j, Xc[:Mv], w["T"], asum)
