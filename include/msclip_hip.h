@@ -318,6 +318,12 @@ int msclip_stream_destroy(void* stream);
 int msclip_bn_fold_bwd(const float* G, long long ldg, const float* w_raw, int cout, int K, const float* dshift, const float* gamma,
                        const float* mean, const float* var, float eps, float* dW, float* dgamma, float* dbeta, void* stream);
 
+/* Train-mode BatchNorm: per-channel tail of the statistics pass.  sums [2][r][C] = (sum x, sum x^2) per row fold (msclip_bn_stats
+ * partials, folded by msclip_colsum) over n values per channel -> out [5][C] = mean, biased variance, 1/sqrt(var + eps),
+ * scale = gamma rstd, shift = beta - mean scale (what msclip_bn_apply and the backward read). */
+int msclip_bn_finish(const float* sums, int r, int C, long long n, const float* gamma, const float* beta, float eps, float* out,
+                     void* stream);
+
 int msclip_abi_version(void);
 const char* msclip_build_arch(void);
 

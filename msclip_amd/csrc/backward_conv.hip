@@ -637,3 +637,37 @@ extern "C" int msclip_bn_fold_bwd(const float* G, long long ldg, const float* w_
                      eps, dW, dgamma, dbeta);
   return msclip_launch_status();
 }
+
+namespace {
+// Train-mode BatchNorm, the per-channel tail of the statistics pass in one launch: sums[0][j][c] = sum x, sums[1][j][c] = sum x^2
+// over the rows of fold j (r folds: narrow maps are reduced as r rows per wide row, hip.py::_bn_fold_rows)
+// -> out[0] = mean, out[1] = biased variance, out[2] = rstd, out[3] = scale = gamma rstd, out[4] = shift = beta - mean scale.
+__global__ __launch_bounds__(256) void bn_finish_kernel(const float* __restrict__ sums, int r, int C, float inv_n,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                        float* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int j = 0; j < r; ++j) {
+    s1 += sums[(size_t)j * C + c];
+    s2 += sums[(size_t)(r + j) * C + c];
+  }
+  const float mean = s1 * inv_n;
+  const float var = fmaxf(s2 * inv_n - mean * mean, 0.f);
+  const float rstd = 1.f / sqrtf(var + eps);
+  const float sc = gamma[c] * rstd;
+  out[c] = mean;
+  out[C + c] = var;
+  out[2 * C + c] = rstd;
+  out[3 * C + c] = sc;
+  out[4 * C + c] = beta[c] - mean * sc;
+}
+}  // namespace
+
+extern "C" int msclip_bn_finish(const float* sums, int r, int C, long long n, const float* gamma, const float* beta, float eps,
+                                float* out, void* stream) {
+  if (!sums || !gamma || !beta || !out || r <= 0 || C <= 0 || n <= 0) return MSCLIP_EINVAL;
+  hipLaunchKernelGGL(bn_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, r, C, 1.f / (float)n, gamma,
+                     beta, eps, out);
+  return msclip_launch_status();
+}

@@ -24,7 +24,7 @@ EXPORTS = (
     "msclip_attention_bwd", "msclip_l2norm_bwd", "msclip_clip_loss_bwd_g", "msclip_embed_tokens_bwd", "msclip_adapter_sum",
     "msclip_adapter_dx", "msclip_adamw", "msclip_adamw_multi", "msclip_im2col", "msclip_col2im", "msclip_relu_bwd", "msclip_dwpool_bwd",
     "msclip_dwpool_wgrad", "msclip_dw3x3_wgrad", "msclip_gemm_splitk", "msclip_bn_stats", "msclip_bn_apply",
-    "msclip_bn_bwd_reduce", "msclip_bn_bwd_dx", "msclip_bn_fold_bwd",
+    "msclip_bn_bwd_reduce", "msclip_bn_bwd_dx", "msclip_bn_fold_bwd", "msclip_bn_finish",
     "msclip_abi_version", "msclip_build_arch",
     "msclip_stream_priority_range", "msclip_stream_create", "msclip_stream_destroy",
 )
@@ -123,6 +123,7 @@ def lib():
         L.msclip_bn_apply.argtypes = [vp, ci, ci, vp, vp, vp, ci, vp, ci, ci, ci, ci, ci, vp]
         L.msclip_bn_bwd_reduce.argtypes = [vp, ci, ci, vp, ci, ci, vp, vp, vp, ci, ci, ci, vp]
         L.msclip_bn_bwd_dx.argtypes = [vp, ci, ci, vp, ci, ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ll, vp]
+        L.msclip_bn_finish.argtypes = [vp, ci, ci, ll, vp, vp, cf, vp, vp]
         L.msclip_bn_fold_bwd.argtypes = [vp, ll, vp, ci, ci, vp, vp, vp, vp, cf, vp, vp, vp, vp]
         L.msclip_abi_version.restype = ci
         L.msclip_build_arch.restype = ctypes.c_char_p
@@ -791,8 +792,9 @@ def _bn_fold_rows(M, C, *mats):
     return r
 
 
-def bn_stats(x, M=None):
-    """x [M, C] bf16 or fp32 -> (mean [C], biased variance [C]) over the rows (fp32)."""
+def bn_stats(x, M=None, gamma=None, beta=None, eps=1e-5):
+    """x [M, C] bf16 or fp32 -> (mean [C], biased variance [C]) over the rows (fp32); with gamma / beta also
+    (rstd, scale = gamma rstd, shift = beta - mean scale): the whole per-channel tail is ONE launch (msclip_bn_finish)."""
     M = x.shape[0] if M is None else M
     C = x.shape[1]
     x = x[:M]
@@ -803,10 +805,23 @@ def bn_stats(x, M=None):
     part = torch.empty(ch, 2 * Cw, dtype=torch.float32, device=x.device)
     _check(lib().msclip_bn_stats(_p(xw), xw.stride(0), int(x.dtype == torch.float32), _p(part), Mw, Cw, ch, _stream()),
            "msclip_bn_stats")
-    s = (colsum(part) if ch > 1 else part[0]).view(2, r, C).sum(1)
-    mean = s[0] / M
-    var = (s[1] / M - mean * mean).clamp_min_(0.0)
-    return mean, var
+    sums = colsum(part) if ch > 1 else part[0]                # [2][r][C]
+    plain = gamma is None
+    if plain:
+        gamma, beta = _bn_unit(C, x.device)
+    out = torch.empty(5, C, dtype=torch.float32, device=x.device)
+    _check(lib().msclip_bn_finish(_p(sums), r, C, M, _p(gamma), _p(beta), eps, _p(out), _stream()), "msclip_bn_finish")
+    return (out[0], out[1]) if plain else (out[0], out[1], out[2], out[3], out[4])
+
+
+_BN_UNIT = {}
+
+
+def _bn_unit(C, device):
+    k = (C, device)
+    if k not in _BN_UNIT:
+        _BN_UNIT[k] = (torch.ones(C, dtype=torch.float32, device=device), torch.zeros(C, dtype=torch.float32, device=device))
+    return _BN_UNIT[k]
 
 
 def bn_apply(x, scale, shift, out, M=None, relu=False, resid=None):

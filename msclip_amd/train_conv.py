@@ -338,13 +338,10 @@ class ConvSideBatchNorm:
     # ------------------------------------------------------------------ forward
     def _bn(self, x_raw, prefix, eps, out, M, relu=False, resid=None):
         sd = self.raw.sd
-        mean, var = hip.bn_stats(x_raw, M)
-        rstd = torch.rsqrt(var + eps)
-        g, b = sd[prefix + ".weight"].float(), sd[prefix + ".bias"].float()
-        scale = (g * rstd).contiguous()
-        shift = (b - mean * scale).contiguous()
+        g = sd[prefix + ".weight"]
+        mean, var, rstd, scale, shift = hip.bn_stats(x_raw, M, gamma=g, beta=sd[prefix + ".bias"], eps=eps)
         hip.bn_apply(x_raw, scale, shift, out, M, relu=relu, resid=resid)
-        self.saved[prefix] = (x_raw, mean.contiguous(), rstd.contiguous(), g.contiguous(), M)
+        self.saved[prefix] = (x_raw, mean, rstd, g, M)
         self.stats[prefix] = (mean, var, M)
         return out
 
@@ -421,23 +418,28 @@ class ConvSideBatchNorm:
         hip.adapter_sum(X, zero_t, self.raw.dww[j], zero_b, raw_full, Bi, L, g, e.usecls)
         graw = raw_full.view(Bi, L, D)[:, 1:].reshape(Bi * g * g, D)
         sd = self.raw.sd
-        mean, var = hip.bn_stats(graw)
-        rstd = torch.rsqrt(var + 1e-5)
-        gam, bet = sd[p + ".weight"].float(), sd[p + ".bias"].float()
-        scale = gam * rstd
-        hip.adapter_sum(X, t, (self.raw.dww[j] * scale).contiguous(), (bet - mean * scale).contiguous(), out, Bi, L, g, e.usecls)
-        self.saved[p] = (graw, mean.contiguous(), rstd.contiguous(), gam.contiguous(), Bi * g * g)
+        gam = sd[p + ".weight"]
+        mean, var, rstd, scale, shift = hip.bn_stats(graw, gamma=gam, beta=sd[p + ".bias"], eps=1e-5)
+        hip.adapter_sum(X, t, (self.raw.dww[j] * scale).contiguous(), shift, out, Bi, L, g, e.usecls)
+        self.saved[p] = (graw, mean, rstd, gam, Bi * g * g)
         self.stats[p] = (mean, var, Bi * g * g)
 
     def update_running_stats(self):
         """running = (1 - m) running + m batch (unbiased variance), num_batches_tracked += 1: in place on the module's buffers."""
         bufs = dict(self.e.model.named_buffers())
         m = self.MOMENTUM
-        with torch.no_grad():
-            for prefix, (mean, var, n) in self.stats.items():
-                bufs[prefix + ".running_mean"].mul_(1 - m).add_(mean, alpha=m)
-                bufs[prefix + ".running_var"].mul_(1 - m).add_(var * (n / max(n - 1, 1)), alpha=m)
-                bufs[prefix + ".num_batches_tracked"].add_(1)
+        keys = list(self.stats)
+        if not keys:
+            return
+        with torch.no_grad():                            # multi-tensor forms: a handful of launches for the 36 BatchNorms
+            rm = [bufs[k + ".running_mean"] for k in keys]
+            rv = [bufs[k + ".running_var"] for k in keys]
+            torch._foreach_mul_(rm, 1 - m)
+            torch._foreach_add_(rm, [self.stats[k][0] for k in keys], alpha=m)
+            torch._foreach_mul_(rv, 1 - m)
+            unbiased = torch._foreach_mul([self.stats[k][1] for k in keys], [m * n / max(n - 1, 1) for _, _, n in (self.stats[k] for k in keys)])
+            torch._foreach_add_(rv, unbiased)
+            torch._foreach_add_([bufs[k + ".num_batches_tracked"] for k in keys], 1)
 
     # ------------------------------------------------------------------ backward
     def _bn_bwd(self, grads, prefix, dy):
