@@ -11,8 +11,9 @@ run_line c2_b32_b512 --shapes
 run_line c3_b16_b256 --model b16-yfcc-msclips --batch 256 --no-cpu-baseline
 run_line c4rank_b32_b1024 --batch 1024 --no-cpu-baseline
 run_line c5_l16_fp8_b256 --model l16-fp8-msclips --batch 256 --no-cpu-baseline --steps 10 --warmup 3
-run_line train_b32_b512_bnbatch --train --bn batch --no-cpu-baseline --steps 10 --warmup 3
-run_line train_b32_b512_bnfrozen --train --bn frozen --no-cpu-baseline --no-pmc --steps 10 --warmup 3
+run_line train_b32_b512_bnbatch --train --bn batch --no-cpu-baseline --steps 15 --warmup 5
+run_line train_b32_b512_bnfrozen --train --bn frozen --no-cpu-baseline --no-pmc --steps 15 --warmup 5
+run_line train_b16_b256_bnbatch --train --bn batch --model b16-yfcc-msclips --batch 256 --no-cpu-baseline --no-pmc --steps 10 --warmup 4
 cd /tmp; export TMPDIR=/tmp
 prof() {  # tag, env..., -- args
   tag=$1; shift
@@ -22,9 +23,11 @@ prof() {  # tag, env..., -- args
 prof c2_b32_b512 --steps 20
 MSCLIP_CONV_SIDE_STREAM=0 prof c2_b32_b512_inline --steps 20
 prof c3_b16_b256 --model b16-yfcc-msclips --batch 256 --steps 20
+MSCLIP_CONV_SIDE_STREAM=0 prof c3_b16_b256_inline --model b16-yfcc-msclips --batch 256 --steps 20
 prof c4rank_b32_b1024 --batch 1024 --steps 10
 prof c5_l16_fp8_b256 --model l16-fp8-msclips --batch 256 --steps 10 --warmup 3
 prof train_b32_b512 --train --bn batch --steps 8 --warmup 3
+prof train_b32_b512_frozen --train --bn frozen --steps 8 --warmup 3
 # per-kernel HBM traffic of the C2 / C3 steps (inline schedule: counters are per kernel)
 cd $R
 MSCLIP_CONV_SIDE_STREAM=0 bash tools/pmc_bench.sh r3c2
