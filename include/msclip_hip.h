@@ -217,6 +217,14 @@ int msclip_layernorm_bwd(const float* x, int ldx, const int* row_idx, int row_mu
                          const float* gamma, float* dx, int lddx, int accumulate, float* part, int part_blocks, int M,
                          int C, float eps, void* stream);
 
+/* msclip_attention for ONE query per sample: the last block, where only the class row of an image (M.py:2685) / the EOT row
+ * of a caption (M.py:3057-3060) is read afterwards.  q: bf16 [nsamples, ldqc] = the (pre-scaled) query rows; qkv: the token
+ * matrix of msclip_attention -- only its k | v columns are read (the q columns may hold anything); sample b's keys are rows
+ * row_base + b*L ... and their count is last_row ? last_row[b] - (row_base + b*L) + 1 : L (a causal query at its own position
+ * sees the keys up to itself; NULL = all L keys).  out: bf16 [nsamples, ldo].  L <= 256. */
+int msclip_attention_lastq(const void* q, int ldqc, const void* qkv, int ldq, void* out, int ldo, int nsamples, int L, int heads,
+                           const int* last_row, int row_base, void* stream);
+
 /* Backward of msclip_attention for L <= 208: dqkv [q | k | v gradients] from qkv, the forward output o and its
  * gradient dout (all bf16, same layouts as the forward).  L <= 96: the whole head resident in LDS; 97-208 (the 197-token
  * grid of ViT-B/16): query axis in blocks of 32, dK / dV accumulated in registers across the blocks. */

@@ -521,6 +521,69 @@ int launch_wg(const void* qkv, void* out, int nsamples, int L, int H, int ldq, i
   return msclip_launch_status();
 }
 
+// ---- One query per sample: the last block's attention when only the class row of an image / the EOT row of a caption is
+// read afterwards (M.py:2685, 3057-3060).  One wave per (sample, head): lane = key for the scores (a lane reads its keys' 128-byte
+// head slices), lane = head dimension for the value sum.  P is rounded to bf16 before the value sum like the full kernel's.
+template <int NK>
+__global__ __launch_bounds__(256) void attn_lastq_kernel(const bf16_t* __restrict__ qc, int ldqc, const bf16_t* __restrict__ kv,
+                                                    int ldkv, bf16_t* __restrict__ out, int ldo, int nsamples, int L, int H,
+                                                    const int* __restrict__ last_row, int row_base) {
+  const int lane = threadIdx.x & 63;
+  const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pair >= nsamples * H) return;
+  const int b = pair / H, h = pair - b * H;
+  const int row0 = row_base + b * L;
+  int nk = last_row ? last_row[b] - row0 + 1 : L;
+  nk = min(max(nk, 1), L);
+  const bf16_t* kbase = kv + (size_t)row0 * ldkv + H * 64 + h * 64;
+  const bf16_t* vbase = kbase + H * 64;
+  float q[64];
+  {
+    const bf16_t* qp = qc + (size_t)b * ldqc + h * 64;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) unpack_bf16x8(*(const uint4*)(qp + i * 8), q + i * 8);
+  }
+  float s[NK];
+  float m = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < NK; ++j) {
+    const int key = j * 64 + lane;
+    s[j] = -INFINITY;
+    if (key < nk) {
+      const bf16_t* kp = kbase + (size_t)key * ldkv;
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float kf[8];
+        unpack_bf16x8(*(const uint4*)(kp + i * 8), kf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc = fmaf(q[i * 8 + e], kf[e], acc);
+      }
+      s[j] = acc;
+    }
+    m = fmaxf(m, s[j]);
+  }
+  m = wave_max(m);
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < NK; ++j) {
+    const float p = j * 64 + lane < nk ? __expf(s[j] - m) : 0.f;
+    sum += p;
+    s[j] = bf16_to_f32(f32_to_bf16(p));
+  }
+  sum = wave_sum(sum);
+  float o = 0.f;
+#pragma unroll
+  for (int j = 0; j < NK; ++j) {
+    const int kend = min(64, nk - j * 64);
+    for (int kk = 0; kk < kend; ++kk) {
+      const float p = __shfl(s[j], kk, 64);
+      o = fmaf(p, bf16_to_f32(vbase[(size_t)(j * 64 + kk) * ldkv + lane]), o);
+    }
+  }
+  out[(size_t)b * ldo + h * 64 + lane] = f32_to_bf16(o / sum);
+}
+
 template <int NT>
 int launch(const void* qkv, void* out, int nsamples, int L, int H, int ldq, int ldo, int causal, hipStream_t st) {
   constexpr int WPB = NT > 4 ? 2 : 4;  // keep dynamic LDS under 64 KiB
@@ -550,4 +613,20 @@ extern "C" int msclip_attention(const void* qkv, void* out, int nsamples, int L,
     return launch_wg<7>(qkv, out, nsamples, L, heads, ldq, ldo, causal, st);
   }
   return MSCLIP_EINVAL;
+}
+
+extern "C" int msclip_attention_lastq(const void* q, int ldqc, const void* qkv, int ldq, void* out, int ldo, int nsamples, int L,
+                                      int heads, const int* last_row, int row_base, void* stream) {
+  if (!q || !qkv || !out || nsamples <= 0 || L <= 0 || L > 256 || heads <= 0 || (ldqc % 8) || (ldq % 8) || ldo < heads * 64 || row_base < 0)
+    return MSCLIP_EINVAL;
+  const int grid = (nsamples * heads + 3) / 4;
+  hipStream_t st = (hipStream_t)stream;
+#define LASTQ(NK)                                                                                                              \
+  hipLaunchKernelGGL(attn_lastq_kernel<NK>, dim3(grid), dim3(256), 0, st, (const bf16_t*)q, ldqc, (const bf16_t*)qkv, ldq,     \
+                     (bf16_t*)out, ldo, nsamples, L, heads, last_row, row_base)
+  if (L <= 64) LASTQ(1);
+  else if (L <= 128) LASTQ(2);
+  else LASTQ(4);
+#undef LASTQ
+  return msclip_launch_status();
 }

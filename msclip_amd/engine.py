@@ -272,7 +272,7 @@ class Engine:
         # compact matrices of the rows that are still read after the last block's attention (cls / EOT rows, _last_block_tail)
         nc = Bi + Bt
         w["XC"] = buf(nc, D, dtype=f32)
-        w["AOC"], w["LNC"], w["HIDC"] = buf(nc, D), buf(nc, D), buf(nc, 4 * D)
+        w["AOC"], w["LNC"], w["HIDC"], w["QC"] = buf(nc, D), buf(nc, D), buf(nc, 4 * D), buf(nc, D)
         if Bi:
             w["fvb"] = buf(Bi, E)                            # bf16 unit features: gather payload / logits operand
         if Bt:
@@ -420,7 +420,29 @@ class Engine:
     def _text_front(self, tok, w, Bt):
         hip.embed_tokens(tok, self.emb, self.tpos, w["X"], w["eot"], w["Mv"])
 
-    def _last_block_tail(self, w, Bi, Bt, vb, tb):
+    def _last_block_attention(self, w, Bi, Bt, groups):
+        """The last block's attention when only the class / EOT rows are read afterwards: keys and values are still projected
+        for every token (the k | v two thirds of in_proj), the query only for the Bi + Bt live rows, and one query per
+        sample attends (msclip_attention_lastq) straight into the compact matrix AOC."""
+        D, Mv = self.D, w["Mv"]
+        LNO, QKV, LNC, QC, AOC = w["LNO"], w["QKV"], w["LNC"], w["QC"], w["AOC"]
+        for r0, r1, bw in groups:
+            hip.gemm(LNO[r0:r1], bw.wqkv[D:], QKV[r0:r1, D:], bias=bw.bqkv[D:])
+        if Bi:
+            hip.gather_rows(LNO, LNC[:Bi], Bi, row_mul=self.Lv)
+        if Bt:
+            hip.gather_rows(LNO, LNC[Bi:], Bt, row_idx=w["eot"])
+        n = Bi + Bt
+        cgroups = [(0, n, groups[0][2])] if len(groups) == 1 else [(0, Bi, groups[0][2]), (Bi, n, groups[1][2])]
+        for r0, r1, bw in cgroups:
+            if r1 > r0:
+                hip.gemm(LNC[r0:r1], bw.wqkv[:D], QC[r0:r1], bias=bw.bqkv[:D])
+        if Bi:
+            hip.attention_lastq(QC[:Bi], QKV, AOC[:Bi], Bi, self.Lv, self.heads)
+        if Bt:
+            hip.attention_lastq(QC[Bi:], QKV, AOC[Bi:], Bt, self.Lt, self.heads, last_row=w["eot"], row_base=Mv)
+
+    def _last_block_tail(self, w, Bi, Bt, vb, tb, attended=False):
         """After the last block's attention only x[:, 0, :] of every image (M.py:2685) and the EOT row of every caption
         (M.py:3057-3060) are read again, and out_proj / ln_2 / c_fc / c_proj are row-wise: they run on those Bi + Bt rows,
         moved to the compact matrices XC (fp32 stream) / AOC (attention output), instead of on all tokens.  Same results
@@ -429,10 +451,12 @@ class Engine:
         X, AO = w["X"], w["AO"]
         if Bi:
             hip.gather_rows(X, XC[:Bi], Bi, row_mul=self.Lv)
-            hip.gather_rows(AO, AOC[:Bi], Bi, row_mul=self.Lv)
+            if not attended:
+                hip.gather_rows(AO, AOC[:Bi], Bi, row_mul=self.Lv)
         if Bt:
             hip.gather_rows(X, XC[Bi:], Bt, row_idx=w["eot"])
-            hip.gather_rows(AO, AOC[Bi:], Bt, row_idx=w["eot"])
+            if not attended:
+                hip.gather_rows(AO, AOC[Bi:], Bt, row_idx=w["eot"])
         n = Bi + Bt
         segs = ([(0, Bi, vb)] if Bi else []) + ([(Bi, n, tb)] if Bt else [])
         groups = [(0, n, vb["w"])] if len(segs) == 2 and vb["w"] is tb["w"] else [(r0, r1, b["w"]) for r0, r1, b in segs]
@@ -526,6 +550,11 @@ class Engine:
             # --- projections: one launch over both towers when the tensors are shared
             groups = [(segs[0][0], segs[-1][1], segs[0][2]["w"])] if len(segs) == 2 and vb["w"] is tb["w"] else \
                      [(r0, r1, b["w"]) for r0, r1, b in segs]
+            last_live = i == self.n_layers - 1 and compact
+            if last_live and not self.fp8 and not hip.env_flag("MSCLIP_LAST_BLOCK_ALL_QUERIES"):
+                self._last_block_attention(w, Bi, Bt, groups)
+                self._last_block_tail(w, Bi, Bt, vb, tb, attended=True)
+                continue
             for r0, r1, bw in groups:
                 if self.fp8:
                     hip.gemm_f8(w["LNQ"][r0:r1], bw.wqkv_q, QKV[r0:r1], w["RS"][r0:r1], bw.wqkv_s, bias=bw.bqkv)
@@ -535,7 +564,7 @@ class Engine:
                 hip.attention(QKV[:Mv], AO[:Mv], Bi, self.Lv, self.heads, False)
             if tb is not None:
                 hip.attention(QKV[Mv:M], AO[Mv:M], Bt, self.Lt, self.heads, True)
-            if i == self.n_layers - 1 and compact:
+            if last_live:
                 self._last_block_tail(w, Bi, Bt, vb, tb)
                 continue
             for r0, r1, bw in groups:

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("MSCLIP_HIP_LIB") or os.path.join(_HERE, "csrc", "libm
 INT_MAX = 2 ** 31 - 1
 
 EXPORTS = (
-    "msclip_gemm", "msclip_gemm_f8", "msclip_layernorm_f8", "msclip_quant_f8_rows", "msclip_gemm_variant", "msclip_attention", "msclip_layernorm", "msclip_layernorm_split", "msclip_embed_tokens", "msclip_fill_cls",
+    "msclip_gemm", "msclip_gemm_f8", "msclip_layernorm_f8", "msclip_quant_f8_rows", "msclip_gemm_variant", "msclip_attention", "msclip_attention_lastq", "msclip_layernorm", "msclip_layernorm_split", "msclip_embed_tokens", "msclip_fill_cls",
     "msclip_adapter_combine_ln", "msclip_l2norm", "msclip_gather_rows", "msclip_stem_conv3x3s2_dual", "msclip_dwpool",
     "msclip_stem_dual_conv3x3s2", "msclip_conv1x1_conv3x3s2", "msclip_convresblock48_s2",
     "msclip_lse_rows", "msclip_clip_loss_partial", "msclip_clip_lse_fused", "msclip_clip_loss_from_partials",
@@ -82,6 +82,7 @@ def lib():
         L.msclip_gemm_variant.argtypes = [ctypes.POINTER(GemmDesc)]
         L.msclip_gemm_variant.restype = ctypes.c_char_p
         L.msclip_attention.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, vp]
+        L.msclip_attention_lastq.argtypes = [vp, ci, vp, ci, vp, ci, ci, ci, ci, vp, ci, vp]
         L.msclip_layernorm.argtypes = [vp, ci, vp, ci, ci, vp, vp, vp, ci, ci, vp, ci, ci, ci, cf, vp]
         L.msclip_layernorm_split.argtypes = [vp, ci, vp, vp, vp, vp, ci, vp, ci, ci, ci, ci, cf, vp]
         L.msclip_embed_tokens.argtypes = [vp, vp, vp, vp, ci, vp, ci, ci, ci, ci, ci, vp]
@@ -471,6 +472,23 @@ def attention(qkv, out, nsamples, L, heads, causal):
     assert qkv.shape[0] == nsamples * L and out.shape[0] == nsamples * L
     _check(lib().msclip_attention(_p(qkv), _p(out), nsamples, L, heads, qkv.stride(0), out.stride(0), int(causal),
                                   _stream()), "msclip_attention")
+    return out
+
+
+def attention_lastq(q, qkv, out, nsamples, L, heads, *, last_row=None, row_base=0):
+    """One query per sample (the last block's class / EOT rows).  q: bf16 [nsamples, heads*64]; qkv: the token matrix of
+    attention() (its q columns are not read); sample b's keys are the rows row_base + b*L ... up to last_row[b] (int32
+    absolute row numbers) or all L of them.  out: bf16 [nsamples, heads*64]."""
+    _bf16(q)
+    _bf16(qkv)
+    _bf16(out)
+    assert q.shape[0] >= nsamples and out.shape[0] >= nsamples and qkv.shape[0] >= row_base + nsamples * L
+    assert qkv.shape[1] == 3 * heads * 64
+    if last_row is not None:
+        assert last_row.dtype == torch.int32 and last_row.numel() >= nsamples
+    _check(lib().msclip_attention_lastq(_p(q), q.stride(0), _p(qkv), qkv.stride(0), _p(out), out.stride(0), nsamples, L, heads,
+                                        _p(last_row) if last_row is not None else None, row_base, _stream()),
+           "msclip_attention_lastq")
     return out
 
 

@@ -1,3 +1,7 @@
+def test_gemm_chip_filling_launches_back_to_back_and_on_two_streams(gpu_device, M, N, K, resid):
+    """Launches of >= 3 tiles per workgroup, repeated and on two streams at once: every tile exactly once (NaN prefill: a
+    skipped tile stays NaN; a tile computed twice into the fp32 residual stream doubles its increment).  Written for the
+    dynamic per-XCD tile lists that were tried in round 3 (history: 'gemm: dynamic tile lists'), kept for the static ones."""
 """Per-kernel parity on a real MI355X: each C-ABI entry point against a plain fp32 PyTorch statement of the same op,
 on seeded random (asymmetric, transpose-detecting) data, including ragged sizes that exercise every bounds guard."""
 import pytest
@@ -281,6 +285,38 @@ def test_attention(gpu_device, B, L, causal):
     ref = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B * L, D)
     close(out[:B * L], ref, 2e-2, 2e-2)
     assert bool((out[B * L:] == 7.0).all())
+
+
+@pytest.mark.parametrize("B,L,causal", [(5, 50, False), (6, 77, True), (3, 197, False), (2, 1, True), (3, 64, True), (2, 130, True)])
+def test_attention_single_query_per_sample(gpu_device, B, L, causal):
+    """msclip_attention_lastq: the class row (all keys) / a caption's EOT row (keys up to itself) only.  Against fp32 softmax
+    attention of that one query, and against the same rows of the full kernel.  The q columns of the token matrix are
+    poisoned: only k | v may be read from it."""
+    Hh, D, base = 12, 768, 7
+    qkv = rnd(base + B * L + 3, 3 * D, seed=18, dtype=BF)
+    g = torch.Generator().manual_seed(5)
+    pos = torch.randint(0, L, (B,), generator=g) if causal else torch.zeros(B, dtype=torch.long)
+    rows = (base + torch.arange(B) * L + pos).to(torch.int32).cuda()
+    q = qkv[rows.long(), :D].contiguous()
+    full = torch.empty(B * L, D, dtype=BF, device="cuda")
+    if L <= 224:
+        hip.attention(qkv[base:base + B * L], full, B, L, Hh, causal)
+    poisoned = qkv.clone()
+    poisoned[:, :D] = float("nan")
+    out = torch.full((B + 2, D), 7.0, dtype=BF, device="cuda")
+    hip.attention_lastq(q, poisoned, out, B, L, Hh, last_row=rows if causal else None, row_base=base)
+    for b in range(B):
+        nk = int(pos[b]) + 1 if causal else L
+        blk = qkv[base + b * L: base + b * L + nk].float()
+        k, v = blk[:, D:2 * D].reshape(nk, Hh, 64), blk[:, 2 * D:].reshape(nk, Hh, 64)
+        s = torch.einsum("hd,khd->hk", q[b].float().reshape(Hh, 64), k)
+        ref = torch.einsum("hk,khd->hd", torch.softmax(s, -1), v).reshape(D)
+        close(out[b], ref, 2e-2, 2e-2)
+        if L <= 224:
+            close(out[b], full[b * L + int(pos[b])].float(), 2e-2, 1e-2)
+    assert bool((out[B:] == 7.0).all())
+    assert hip.lib().msclip_attention_lastq(None, D, None, 3 * D, None, D, 1, 8, Hh, None, 0, None) == -1
+    assert hip.lib().msclip_attention_lastq(q.data_ptr(), D, qkv.data_ptr(), 3 * D, out.data_ptr(), D, 1, 300, Hh, None, 0, None) == -1
 
 
 def test_attention_forced_sharp_softmax(gpu_device):
@@ -750,6 +786,44 @@ def test_layernorm_f8_and_row_quant(gpu_device, C):
     close(s, xb.float().abs().amax(1) / 448.0, 0.0, 1e-5)
     ref_q, _ = hip.quantize_rows_f8(xb)                                          # torch's own e4m3 rounding of the same scaled values
     assert (q != ref_q).float().mean().item() < 1e-3                              # (1/s vs division: a rare last-bit tie)
+
+
+@pytest.mark.parametrize("M,N,K,resid", [(256 * 100, 2304, 768, False), (256 * 100 + 37, 768, 768, True), (256 * 90, 3072, 256, False),
+                                          (256 * 33 + 5, 3072 - 8, 1024, False)])
+def test_gemm_dynamic_tile_lists(gpu_device, M, N, K, resid):
+    """Launches that fill the chip with >= 3 tiles per workgroup take their tiles from the per-XCD counters
+    (gemm_pp_kernel<0, false, true>): every tile exactly once (NaN prefill: a skipped tile stays NaN, a tile computed twice
+    into the fp32 residual stream doubles its increment), over back-to-back launches (counter and mailbox left clean) and
+    two streams at once (a scheduling block per stream)."""
+    x, w, b = rnd(M, K, seed=41, dtype=BF), rnd(N, K, seed=42, scale=0.05, dtype=BF), rnd(N, seed=43)
+    ref = x.float() @ w.float().t() + b
+    outs = []
+    for rep in range(6):
+        if resid:
+            out = torch.ones(M, N, dtype=torch.float32, device="cuda")
+            hip.gemm(x, w, out, bias=b, resid=out, resid_kind=hip.RESID_F32)
+        else:
+            out = torch.full((M, N), float("nan"), dtype=BF, device="cuda")
+            hip.gemm(x, w, out, bias=b)
+        outs.append(out)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for rep in range(3):
+            o2 = torch.full((M, N), float("nan"), dtype=BF, device="cuda")
+            hip.gemm(x, w, o2, bias=b)
+            outs.append(o2)
+    for rep in range(3):
+        o3 = torch.full((M, N), float("nan"), dtype=BF, device="cuda")
+        hip.gemm(x, w, o3, bias=b)
+        outs.append(o3)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    for out in outs:
+        if out.dtype == torch.float32:
+            close(out, ref + 1.0, 6e-2, 1e-2)
+        else:
+            close(out, ref, 6e-2, 2e-2)
 
 
 @pytest.mark.parametrize("tile", [0, 4, 8])
