@@ -20,7 +20,6 @@
 //    columns of one row; interior tiles are transposed through the just-consumed LDS slab
 //    so every global store / residual load instruction moves full 128-byte lines.
 #include <stdlib.h>
-#include <mutex>
 #include <type_traits>
 #include "common.h"
 #include "../../include/msclip_hip.h"
@@ -483,23 +482,10 @@ __device__ __forceinline__ f32x4 pp_mma(const bf16x8 (&w)[2], const bf16x8 (&x)[
 // rows, regions, ring and LDS-DMA stream -- contracted by ONE v_mfma_scale_f32_16x16x128_f8f6f4 per 16 x 16 tile and K-tile
 // (twice the bf16 rate; block scales 2^0: the operands carry per-row scales instead, row_scale[m] for X rows and col_scale[n]
 // for W rows, fp32, applied to the accumulators in front of the epilogue).
-// DYN (dense bf16 launches that fill the chip, outside stream capture): the tile list of a workgroup is no longer
-// blockIdx + k * gridDim.  Tiles 0 and 1 of a workgroup are the static ones; every later one comes from a counter of the
-// workgroup's XCD (dyn[xcd]; the XCD keeps walking its own contiguous chunk of tile ids, so the L2 picture is the static
-// one), fetched TWO tiles ahead by lane 0 of wave 0 and handed to the other seven waves through an 8-byte mailbox in global
-// memory (dyn[16 + 4*blockIdx + 2*(ordinal & 1)]: {ordinal tag, tile}; two slots, so a slot is rewritten two tiles later) -- the LDS is the ring, every byte of it.  A workgroup that starts
-// late (its CU was still held by a kernel of another stream -- the conv branch, the text front, the weight-gradient lane) or
-// runs slow simply takes fewer tiles; with the static lists the launch ended when ITS list did.  Timing of the three
-// memory operations (none tracked by the compiler, all ordered by the K loop's counted waits): tile n, K-tile 0 = the
-// atomic, K-tile 1 = its result is back (eight pieces younger) -> publish {n + 2, tile or sentinel}, last K-tile = every wave
-// requests the mailbox, read after the K loop.  A tag that is not n + 2 (the store has not landed: never seen, K >= 256)
-// falls into a polling loop.  Every workgroup fetches until its first failure, so the counter ends at a known value: the
-// workgroup that draws it resets the counter; wave 0 clears the mailbox behind a last barrier.
-template <int MODE, bool F8 = false, bool DYN = false>
+template <int MODE, bool F8 = false>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a_in, const float* __restrict__ row_scale,
-                                                      const float* __restrict__ col_scale, unsigned* __restrict__ dyn) {
+                                                      const float* __restrict__ col_scale) {
   static_assert(!(F8 && MODE == 1), "fp8 operands: dense GEMM only");
-  static_assert(!DYN || MODE == 0, "dynamic tile lists: dense GEMM only");
   // Split-K launches (msclip_gemm_splitk with tile = 4; the weight gradients of the training step): blockIdx.y = K slice;
   // slice s contracts columns [s*K/S, (s+1)*K/S) of both operands into its own fp32 matrix out[s][M][ldo].  A weight
   // gradient is 9-36 output tiles over a 65 024-deep contraction: tiles x slices workgroups of ONE launch fill the chip.
@@ -561,7 +547,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a_i
   }
   const unsigned xhalf = 128u * (unsigned)a.ldx * ES, whalf = 128u * (unsigned)a.ldw * ES;
   int ti = blockIdx.x, kti = 0, islot = 0;
-  int t_nxt = blockIdx.x + gridDim.x;              // DYN: tile after the one being computed (the issue side crosses into it)
   __amdgpu_buffer_rsrc_t rx, rw;
   // conv mode: window origin of this lane's pixel rows [half][piece]: byte offset + 16-byte chunk, and (ih0, iw0)
   int cpix[2][2], chw[2][2];                       // (ih0 in the low half, iw0 in the high half)
@@ -631,7 +616,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a_i
     if (J == 3) {
       if (++kti == nk) {
         kti = 0;
-        ti = DYN ? t_nxt : ti + (int)gridDim.x;
+        ti += gridDim.x;
         set_tile(ti);
       }
     }
@@ -673,15 +658,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a_i
   int cslot = 0;                                   // ring slot of region 0 of the K-tile being computed
   bf16x8 w0[2][2], w1[2][2], xf[4][2];             // [16-row tile][k-step]: W rows 0-31 / 32-63 of the wave, X rows of a sub-block
   int epi_stores = 0;                              // stores this wave is known to have issued in the previous tile's epilogue
-  // DYN state.  xcd: gridDim.x is a multiple of 8 (host), workgroups go to the XCDs round robin.
-  const int xcd = blockIdx.x & 7;
-  const int nwg_x = (int)gridDim.x >> 3;                           // workgroups of this launch on the XCD
-  const int clen = (ntiles >> 3) + (xcd < (ntiles & 7) ? 1 : 0);   // tiles of the XCD's chunk (tile t: chunk t & 7, position t >> 3)
-  unsigned vret = 0;                               // wave 0, lane 0: the pending fetch
-  u32x2 vmb = {0u, 0u};                            // the pending mailbox read {tag, tile}
-  bool fetch_done = false;                         // wave 0: a fetch has failed, the chunk is empty
-  int ord = 0;                                     // ordinal of the tile being computed
-  for (int tc = blockIdx.x; tc < ntiles;) {
+  for (int tc = blockIdx.x; tc < ntiles; tc += gridDim.x) {
     int cm0, cn0;
     tile_origin(tc, cm0, cn0);
     f32x4 acc[4][8];                               // [16-column tile][16-row tile] of the wave's 128 x 64 block
@@ -756,10 +733,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a_i
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) w1[i][ks] = pp_ld(wreg + 4096 + i * 2048 + la[ks]);
-      if (DYN && kt == nk - 1) {                   // eight pieces follow in this K-tile: back by its vmcnt(8)
-        const unsigned* mb = dyn + 16 + 4 * blockIdx.x + 2 * (ord & 1);
-        asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1" : "=&v"(vmb) : "v"(mb) : "memory");
-      }
       if (kt) {                                    // K-tile 0: the slots are still the epilogue's staging until the first barrier
         issue(I0{});
         issue(I1{});
@@ -795,31 +768,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a_i
       if (kt == 0 && nk >= 3 && epi_stores == 16) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
       else if (kt == 0 && nk >= 3 && epi_stores == 32) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      if (DYN && wave == 0 && kt < 2) {
-        if (kt == 0) {
-          if (!fetch_done) {                       // one lane: exec = 1 around the atomic
-            unsigned long long keep;
-            const unsigned one = 1u;
-            asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %0, %2, %3, off sc0\n\ts_mov_b64 exec, %1"
-                         : "=&v"(vret), "=&s"(keep) : "v"(dyn + xcd), "v"(one) : "memory");
-          }
-        } else {
-          unsigned tile = (unsigned)ntiles;        // sentinel: no tile
-          if (!fetch_done) {
-            const unsigned ret = (unsigned)__builtin_amdgcn_readfirstlane((int)vret);
-            const unsigned pos = 2u * (unsigned)nwg_x + ret;
-            if (pos < (unsigned)clen) tile = pos * 8u + (unsigned)xcd;
-            else fetch_done = true;
-            const unsigned total = (unsigned)(clen > 2 * nwg_x ? clen - 2 * nwg_x : 0) + (unsigned)nwg_x;
-            if (ret == total - 1u) {               // the last fetch of the launch on this XCD: leave the counter at zero
-              const unsigned zero = 0u;
-              asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(dyn + xcd), "v"(zero) : "memory");
-            }
-          }
-          const u32x2 msg = {(unsigned)ord + 2u, tile};
-          asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(dyn + 16 + 4 * blockIdx.x + 2 * (ord & 1)), "v"(msg) : "memory");
-        }
-      }
       PP_SYNC_IN();
 #pragma unroll
       for (int ks = 0; ks < (F8 ? 1 : 2); ++ks)
@@ -840,22 +788,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a_i
       PP_SYNC_OUT();
     }
 
-    int t_after = ntiles;
-    if (DYN) {
-      unsigned tag = (unsigned)__builtin_amdgcn_readfirstlane((int)vmb[0]);
-      t_after = __builtin_amdgcn_readfirstlane((int)vmb[1]);
-      for (int spin = 0; tag != (unsigned)ord + 2u; ++spin) {          // the publication has not landed yet
-        if (spin == (1 << 16)) {                   // ~0.1 s: give up rather than hang the device (the tests see the missing tiles)
-          t_after = ntiles;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(8);
-        const unsigned long long m = __hip_atomic_load((const unsigned long long*)(dyn + 16 + 4 * blockIdx.x + 2 * (ord & 1)),
-                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        tag = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)m);
-        t_after = __builtin_amdgcn_readfirstlane((int)(unsigned)(m >> 32));
-      }
-    }
     // Both groups run the epilogue together: the leading group waits one barrier, the trailing one re-staggers after.
     // Staging = the ring slots of the last K-tile's X regions (dead since its phase 2; re-issued in phase 1 of the
     // next tile, behind a barrier every wave reaches only after its epilogue).
@@ -921,24 +853,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a_i
     }
     if (grp) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (DYN) {
-      tc = t_nxt;
-      t_nxt = t_after;
-      ++ord;
-    } else {
-      tc += gridDim.x;
-    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing empty pieces must retire before the LDS is released
-  if (DYN) {
-    // every wave has taken its last mailbox value in front of its last epilogue; the trailing group's barrier behind that
-    // epilogue pairs with this one
-    if (!grp) __builtin_amdgcn_s_barrier();
-    if (wave == 0) {
-      const u32x4 none = {0u, 0u, 0u, 0u};
-      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" ::"v"(dyn + 16 + 4 * blockIdx.x), "v"(none) : "memory");
-    }
-  }
 #undef PP_SYNC_IN
 #undef PP_SYNC_OUT
 #undef PP_PRIO
@@ -969,38 +885,6 @@ bool msclip_gemm_w4_eligible(const msclip_gemm_desc* d);                        
 void msclip_gemm_w4_launch(const msclip_gemm_desc* d, hipStream_t st);
 bool msclip_gemm_pp2_eligible(const msclip_gemm_desc* d);                           // gemm_pp2.hip
 void msclip_gemm_pp2_launch(const msclip_gemm_desc* d, hipStream_t st, int ncu);
-
-// Scheduling blocks of the dynamic tile lists (gemm_pp_kernel<.., DYN>): 8 per-XCD counters (+ padding to 16 words) and a
-// 4-word mailbox per workgroup, one block per (device, stream) -- launches of one stream run in order and leave their
-// block clean, launches of different streams (the conv branch, the text front, the weight-gradient lane beside the main
-// stream) must not share one.  Made on first use, zeroed on the launching stream, never freed.  nullptr = use the static
-// lists: MSCLIP_GEMM_DYN=0, a stream that is being captured (a replay may run beside another replay of the same
-// graph's kernels on any stream), or more than 64 streams.
-static unsigned* dyn_sched(hipStream_t st, int ncu) {
-  static const bool enabled = [] {
-    const char* e = getenv("MSCLIP_GEMM_DYN");
-    return !(e && e[0] == '0');
-  }();
-  if (!enabled) return nullptr;
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
-  struct Entry { int dev; hipStream_t st; unsigned* blk; };
-  static Entry table[64];
-  static int used = 0;
-  static std::mutex mu;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  std::lock_guard<std::mutex> lock(mu);
-  for (int i = 0; i < used; ++i)
-    if (table[i].dev == dev && table[i].st == st) return table[i].blk;
-  if (used == 64) return nullptr;
-  const size_t bytes = (16 + 4 * (size_t)ncu) * sizeof(unsigned);
-  unsigned* blk = nullptr;
-  if (hipMalloc((void**)&blk, bytes) != hipSuccess) return nullptr;
-  if (hipMemsetAsync(blk, 0, bytes, st) != hipSuccess) return nullptr;
-  table[used++] = Entry{dev, st, blk};
-  return blk;
-}
 
 static int device_cus() {
   static int ncu = 0;
@@ -1091,7 +975,7 @@ extern "C" int msclip_gemm_splitk(const msclip_gemm_desc* d, int slices, void* s
     const int t256 = ((d->M + 255) / 256) * ((d->N + 255) / 256);
     const int ncu = device_cus();
     hipLaunchKernelGGL((gemm_pp_kernel<0, false>), dim3(t256 < ncu ? t256 : ncu, slices), dim3(512), 0, (hipStream_t)stream, *d,
-                       nullptr, nullptr, nullptr);
+                       nullptr, nullptr);
     return msclip_launch_status();
   }
   const int tiles = ((d->M + 127) / 128) * ((d->N + 127) / 128);
@@ -1117,7 +1001,7 @@ extern "C" int msclip_gemm_f8(const msclip_gemm_desc* d, const float* row_scale,
     return MSCLIP_EINVAL;
   const int ncu = device_cus();
   hipLaunchKernelGGL((gemm_pp_kernel<0, true>), dim3(tiles < ncu ? (int)tiles : ncu), dim3(512), 0, (hipStream_t)stream, *d,
-                     row_scale, col_scale, nullptr);
+                     row_scale, col_scale);
   return msclip_launch_status();
 }
 
@@ -1132,15 +1016,8 @@ extern "C" int msclip_gemm(const msclip_gemm_desc* d, void* stream) {
     case GV_STREAM: if (!msclip_gemm_small_try(d, st, ncu)) return MSCLIP_EINVAL; break;
     case GV_W4: msclip_gemm_w4_launch(d, st); break;
     case GV_PP2: msclip_gemm_pp2_launch(d, st, ncu); break;
-    case GV_PP: {
-      unsigned* sched = nullptr;
-      // dynamic tile lists: the launch fills the chip, every workgroup has at least three tiles' worth of list, K >= 256
-      if (grid == ncu && !(ncu & 7) && tiles >= 3 * ncu && d->K >= 256) sched = dyn_sched(st, ncu);
-      if (sched) hipLaunchKernelGGL((gemm_pp_kernel<0, false, true>), dim3(grid), dim3(512), 0, st, *d, nullptr, nullptr, sched);
-      else hipLaunchKernelGGL((gemm_pp_kernel<0, false>), dim3(grid), dim3(512), 0, st, *d, nullptr, nullptr, nullptr);
-      break;
-    }
-    case GV_PPCONV: hipLaunchKernelGGL((gemm_pp_kernel<1, false>), dim3(grid), dim3(512), 0, st, *d, nullptr, nullptr, nullptr); break;
+    case GV_PP: hipLaunchKernelGGL((gemm_pp_kernel<0, false>), dim3(grid), dim3(512), 0, st, *d, nullptr, nullptr); break;
+    case GV_PPCONV: hipLaunchKernelGGL((gemm_pp_kernel<1, false>), dim3(grid), dim3(512), 0, st, *d, nullptr, nullptr); break;
     case GV_DENSE128: launch_cfg<0, 128, 128, 2, 2>(d, st, 2); break;
     case GV_CONV192: launch_cfg<1, 256, 192, 4, 2>(d, st, 1); break;
     case GV_CONV128: launch_cfg<1, 128, 128, 2, 2>(d, st, 2); break;
