@@ -237,6 +237,12 @@ def main():
         gf_ref = GFLOP_PER_PAIR[args.model]
         skipped = 0.0 if (ts is not None or hip.env_flag("MSCLIP_FULL_LAST_BLOCK")) else \
             SKIPPED_ROWS_PER_PAIR[args.model] * 18 * WIDTH[args.model] ** 2 / 1e9
+        if skipped and model.precision == "bf16" and not hip.env_flag("MSCLIP_LAST_BLOCK_ALL_QUERIES"):
+            # ... and the last block's query projection (2 d^2 per skipped row) and attention (4 L d per skipped query) of
+            # the rows that are not read afterwards (engine._last_block_attention)
+            lv = SKIPPED_ROWS_PER_PAIR[args.model] + 2 - 77
+            skipped += (SKIPPED_ROWS_PER_PAIR[args.model] * 2 * WIDTH[args.model] ** 2 +
+                        ((lv - 1) * lv + 76 * 77) * 4 * WIDTH[args.model]) / 1e9
         gf = gf_ref - skipped                      # executed algorithmic FLOPs per pair
         fmul = 3 if ts is not None else 1          # backward counted as 2x forward
         rec = {
