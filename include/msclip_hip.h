@@ -299,12 +299,15 @@ typedef struct msclip_adamw_tensor {
   long long n;
   float lr;
   float weight_decay;
+  void* pk;        /* optional: a packed copy of the updated values, pk[i] = p[i] * pk_scale (the engine's bf16 operand of a */
+  float pk_scale;  /* projection weight, the 64^-0.5 of the q rows folded in), written by the same kernel; NULL = none      */
+  int pk_f32;      /* element type of pk: 0 = bf16, 1 = fp32                                                                */
 } msclip_adamw_tensor;
 
 /* AdamW with decoupled weight decay on one fp32 tensor (step >= 1 for the bias corrections). */
 int msclip_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
                  float weight_decay, int step, void* stream);
-/* The same update for `count` tensors in a handful of launches (32 K-element chunks of up to 48 tensors per launch, the
+/* The same update for `count` tensors in a handful of launches (32 K-element chunks of up to 36 tensors per launch, the
  * tensor table travels in the kernel arguments): bitwise the result of `count` msclip_adamw calls.  `tensors` is a HOST
  * array, read before the call returns. */
 int msclip_adamw_multi(const msclip_adamw_tensor* tensors, int count, float beta1, float beta2, float eps, int step,

@@ -472,11 +472,12 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 }
 
 // ---- the same update over many tensors per launch: block b works on chunk (map[b] >> 8) of tensor (map[b] & 255).
-constexpr int AW_TENSORS = 48, AW_BLOCKS = 400, AW_CHUNK = 32768;
+constexpr int AW_TENSORS = 36, AW_BLOCKS = 400, AW_CHUNK = 32768;   // 36 x 64 B + 400 x 4 B of kernel arguments (< 4 KiB)
 struct AdamwBatch {
   msclip_adamw_tensor t[AW_TENSORS];
   unsigned map[AW_BLOCKS];
 };
+static_assert(sizeof(AdamwBatch) <= 4000, "the tensor table travels in the kernel arguments");
 
 __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamwBatch a, float b1, float b2, float eps, float c1, float c2) {
   const unsigned e = a.map[blockIdx.x];
@@ -490,8 +491,12 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamwBatch a, fl
   float* __restrict__ v = t.v + lo;
   const float lr = t.lr, wd = t.weight_decay;
   auto upd = [&](float gi, float& mi, float& vi, float& pi) { adamw_update(gi, mi, vi, pi, lr, b1, b2, eps, wd, c1, c2); };
+  // packed copy of the new values (the engine's GEMM operand): same rounding as a cast of the updated tensor
+  bf16_t* __restrict__ pkb = t.pk && !t.pk_f32 ? (bf16_t*)t.pk + lo : nullptr;
+  float* __restrict__ pkf = t.pk && t.pk_f32 ? (float*)t.pk + lo : nullptr;
+  const float ps = t.pk_scale;
   int i0 = 0;
-  if (!(((size_t)p | (size_t)g | (size_t)m | (size_t)v) & 15)) {
+  if (!(((size_t)p | (size_t)g | (size_t)m | (size_t)v | (size_t)pkf) & 15) && !((size_t)pkb & 7)) {
     const int n4 = cnt >> 2;
     for (int i = threadIdx.x; i < n4; i += 256) {
       const float4 g4 = ((const float4*)g)[i];
@@ -503,6 +508,8 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamwBatch a, fl
       ((float4*)m)[i] = m4;
       ((float4*)v)[i] = v4;
       ((float4*)p)[i] = p4;
+      if (pkb) ((uint2*)pkb)[i] = make_uint2(pack_bf16x2(p4.x * ps, p4.y * ps), pack_bf16x2(p4.z * ps, p4.w * ps));
+      if (pkf) ((float4*)pkf)[i] = make_float4(p4.x * ps, p4.y * ps, p4.z * ps, p4.w * ps);
     }
     i0 = n4 << 2;
   }
@@ -512,6 +519,8 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamwBatch a, fl
     m[i] = mi;
     v[i] = vi;
     p[i] = pi;
+    if (pkb) pkb[i] = f32_to_bf16(pi * ps);
+    if (pkf) pkf[i] = pi * ps;
   }
 }
 
@@ -662,7 +671,9 @@ extern "C" int msclip_adamw_multi(const msclip_adamw_tensor* tensors, int count,
                                   void* stream) {
   if (!tensors || count < 0 || step < 1) return MSCLIP_EINVAL;
   for (int i = 0; i < count; ++i)
-    if (!tensors[i].p || !tensors[i].g || !tensors[i].m || !tensors[i].v || tensors[i].n <= 0) return MSCLIP_EINVAL;
+    if (!tensors[i].p || !tensors[i].g || !tensors[i].m || !tensors[i].v || tensors[i].n <= 0 ||
+        (tensors[i].pk && (tensors[i].pk_f32 < 0 || tensors[i].pk_f32 > 1)))
+      return MSCLIP_EINVAL;
   const float c1 = 1.f / (1.f - powf(beta1, (float)step)), c2 = 1.f / (1.f - powf(beta2, (float)step));
   AdamwBatch b;
   int nt = 0, nb = 0;
@@ -682,6 +693,7 @@ extern "C" int msclip_adamw_multi(const msclip_adamw_tensor* tensors, int count,
       b.t[nt].m += c * AW_CHUNK;
       b.t[nt].v += c * AW_CHUNK;
       b.t[nt].n -= c * AW_CHUNK;
+      if (b.t[nt].pk) b.t[nt].pk = (char*)b.t[nt].pk + (size_t)c * AW_CHUNK * (b.t[nt].pk_f32 ? 4 : 2);
       long long local = 0;
       while (c < chunks && nb < AW_BLOCKS) {
         b.map[nb++] = (unsigned)nt | ((unsigned)local << 8);

@@ -42,6 +42,8 @@ class _BlockW:
     """Packed weights of one ResidualAttentionBlock's shareable part."""
 
     def __init__(self, blk, heads, fp8=False):
+        self.blk = blk                               # the module these copies were made from (train.TrainStep maps parameters to them)
+        self.qscale = float(blk.attn.in_proj_weight.shape[1] // heads) ** -0.5
         self.wqkv, self.bqkv = P.qkv_weights(blk.attn.in_proj_weight.detach(), blk.attn.in_proj_bias.detach(), heads)
         if fp8:
             # MODEL.SPEC.PRECISION fp8 (BASELINE config C5): the LayerNorm-fed projections' weights as OCP e4m3 with one
@@ -106,17 +108,40 @@ class Engine:
             if not ref.is_cuda or ref.device != self.dev:
                 raise hip.HipUnavailable("model parameters left the engine's device: rebuild the engine (model.engine())")
             with torch.cuda.device(self.dev), torch.no_grad():
+                self._sdv = None
                 self._pack(self.model)
             self._stamp = stamp
             self._ws = {k: w for k, w in self._ws.items() if not (isinstance(k, tuple) and k and k[0] == "graph")}
             return True
         return False
 
+    def repack_after_optimizer(self):
+        """The re-pack behind an in-place optimizer step whose kernel has already written the transformer blocks' bf16 /
+        scaled copies itself (msclip_adamw_multi's `pk` outputs, train.TrainStep.step): the conv side (BatchNorm folds, NHWC
+        weight matrices), the heads and the logit scale, from the cached state-dict views -- not the 0.8 ms state_dict()
+        walk and the ~100 per-tensor casts of the blocks on a host that the GPU is waiting for.  Falls back to the full
+        re-pack for fp8 models (their e4m3 copies are quantised per row on the host side of the pack)."""
+        if self.fp8 or getattr(self, "_sdv", None) is None:
+            return self.refresh(force=True)
+        with torch.cuda.device(self.dev), torch.no_grad():
+            self._pack(self.model, blocks=False)
+        self._stamp = self._fingerprint()
+        self._ws = {k: w for k, w in self._ws.items() if not (isinstance(k, tuple) and k and k[0] == "graph")}
+        return True
+
+    def state_views(self):
+        """{state_dict key: detached tensor} of the module, made once per full re-pack: the tensors are the module's own
+        storage, so in-place updates (an optimizer step, load_state_dict) show through; a re-assigned parameter changes the
+        fingerprint and with it this cache."""
+        if getattr(self, "_sdv", None) is None:
+            self._sdv = {k: t.detach() for k, t in self.model.state_dict().items()}
+        return self._sdv
+
     # ------------------------------------------------------------------ packing
-    def _pack(self, m):
+    def _pack(self, m, blocks=True):
         dev = self.dev
         v, vt = m.visual, m.visual.transformer
-        sd = {k: t.detach() for k, t in m.state_dict().items()}
+        sd = dict(self.state_views())                # a copy: bn_fold_all parks its folds in it
         P.bn_fold_all(sd)
         self.D = m.transformer_width
         self.E = m.embed_dim
@@ -186,14 +211,15 @@ class Engine:
                 cache[key] = _BlockW(blk, self.heads, self.fp8)
             return cache[key]
 
-        self.vblk, self.tblk = [None] * self.n_layers, [None] * self.n_layers
-        for i in range(self.n_layers):
-            tb = m.transformer.resblocks[i]
-            self.tblk[i] = dict(w=blockw(tb), ln1=_LN(tb.ln_1), ln2=_LN(tb.ln_2))
-            if i >= 1:
-                vb = vt.resblocks[i]
-                self.vblk[i] = dict(w=blockw(vb), ln1=_LN(vb.ln_1), ln2=_LN(vb.ln_2))
-        self.n_packed_blocks = len(cache)
+        if blocks:                                   # (False: repack_after_optimizer, the copies are already current)
+            self.vblk, self.tblk = [None] * self.n_layers, [None] * self.n_layers
+            for i in range(self.n_layers):
+                tb = m.transformer.resblocks[i]
+                self.tblk[i] = dict(w=blockw(tb), ln1=_LN(tb.ln_1), ln2=_LN(tb.ln_2))
+                if i >= 1:
+                    vb = vt.resblocks[i]
+                    self.vblk[i] = dict(w=blockw(vb), ln1=_LN(vb.ln_1), ln2=_LN(vb.ln_2))
+            self.n_packed_blocks = len(cache)
 
         # --- text front / heads
         self.emb = m.token_embedding.weight.detach()

@@ -907,22 +907,55 @@ def bn_fold_bwd(G, w_raw, dshift, gamma, mean, var, eps):
 class AdamwTensor(ctypes.Structure):
     """msclip_adamw_tensor (include/msclip_hip.h)."""
     _fields_ = [("p", ctypes.c_void_p), ("g", ctypes.c_void_p), ("m", ctypes.c_void_p), ("v", ctypes.c_void_p),
-                ("n", ctypes.c_longlong), ("lr", ctypes.c_float), ("weight_decay", ctypes.c_float)]
+                ("n", ctypes.c_longlong), ("lr", ctypes.c_float), ("weight_decay", ctypes.c_float),
+                ("pk", ctypes.c_void_p), ("pk_scale", ctypes.c_float), ("pk_f32", ctypes.c_int)]
+
+
+class AdamwPlan:
+    """The host-side tensor table of msclip_adamw_multi, built once and reused while the tensors stay where they are (the
+    training step's parameters, its gradient slots inside the all-reduce buckets and the optimizer state do).
+    items: [(p, g, m, v, lr, weight_decay)] or [(p, g, m, v, lr, weight_decay, packed, packed_scale)] of contiguous fp32
+    tensors (flat views are fine); `packed` = a bf16 or fp32 tensor of the same element count that receives
+    p_new * packed_scale from the same kernel (the engine's operand copy), or None."""
+
+    def __init__(self, items):
+        n = len(items)
+        self.n = n
+        self.arr = (AdamwTensor * max(n, 1))()
+        self.device = items[0][0].device if n else None
+        # parameters, moments and packed copies live as long as the table; the gradients do not (set_grads re-points them)
+        self.keep = [(it[0], it[2], it[3]) + tuple(it[6:7]) for it in items]
+        for a, it in zip(self.arr, items):
+            p, g, m, v, lr, wd = it[:6]
+            for t in (p, g, m, v):
+                assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel() and t.device == p.device
+            a.p, a.g, a.m, a.v, a.n, a.lr, a.weight_decay = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, wd
+            pk = it[6] if len(it) > 6 else None
+            if pk is not None:
+                assert pk.dtype in (torch.bfloat16, torch.float32) and pk.is_contiguous() and pk.numel() == p.numel() and pk.device == p.device
+                a.pk, a.pk_scale, a.pk_f32 = pk.data_ptr(), float(it[7]), int(pk.dtype == torch.float32)
+
+    def set_grads(self, ptrs):
+        """Device addresses of this step's gradients, one per item (same element counts as at construction)."""
+        for a, g in zip(self.arr, ptrs):
+            a.g = g
+
+    def set_rates(self, rates):
+        """rates: [(lr, weight_decay)] per item."""
+        for a, (lr, wd) in zip(self.arr, rates):
+            a.lr, a.weight_decay = lr, wd
+
+    def run(self, beta1, beta2, eps, step):
+        if not self.n:
+            return
+        with torch.cuda.device(self.device):
+            _check(lib().msclip_adamw_multi(self.arr, self.n, beta1, beta2, eps, step, _stream()), "msclip_adamw_multi")
 
 
 def adamw_multi(items, beta1, beta2, eps, step):
-    """items: [(p, g, m, v, lr, weight_decay)] of contiguous fp32 tensors: one msclip_adamw_multi call (a handful of
-    launches for the model's 325 tensors instead of one each)."""
-    n = len(items)
-    if not n:
-        return
-    arr = (AdamwTensor * n)()
-    for a, (p, g, m, v, lr, wd) in zip(arr, items):
-        for t in (p, g, m, v):
-            assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel() and t.device == p.device
-        a.p, a.g, a.m, a.v, a.n, a.lr, a.weight_decay = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, wd
-    with torch.cuda.device(items[0][0].device):
-        _check(lib().msclip_adamw_multi(arr, n, beta1, beta2, eps, step, _stream()), "msclip_adamw_multi")
+    """items: see AdamwPlan: one msclip_adamw_multi call (a handful of launches for the model's 325 tensors instead of one
+    each)."""
+    AdamwPlan(items).run(beta1, beta2, eps, step)
 
 
 def adamw(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):

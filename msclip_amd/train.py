@@ -460,30 +460,86 @@ class TrainStep:
         """(name, parameter, lr, weight_decay) for every parameter: module-level param_groups() with this step's settings."""
         return param_groups(self.model, self.lr, self.lr_share, self.wd, self.wd_share, self.without_wd)
 
+    def _packed_destinations(self):
+        """{id(parameter): [(first element, element count, packed tensor, scale)]}: the engine's copies of the transformer
+        blocks' projection tensors that are plain (scaled) casts of a parameter -- AdamW writes them from the same kernel as
+        the parameter itself (msclip_adamw_tensor.pk).  in_proj: the q rows carry head_dim^-0.5 (packing.qkv_weights)."""
+        e = self.eng
+        out = {}
+        for blk in {id(b["w"]): b["w"] for b in list(e.tblk) + [b for b in e.vblk if b is not None]}.values():
+            a, mlp = blk.blk.attn, blk.blk.mlp
+            d = a.in_proj_weight.shape[1]
+            out[id(a.in_proj_weight)] = [(0, d * d, blk.wqkv.view(-1)[:d * d], blk.qscale),
+                                         (d * d, 2 * d * d, blk.wqkv.view(-1)[d * d:], 1.0)]
+            out[id(a.in_proj_bias)] = [(0, d, blk.bqkv[:d], blk.qscale), (d, 2 * d, blk.bqkv[d:], 1.0)]
+            out[id(a.out_proj.weight)] = [(0, blk.wo.numel(), blk.wo.view(-1), 1.0)]
+            out[id(mlp.c_fc.weight)] = [(0, blk.wfc.numel(), blk.wfc.view(-1), 1.0)]
+            out[id(mlp.c_proj.weight)] = [(0, blk.wpr.numel(), blk.wpr.view(-1), 1.0)]
+        return out
+
+    def _adamw_plan(self, grads):
+        """The tensor table of the optimizer launch: built once, per step only the gradient addresses are re-pointed;
+        rebuilt when the set of gradients changes, the optimizer state is replaced or the engine has re-packed (new copies)."""
+        pk_ok = not self.eng.fp8
+        sig = (id(self.eng.tblk[0]["w"].wqkv), pk_ok, id(self.state))
+        plan = getattr(self, "_plan", None)
+        if plan is not None and plan.sig == sig and len(grads) == plan.ngrads and \
+                all(k in grads and grads[k].dtype == F32 and grads[k].numel() == n for k, n in plan.names.items()):
+            # same tensors, this step's gradients (fresh allocations on one GPU, the bucket slots at N > 1); the few that
+            # arrive as permuted views (depthwise adapter weights) are made contiguous, alive until the launch is queued
+            flat = {k: (grads[k] if grads[k].is_contiguous() else grads[k].contiguous()) for k in plan.names}
+            plan.hold = flat
+            plan.set_grads([flat[k].data_ptr() + 4 * lo for k, lo in plan.pieces])
+            if plan.rates_for != (self.lr, self.lr_share, self.wd, self.wd_share):
+                groups = {k: (lr, wd) for k, _, lr, wd in self.param_groups()}
+                plan.set_rates([groups[k] for k, _ in plan.pieces])
+                plan.rates_for = (self.lr, self.lr_share, self.wd, self.wd_share)
+            return plan
+        dests = self._packed_destinations() if pk_ok else {}
+        items, pieces, names, hold = [], [], {}, []
+        for k, p, lr, wd in self.param_groups():
+            g = grads.get(k)
+            if g is None:
+                continue
+            g = g.reshape(p.shape).contiguous().view(-1)
+            hold.append(g)
+            st = self.state.get(k)
+            if st is None:
+                st = self.state[k] = (torch.zeros_like(p), torch.zeros_like(p))
+            pf, mf, vf = p.data.view(-1), st[0].view(-1), st[1].view(-1)
+            names[k] = p.numel()
+            for lo, n, pk, scale in dests.get(id(p), [(0, p.numel(), None, 1.0)]):
+                items.append((pf[lo:lo + n], g[lo:lo + n], mf[lo:lo + n], vf[lo:lo + n], lr, wd, pk, scale))
+                pieces.append((k, lo))
+        plan = hip.AdamwPlan(items)
+        plan.sig, plan.pieces, plan.names, plan.ngrads = sig, pieces, names, len(grads)
+        plan.rates_for = (self.lr, self.lr_share, self.wd, self.wd_share)
+        plan.packs = bool(dests)
+        plan.hold = hold
+        self._plan = plan
+        return plan
+
     @hip.off_default_stream
     def step(self, grads, world_average=False):
-        """AdamW on the module's fp32 parameters (msclip_adamw), then the engine re-packs its bf16 copies.  backward()
-        already returns rank-averaged gradients; world_average=True averages here instead, tensor by tensor (for
-        gradients produced with backward(reduce=False))."""
+        """AdamW on the module's fp32 parameters (msclip_adamw_multi), which also writes the engine's bf16 copies of the
+        transformer blocks' projections; the engine re-packs the rest (conv side, heads).  backward() already returns
+        rank-averaged gradients; world_average=True averages here instead, tensor by tensor (for gradients produced with
+        backward(reduce=False))."""
         if self.lr is None:
             raise ValueError("TrainStep.step() needs a learning rate: TrainStep(model, lr=...) or train.from_config(model, config)")
         self.steps += 1
         with torch.no_grad():
-            items = []
-            for k, p, lr, wd in self.param_groups():
-                g = grads.get(k)
-                if g is None:
-                    continue
-                g = g.reshape(p.shape).contiguous()
-                if world_average and C.comm.world_size > 1:
+            if world_average and C.comm.world_size > 1:
+                for g in grads.values():
                     dist.all_reduce(g)
                     g /= C.comm.world_size
-                st = self.state.get(k)
-                if st is None:
-                    st = self.state[k] = (torch.zeros_like(p), torch.zeros_like(p))
-                items.append((p.data.view(-1), g.view(-1), st[0].view(-1), st[1].view(-1), lr, wd))
-            hip.adamw_multi(items, self.betas[0], self.betas[1], self.eps, self.steps)     # in-place: refresh below re-packs
-        self.eng.refresh(force=True)
+            plan = self._adamw_plan(grads)
+            plan.run(self.betas[0], self.betas[1], self.eps, self.steps)
+            plan.hold = None
+        if plan.packs:
+            self.eng.repack_after_optimizer()
+        else:
+            self.eng.refresh(force=True)
 
 
 def param_groups(model, lr, lr_share, wd, wd_share, without_wd=("bn", "bias", "ln")):
@@ -557,6 +613,7 @@ def resume_checkpoint(model, ts, path):
         p = params[names[int(i)]]
         ts.state[names[int(i)]] = (st["exp_avg"].to(p.device).contiguous(), st["exp_avg_sq"].to(p.device).contiguous())
     ts.steps = int(opt["msclip"]["steps"])
+    ts._plan = None                                   # the cached optimizer table points at the moments just replaced
     ts.eng.refresh(force=True)
     return int(obj.get("step", ts.steps))
 

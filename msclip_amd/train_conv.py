@@ -273,7 +273,7 @@ class _RawSpecs:
 
     def __init__(self, e):
         self.e = e
-        sd = {k: t.detach() for k, t in e.model.state_dict().items()}
+        sd = e.state_views()
         dev = e.dev
         sp = "visual.transformer.resblocks.0"
 
@@ -305,9 +305,13 @@ class _RawSpecs:
 
     def refresh(self):
         e = self.e
-        sd = {k: t.detach() for k, t in e.model.state_dict().items()}
+        sd = e.state_views()
         for sp_, key in self.items:
-            sp_.weight.copy_(P.pad_k(P.conv_weight_matrix(sd[key].float())).to(BF))
+            # [Cout, Cin, KH, KW] fp32 -> the spec's [Cout, Kpad] bf16 matrix in (kh, kw, ci) order: ONE strided, converting copy
+            # into its first K columns (the pad columns stay zero) instead of permute / pad / cast / copy
+            wt = sd[key]
+            co, ci, kh, kw = wt.shape
+            sp_.weight[:, :kh * kw * ci].view(co, kh, kw, ci).copy_(wt.permute(0, 2, 3, 1))
         sp = "visual.transformer.resblocks.0"
 
         def first(key):                                  # [48, 3, 3, 3] -> [48, 64] bf16 in the patch matrix's (kh, kw, ci) order

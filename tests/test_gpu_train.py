@@ -250,6 +250,35 @@ def test_adamw_multi_equals_per_tensor_calls(gpu_device):
         hip.adamw_multi([(one[0][0], one[0][0], one[0][1], one[0][2], 1e-3, 0.0)], 0.9, 0.98, 1e-6, 0)
 
 
+def test_adamw_multi_packed_copies(gpu_device):
+    """msclip_adamw_tensor.pk: the kernel also writes p_new * pk_scale as bf16 (the engine's projection operands, q rows
+    carrying 64^-0.5) or fp32 (the scaled in_proj bias): bitwise what a cast of the updated tensor gives; tensors that span
+    launches and unaligned gradient views included; the parameter update itself is unchanged."""
+    sizes = [8, 768 * 768, 3 * 32768 + 12, 20_000_003, 5000, 7]
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    flat = torch.randn(sum(sizes) + len(sizes) + 1, device="cuda", generator=gen)
+    offs, o = [], 1
+    for n in sizes:
+        offs.append(o)
+        o += n + 1
+    gs = [flat[o:o + n] for o, n in zip(offs, sizes)]
+    ps = [torch.randn(n, device="cuda", generator=gen) for n in sizes]
+    plain = [(p.clone(), torch.zeros_like(p), torch.zeros_like(p)) for p in ps]
+    packd = [(p.clone(), torch.zeros_like(p), torch.zeros_like(p)) for p in ps]
+    kinds = [(torch.bfloat16, 0.125), (torch.bfloat16, 1.0), (torch.float32, 0.125), (torch.bfloat16, 0.125), (None, 1.0), (torch.float32, 1.0)]
+    pks = [None if dt is None else torch.full((n + 8,), 7.0, dtype=dt, device="cuda") for (dt, _), n in zip(kinds, sizes)]
+    plan = hip.AdamwPlan([(p, g, m, v, 1e-3, 0.1, None if pk is None else pk[:n], sc)
+                          for (p, m, v), g, pk, (_, sc), n in zip(packd, gs, pks, kinds, sizes)])
+    for step in (1, 2):
+        hip.adamw_multi([(p, g, m, v, 1e-3, 0.1) for (p, m, v), g in zip(plain, gs)], 0.9, 0.999, 1e-8, step)
+        plan.run(0.9, 0.999, 1e-8, step)
+    for (p1, _, _), (p2, _, _), pk, (dt, sc), n in zip(plain, packd, pks, kinds, sizes):
+        assert torch.equal(p1, p2)
+        if pk is not None:
+            assert torch.equal(pk[:n], (p2 * sc).to(dt)), (n, dt)
+            assert bool((pk[n:] == 7.0).all())
+
+
 @pytest.mark.parametrize("geom", [(2, 12, 16, 3, 2, 1), (3, 9, 8, 1, 2, 0), (2, 8, 24, 3, 1, 1), (2, 10, 3, 3, 2, 1)])
 def test_im2col_col2im_against_conv_autograd(gpu_device, geom):
     """dW = dY^T . im2col(X) and dX = col2im(dY . W) against autograd of F.conv2d (fp32 on the same bf16 values);
@@ -576,6 +605,46 @@ def test_adamw_step_with_reference_param_groups_lowers_the_loss(gpu_device, bn):
         assert abs(m.contrastive_loss(img, tok).item() - inf0) > 1e-4
     ts.saved = None
     assert l1 < l0, (l0, l1)
+
+
+@pytest.mark.parametrize("bn", ["frozen", "batch"])
+def test_optimizer_step_keeps_the_engine_copies_current(gpu_device, bn):
+    """TrainStep.step() lets AdamW write the transformer blocks' bf16 copies and re-packs only the conv side / heads
+    (Engine.repack_after_optimizer); after three steps every packed tensor equals, bit for bit, what a freshly built engine
+    packs from the module, and the cached optimizer table is the one of step 1."""
+    from msclip_amd.engine import Engine
+    m = _fresh_model("b32-yfcc-msclips")
+    ts = train.TrainStep(m, lr=3e-5, lr_share=2e-5, bn=bn)
+    img, tok = synth.synth_images(6, seed=61).cuda(), synth.synth_tokens(6, seed=62).cuda()
+    plans = []
+    for _ in range(3):
+        ts.forward(img, tok)
+        ts.step(ts.backward())
+        plans.append(ts._plan)
+    assert plans[1] is plans[0] and plans[2] is plans[0] and plans[0].packs
+    ts.lr = 1e-5                                                       # a schedule moves the rate: same table, new rates
+    ts.forward(img, tok)
+    ts.step(ts.backward())
+    assert ts._plan is plans[0]
+    got, want = ts.eng, Engine(m)
+    for i in range(got.n_layers):
+        for blocks in ("tblk", "vblk"):
+            a, b = getattr(got, blocks)[i], getattr(want, blocks)[i]
+            if a is None:
+                assert b is None
+                continue
+            for f in ("wqkv", "bqkv", "wo", "bo", "wfc", "bfc", "wpr", "bpr"):
+                assert torch.equal(getattr(a["w"], f), getattr(b["w"], f)), (blocks, i, f)
+            for ln in ("ln1", "ln2"):
+                assert torch.equal(a[ln].g, b[ln].g) and torch.equal(a[ln].b, b[ln].b)
+    for a, b in zip(got.stem_specs, want.stem_specs):
+        assert torch.equal(a.weight, b.weight) and torch.equal(a.bias, b.bias)
+    for j in range(1, 5):
+        for a, b in zip(got.par_specs[j], want.par_specs[j]):
+            assert torch.equal(a.weight, b.weight) and torch.equal(a.bias, b.bias)
+    assert torch.equal(got.w_vproj, want.w_vproj) and torch.equal(got.w_tproj, want.w_tproj) and torch.equal(got.w_last, want.w_last)
+    assert torch.equal(got.dual_w, want.dual_w)
+    assert got.logit_scale_exp == want.logit_scale_exp
 
 
 @pytest.mark.parametrize("name", ["b32-yfcc-msclips", "b16-yfcc-msclips"])
