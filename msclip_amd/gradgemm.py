@@ -9,22 +9,13 @@ from . import hip
 BF = torch.bfloat16
 F32 = torch.float32
 
-_SIDE = {}
-import os
-# Cap on the concurrent K-slices of a wide weight gradient.  Each slice is a persistent GEMM of `tiles` workgroups (9-36)
-# on its own stream, and the whole job runs beside the main stream's dgrad GEMMs (wgrad_async): TWO slices (18-72 CUs
-# for the gradient, the rest for the critical path) measured best -- ViT-B/32 batch 512 step 142.5 / 126.1 / 129.3 / 132.0 /
-# 138.3 ms at caps 1 / 2 / 4 / 8 / 28 -- and is the only setting that does not depend on how many hardware queues the
-# runtime maps streams to (GPU_MAX_HW_QUEUES 4 -> 8: cap 2 127 -> 127 ms, cap 3 131 -> 168 ms, cap 28 139 -> 186 ms).
-_WGRAD_STREAMS = int(os.environ.get("MSCLIP_WGRAD_STREAMS", "2"))
-
 
 def wgrad(dy_bf, x_bf, M, out=None):
     """dW[N, K] = dY^T @ X over the first M rows of dy_bf [*, N] and x_bf [*, K] (bf16): both operands transposed so the
-    token axis is the contiguous K axis of the GEMM (zero-padded).  A weight gradient has few output tiles (9-36 of
-    256 x 256) over a very deep contraction (65 024 tokens at batch 512): the contraction is cut into S slices whose
-    GEMMs run concurrently on S side streams into fp32 partials, folded in a fixed order (deterministic).  `out` (fp32
-    [N, K], contiguous): where the gradient is written (a slot of a gradient bucket, comm.GradReducer.reserve)."""
+    token axis is the contiguous K axis of the GEMM (zero-padded).  A weight gradient has few output tiles over a very
+    deep contraction (65 024 tokens at batch 512, up to 6.4 M pixels): the contraction is cut into S slices, workgroup
+    rows of ONE launch, into fp32 partials folded in a fixed order (deterministic).  `out` (fp32 [N, K], contiguous):
+    where the gradient is written (a slot of a gradient bucket, comm.GradReducer.reserve)."""
     N, K = dy_bf.shape[1], x_bf.shape[1]
     tiles = ((N + 255) // 256) * ((K + 255) // 256)
     if tiles <= 4:
@@ -34,7 +25,8 @@ def wgrad(dy_bf, x_bf, M, out=None):
         S = max(1, min(512 // t128, M // 1024))
         Mpad = (M + 64 * S - 1) // (64 * S) * (64 * S)
         return hip.gemm_splitk(hip.transpose_bf16(dy_bf, M, Mpad), hip.transpose_bf16(x_bf, M, Mpad), S, out=out)
-    S = max(1, min(_WGRAD_STREAMS, 256 // tiles, M // 4096))
+    # wide gradients: ONE split-K launch of the ping-pong GEMM (tiles x slices workgroups, see WgradJob)
+    S = max(1, min(256 // tiles, M // 2048))
     Mpad = (M + 64 * S - 1) // (64 * S) * (64 * S)
     a = hip.transpose_bf16(dy_bf, M, Mpad)
     b = hip.transpose_bf16(x_bf, M, Mpad)
@@ -43,25 +35,7 @@ def wgrad(dy_bf, x_bf, M, out=None):
     if S == 1:
         hip.gemm(a, b, out)
         return out
-    kc = Mpad // S
-    part = torch.empty(S, N, K, dtype=F32, device=a.device)
-    cur = torch.cuda.current_stream(a.device)
-    pool = _SIDE.get(a.device)
-    if pool is None:
-        pool = _SIDE[a.device] = [hip.background_stream(a.device) for _ in range(_WGRAD_STREAMS)]
-    ready = torch.cuda.Event()
-    ready.record(cur)
-    for sidx in range(S):
-        st = pool[sidx]
-        st.wait_event(ready)
-        with torch.cuda.stream(st):
-            hip.gemm(a[:, sidx * kc:(sidx + 1) * kc], b[:, sidx * kc:(sidx + 1) * kc], part[sidx], tile=4)
-        cur.wait_stream(st)
-    for t in (a, b, part):
-        for sidx in range(S):
-            t.record_stream(pool[sidx])
-    hip.colsum(part.view(S, N * K), out=out.view(-1))
-    return out
+    return hip.gemm_splitk(a, b, S, out=out, tile=4)
 
 
 def dgrad(dy_bf, w_t, out=None):
