@@ -120,8 +120,6 @@ def main():
                     help="time forward + backward + AdamW of the training step (msclip_amd.train: every parameter gets a "
                          "gradient; BatchNorm with frozen running statistics) instead of the forward step -- a separate "
                          "metric, never the headline")
-    ap.add_argument("--graph", action="store_true",
-                    help="--train: replay the step from one captured hipGraph (train.TrainStep.capture) instead of launching it from Python")
     ap.add_argument("--bn", choices=("batch", "frozen"), default="batch",
                     help="--train only: train-mode BatchNorm with per-GPU batch statistics (default, the reference's train() "
                          "semantics) or frozen running statistics")
@@ -166,15 +164,7 @@ def main():
         from msclip_amd import train
         ts = train.from_config(model, named_config(args.model), bn=args.bn)
 
-    captured = [None]
-    if ts is not None and args.graph:
-        if world > 1:
-            raise SystemExit("--graph: single-GPU steps only")
-        captured[0] = ts.capture(img, tok)
-
     def step():
-        if captured[0] is not None:
-            return captured[0](img, tok)
         if ts is not None:
             loss = ts.forward(img, tok)
             ts.step(ts.backward())
@@ -223,15 +213,8 @@ def main():
     # being timed); the timed region's own (overlapped) figure is reported beside it.
     overlapped = (ts is None and os.environ.get("MSCLIP_CONV_SIDE_STREAM", "1") != "0")
     probe_timed, dt_probe = probe, dt
-    replayed = captured[0] is not None
-    if probe is not None and replayed:
-        # a replayed graph has no launches to bracket: the per-kernel figures come from a pass of the same steps launched
-        # from Python (same kernels, same arguments)
-        captured[0] = None
-        probe_timed = None
-    if probe is not None and (overlapped or replayed):
-        if overlapped:
-            os.environ["MSCLIP_CONV_SIDE_STREAM"] = "0"
+    if probe is not None and overlapped:
+        os.environ["MSCLIP_CONV_SIDE_STREAM"] = "0"
         step()
         probe, probe8 = hip.KernelProbe(), hip.KernelProbe()
         hip.set_gemm_probe(DOMINANT["variant"], probe)
@@ -246,8 +229,7 @@ def main():
         hip.set_gemm_probe(DOMINANT["variant"], None)
         hip.set_gemm_probe("pp2", None)
         hip.set_gemm_f8_probe(None)
-        if overlapped:
-            del os.environ["MSCLIP_CONV_SIDE_STREAM"]
+        del os.environ["MSCLIP_CONV_SIDE_STREAM"]
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -289,8 +271,6 @@ def main():
             rec["config"]["bn"] = ("train mode: per-GPU batch statistics, running statistics updated (momentum 0.1)"
                                    if args.bn == "batch" else "frozen running statistics (folded); gamma / beta receive gradients")
         if not shared:
-            if replayed:
-                rec["config"]["launch"] = "one hipGraph replay per step (train.TrainStep.capture)"
             rec["config"]["rccl_ranks"] = dist.get_world_size() if world > 1 else 1
         else:
             rec["config"]["gloo_ranks"] = dist.get_world_size()
@@ -310,10 +290,7 @@ def main():
                                "flops_per_launch_avg": round(flops / n / 1e9, 3), "flops_unit": "GFLOP",
                                "algorithmic_bytes_per_launch": round(alg_bytes),
                                "time_share_of_step": round(kms / (dt_probe * 1e3), 4)}
-            if replayed:
-                rec["roofline"]["measured_in"] = (f"probe pass: the same {args.steps} steps launched from Python "
-                                                  f"({dt_probe / args.steps * 1e3:.3f} ms/step); the timed region replays them from one hipGraph")
-            elif probe_timed is not probe:
+            if probe_timed is not probe:
                 n2, kms2, flops2 = probe_timed.summary()
                 ach2 = flops2 / (kms2 * 1e-3) / 1e12
                 rec["roofline"]["measured_in"] = (f"probe pass: the same {args.steps} steps with the conv branch inline "

@@ -312,11 +312,6 @@ int msclip_adamw(float* p, const float* g, float* m, float* v, long long n, floa
  * array, read before the call returns. */
 int msclip_adamw_multi(const msclip_adamw_tensor* tensors, int count, float beta1, float beta2, float eps, int step,
                        void* stream);
-/* The same with this step's scalars read from DEVICE memory, hyper = {1 / (1 - beta1^step), 1 / (1 - beta2^step), factor on
- * every tensor's lr}: the form a captured hipGraph replays (train.TrainStep.capture); the caller updates `hyper` in stream
- * order ahead of each replay. */
-int msclip_adamw_multi_dev(const msclip_adamw_tensor* tensors, int count, float beta1, float beta2, float eps,
-                           const float* hyper, void* stream);
 
 /* HIP streams with an explicit priority on the current device.  The training step runs its weight-gradient jobs beside the
  * dgrad chain (the role torch DDP's / autograd's side streams play under the reference's lib/core/function.py:66-77

@@ -479,16 +479,7 @@ struct AdamwBatch {
 };
 static_assert(sizeof(AdamwBatch) <= 4000, "the tensor table travels in the kernel arguments");
 
-// hyper (optional, device memory): {bias correction 1, bias correction 2, learning-rate factor} of THIS step, for launches
-// that are replayed from a captured graph (the host-side values would be the capture step's for ever).
-__global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamwBatch a, float b1, float b2, float eps, float c1, float c2,
-                                                          const float* __restrict__ hyper) {
-  float lr_factor = 1.f;
-  if (hyper) {
-    c1 = hyper[0];
-    c2 = hyper[1];
-    lr_factor = hyper[2];
-  }
+__global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamwBatch a, float b1, float b2, float eps, float c1, float c2) {
   const unsigned e = a.map[blockIdx.x];
   const msclip_adamw_tensor& t = a.t[e & 255u];
   const size_t lo = (size_t)(e >> 8) * AW_CHUNK;
@@ -498,7 +489,7 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamwBatch a, fl
   const float* __restrict__ g = t.g + lo;
   float* __restrict__ m = t.m + lo;
   float* __restrict__ v = t.v + lo;
-  const float lr = t.lr * lr_factor, wd = t.weight_decay;
+  const float lr = t.lr, wd = t.weight_decay;
   auto upd = [&](float gi, float& mi, float& vi, float& pi) { adamw_update(gi, mi, vi, pi, lr, b1, b2, eps, wd, c1, c2); };
   // packed copy of the new values (the engine's GEMM operand): same rounding as a cast of the updated tensor
   bf16_t* __restrict__ pkb = t.pk && !t.pk_f32 ? (bf16_t*)t.pk + lo : nullptr;
@@ -676,24 +667,9 @@ extern "C" int msclip_adamw(float* p, const float* g, float* m, float* v, long l
   return msclip_launch_status();
 }
 
-static int adamw_multi_launch(const msclip_adamw_tensor* tensors, int count, float beta1, float beta2, float eps, int step,
-                              const float* hyper, void* stream);
-
 extern "C" int msclip_adamw_multi(const msclip_adamw_tensor* tensors, int count, float beta1, float beta2, float eps, int step,
                                   void* stream) {
-  if (step < 1) return MSCLIP_EINVAL;
-  return adamw_multi_launch(tensors, count, beta1, beta2, eps, step, nullptr, stream);
-}
-
-extern "C" int msclip_adamw_multi_dev(const msclip_adamw_tensor* tensors, int count, float beta1, float beta2, float eps,
-                                      const float* hyper, void* stream) {
-  if (!hyper) return MSCLIP_EINVAL;
-  return adamw_multi_launch(tensors, count, beta1, beta2, eps, 1, hyper, stream);
-}
-
-static int adamw_multi_launch(const msclip_adamw_tensor* tensors, int count, float beta1, float beta2, float eps, int step,
-                              const float* hyper, void* stream) {
-  if (!tensors || count < 0) return MSCLIP_EINVAL;
+  if (!tensors || count < 0 || step < 1) return MSCLIP_EINVAL;
   for (int i = 0; i < count; ++i)
     if (!tensors[i].p || !tensors[i].g || !tensors[i].m || !tensors[i].v || tensors[i].n <= 0 ||
         (tensors[i].pk && (tensors[i].pk_f32 < 0 || tensors[i].pk_f32 > 1)))
@@ -702,7 +678,7 @@ static int adamw_multi_launch(const msclip_adamw_tensor* tensors, int count, flo
   AdamwBatch b;
   int nt = 0, nb = 0;
   auto flush = [&]() {
-    if (nb) hipLaunchKernelGGL(adamw_multi_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, b, beta1, beta2, eps, c1, c2, hyper);
+    if (nb) hipLaunchKernelGGL(adamw_multi_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, b, beta1, beta2, eps, c1, c2);
     nt = nb = 0;
   };
   for (int i = 0; i < count; ++i) {

@@ -138,7 +138,7 @@ class Engine:
         return self._sdv
 
     # ------------------------------------------------------------------ packing
-    def _pack(self, m, blocks=True, logit_scale=True):
+    def _pack(self, m, blocks=True):
         dev = self.dev
         v, vt = m.visual, m.visual.transformer
         sd = dict(self.state_views())                # a copy: bn_fold_all parks its folds in it
@@ -159,11 +159,10 @@ class Engine:
         # host until everything queued before the re-pack has finished -- after an optimizer step that is the whole
         # training step, and the next step's launches would start against an empty GPU queue.  So: an asynchronous copy into
         # pinned memory now, the wait when the value is first used (the logits stage, at the end of a forward).
-        if logit_scale:                              # (False: inside a captured training step, which keeps it on the device)
-            self._ls_host = torch.empty(1, dtype=torch.float32).pin_memory()
-            self._ls_host.copy_(m.logit_scale.detach().exp().reshape(1), non_blocking=True)
-            self._ls_event = torch.cuda.Event()
-            self._ls_event.record(torch.cuda.current_stream(dev))
+        self._ls_host = torch.empty(1, dtype=torch.float32).pin_memory()
+        self._ls_host.copy_(m.logit_scale.detach().exp().reshape(1), non_blocking=True)
+        self._ls_event = torch.cuda.Event()
+        self._ls_event.record(torch.cuda.current_stream(dev))
 
         # --- stem
         sp = "visual.transformer.resblocks.0"

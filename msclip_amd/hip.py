@@ -22,7 +22,7 @@ EXPORTS = (
     "msclip_lse_rows", "msclip_clip_loss_partial", "msclip_clip_lse_fused", "msclip_clip_loss_from_partials",
     "msclip_transpose_bf16", "msclip_cast_bf16", "msclip_colsum", "msclip_quickgelu", "msclip_quickgelu_bwd", "msclip_layernorm_bwd",
     "msclip_attention_bwd", "msclip_l2norm_bwd", "msclip_clip_loss_bwd_g", "msclip_embed_tokens_bwd", "msclip_adapter_sum",
-    "msclip_adapter_dx", "msclip_adamw", "msclip_adamw_multi", "msclip_adamw_multi_dev", "msclip_im2col", "msclip_col2im", "msclip_relu_bwd", "msclip_dwpool_bwd",
+    "msclip_adapter_dx", "msclip_adamw", "msclip_adamw_multi", "msclip_im2col", "msclip_col2im", "msclip_relu_bwd", "msclip_dwpool_bwd",
     "msclip_dwpool_wgrad", "msclip_dw3x3_wgrad", "msclip_gemm_splitk", "msclip_bn_stats", "msclip_bn_apply",
     "msclip_bn_bwd_reduce", "msclip_bn_bwd_dx", "msclip_bn_fold_bwd", "msclip_bn_finish",
     "msclip_abi_version", "msclip_build_arch",
@@ -114,7 +114,6 @@ def lib():
         L.msclip_adapter_dx.argtypes = [vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, vp]
         L.msclip_adamw.argtypes = [vp, vp, vp, vp, ll, cf, cf, cf, cf, cf, ci, vp]
         L.msclip_adamw_multi.argtypes = [ctypes.POINTER(AdamwTensor), ci, cf, cf, cf, ci, vp]
-        L.msclip_adamw_multi_dev.argtypes = [ctypes.POINTER(AdamwTensor), ci, cf, cf, cf, vp, vp]
         L.msclip_im2col.argtypes = [vp, ci, vp] + [ci] * 11 + [vp]
         L.msclip_col2im.argtypes = [vp, ci, vp] + [ci] * 11 + [vp]
         L.msclip_relu_bwd.argtypes = [vp, vp, vp, vp, ll, vp]
@@ -234,7 +233,7 @@ def priority_stream(device, urgent):
 
 
 def background_stream(device):
-    """The stream kind of the weight-gradient lane: a torch pool stream (normal priority).  Lowest
+    """The stream kind of the weight-gradient lane and its slice streams: a torch pool stream (normal priority).  Lowest
     priority (MSCLIP_LANE_PRIORITY=low) measured the same without collectives but 139-147 ms instead of 110-112 on the
     ViT-B/32 batch-512 step once RCCL collectives are issued in the process (tools/probes/reducer_probe.py)."""
     if os.environ.get("MSCLIP_LANE_PRIORITY", "normal") == "low":
@@ -946,17 +945,11 @@ class AdamwPlan:
         for a, (lr, wd) in zip(self.arr, rates):
             a.lr, a.weight_decay = lr, wd
 
-    def run(self, beta1, beta2, eps, step, hyper=None):
-        """hyper: fp32 device tensor {1 / (1 - beta1^step), 1 / (1 - beta2^step), lr factor} read by the kernel instead of
-        the host-side `step` (graph replays)."""
+    def run(self, beta1, beta2, eps, step):
         if not self.n:
             return
         with torch.cuda.device(self.device):
-            if hyper is not None:
-                assert hyper.dtype == torch.float32 and hyper.is_cuda and hyper.numel() >= 3
-                _check(lib().msclip_adamw_multi_dev(self.arr, self.n, beta1, beta2, eps, _p(hyper), _stream()), "msclip_adamw_multi_dev")
-            else:
-                _check(lib().msclip_adamw_multi(self.arr, self.n, beta1, beta2, eps, step, _stream()), "msclip_adamw_multi")
+            _check(lib().msclip_adamw_multi(self.arr, self.n, beta1, beta2, eps, step, _stream()), "msclip_adamw_multi")
 
 
 def adamw_multi(items, beta1, beta2, eps, step):

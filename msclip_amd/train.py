@@ -72,10 +72,9 @@ class TrainStep:
         finally:
             self.eng.force_unfused = False
 
-    def _forward(self, img, tok, refresh=True):
+    def _forward(self, img, tok):
         e = self.eng
-        if refresh:
-            e.refresh()
+        e.refresh()
         with torch.cuda.device(e.dev), torch.no_grad():
             Bi, Bt = img.shape[0], tok.shape[0]
             assert Bi == Bt, "a training step needs image-text pairs"
@@ -541,92 +540,6 @@ class TrainStep:
             self.eng.repack_after_optimizer()
         else:
             self.eng.refresh(force=True)
-
-
-    def capture(self, img, tok, warmup=2):
-        """-> CapturedStep: this step (conv-side re-pack, forward, backward, AdamW) recorded once as a hipGraph on example
-        inputs of the batch shape, then replayed -- one graph launch per step instead of ~1 900 kernel launches."""
-        return CapturedStep(self, img, tok, warmup)
-
-
-class CapturedStep:
-    """A whole training step as ONE hipGraph launch.  What is recorded, in this order: the engine's re-pack of the conv side
-    and the heads from the parameters as the previous replay left them, TrainStep.forward, .backward, and AdamW with its
-    per-step scalars read from device memory (msclip_adamw_multi_dev: the bias corrections come from a step counter that
-    lives on the device and is advanced inside the graph, the learning-rate factor is a device scalar the caller sets).
-    The eager step launches ~1 900 kernels from Python; at batch 512 the host keeps ahead of the GPU except around the step
-    boundary (the conv side's backward, the optimizer, the re-pack and the conv front are hundreds of short launches in a
-    row), where the GPU idles ~6 of 86 ms waiting for launches (profiles/r03_train_host_gaps.md).
-
-        step = ts.capture(img, tok)          # a few eager warm-up steps, then the capture (both are real steps)
-        loss = step(img, tok, lr_factor=1.0) # copies the batch into the graph's input tensors, replays
-
-    One process, one GPU stream set: collectives are not recorded (world size 1 only); PRECISION fp8 models are not
-    supported (their e4m3 copies are quantised by the host-side pack).  Between replays the module's parameters are
-    current; the engine's own copies of the conv side lag one step, so the first eager call afterwards re-packs."""
-
-    def __init__(self, ts, img, tok, warmup=2):
-        if C.comm.collectives or C.comm.world_size > 1:
-            raise NotImplementedError("CapturedStep: single-process steps only (collectives are not recorded)")
-        e = ts.eng
-        if e.fp8:
-            raise NotImplementedError("CapturedStep: PRECISION fp8 models re-pack on the host")
-        if ts.lr is None:
-            raise ValueError("TrainStep.capture() needs a learning rate")
-        self.ts = ts
-        dev = e.dev
-        with torch.cuda.device(dev):
-            self.img, self.tok = img.detach().clone(), tok.detach().clone()
-            b1, b2 = ts.betas
-            self.step_t = torch.full((1,), float(ts.steps), dtype=torch.float64, device=dev)
-            self.hyper = torch.ones(3, dtype=F32, device=dev)
-            self.beta = torch.tensor([b1, b2], dtype=torch.float64, device=dev)
-            cur = torch.cuda.current_stream(dev)
-            side = torch.cuda.Stream(device=dev)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                for _ in range(max(1, warmup)):
-                    self._body()
-            cur.wait_stream(side)
-            torch.cuda.synchronize(dev)
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self.loss = self._body()
-            # the graph reads and writes these by address: they live as long as it does
-            self._keep = (ts._plan, list(e.tblk), list(e.vblk), e._ws)
-        ts.steps += max(1, warmup)                        # (the capture itself records, it does not execute)
-        e._stamp = None                                   # the next eager call re-packs (refresh() compares against it)
-
-    def _body(self):
-        ts = self.ts
-        e = ts.eng
-        with torch.cuda.device(e.dev), torch.no_grad():
-            e._pack(e.model, blocks=False, logit_scale=False)
-            self.step_t += 1
-            self.hyper[:2] = (1.0 / (1.0 - torch.pow(self.beta, self.step_t))).to(F32)
-        try:
-            loss = ts._forward(self.img, self.tok, refresh=False)
-        finally:
-            e.force_unfused = False
-        grads = ts.backward()
-        with torch.no_grad():
-            plan = ts._adamw_plan(grads)
-            if not plan.packs:
-                raise NotImplementedError("CapturedStep needs the optimizer kernel to write the engine's copies")
-            plan.run(ts.betas[0], ts.betas[1], ts.eps, 1, hyper=self.hyper)
-            plan.hold = None
-        return loss
-
-    def __call__(self, img, tok, lr_factor=1.0):
-        ts = self.ts
-        with torch.cuda.device(ts.eng.dev), torch.no_grad():
-            self.img.copy_(img, non_blocking=True)
-            self.tok.copy_(tok, non_blocking=True)
-            self.hyper[2:].fill_(float(lr_factor))
-            self.graph.replay()
-        ts.steps += 1
-        ts.eng._stamp = None
-        return self.loss
 
 
 def param_groups(model, lr, lr_share, wd, wd_share, without_wd=("bn", "bias", "ln")):
