@@ -233,7 +233,7 @@ def priority_stream(device, urgent):
 
 
 def background_stream(device):
-    """The stream kind of the weight-gradient lane and its slice streams: a torch pool stream (normal priority).  Lowest
+    """The stream kind of the weight-gradient lane: a torch pool stream (normal priority).  Lowest
     priority (MSCLIP_LANE_PRIORITY=low) measured the same without collectives but 139-147 ms instead of 110-112 on the
     ViT-B/32 batch-512 step once RCCL collectives are issued in the process (tools/probes/reducer_probe.py)."""
     if os.environ.get("MSCLIP_LANE_PRIORITY", "normal") == "low":
