@@ -199,6 +199,11 @@ int msclip_transpose_bf16(const void* in, int ldi, void* out, int ldo, int M, in
 
 /* y = bf16(x) for an fp32 matrix (C, ldx, ldy multiples of 4): gradient streams are fp32, GEMM operands bf16. */
 int msclip_cast_bf16(const float* x, int ldx, void* y, int ldy, int M, int C, void* stream);
+/* msclip_cast_bf16 that also leaves the column sums of x: part [part_blocks][C] fp32 receives per-block partial sums (block b
+ * sums the rows b, b + part_blocks, ...); fold them with msclip_colsum.  The training step's residual-stream gradient is both
+ * the bf16 operand of its projection's dgrad / wgrad GEMMs and, summed over the tokens, that projection's bias gradient.
+ * C <= 1024, C % 4 == 0. */
+int msclip_cast_bf16_colsum(const float* x, int ldx, void* y, int ldy, int M, int C, float* part, int part_blocks, void* stream);
 
 /* out[n] (+)= sum_m x[m][n] (x bf16 or fp32): bias gradients, LayerNorm parameter gradients' second stage.  chunks > 1:
  * two deterministic stages through scratch [chunks, N] (row chunks in parallel, then folded); chunks == 1: one launch. */

@@ -170,6 +170,29 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ x, 
   }
 }
 
+// ---- the same copy, and the column sums of the fp32 matrix from the same pass (a residual-stream gradient is cast for its
+// dgrad / wgrad GEMMs and summed over the tokens for the projection's bias gradient: one read instead of two).  Block b takes
+// the rows b, b + gridDim.x, ...; thread t the columns 4t .. 4t+3 of every one of them (blockDim.x >= C/4); part[b][C] receives
+// the block's sums (folded by msclip_colsum, fixed order: deterministic).
+__global__ __launch_bounds__(256) void cast_colsum_kernel(const float* __restrict__ x, int ldx, bf16_t* __restrict__ y, int ldy,
+                                                          int M, int C4, float* __restrict__ part) {
+  const int t = threadIdx.x;
+  if (t >= C4) return;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int m = blockIdx.x; m < M; m += gridDim.x) {
+    const float4 v = *(const float4*)(x + (size_t)m * ldx + t * 4);
+    uint2 o;
+    o.x = pack_bf16x2(v.x, v.y);
+    o.y = pack_bf16x2(v.z, v.w);
+    *(uint2*)(y + (size_t)m * ldy + t * 4) = o;
+    acc.x += v.x;
+    acc.y += v.y;
+    acc.z += v.z;
+    acc.w += v.w;
+  }
+  *(float4*)(part + ((size_t)blockIdx.x * C4 + t) * 4) = acc;
+}
+
 // ---- QuickGELU forward on a saved pre-activation (training keeps h for the backward) and its backward:
 // y = h * sigma(1.702 h)  (M.py:222-224);  dh = dy * (sigma + 1.702 h sigma (1 - sigma)).
 __global__ __launch_bounds__(256) void quickgelu_kernel(const bf16_t* __restrict__ h, bf16_t* __restrict__ y, size_t n8) {
@@ -546,6 +569,16 @@ extern "C" int msclip_cast_bf16(const float* x, int ldx, void* y, int ldy, int M
   if (!x || !y || M <= 0 || C <= 0 || (C & 3) || (ldx & 3) || (ldy & 3)) return MSCLIP_EINVAL;
   hipLaunchKernelGGL(cast_kernel, dim3(grid_for((size_t)M * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, x, ldx,
                      (bf16_t*)y, ldy, M, C / 4);
+  return msclip_launch_status();
+}
+
+extern "C" int msclip_cast_bf16_colsum(const float* x, int ldx, void* y, int ldy, int M, int C, float* part, int part_blocks,
+                                       void* stream) {
+  if (!x || !y || !part || M <= 0 || C <= 0 || C > 1024 || (C & 3) || (ldx & 3) || (ldy & 3) || part_blocks < 1 ||
+      ((size_t)part & 15))
+    return MSCLIP_EINVAL;
+  hipLaunchKernelGGL(cast_colsum_kernel, dim3(part_blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, (bf16_t*)y, ldy, M, C / 4,
+                     part);
   return msclip_launch_status();
 }
 

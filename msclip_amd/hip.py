@@ -20,7 +20,7 @@ EXPORTS = (
     "msclip_adapter_combine_ln", "msclip_l2norm", "msclip_gather_rows", "msclip_stem_conv3x3s2_dual", "msclip_dwpool",
     "msclip_stem_dual_conv3x3s2", "msclip_conv1x1_conv3x3s2", "msclip_convresblock48_s2",
     "msclip_lse_rows", "msclip_clip_loss_partial", "msclip_clip_lse_fused", "msclip_clip_loss_from_partials",
-    "msclip_transpose_bf16", "msclip_cast_bf16", "msclip_colsum", "msclip_quickgelu", "msclip_quickgelu_bwd", "msclip_layernorm_bwd",
+    "msclip_transpose_bf16", "msclip_cast_bf16", "msclip_cast_bf16_colsum", "msclip_colsum", "msclip_quickgelu", "msclip_quickgelu_bwd", "msclip_layernorm_bwd",
     "msclip_attention_bwd", "msclip_l2norm_bwd", "msclip_clip_loss_bwd_g", "msclip_embed_tokens_bwd", "msclip_adapter_sum",
     "msclip_adapter_dx", "msclip_adamw", "msclip_adamw_multi", "msclip_im2col", "msclip_col2im", "msclip_relu_bwd", "msclip_dwpool_bwd",
     "msclip_dwpool_wgrad", "msclip_dw3x3_wgrad", "msclip_gemm_splitk", "msclip_bn_stats", "msclip_bn_apply",
@@ -102,6 +102,7 @@ def lib():
         ll = ctypes.c_longlong
         L.msclip_transpose_bf16.argtypes = [vp, ci, vp, ci, ci, ci, ci, vp]
         L.msclip_cast_bf16.argtypes = [vp, ci, vp, ci, ci, ci, vp]
+        L.msclip_cast_bf16_colsum.argtypes = [vp, ci, vp, ci, ci, ci, vp, ci, vp]
         L.msclip_colsum.argtypes = [vp, ci, ci, vp, ci, ci, ci, vp, ci, vp]
         L.msclip_quickgelu.argtypes = [vp, vp, ll, vp]
         L.msclip_quickgelu_bwd.argtypes = [vp, vp, vp, ll, vp]
@@ -633,6 +634,19 @@ def cast_bf16(x, out=None):
         out = torch.empty(M, C, dtype=torch.bfloat16, device=x.device)
     _check(lib().msclip_cast_bf16(_p(x), x.stride(0), _p(out), out.stride(0), M, C, _stream()), "msclip_cast_bf16")
     return out
+
+
+def cast_bf16_colsum(x, out=None):
+    """-> (bf16 copy of the fp32 matrix x, its column sums fp32 [C]) from one pass over x."""
+    assert x.dtype == torch.float32 and x.stride(-1) == 1
+    M, C = x.shape
+    if out is None:
+        out = torch.empty(M, C, dtype=torch.bfloat16, device=x.device)
+    blocks = max(1, min(1024, M // 16))
+    part = torch.empty(blocks, C, dtype=torch.float32, device=x.device)
+    _check(lib().msclip_cast_bf16_colsum(_p(x), x.stride(0), _p(out), out.stride(0), M, C, _p(part), blocks, _stream()),
+           "msclip_cast_bf16_colsum")
+    return out, colsum(part)
 
 
 def colsum(x, out=None, M=None, accumulate=False):

@@ -347,6 +347,16 @@ class TrainStep:
             head(sv["fv_raw"], dfi, sv["hv"], e.w_vproj, e.ln_post, "visual.proj", "visual.ln_post", row_mul=e.Lv)
             head(sv["ft_raw"], dft, sv["ht"], e.w_tproj, e.ln_final, "text_projection", "ln_final", row_idx=sv["eot"])
 
+            def cast_with_bias_sums(dX, dY, r_lo, groups):
+                """dY[r_lo:M] = bf16(dX[r_lo:M]) -- the operand of a projection's dgrad / wgrad GEMMs -- and {id(block
+                weights): column sums of the group's rows} = that projection's bias gradient; one pass over dX when a
+                single (shared) weight set covers all rows."""
+                if len(groups) == 1 and groups[0][0] == r_lo and groups[0][1] == M:
+                    _, s = hip.cast_bf16_colsum(dX[r_lo:M], dY[r_lo:M])
+                    return {id(groups[0][2]): s}
+                hip.cast_bf16(dX[r_lo:M], dY[r_lo:M])
+                return {id(bw): hip.colsum(dX[r0:r1]) for r0, r1, bw in groups}
+
             # ---- blocks, last to first
             for i in reversed(range(e.n_layers)):
                 L = sv["layers"][i]
@@ -356,14 +366,14 @@ class TrainStep:
                     names[id(e.vblk[i]["w"])] = f"visual.transformer.resblocks.{i}"
                 hid = L["hid"]
                 dY = torch.empty(M, D, dtype=BF, device=dev)
-                hip.cast_bf16(dX[r_lo:M], dY[r_lo:M])
+                bsum = cast_with_bias_sums(dX, dY, r_lo, groups)
                 # gradients of the LayerNorm outputs stay fp32: they are only read by the LayerNorm backward, whose dbeta /
                 # dgamma are column sums of nearly cancelling terms (a bf16 dy costs 10-30 % on those sums at small batch)
                 dlno = torch.empty(M, D, dtype=F32, device=dev)
                 for r0, r1, bw in groups:
                     p = names[id(bw)]
                     wide_wgrad(p + ".mlp.c_proj.weight", dY[r0:r1], hid[r0:r1], r1 - r0, (D, 4 * D))
-                    grads[p + ".mlp.c_proj.bias"] = hip.colsum(dX[r0:r1])
+                    grads[p + ".mlp.c_proj.bias"] = bsum[id(bw)]
                 dh = torch.empty(M, 4 * D, dtype=BF, device=dev)
                 for r0, r1, bw in groups:
                     if (r1 - r0) % 256 == 0:
@@ -385,13 +395,13 @@ class TrainStep:
                     grads[pre + ".ln_2.weight"], grads[pre + ".ln_2.bias"] = dg, db
                 # attention half
                 dY2 = torch.empty(M, D, dtype=BF, device=dev)          # not dY again: the lane stream may still read it (c_proj wgrad)
-                hip.cast_bf16(dX[r_lo:M], dY2[r_lo:M])
+                bsum = cast_with_bias_sums(dX, dY2, r_lo, groups)
                 dao = torch.empty(M, D, dtype=BF, device=dev)
                 dqkv = torch.zeros(M, 3 * D, dtype=BF, device=dev)
                 for r0, r1, bw in groups:
                     p = names[id(bw)]
                     wide_wgrad(p + ".attn.out_proj.weight", dY2[r0:r1], L["ao"][r0:r1], r1 - r0, (D, D))
-                    grads[p + ".attn.out_proj.bias"] = hip.colsum(dX[r0:r1])
+                    grads[p + ".attn.out_proj.bias"] = bsum[id(bw)]
                     _dgrad(dY2[r0:r1], bw.wo.t().contiguous(), dao[r0:r1])
                 if e.vblk[i] is not None:
                     hip.attention_bwd(L["qkv"][:Mv], L["ao"][:Mv], dao[:Mv], dqkv[:Mv], Bi, e.Lv, e.heads, False)

@@ -1,7 +1,3 @@
-def test_gemm_chip_filling_launches_back_to_back_and_on_two_streams(gpu_device, M, N, K, resid):
-    """Launches of >= 3 tiles per workgroup, repeated and on two streams at once: every tile exactly once (NaN prefill: a
-    skipped tile stays NaN; a tile computed twice into the fp32 residual stream doubles its increment).  Written for the
-    dynamic per-XCD tile lists that were tried in round 3 (history: 'gemm: dynamic tile lists'), kept for the static ones."""
 """Per-kernel parity on a real MI355X: each C-ABI entry point against a plain fp32 PyTorch statement of the same op,
 on seeded random (asymmetric, transpose-detecting) data, including ragged sizes that exercise every bounds guard."""
 import pytest
@@ -790,11 +786,10 @@ def test_layernorm_f8_and_row_quant(gpu_device, C):
 
 @pytest.mark.parametrize("M,N,K,resid", [(256 * 100, 2304, 768, False), (256 * 100 + 37, 768, 768, True), (256 * 90, 3072, 256, False),
                                           (256 * 33 + 5, 3072 - 8, 1024, False)])
-def test_gemm_dynamic_tile_lists(gpu_device, M, N, K, resid):
-    """Launches that fill the chip with >= 3 tiles per workgroup take their tiles from the per-XCD counters
-    (gemm_pp_kernel<0, false, true>): every tile exactly once (NaN prefill: a skipped tile stays NaN, a tile computed twice
-    into the fp32 residual stream doubles its increment), over back-to-back launches (counter and mailbox left clean) and
-    two streams at once (a scheduling block per stream)."""
+def test_gemm_chip_filling_launches_back_to_back_and_on_two_streams(gpu_device, M, N, K, resid):
+    """Launches of >= 3 tiles per workgroup, repeated and on two streams at once: every tile exactly once (NaN prefill: a
+    skipped tile stays NaN; a tile computed twice into the fp32 residual stream doubles its increment).  Written for the
+    dynamic per-XCD tile lists that were tried in round 3 (history: 'gemm: dynamic tile lists'), kept for the static ones."""
     x, w, b = rnd(M, K, seed=41, dtype=BF), rnd(N, K, seed=42, scale=0.05, dtype=BF), rnd(N, seed=43)
     ref = x.float() @ w.float().t() + b
     outs = []

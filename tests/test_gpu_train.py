@@ -91,6 +91,21 @@ def test_transpose_cast_colsum_gelu(gpu_device):
     assert rel(dh, hf.grad) < 1e-2
 
 
+@pytest.mark.parametrize("M,C", [(65024, 768), (1000, 768), (37, 512), (5000, 1024)])
+def test_cast_with_column_sums(gpu_device, M, C):
+    """msclip_cast_bf16_colsum: the bf16 copy of msclip_cast_bf16 (bitwise) and the fp32 column sums of the same pass, on a
+    row-range view of a wider buffer; rows past M untouched."""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    buf = torch.randn(M + 5, C + 8, device="cuda", generator=g)
+    x = buf[2:2 + M, :C]
+    out = torch.full((M + 2, C), 7.0, dtype=torch.bfloat16, device="cuda")
+    y, s = hip.cast_bf16_colsum(x, out[:M])
+    assert torch.equal(y, hip.cast_bf16(x.contiguous())) and bool((out[M:] == 7.0).all())
+    ref = x.double().sum(0)
+    assert (s.double() - ref).abs().max().item() <= 2e-6 * x.abs().double().sum(0).max().item()
+    assert torch.equal(s, hip.cast_bf16_colsum(x, out[:M])[1])                      # fixed order
+
+
 @pytest.mark.parametrize("C,dy_f32,gather", [(768, False, False), (768, True, False), (512, False, False), (768, False, True)])
 def test_layernorm_backward(gpu_device, C, dy_f32, gather):
     M = 1000
