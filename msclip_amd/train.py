@@ -397,7 +397,7 @@ class TrainStep:
                 dY2 = torch.empty(M, D, dtype=BF, device=dev)          # not dY again: the lane stream may still read it (c_proj wgrad)
                 bsum = cast_with_bias_sums(dX, dY2, r_lo, groups)
                 dao = torch.empty(M, D, dtype=BF, device=dev)
-                dqkv = torch.zeros(M, 3 * D, dtype=BF, device=dev)
+                dqkv = torch.empty(M, 3 * D, dtype=BF, device=dev)      # attention_bwd writes every row of the towers that ran
                 for r0, r1, bw in groups:
                     p = names[id(bw)]
                     wide_wgrad(p + ".attn.out_proj.weight", dY2[r0:r1], L["ao"][r0:r1], r1 - r0, (D, D))
