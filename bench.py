@@ -120,6 +120,8 @@ def main():
                     help="time forward + backward + AdamW of the training step (msclip_amd.train: every parameter gets a "
                          "gradient; BatchNorm with frozen running statistics) instead of the forward step -- a separate "
                          "metric, never the headline")
+    ap.add_argument("--precision", choices=("bf16", "fp8", "fp8-qkv"), default=None,
+                    help="override MODEL.SPEC.PRECISION of the config (fp8: c_fc / c_proj on the fp8 MFMA; fp8-qkv: in_proj as well)")
     ap.add_argument("--bn", choices=("batch", "frozen"), default="batch",
                     help="--train only: train-mode BatchNorm with per-GPU batch statistics (default, the reference's train() "
                          "semantics) or frozen running statistics")
@@ -151,7 +153,7 @@ def main():
     grouped = dist.is_initialized()
 
     sd = synth.synth_state_dict(load_schema(args.model), seed=0)
-    model = get_clip_model(named_config(args.model))
+    model = get_clip_model(named_config(args.model, ["MODEL.SPEC.PRECISION", args.precision] if args.precision else None))
     model.load_state_dict(sd, strict=True)
     model = model.to(dev).eval()
     eng = model.engine()
@@ -237,7 +239,7 @@ def main():
         gf_ref = GFLOP_PER_PAIR[args.model]
         skipped = 0.0 if (ts is not None or hip.env_flag("MSCLIP_FULL_LAST_BLOCK")) else \
             SKIPPED_ROWS_PER_PAIR[args.model] * 18 * WIDTH[args.model] ** 2 / 1e9
-        if skipped and model.precision == "bf16" and not hip.env_flag("MSCLIP_LAST_BLOCK_ALL_QUERIES"):
+        if skipped and model.precision != "fp8-qkv" and not hip.env_flag("MSCLIP_LAST_BLOCK_ALL_QUERIES"):
             # ... and the last block's query projection (2 d^2 per skipped row) and attention (4 L d per skipped query) of
             # the rows that are not read afterwards (engine._last_block_attention)
             lv = SKIPPED_ROWS_PER_PAIR[args.model] + 2 - 77
@@ -251,7 +253,8 @@ def main():
             "mfma_util_pct": None,
             "value": round(pairs_s, 1), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if model.precision == "bf16" else "fp8 e4m3 operands (QKV, c_fc) + bf16 (everything else), fp32 accumulation",
+            "dtype": "bf16" if model.precision == "bf16" else
+                     f"fp8 e4m3 operands ({'in_proj, ' if model.precision == 'fp8-qkv' else ''}c_fc, c_proj) + bf16 (everything else), fp32 accumulation",
             "data": "synthetic",
             "config": {"workload": f"MS-CLIP-S {args.model} fwd + contrastive step (both towers, gather, logits, "
                                    f"symmetric CE), per-GPU batch {B}, 224x224 images + 77-token captions, "
@@ -327,7 +330,7 @@ def main():
         if n8 > 0:                      # PRECISION fp8: the config's own kernel gets the headline roofline, the bf16 GEMM moves beside it
             n8, kms8, flops8 = probe8.summary()
             ach8 = flops8 / (kms8 * 1e-3) / 1e12
-            r8 = {"kernel": "gemm_pp_kernel<0, true> (dense fp8 e4m3 MX-MFMA GEMM: QKV and c_fc of every block)", "bound": "mfma",
+            r8 = {"kernel": "gemm_pp_kernel<0, true> (dense fp8 e4m3 MX-MFMA GEMM: c_fc / c_proj of every block, in_proj under fp8-qkv)", "bound": "mfma",
                   "achieved": round(ach8, 1), "peak": PEAK_FP8_TFLOPS, "unit": "TFLOP/s", "frac": round(ach8 / PEAK_FP8_TFLOPS, 4),
                   "traffic": None, "launches_per_step": n8 // args.steps, "avg_launch_us": round(kms8 / n8 * 1e3, 2),
                   "flops_per_launch_avg": round(flops8 / n8 / 1e9, 3), "flops_unit": "GFLOP",

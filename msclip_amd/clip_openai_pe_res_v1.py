@@ -227,9 +227,10 @@ class CLIP(nn.Module):
                  vocab_size, transformer_width, transformer_heads, transformer_layers, gather_tensors=False,
                  custom_config=None, precision="bf16"):
         super().__init__()
-        if precision not in ("bf16", "fp8"):
-            raise NotImplementedError(f"MODEL.SPEC.PRECISION = {precision!r}: 'bf16' (default) or 'fp8' (BASELINE config C5: the "
-                                      "LayerNorm-fed projections on the MX fp8 MFMA; no reference semantics)")
+        if precision not in ("bf16", "fp8", "fp8-qkv"):
+            raise NotImplementedError(f"MODEL.SPEC.PRECISION = {precision!r}: 'bf16' (default), 'fp8' (BASELINE config C5: the MLP "
+                                      "projections c_fc / c_proj on the MX fp8 MFMA) or 'fp8-qkv' (in_proj as well: faster, and "
+                                      "noisier through the softmax); no reference semantics")
         self.precision = precision
         for key in _UNSUPPORTED_TRUTHY:
             if _get(custom_config, key, False):

@@ -41,17 +41,18 @@ def _text0_stream(device):
 class _BlockW:
     """Packed weights of one ResidualAttentionBlock's shareable part."""
 
-    def __init__(self, blk, heads, fp8=False):
+    def __init__(self, blk, heads, fp8=False, fp8_qkv=False):
         self.blk = blk                               # the module these copies were made from (train.TrainStep maps parameters to them)
         self.qscale = float(blk.attn.in_proj_weight.shape[1] // heads) ** -0.5
         self.wqkv, self.bqkv = P.qkv_weights(blk.attn.in_proj_weight.detach(), blk.attn.in_proj_bias.detach(), heads)
         if fp8:
             # MODEL.SPEC.PRECISION fp8 (BASELINE config C5): the LayerNorm-fed projections' weights as OCP e4m3 with one
             # scale per output channel, quantised from the fp32 parameters (q rows carry 64^-0.5 like the bf16 copy)
-            d = blk.attn.in_proj_weight.shape[1]
-            wq = blk.attn.in_proj_weight.detach().float().clone()
-            wq[:d] *= 0.125
-            self.wqkv_q, self.wqkv_s = hip.quantize_rows_f8(wq)
+            if fp8_qkv:
+                d = blk.attn.in_proj_weight.shape[1]
+                wq = blk.attn.in_proj_weight.detach().float().clone()
+                wq[:d] *= self.qscale
+                self.wqkv_q, self.wqkv_s = hip.quantize_rows_f8(wq)
             self.wfc_q, self.wfc_s = hip.quantize_rows_f8(blk.mlp.c_fc.weight.detach())
             self.wpr_q, self.wpr_s = hip.quantize_rows_f8(blk.mlp.c_proj.weight.detach())
             # static scale of the MLP hidden matrix (c_fc's e4m3 output = c_proj's operand): calibrated on the first batch
@@ -151,7 +152,8 @@ class Engine:
         self.Lt = m.context_length
         self.S = v.input_resolution
         self.n_layers = len(m.transformer.resblocks)
-        self.fp8 = getattr(m, "precision", "bf16") == "fp8"
+        self.fp8 = getattr(m, "precision", "bf16").startswith("fp8")          # c_fc / c_proj on the fp8 MFMA
+        self.fp8_qkv = getattr(m, "precision", "bf16") == "fp8-qkv"           # ... and in_proj
         if self.fp8 and self.D % 128:
             raise NotImplementedError("PRECISION fp8 needs a width that is a multiple of 128 (one K-tile of the MX MFMA)")
         assert len(vt.resblocks) == self.n_layers, "vision and text depth must match for the batched layer loop"
@@ -208,7 +210,7 @@ class Engine:
             key = (blk.attn.in_proj_weight.data_ptr(), blk.attn.out_proj.weight.data_ptr(),
                    blk.mlp.c_fc.weight.data_ptr(), blk.mlp.c_proj.weight.data_ptr())
             if key not in cache:
-                cache[key] = _BlockW(blk, self.heads, self.fp8)
+                cache[key] = _BlockW(blk, self.heads, self.fp8, self.fp8_qkv)
             return cache[key]
 
         if blocks:                                   # (False: repack_after_optimizer, the copies are already current)
@@ -561,7 +563,8 @@ class Engine:
                 vis_src, raw = w["XA"], X[:Mv]          # ln_1 reads the adapter output and moves it back into X
             # --- ln_1 (modality specific parameters; one launch over both towers' rows unless the adapter output
             #     has to be picked up from its own buffer)
-            if self.fp8:
+            f8_qkv = self.fp8_qkv
+            if f8_qkv:
                 if raw is not None:                          # the adapter's output moves back into the residual matrix first
                     hip.gather_rows(vis_src, raw, Mv)
                 self._ln_f8(w, segs, "ln1")
@@ -577,12 +580,12 @@ class Engine:
             groups = [(segs[0][0], segs[-1][1], segs[0][2]["w"])] if len(segs) == 2 and vb["w"] is tb["w"] else \
                      [(r0, r1, b["w"]) for r0, r1, b in segs]
             last_live = i == self.n_layers - 1 and compact
-            if last_live and not self.fp8 and not hip.env_flag("MSCLIP_LAST_BLOCK_ALL_QUERIES"):
+            if last_live and not f8_qkv and not hip.env_flag("MSCLIP_LAST_BLOCK_ALL_QUERIES"):
                 self._last_block_attention(w, Bi, Bt, groups)
                 self._last_block_tail(w, Bi, Bt, vb, tb, attended=True)
                 continue
             for r0, r1, bw in groups:
-                if self.fp8:
+                if f8_qkv:
                     hip.gemm_f8(w["LNQ"][r0:r1], bw.wqkv_q, QKV[r0:r1], w["RS"][r0:r1], bw.wqkv_s, bias=bw.bqkv)
                 else:
                     hip.gemm(LNO[r0:r1], bw.wqkv, QKV[r0:r1], bias=bw.bqkv)

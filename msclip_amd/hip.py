@@ -671,7 +671,13 @@ def colsum(x, out=None, M=None, accumulate=False):
             return out
     if out is None:
         out = torch.empty(N, dtype=torch.float32, device=x.device)
-    chunks = 1 if M <= 2048 else min(256, (M + 511) // 512)           # long matrices: row chunks in parallel, then folded
+    if M > 2048:
+        chunks = min(256, (M + 511) // 512)                           # long matrices: row chunks in parallel, then folded
+    else:
+        # 64-2048 rows (per-block partials of the LayerNorm backward, of the cast + column-sum pass, of the BatchNorm kernels):
+        # one chunk would be (N / 64) workgroups -- 12 for 768 columns -- each walking every row: 26 us for 3 MB.  Enough
+        # chunks for ~384 workgroups of >= 32 rows
+        chunks = max(1, min(M // 32, -(-384 // ((N + 63) // 64))))
     scratch = torch.empty(chunks, N, dtype=torch.float32, device=x.device) if chunks > 1 else None
     _check(lib().msclip_colsum(_p(x), x.stride(0), int(x.dtype == torch.float32), _p(out), M, N, int(accumulate),
                                _p(scratch), chunks, _stream()), "msclip_colsum")

@@ -636,33 +636,38 @@ def test_l16_standin_bf16_against_reference_golden(gpu_device):
     assert el <= LOGIT_TOL
 
 
+@pytest.mark.parametrize("precision", ["fp8", "fp8-qkv"])
 @pytest.mark.parametrize("name", ["b32-yfcc-msclips", "l16-fp8-msclips"])
-def test_fp8_projections_against_the_bf16_path(gpu_device, name):
-    """MODEL.SPEC.PRECISION fp8 (QKV and c_fc on the MX fp8 MFMA, e4m3 LayerNorm outputs with per-token scales, per-channel
-    weight scales) has no reference semantics: PARITY UNPINNED.  Checked against this build's own bf16 path on the same
-    weights (cosine floors below, on the unit features) and, through it, loosely against the reference golden."""
+def test_fp8_projections_against_the_bf16_path(gpu_device, name, precision):
+    """MODEL.SPEC.PRECISION fp8 (c_fc and c_proj on the MX fp8 MFMA: e4m3 LayerNorm output with per-token scales, e4m3 hidden
+    matrix with a calibrated static scale, per-channel weight scales) and fp8-qkv (in_proj as well) have no reference
+    semantics: PARITY UNPINNED.  Checked against this build's own bf16 path on the same weights (cosine floors below, on the
+    unit features) and, through it, loosely against the reference golden."""
     bf = _model_with(name, ["MODEL.SPEC.PRECISION", "bf16"])
-    f8 = _model_with(name, ["MODEL.SPEC.PRECISION", "fp8"])
-    assert f8.engine().fp8 and not bf.engine().fp8
+    f8 = _model_with(name, ["MODEL.SPEC.PRECISION", precision])
+    assert f8.engine().fp8 and not bf.engine().fp8 and f8.engine().fp8_qkv == (precision == "fp8-qkv")
     img, tok = synth.synth_images(6, seed=33).cuda(), synth.synth_tokens(6, seed=34).cuda()
     # first batch = calibration of the MLP hidden matrix's static e4m3 scale (c_fc with a bf16 output, c_proj in bf16); the
     # measured calls below run c_fc -> e4m3 hidden -> fp8 c_proj wherever the row count is whole 256-row tiles
     f8(synth.synth_images(256, seed=35).cuda(), synth.synth_tokens(256, seed=36).cuda())
     assert all(b["w"].hid_scale is not None for b in f8.engine().tblk[:-1])      # (the last block's tail runs on the live rows, bf16)
     big_i, big_t = synth.synth_images(256, seed=37).cuda(), synth.synth_tokens(256, seed=38).cuda()
-    cb = torch.nn.functional.cosine_similarity(f8.encode_text(big_t), bf.encode_text(big_t), dim=-1).min().item()
-    ci_b = torch.nn.functional.cosine_similarity(f8.encode_image(big_i), bf.encode_image(big_i), dim=-1).min().item()
-    print(f"{name}: batch 256 (fp8 c_proj active): min cosine image {ci_b:.5f} text {cb:.5f}")
     cos = torch.nn.functional.cosine_similarity
+    cb = cos(f8.encode_text(big_t), bf.encode_text(big_t), dim=-1).min().item()
+    ci_b = cos(f8.encode_image(big_i), bf.encode_image(big_i), dim=-1).min().item()
+    print(f"{name} {precision}: batch 256 (fp8 c_proj active): min cosine image {ci_b:.5f} text {cb:.5f}")
     ci = cos(f8.encode_image(img), bf.encode_image(img), dim=-1).min().item()
     ct = cos(f8.encode_text(tok), bf.encode_text(tok), dim=-1).min().item()
     dl = (f8(img, tok) - bf(img, tok)).abs().max().item()
-    print(f"{name}: fp8 vs bf16 path: min cosine image {ci:.5f} text {ct:.5f}, logits max-abs diff {dl:.3f} (T = 1/0.07)")
-    # e4m3 operands carry ~2^-4 relative rounding noise per element (~3 % per projection output, uncorrelated between
-    # layers; the softmax of the synthetic weights' wide attention logits amplifies the QKV share, most in the causal text
-    # tower).  Measured (deterministic): ViT-B/32 image 0.99888 / text 0.99509, the 24-layer stand-in 0.9982 / 0.9928.
-    # Stated floors: 0.998 / 0.994 and 0.997 / 0.99.
-    fi, ft = (0.998, 0.994) if name.startswith("b32") else (0.997, 0.99)
+    print(f"{name} {precision}: batch 6 (fp8 c_fc, bf16 c_proj): min cosine image {ci:.5f} text {ct:.5f}, logits max-abs diff {dl:.3f} (T = 1/0.07)")
+    # e4m3 operands carry ~2^-4 relative rounding noise per element (~3 % per projection output, uncorrelated between layers).
+    # Measured (deterministic), image / text, batch 6 | batch 256:
+    #   fp8      ViT-B/32 0.99950 / 0.99884 | 0.99897 / 0.99693     24-layer stand-in 0.99921 / 0.99844 | 0.99814 / 0.99552
+    #   fp8-qkv  ViT-B/32 0.99888 / 0.99509 | 0.99805 / 0.99225     24-layer stand-in 0.99820 / 0.99282 | 0.99695 / 0.98828
+    # (in_proj's noise is amplified by the softmax of the synthetic weights' wide attention logits, most in the causal text tower)
+    floors = {("fp8", "b32"): ((0.999, 0.998), (0.9985, 0.996)), ("fp8", "l16"): ((0.9985, 0.9975), (0.9975, 0.9945)),
+              ("fp8-qkv", "b32"): ((0.998, 0.994), (0.995, 0.990)), ("fp8-qkv", "l16"): ((0.997, 0.99), (0.994, 0.986))}
+    (fi, ft), (fib, ftb) = floors[(precision, name[:3])]
     assert ci >= fi and ct >= ft
-    assert ci_b >= fi - 0.003 and cb >= ft - 0.004               # ... with the e4m3 hidden matrix and fp8 c_proj on top
+    assert ci_b >= fib and cb >= ftb                             # ... with the e4m3 hidden matrix and fp8 c_proj on top
     assert abs(f8.contrastive_loss(img, tok).item() - bf.contrastive_loss(img, tok).item()) <= 0.1
