@@ -11,6 +11,8 @@ run_line c2_b32_b512 --shapes
 run_line c3_b16_b256 --model b16-yfcc-msclips --batch 256 --no-cpu-baseline
 run_line c4rank_b32_b1024 --batch 1024 --no-cpu-baseline
 run_line c5_l16_fp8_b256 --model l16-fp8-msclips --batch 256 --no-cpu-baseline --steps 10 --warmup 3
+run_line c5_l16_fp8qkv_b256 --model l16-fp8-msclips --precision fp8-qkv --batch 256 --no-cpu-baseline --no-pmc --steps 10 --warmup 3
+run_line c5_l16_bf16_b256 --model l16-fp8-msclips --precision bf16 --batch 256 --no-cpu-baseline --no-pmc --steps 10 --warmup 3
 run_line train_b32_b512_bnbatch --train --bn batch --no-cpu-baseline --steps 15 --warmup 5
 run_line train_b32_b512_bnfrozen --train --bn frozen --no-cpu-baseline --no-pmc --steps 15 --warmup 5
 run_line train_b16_b256_bnbatch --train --bn batch --model b16-yfcc-msclips --batch 256 --no-cpu-baseline --no-pmc --steps 10 --warmup 4
