@@ -226,7 +226,7 @@ int msclip_layernorm_bwd(const float* x, int ldx, const int* row_idx, int row_mu
  * of a caption (M.py:3057-3060) is read afterwards.  q: bf16 [nsamples, ldqc] = the (pre-scaled) query rows; qkv: the token
  * matrix of msclip_attention -- only its k | v columns are read (the q columns may hold anything); sample b's keys are rows
  * row_base + b*L ... and their count is last_row ? last_row[b] - (row_base + b*L) + 1 : L (a causal query at its own position
- * sees the keys up to itself; NULL = all L keys).  out: bf16 [nsamples, ldo].  L <= 256. */
+ * sees the keys up to itself; NULL = all L keys).  out: bf16 [nsamples, ldo].  L <= 256; ldqc, ldq, ldo multiples of 8. */
 int msclip_attention_lastq(const void* q, int ldqc, const void* qkv, int ldq, void* out, int ldo, int nsamples, int L, int heads,
                            const int* last_row, int row_base, void* stream);
 

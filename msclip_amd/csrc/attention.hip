@@ -522,9 +522,11 @@ int launch_wg(const void* qkv, void* out, int nsamples, int L, int H, int ldq, i
 }
 
 // ---- One query per sample: the last block's attention when only the class row of an image / the EOT row of a caption is
-// read afterwards (M.py:2685, 3057-3060).  One wave per (sample, head): lane = key for the scores (a lane reads its keys' 128-byte
-// head slices), lane = head dimension for the value sum.  P is rounded to bf16 before the value sum like the full kernel's.
-template <int NK>
+// read afterwards (M.py:2685, 3057-3060).  One wave per (sample, head); lane = (key group g = lane / 8, 16-byte chunk
+// c = lane % 8): an iteration reads the 128-byte head slices of 8 keys as full lines (8 lanes per key), a lane forms the partial
+// dot product of its 8 dimensions, three shuffles inside the 8-lane group finish the score; the value sum uses the same
+// mapping (8 dimensions per lane, the 8 key groups folded at the end).  P is rounded to bf16 like the full kernel's.
+template <int MAXI>                                  // iterations of 8 keys: L <= 8 * MAXI
 __global__ __launch_bounds__(256) void attn_lastq_kernel(const bf16_t* __restrict__ qc, int ldqc, const bf16_t* __restrict__ kv,
                                                     int ldkv, bf16_t* __restrict__ out, int ldo, int nsamples, int L, int H,
                                                     const int* __restrict__ last_row, int row_base) {
@@ -535,53 +537,68 @@ __global__ __launch_bounds__(256) void attn_lastq_kernel(const bf16_t* __restric
   const int row0 = row_base + b * L;
   int nk = last_row ? last_row[b] - row0 + 1 : L;
   nk = min(max(nk, 1), L);
-  const bf16_t* kbase = kv + (size_t)row0 * ldkv + H * 64 + h * 64;
+  const int g = lane >> 3, c = lane & 7;
+  const bf16_t* kbase = kv + (size_t)row0 * ldkv + H * 64 + h * 64 + c * 8;
   const bf16_t* vbase = kbase + H * 64;
-  float q[64];
-  {
-    const bf16_t* qp = qc + (size_t)b * ldqc + h * 64;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) unpack_bf16x8(*(const uint4*)(qp + i * 8), q + i * 8);
-  }
-  float s[NK];
+  float q8[8];
+  unpack_bf16x8(*(const uint4*)(qc + (size_t)b * ldqc + h * 64 + c * 8), q8);
+  float s[MAXI];
   float m = -INFINITY;
 #pragma unroll
-  for (int j = 0; j < NK; ++j) {
-    const int key = j * 64 + lane;
-    s[j] = -INFINITY;
+  for (int i = 0; i < MAXI; ++i) {
+    const int key = i * 8 + g;
+    float d = 0.f;
     if (key < nk) {
-      const bf16_t* kp = kbase + (size_t)key * ldkv;
-      float acc = 0.f;
+      float kf[8];
+      unpack_bf16x8(*(const uint4*)(kbase + (size_t)key * ldkv), kf);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        float kf[8];
-        unpack_bf16x8(*(const uint4*)(kp + i * 8), kf);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc = fmaf(q[i * 8 + e], kf[e], acc);
-      }
-      s[j] = acc;
+      for (int e = 0; e < 8; ++e) d = fmaf(q8[e], kf[e], d);
     }
-    m = fmaxf(m, s[j]);
+    d += __shfl_xor(d, 1, 64);
+    d += __shfl_xor(d, 2, 64);
+    d += __shfl_xor(d, 4, 64);
+    s[i] = key < nk ? d : -INFINITY;
+    m = fmaxf(m, s[i]);
   }
-  m = wave_max(m);
+  m = fmaxf(m, __shfl_xor(m, 8, 64));
+  m = fmaxf(m, __shfl_xor(m, 16, 64));
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
   float sum = 0.f;
 #pragma unroll
-  for (int j = 0; j < NK; ++j) {
-    const float p = j * 64 + lane < nk ? __expf(s[j] - m) : 0.f;
+  for (int i = 0; i < MAXI; ++i) {
+    const float p = i * 8 + g < nk ? __expf(s[i] - m) : 0.f;
     sum += p;
-    s[j] = bf16_to_f32(f32_to_bf16(p));
+    s[i] = bf16_to_f32(f32_to_bf16(p));
   }
-  sum = wave_sum(sum);
-  float o = 0.f;
+  sum += __shfl_xor(sum, 8, 64);
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int j = 0; j < NK; ++j) {
-    const int kend = min(64, nk - j * 64);
-    for (int kk = 0; kk < kend; ++kk) {
-      const float p = __shfl(s[j], kk, 64);
-      o = fmaf(p, bf16_to_f32(vbase[(size_t)(j * 64 + kk) * ldkv + lane]), o);
+  for (int i = 0; i < MAXI; ++i) {
+    const int key = i * 8 + g;
+    if (key < nk) {
+      float vf[8];
+      unpack_bf16x8(*(const uint4*)(vbase + (size_t)key * ldkv), vf);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = fmaf(s[i], vf[e], acc[e]);
     }
   }
-  out[(size_t)b * ldo + h * 64 + lane] = f32_to_bf16(o / sum);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    acc[e] += __shfl_xor(acc[e], 8, 64);
+    acc[e] += __shfl_xor(acc[e], 16, 64);
+    acc[e] += __shfl_xor(acc[e], 32, 64);
+  }
+  if (g == 0) {
+    const float r = 1.f / sum;
+    uint4 o;
+    o.x = pack_bf16x2(acc[0] * r, acc[1] * r);
+    o.y = pack_bf16x2(acc[2] * r, acc[3] * r);
+    o.z = pack_bf16x2(acc[4] * r, acc[5] * r);
+    o.w = pack_bf16x2(acc[6] * r, acc[7] * r);
+    *(uint4*)(out + (size_t)b * ldo + h * 64 + c * 8) = o;
+  }
 }
 
 template <int NT>
@@ -617,16 +634,17 @@ extern "C" int msclip_attention(const void* qkv, void* out, int nsamples, int L,
 
 extern "C" int msclip_attention_lastq(const void* q, int ldqc, const void* qkv, int ldq, void* out, int ldo, int nsamples, int L,
                                       int heads, const int* last_row, int row_base, void* stream) {
-  if (!q || !qkv || !out || nsamples <= 0 || L <= 0 || L > 256 || heads <= 0 || (ldqc % 8) || (ldq % 8) || ldo < heads * 64 || row_base < 0)
+  if (!q || !qkv || !out || nsamples <= 0 || L <= 0 || L > 256 || heads <= 0 || (ldqc % 8) || (ldq % 8) || (ldo % 8) || ldo < heads * 64 || row_base < 0)
     return MSCLIP_EINVAL;
   const int grid = (nsamples * heads + 3) / 4;
   hipStream_t st = (hipStream_t)stream;
-#define LASTQ(NK)                                                                                                              \
-  hipLaunchKernelGGL(attn_lastq_kernel<NK>, dim3(grid), dim3(256), 0, st, (const bf16_t*)q, ldqc, (const bf16_t*)qkv, ldq,     \
+#define LASTQ(MAXI)                                                                                                            \
+  hipLaunchKernelGGL(attn_lastq_kernel<MAXI>, dim3(grid), dim3(256), 0, st, (const bf16_t*)q, ldqc, (const bf16_t*)qkv, ldq,   \
                      (bf16_t*)out, ldo, nsamples, L, heads, last_row, row_base)
-  if (L <= 64) LASTQ(1);
-  else if (L <= 128) LASTQ(2);
-  else LASTQ(4);
+  if (L <= 64) LASTQ(8);
+  else if (L <= 80) LASTQ(10);
+  else if (L <= 128) LASTQ(16);
+  else LASTQ(32);
 #undef LASTQ
   return msclip_launch_status();
 }
