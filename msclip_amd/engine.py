@@ -122,8 +122,8 @@ class Engine:
         weight matrices), the heads and the logit scale, from the cached state-dict views -- not the 0.8 ms state_dict()
         walk and the ~100 per-tensor casts of the blocks on a host that the GPU is waiting for.  Falls back to the full
         re-pack for fp8 models (their e4m3 copies are quantised per row on the host side of the pack)."""
-        if self.fp8 or getattr(self, "_sdv", None) is None:
-            return self.refresh(force=True)
+        if self.fp8 or getattr(self, "_sdv", None) is None or self.tensor_identity() != self._sdv_ident:
+            return self.refresh(force=True)          # (a re-assigned parameter: the blocks' copies / aliases are of the old tensor)
         with torch.cuda.device(self.dev), torch.no_grad():
             self._pack(self.model, blocks=False)
         self._stamp = self._fingerprint()
@@ -134,9 +134,21 @@ class Engine:
         """{state_dict key: detached tensor} of the module, made once per full re-pack: the tensors are the module's own
         storage, so in-place updates (an optimizer step, load_state_dict) show through; a re-assigned parameter changes the
         fingerprint and with it this cache."""
-        if getattr(self, "_sdv", None) is None:
+        ident = self.tensor_identity()
+        if getattr(self, "_sdv", None) is None or self._sdv_ident != ident:
             self._sdv = {k: t.detach() for k, t in self.model.state_dict().items()}
+            self._sdv_ident = ident
         return self._sdv
+
+    def tensor_identity(self):
+        """Which tensor OBJECTS the module holds (a parameter that has been re-assigned is another object): what cached
+        views of them and cached optimizer tables are valid for."""
+        v = 0
+        for t in self.model.parameters():
+            v = (v * 1000003 + id(t)) & 0xFFFFFFFFFFFF
+        for t in self.model.buffers():
+            v = (v * 1000003 + id(t)) & 0xFFFFFFFFFFFF
+        return v
 
     # ------------------------------------------------------------------ packing
     def _pack(self, m, blocks=True):

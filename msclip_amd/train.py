@@ -491,7 +491,7 @@ class TrainStep:
         """The tensor table of the optimizer launch: built once, per step only the gradient addresses are re-pointed;
         rebuilt when the set of gradients changes, the optimizer state is replaced or the engine has re-packed (new copies)."""
         pk_ok = not self.eng.fp8
-        sig = (id(self.eng.tblk[0]["w"].wqkv), pk_ok, id(self.state))
+        sig = (id(self.eng.tblk[0]["w"].wqkv), pk_ok, id(self.state), self.eng.tensor_identity())
         plan = getattr(self, "_plan", None)
         if plan is not None and plan.sig == sig and len(grads) == plan.ngrads and \
                 all(k in grads and grads[k].dtype == F32 and grads[k].numel() == n for k, n in plan.names.items()):

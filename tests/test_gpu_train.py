@@ -660,6 +660,15 @@ def test_optimizer_step_keeps_the_engine_copies_current(gpu_device, bn):
     assert torch.equal(got.w_vproj, want.w_vproj) and torch.equal(got.w_tproj, want.w_tproj) and torch.equal(got.w_last, want.w_last)
     assert torch.equal(got.dual_w, want.dual_w)
     assert got.logit_scale_exp == want.logit_scale_exp
+    # a RE-ASSIGNED parameter (another tensor object) invalidates the cached optimizer table and the engine's cached views /
+    # aliases: the next step trains the new tensor and the engine serves it
+    blk = m.transformer.resblocks[3]
+    blk.ln_2.weight = torch.nn.Parameter(blk.ln_2.weight.detach().clone() * 1.5)
+    ts.forward(img, tok)
+    ts.step(ts.backward())
+    assert ts._plan is not plans[0]
+    assert torch.equal(ts.eng.tblk[3]["ln2"].g, blk.ln_2.weight.detach())
+    assert torch.equal(ts.eng.tblk[3]["w"].wfc, blk.mlp.c_fc.weight.detach().to(torch.bfloat16))
 
 
 @pytest.mark.parametrize("name", ["b32-yfcc-msclips", "b16-yfcc-msclips"])
