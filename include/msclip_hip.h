@@ -57,7 +57,26 @@ typedef struct msclip_gemm_desc {
   int rpg, radd, roff;   /* rpg > 0; use rpg = INT_MAX, radd = roff = 0 for the identity */
   void* out2;            /* optional second bf16 output: the epilogue value before the activation (NULL: none) */
   float out_scale;       /* out_kind 2 (e4m3 output, msclip_gemm_f8 only): stored value = fp8(epilogue value * out_scale), saturating */
-  int tile;              /* 0 = auto, 1 = 128x128 (4 waves), 4 = 256x256 ping-pong (what auto picks for large problems; dense X, or implicit conv with Cin % 64 == 0), 5 = streaming kernel with LDS-resident weights (K <= 192, or the 3x3 convolutions with 48 input channels; M >= 4096; auto picks it there), 6 = 256x192 two-buffer (implicit conv with N % 192 == 0), 7 = 4-wave 256x256 kernel with the epilogue carried under the next tile's K loop (dense X, bf16 output, no residual, N % 256 == 0, K >= 576, alpha 1; opt-in: measured slower than 4; EINVAL otherwise), 8 = two 4-wave workgroups per CU on 256x128 tiles (gemm_pp2.hip; dense X; opt-in: measured slower than 4, profiles/r03_gemm_pp2_ab.md) */
+  int tile;              /* 0 = auto, 1 = 128x128 (4 waves), 4 = 256x256 ping-pong (what auto picks for large problems; dense X, or implicit conv with Cin % 64 == 0), 5 = streaming kernel with LDS-resident weights (K <= 192, or the 3x3 convolutions with 48 input channels; M >= 4096; auto picks it there), 6 = 256x192 two-buffer (implicit conv with N % 192 == 0), (7 and 8, the two epilogue-hiding kernels of rounds 2-3, were measured slower and retired in round 4: EINVAL) */
+  int wg_cap;            /* 0 = the launch may take every CU; > 0: at most this many persistent workgroups (CUs) for the dense / implicit-conv MFMA kernels (round-4 probe of two half-batch chains on two streams, tools/probes/two_chain_probe.py: measured neutral, the engine leaves it 0) */
+  /* ---- LayerNorm fold (dense ping-pong kernel only; M, seg_split and N multiples of 256; DESIGN.md "LayerNorm fold").
+   * Consumer (a projection that follows a LayerNorm, M.py:1027-1028 + 204-219): X holds bf16 (x - center[m]) instead of the
+   * LayerNorm output, W carries gamma (W'[n][k] = gamma[k] W[n][k]), and
+   *     out[m][n] = act( rowstat[m][0] * acc - rowstat[m][1] * csum[n] + bias[n] ),
+   * rowstat[m] = (rstd, (mean - center) * rstd) of row m, csum[n] = sum_k W'[n][k], bias = b + W beta.  Rows >= seg_split (the
+   * other modality's tokens: own gamma / beta, shared W) take W2 / bias2 / csum2.  bf16 output, act 0 / 1, no residual. */
+  const void* W2;        /* NULL: one row segment */
+  const float* bias2;
+  const float* csum;     /* [N] (with rowstat) */
+  const float* csum2;
+  const float* rowstat;  /* [M][2] fp32; NULL: fold off */
+  int seg_split;
+  /* Producer (out_proj / c_proj, resid_kind 1, fp32 out): besides out = resid + acc + bias it writes
+   * xb[m][n] = bf16(out[m][n] - center[m]) and part[m][n / 64] = (sum, sum of squares) of (out - center) over 64 columns. */
+  int ldxb;
+  void* xb;              /* bf16 [M][ldxb]; NULL: off */
+  const float* center;   /* [M] */
+  float* part;           /* [M][N / 64][2] */
 } msclip_gemm_desc;
 
 int msclip_gemm(const msclip_gemm_desc* desc, void* stream);
@@ -84,7 +103,7 @@ int msclip_layernorm_f8(const float* x, int ldx, const float* gamma, const float
 /* bf16 [M, C] rows -> e4m3 + per-row scale (same convention).  C % 8 == 0. */
 int msclip_quant_f8_rows(const void* x, int ldx, void* q, int ldq, float* row_scale, int M, int C, void* stream);
 
-/* Name of the kernel msclip_gemm would launch for this descriptor ("w4", "pp", "pp2", "ppconv", "stream", "dense128",
+/* Name of the kernel msclip_gemm would launch for this descriptor ("pp", "ppconv", "stream", "dense128",
  * "conv192", "conv128"; "invalid" for rejected arguments): the library's own dispatch rule, so
  * that measurement code (bench.py's roofline leg) counts exactly the launches of one kernel.  No GPU work. */
 const char* msclip_gemm_variant(const msclip_gemm_desc* desc);
@@ -101,6 +120,17 @@ int msclip_attention(const void* qkv, void* out, int nsamples, int L, int heads,
 int msclip_layernorm(const float* x, int ldx, const int* row_idx, int row_mul, int row_add, const float* gamma,
                      const float* beta, void* out, int ldo, int out_kind, float* raw_out, int ld_raw, int M, int C,
                      float eps, void* stream);
+
+/* msclip_layernorm over contiguous rows that also leaves what the LayerNorm fold needs about these rows: center[m] = the row's
+ * mean (the next producing GEMM centres its bf16 copy on it) and rowstat[m] = (1, 0) (the consuming GEMM takes `out` as it
+ * is).  Either pointer may be NULL. */
+int msclip_layernorm_stats(const float* x, int ldx, const float* gamma, const float* beta, void* out, int ldo, int out_kind,
+                           float* raw_out, int ld_raw, float* center, float* rowstat, int M, int C, float eps, void* stream);
+
+/* Row statistics of a producing GEMM's partial sums (msclip_gemm_desc.part): for rows [0, M)
+ *   mu = sum_g part[m][g][0] / C,  var = sum_g part[m][g][1] / C - mu^2  (sums of x - center[m]: the subtraction is benign),
+ *   rowstat[m] = (1 / sqrt(var + eps), mu / sqrt(var + eps)),  center[m] += mu.   groups = C / 64, folded in index order. */
+int msclip_rowstat_finalize(const float* part, int groups, float* center, float* rowstat, int M, int C, float eps, void* stream);
 
 /* The same over one [M, C] matrix whose rows [0, split) and [split, M) carry different parameters: the image and
  * the text tokens of the shared residual matrix with their modality-specific LayerNorms (M.py:1027-1028 run per

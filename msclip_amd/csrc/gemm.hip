@@ -482,10 +482,15 @@ __device__ __forceinline__ f32x4 pp_mma(const bf16x8 (&w)[2], const bf16x8 (&x)[
 // rows, regions, ring and LDS-DMA stream -- contracted by ONE v_mfma_scale_f32_16x16x128_f8f6f4 per 16 x 16 tile and K-tile
 // (twice the bf16 rate; block scales 2^0: the operands carry per-row scales instead, row_scale[m] for X rows and col_scale[n]
 // for W rows, fp32, applied to the accumulators in front of the epilogue).
-template <int MODE, bool F8 = false>
+// EPI (dense bf16 only): the LayerNorm fold's two epilogue kinds are instantiations of their own, so that the standard kernel's
+// register allocation stays what it was (with all forms in one kernel hipcc spilled inside the K loop): 1 = consumer (the
+// projection behind a folded LayerNorm: per-row rstd / mean, per-column weight sums, two row segments), 2 = producer
+// (out_proj / c_proj: residual update + bf16 centred copy + per-row partial statistics).
+template <int MODE, bool F8 = false, int EPI = 0>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a_in, const float* __restrict__ row_scale,
                                                       const float* __restrict__ col_scale) {
   static_assert(!(F8 && MODE == 1), "fp8 operands: dense GEMM only");
+  static_assert(EPI == 0 || (MODE == 0 && !F8), "LayerNorm fold: dense bf16 GEMM only");
   // Split-K launches (msclip_gemm_splitk with tile = 4; the weight gradients of the training step): blockIdx.y = K slice;
   // slice s contracts columns [s*K/S, (s+1)*K/S) of both operands into its own fp32 matrix out[s][M][ldo].  A weight
   // gradient is 9-36 output tiles over a 65 024-deep contraction: tiles x slices workgroups of ONE launch fill the chip.
@@ -500,7 +505,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a_i
   constexpr unsigned ES = F8 ? 1u : 2u;            // operand element size in bytes
   constexpr int KT = F8 ? 128 : 64;                // elements per K-tile (128 bytes)
   constexpr int TM = 4, TN = 2;
-  constexpr bool TE = MODE == 0 && !F8;                          // training-step epilogue forms (out2, resid_kind 4) compiled in
+  constexpr bool TE = MODE == 0 && !F8 && EPI == 0;              // training-step epilogue forms (out2, resid_kind 4) compiled in
   __shared__ __attribute__((aligned(1024))) bf16_t smem[PSLOTS * PREG];
 
   const int tid = threadIdx.x;
@@ -580,7 +585,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a_i
       const unsigned long long xb = (unsigned long long)(a.M - m0) * (unsigned long long)a.ldx * ES;
       const unsigned long long wb = (unsigned long long)(a.N - n0) * (unsigned long long)a.ldw * ES;
       rx = make_rsrc((const char*)a.X + (size_t)m0 * a.ldx * ES, xb > 0xffffffffull ? 0xffffffffu : (unsigned)xb);
-      rw = make_rsrc((const char*)a.W + (size_t)n0 * a.ldw * ES, wb > 0xffffffffull ? 0xffffffffu : (unsigned)wb);
+      const void* wseg = (EPI == 1 && a.W2 && m0 >= a.seg_split) ? a.W2 : a.W;   // second row segment: the other modality's folded weight
+      rw = make_rsrc((const char*)wseg + (size_t)n0 * a.ldw * ES, wb > 0xffffffffull ? 0xffffffffu : (unsigned)wb);
     } else {                                       // past the tile list: empty descriptors, the counts stay exact
       rx = make_rsrc(a.X, 0);
       rw = make_rsrc(a.W, 0);
@@ -673,8 +679,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a_i
     // or a reloaded spill at this point would bring an s_waitcnt vmcnt(0), i.e. a wait for the previous tile's stores.
     int lane_s;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_s));
-    const float* bsrc = a.bias ? a.bias : (const float*)a.zero;
-    const int nlast = a.bias ? a.N - 1 : 0;
+    const bool seg2 = EPI == 1 && a.W2 && cm0 >= a.seg_split;
+    const float* bseg = seg2 ? a.bias2 : a.bias;
+    const float* bsrc = bseg ? bseg : (const float*)a.zero;
+    const int nlast = bseg ? a.N - 1 : 0;
     // bias4[i]: this lane's 4 epilogue columns of 32-column block i (see epilogue_rows).
     // The loads are inline asm: the compiler must not know they are pending (it would wait for them -- and so for the
     // previous tile's stores, the VM counter retires in order -- before entering the K loop).  They are older than the
@@ -685,15 +693,25 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a_i
       const float* p = bsrc + (n < nlast ? n : nlast);
       asm volatile("global_load_dword %0, %1, off" : "=&v"(bcol) : "v"(p));
     }
-    float4 bias4[TN];
-#pragma unroll
-    for (int i = 0; i < TN; ++i) {
-      int n = cn0 + wn + i * 32 + (lane_s & 7) * 4;
-      n = n + 3 < nlast ? n : (nlast & ~3);
-      const float* p = bsrc + (vec ? n : 0);
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(v) : "v"(p));
-      bias4[i] = make_float4(v[0], v[1], v[2], v[3]);
+    // LayerNorm fold: the consumer asks for the column sums of its segment's weight like the bias (lane j: column j) and for its
+    // wave's 128 rows' (rstd, mean * rstd) -- lane j holds rows j (.x, .y) and j + 64 (.z, .w); the producer for its rows'
+    // centres (.x, .z).  M % 256 == 0 on these paths (host-checked): no clamping.
+    float ccol = 0.f;
+    f32x4 rstat4 = {1.f, 0.f, 1.f, 0.f};
+    if constexpr (EPI == 1) {
+      const float* p = (seg2 ? a.csum2 : a.csum) + cn0 + wn + lane_s;
+      asm volatile("global_load_dword %0, %1, off" : "=&v"(ccol) : "v"(p));
+      const float* q0 = a.rowstat + 2 * (size_t)(cm0 + wm + lane_s);
+      f32x2 lo, hi;
+      asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(lo) : "v"(q0));
+      asm volatile("global_load_dwordx2 %0, %1, off offset:512" : "=&v"(hi) : "v"(q0));
+      rstat4 = f32x4{lo[0], lo[1], hi[0], hi[1]};
+    } else if constexpr (EPI == 2) {
+      const float* q0 = a.center + cm0 + wm + lane_s;
+      float lo, hi;
+      asm volatile("global_load_dword %0, %1, off" : "=&v"(lo) : "v"(q0));
+      asm volatile("global_load_dword %0, %1, off offset:256" : "=&v"(hi) : "v"(q0));
+      rstat4 = f32x4{lo, 0.f, hi, 0.f};
     }
 
     for (int kt = 0; kt < nk; ++kt) {
@@ -823,6 +841,17 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a_i
             for (int mi = 0; mi < 8; ++mi) acc[ni][mi][r] *= sw;
           }
       }
+      if constexpr (EPI == 1) {                    // whole tiles, bf16 output, act 0 / 1 (host-checked)
+        const float4 rstat = make_float4(rstat4[0], rstat4[1], rstat4[2], rstat4[3]);
+        epi_stores = 4 * TM;
+        if (a.act == 0)
+          epilogue_pack16<TM, TN, 0, true>(acc, a, stg, cm0 + wm, cn0 + wn, lane_e, bcol, a.out, ccol, rstat);   // QKV behind a folded LayerNorm
+        else
+          epilogue_pack16<TM, TN, 1, true>(acc, a, stg, cm0 + wm, cn0 + wn, lane_e, bcol, a.out, ccol, rstat);   // c_fc + QuickGELU
+      } else if constexpr (EPI == 2) {             // whole tiles, in-place fp32 residual update (host-checked)
+        epi_stores = 0;                            // (stores + row partials: beyond the counted waits of the next tile's first K-tile)
+        epilogue_rows_stats<TM, TN>(acc, a, stg, cm0 + wm, cn0 + wn, lane_e, bcol, rstat4[0], rstat4[2]);
+      } else
       if (vec && plain_rows && cm0 + 256 <= a.M)
       {
         const bool full_n = cn0 + 256 <= a.N;      // no lane's store is predicated off
@@ -843,9 +872,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a_i
         else if (pack16 && a.act == 2)
           epilogue_pack16<TM, TN, 2>(acc, a, stg, mw0, nw0, lane_e, bcol, a.out);        // convolution + ReLU
         else if (a.resid_kind == 1 && a.act == 0 && a.out_kind == 1)
-          epilogue_rows<TM, TN, 1, 0, 1>(acc, a, stg, mw0, nw0, lane_e, bias4);          // out_proj / c_proj into the fp32 stream
+          epilogue_rows<TM, TN, 1, 0, 1>(acc, a, stg, mw0, nw0, lane_e, bcol);           // out_proj / c_proj into the fp32 stream
         else
-          epilogue_rows<TM, TN, -1, -1, -1, TE>(acc, a, stg, mw0, nw0, lane_e, bias4);   // pointwise convolutions, heads, training forms
+          epilogue_rows<TM, TN, -1, -1, -1, TE>(acc, a, stg, mw0, nw0, lane_e, bcol);    // pointwise convolutions, heads, training forms
         }
       }
       else
@@ -881,10 +910,6 @@ static void launch_cfg(const msclip_gemm_desc* d, hipStream_t st, int blocks_per
 
 bool msclip_gemm_small_try(const msclip_gemm_desc* d, hipStream_t st, int ncu);   // gemm_small.hip
 bool msclip_gemm_small_eligible(const msclip_gemm_desc* d);
-bool msclip_gemm_w4_eligible(const msclip_gemm_desc* d);                            // gemm_w4.hip
-void msclip_gemm_w4_launch(const msclip_gemm_desc* d, hipStream_t st);
-bool msclip_gemm_pp2_eligible(const msclip_gemm_desc* d);                           // gemm_pp2.hip
-void msclip_gemm_pp2_launch(const msclip_gemm_desc* d, hipStream_t st, int ncu);
 
 static int device_cus() {
   static int ncu = 0;
@@ -898,19 +923,8 @@ static int device_cus() {
 }
 
 // ---- kernel choice: ONE function decides, msclip_gemm launches what it says and msclip_gemm_variant reports it
-enum GemmVariant { GV_INVALID = 0, GV_STREAM, GV_PP, GV_DENSE128, GV_PPCONV, GV_CONV192, GV_CONV128, GV_W4, GV_PP2 };
-static const char* const kVariantName[] = {"invalid", "stream", "pp", "dense128", "ppconv", "conv192", "conv128", "w4", "pp2"};
-
-// MSCLIP_GEMM_PP2=1: the auto-dispatch takes gemm_pp2_kernel (two 4-wave workgroups per CU, 256 x 128 tiles) wherever it
-// would take the ping-pong kernel; 0: never; unset: the measured default below.
-static int pp2_auto() {
-  static int v = -2;
-  if (v == -2) {
-    const char* e = getenv("MSCLIP_GEMM_PP2");
-    v = e ? atoi(e) : -1;
-  }
-  return v;
-}
+enum GemmVariant { GV_INVALID = 0, GV_STREAM, GV_PP, GV_DENSE128, GV_PPCONV, GV_CONV192, GV_CONV128 };
+static const char* const kVariantName[] = {"invalid", "stream", "pp", "dense128", "ppconv", "conv192", "conv128"};
 
 static GemmVariant pick_variant(const msclip_gemm_desc* d) {
   if (!d || !d->X || !d->W || !d->out || !d->zero) return GV_INVALID;
@@ -927,26 +941,33 @@ static GemmVariant pick_variant(const msclip_gemm_desc* d) {
   if (train_epi && (d->mode != 0 || d->out_kind != 0 || ((d->N | d->ldo) & 7) || (d->M % 256) || (d->out2 && d->resid_kind) ||
                     (d->resid_kind == 4 && (!d->resid || (d->ldr & 3))) || d->rpg != 0x7fffffff))
     return GV_INVALID;
-  if (train_epi && d->tile != 4 && d->tile != 8 && d->tile != 0) return GV_INVALID;
+  if (train_epi && d->tile != 4 && d->tile != 0) return GV_INVALID;
+  // LayerNorm fold (consumer: rowstat / W2; producer: xb): whole 256 x 256 tiles of the dense ping-pong kernel only
+  const bool fold_c = d->rowstat || d->W2, fold_p = d->xb != nullptr;
+  if (fold_c && (d->mode != 0 || !d->rowstat || !d->csum || d->out_kind != 0 || d->resid_kind || d->act > 1 || d->out2 ||
+                 d->alpha != 1.f || (d->M % 256) || (d->N % 256) || (d->ldo % 8) || d->rpg != 0x7fffffff ||
+                 (d->W2 && (!d->csum2 || d->seg_split <= 0 || (d->seg_split % 256) || d->seg_split >= d->M)) || fold_p))
+    return GV_INVALID;
+  if (fold_p && (d->mode != 0 || d->resid_kind != 1 || d->out_kind != 1 || d->act || d->out2 || !d->center || !d->part ||
+                 (d->M % 256) || (d->N % 256) || (d->ldxb % 4) || (d->ldo % 4) || (d->ldr % 4) || d->rpg != 0x7fffffff))
+    return GV_INVALID;
+  if ((fold_c || fold_p) && d->tile != 4 && d->tile != 0) return GV_INVALID;
   // tile choice: the 256x256 / 8-wave config whenever the problem fills the chip with it, else 128x128
   const long long big_tiles = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256);
-  if (d->tile < 0 || d->tile > 8 || d->tile == 2 || d->tile == 3) return GV_INVALID;   // 2, 3: retired main loops
-  const bool big = d->tile >= 4 || (d->tile == 0 && ((d->N >= 192 && big_tiles >= 128) || train_epi));
-  if ((d->tile == 0 || d->tile == 5) && !train_epi && msclip_gemm_small_eligible(d)) return GV_STREAM;
-  if (d->tile == 7) return msclip_gemm_w4_eligible(d) ? GV_W4 : GV_INVALID;
-  if (d->tile == 8) return msclip_gemm_pp2_eligible(d) ? GV_PP2 : GV_INVALID;
-  // (the 4-wave kernel with the carried epilogue, gemm_w4.hip, is opt-in through tile = 7: its main loop matches the
-  //  ping-pong kernel's (QKV 153 vs 156 us, c_fc 203 vs 203 us in the model step without any epilogue), but with one
-  //  wave per SIMD the epilogue's VALU work has no second wave's issue slots to hide in: 200 / 291 us against 190 / 266)
+  if (d->tile < 0 || d->tile > 6 || d->tile == 2 || d->tile == 3) return GV_INVALID;   // 2, 3 (and 7, 8 of rounds 2-3): retired kernels
+  const bool big = d->tile == 4 || (d->tile == 0 && ((d->N >= 192 && big_tiles >= 128) || train_epi || fold_c || fold_p));
+  if ((d->tile == 0 || d->tile == 5) && !train_epi && !fold_c && !fold_p && msclip_gemm_small_eligible(d)) return GV_STREAM;
+  // (rounds 2-3 built two kernels that hide the epilogue -- a 4-wave kernel carrying it under the next tile's K loop and two
+  //  4-wave workgroups per CU on 256 x 128 tiles; both measured slower than the ping-pong kernel and were retired in round 4:
+  //  DESIGN.md "The epilogue problem", "Two workgroups per CU"; sources in the git history up to round 3)
   if (d->mode == 0) {
     // 256-row tile offsets must fit the 32-bit buffer offsets of the ping-pong kernel's loads
     // ... and tile id x (4 row-tile counts) below 2^32 for the kernel's reciprocal-multiply tile mapping
     const bool pp_ok = (long long)d->ldx * 2 * 256 + (long long)d->K * 2 < (1ll << 31) &&
                        (long long)d->ldw * 2 * 256 + (long long)d->K * 2 < (1ll << 31) &&
                        big_tiles * ((d->M + 255) / 256) * 4 < (1ll << 32);
-    if (pp_ok && d->tile == 0 && big && pp2_auto() == 1 && msclip_gemm_pp2_eligible(d)) return GV_PP2;
     if (pp_ok && (d->tile == 4 || (d->tile == 0 && big))) return GV_PP;     // ping-pong kernel (default for the projections)
-    if (train_epi) return GV_INVALID;          // (offsets beyond the ping-pong kernel's 32-bit addressing)
+    if (train_epi || fold_c || fold_p) return GV_INVALID;   // (offsets beyond the ping-pong kernel's 32-bit addressing)
     return GV_DENSE128;                        // small problems, heads, logits (and tile 1)
   }
   // input channels a multiple of 64 (a K-tile stays inside one filter tap): the ping-pong kernel gathers the rows itself
@@ -1014,9 +1035,11 @@ extern "C" int msclip_gemm(const msclip_gemm_desc* d, void* stream) {
   const int grid = tiles < ncu ? tiles : ncu;
   switch (v) {
     case GV_STREAM: if (!msclip_gemm_small_try(d, st, ncu)) return MSCLIP_EINVAL; break;
-    case GV_W4: msclip_gemm_w4_launch(d, st); break;
-    case GV_PP2: msclip_gemm_pp2_launch(d, st, ncu); break;
-    case GV_PP: hipLaunchKernelGGL((gemm_pp_kernel<0, false>), dim3(grid), dim3(512), 0, st, *d, nullptr, nullptr); break;
+    case GV_PP:
+      if (d->rowstat) hipLaunchKernelGGL((gemm_pp_kernel<0, false, 1>), dim3(grid), dim3(512), 0, st, *d, nullptr, nullptr);
+      else if (d->xb) hipLaunchKernelGGL((gemm_pp_kernel<0, false, 2>), dim3(grid), dim3(512), 0, st, *d, nullptr, nullptr);
+      else hipLaunchKernelGGL((gemm_pp_kernel<0, false>), dim3(grid), dim3(512), 0, st, *d, nullptr, nullptr);
+      break;
     case GV_PPCONV: hipLaunchKernelGGL((gemm_pp_kernel<1, false>), dim3(grid), dim3(512), 0, st, *d, nullptr, nullptr); break;
     case GV_DENSE128: launch_cfg<0, 128, 128, 2, 2>(d, st, 2); break;
     case GV_CONV192: launch_cfg<1, 256, 192, 4, 2>(d, st, 1); break;

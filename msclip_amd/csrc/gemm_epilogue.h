@@ -34,6 +34,7 @@ __device__ __forceinline__ f32x4 stg_read16(unsigned addr) {
 // alias LDS", and while it is pending the compiler guards the K loop's fragment reads with s_waitcnt vmcnt(0).
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 __device__ __forceinline__ void st_global(void* p, float4 v) { *(AS1 f32x4*)p = f32x4{v.x, v.y, v.z, v.w}; }
 __device__ __forceinline__ void st_global(void* p, uint4 v) { *(AS1 u32x4*)p = u32x4{v.x, v.y, v.z, v.w}; }
 __device__ __forceinline__ void st_global(void* p, uint2 v) { *(AS1 u32x2*)p = u32x2{v.x, v.y}; }
@@ -52,9 +53,33 @@ __device__ __forceinline__ float quickgelu_grad(float h) {
   return s + 1.702f * h * s * (1.f - s);
 }
 
+// bias4[tn] = this lane's 4 epilogue columns (lane & 7) * 4 .. + 3 of 32-column block tn, from the wave's one-register bias
+// (lane j: column j; requested at tile start): 8 lane-crossbar reads here instead of 8 registers live across the K loop.
+template <int TN>
+__device__ __forceinline__ void bias4_from_bcol(float bcol, int lane, float4 (&bias4)[TN]) {
+  const int src = __float_as_int(bcol);
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int base = (tn * 32 + (lane & 7) * 4) * 4;
+    bias4[tn].x = __int_as_float(__builtin_amdgcn_ds_bpermute(base, src));
+    bias4[tn].y = __int_as_float(__builtin_amdgcn_ds_bpermute(base + 4, src));
+    bias4[tn].z = __int_as_float(__builtin_amdgcn_ds_bpermute(base + 8, src));
+    bias4[tn].w = __int_as_float(__builtin_amdgcn_ds_bpermute(base + 12, src));
+  }
+  // all of them are back before the first hand-counted LDS operation of the staging code is issued
+  static_assert(TN == 2, "wave tile = 64 columns");
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(bias4[0].x), "+v"(bias4[0].y), "+v"(bias4[0].z), "+v"(bias4[0].w), "+v"(bias4[1].x), "+v"(bias4[1].y),
+                 "+v"(bias4[1].z), "+v"(bias4[1].w)
+               :
+               : "memory");
+}
+
 template <int TM, int TN, int RK, int ACT, int OUTK, bool TE = false>     // TE: the training-step forms are compiled in
 __device__ __forceinline__ void epilogue_rows(f32x4 (&acc)[2 * TN][2 * TM], const msclip_gemm_desc& a, unsigned stg,
-                                              int mw0, int nw0, int lane, const float4 (&bias4)[TN]) {
+                                              int mw0, int nw0, int lane, float bcol) {
+  float4 bias4[TN];
+  bias4_from_bcol<TN>(bcol, lane, bias4);
   // accumulator layout of v_mfma_f32_16x16x32 with swapped operands: acc[ni][mi][r] = C[mi*16 + lane%16][ni*16 + 4*(lane/16) + r]
   const int r16 = lane & 15, quad = lane >> 4;
   const int srow = lane >> 3, sch = lane & 7;
@@ -146,6 +171,124 @@ __device__ __forceinline__ void epilogue_rows(f32x4 (&acc)[2 * TN][2 * TM], cons
   }
 }
 
+// out_proj / c_proj as the PRODUCER of the next LayerNorm's operands (DESIGN "LayerNorm fold"): besides the in-place fp32
+// residual update v = resid + alpha acc + bias it writes xb[m][n] = bf16(v - center[m]) -- the operand the next projection reads
+// instead of a LayerNorm output; center[m] is the row's mean at the previous LayerNorm point, so the bf16 rounding is relative
+// to the deviation from the mean as it is for a LayerNorm output -- and part[m][column group][2] = (sum, sum of squares) of
+// v - center[m] over the wave's 64 columns, fp32 (msclip_rowstat_finalize folds a row's N / 64 groups in a fixed order: mean,
+// rstd).  Same staging / residual look-ahead as epilogue_rows<.., 1, 0, 1>.
+// sum over each aligned group of 8 lanes, in every lane of the group: DPP moves (quad xor 1, quad xor 2, half-row mirror), no
+// LDS-pipe traffic (a ds_bpermute-based shuffle would sit in the hand-counted lgkmcnt sequence of the staging code)
+__device__ __forceinline__ float sum8_dpp(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1, 0, 3, 2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2, 3, 0, 1]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  return v;
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue_rows_stats(f32x4 (&acc)[2 * TN][2 * TM], const msclip_gemm_desc& a, unsigned stg,
+                                                    int mw0, int nw0, int lane, float bcol, float cen_lo, float cen_hi) {
+  static_assert(TN == 2 && TM == 4, "wave tile = 128 rows x 64 columns = one statistics group per row");
+  float4 bias4[TN];
+  bias4_from_bcol<TN>(bcol, lane, bias4);
+  const int r16 = lane & 15, quad = lane >> 4;
+  const int srow = lane >> 3, sch = lane & 7;
+  const unsigned wr = stg + r16 * 128;
+  const int wsw = r16 & 7;
+  const unsigned rd = stg + srow * 128 + ((sch ^ srow) << 4);
+  constexpr int RAHEAD = 2;
+  float4 rv[RAHEAD][4];
+  auto load_res = [&](int b, float4 (&dst)[4]) {
+    const int tm = b / TN, tn = b % TN;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const size_t row = (size_t)(mw0 + tm * 32 + i * 8 + srow);
+      dst[i] = ld_global_f4((const float*)a.resid + row * a.ldr + nw0 + tn * 32 + sch * 4);
+    }
+  };
+#pragma unroll
+  for (int b = 0; b < RAHEAD; ++b) load_res(b, rv[b]);
+  // centre of row r of the wave's 128: lane r & 63 of cen_lo (r < 64) / cen_hi (requested at tile start like the bias).  The
+  // lane-crossbar reads are inline asm (the compiler must not count them: its own wait would also drain the staging reads
+  // issued behind them); LDS-pipe operations return in order, so the hand-counted waits below cover them.
+  auto issue_cen = [&](int tm, float (&dst)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int addr = ((tm & 1) * 32 + i * 8 + srow) * 4;
+      asm volatile("ds_bpermute_b32 %0, %1, %2" : "=v"(dst[i]) : "v"(addr), "v"(tm < 2 ? cen_lo : cen_hi) : "memory");
+    }
+  };
+  float cen[4], cenn[4];
+  issue_cen(0, cen);
+  f32x4 x[2][4];
+  auto stage = [&](int b, f32x4 (&dst)[4]) {
+    const int tm = b / TN, tn = b % TN;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const f32x4 v = acc[2 * tn + ni][2 * tm + mi] * a.alpha;
+        stg_write16(wr + mi * 2048 + (((ni * 4 + quad) ^ wsw) << 4), v);
+      }
+    dst[0] = stg_read16<0>(rd); dst[1] = stg_read16<1024>(rd);
+    dst[2] = stg_read16<2048>(rd); dst[3] = stg_read16<3072>(rd);
+  };
+  stage(0, x[0]);
+  float ps[4], pq[4];                                              // this lane's share of the row sums over the block row's 64 columns
+  const int ngrp = a.N >> 6, grp = nw0 >> 6;
+#pragma unroll
+  for (int b = 0; b < TM * TN; ++b) {
+    const int tm = b / TN, tn = b % TN;
+    f32x4(&xb)[4] = x[b & 1];
+    const bool next_cen = tn == TN - 1 && tm + 1 < TM;
+    if (next_cen) issue_cen(tm + 1, cenn);                         // older than the staging of block b + 1: covered by its wait
+    if (b + 1 < TM * TN) {
+      stage(b + 1, x[(b + 1) & 1]);
+      asm volatile("s_waitcnt lgkmcnt(8)"
+                   : "+v"(xb[0]), "+v"(xb[1]), "+v"(xb[2]), "+v"(xb[3]), "+v"(cen[0]), "+v"(cen[1]), "+v"(cen[2]), "+v"(cen[3]),
+                     "+v"(cenn[0]), "+v"(cenn[1]), "+v"(cenn[2]), "+v"(cenn[3])
+                   :
+                   : "memory");
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xb[0]), "+v"(xb[1]), "+v"(xb[2]), "+v"(xb[3])::"memory");
+    }
+    const int n = nw0 + tn * 32 + sch * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 r = rv[b % RAHEAD][i];
+      const float4 v = make_float4(xb[i][0] + bias4[tn].x + r.x, xb[i][1] + bias4[tn].y + r.y, xb[i][2] + bias4[tn].z + r.z,
+                                   xb[i][3] + bias4[tn].w + r.w);
+      const size_t row = (size_t)(mw0 + tm * 32 + i * 8 + srow);
+      st_global((float*)a.out + row * a.ldo + n, v);
+      const float c = cen[i];
+      const float d0 = v.x - c, d1 = v.y - c, d2 = v.z - c, d3 = v.w - c;
+      uint2 o;
+      o.x = pack_bf16x2(d0, d1);
+      o.y = pack_bf16x2(d2, d3);
+      st_global((bf16_t*)a.xb + row * a.ldxb + n, o);
+      const float s4 = (d0 + d1) + (d2 + d3), q4 = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+      ps[i] = tn == 0 ? s4 : ps[i] + s4;
+      pq[i] = tn == 0 ? q4 : pq[i] + q4;
+    }
+    if (b + RAHEAD < TM * TN) load_res(b + RAHEAD, rv[b % RAHEAD]);
+    if (tn == TN - 1) {                                             // the block row's 64 columns are complete: fold the 8 lanes of a row
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float s = sum8_dpp(ps[i]), q = sum8_dpp(pq[i]);
+        if (sch == 0) {
+          const size_t row = (size_t)(mw0 + tm * 32 + i * 8 + srow);
+          *(AS1 f32x2*)(a.part + (row * ngrp + grp) * 2) = f32x2{s, q};
+        }
+      }
+      if (next_cen) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cen[i] = cenn[i];
+      }
+    }
+  }
+}
+
 // bf16 outputs without a residual (QKV, c_fc).  The staged fp32 epilogue above is bound by its LDS-write and
 // store-instruction issue (8-byte stores, 16-byte LDS writes), so here bias and activation are applied in the
 // accumulator layout, the tile is packed to bf16 BEFORE staging (8-byte LDS writes, half the bytes) and a whole
@@ -163,9 +306,14 @@ __device__ __forceinline__ u32x4 stg_read16u(unsigned addr) {
   return v;
 }
 
-template <int TM, int TN, int ACT>
+// FOLD (DESIGN "LayerNorm fold"): the X operand was (x - center) in bf16 and W carries the LayerNorm's gamma, so the LayerNorm
+// output's projection is  rstd[m] * acc - (mean[m] * rstd[m]) * csum[n] + bias'[n]  (M.py:204-219 applied to the GEMM's result:
+// csum[n] = sum_k W'[n][k], bias' = bias + W beta).  rstat = this wave's 128 rows' (rstd, mean * rstd), lane j: rows j (.x, .y)
+// and j + 64 (.z, .w), requested at tile start like the bias; ccol = csum of the wave's column j.
+template <int TM, int TN, int ACT, bool FOLD = false>
 __device__ __forceinline__ void epilogue_pack16(f32x4 (&acc)[2 * TN][2 * TM], const msclip_gemm_desc& a, unsigned stg,
-                                                int mw0, int nw0, int lane, float bcol, void* outp) {
+                                                int mw0, int nw0, int lane, float bcol, void* outp, float ccol = 0.f,
+                                                float4 rstat = make_float4(1.f, 0.f, 1.f, 0.f)) {
   static_assert(TN == 2, "64 bf16 columns = one 128-byte staged row");
   const int r16 = lane & 15, quad = lane >> 4;
   const int srow = lane >> 3, sch = lane & 7;
@@ -191,6 +339,30 @@ __device__ __forceinline__ void epilogue_pack16(f32x4 (&acc)[2 * TN][2 * TM], co
                  :
                  : "memory");
   }
+  float cs[FOLD ? 4 : 1][4], rs[FOLD ? 2 * TM : 1], sh[FOLD ? 2 * TM : 1];
+  if constexpr (FOLD) {
+    const int src = __float_as_int(ccol), base = quad * 16;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        cs[ni][r] = __int_as_float(__builtin_amdgcn_ds_bpermute(base + (ni * 16 + r) * 4, src));
+#pragma unroll
+    for (int mi = 0; mi < 2 * TM; ++mi) {                            // row mi*16 + r16 of the wave's 128: lane (mi & 3)*16 + r16, half mi >> 2
+      const int sl = ((mi & 3) * 16 + r16) * 4;
+      rs[mi] = __int_as_float(__builtin_amdgcn_ds_bpermute(sl, __float_as_int(mi < 4 ? rstat.x : rstat.z)));
+      sh[mi] = __int_as_float(__builtin_amdgcn_ds_bpermute(sl, __float_as_int(mi < 4 ? rstat.y : rstat.w)));
+    }
+    static_assert(!FOLD || TM == 4, "128 rows per wave");
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(cs[0][0]), "+v"(cs[0][1]), "+v"(cs[0][2]), "+v"(cs[0][3]), "+v"(cs[1][0]), "+v"(cs[1][1]), "+v"(cs[1][2]),
+                   "+v"(cs[1][3]), "+v"(cs[2][0]), "+v"(cs[2][1]), "+v"(cs[2][2]), "+v"(cs[2][3]), "+v"(cs[3][0]), "+v"(cs[3][1]),
+                   "+v"(cs[3][2]), "+v"(cs[3][3])
+                 :
+                 : "memory");
+    asm volatile("" : "+v"(rs[0]), "+v"(rs[1]), "+v"(rs[2]), "+v"(rs[3]), "+v"(rs[4]), "+v"(rs[5]), "+v"(rs[6]), "+v"(rs[7]),
+                      "+v"(sh[0]), "+v"(sh[1]), "+v"(sh[2]), "+v"(sh[3]), "+v"(sh[4]), "+v"(sh[5]), "+v"(sh[6]), "+v"(sh[7]));
+  }
   // Block tm = 32 rows x 64 columns of the wave.  Its values are computed in four QUARTERS (8 values + one 16-byte staging
   // write pair each); between the quarters of block tm+1 the four 1-KiB store instructions of block tm go out one at a
   // time instead of back to back.  Measured same-box against the back-to-back form: QKV 226.6 -> 223.1 us, c_fc unchanged
@@ -210,7 +382,8 @@ __device__ __forceinline__ void epilogue_pack16(f32x4 (&acc)[2 * TN][2 * TM], co
       float v[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        v[e] = acc[ni][2 * tm + mi][e] * a.alpha + b[ni][e];
+        if constexpr (FOLD) v[e] = acc[ni][2 * tm + mi][e] * rs[2 * tm + mi] + (b[ni][e] - sh[2 * tm + mi] * cs[ni][e]);
+        else v[e] = acc[ni][2 * tm + mi][e] * a.alpha + b[ni][e];
         if (ACT == 1) v[e] = v[e] / (1.f + __expf(-1.702f * v[e]));
         if (ACT == 2) v[e] = fmaxf(v[e], 0.f);
       }

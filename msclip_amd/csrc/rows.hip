@@ -13,8 +13,8 @@ namespace {
 constexpr int WPB = 4;  // waves (rows) per block
 
 template <int NV>
-__device__ __forceinline__ void ln_core(float4 (&v)[NV], const float* __restrict__ gamma,
-                                        const float* __restrict__ beta, float eps, int lane) {
+__device__ __forceinline__ float ln_core(float4 (&v)[NV], const float* __restrict__ gamma,
+                                         const float* __restrict__ beta, float eps, int lane) {
   constexpr float invC = 1.f / (NV * 256);
   float s = 0.f;
 #pragma unroll
@@ -37,6 +37,7 @@ __device__ __forceinline__ void ln_core(float4 (&v)[NV], const float* __restrict
     v[i].z = g.z * (v[i].z * rstd) + b.z;
     v[i].w = g.w * (v[i].w * rstd) + b.w;
   }
+  return mean;
 }
 
 template <int NV>
@@ -56,6 +57,51 @@ __device__ __forceinline__ void store_row(const float4 (&v)[NV], void* out, size
       *(uint2*)(o + i * 256 + lane * 4) = p;
     }
   }
+}
+
+// LayerNorm of contiguous rows that also leaves the LayerNorm fold's per-row state (msclip_layernorm_stats): center[m] = mean,
+// rowstat[m] = (1, 0): the consuming projection reads `out` as it is, the next producing one centres its bf16 copy on the mean.
+template <int NV>
+__global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, void* out, int ldo, int out_kind,
+                                                       float* __restrict__ raw_out, int ld_raw, float* __restrict__ center,
+                                                       float* __restrict__ rowstat, int M, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * WPB + (threadIdx.x >> 6);
+  if (m >= M) return;
+  float4 v[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = *(const float4*)(x + (size_t)m * ldx + i * 256 + lane * 4);
+  if (raw_out) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) *(float4*)(raw_out + (size_t)m * ld_raw + i * 256 + lane * 4) = v[i];
+  }
+  const float mean = ln_core<NV>(v, gamma, beta, eps, lane);
+  store_row<NV>(v, out, (size_t)m, ldo, out_kind, lane);
+  if (lane == 0) {
+    if (center) center[m] = mean;
+    if (rowstat) *(float2*)(rowstat + 2 * (size_t)m) = make_float2(1.f, 0.f);
+  }
+}
+
+// Row statistics from the producing GEMM's per-64-column partial sums of (x - center[m]) (msclip_rowstat_finalize): one
+// thread per row, the groups folded in index order (deterministic).
+__global__ __launch_bounds__(256) void rowstat_finalize_kernel(const float* __restrict__ part, int groups, float* __restrict__ center,
+                                                               float* __restrict__ rowstat, int M, float invC, float eps) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  const float2* p = (const float2*)(part + (size_t)m * groups * 2);
+  float s = 0.f, q = 0.f;
+  for (int g = 0; g < groups; ++g) {
+    const float2 v = p[g];
+    s += v.x;
+    q += v.y;
+  }
+  const float mu = s * invC;
+  const float var = fmaxf(q * invC - mu * mu, 0.f);
+  const float rstd = 1.f / sqrtf(var + eps);
+  *(float2*)(rowstat + 2 * (size_t)m) = make_float2(rstd, mu * rstd);
+  center[m] += mu;
 }
 
 // y[m] = LN(x[src(m)]) ; src(m) = row_idx ? row_idx[m] : m * row_mul + row_add; rows >= split use (gamma2, beta2)
@@ -384,6 +430,24 @@ extern "C" int msclip_layernorm(const float* x, int ldx, const int* row_idx, int
   if (!x || !gamma || !beta || !out || M <= 0 || (ldx % 4) || (ldo % 4)) return MSCLIP_EINVAL;
   return launch_ln(x, ldx, row_idx, row_mul, row_add, gamma, beta, out, ldo, out_kind, raw_out, ld_raw, M, C, eps, gamma,
                    beta, M, (hipStream_t)stream);
+}
+
+extern "C" int msclip_layernorm_stats(const float* x, int ldx, const float* gamma, const float* beta, void* out, int ldo,
+                                      int out_kind, float* raw_out, int ld_raw, float* center, float* rowstat, int M, int C,
+                                      float eps, void* stream) {
+  if (!x || !gamma || !beta || !out || M <= 0 || (ldx % 4) || (ldo % 4) || (raw_out && (ld_raw % 4))) return MSCLIP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((M + WPB - 1) / WPB), blk(256);
+  NV_LAUNCH(C, ln_stats_kernel, grid, blk, st, x, ldx, gamma, beta, out, ldo, out_kind, raw_out, ld_raw, center, rowstat, M, eps)
+  return msclip_launch_status();
+}
+
+extern "C" int msclip_rowstat_finalize(const float* part, int groups, float* center, float* rowstat, int M, int C, float eps,
+                                       void* stream) {
+  if (!part || !center || !rowstat || M <= 0 || groups <= 0 || C != groups * 64) return MSCLIP_EINVAL;
+  hipLaunchKernelGGL(rowstat_finalize_kernel, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, groups, center,
+                     rowstat, M, 1.f / (float)C, eps);
+  return msclip_launch_status();
 }
 
 extern "C" int msclip_layernorm_split(const float* x, int ldx, const float* gamma, const float* beta,

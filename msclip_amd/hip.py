@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("MSCLIP_HIP_LIB") or os.path.join(_HERE, "csrc", "libm
 INT_MAX = 2 ** 31 - 1
 
 EXPORTS = (
-    "msclip_gemm", "msclip_gemm_f8", "msclip_layernorm_f8", "msclip_quant_f8_rows", "msclip_gemm_variant", "msclip_attention", "msclip_attention_lastq", "msclip_layernorm", "msclip_layernorm_split", "msclip_embed_tokens", "msclip_fill_cls",
+    "msclip_gemm", "msclip_gemm_f8", "msclip_layernorm_stats", "msclip_rowstat_finalize", "msclip_layernorm_f8", "msclip_quant_f8_rows", "msclip_gemm_variant", "msclip_attention", "msclip_attention_lastq", "msclip_layernorm", "msclip_layernorm_split", "msclip_embed_tokens", "msclip_fill_cls",
     "msclip_adapter_combine_ln", "msclip_l2norm", "msclip_gather_rows", "msclip_stem_conv3x3s2_dual", "msclip_dwpool",
     "msclip_stem_dual_conv3x3s2", "msclip_conv1x1_conv3x3s2", "msclip_convresblock48_s2",
     "msclip_lse_rows", "msclip_clip_loss_partial", "msclip_clip_lse_fused", "msclip_clip_loss_from_partials",
@@ -51,7 +51,11 @@ class GemmDesc(ctypes.Structure):
         ("ktab", ctypes.c_void_p),
         ("act", ctypes.c_int), ("resid_kind", ctypes.c_int), ("out_kind", ctypes.c_int),
         ("alpha", ctypes.c_float),
-        ("rpg", ctypes.c_int), ("radd", ctypes.c_int), ("roff", ctypes.c_int), ("out2", ctypes.c_void_p), ("out_scale", ctypes.c_float), ("tile", ctypes.c_int),
+        ("rpg", ctypes.c_int), ("radd", ctypes.c_int), ("roff", ctypes.c_int), ("out2", ctypes.c_void_p), ("out_scale", ctypes.c_float), ("tile", ctypes.c_int), ("wg_cap", ctypes.c_int),
+        # LayerNorm fold: consumer (W2, bias2, csum, csum2, rowstat, seg_split) and producer (ldxb, xb, center, part)
+        ("W2", ctypes.c_void_p), ("bias2", ctypes.c_void_p), ("csum", ctypes.c_void_p), ("csum2", ctypes.c_void_p),
+        ("rowstat", ctypes.c_void_p), ("seg_split", ctypes.c_int), ("ldxb", ctypes.c_int), ("xb", ctypes.c_void_p),
+        ("center", ctypes.c_void_p), ("part", ctypes.c_void_p),
     ]
 
 
@@ -84,6 +88,8 @@ def lib():
         L.msclip_attention.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, vp]
         L.msclip_attention_lastq.argtypes = [vp, ci, vp, ci, vp, ci, ci, ci, ci, vp, ci, vp]
         L.msclip_layernorm.argtypes = [vp, ci, vp, ci, ci, vp, vp, vp, ci, ci, vp, ci, ci, ci, cf, vp]
+        L.msclip_layernorm_stats.argtypes = [vp, ci, vp, vp, vp, ci, ci, vp, ci, vp, vp, ci, ci, cf, vp]
+        L.msclip_rowstat_finalize.argtypes = [vp, ci, vp, vp, ci, ci, cf, vp]
         L.msclip_layernorm_split.argtypes = [vp, ci, vp, vp, vp, vp, ci, vp, ci, ci, ci, ci, cf, vp]
         L.msclip_embed_tokens.argtypes = [vp, vp, vp, vp, ci, vp, ci, ci, ci, ci, ci, vp]
         L.msclip_fill_cls.argtypes = [vp, vp, vp, ci, ci, ci, ci, vp]
@@ -318,11 +324,39 @@ def set_gemm_probe(variant, probe):
 
 
 ACT_NONE, ACT_QUICKGELU, ACT_RELU = 0, 1, 2
+
+_WG_CAP = [0]
+
+
+def set_wg_cap(n):
+    """Upper bound on the persistent workgroups (= CUs) a msclip_gemm / msclip_gemm_f8 launch may take (0: all of them); returns
+    the previous value.  The engine's two-chain schedule sets it around each chain so that the other chain's kernels find CUs."""
+    prev = _WG_CAP[0]
+    _WG_CAP[0] = int(n)
+    return prev
+
 RESID_NONE, RESID_F32, RESID_BF16, RESID_TABLE, RESID_GELUGRAD = 0, 1, 2, 3, 4
 
 
+class FoldIn:
+    """Consumer side of the LayerNorm fold for one projection launch (msclip_gemm_desc.rowstat ...): the GEMM's X operand holds
+    bf16 (x - center) rows, `w` (the gemm() argument) / bias are the first row segment's gamma-folded weight and bias' = b + W beta,
+    csum its column sums; rows >= split take w2 / bias2 / csum2 (the other modality).  rowstat: fp32 [M, 2] = (rstd, mean * rstd)."""
+
+    def __init__(self, rowstat, csum, w2=None, bias2=None, csum2=None, split=0):
+        self.rowstat, self.csum, self.w2, self.bias2, self.csum2, self.split = rowstat, csum, w2, bias2, csum2, split
+
+
+class FoldOut:
+    """Producer side (msclip_gemm_desc.xb ...): out_proj / c_proj also write xb = bf16(out - center[m]) and the per-64-column
+    partial sums part [M, N / 64, 2] of (out - center) and its square."""
+
+    def __init__(self, xb, center, part):
+        self.xb, self.center, self.part = xb, center, part
+
+
 def gemm(x, w, out, *, M=None, bias=None, resid=None, resid_kind=0, act=0, alpha=1.0, conv=None, ktab=None,
-         ldx=None, ldo=None, ldr=None, rpg=INT_MAX, radd=0, roff=0, N=None, tile=0, out2=None):
+         ldx=None, ldo=None, ldr=None, rpg=INT_MAX, radd=0, roff=0, N=None, tile=0, out2=None, fold_in=None, fold_out=None):
     """out = epilogue(alpha * x @ w^T).  x: bf16 [M, K] (or NHWC activation when conv=(H, W, Cin, Ho, Wo, stride, pad)),
     w: bf16 [N, Kpad]; out: bf16 or fp32 2-D buffer.  Training-step forms (ping-pong kernel): out2 = second bf16 output that
     receives the value before the activation; resid_kind = RESID_GELUGRAD multiplies by QuickGELU'(resid) (resid bf16)."""
@@ -350,6 +384,22 @@ def gemm(x, w, out, *, M=None, bias=None, resid=None, resid_kind=0, act=0, alpha
     d.alpha = alpha
     d.rpg, d.radd, d.roff = rpg, radd, roff
     d.tile = tile
+    d.wg_cap = _WG_CAP[0]
+    if fold_in is not None:
+        f = fold_in
+        _f32(f.rowstat), _f32(f.csum)
+        assert f.rowstat.numel() >= 2 * d.M and f.csum.numel() >= d.N
+        d.rowstat, d.csum = f.rowstat.data_ptr(), f.csum.data_ptr()
+        if f.w2 is not None:
+            _bf16(f.w2)
+            assert f.w2.shape == w.shape and f.w2.stride(0) == w.stride(0) and f.csum2.numel() >= d.N and f.bias2.numel() >= d.N
+            d.W2, d.bias2, d.csum2, d.seg_split = f.w2.data_ptr(), f.bias2.data_ptr(), f.csum2.data_ptr(), f.split
+    if fold_out is not None:
+        f = fold_out
+        _bf16(f.xb)
+        assert f.xb.shape[0] >= d.M and f.center.numel() >= d.M and f.part.numel() >= d.M * (d.N // 64) * 2
+        assert f.center.dtype == torch.float32 and f.part.dtype == torch.float32
+        d.xb, d.ldxb, d.center, d.part = f.xb.data_ptr(), f.xb.stride(0), f.center.data_ptr(), f.part.data_ptr()
     if out2 is not None:
         assert out2.dtype == torch.bfloat16 and out2.stride(0) == d.ldo and out.dtype == torch.bfloat16
         d.out2 = out2.data_ptr()
@@ -402,6 +452,7 @@ def gemm_f8(xq, wq, out, row_scale, col_scale, *, M=None, bias=None, resid=None,
     d.mode, d.act, d.resid_kind, d.alpha, d.rpg = 0, act, resid_kind, alpha, INT_MAX
     d.out_kind = 1 if out.dtype == torch.float32 else 2 if out.dtype == torch.uint8 else 0
     d.out_scale = out_scale
+    d.wg_cap = _WG_CAP[0]
     assert row_scale.numel() >= d.M and col_scale.numel() >= d.N
     probe = _f8_probe[0]
     t0 = probe.begin() if probe is not None else None
@@ -502,6 +553,22 @@ def layernorm(x, gamma, beta, out, M, *, row_idx=None, row_mul=1, row_add=0, eps
                                   raw_out.stride(0) if raw_out is not None else 0, M, C, eps, _stream()),
            "msclip_layernorm")
     return out
+
+
+def layernorm_stats(x, gamma, beta, out, M, center, rowstat, *, eps=1e-12, raw_out=None):
+    """out[m] = LN(x[m]) over contiguous rows, plus the LayerNorm fold's per-row state: center[m] = mean of the row,
+    rowstat[m] = (1, 0) (the consuming projection takes `out` as it is)."""
+    assert x.dtype == torch.float32 and x.is_cuda and x.stride(-1) == 1
+    _check(lib().msclip_layernorm_stats(_p(x), x.stride(0), _p(gamma), _p(beta), _p(out), out.stride(0),
+                                        1 if out.dtype == torch.float32 else 0, _p(raw_out),
+                                        raw_out.stride(0) if raw_out is not None else 0, _p(center), _p(rowstat), M, x.shape[-1],
+                                        eps, _stream()), "msclip_layernorm_stats")
+    return out
+
+
+def rowstat_finalize(part, center, rowstat, M, C, eps=1e-12):
+    """rowstat[m] = (rstd, mu * rstd) and center[m] += mu from a producing GEMM's partial sums part [M, C / 64, 2]."""
+    _check(lib().msclip_rowstat_finalize(_p(part), C // 64, _p(center), _p(rowstat), M, C, eps, _stream()), "msclip_rowstat_finalize")
 
 
 def layernorm_split(x, gamma, beta, gamma2, beta2, split, out, M, eps=1e-12):

@@ -34,11 +34,10 @@ def test_gemm_dense_bias_and_shapes(gpu_device, M, N, K):
     close(outf, 0.5 * (x.float() @ w.float().t()) + b, 2e-3, 1e-4)
 
 
-@pytest.mark.parametrize("tile", [1, 4, 8])
+@pytest.mark.parametrize("tile", [1, 4])
 @pytest.mark.parametrize("M,N,K", [(1000, 768, 3072), (700, 520, 128), (256, 256, 64), (2051, 1096, 768)])
 def test_gemm_every_tile_config(gpu_device, tile, M, N, K):
-    """The dense main loops (128x128 two-buffer, 256x256 ping-pong, 256x128 two-workgroups-per-CU) on ragged edges, all three
-    epilogue kinds (the 4-wave kernel, tile 7, has its own test below)."""
+    """The dense main loops (128x128 two-buffer, 256x256 ping-pong) on ragged edges, all three epilogue kinds."""
     x, w, b = rnd(M, K, seed=11, dtype=BF), rnd(N, K, seed=12, scale=0.05, dtype=BF), rnd(N, seed=13)
     base = x.float() @ w.float().t() + b
     out = torch.full((M + 3, N), float("nan"), dtype=BF, device="cuda")
@@ -53,7 +52,7 @@ def test_gemm_every_tile_config(gpu_device, tile, M, N, K):
         close(xres, r32 + base, 4e-3, 1e-4)
 
 
-@pytest.mark.parametrize("tile", [4, 8])
+@pytest.mark.parametrize("tile", [4])
 @pytest.mark.parametrize("nt_m,nt_n", [(1, 1), (3, 2), (5, 3), (2, 4), (7, 5), (4, 6), (3, 7), (9, 9), (40, 3), (300, 1), (5, 17), (70, 9), (3, 24)])
 def test_gemm_pingpong_tile_map_covers_every_tile(gpu_device, tile, nt_m, nt_n):
     """The ping-pong kernels' tile-id -> origin maps (XCD remap, column groups of four 256-column / eight 128-column tiles,
@@ -97,7 +96,7 @@ def test_gemm_streaming_small_k(gpu_device, M, N, K, ldx):
     close(out[:M], ref1, 2e-2, 1e-2)                                             # agrees with the 128x128 kernel
 
 
-@pytest.mark.parametrize("tile", [4, 8])
+@pytest.mark.parametrize("tile", [4])
 def test_gemm_pingpong_race_screen(gpu_device, tile):
     """The ping-pong kernels order LDS-DMA writes, fragment reads and ring-slot reuse by counted waits and barriers only;
     a misplaced one shows up as rare wrong tiles.  Many launches, every output element, bitwise-equal results."""
@@ -126,7 +125,7 @@ def test_gemm_pingpong_race_screen(gpu_device, tile):
             assert torch.equal(acc, first), f"launch {it} differs from launch 0"
 
 
-@pytest.mark.parametrize("tile", [4, 8])
+@pytest.mark.parametrize("tile", [4])
 @pytest.mark.parametrize("act", [hip.ACT_NONE, hip.ACT_QUICKGELU])
 def test_gemm_pingpong_race_screen_multi_tile(gpu_device, act, tile):
     """Same screen with several tiles per workgroup (768 tiles on <= 256 workgroups, 12 K-tiles each): the DMA stream
@@ -206,7 +205,7 @@ def test_gemm_token_scatter_with_table(gpu_device):
     assert float(got[:, 0].abs().max()) == 0.0 and float(X[B * L:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("tile", [0, 1, 4, 8])
+@pytest.mark.parametrize("tile", [0, 1, 4])
 def test_gemm_token_scatter_every_tile_config(gpu_device, tile):
     """The stem -> token-row scatter with the positional table at a batch where the large-tile kernels take it."""
     B, g2, D, K = 700, 49, 768, 768                                # M = 34300: 134 row tiles of 256
@@ -643,55 +642,6 @@ def test_bad_arguments_are_rejected(gpu_device):
         hip.attention(rnd(300, 2304, dtype=BF), torch.empty(300, 768, dtype=BF, device="cuda"), 1, 300, 12, False)
 
 
-# ---------------------------------------------------------------------------------------------------------------------
-# round 2: the 4-wave GEMM whose epilogue is carried under the next tile's K loop (csrc/gemm_w4.hip, tile = 7)
-# ---------------------------------------------------------------------------------------------------------------------
-
-@pytest.mark.parametrize("act", [hip.ACT_NONE, hip.ACT_QUICKGELU, hip.ACT_RELU])
-@pytest.mark.parametrize("M,N,K", [(256, 256, 576), (1000, 768, 768), (77, 512, 3072), (2051, 1024, 640), (5000, 2304, 768),
-                                    (300 * 256 - 19, 256, 576), (9 * 256, 9 * 256, 1024)])
-def test_gemm_w4_carried_epilogue(gpu_device, M, N, K, act):
-    """Every epilogue unit / row guard / tile hand-over of the 4-wave kernel: one tile, fewer and more tiles than
-    workgroups, ragged M (rows past M never written), 9 K-tiles (the minimum: units on K-tiles 1..8) and more, all
-    three activations, with and without bias.  Checked on EVERY output element against fp32 torch."""
-    x, w, b = rnd(M, K, seed=31, dtype=BF), rnd(N, K, seed=32, scale=0.05, dtype=BF), rnd(N, seed=33)
-    assert hip.gemm_variant(hip.describe_gemm(0, M, N, K, tile=7)) == "w4"
-    base = x.float() @ w.float().t()
-    for bias in (b, None):
-        ref = base + (bias if bias is not None else 0.0)
-        if act == hip.ACT_QUICKGELU:
-            ref = ref * torch.sigmoid(1.702 * ref)
-        elif act == hip.ACT_RELU:
-            ref = F.relu(ref)
-        out = torch.full((M + 5, N), float("nan"), dtype=BF, device="cuda")
-        for rep in range(2):                                                    # second launch: same result bit for bit
-            hip.gemm(x, w, out[:M], bias=bias, act=act, tile=7)
-            if rep == 0:
-                first = out[:M].clone()
-        assert torch.equal(first.view(torch.int16), out[:M].view(torch.int16))
-        # operands rounded to bf16 once more before the bias / activation (the packed carry): 2^-8 relative on |acc|
-        close(out[:M], ref, 3e-2, 1.5e-2)
-        assert bool(torch.isnan(out[M:].float()).all())                          # nothing written past M
-
-
-def test_gemm_w4_against_the_pingpong_kernel_on_the_qkv_shape(gpu_device):
-    """The QKV projection of the B/32 step (65 024 x 2304 x 768, 2286 tiles on 256 workgroups: ~9 tiles each, every tile
-    hand-over carried) through both main kernels; auto still picks the ping-pong kernel, the 4-wave one is opt-in."""
-    assert hip.gemm_variant(hip.describe_gemm(0, 65024, 2304, 768)) == "pp"
-    assert hip.gemm_variant(hip.describe_gemm(0, 65024, 2304, 768, tile=7)) == "w4"
-    assert hip.gemm_variant(hip.describe_gemm(0, 1000, 768, 768, tile=7, resid_kind=hip.RESID_F32)) == "invalid"
-    x, w = rnd(65024, 768, seed=41, dtype=BF), rnd(2304, 768, seed=42, scale=0.05, dtype=BF)
-    b = rnd(2304, seed=43)
-    out = torch.empty(65024, 2304, dtype=BF, device="cuda")
-    hip.gemm(x, w, out, bias=b, tile=7)
-    ref = torch.empty_like(out)
-    hip.gemm(x, w, ref, bias=b, tile=4)                                          # the ping-pong kernel on the same data
-    d = (out.float() - ref.float()).abs()
-    assert d.max().item() <= 3e-2 * max(1.0, ref.float().abs().max().item())
-    rows = torch.tensor([0, 255, 256, 32767, 65023], device="cuda")
-    close(out[rows], x[rows].float() @ w.float().t() + b, 3e-2, 1.5e-2)
-
-
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gather_rows(gpu_device, dtype):
     """msclip_gather_rows: rows by stride or by index, fp32 and bf16, out of a wider parent (row-range / column views)."""
@@ -706,26 +656,6 @@ def test_gather_rows(gpu_device, dtype):
     assert torch.equal(out2[3:36], x[idx.long()]) and not out2[:3].any() and not out2[36:].any()
     hip.gather_rows(x, out[:10], 10, row_mul=7, row_add=2)
     assert torch.equal(out[:10], x[2::7][:10])
-
-
-def test_gemm_pp2_against_the_pingpong_kernel_on_the_projection_shapes(gpu_device):
-    """gemm_pp2_kernel (tile 8: two 4-wave workgroups per CU, 256 x 128 tiles) and gemm_pp_kernel (tile 4) run the same
-    K order per output element with the same MFMA shape and the same epilogue code: bitwise-equal outputs on the model's
-    four projection shapes at a batch-64 token count, bias / QuickGELU / fp32 residual epilogues."""
-    M = 64 * 127
-    for N, K, kind in ((2304, 768, "bias"), (3072, 768, "gelu"), (768, 768, "resid"), (768, 3072, "resid")):
-        x, w, b = rnd(M, K, seed=61, dtype=BF), rnd(N, K, seed=62, scale=0.04, dtype=BF), rnd(N, seed=63)
-        outs = []
-        for tile in (4, 8):
-            assert hip.gemm_variant(hip.describe_gemm(0, M, N, K, tile=tile)) == ("pp" if tile == 4 else "pp2")
-            if kind == "resid":
-                o = rnd(M, N, seed=64)
-                hip.gemm(x, w, o, bias=b, resid=o, resid_kind=hip.RESID_F32, tile=tile)
-            else:
-                o = torch.empty(M, N, dtype=BF, device="cuda")
-                hip.gemm(x, w, o, bias=b, act=hip.ACT_QUICKGELU if kind == "gelu" else hip.ACT_NONE, tile=tile)
-            outs.append(o)
-        assert torch.equal(outs[0], outs[1]), (N, K, kind, (outs[0].float() - outs[1].float()).abs().max().item())
 
 
 def _dq(q, s):
@@ -821,7 +751,7 @@ def test_gemm_chip_filling_launches_back_to_back_and_on_two_streams(gpu_device, 
             close(out, ref, 6e-2, 2e-2)
 
 
-@pytest.mark.parametrize("tile", [0, 4, 8])
+@pytest.mark.parametrize("tile", [0, 4])
 @pytest.mark.parametrize("M,N,K", [(768, 520, 128), (2048, 1096, 768), (256 * 9, 3072, 768)])
 def test_gemm_training_epilogue_forms(gpu_device, tile, M, N, K):
     """The ping-pong kernels' training-step epilogues: out2 = the value BEFORE the activation beside QuickGELU(value) from one
@@ -868,3 +798,109 @@ def test_gemm_f8_e4m3_output(gpu_device, M, N, K):
     assert bool((err <= tol).all()), float((err - tol).max())
     assert (got != want).float().mean().item() < 0.02               # nearly all elements bit-equal
     assert float(got.abs().max()) <= 448 * (s / 2.0) + 1e-6 and bool((got.abs() >= 447 * (s / 2.0)).any())    # saturated, no NaN
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 4: LayerNorm fold (DESIGN.md "LayerNorm fold"): out_proj / c_proj produce the next LayerNorm's operands, the
+# projection behind it applies the normalisation to its accumulators
+# ---------------------------------------------------------------------------------------------------------------------
+
+def _fold_weights(w, bias, gamma, beta):
+    """W' = bf16(gamma o W), csum = row sums of W' (of the bf16 values), bias' = bias + W beta (fp32)."""
+    wf = (w.float() * gamma[None, :]).to(BF).contiguous()
+    return wf, wf.float().sum(dim=1).contiguous(), (bias + w.float() @ beta).contiguous()
+
+
+@pytest.mark.parametrize("M,K", [(1024, 768), (2560, 3072)])
+def test_layernorm_fold_producer(gpu_device, M, K):
+    """msclip_gemm with xb / center / part: the fp32 residual update is bitwise the plain launch's, xb is bitwise
+    bf16(out - center), the partial sums are the 64-column sums of (out - center) and its square; msclip_rowstat_finalize
+    turns them into (rstd, mean * rstd) of M.py:204-219 and moves the centre to the row mean."""
+    D = 768
+    a, w, b = rnd(M, K, seed=71, dtype=BF), rnd(D, K, seed=72, scale=0.03, dtype=BF), rnd(D, seed=73)
+    x0 = rnd(M, D, seed=74) + rnd(M, 1, seed=75, scale=3.0)               # rows with a sizeable mean
+    cen = x0.mean(dim=1) + rnd(M, seed=76, scale=0.2)                      # "mean at the previous LayerNorm point"
+    plain = x0.clone()
+    hip.gemm(a, w, plain, bias=b, resid=plain, resid_kind=hip.RESID_F32, tile=4)          # the same main loop
+    out, xb = x0.clone(), torch.full((M, D), float("nan"), dtype=BF, device="cuda")
+    part = torch.full((M, D // 64, 2), float("nan"), device="cuda")
+    c = cen.clone()
+    fo = hip.FoldOut(xb, c, part)
+    for rep in range(2):
+        out.copy_(x0)
+        hip.gemm(a, w, out, bias=b, resid=out, resid_kind=hip.RESID_F32, fold_out=fo)
+        assert torch.equal(out, plain)
+        assert torch.equal(xb.view(torch.int16), (out - cen[:, None]).to(BF).view(torch.int16))
+    d = (out - cen[:, None]).view(M, D // 64, 64)
+    close(part[..., 0], d.sum(-1), 2e-3, 1e-5)
+    close(part[..., 1], (d * d).sum(-1), 2e-3, 1e-5)
+    rstat = torch.empty(M, 2, device="cuda")
+    hip.rowstat_finalize(part, c, rstat, M, D)
+    mu, var = out.mean(dim=1), out.var(dim=1, unbiased=False)
+    close(c, mu, 1e-5, 1e-6)
+    close(rstat[:, 0], 1.0 / torch.sqrt(var + 1e-12), 0.0, 2e-5)
+    close(rstat[:, 1], (mu - cen) / torch.sqrt(var + 1e-12), 2e-5, 2e-5)
+
+
+@pytest.mark.parametrize("act", [hip.ACT_NONE, hip.ACT_QUICKGELU])
+@pytest.mark.parametrize("two", [False, True])
+def test_layernorm_fold_consumer(gpu_device, act, two):
+    """The projection behind a folded LayerNorm against fp32 torch (LayerNorm of M.py:204-219, then the linear layer) and
+    against the unfused chain of this library (msclip_layernorm_split + msclip_gemm): both deviate from fp32 only by the bf16
+    rounding of their operands, and the fold's deviation must not exceed the unfused chain's by more than a quarter.  Two row
+    segments = image / text rows with their own gamma / beta under one shared weight."""
+    M, D, N = 2048, 768, 2304 if act == hip.ACT_NONE else 3072
+    split = 768 if two else M
+    x = rnd(M, D, seed=81, scale=1.5) + rnd(M, 1, seed=82, scale=2.0)
+    w, b = rnd(N, D, seed=83, scale=0.04, dtype=BF), rnd(N, seed=84, scale=0.3)
+    g1, b1 = 1.0 + rnd(D, seed=85, scale=0.2), rnd(D, seed=86, scale=0.3)
+    g2, b2 = 1.0 + rnd(D, seed=87, scale=0.2), rnd(D, seed=88, scale=0.3)
+    mu, var = x.mean(1, keepdim=True), x.var(1, unbiased=False, keepdim=True)
+    xn = (x - mu) / torch.sqrt(var + 1e-12)
+    ln = torch.cat([xn[:split] * g1 + b1, xn[split:] * g2 + b2])
+    ref = ln @ w.float().t() + b
+    if act == hip.ACT_QUICKGELU:
+        ref = ref * torch.sigmoid(1.702 * ref)
+    # unfused chain
+    lno = torch.empty(M, D, dtype=BF, device="cuda")
+    hip.layernorm_split(x, g1, b1, g2, b2, split, lno, M)
+    chain = torch.empty(M, N, dtype=BF, device="cuda")
+    hip.gemm(lno, w, chain, bias=b, act=act, tile=4)
+    # fold: centres a little off the true means, as they are one layer later
+    cen = mu[:, 0] + rnd(M, seed=89, scale=0.05)
+    xb = (x - cen[:, None]).to(BF).contiguous()
+    d = x - cen[:, None]
+    mu_d = d.mean(1)
+    rstd = 1.0 / torch.sqrt(d.var(1, unbiased=False) + 1e-12)
+    rstat = torch.stack([rstd, mu_d * rstd], dim=1).contiguous()
+    w1, c1, bb1 = _fold_weights(w, b, g1, b1)
+    w2, c2, bb2 = _fold_weights(w, b, g2, b2)
+    fi = hip.FoldIn(rstat, c1, w2, bb2, c2, split) if two else hip.FoldIn(rstat, c1)
+    out = torch.full((M, N), float("nan"), dtype=BF, device="cuda")
+    outs = []
+    for rep in range(2):
+        hip.gemm(xb, w1, out, bias=bb1, act=act, fold_in=fi)
+        outs.append(out.clone())
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    e_fold = (out.float() - ref).abs()
+    e_chain = (chain.float() - ref).abs()
+    scale = ref.abs().max().item()
+    assert e_fold.max().item() <= 0.02 * scale, (e_fold.max().item(), scale)
+    assert e_fold.mean().item() <= 1.25 * e_chain.mean().item() + 1e-4, (e_fold.mean().item(), e_chain.mean().item())
+    # a descriptor the fold cannot take (ragged rows) is rejected, not mis-computed
+    with pytest.raises(hip.HipError):
+        hip.gemm(xb[:1000], w1, out[:1000], bias=bb1, act=act, fold_in=hip.FoldIn(rstat, c1))
+
+
+def test_layernorm_stats_rows(gpu_device):
+    """msclip_layernorm_stats = msclip_layernorm + the fold's per-row state (centre = mean, rowstat = (1, 0)), with the raw copy."""
+    M, D = 1000, 768
+    x, g, b = rnd(M, D, seed=91) + 2.0, 1.0 + rnd(D, seed=92, scale=0.1), rnd(D, seed=93, scale=0.1)
+    ref = torch.empty(M, D, dtype=BF, device="cuda")
+    hip.layernorm(x, g, b, ref, M)
+    out, raw = torch.empty(M, D, dtype=BF, device="cuda"), torch.empty(M, D, device="cuda")
+    cen, rs = torch.empty(M, device="cuda"), torch.empty(M, 2, device="cuda")
+    hip.layernorm_stats(x, g, b, out, M, cen, rs, raw_out=raw)
+    assert torch.equal(out.view(torch.int16), ref.view(torch.int16)) and torch.equal(raw, x)
+    close(cen, x.mean(1), 1e-5)
+    assert bool((rs[:, 0] == 1).all()) and bool((rs[:, 1] == 0).all())
