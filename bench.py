@@ -30,7 +30,7 @@ WIDTH = {"b32-yfcc-msclips": 768, "b16-yfcc-msclips": 768, "l16-fp8-msclips": 10
 SKIPPED_ROWS_PER_PAIR = {"b32-yfcc-msclips": 50 + 77 - 2, "b16-yfcc-msclips": 197 + 77 - 2, "l16-fp8-msclips": 197 + 77 - 2}
 PEAK_FP8_TFLOPS = 5000.0                                                       # MI355X_MICROARCH.md: dense fp8 (MX K = 128) MFMA
 PEAK_BF16_TFLOPS = 2500.0                                                      # MI355X_MICROARCH.md: dense bf16 MFMA
-DOMINANT = {"variant": "pp", "kernel": "gemm_pp_kernel<0, false>",             # what hip.gemm_variant calls it / rocprof's name
+DOMINANT = {"variant": "pp", "kernel": "gemm_pp_kernel<0, false",              # what hip.gemm_variant calls it / rocprof's name (prefix: <0, false, 0 | 1 | 2> = standard / LayerNorm-fold consumer / producer epilogues of one main loop)
             "what": "dense bf16 MFMA GEMM: all transformer projections + wide pointwise convs"}
 N_SIMD, N_XCD = 1024, 8                                                        # 256 CUs x 4 SIMDs; GRBM counters sum over XCDs
 
@@ -66,7 +66,7 @@ def pmc_passes(args, kernel):
             vals, tot = {}, {}
             for r in csv.DictReader(open(files[0])):
                 tot[r["Counter_Name"]] = tot.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
-                if short(r["Kernel_Name"]) == kernel:
+                if short(r["Kernel_Name"]).startswith(kernel):
                     vals.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
             for c in counters:
                 out[c] = sum(vals[c]) / len(vals[c])
@@ -77,6 +77,57 @@ def pmc_passes(args, kernel):
         finally:
             shutil.rmtree(d, ignore_errors=True)
     return out
+
+
+HBM_PEAK_TBPS = 8.0                                                           # MI355X_MICROARCH.md: HBM3E spec peak (6.3 measured achievable)
+
+
+def hbm_kernel_rates(args, B, width, Lv, Lt, g):
+    """Achieved HBM rate of the largest bandwidth-bound kernels of the step ("per-kernel HBM GB/s for the
+    bandwidth-bound kernels"): average launch time from a rocprofv3 --kernel-trace child pass of this command (inline
+    schedule: nothing else on the chip), algorithmic bytes per launch from the shapes (s8(d) "algorithmic bytes")."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    Mv, Mt, D = B * Lv, B * Lt, width
+    alg = {   # kernel-name prefix -> (what, algorithmic bytes per launch)
+        "attn_kernel<3, true": ("text attention core (causal, 77 tokens): q|k|v read + output written, bf16", 4 * Mt * D * 2),
+        "attn_kernel<2, false": ("image attention core (50 tokens)", 4 * Mv * D * 2),
+        "attn_wg_kernel": ("image attention core (197 tokens)", 4 * Mv * D * 2),
+        "ln_pair_kernel": ("LayerNorm over all token rows: fp32 in, bf16 out", (Mv + Mt) * D * 6),
+        "ln_stats_kernel": ("LayerNorm pass of one tower's rows (+ fold state; adapter layers also copy the fp32 row)", None),
+        "front_ws_kernel<0": ("stem conv1 + parallel stage 0 + stem stage 0 in one pass: fp32 image in, two bf16 maps out",
+                              B * (3 * 224 * 224 * 4 + 112 * 112 * (D // 16) * 2 + 56 * 56 * (D // 8) * 2)),
+        "adapter_gridrow_kernel": ("lateral adapter bottom half + sum + ln_adapt: x, t fp32 in, fp32 out", Mv * D * 4 * 3),
+    }
+    d = tempfile.mkdtemp(prefix="msclip_ktrace_", dir="/tmp")
+    cmd = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "-o", "run", "--",
+           sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "2", "--batch", str(args.batch),
+           "--model", args.model, "--no-cpu-baseline", "--no-probe", "--no-pmc", "--no-hbm-kernels"]
+    try:
+        subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", MSCLIP_CONV_SIDE_STREAM="0"), timeout=900,
+                       capture_output=True, check=True)
+        f = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)[0]
+        rows = []
+        for r in csv.DictReader(open(f)):
+            name = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+            for pre, (what, nbytes) in alg.items():
+                if name.startswith(pre) and nbytes:
+                    us = float(r["AverageNs"]) / 1e3
+                    rows.append({"kernel": name.split("(")[0], "what": what, "launches_per_step": int(r["Calls"]) // 5,
+                                 "avg_us": round(us, 1), "algorithmic_MB": round(nbytes / 1e6, 1),
+                                 "achieved_TBps": round(nbytes / us / 1e6, 2), "frac_of_hbm_peak": round(nbytes / us / 1e6 / HBM_PEAK_TBPS, 3),
+                                 "step_share_us": round(us * (int(r["Calls"]) // 5), 1)})
+        rows.sort(key=lambda r: -r["step_share_us"])
+        return rows[:4]
+    except Exception as e:
+        return [{"error": f"{type(e).__name__}: {str(e)[:200]}"}]
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def load_schema(name):
@@ -113,6 +164,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true", help="do not bracket GEMM launches with HIP events")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic = null)")
+    ap.add_argument("--no-hbm-kernels", action="store_true", help="skip the kernel-trace child pass (per-kernel HBM rates of the bandwidth-bound kernels)")
     ap.add_argument("--prefill-random", action="store_true",
                     help="probe runs only: fill the workspace with random data first (timing ablation builds of the "
                          "library whose kernels skip their stores; zero-filled operands would raise the clock)")
@@ -193,7 +245,6 @@ def main():
     probe = None if args.no_probe else hip.KernelProbe()
     probe8 = None if args.no_probe else hip.KernelProbe()                   # the fp8 launches of PRECISION fp8 models
     hip.set_gemm_probe(DOMINANT["variant"], probe)
-    hip.set_gemm_probe("pp2", probe)                   # the same launches when the two-workgroups-per-CU kernel takes them
     hip.set_gemm_f8_probe(probe8)
     fence()
     t0 = time.perf_counter()
@@ -202,7 +253,6 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     hip.set_gemm_probe(DOMINANT["variant"], None)
-    hip.set_gemm_probe("pp2", None)
     hip.set_gemm_f8_probe(None)
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if grouped:
@@ -214,13 +264,12 @@ def main():
     # therefore taken from a second pass of the same K steps with the inline schedule (nothing concurrent with the kernel
     # being timed); the timed region's own (overlapped) figure is reported beside it.
     overlapped = (ts is None and os.environ.get("MSCLIP_CONV_SIDE_STREAM", "1") != "0")
-    probe_timed, dt_probe = probe, dt
+    probe_timed, probe8_timed, dt_probe = probe, probe8, dt
     if probe is not None and overlapped:
         os.environ["MSCLIP_CONV_SIDE_STREAM"] = "0"
         step()
         probe, probe8 = hip.KernelProbe(), hip.KernelProbe()
         hip.set_gemm_probe(DOMINANT["variant"], probe)
-        hip.set_gemm_probe("pp2", probe)
         hip.set_gemm_f8_probe(probe8)
         fence()
         t0 = time.perf_counter()
@@ -229,7 +278,6 @@ def main():
         fence()
         dt_probe = time.perf_counter() - t0
         hip.set_gemm_probe(DOMINANT["variant"], None)
-        hip.set_gemm_probe("pp2", None)
         hip.set_gemm_f8_probe(None)
         del os.environ["MSCLIP_CONV_SIDE_STREAM"]
 
@@ -249,7 +297,8 @@ def main():
         fmul = 3 if ts is not None else 1          # backward counted as 2x forward
         rec = {
             "metric": {"b32": "image-text pairs/sec ViT-B/32 bf16", "b16": "image-text pairs/sec ViT-B/16 bf16",
-                       "l16": "image-text pairs/sec ViT-L/16-width stand-in of config C5 (L/14 is inexpressible), fp8 + bf16"}[args.model[:3]],
+                       "l16": "image-text pairs/sec ViT-L/16-width stand-in of config C5 (L/14 is inexpressible), "
+                              + ("bf16" if model.precision == "bf16" else "fp8 + bf16")}[args.model[:3]],
             "mfma_util_pct": None,
             "value": round(pairs_s, 1), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -261,7 +310,7 @@ def main():
                                    f"random-init weights", "per_gpu_batch": B, "global_batch": B * world,
                        "parallelism": f"dp{world}", "bn": "eval (folded running statistics)"},
             "step_tflops_per_gpu": round(pairs_s / world * gf / 1e3 * fmul, 1),
-            "whole_step_mfma_frac": round(pairs_s / world * gf / 1e3 * fmul / PEAK_BF16_TFLOPS, 4),
+            "whole_step_mfma_frac": round(pairs_s / world * gf / 1e3 * fmul / PEAK_BF16_TFLOPS, 4),   # (fp8 models: re-stated against the mixed peak below)
             "gflop_per_pair": {"reference_forward": gf_ref, "executed": round(gf * fmul, 3),
                                "not_executed_dead_rows_of_last_block": round(skipped, 3)},
             "loss": round(loss_val, 5),
@@ -283,25 +332,29 @@ def main():
             rec["config"]["TEST_ONLY"] = "all ranks share GPU 0 over gloo (MSCLIP_TEST_SHARED_GPU): not a measurement"
         n = probe.summary()[0] if probe is not None else 0
         if n > 0:                       # tiny batches never reach the ping-pong kernel: no roofline line then
-            n, kms, flops = probe.summary()
-            alg_bytes = sum(probe.bytes) / n
-            ach = flops / (kms * 1e-3) / 1e12
-            rec["roofline"] = {"kernel": f"{DOMINANT['kernel']} ({DOMINANT['what']})",
-                               "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                               "launches_per_step": n // args.steps, "avg_launch_us": round(kms / n * 1e3, 2),
-                               "flops_per_launch_avg": round(flops / n / 1e9, 3), "flops_unit": "GFLOP",
+            # `probe_timed` bracketed the dominant kernel's launches INSIDE the timed region (side streams on: other kernels share
+            # the chip with them): that is the roofline of the number in `value`.  `probe` = the same K steps re-run with the
+            # inline schedule (nothing concurrent with the launch being timed): the kernel's own rate, under roofline.isolated.
+            nt, kmst, flopst = probe_timed.summary()
+            alg_bytes = sum(probe_timed.bytes) / nt
+            acht = flopst / (kmst * 1e-3) / 1e12
+            rec["roofline"] = {"kernel": f"{DOMINANT['kernel']}, *> ({DOMINANT['what']}; incl. the LayerNorm-fold instantiations <0, false, 1 / 2> of the same main loop)",
+                               "bound": "mfma", "achieved": round(acht, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(acht / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                               "measured_in": "the timed region (HIP events around every launch of the kernel on its launch stream)",
+                               "launches_per_step": nt // args.steps, "avg_launch_us": round(kmst / nt * 1e3, 2),
+                               "flops_per_launch_avg": round(flopst / nt / 1e9, 3), "flops_unit": "GFLOP",
                                "algorithmic_bytes_per_launch": round(alg_bytes),
-                               "time_share_of_step": round(kms / (dt_probe * 1e3), 4)}
+                               "time_share_of_step": round(kmst / (dt * 1e3), 4)}
             if probe_timed is not probe:
-                n2, kms2, flops2 = probe_timed.summary()
-                ach2 = flops2 / (kms2 * 1e-3) / 1e12
-                rec["roofline"]["measured_in"] = (f"probe pass: the same {args.steps} steps with the conv branch inline "
-                                                  f"(MSCLIP_CONV_SIDE_STREAM=0, {dt_probe / args.steps * 1e3:.3f} ms/step), so no other "
-                                                  "kernel shares the chip with the launch being timed")
-                rec["roofline"]["timed_region_overlapped"] = {
-                    "achieved": round(ach2, 1), "frac": round(ach2 / PEAK_BF16_TFLOPS, 4), "avg_launch_us": round(kms2 / n2 * 1e3, 2),
-                    "note": "same launches inside the timed region, where conv-branch kernels run concurrently on a side stream"}
+                n, kms, flops = probe.summary()
+                ach = flops / (kms * 1e-3) / 1e12
+                rec["roofline"]["isolated"] = {
+                    "achieved": round(ach, 1), "frac": round(ach / PEAK_BF16_TFLOPS, 4), "avg_launch_us": round(kms / n * 1e3, 2),
+                    "time_share_of_step": round(kms / (dt_probe * 1e3), 4),
+                    "note": (f"probe pass: the same {args.steps} steps with the conv branch inline (MSCLIP_CONV_SIDE_STREAM=0, "
+                             f"{dt_probe / args.steps * 1e3:.3f} ms/step): no other kernel shares the chip with the launch being timed; "
+                             "the rocprofv3 --kernel-trace summaries under profiles/ are of this schedule")}
             if args.shapes:
                 rec["roofline"]["shapes"] = [
                     {"M": t[0], "N": t[1], "K": t[2], "conv": t[4], "act": t[5], "resid": t[6], "out_fp32": t[7],
@@ -326,22 +379,38 @@ def main():
                     errs = {k: v for k, v in pmc.items() if k.startswith("error_")}
                     if errs:
                         rec["roofline"]["pmc_errors"] = errs
-        n8 = probe8.summary()[0] if probe8 is not None else 0
+        n8 = probe8_timed.summary()[0] if probe8_timed is not None else 0
         if n8 > 0:                      # PRECISION fp8: the config's own kernel gets the headline roofline, the bf16 GEMM moves beside it
-            n8, kms8, flops8 = probe8.summary()
+            n8, kms8, flops8 = probe8_timed.summary()
             ach8 = flops8 / (kms8 * 1e-3) / 1e12
             r8 = {"kernel": "gemm_pp_kernel<0, true> (dense fp8 e4m3 MX-MFMA GEMM: c_fc / c_proj of every block, in_proj under fp8-qkv)", "bound": "mfma",
                   "achieved": round(ach8, 1), "peak": PEAK_FP8_TFLOPS, "unit": "TFLOP/s", "frac": round(ach8 / PEAK_FP8_TFLOPS, 4),
-                  "traffic": None, "launches_per_step": n8 // args.steps, "avg_launch_us": round(kms8 / n8 * 1e3, 2),
+                  "traffic": None, "measured_in": "the timed region (HIP events around every launch)",
+                  "launches_per_step": n8 // args.steps, "avg_launch_us": round(kms8 / n8 * 1e3, 2),
                   "flops_per_launch_avg": round(flops8 / n8 / 1e9, 3), "flops_unit": "GFLOP",
-                  "algorithmic_bytes_per_launch": round(sum(probe8.bytes) / n8),
-                  "time_share_of_step": round(kms8 / (dt_probe * 1e3), 4)}
+                  "algorithmic_bytes_per_launch": round(sum(probe8_timed.bytes) / n8),
+                  "time_share_of_step": round(kms8 / (dt * 1e3), 4)}
+            if probe8 is not probe8_timed and probe8.summary()[0] > 0:
+                ni, kmsi, flopsi = probe8.summary()
+                r8["isolated"] = {"achieved": round(flopsi / (kmsi * 1e-3) / 1e12, 1),
+                                  "frac": round(flopsi / (kmsi * 1e-3) / 1e12 / PEAK_FP8_TFLOPS, 4),
+                                  "avg_launch_us": round(kmsi / ni * 1e3, 2), "note": "inline-schedule probe pass (nothing concurrent)"}
             if "roofline" in rec:
                 rec["roofline_bf16_gemm"] = rec["roofline"]
             rec["roofline"] = r8
+            # whole-step fraction against the peak of the units the step's FLOPs run on: time at peak = fp8 FLOPs / 5 PF +
+            # everything else / 2.5 PF, over the measured step time
+            f8_step = flops8 / args.steps
+            tot_step = B * gf * 1e9 * fmul
+            t_peak = f8_step / (PEAK_FP8_TFLOPS * 1e12) + max(tot_step - f8_step, 0.0) / (PEAK_BF16_TFLOPS * 1e12)
+            rec["whole_step_mfma_frac"] = round(t_peak / (ms * 1e-3), 4)
+            rec["whole_step_mfma_frac_note"] = (f"mixed peak: {f8_step / 1e12:.2f} TFLOP/step on the fp8 MFMA (5 PF), "
+                                                f"{(tot_step - f8_step) / 1e12:.2f} on bf16 (2.5 PF)")
         for key in ("roofline", "roofline_bf16_gemm"):
             if key in rec and "mfma_busy_pct_whole_step" in rec[key]:
                 rec["mfma_util_pct"] = rec[key]["mfma_busy_pct_whole_step"]      # BASELINE metric's second half (all kernels of a step)
+        if world == 1 and ts is None and not args.no_hbm_kernels and not args.no_pmc:
+            rec["hbm_bound_kernels"] = hbm_kernel_rates(args, B, WIDTH[args.model], eng.Lv, eng.Lt, eng.g)
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(args.model, sd)
         if grouped:                     # RCCL's version banner sits in libc's stdout buffer: out with it BEFORE the record, so

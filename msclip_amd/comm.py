@@ -158,6 +158,7 @@ class GradReducer:
     device starts filling its buckets (i.e. until the next backward).  World size 1: a pass-through."""
 
     def __init__(self, bucket_bytes=64 << 20, average=True):
+        self.generation = None       # arena generation this reducer's buckets belong to (set when it takes its first bucket)
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.average = average
         self.flat = None             # the open bucket
@@ -176,6 +177,11 @@ class GradReducer:
         if self.flat is None:
             size = max(self.bucket_elems, need)
             arena = _ARENA.setdefault((device, self.bucket_elems), [])
+            if self.used == 0:
+                # this reducer starts overwriting the arena: whatever an earlier reducer's finish() handed out is stale from here
+                key = (device, self.bucket_elems)
+                _ARENA_GEN[key] = _ARENA_GEN.get(key, 0) + 1
+                self.generation, self.arena_key = _ARENA_GEN[key], key
             while len(arena) <= self.used:
                 arena.append(None)
             if arena[self.used] is None or arena[self.used].numel() < size:
@@ -189,6 +195,9 @@ class GradReducer:
         size 1).  The producer's add(name, view) must follow before any other gradient is handed over."""
         if not comm.collectives:
             return None
+        if self.reserved:
+            raise RuntimeError(f"GradReducer.reserve({name!r}): the slot of {next(iter(self.reserved))!r} is still open "
+                               "(a reserve() must be followed by its add() before the next gradient is handed over)")
         n = 1
         for d in shape:
             n *= int(d)
@@ -201,6 +210,9 @@ class GradReducer:
         if not comm.collectives:
             self.flights.append((None, None, None, [(name, grad)], None))
             return
+        if self.reserved and name not in self.reserved:
+            raise RuntimeError(f"GradReducer.add({name!r}) while the reserved slot of {next(iter(self.reserved))!r} is open: "
+                               "it would overlap that slot")
         r = self.reserved.pop(name, None)
         if r is not None and r[0].data_ptr() == grad.data_ptr() and tuple(r[0].shape) == tuple(grad.shape):
             o, n = r[1], r[2]                                  # born in the bucket: nothing to copy
@@ -257,10 +269,15 @@ class GradReducer:
         self.launched += 1
         self.flights.append((flat, work, side, layout, [g for _, g in copies]))   # sources: alive until the side stream has read them
 
-    def finish(self):
-        """-> {name: averaged gradient}; the current stream is ordered behind every collective."""
+    def finish(self, clone=False):
+        """-> {name: averaged gradient}; the current stream is ordered behind every collective.  At world size > 1 the values
+        are VIEWS into the per-device bucket arena: they are overwritten by the next reducer on this device (the next
+        backward) -- consume them (optimizer step) before that, or ask for clone=True (accumulating over micro-batches,
+        comparing two backward passes).  The returned GradViews knows its arena generation: check_fresh() raises once a later
+        reducer has started filling the buckets."""
         self.flush()
-        out = {}
+        out = GradViews()
+        out.generation, out.arena_key = (None, None) if clone else (self.generation, getattr(self, "arena_key", None))
         for flat, work, side, layout, _ in self.flights:
             if flat is None:
                 out[layout[0][0]] = layout[0][1]
@@ -272,9 +289,24 @@ class GradReducer:
             if side is not None:
                 torch.cuda.current_stream(flat.device).wait_stream(side)
             for name, shape, o, n in layout:
-                out[name] = flat[o:o + n].view(shape)
+                v = flat[o:o + n].view(shape)
+                out[name] = v.clone() if clone else v
         self.flights = []
         return out
+
+
+_ARENA_GEN = {}
+
+
+class GradViews(dict):
+    """GradReducer.finish()'s result: a dict whose tensors may be views into the shared bucket arena."""
+    generation = None
+    arena_key = None
+
+    def check_fresh(self):
+        if self.generation is not None and _ARENA_GEN.get(self.arena_key) != self.generation:
+            raise RuntimeError("these gradients are views into the gradient-bucket arena and a later backward() on this device "
+                               "has overwritten them: step() right after backward(), or backward(clone=True)")
 
 
 def local_label_offset(local_batch):

@@ -714,6 +714,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a_i
       rstat4 = f32x4{lo, 0.f, hi, 0.f};
     }
 
+    float pf_sink = 0.f;                           // destination of the next tile's statistics prefetch (kept allocated until it has landed)
     for (int kt = 0; kt < nk; ++kt) {
       int s1 = cslot + wsub, s2 = cslot + 2 + grp;
       if (s1 >= PSLOTS) s1 -= PSLOTS;
@@ -783,8 +784,23 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a_i
       }
       issue(I2{});
       issue(I3{});
+      if constexpr (EPI != 0) {
+        // The row statistics / centres a tile asks for at its start were written by the previous kernel on other XCDs: a miss
+        // to the MALL takes longer than the 0.65 us to the first counted wait of the K loop, which retires in order.  So each
+        // wave touches the NEXT tile's lines here (lanes 0-7: one 128-byte line each; value discarded), a K-tile away from the
+        // wait that covers it; at the next tile's start they are L2 hits like the bias.
+        if (kt == 2) {
+          int nm0, nn0;
+          tile_origin(tc + (int)gridDim.x < ntiles ? tc + (int)gridDim.x : tc, nm0, nn0);
+          const float* q = (EPI == 1 ? a.rowstat + 2 * (size_t)(nm0 + wm) : a.center + (nm0 + wm)) + (lane_s & (EPI == 1 ? 7 : 3)) * 32;
+          asm volatile("global_load_dword %0, %1, off" : "=&v"(pf_sink) : "v"(q));
+        }
+      }
+      if (EPI != 0 && kt == 2) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+      else
       if (kt == 0 && nk >= 3 && epi_stores == 16) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
       else if (kt == 0 && nk >= 3 && epi_stores == 32) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+      else if (kt == 0 && nk >= 3 && epi_stores == 52) asm volatile("s_waitcnt vmcnt(60)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       PP_SYNC_IN();
 #pragma unroll
@@ -810,7 +826,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a_i
     // Staging = the ring slots of the last K-tile's X regions (dead since its phase 2; re-issued in phase 1 of the
     // next tile, behind a barrier every wave reaches only after its epilogue).
     if (!grp) __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
+    asm volatile("" : "+v"(pf_sink)::"memory");
     {
       int ss = cslot + 8 + (wave >> 2);            // cslot already points 4 ahead: X regions of the last K-tile = cslot - 2, - 1
       while (ss >= PSLOTS) ss -= PSLOTS;
@@ -849,7 +865,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a_i
         else
           epilogue_pack16<TM, TN, 1, true>(acc, a, stg, cm0 + wm, cn0 + wn, lane_e, bcol, a.out, ccol, rstat);   // c_fc + QuickGELU
       } else if constexpr (EPI == 2) {             // whole tiles, in-place fp32 residual update (host-checked)
-        epi_stores = 0;                            // (stores + row partials: beyond the counted waits of the next tile's first K-tile)
+        epi_stores = 52;                           // 32 fp32 + 16 bf16 full-line stores + 4 stores of row partials per wave
         epilogue_rows_stats<TM, TN>(acc, a, stg, cm0 + wm, cn0 + wn, lane_e, bcol, rstat4[0], rstat4[2]);
       } else
       if (vec && plain_rows && cm0 + 256 <= a.M)

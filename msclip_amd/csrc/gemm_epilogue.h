@@ -236,6 +236,7 @@ __device__ __forceinline__ void epilogue_rows_stats(f32x4 (&acc)[2 * TN][2 * TM]
   };
   stage(0, x[0]);
   float ps[4], pq[4];                                              // this lane's share of the row sums over the block row's 64 columns
+  uint2 hold[4];
   const int ngrp = a.N >> 6, grp = nw0 >> 6;
 #pragma unroll
   for (int b = 0; b < TM * TN; ++b) {
@@ -266,20 +267,37 @@ __device__ __forceinline__ void epilogue_rows_stats(f32x4 (&acc)[2 * TN][2 * TM]
       uint2 o;
       o.x = pack_bf16x2(d0, d1);
       o.y = pack_bf16x2(d2, d3);
-      st_global((bf16_t*)a.xb + row * a.ldxb + n, o);
+      if (tn == 0) {
+        hold[i] = o;                                                // the row's first 32 columns wait for the other 32
+      } else {
+        // one full 128-byte line per row and store instruction: neighbouring lanes swap 8-byte pieces, even lanes write the
+        // line's first half (16 bytes of the first block: own + neighbour's), odd lanes the second (neighbour's + own)
+        const bool odd = sch & 1;
+        const uint2 send = odd ? hold[i] : o;
+        uint2 recv;
+        recv.x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send.x, 0xB1, 0xF, 0xF, true);     // quad_perm [1, 0, 3, 2]
+        recv.y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send.y, 0xB1, 0xF, 0xF, true);
+        const uint4 q = odd ? make_uint4(recv.x, recv.y, o.x, o.y) : make_uint4(hold[i].x, hold[i].y, recv.x, recv.y);
+        st_global((bf16_t*)a.xb + row * a.ldxb + nw0 + (odd ? 32 + (sch - 1) * 4 : sch * 4), q);
+      }
       const float s4 = (d0 + d1) + (d2 + d3), q4 = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
       ps[i] = tn == 0 ? s4 : ps[i] + s4;
       pq[i] = tn == 0 ? q4 : pq[i] + q4;
     }
     if (b + RAHEAD < TM * TN) load_res(b + RAHEAD, rv[b % RAHEAD]);
     if (tn == TN - 1) {                                             // the block row's 64 columns are complete: fold the 8 lanes of a row
+      float s[4], q[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float s = sum8_dpp(ps[i]), q = sum8_dpp(pq[i]);
-        if (sch == 0) {
-          const size_t row = (size_t)(mw0 + tm * 32 + i * 8 + srow);
-          *(AS1 f32x2*)(a.part + (row * ngrp + grp) * 2) = f32x2{s, q};
-        }
+        s[i] = sum8_dpp(ps[i]);
+        q[i] = sum8_dpp(pq[i]);
+      }
+      // lane sch = i of a row group writes row i * 8 + srow: the block row's 32 rows leave in ONE store instruction
+      const float ss = sch == 0 ? s[0] : sch == 1 ? s[1] : sch == 2 ? s[2] : s[3];
+      const float qq = sch == 0 ? q[0] : sch == 1 ? q[1] : sch == 2 ? q[2] : q[3];
+      if (sch < 4) {
+        const size_t row = (size_t)(mw0 + tm * 32 + sch * 8 + srow);
+        *(AS1 f32x2*)(a.part + (row * ngrp + grp) * 2) = f32x2{ss, qq};
       }
       if (next_cen) {
 #pragma unroll

@@ -86,16 +86,29 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__
 
 // Row statistics from the producing GEMM's per-64-column partial sums of (x - center[m]) (msclip_rowstat_finalize): one
 // thread per row, the groups folded in index order (deterministic).
+template <int G4>                                      // G4 = groups / 2 float4 pieces per row (groups = C / 64: 12 or 16), or 0 = any
 __global__ __launch_bounds__(256) void rowstat_finalize_kernel(const float* __restrict__ part, int groups, float* __restrict__ center,
                                                                float* __restrict__ rowstat, int M, float invC, float eps) {
   const int m = blockIdx.x * 256 + threadIdx.x;
   if (m >= M) return;
-  const float2* p = (const float2*)(part + (size_t)m * groups * 2);
   float s = 0.f, q = 0.f;
-  for (int g = 0; g < groups; ++g) {
-    const float2 v = p[g];
-    s += v.x;
-    q += v.y;
+  if (G4 > 0) {                                       // all of the row's partials in flight at once
+    const float4* p = (const float4*)(part + (size_t)m * (G4 * 4));
+    float4 v[G4 > 0 ? G4 : 1];
+#pragma unroll
+    for (int g = 0; g < G4; ++g) v[g] = p[g];
+#pragma unroll
+    for (int g = 0; g < G4; ++g) {                    // (group order: same sums as the generic loop)
+      s += v[g].x; q += v[g].y;
+      s += v[g].z; q += v[g].w;
+    }
+  } else {
+    const float2* p = (const float2*)(part + (size_t)m * groups * 2);
+    for (int g = 0; g < groups; ++g) {
+      const float2 v = p[g];
+      s += v.x;
+      q += v.y;
+    }
   }
   const float mu = s * invC;
   const float var = fmaxf(q * invC - mu * mu, 0.f);
@@ -445,8 +458,11 @@ extern "C" int msclip_layernorm_stats(const float* x, int ldx, const float* gamm
 extern "C" int msclip_rowstat_finalize(const float* part, int groups, float* center, float* rowstat, int M, int C, float eps,
                                        void* stream) {
   if (!part || !center || !rowstat || M <= 0 || groups <= 0 || C != groups * 64) return MSCLIP_EINVAL;
-  hipLaunchKernelGGL(rowstat_finalize_kernel, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, groups, center,
-                     rowstat, M, 1.f / (float)C, eps);
+  const dim3 grid((M + 255) / 256), blk(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (groups == 12) hipLaunchKernelGGL(rowstat_finalize_kernel<6>, grid, blk, 0, st, part, groups, center, rowstat, M, 1.f / (float)C, eps);
+  else if (groups == 16) hipLaunchKernelGGL(rowstat_finalize_kernel<8>, grid, blk, 0, st, part, groups, center, rowstat, M, 1.f / (float)C, eps);
+  else hipLaunchKernelGGL(rowstat_finalize_kernel<0>, grid, blk, 0, st, part, groups, center, rowstat, M, 1.f / (float)C, eps);
   return msclip_launch_status();
 }
 

@@ -217,6 +217,7 @@ class Engine:
 
         # --- transformer blocks (shared tensors packed once)
         cache = {}
+        self._foldw = {}                             # gamma-folded projection weights of the LayerNorm fold, built on first use
 
         def blockw(blk):
             key = (blk.attn.in_proj_weight.data_ptr(), blk.attn.out_proj.weight.data_ptr(),
@@ -283,6 +284,10 @@ class Engine:
         w = dict(Mv=Mv, Mt=Mt, M=M)
         w["X"] = buf(M, D, dtype=f32)
         w["LNO"], w["QKV"], w["AO"], w["HID"] = buf(M, D), buf(M, 3 * D), buf(M, D), buf(M, 4 * D)
+        # LayerNorm fold (_blocks_fold): per-row centre (the row's mean at the previous LayerNorm point), (rstd, mean * rstd) for
+        # the consuming projection, the producing GEMM's per-64-column partial sums; which row segments hold produced operands
+        w["CEN"], w["RST"], w["PART"] = buf(M, dtype=f32), buf(M, 2, dtype=f32), buf(M, D // 64, 2, dtype=f32)
+        w["fold_pending"] = {"v": False, "t": False}
         if self.fp8:                                         # e4m3 LayerNorm output + its per-token scales; e4m3 MLP hidden
             w["LNQ"] = torch.zeros(M * D + 256, dtype=torch.uint8, device=dev)[:M * D].view(M, D)
             w["RS"] = torch.empty(M, dtype=f32, device=dev)
@@ -543,7 +548,138 @@ class Engine:
             for r0, r1, b in segs:
                 hip.layernorm_f8(X[r0:r1], b[which].g, b[which].b, b[which].g, b[which].b, r1 - r0, w["LNQ"][r0:r1], w["RS"][r0:r1], r1 - r0)
 
+    # ------------------------------------------------------------------ LayerNorm fold
+    def _fold_eligible(self, w, Bi, Bt):
+        """The fold runs on whole 256-row tiles of the ping-pong GEMM that never straddle the image / text boundary."""
+        if self.fp8 or os.environ.get("MSCLIP_LN_FOLD", "1") == "0" or self.D % 256:
+            return False
+        rows = [n for n in ((w["Mv"] if Bi else 0), (w["M"] - w["Mv"] if Bt else 0)) if n]
+        return bool(rows) and all(n % 256 == 0 and n >= 256 * 16 for n in rows)
+
+    def _fold_weights(self, i, tower, which):
+        """(W', csum, bias') of layer i's in_proj ("qkv") / c_fc ("fc") behind tower's ln_1 / ln_2 (M.py:1027-1028, 204-219):
+        LN(x) W^T + b = rstd (x - mean) (gamma o W)^T + (b + W beta): W' = bf16(gamma o W) from the packed bf16 weight (the q rows
+        carry their 64^-0.5), csum = row sums of the bf16 values (what the MFMA contracts), bias' in fp32."""
+        key = (i, tower, which)
+        if key not in self._foldw:
+            blk = (self.vblk if tower == "v" else self.tblk)[i]
+            bw, ln = blk["w"], blk["ln1" if which == "qkv" else "ln2"]
+            W, b = (bw.wqkv, bw.bqkv) if which == "qkv" else (bw.wfc, bw.bfc)
+            Wf = (W.float() * ln.g[None, :]).to(torch.bfloat16).contiguous()
+            self._foldw[key] = (Wf, Wf.float().sum(dim=1).contiguous(), (b + W.float() @ ln.b).contiguous())
+        return self._foldw[key]
+
+    def _fold_proj(self, w, i, which, r0, r1, modes, out, act):
+        """One projection over rows [r0, r1) behind a LayerNorm.  modes = [(tower, row0, row1, folded)]: a folded segment's rows
+        of LNO hold bf16 (x - centre) and take the gamma-folded weight; a plain segment's rows hold a LayerNorm output (RST rows
+        (1, 0)) and take the packed weight as it is."""
+        def seg_weights(tower, folded):
+            if folded:
+                return self._fold_weights(i, tower, which)
+            bw = (self.vblk if tower == "v" else self.tblk)[i]["w"]
+            W, b = (bw.wqkv, bw.bqkv) if which == "qkv" else (bw.wfc, bw.bfc)
+            if "zcs" not in self._foldw:
+                self._foldw["zcs"] = torch.zeros(4 * self.D, dtype=torch.float32, device=self.dev)
+            return W, self._foldw["zcs"], b
+        LNO, RST = w["LNO"], w["RST"]
+        if not any(m[3] for m in modes):
+            W, _, b = seg_weights(modes[0][0], False)
+            return hip.gemm(LNO[r0:r1], W, out[r0:r1], bias=b, act=act)
+        W1, c1, b1 = seg_weights(modes[0][0], modes[0][3])
+        if len(modes) == 1:
+            fi = hip.FoldIn(RST[r0:r1], c1)
+        else:
+            W2, c2, b2 = seg_weights(modes[1][0], modes[1][3])
+            fi = hip.FoldIn(RST[r0:r1], c1, W2, b2, c2, modes[1][1] - r0)
+        return hip.gemm(LNO[r0:r1], W1, out[r0:r1], bias=b1, act=act, fold_in=fi)
+
+    def _blocks_fold(self, w, Bi, Bt, taps, conv_events, compact, layers):
+        """The layer loop with the LayerNorms folded into the GEMMs around them (DESIGN.md "LayerNorm fold"): out_proj and c_proj
+        write, beside the fp32 residual update, the bf16 operand of the projection that follows -- (x - centre[m]), the centre being
+        the row's mean one LayerNorm earlier -- and per-row partial sums; a one-thread-per-row kernel turns those into (rstd, mean
+        rstd); in_proj / c_fc apply them (and gamma / beta through their weights) to their accumulators.  The separate LayerNorm
+        passes over the token matrix (a 200 MB read + 100 MB write each) remain only where the rows come from somewhere else:
+        behind the stem / the embedding, behind a lateral adapter, and in the last block's live-row tail."""
+        Mv, M, D = w["Mv"], w["M"], self.D
+        X, LNO, QKV, AO, HID, CEN, RST, PART = (w[k] for k in ("X", "LNO", "QKV", "AO", "HID", "CEN", "RST", "PART"))
+        pend = w["fold_pending"]
+        n_last = self.n_layers - 1
+        for i in (range(self.n_layers) if layers is None else layers):
+            vb = self.vblk[i] if Bi else None
+            tb = self.tblk[i] if Bt else None
+            if vb is None and tb is None:
+                continue
+            segs = ([("v", 0, Mv, vb)] if vb is not None else []) + ([("t", Mv, M, tb)] if tb is not None else [])
+            last_live = i == n_last and compact
+            # --- ln_1: folded where the previous c_proj produced these rows' operands, a LayerNorm pass elsewhere
+            modes = []
+            for tower, r0, r1, b in segs:
+                src, raw = X[r0:r1], None
+                if tower == "v" and i in self.lateral:
+                    j = self.lateral.index(i)
+                    if conv_events is not None:
+                        torch.cuda.current_stream(self.dev).wait_event(conv_events[j])
+                        self._adapter(j, w, Bi, t=w["Ts"][j])
+                    else:
+                        self._parallel_stage(j, w, Bi)
+                        self._adapter(j, w, Bi)
+                    if taps is not None:
+                        if j:
+                            c3 = self.par_specs[j][3]
+                            self._tap_nhwc(taps, f"parallel{j}", w["par"][j], Bi, c3.h_out, c3.cout)
+                        self._tap_tokens(taps, f"adapter{j}", w["XA"], Bi, self.Lv)
+                    src, raw = w["XA"], X[:Mv]              # ln_1 reads the adapter output and moves it back into X
+                    pend[tower] = False
+                if pend[tower]:
+                    modes.append((tower, r0, r1, True))
+                else:
+                    hip.layernorm_stats(src, b["ln1"].g, b["ln1"].b, LNO[r0:r1], r1 - r0, CEN[r0:r1], RST[r0:r1], raw_out=raw)
+                    modes.append((tower, r0, r1, False))
+                pend[tower] = False
+            shared = len(segs) == 2 and vb["w"] is tb["w"]
+            groups = [(segs[0][1], segs[-1][2], modes)] if shared else [(m[1], m[2], [m]) for m in modes]
+            if last_live and not hip.env_flag("MSCLIP_LAST_BLOCK_ALL_QUERIES"):
+                assert not any(m[3] for m in modes)       # (the block before the last one does not produce: see below)
+                cg = [(r0, r1, (self.vblk if ms[0][0] == "v" else self.tblk)[i]["w"]) for r0, r1, ms in groups]
+                self._last_block_attention(w, Bi, Bt, cg)
+                self._last_block_tail(w, Bi, Bt, vb, tb, attended=True)
+                continue
+            for r0, r1, ms in groups:
+                self._fold_proj(w, i, "qkv", r0, r1, ms, QKV, hip.ACT_NONE)
+            if vb is not None:
+                hip.attention(QKV[:Mv], AO[:Mv], Bi, self.Lv, self.heads, False)
+            if tb is not None:
+                hip.attention(QKV[Mv:M], AO[Mv:M], Bt, self.Lt, self.heads, True)
+            if last_live:
+                self._last_block_tail(w, Bi, Bt, vb, tb)
+                continue
+            # --- out_proj produces ln_2's operands; c_fc consumes them; c_proj produces the next block's ln_1 operands unless
+            #     that block takes a LayerNorm pass anyway (the compact last block; image rows in front of a lateral adapter
+            #     are produced too -- one launch over both towers -- and overwritten by the adapter's pass)
+            nxt_fold = i + 1 <= n_last and not (i + 1 == n_last and compact and not hip.env_flag("MSCLIP_LAST_BLOCK_ALL_QUERIES"))
+            for r0, r1, ms in groups:
+                bw = (self.vblk if ms[0][0] == "v" else self.tblk)[i]["w"]
+                hip.gemm(AO[r0:r1], bw.wo, X[r0:r1], bias=bw.bo, resid=X[r0:r1], resid_kind=hip.RESID_F32,
+                         fold_out=hip.FoldOut(LNO[r0:r1], CEN[r0:r1], PART[r0:r1]))
+                hip.rowstat_finalize(PART[r0:r1], CEN[r0:r1], RST[r0:r1], r1 - r0, D)
+                self._fold_proj(w, i, "fc", r0, r1, [(m[0], m[1], m[2], True) for m in ms], HID, hip.ACT_QUICKGELU)
+                if nxt_fold:
+                    hip.gemm(HID[r0:r1], bw.wpr, X[r0:r1], bias=bw.bpr, resid=X[r0:r1], resid_kind=hip.RESID_F32,
+                             fold_out=hip.FoldOut(LNO[r0:r1], CEN[r0:r1], PART[r0:r1]))
+                    hip.rowstat_finalize(PART[r0:r1], CEN[r0:r1], RST[r0:r1], r1 - r0, D)
+                    for m in ms:
+                        pend[m[0]] = True
+                else:
+                    hip.gemm(HID[r0:r1], bw.wpr, X[r0:r1], bias=bw.bpr, resid=X[r0:r1], resid_kind=hip.RESID_F32)
+            if taps is not None:
+                if vb is not None:
+                    self._tap_tokens(taps, f"vblock{i}", X[:Mv], Bi, self.Lv)
+                if tb is not None:
+                    self._tap_tokens(taps, f"tblock{i}", X[Mv:M], Bt, self.Lt)
+
     def _blocks(self, w, Bi, Bt, taps=None, conv_events=None, compact=False, layers=None):
+        if self._fold_eligible(w, Bi, Bt):
+            return self._blocks_fold(w, Bi, Bt, taps, conv_events, compact, layers)
         Mv, M = w["Mv"], w["M"]
         X, LNO, QKV, AO, HID = w["X"], w["LNO"], w["QKV"], w["AO"], w["HID"]
         for i in (range(self.n_layers) if layers is None else layers):
@@ -692,6 +828,7 @@ class Engine:
             Bi = img.shape[0] if img is not None else 0
             Bt = tok.shape[0] if tok is not None else 0
             w = self._workspace(Bi, Bt, inference=True)
+            w["fold_pending"] = {"v": False, "t": False}
             conv_events = None
             side_ok = (taps is None and os.environ.get("MSCLIP_CONV_SIDE_STREAM", "1") != "0"
                        and not torch.cuda.is_current_stream_capturing())

@@ -267,12 +267,17 @@ class TrainStep:
 
     # ------------------------------------------------------------------ backward
     @hip.off_default_stream
-    def backward(self, reduce=True, bucket_bytes=64 << 20):
+    def backward(self, reduce=True, bucket_bytes=64 << 20, clone=False):
         """-> {reference state_dict key: fp32 gradient} for every parameter of the slice (shared tensors under their
         visual.* key; the text-tower aliases are the same Parameter objects).  Under N > 1 ranks (and reduce=True) the
         gradients are averaged over the ranks as the reference's DDP wrapper would: every gradient goes into a
         comm.GradReducer bucket the moment it exists, and the buckets' RCCL all-reduces run on the side stream under
-        the rest of the backward (last block's bucket first)."""
+        the rest of the backward (last block's bucket first).
+        LIFETIME: at world size > 1 the returned tensors are views into the per-device gradient-bucket arena, which the NEXT
+        backward() on this device overwrites (in-place 1 / world scaling and split-K writes included): call step() before the
+        next backward, or pass clone=True to own the tensors (gradient accumulation over micro-batches, comparing two backward
+        passes, two TrainSteps on one device).  step() refuses stale views (comm.GradViews.check_fresh).  At world size 1 the
+        gradients are fresh tensors either way."""
         e, sv = self.eng, getattr(self, "saved", None)
         if sv is None:
             raise RuntimeError("TrainStep.backward() needs the activations of a TrainStep.forward() that has not been "
@@ -463,7 +468,7 @@ class TrainStep:
             gradgemm.join(dev)                                   # the gradients queued on the lane stream
             sv["w"].pop("held", None)
             self.saved = None
-            return reducer.finish() if reducer is not None else dict(grads)
+            return reducer.finish(clone=clone) if reducer is not None else dict(grads)
 
     # ------------------------------------------------------------------ optimizer
     def param_groups(self):
@@ -537,12 +542,12 @@ class TrainStep:
         backward(reduce=False))."""
         if self.lr is None:
             raise ValueError("TrainStep.step() needs a learning rate: TrainStep(model, lr=...) or train.from_config(model, config)")
+        if hasattr(grads, "check_fresh"):
+            grads.check_fresh()
         self.steps += 1
         with torch.no_grad():
-            if world_average and C.comm.world_size > 1:
-                for g in grads.values():
-                    dist.all_reduce(g)
-                    g /= C.comm.world_size
+            if world_average:
+                world_average_(grads)
             plan = self._adamw_plan(grads)
             plan.run(self.betas[0], self.betas[1], self.eps, self.steps)
             plan.hold = None
@@ -550,6 +555,21 @@ class TrainStep:
             self.eng.repack_after_optimizer()
         else:
             self.eng.refresh(force=True)
+
+
+def world_average_(grads):
+    """In-place rank mean of a gradient dict produced with backward(reduce=False) (what step(world_average=True) runs): one
+    all-reduce per tensor.  Non-contiguous entries (the conv side's depthwise weight gradients are transposed views,
+    train_conv.py) are replaced by dense copies first: NCCL / gloo reject strided tensors."""
+    if C.comm.world_size <= 1:
+        return grads
+    for k in list(grads):
+        g = grads[k]
+        if not g.is_contiguous():
+            g = grads[k] = g.contiguous()
+        dist.all_reduce(g)
+        g /= C.comm.world_size
+    return grads
 
 
 def param_groups(model, lr, lr_share, wd, wd_share, without_wd=("bn", "bias", "ln")):

@@ -78,6 +78,38 @@ def _worker(rank, world, port, q):
         ok2 = ok2 and torch.allclose(avg2[f"p{i}"], sum(both) / world, atol=1e-6)
     res["second_ok"] = bool(ok2)
     res["reducer_ok"], res["reducer_launched"] = bool(ok), red.launched
+    # lifetime of finish()'s views: `avg` belongs to a generation the second reducer has overwritten; clone=True owns
+    stale = False
+    try:
+        avg.check_fresh()
+    except RuntimeError:
+        stale = True
+    avg2.check_fresh()
+    red3 = C.GradReducer(bucket_bytes=64 * 4)
+    for i, sh in enumerate(shapes):
+        red3.add(f"p{i}", mine[f"p{i}"].clone())
+    own = red3.finish(clone=True)
+    arena_ptrs = [(b.data_ptr(), b.data_ptr() + b.numel() * 4) for b in C._ARENA[(torch.device("cpu"), 64)] if b is not None]
+    owned = all(not any(lo <= t.data_ptr() < hi for lo, hi in arena_ptrs) for t in own.values() if t.numel())
+    own.check_fresh()
+    res["lifetime_ok"] = bool(stale and owned)
+    # the reserve() contract: the reserved slot's add() must come next
+    red4 = C.GradReducer(bucket_bytes=64 * 4)
+    red4.reserve("a", (4,), torch.device("cpu"))
+    guarded = 0
+    for bad in (lambda: red4.add("b", torch.zeros(3)), lambda: red4.reserve("c", (2,), torch.device("cpu"))):
+        try:
+            bad()
+        except RuntimeError:
+            guarded += 1
+    res["reserve_guarded"] = guarded == 2
+    # step(world_average=True)'s rank mean with a strided gradient (the conv side's depthwise gradients are transposed views)
+    from msclip_amd import train
+    base = torch.arange(12, dtype=torch.float32).reshape(3, 4) * (rank + 1)
+    gd = {"dw": base.t(), "dense": torch.full((5,), float(rank))}
+    train.world_average_(gd)
+    res["world_average_ok"] = bool(gd["dw"].is_contiguous() and torch.equal(gd["dw"], (torch.arange(12, dtype=torch.float32).reshape(3, 4) * 1.5).t())
+                                   and torch.equal(gd["dense"], torch.full((5,), 0.5)))
     if rank == 0:
         q.put(res)
     dist.barrier()
@@ -96,6 +128,7 @@ def test_two_rank_gather_and_sharded_loss():
     assert res["rank"] == 0 and res["world"] == 2 and res["off"] == 0 and res["packed_ok"] and res["async_ok"]
     assert res["reducer_ok"], res["reducer_launched"]
     assert res["arena_reused"] and res["second_ok"]
+    assert res["lifetime_ok"] and res["reserve_guarded"] and res["world_average_ok"]
     assert abs(res["loss_sharded"] - res["loss_full"]) < 1e-5
 
 

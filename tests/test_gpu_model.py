@@ -671,3 +671,57 @@ def test_fp8_projections_against_the_bf16_path(gpu_device, name, precision):
     assert ci >= fi and ct >= ft
     assert ci_b >= fib and cb >= ftb                             # ... with the e4m3 hidden matrix and fp8 c_proj on top
     assert abs(f8.contrastive_loss(img, tok).item() - bf.contrastive_loss(img, tok).item()) <= 0.1
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 4: the LayerNorm fold (engine._blocks_fold)
+# ---------------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("name,B", [("b32-yfcc-msclips", 256), ("b16-yfcc-msclips", 256)])
+def test_layernorm_fold_against_the_unfused_layer_loop(gpu_device, monkeypatch, name, B):
+    """The layer loop with the LayerNorms folded into the GEMMs around them (out_proj / c_proj write the next projection's
+    bf16 operand (x - centre) + row partials, in_proj / c_fc apply rstd / mean / gamma / beta on their accumulators) against the
+    same engine with MSCLIP_LN_FOLD=0 (a LayerNorm pass per ln_1 / ln_2, M.py:1027-1028): every per-block tap of both towers,
+    the features, image-only and text-only calls.  Both paths round the same quantities to bf16 at different points, so they
+    agree to bf16-operand noise; each is separately pinned to the oracle at these sizes (test_full_bench_batch_properties,
+    test_full_batch_b16_against_oracle, test_c4_per_rank_batch_1024_against_oracle run the fold)."""
+    from msclip_amd import hip
+    m = model_for(name)
+    img = synth.synth_images(B, seed=51).cuda()
+    tok = synth.synth_tokens(B, seed=52).cuda()
+    eng = m.engine()
+    calls = []
+    real = hip.rowstat_finalize
+    monkeypatch.setattr(hip, "rowstat_finalize", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    monkeypatch.setenv("MSCLIP_LN_FOLD", "0")
+    t0 = {}
+    w = eng.run(img, tok, taps=t0)
+    f0i, f0t = w["fv"].clone(), w["ft"].clone()
+    assert not calls
+    monkeypatch.setenv("MSCLIP_LN_FOLD", "1")
+    t1 = {}
+    w = eng.run(img, tok, taps=t1)
+    f1i, f1t = w["fv"].clone(), w["ft"].clone()
+    assert len(calls) >= 2 * (eng.n_layers - 2)                     # the fold ran: one finalize per folded LayerNorm
+    blocks = [k for k in t0 if k.startswith("vblock") or k.startswith("tblock") or k.startswith("adapter")]
+    assert len(blocks) >= 2 * (eng.n_layers - 1)
+    worst = 0.0
+    for k in blocks:
+        a, b = t0[k], t1[k]
+        err = (a - b).abs().max().item() / max(a.abs().max().item(), 1e-3)
+        worst = max(worst, err)
+        assert err <= 1.5e-2, (k, err)
+        assert torch.nn.functional.cosine_similarity(a.flatten(1), b.flatten(1), dim=-1).min().item() >= 0.9999, k
+    for a, b in ((f0i, f1i), (f0t, f1t)):
+        assert (a - b).abs().max().item() <= 2e-3
+        assert torch.nn.functional.cosine_similarity(a, b, dim=-1).min().item() >= 0.99995
+    # the shipped schedule (no taps: live-row tail of the last block, side streams), then single-tower calls
+    calls.clear()
+    w = eng.run(img, tok)
+    assert calls and (w["fv"] - f0i).abs().max().item() <= 2e-3 and (w["ft"] - f0t).abs().max().item() <= 2e-3
+    assert (m.encode_image(img) - f0i).abs().max().item() <= 2e-3
+    assert (m.encode_text(tok) - f0t).abs().max().item() <= 2e-3
+    for _ in range(2):                                               # repeatable bit for bit (buffer reuse across steps)
+        w2 = eng.run(img, tok)
+        assert torch.equal(w2["fv"], w["fv"]) and torch.equal(w2["ft"], w["ft"])
+    print(f"{name}: fold vs unfused, worst tap deviation {worst:.2e} of abs-max")
