@@ -22,12 +22,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 GFLOP_PER_PAIR = {"b32-yfcc-msclips": 23.549, "b16-yfcc-msclips": 49.617,    # SURVEY.md s8(d), counted on the reference
-                  "l16-fp8-msclips": 172.436}   # torch.utils.flop_counter on the reference built from experiments/model/l16-fp8-msclips.yaml (image 125.345 + text 47.091)
-WIDTH = {"b32-yfcc-msclips": 768, "b16-yfcc-msclips": 768, "l16-fp8-msclips": 1024}
+                  "l16-fp8-msclips": 172.436,   # torch.utils.flop_counter on the reference built from experiments/model/l16-fp8-msclips.yaml (image 125.345 + text 47.091)
+                  "l14-fp8-msclips": 209.116}   # the same for experiments/model/l14-fp8-msclips.yaml, tools/make_golden.py --l14 (image 162.026 + text 47.091)
+WIDTH = {"b32-yfcc-msclips": 768, "b16-yfcc-msclips": 768, "l16-fp8-msclips": 1024, "l14-fp8-msclips": 1024}
 # The reference computes out_proj / c_fc / c_proj of the LAST block on every token although only x[:, 0] (M.py:2685) and the
 # EOT row (M.py:3057-3060) are read afterwards; the engine runs them on those rows only (engine._last_block_tail).  FLOPs it
 # does not execute are not credited: 18 d^2 per skipped row (2 d^2 out_proj + 8 d^2 c_fc + 8 d^2 c_proj), d = 768.
-SKIPPED_ROWS_PER_PAIR = {"b32-yfcc-msclips": 50 + 77 - 2, "b16-yfcc-msclips": 197 + 77 - 2, "l16-fp8-msclips": 197 + 77 - 2}
+SKIPPED_ROWS_PER_PAIR = {"b32-yfcc-msclips": 50 + 77 - 2, "b16-yfcc-msclips": 197 + 77 - 2, "l16-fp8-msclips": 197 + 77 - 2,
+                         "l14-fp8-msclips": 257 + 77 - 2}
 PEAK_FP8_TFLOPS = 5000.0                                                       # MI355X_MICROARCH.md: dense fp8 (MX K = 128) MFMA
 PEAK_BF16_TFLOPS = 2500.0                                                      # MI355X_MICROARCH.md: dense bf16 MFMA
 DOMINANT = {"variant": "pp", "kernel": "gemm_pp_kernel<0, false",              # what hip.gemm_variant calls it / rocprof's name (prefix: <0, false, 0 | 1 | 2> = standard / LayerNorm-fold consumer / producer epilogues of one main loop)
@@ -142,7 +144,8 @@ def cpu_baseline(name, sd, batch=32, iters=3):
     from oracle import msclip_oracle as O
     cores = min(os.cpu_count() or 1, 32)     # more intra-op threads than this only adds barrier overhead on these op sizes
     torch.set_num_threads(cores)
-    arch = O.arch_b32() if name.startswith("b32") else O.arch_l16() if name.startswith("l16") else O.arch_b16()
+    arch = (O.arch_b32() if name.startswith("b32") else O.arch_l16() if name.startswith("l16") else
+            O.arch_l14() if name.startswith("l14") else O.arch_b16())
     img, tok = synth.synth_images(batch, seed=3), synth.synth_tokens(batch, seed=4)
     with torch.no_grad():
         O.contrastive_loss(O.forward(img[:2], tok[:2], sd, arch))            # warm-up
@@ -297,7 +300,9 @@ def main():
         fmul = 3 if ts is not None else 1          # backward counted as 2x forward
         rec = {
             "metric": {"b32": "image-text pairs/sec ViT-B/32 bf16", "b16": "image-text pairs/sec ViT-B/16 bf16",
-                       "l16": "image-text pairs/sec ViT-L/16-width stand-in of config C5 (L/14 is inexpressible), "
+                       "l16": "image-text pairs/sec ViT-L/16-width model with the MS-CLIP-S conv stem / adapters (second C5 model), "
+                              + ("bf16" if model.precision == "bf16" else "fp8 + bf16"),
+                       "l14": "image-text pairs/sec MS-CLIP ViT-L/14 (patch-conv stem, 257 tokens; BASELINE config C5), "
                               + ("bf16" if model.precision == "bf16" else "fp8 + bf16")}[args.model[:3]],
             "mfma_util_pct": None,
             "value": round(pairs_s, 1), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -108,7 +108,7 @@ int msclip_quant_f8_rows(const void* x, int ldx, void* q, int ldq, float* row_sc
  * that measurement code (bench.py's roofline leg) counts exactly the launches of one kernel.  No GPU work. */
 const char* msclip_gemm_variant(const msclip_gemm_desc* desc);
 
-/* Fused softmax(q k^T [+ causal]) v per (sample, head), head_dim 64, L <= 224; q pre-scaled.
+/* Fused softmax(q k^T [+ causal]) v per (sample, head), head_dim 64, L <= 288 (257 = the 16 x 16 grid of a 14-pixel patch); q pre-scaled.
  * qkv: bf16 [nsamples*L, ldq] with columns [q | k | v], each heads*64 wide.  out: bf16
  * [nsamples*L, ldo], ldq % 8 == 0 and ldo % 8 == 0 (16-byte row pieces).  Replaces M.py:707-738 (scale, reshapes, bmm, mask add, softmax, bmm). */
 int msclip_attention(const void* qkv, void* out, int nsamples, int L, int heads, int ldq, int ldo, int causal,
@@ -176,6 +176,12 @@ int msclip_stem_conv3x3s2_dual(const void* img, int img_is_bf16, const float* w,
 int msclip_stem_dual_conv3x3s2(const void* img, int img_is_bf16, const float* w, const float* bias, void* out_b,
                                const void* w2, const float* b2, void* out2, int B, int H, int W, int Cout,
                                void* stream);
+
+/* Patch matrix of a kernel == stride == P convolution over an NCHW image [B, 3, H, W] (fp32 or bf16), the plain patch conv
+ * of M.py:2502-2508 / 2657 as a dense GEMM operand: out[b*g*g + py*g + px][c*P*P + kh*P + kw] (bf16, row stride kpad, columns
+ * [3*P*P, kpad) zero; kpad % 64 == 0).  The convolution itself is msclip_gemm over this matrix with the token scatter /
+ * positional-table epilogue (rpg = g*g, radd = roff = 1). */
+int msclip_patchify(const void* img, int img_is_bf16, void* out, int kpad, int B, int H, int W, int P, void* stream);
 
 /* relu(conv3x3/s2/p1(relu(conv1x1(x)))) with folded BatchNorms (ConvResBlock conv1-bn1-relu-conv2-bn2-relu,
  * M.py:1825-1840) without materialising the 1x1's output.  x NHWC bf16 [B, H, W, 48]; w1 bf16 [48][64] (K padded),

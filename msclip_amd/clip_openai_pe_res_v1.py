@@ -202,20 +202,30 @@ class Transformer(nn.Module):
 
 
 class VisualTransformer(nn.Module):
-    """M.py:2476-2543."""
+    """M.py:2476-2543.  Two stems: the MS-CLIP-S conv stem inside the Transformer's slot 0 (EARLY_CONV +
+    EARLY_CONV_NEW_IMPLEMENT, the released configs) or the plain patch convolution `conv1` (EARLY_CONV off, M.py:2502-2508:
+    the reference's only way to a 16 x 16 grid, BASELINE config C5's ViT-L/14)."""
 
     def __init__(self, input_resolution, patch_size, width, layers, heads, output_dim, custom):
         super().__init__()
-        if not (_get(custom, "EARLY_CONV", False) and _get(custom, "EARLY_CONV_NEW_IMPLEMENT", False)):
-            raise NotImplementedError("only the EARLY_CONV + EARLY_CONV_NEW_IMPLEMENT stem (MS-CLIP-S) is built; "
-                                      "the plain patch-conv ViT of b32.yaml is outside the hot path")
+        self.early_conv = bool(_get(custom, "EARLY_CONV", False))
+        if self.early_conv and not _get(custom, "EARLY_CONV_NEW_IMPLEMENT", False):
+            raise NotImplementedError("EARLY_CONV without EARLY_CONV_NEW_IMPLEMENT (the 5-conv patch stack of M.py:2555-2618) is "
+                                      "built by no released config")
+        if not self.early_conv:
+            if _get(custom, "PARALLEL_IN_V", False):
+                raise NotImplementedError("PARALLEL_IN_V without the conv stem: the lateral adapters pool stride-2 maps onto the "
+                                          "token grid, which a patch-conv grid does not match (DESIGN.md s9)")
+            if input_resolution % patch_size:
+                raise NotImplementedError("image size must be a multiple of the patch size")
+            self.conv1 = nn.Conv2d(3, width, patch_size, patch_size, bias=False)              # M.py:2502-2508
         self.input_resolution, self.patch_size, self.output_dim = input_resolution, patch_size, output_dim
         self.sequence_length = (input_resolution // patch_size) ** 2 + 1
         scale = width ** -0.5
         self.class_embedding = nn.Parameter(scale * torch.randn(width))
         self.positional_embedding = nn.Parameter(scale * torch.randn(self.sequence_length, width))
         self.ln_pre = _ln(width)
-        self.transformer = Transformer(width, layers, heads, custom, "visual", first_conv=True)
+        self.transformer = Transformer(width, layers, heads, custom, "visual", first_conv=self.early_conv)
         self.ln_post = _ln(width)
         self.proj = nn.Parameter(scale * torch.randn(width, output_dim))
 

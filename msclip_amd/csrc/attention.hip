@@ -629,12 +629,13 @@ extern "C" int msclip_attention(const void* qkv, void* out, int nsamples, int L,
     if (old && old[0] == '1') return launch<7>(qkv, out, nsamples, L, heads, ldq, ldo, causal, st);
     return launch_wg<7>(qkv, out, nsamples, L, heads, ldq, ldo, causal, st);
   }
+  if (L <= 288) return launch_wg<9>(qkv, out, nsamples, L, heads, ldq, ldo, causal, st);    // 257 tokens: the 16 x 16 grid of ViT-L/14
   return MSCLIP_EINVAL;
 }
 
 extern "C" int msclip_attention_lastq(const void* q, int ldqc, const void* qkv, int ldq, void* out, int ldo, int nsamples, int L,
                                       int heads, const int* last_row, int row_base, void* stream) {
-  if (!q || !qkv || !out || nsamples <= 0 || L <= 0 || L > 256 || heads <= 0 || (ldqc % 8) || (ldq % 8) || (ldo % 8) || ldo < heads * 64 || row_base < 0)
+  if (!q || !qkv || !out || nsamples <= 0 || L <= 0 || L > 288 || heads <= 0 || (ldqc % 8) || (ldq % 8) || (ldo % 8) || ldo < heads * 64 || row_base < 0)
     return MSCLIP_EINVAL;
   const int grid = (nsamples * heads + 3) / 4;
   hipStream_t st = (hipStream_t)stream;
@@ -644,7 +645,8 @@ extern "C" int msclip_attention_lastq(const void* q, int ldqc, const void* qkv, 
   if (L <= 64) LASTQ(8);
   else if (L <= 80) LASTQ(10);
   else if (L <= 128) LASTQ(16);
-  else LASTQ(32);
+  else if (L <= 256) LASTQ(32);
+  else LASTQ(36);
 #undef LASTQ
   return msclip_launch_status();
 }

@@ -308,6 +308,38 @@ __global__ __launch_bounds__(256) void dwpool_rows_kernel(const bf16_t* __restri
   }
 }
 
+
+// Patch matrix of a kernel == stride == P convolution over an NCHW image (the plain patch conv of M.py:2502-2508, 2657:
+// BASELINE config C5's ViT-L/14): out[b*g*g + py*g + px][c*P*P + kh*P + kw] = bf16(img[b][c][py*P + kh][px*P + kw]), columns
+// [3*P*P, kpad) zero.  One workgroup per (image, patch row): it reads the 3*P image rows of that patch row whole (W contiguous
+// pixels each: coalesced), lays the g output rows out in LDS and writes them as one contiguous run of g * kpad bf16 (the g patches
+// of a patch row are consecutive rows of the matrix).  HBM-bound: image once in, matrix once out.
+template <typename T>
+__global__ __launch_bounds__(256) void patchify_kernel(const T* __restrict__ img, bf16_t* __restrict__ out, int kpad, int H, int W,
+                                                       int P, int g) {
+  extern __shared__ bf16_t tile[];                 // [g][kpad]
+  const int b = blockIdx.x / g, py = blockIdx.x - b * g;
+  const int kp = 3 * P * P;
+  for (int i = threadIdx.x; i < g * (kpad - kp); i += 256) {
+    const int r = i / (kpad - kp);
+    tile[r * kpad + kp + (i - r * (kpad - kp))] = 0;
+  }
+  for (int cr = 0; cr < 3 * P; ++cr) {             // (channel, row inside the patch)
+    const int c = cr / P, kh = cr - c * P;
+    const T* src = img + (((size_t)b * 3 + c) * H + py * P + kh) * W;
+    for (int x = threadIdx.x; x < g * P; x += 256) {
+      const int px = x / P, kw = x - px * P;
+      float v;
+      if constexpr (sizeof(T) == 2) v = bf16_to_f32(src[x]);
+      else v = src[x];
+      tile[px * kpad + c * P * P + kh * P + kw] = f32_to_bf16(v);
+    }
+  }
+  __syncthreads();
+  const uint4* t4 = (const uint4*)tile;
+  uint4* o4 = (uint4*)(out + ((size_t)b * g * g + (size_t)py * g) * kpad);
+  for (int i = threadIdx.x; i < g * kpad / 8; i += 256) o4[i] = t4[i];
+}
 }  // namespace
 
 extern "C" int msclip_stem_conv3x3s2_dual(const void* img, int img_is_bf16, const float* w, const float* bias,
@@ -368,5 +400,18 @@ extern "C" int msclip_dwpool(const void* top, const float* w, void* out, int ldo
   const long long total = (long long)B * g * g * (C / 8);
   hipLaunchKernelGGL(dwpool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)top, w, (bf16_t*)out, ldo, B, H, W, C, k, g);
+  return msclip_launch_status();
+}
+
+extern "C" int msclip_patchify(const void* img, int img_is_bf16, void* out, int kpad, int B, int H, int W, int P, void* stream) {
+  if (!img || !out || B <= 0 || P <= 0 || H != W || (H % P) || kpad < 3 * P * P || (kpad % 64)) return MSCLIP_EINVAL;
+  const int g = H / P;
+  const size_t lds = (size_t)g * kpad * sizeof(bf16_t);
+  if (lds > 65536) return MSCLIP_EINVAL;
+  const dim3 grid((unsigned)(B * g)), blk(256);
+  if (img_is_bf16)
+    hipLaunchKernelGGL(patchify_kernel<bf16_t>, grid, blk, lds, (hipStream_t)stream, (const bf16_t*)img, (bf16_t*)out, kpad, H, W, P, g);
+  else
+    hipLaunchKernelGGL(patchify_kernel<float>, grid, blk, lds, (hipStream_t)stream, (const float*)img, (bf16_t*)out, kpad, H, W, P, g);
   return msclip_launch_status();
 }

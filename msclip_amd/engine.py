@@ -178,6 +178,53 @@ class Engine:
         self._ls_event = torch.cuda.Event()
         self._ls_event.record(torch.cuda.current_stream(dev))
 
+        self.patch = hasattr(v, "conv1")               # plain patch-conv stem (EARLY_CONV off, M.py:2502-2508): BASELINE config C5's ViT-L/14
+        self.cls = sd["visual.class_embedding"].float().contiguous()
+        self.vpos = sd["visual.positional_embedding"].float().contiguous()
+        self.ln_pre, self.ln_post = _LN(v.ln_pre), _LN(v.ln_post)
+        self.w_vproj = sd["visual.proj"].t().to(torch.bfloat16).contiguous()          # [E, D]
+        if self.patch:
+            # conv1 (kernel == stride == patch, no bias) is a dense GEMM over the patch matrix msclip_patchify builds:
+            # K index = (c, kh, kw) as the weight lies in memory, zero-padded to a multiple of 64
+            kp = 3 * v.patch_size * v.patch_size
+            self.patch_k = (kp + 63) // 64 * 64
+            wp = torch.zeros(self.D, self.patch_k, dtype=torch.bfloat16, device=dev)
+            wp[:, :kp] = sd["visual.conv1.weight"].reshape(self.D, kp).to(torch.bfloat16)
+            self.w_patch = wp
+            self.stem_specs, self.lateral, self.usecls, self.adapters = [], [], False, []
+            self.par_specs, self.par_b3r, self.par_hw, self.h1 = [None], [None], [], 0
+        else:
+            self._pack_conv_side(sd, v, vt, dev)
+
+        # --- transformer blocks (shared tensors packed once)
+        cache = {}
+        self._foldw = {}                             # gamma-folded projection weights of the LayerNorm fold, built on first use
+
+        def blockw(blk):
+            key = (blk.attn.in_proj_weight.data_ptr(), blk.attn.out_proj.weight.data_ptr(),
+                   blk.mlp.c_fc.weight.data_ptr(), blk.mlp.c_proj.weight.data_ptr())
+            if key not in cache:
+                cache[key] = _BlockW(blk, self.heads, self.fp8, self.fp8_qkv)
+            return cache[key]
+
+        if blocks:                                   # (False: repack_after_optimizer, the copies are already current)
+            self.vblk, self.tblk = [None] * self.n_layers, [None] * self.n_layers
+            for i in range(self.n_layers):
+                tb = m.transformer.resblocks[i]
+                self.tblk[i] = dict(w=blockw(tb), ln1=_LN(tb.ln_1), ln2=_LN(tb.ln_2))
+                if i >= 1 or self.patch:                 # (slot 0 is the conv stem unless the patch conv tokenises)
+                    vb = vt.resblocks[i]
+                    self.vblk[i] = dict(w=blockw(vb), ln1=_LN(vb.ln_1), ln2=_LN(vb.ln_2))
+            self.n_packed_blocks = len(cache)
+
+        # --- text front / heads
+        self.emb = m.token_embedding.weight.detach()
+        self.tpos = sd["positional_embedding"].float().contiguous()
+        self.ln_final = _LN(m.ln_final)
+        self.w_tproj = sd["text_projection"].t().to(torch.bfloat16).contiguous()      # [E, D]
+
+    def _pack_conv_side(self, sd, v, vt, dev):
+        """The MS-CLIP-S conv stem (slot 0 of the visual Transformer), the parallel branch and the lateral adapters."""
         # --- stem
         sp = "visual.transformer.resblocks.0"
         self.dual_w, self.dual_b = [t.to(dev) for t in P.stem_dual_weights(sd, sp, "visual.transformer.parallel_branch_v.0")]
@@ -191,10 +238,6 @@ class Engine:
             h = spec.h_out
         assert h == self.g, f"stem output grid {h} != token grid {self.g}"
         self.w_last = sd[sp + ".last_conv.weight"][:, :, 0, 0].to(torch.bfloat16).contiguous()
-        self.cls = sd["visual.class_embedding"].float().contiguous()
-        self.vpos = sd["visual.positional_embedding"].float().contiguous()
-        self.ln_pre, self.ln_post = _LN(v.ln_pre), _LN(v.ln_post)
-        self.w_vproj = sd["visual.proj"].t().to(torch.bfloat16).contiguous()          # [E, D]
 
         # --- parallel branch + adapters
         self.lateral = list(vt.parallel_lateral_layers)
@@ -215,32 +258,6 @@ class Engine:
             self.adapters.append(dict(pool=pool.to(dev), k=k, pw=pw.to(dev), dww=dww.to(dev), dwb=dwb.to(dev),
                                       ln=_LN(vt.parallel_lateral_adapter[j].ln_adapt), C=pool.shape[1]))
 
-        # --- transformer blocks (shared tensors packed once)
-        cache = {}
-        self._foldw = {}                             # gamma-folded projection weights of the LayerNorm fold, built on first use
-
-        def blockw(blk):
-            key = (blk.attn.in_proj_weight.data_ptr(), blk.attn.out_proj.weight.data_ptr(),
-                   blk.mlp.c_fc.weight.data_ptr(), blk.mlp.c_proj.weight.data_ptr())
-            if key not in cache:
-                cache[key] = _BlockW(blk, self.heads, self.fp8, self.fp8_qkv)
-            return cache[key]
-
-        if blocks:                                   # (False: repack_after_optimizer, the copies are already current)
-            self.vblk, self.tblk = [None] * self.n_layers, [None] * self.n_layers
-            for i in range(self.n_layers):
-                tb = m.transformer.resblocks[i]
-                self.tblk[i] = dict(w=blockw(tb), ln1=_LN(tb.ln_1), ln2=_LN(tb.ln_2))
-                if i >= 1:
-                    vb = vt.resblocks[i]
-                    self.vblk[i] = dict(w=blockw(vb), ln1=_LN(vb.ln_1), ln2=_LN(vb.ln_2))
-            self.n_packed_blocks = len(cache)
-
-        # --- text front / heads
-        self.emb = m.token_embedding.weight.detach()
-        self.tpos = sd["positional_embedding"].float().contiguous()
-        self.ln_final = _LN(m.ln_final)
-        self.w_tproj = sd["text_projection"].t().to(torch.bfloat16).contiguous()      # [E, D]
 
     @property
     def logit_scale_exp(self):
@@ -293,7 +310,12 @@ class Engine:
             w["RS"] = torch.empty(M, dtype=f32, device=dev)
             w["HIDQ"] = torch.zeros(M * 4 * D + 256, dtype=torch.uint8, device=dev)[:M * 4 * D].view(M, 4 * D)
             w["ONES"] = torch.ones(M, dtype=f32, device=dev)
-        if Bi:
+        if Bi and self.patch:
+            w["PATCH"] = buf(Bi * self.g * self.g, self.patch_k)     # bf16 patch matrix of the patch-conv stem (msclip_patchify)
+            w["Ts"] = None
+            w["hv"] = buf(Bi, D)
+            w["fv_raw"], w["fv"] = buf(Bi, E, dtype=f32), buf(Bi, E, dtype=f32)
+        elif Bi:
             w["XA"] = buf(Mv, D, dtype=f32)
             h1 = self.h1
             w["P0"] = buf(Bi * h1 * h1, D // 16)            # S1 (conv1's map) only exists on the unfused path: _s1()
@@ -353,6 +375,9 @@ class Engine:
     def _vision_front(self, img, w, Bi, taps=None, keep_pre=None, convs_done=False):
         """Stem + tokenisation (M.py:2416-2426) and stage 0 of the parallel branch (M.py:2436).  convs_done: the stem's maps
         are already in the workspace (the training step's train-mode BatchNorm chain), only the tokenisation runs."""
+        if self.patch:                                       # M.py:2657: conv1 as patchify + one dense GEMM (scatter + positional add fused)
+            hip.patchify(img, w["PATCH"], Bi, self.S, self.S // self.g, self.patch_k)
+            return self._tokenise(w["PATCH"], w, Bi, taps, keep_pre, weight=self.w_patch)
         if convs_done:
             return self._tokenise(w["stem"][-1], w, Bi, taps, keep_pre)
         first = self.stem_specs[0]
@@ -377,10 +402,12 @@ class Engine:
             self._tap_nhwc(taps, "parallel0", w["P0"], Bi, self.h1, self.D // 16)
         self._tokenise(x, w, Bi, taps, keep_pre)
 
-    def _tokenise(self, x, w, Bi, taps=None, keep_pre=None):
+    def _tokenise(self, x, w, Bi, taps=None, keep_pre=None, weight=None):
         g2 = self.g * self.g
-        # last_conv (1x1, no BN/ReLU) fused with "+ positional_embedding" and the scatter to token rows b*L + 1 + p
-        hip.gemm(x, self.w_last, w["X"], M=Bi * g2, resid=self.vpos, resid_kind=hip.RESID_TABLE, rpg=g2, radd=1, roff=1)
+        # last_conv (1x1, no BN/ReLU) -- or the patch conv over the patch matrix -- fused with "+ positional_embedding" and the
+        # scatter to token rows b*L + 1 + p
+        hip.gemm(x, self.w_last if weight is None else weight, w["X"], M=Bi * g2, resid=self.vpos, resid_kind=hip.RESID_TABLE,
+                 rpg=g2, radd=1, roff=1)
         hip.fill_cls(self.cls, self.vpos, w["X"], Bi, self.Lv)
         xv = w["X"][:w["Mv"]]
         if keep_pre is not None:
@@ -854,7 +881,7 @@ class Engine:
                 # default (MSCLIP_CONV_SIDE_STREAM=0 turns it off): +1.6 % pairs/s on B/32, +2.2 % on B/16 same-box.  The GEMM
                 # launches it overlaps measure ~11 % longer each, so bench.py takes its per-kernel roofline from a probe
                 # pass with the inline schedule and reports the overlapped figure beside it.
-                if side_ok and self.lateral == sorted(self.lateral):
+                if side_ok and self.lateral and self.lateral == sorted(self.lateral):
                     conv_events = self._conv_branch_on_side_stream(w, Bi)
             if Bt and text0 is None:
                 self._text_front(self._check_tok(tok), w, Bt)

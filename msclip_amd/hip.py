@@ -18,7 +18,7 @@ INT_MAX = 2 ** 31 - 1
 EXPORTS = (
     "msclip_gemm", "msclip_gemm_f8", "msclip_layernorm_stats", "msclip_rowstat_finalize", "msclip_layernorm_f8", "msclip_quant_f8_rows", "msclip_gemm_variant", "msclip_attention", "msclip_attention_lastq", "msclip_layernorm", "msclip_layernorm_split", "msclip_embed_tokens", "msclip_fill_cls",
     "msclip_adapter_combine_ln", "msclip_l2norm", "msclip_gather_rows", "msclip_stem_conv3x3s2_dual", "msclip_dwpool",
-    "msclip_stem_dual_conv3x3s2", "msclip_conv1x1_conv3x3s2", "msclip_convresblock48_s2",
+    "msclip_stem_dual_conv3x3s2", "msclip_conv1x1_conv3x3s2", "msclip_convresblock48_s2", "msclip_patchify",
     "msclip_lse_rows", "msclip_clip_loss_partial", "msclip_clip_lse_fused", "msclip_clip_loss_from_partials",
     "msclip_transpose_bf16", "msclip_cast_bf16", "msclip_cast_bf16_colsum", "msclip_colsum", "msclip_quickgelu", "msclip_quickgelu_bwd", "msclip_layernorm_bwd",
     "msclip_attention_bwd", "msclip_l2norm_bwd", "msclip_clip_loss_bwd_g", "msclip_embed_tokens_bwd", "msclip_adapter_sum",
@@ -101,6 +101,7 @@ def lib():
         L.msclip_stem_dual_conv3x3s2.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
         L.msclip_conv1x1_conv3x3s2.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
         L.msclip_convresblock48_s2.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]
+        L.msclip_patchify.argtypes = [vp, ci, vp, ci, ci, ci, ci, ci, vp]
         L.msclip_lse_rows.argtypes = [vp, ci, vp, ci, ci, vp]
         L.msclip_clip_loss_partial.argtypes = [vp, vp, vp, ci, ci, ci, cf, vp, vp]
         L.msclip_clip_lse_fused.argtypes = [vp, ci, vp, ci, ci, ci, ci, cf, ci, ci, vp, vp, vp, vp]
@@ -595,6 +596,16 @@ def adapter_combine_ln(xin, t, dww, dwb, gamma, beta, xout, B, L, g, usecls, eps
     _check(lib().msclip_adapter_combine_ln(_p(xin), xin.stride(0), _p(t), t.stride(0), _p(dww), _p(dwb), _p(gamma),
                                            _p(beta), _p(xout), xout.stride(0), B, L, g, xin.shape[1], int(usecls), eps,
                                            _stream()), "msclip_adapter_combine_ln")
+
+
+def patchify(img, out, B, S, P, kpad):
+    """out[b * g * g + py * g + px][c * P * P + kh * P + kw] = bf16(img[b, c, py * P + kh, px * P + kw]), zero-padded to kpad
+    columns: the patch matrix of a kernel == stride == P convolution (M.py:2502-2508, 2657).  img NCHW fp32 / bf16 [B, 3, S, S]."""
+    assert img.is_cuda and img.is_contiguous() and img.dtype in (torch.float32, torch.bfloat16) and tuple(img.shape) == (B, 3, S, S)
+    _bf16(out)
+    assert out.shape[0] >= B * (S // P) ** 2 and out.shape[1] == kpad and out.stride(0) == kpad
+    _check(lib().msclip_patchify(_p(img), int(img.dtype == torch.bfloat16), _p(out), kpad, B, S, S, P, _stream()), "msclip_patchify")
+    return out
 
 
 def l2norm(x, out_f32=None, out_bf16=None):

@@ -50,6 +50,7 @@ class Arch:
     t2b_paddings: Sequence[int] = (0, 0, 0, 0, 0)
     t2b_usecls: bool = True                              # PRALLEL_T2B_USECLS
     share_from_layer: int = 1                            # N_LAYERS
+    patch_conv: bool = False                             # EARLY_CONV off: plain patch convolution `visual.conv1` (M.py:2502-2508)
 
     @property
     def grid(self):
@@ -70,6 +71,14 @@ def arch_l16():
     a = arch_b16()
     a.embed_dim, a.width, a.heads, a.vision_layers, a.text_layers = 768, 1024, 16, 24, 24
     return a
+
+
+def arch_l14():
+    """experiments/model/l14-fp8-msclips.yaml (BASELINE config C5): ViT-L/14 with the reference's plain patch convolution
+    (M.py:2502-2508, VisualTransformer.forward :2655-2668), 16 x 16 grid, no parallel branch / adapters; every vision slot is an
+    attention block."""
+    return Arch(embed_dim=768, patch_size=14, width=1024, heads=16, vision_layers=24, text_layers=24, lateral_layers=(),
+                patch_conv=True)
 
 
 def arch_b16():
@@ -211,7 +220,10 @@ def lateral_adapter(top: Tensor, x: Tensor, sd: SD, arch: Arch, j: int) -> Tenso
 def image_tokens(img: Tensor, sd: SD, arch: Arch, taps: dict = None) -> Tensor:
     """Slot 0 of the visual Transformer: stem -> tokens, cls, +pos, ln_pre
     (M.py:2416-2426)."""
-    x = stem(img, sd, arch, taps)
+    if arch.patch_conv:                                   # M.py:2657: conv1 with kernel == stride == patch, no bias
+        x = F.conv2d(img, sd["visual.conv1.weight"], stride=arch.patch_size)
+    else:
+        x = stem(img, sd, arch, taps)
     B = x.shape[0]
     x = x.flatten(2).transpose(1, 2)
     cls = sd["visual.class_embedding"].to(x.dtype).expand(B, 1, -1)
@@ -227,7 +239,7 @@ def encode_image(img: Tensor, sd: SD, arch: Arch, norm: bool = True, taps: dict 
     if taps is not None:
         taps["tokens_ln_pre"] = x
     par = img
-    for idx in range(1, arch.vision_layers):
+    for idx in range(0 if arch.patch_conv else 1, arch.vision_layers):      # slot 0 is the conv stem unless the patch conv tokenises
         if idx in arch.lateral_layers:
             j = list(arch.lateral_layers).index(idx)
             par = parallel_stage(par, sd, arch, j)

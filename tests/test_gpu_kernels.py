@@ -267,7 +267,7 @@ def test_gemm_conv_pingpong_forced_small(gpu_device, B, H, Cin, Cout, k, stride,
 
 
 @pytest.mark.parametrize("B,L,causal", [(3, 50, False), (5, 77, True), (2, 197, False), (1, 1, False), (2, 33, True),
-                                        (2, 64, True), (1, 96, False)])
+                                        (2, 64, True), (1, 96, False), (2, 257, False), (1, 288, True), (2, 230, False)])
 def test_attention(gpu_device, B, L, causal):
     Hh, D = 12, 768
     qkv = rnd(B * L + 5, 3 * D, seed=16, dtype=BF)                 # extra rows: nothing may read/write past B*L
@@ -282,7 +282,8 @@ def test_attention(gpu_device, B, L, causal):
     assert bool((out[B * L:] == 7.0).all())
 
 
-@pytest.mark.parametrize("B,L,causal", [(5, 50, False), (6, 77, True), (3, 197, False), (2, 1, True), (3, 64, True), (2, 130, True)])
+@pytest.mark.parametrize("B,L,causal", [(5, 50, False), (6, 77, True), (3, 197, False), (2, 1, True), (3, 64, True), (2, 130, True),
+                                        (3, 257, False), (2, 288, True)])
 def test_attention_single_query_per_sample(gpu_device, B, L, causal):
     """msclip_attention_lastq: the class row (all keys) / a caption's EOT row (keys up to itself) only.  Against fp32 softmax
     attention of that one query, and against the same rows of the full kernel.  The q columns of the token matrix are
@@ -294,7 +295,7 @@ def test_attention_single_query_per_sample(gpu_device, B, L, causal):
     rows = (base + torch.arange(B) * L + pos).to(torch.int32).cuda()
     q = qkv[rows.long(), :D].contiguous()
     full = torch.empty(B * L, D, dtype=BF, device="cuda")
-    if L <= 224:
+    if L <= 288:
         hip.attention(qkv[base:base + B * L], full, B, L, Hh, causal)
     poisoned = qkv.clone()
     poisoned[:, :D] = float("nan")
@@ -307,7 +308,7 @@ def test_attention_single_query_per_sample(gpu_device, B, L, causal):
         s = torch.einsum("hd,khd->hk", q[b].float().reshape(Hh, 64), k)
         ref = torch.einsum("hk,khd->hd", torch.softmax(s, -1), v).reshape(D)
         close(out[b], ref, 2e-2, 2e-2)
-        if L <= 224:
+        if L <= 288:
             close(out[b], full[b * L + int(pos[b])].float(), 2e-2, 1e-2)
     assert bool((out[B:] == 7.0).all())
     assert hip.lib().msclip_attention_lastq(None, D, None, 3 * D, None, D, 1, 8, Hh, None, 0, None) == -1
@@ -904,3 +905,30 @@ def test_layernorm_stats_rows(gpu_device):
     assert torch.equal(out.view(torch.int16), ref.view(torch.int16)) and torch.equal(raw, x)
     close(cen, x.mean(1), 1e-5)
     assert bool((rs[:, 0] == 1).all()) and bool((rs[:, 1] == 0).all())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,S,P", [(3, 224, 14), (2, 224, 16), (1, 64, 32)])
+def test_patchify_and_patch_conv(gpu_device, dtype, B, S, P):
+    """msclip_patchify + msclip_gemm with the token scatter = the plain patch convolution + cls / positional layout of
+    M.py:2657-2664 (BASELINE config C5's stem): the patch matrix is bitwise the bf16 unfold of the image (pad columns zero),
+    the GEMM over it against F.conv2d."""
+    g = S // P
+    kp, D = 3 * P * P, 256
+    kpad = (kp + 63) // 64 * 64
+    img = rnd(B, 3, S, S, seed=95).to(dtype)
+    pm = torch.full((B * g * g + 2, kpad), float("nan"), dtype=BF, device="cuda")
+    hip.patchify(img, pm[:B * g * g], B, S, P, kpad)
+    ref = F.unfold(img.float(), P, stride=P).transpose(1, 2).reshape(B * g * g, kp).to(BF)      # columns (c, kh, kw), rows (b, py, px)
+    assert torch.equal(pm[:B * g * g, :kp].view(torch.int16), ref.view(torch.int16))
+    assert bool((pm[:B * g * g, kp:] == 0).all()) and bool(torch.isnan(pm[B * g * g:].float()).all())
+    w = rnd(D, 3, P, P, seed=96, scale=0.05)
+    wp = torch.zeros(D, kpad, dtype=BF, device="cuda")
+    wp[:, :kp] = w.reshape(D, kp).to(BF)
+    pos = rnd(g * g + 1, D, seed=97)
+    L = g * g + 1
+    X = torch.zeros(B * L, D, device="cuda")
+    hip.gemm(pm[:B * g * g], wp, X, M=B * g * g, resid=pos, resid_kind=hip.RESID_TABLE, rpg=g * g, radd=1, roff=1)
+    conv = F.conv2d(img.float().to(BF).float(), w.to(BF).float(), stride=P).flatten(2).transpose(1, 2)           # [B, g*g, D]
+    close(X.view(B, L, D)[:, 1:], conv + pos[1:], 2e-2, 1e-3)
+    assert bool((X.view(B, L, D)[:, 0] == 0).all())                                              # the cls rows are not the GEMM's

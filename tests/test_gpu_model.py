@@ -636,6 +636,45 @@ def test_l16_standin_bf16_against_reference_golden(gpu_device):
     assert el <= LOGIT_TOL
 
 
+def test_l14_patch_conv_model_bf16_against_reference_golden(gpu_device):
+    """BASELINE config C5 proper (experiments/model/l14-fp8-msclips.yaml): ViT-L/14 with the reference's plain patch convolution
+    (M.py:2502-2508, 2655-2668), 16 x 16 grid = 257 tokens, attention / MLP shared from block 1, no conv branch.  The reference
+    builds it from that yaml: bf16 path here against features, logits and the captured taps (tokens after ln_pre, blocks 0 / 1 /
+    23 of both towers) of the REAL reference (tests/golden/l14-fp8-msclips.npz, tools/make_golden.py --l14)."""
+    from conftest import summarize
+    name = "l14-fp8-msclips"
+    g = golden(name)
+    m = _model_with(name, ["MODEL.SPEC.PRECISION", "bf16"])
+    b = int(g["batch"])
+    img = synth.synth_images(b, seed=int(g["seed"])).cuda()
+    tok = synth.synth_tokens(b, seed=int(g["seed"]) + 1).cuda()
+    ei, ci = check_feats(m.encode_image(img), g["image_features"])
+    et, ct = check_feats(m.encode_text(tok), g["text_features"])
+    el = np.abs(m(img, tok).cpu().numpy() - g["logits"]).max()
+    print(f"{name} bf16: image max-abs {ei:.2e} cos {ci:.6f}; text max-abs {et:.2e} cos {ct:.6f}; logits max-abs {el:.2e}")
+    assert el <= LOGIT_TOL
+    taps = {}
+    m.engine().run(img, tok, taps=taps)
+    names = [k[4:] for k in g.files if k.startswith("tap_")]
+    assert len(names) == 7
+    for k in names:
+        t = taps[k]
+        assert tuple(t.shape) == tuple(g["tapshape_" + k]), (k, t.shape)
+        got, ref = summarize(t), g["tap_" + k]
+        scale = max(np.abs(ref[2:]).max(), 1e-3)
+        assert np.abs(got[2:] - ref[2:]).max() / scale <= 4e-2, k
+    # batch 256 (Mv = 257 * 256 rows: the LayerNorm fold and the 257-token attention at full size) against the oracle on a few samples
+    sd, arch = synth_sd(name), O.arch_l14()
+    B = 256
+    img = synth.synth_images(B, seed=61).cuda()
+    tok = synth.synth_tokens(B, seed=62).cuda()
+    w = m.engine().run(img, tok)
+    fi, ft = w["fv"].clone(), w["ft"].clone()
+    with torch.no_grad():
+        check_feats(fi[[0, 255]], O.encode_image(img[[0, 255]].cpu(), sd, arch))
+        check_feats(ft[[1, 254]], O.encode_text(tok[[1, 254]].cpu(), sd, arch))
+
+
 @pytest.mark.parametrize("precision", ["fp8", "fp8-qkv"])
 @pytest.mark.parametrize("name", ["b32-yfcc-msclips", "l16-fp8-msclips"])
 def test_fp8_projections_against_the_bf16_path(gpu_device, name, precision):

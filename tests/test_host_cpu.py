@@ -26,7 +26,7 @@ def test_config_base_inheritance_and_opts():
         c.NAME = "frozen"
 
 
-@pytest.mark.parametrize("name", ["b32-yfcc-msclips", "b16-yfcc-msclips", "l16-fp8-msclips"])
+@pytest.mark.parametrize("name", ["b32-yfcc-msclips", "b16-yfcc-msclips", "l16-fp8-msclips", "l14-fp8-msclips"])
 def test_state_dict_abi_matches_reference_schema(name):
     model = get_clip_model(named_config(name))
     mine = [(k, tuple(v.shape), v.dtype) for k, v in model.state_dict().items()]
@@ -37,7 +37,7 @@ def test_state_dict_abi_matches_reference_schema(name):
         assert v.attn.in_proj_weight is t.attn.in_proj_weight and v.attn.in_proj_bias is t.attn.in_proj_bias
         assert v.attn.out_proj is t.attn.out_proj and v.mlp is t.mlp
         assert v.ln_1 is not t.ln_1 and v.ln_2 is not t.ln_2
-    assert sum(p.numel() for p in model.parameters()) == {"b32": 132408001, "b16": 132503617, "l16": 369877761}[name[:3]]
+    assert sum(p.numel() for p in model.parameters()) == {"b32": 132408001, "b16": 132503617, "l16": 369877761, "l14": 368117761}[name[:3]]
 
 
 def test_strict_load_keeps_aliases_and_build_model_alias():

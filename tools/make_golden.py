@@ -252,13 +252,43 @@ def l16_fixture(name="l16-fp8-msclips", batch=2):
         json.dump([(k, list(s), str(d).replace("torch.", "")) for k, s, d in schema], f)
     img, tok = synth.synth_images(batch, seed=SEED), synth.synth_tokens(batch, seed=SEED + 1)
     R.ensure_single_rank_group()
+    taps, hooks = {}, []
+    if hasattr(model.visual, "conv1"):          # the patch-conv stem (l14): tokens after ln_pre and a few blocks of both towers
+        def tap(nm):
+            def fn(_m, _i, o):
+                taps[nm] = o[1] if isinstance(o, tuple) else o
+            return fn
+        hooks.append(model.visual.ln_pre.register_forward_hook(tap("tokens_ln_pre")))
+        for i in (0, 1, 23):
+            hooks.append(model.visual.transformer.resblocks[i].register_forward_hook(tap(f"vblock{i}")))
+            hooks.append(model.transformer.resblocks[i].register_forward_hook(tap(f"tblock{i}")))
     with torch.no_grad():
         fi, ft = model.encode_image(img), model.encode_text(tok)
+        for h in hooks:
+            h.remove()
         fir = model.encode_image(img, norm=False)
         logits = model(img, tok)
-    np.savez_compressed(os.path.join(OUT, name + ".npz"), image_features=fi.numpy(), text_features=ft.numpy(),
-                        image_features_raw=fir.numpy(), logits=logits.numpy(), batch=np.int64(batch), seed=np.int64(SEED))
-    print(f"{name}: {len(schema)} keys, features {tuple(fi.shape)}, logits {logits.numpy().round(3).tolist()}")
+    out = dict(image_features=fi.numpy(), text_features=ft.numpy(), image_features_raw=fir.numpy(), logits=logits.numpy(),
+               batch=np.int64(batch), seed=np.int64(SEED))
+    for k, v in taps.items():
+        if k.startswith(("vblock", "tblock")):
+            v = v.permute(1, 0, 2)              # reference activations are seq-first [L, B, C]; store batch-first
+        out["tap_" + k] = summarize(v)
+        out["tapshape_" + k] = np.array(v.shape, dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    flops = None
+    try:                                        # algorithmic forward FLOPs per pair, counted on the reference itself
+        from torch.utils.flop_counter import FlopCounterMode
+        with torch.no_grad(), FlopCounterMode(display=False) as fc:
+            model.encode_image(img[:1])
+        fi_flops = fc.get_total_flops()
+        with torch.no_grad(), FlopCounterMode(display=False) as fc:
+            model.encode_text(tok[:1])
+        flops = (fi_flops / 1e9, fc.get_total_flops() / 1e9)
+    except Exception as e:
+        flops = repr(e)
+    print(f"{name}: {len(schema)} keys, {sum(p.numel() for p in model.parameters())} unique params, features {tuple(fi.shape)}, "
+          f"logits {logits.numpy().round(3).tolist()}, taps {sorted(taps)}, GFLOP/pair image, text = {flops}")
 
 
 def main():
@@ -269,6 +299,8 @@ def main():
         return refresh_prompt_features()
     if "--l16" in sys.argv:
         return l16_fixture()
+    if "--l14" in sys.argv:                      # BASELINE config C5 proper: patch-14 conv stem, 16 x 16 grid (experiments/model/l14-fp8-msclips.yaml)
+        return l16_fixture("l14-fp8-msclips")
     for name in ("b32-yfcc-msclips", "b16-yfcc-msclips"):
         model, _ = run_config(name)
         if name.startswith("b32"):
