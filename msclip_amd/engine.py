@@ -85,6 +85,9 @@ class Engine:
         self.dev = ref.device
         self.model = model
         self._ws = {}
+        self._calib = None              # calibrate_fp8() in progress: {id(_BlockW): (block, [device amax, ...])}
+        self._fp8_saved = {}            # calibrated hidden scales, restored into the fresh _BlockW objects of a re-pack
+        self._fp8_warned = False
         self.force_unfused = False      # the training step runs the conv side layer by layer: every map stays in the workspace
         with torch.cuda.device(self.dev), torch.no_grad():
             self._pack(model)
@@ -216,6 +219,8 @@ class Engine:
                     vb = vt.resblocks[i]
                     self.vblk[i] = dict(w=blockw(vb), ln1=_LN(vb.ln_1), ln2=_LN(vb.ln_2))
             self.n_packed_blocks = len(cache)
+            if self.fp8 and self._fp8_saved:             # a re-pack (optimizer step, load_state_dict) keeps the calibration
+                self.load_fp8_state(self._fp8_saved)
 
         # --- text front / heads
         self.emb = m.token_embedding.weight.detach()
@@ -544,25 +549,85 @@ class Engine:
             hip.gemm(HIDC[r0:r1], bw.wpr, XC[r0:r1], bias=bw.bpr, resid=XC[r0:r1], resid_kind=hip.RESID_F32)
 
     def _mlp_f8(self, w, r0, r1, bw):
-        """c_fc + QuickGELU + c_proj of the rows [r0, r1) under PRECISION fp8.  c_fc (e4m3 LayerNorm output x e4m3 weight) writes
-        the hidden matrix as e4m3 with ONE static scale per layer, which makes it the fp8 operand of c_proj without another pass
-        (its row maximum spans 16-32 column tiles: a per-token scale cannot come out of a tile's epilogue; a static, calibrated
-        per-tensor scale is the usual recipe for such activations).  Calibration: the first batch a layer sees runs c_fc with a
-        bf16 output and c_proj in bf16, and fixes the scale at 1.25 x its max |hidden| / 448 (one host read per layer, once);
-        later values beyond that range saturate.  Row counts that are not whole 256-row tiles keep the bf16 hidden matrix."""
+        """c_fc + QuickGELU + c_proj of the rows [r0, r1) under PRECISION fp8 (recipe: DESIGN.md s9, emulated by
+        oracle/fp8_recipe.py).  c_fc (e4m3 LayerNorm output x e4m3 weight, per-token x per-channel scales) writes the hidden
+        matrix as e4m3 with ONE static scale per layer -- its row maximum spans 16-32 column tiles, so a per-token scale cannot
+        come out of a tile's epilogue -- which makes it the fp8 operand of c_proj without another pass.  The scale comes from
+        calibrate_fp8() (explicit; both modalities of a shared layer, all ranks): an uncalibrated layer, and row counts that are
+        not whole 256-row tiles, keep a bf16 hidden matrix and a bf16 c_proj."""
         X, HID, LNQ, RS = w["X"], w["HID"], w["LNQ"], w["RS"]
         if bw.hid_scale is None or (r1 - r0) % 256:
             hip.gemm_f8(LNQ[r0:r1], bw.wfc_q, HID[r0:r1], RS[r0:r1], bw.wfc_s, bias=bw.bfc, act=hip.ACT_QUICKGELU)
-            if bw.hid_scale is None and not torch.cuda.is_current_stream_capturing():
-                amax = float(HID[r0:r1].abs().amax())
-                bw.hid_scale = max(amax, 1e-6) * 1.25 / 448.0
-                bw.wpr_cs = (bw.wpr_s * bw.hid_scale).contiguous()
+            if self._calib is not None:                    # calibrate_fp8(): max |hidden| of this launch, kept on the device
+                self._calib.setdefault(id(bw), (bw, []))[1].append(HID[r0:r1].abs().amax())
             hip.gemm(HID[r0:r1], bw.wpr, X[r0:r1], bias=bw.bpr, resid=X[r0:r1], resid_kind=hip.RESID_F32)
             return
         HQ = w["HIDQ"]
         hip.gemm_f8(LNQ[r0:r1], bw.wfc_q, HQ[r0:r1], RS[r0:r1], bw.wfc_s, bias=bw.bfc, act=hip.ACT_QUICKGELU,
                     out_scale=1.0 / bw.hid_scale)
         hip.gemm_f8(HQ[r0:r1], bw.wpr_q, X[r0:r1], w["ONES"][r0:r1], bw.wpr_cs, bias=bw.bpr, resid=X[r0:r1], resid_kind=hip.RESID_F32)
+
+    # ------------------------------------------------------------------ fp8 calibration (PRECISION fp8 / fp8-qkv)
+    HID_HEADROOM = 1.25                                   # static hidden scale = HID_HEADROOM * calibrated max |hidden| / 448
+
+    def _fp8_blocks(self):
+        """{(layer, tower): _BlockW} of every packed block (shared layers appear under both towers with the same object)."""
+        out = {}
+        for i in range(self.n_layers):
+            for tower, blks in (("v", self.vblk), ("t", self.tblk)):
+                if blks[i] is not None:
+                    out[(i, tower)] = blks[i]["w"]
+        return out
+
+    def fp8_calibrated(self):
+        """True once calibrate_fp8 has run (or scales were loaded).  Blocks whose MLP never runs on the token matrix -- the last
+        block's live-row tail -- have no scale and need none."""
+        return not self.fp8 or bool(self._fp8_saved)
+
+    def calibrate_fp8(self, img, tok):
+        """Fix the static e4m3 scale of every layer's MLP hidden matrix from ONE calibration batch that has both modalities
+        (a shared layer's hidden activations differ between image and text rows; the scale covers both): the batch runs with
+        bf16 hidden matrices, each layer's max |hidden| stays on the device, the maxima are all-reduced (MAX) over the ranks
+        of a process group -- every rank ends with the same scales -- and read by the host once.  Scales survive re-packs
+        (optimizer steps, load_state_dict): call again to re-calibrate; fp8_state() / load_fp8_state() carry them in a checkpoint."""
+        if not self.fp8:
+            return {}
+        if img is None or tok is None:
+            raise ValueError("calibrate_fp8 needs images AND captions: the shared layers' hidden scale must cover both modalities")
+        blocks = self._fp8_blocks()
+        for bw in blocks.values():
+            bw.hid_scale, bw.wpr_cs = None, None
+        self._calib = {}
+        try:
+            self.run(img, tok)
+            objs = [bw for bw, _ in self._calib.values()]
+            amax = torch.stack([torch.stack(vals).amax() for _, vals in self._calib.values()])
+        finally:
+            self._calib = None
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(amax, op=dist.ReduceOp.MAX)
+        host = amax.cpu().tolist()                           # the one host read of the calibration
+        for bw, a in zip(objs, host):
+            self._set_hid_scale(bw, max(a, 1e-6) * self.HID_HEADROOM / 448.0)
+        self._fp8_saved = self.fp8_state()
+        return dict(self._fp8_saved)
+
+    @staticmethod
+    def _set_hid_scale(bw, s):
+        bw.hid_scale = float(s)
+        bw.wpr_cs = (bw.wpr_s * bw.hid_scale).contiguous()
+
+    def fp8_state(self):
+        """{"layer.tower": hidden scale} of the calibrated layers (plain floats: goes into a checkpoint next to the weights)."""
+        return {f"{i}.{t}": bw.hid_scale for (i, t), bw in self._fp8_blocks().items() if bw.hid_scale is not None}
+
+    def load_fp8_state(self, state):
+        blocks = self._fp8_blocks()
+        for key, s in state.items():
+            i, t = key.split(".")
+            if (int(i), t) in blocks:
+                self._set_hid_scale(blocks[(int(i), t)], s)
+        self._fp8_saved = self.fp8_state()
 
     def _ln_f8(self, w, segs, which):
         """LayerNorm of the token rows straight to e4m3 + per-token scales (w["LNQ"], w["RS"]): one launch over both towers'
@@ -854,6 +919,14 @@ class Engine:
                 self.refresh()
             Bi = img.shape[0] if img is not None else 0
             Bt = tok.shape[0] if tok is not None else 0
+            if self.fp8 and self._calib is None and not self.fp8_calibrated() and not torch.cuda.is_current_stream_capturing():
+                if Bi and Bt:
+                    self.calibrate_fp8(img, tok)          # first two-modality batch = the calibration batch (explicit call: calibrate_fp8)
+                elif not self._fp8_warned:
+                    self._fp8_warned = True
+                    import warnings
+                    warnings.warn("PRECISION fp8: the MLP hidden scales are not calibrated yet (engine.calibrate_fp8(images, captions)); "
+                                  "single-modality calls run c_proj in bf16 until then")
             w = self._workspace(Bi, Bt, inference=True)
             w["fold_pending"] = {"v": False, "t": False}
             conv_events = None

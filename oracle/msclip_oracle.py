@@ -231,9 +231,11 @@ def image_tokens(img: Tensor, sd: SD, arch: Arch, taps: dict = None) -> Tensor:
     return layer_norm(x, sd["visual.ln_pre.weight"], sd["visual.ln_pre.bias"])
 
 
-def encode_image(img: Tensor, sd: SD, arch: Arch, norm: bool = True, taps: dict = None) -> Tensor:
+def encode_image(img: Tensor, sd: SD, arch: Arch, norm: bool = True, taps: dict = None, block_fn=None) -> Tensor:
     """CLIP.encode_image (M.py:2979-2985) -> VisualTransformer.forward
-    (M.py:2621-2638, 2669-2697) -> Transformer.forward (M.py:2388-2459)."""
+    (M.py:2621-2638, 2669-2697) -> Transformer.forward (M.py:2388-2459).
+    block_fn: stand-in for residual_block (oracle/fp8_recipe.py emulates PRECISION fp8 through it)."""
+    residual_block = block_fn or globals()["residual_block"]
     img = img.float()
     x = image_tokens(img, sd, arch, taps)
     if taps is not None:
@@ -259,9 +261,10 @@ def encode_image(img: Tensor, sd: SD, arch: Arch, norm: bool = True, taps: dict 
 # text tower
 # ----------------------------------------------------------------------------
 
-def encode_text(text: Tensor, sd: SD, arch: Arch, norm: bool = True, taps: dict = None) -> Tensor:
+def encode_text(text: Tensor, sd: SD, arch: Arch, norm: bool = True, taps: dict = None, block_fn=None) -> Tensor:
     """CLIP.encode_text (M.py:3043-3079): embed + pos, 12 causal blocks, row at
     argmax(token id) (EOT has the largest id), ln_final, @text_projection, L2."""
+    residual_block = block_fn or globals()["residual_block"]
     x = sd["token_embedding.weight"][text] + sd["positional_embedding"]
     mask = causal_mask(text.shape[1])
     for i in range(arch.text_layers):
