@@ -86,6 +86,13 @@ int msclip_gemm(const msclip_gemm_desc* desc, void* stream);
  * activation / scatter.  The caller folds the slices (msclip_colsum over [slices, M*ldo]: fixed order). */
 int msclip_gemm_splitk(const msclip_gemm_desc* desc, int slices, void* stream);
 
+/* The same contraction for TOKEN-major operands -- what a weight gradient dW = dY^T X is made of -- without
+ * transposing them first: desc->X is [T, ldx] bf16 whose COLUMNS are the output rows m (dY), desc->W is [T, ldw] whose columns
+ * are the output columns n (the layer input), desc->K = T tokens (any count: rows past T contribute zero), out fp32
+ * [slices][M][ldo] partials (slice s = token rows [s * ceil(T / 64 / slices) * 64, ...)).  The ping-pong kernel with 64-token x
+ * 128-channel LDS regions and ds_read_b64_tr_b16 fragment reads.  No bias / residual / activation. */
+int msclip_gemm_splitk_tn(const msclip_gemm_desc* desc, int slices, void* stream);
+
 /* The dense ping-pong GEMM on OCP e4m3 (fp8) operands, CDNA4's MX matrix instruction v_mfma_scale_f32_16x16x128_f8f6f4 with
  * unit block scales (BASELINE config C5; the reference has no fp8 semantics).  desc->X [M, K] and desc->W [N, K] are e4m3 BYTES
  * (ldx / ldw in bytes, multiples of 16; K a multiple of 128; mode 0 only); row_scale [M] and col_scale [N] are the fp32

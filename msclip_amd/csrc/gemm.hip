@@ -486,15 +486,38 @@ __device__ __forceinline__ f32x4 pp_mma(const bf16x8 (&w)[2], const bf16x8 (&x)[
 // register allocation stays what it was (with all forms in one kernel hipcc spilled inside the K loop): 1 = consumer (the
 // projection behind a folded LayerNorm: per-row rstd / mean, per-column weight sums, two row segments), 2 = producer
 // (out_proj / c_proj: residual update + bf16 centred copy + per-row partial statistics).
-template <int MODE, bool F8 = false, int EPI = 0>
+// TNL (dense bf16, msclip_gemm_splitk_tn: the weight gradients dW = dY^T X of the training step): both operands are TOKEN-major,
+// X [K, ldx] holds the output rows m as COLUMNS and W [K, ldw] the output columns n as columns; the contraction runs over rows.
+// A region is 64 token rows x 128 channels (256-byte row segments: full lines), four 1-KiB DMA pieces of 4 rows per wave, and a
+// fragment (16 channels x 32 tokens) is built by ds_read_b64_tr_b16 -- the LDS transpose read: 16 lanes read a 4-token x
+// 16-channel block, lane i receives channel i's 4 tokens -- two reads per 16 x 16 x 32 operand instead of one ds_read_b128.
+// 32-byte channel pairs of a row are XOR-swizzled by (row & 3) | (row >> 3 & 1) << 2: the 8 token rows a half-wave reads in one
+// instruction then cover all 64 banks.  Ring, phases, barriers, MFMA order and epilogues are the NT kernel's.
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4v;
+__device__ __forceinline__ bf16x8 pp_ld_tr(const char* p) {         // tokens k0 .. k0 + 7 of this lane's channel
+  const bf16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((AS3 bf16x4v*)p);
+  const bf16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((AS3 bf16x4v*)(p + 1024));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int MODE, bool F8 = false, int EPI = 0, bool TNL = false>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a_in, const float* __restrict__ row_scale,
                                                       const float* __restrict__ col_scale) {
   static_assert(!(F8 && MODE == 1), "fp8 operands: dense GEMM only");
   static_assert(EPI == 0 || (MODE == 0 && !F8), "LayerNorm fold: dense bf16 GEMM only");
+  static_assert(!TNL || (MODE == 0 && !F8 && EPI == 0), "token-major operands: dense bf16 GEMM, plain epilogues");
   // Split-K launches (msclip_gemm_splitk with tile = 4; the weight gradients of the training step): blockIdx.y = K slice;
   // slice s contracts columns [s*K/S, (s+1)*K/S) of both operands into its own fp32 matrix out[s][M][ldo].  A weight
   // gradient is 9-36 output tiles over a 65 024-deep contraction: tiles x slices workgroups of ONE launch fill the chip.
   msclip_gemm_desc a = a_in;
+  unsigned kbase = 0;                              // TNL: first token row of this K slice
+  const int ktot = a.K;                            // TNL: rows of the operands (tokens beyond it read as zero)
+  if (TNL) {
+    const int kc = ((a.K + 63) / 64 + (int)gridDim.y - 1) / (int)gridDim.y * 64;      // whole K-tiles per slice
+    kbase = blockIdx.y * (unsigned)kc;
+    a.out = (float*)a.out + (size_t)blockIdx.y * a.M * a.ldo;
+    a.K = kc;
+  } else
   if (MODE == 0 && !F8 && gridDim.y > 1) {
     const int kc = a.K / (int)gridDim.y;
     a.X = (const bf16_t*)a.X + (size_t)blockIdx.y * kc;
@@ -545,12 +568,20 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a_i
   unsigned vx[2], vw[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
+    if (TNL) {                                     // piece = 4 token rows x 256 B; lane -> row 4p + lane / 16, physical 16-byte chunk lane % 16
+      const int row = (wave + 8 * i) * 4 + (lane >> 4);
+      const int g = (row & 3) | (((row >> 3) & 1) << 2);
+      const unsigned ch = (unsigned)(((((lane & 15) >> 1) ^ g) << 1) | (lane & 1)) << 4;
+      vx[i] = (unsigned)row * (unsigned)a.ldx * 2u + ch;
+      vw[i] = (unsigned)row * (unsigned)a.ldw * 2u + ch;
+      continue;
+    }
     const int row = (wave + 8 * i) * 8 + (lane >> 3);
     const unsigned ch = (unsigned)((lane & 7) ^ ((row >> 1) & 7)) << 4;
     vx[i] = (unsigned)row * (unsigned)a.ldx * ES + ch;
     vw[i] = (unsigned)row * (unsigned)a.ldw * ES + ch;
   }
-  const unsigned xhalf = 128u * (unsigned)a.ldx * ES, whalf = 128u * (unsigned)a.ldw * ES;
+  const unsigned xhalf = TNL ? 256u : 128u * (unsigned)a.ldx * ES, whalf = TNL ? 256u : 128u * (unsigned)a.ldw * ES;
   int ti = blockIdx.x, kti = 0, islot = 0;
   __amdgpu_buffer_rsrc_t rx, rw;
   // conv mode: window origin of this lane's pixel rows [half][piece]: byte offset + 16-byte chunk, and (ih0, iw0)
@@ -579,6 +610,15 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a_i
                       : make_rsrc(a.W, 0);
       return;
     }
+    if (TNL) {
+      int m0 = 0, n0 = 0;
+      if (t < ntiles) tile_origin(t, m0, n0);
+      const unsigned long long xb = (unsigned long long)ktot * a.ldx * 2ull - (unsigned long long)m0 * 2ull;
+      const unsigned long long wb = (unsigned long long)ktot * a.ldw * 2ull - (unsigned long long)n0 * 2ull;
+      rx = t < ntiles ? make_rsrc((const char*)a.X + (size_t)m0 * 2, (unsigned)xb) : make_rsrc(a.X, 0);
+      rw = t < ntiles ? make_rsrc((const char*)a.W + (size_t)n0 * 2, (unsigned)wb) : make_rsrc(a.W, 0);
+      return;
+    }
     if (t < ntiles) {
       int m0, n0;
       tile_origin(t, m0, n0);
@@ -596,6 +636,20 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a_i
     constexpr int J = decltype(jc)::value;
     bf16_t* dst = smem + islot * PREG + wave * 512;
     const unsigned ko = (unsigned)kti * 128u;
+    if (TNL) {                                     // K-tile = 64 token rows down the matrix, region half = 128 columns to the right
+      // (the row offset goes into the LANE offset: the descriptor's range check -- token rows past the matrix read as zero,
+      //  which a ragged last K-tile / an over-hanging last slice rely on -- covers the lane offset, not the scalar one)
+      const unsigned kr = kbase + (unsigned)kti * 64u;
+      if (J < 2) {
+        const unsigned ro = kr * (unsigned)a.ldw * 2u;
+        blds16(rw, vw[0] + ro, (J & 1) * 256u, dst);
+        blds16(rw, vw[1] + ro, (J & 1) * 256u, dst + 8 * 512);
+      } else {
+        const unsigned ro = kr * (unsigned)a.ldx * 2u;
+        blds16(rx, vx[0] + ro, (J & 1) * 256u, dst);
+        blds16(rx, vx[1] + ro, (J & 1) * 256u, dst + 8 * 512);
+      }
+    } else
     if (J < 2) {
       blds16(rw, vw[0], ko + (J & 1) * whalf, dst);
       blds16(rw, vw[1], ko + (J & 1) * whalf, dst + 8 * 512);
@@ -648,6 +702,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a_i
     la[ks] = r16 * 128 + (((F8 ? (quad << 1) | ks : (ks << 2) | quad) ^ ((r16 >> 1) & 7)) << 4);
   const int wsub = ((wave >> 1) & 1);              // W half-region of this wave
   const int woff = (wave & 1) * 64 * 128;          // byte offset of its 64 rows inside that region
+  // TNL: lane l of a 16-lane group reads the 8 bytes at (token row 8 * quad + (l >> 2) [+ 4 for the second read, + 32 for the
+  // second k-step], channels 4 * (l & 3) .. + 3 of a 16-channel block); block cb sits at 32-byte pair cb ^ g(row) of the row
+  const int lt = (8 * quad + (r16 >> 2)) * 256 + ((((r16 >> 2) & 3) | ((quad & 1) << 2)) << 5) + (r16 & 3) * 8;
+  const int ltw = lt ^ ((wave & 1) * 128);         // the wave's 64 W channels: pairs 4 * (wave & 1) + 0..3
   const char* lds = (const char*)smem;
 
   if (MODE == 1)                                   // one descriptor over the whole NHWC input (< 2 GiB, checked by the host)
@@ -739,6 +797,22 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a_i
   __builtin_amdgcn_sched_barrier(0)
 
       // ---- phase 0: W sub 0 (32 rows), X sub 0 (64 rows) -> quadrant (0, 0)
+      const size_t wtn = (size_t)(lds + s1 * (PREG * 2) + ltw), xtn = (size_t)(lds + s2 * (PREG * 2) + lt);     // (TNL)
+      if constexpr (TNL) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) w0[i][ks] = pp_ld_tr((const char*)(wtn ^ (size_t)(i * 32)) + ks * 8192);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) xf[j][ks] = pp_ld_tr((const char*)(xtn ^ (size_t)(j * 32)) + ks * 8192);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) w1[i][ks] = pp_ld_tr((const char*)(wtn ^ (size_t)((2 + i) * 32)) + ks * 8192);
+      } else {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -752,6 +826,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a_i
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) w1[i][ks] = pp_ld(wreg + 4096 + i * 2048 + la[ks]);
+      }
       if (kt) {                                    // K-tile 0: the slots are still the epilogue's staging until the first barrier
         issue(I0{});
         issue(I1{});
@@ -774,10 +849,17 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a_i
       PP_SYNC_OUT();
 
       // ---- phase 2: X sub 1 -> quadrant (1, 1)
+      if constexpr (TNL) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) xf[j][ks] = pp_ld_tr((const char*)(xtn ^ (size_t)((4 + j) * 32)) + ks * 8192);
+      } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) xf[j][ks] = pp_ld(xreg + 8192 + j * 2048 + la[ks]);
+      }
       if (!kt) {
         issue(I0{});
         issue(I1{});
@@ -1019,6 +1101,26 @@ extern "C" int msclip_gemm_splitk(const msclip_gemm_desc* d, int slices, void* s
   const int cap = device_cus() * 2;
   hipLaunchKernelGGL((gemm_kernel<0, 128, 128, 2, 2>), dim3(tiles < cap ? tiles : cap, slices), dim3(256), 0,
                      (hipStream_t)stream, *d);
+  return msclip_launch_status();
+}
+
+// dW [M, N] (fp32, `slices` partial matrices) = X^T W for TOKEN-major operands X [T, ldx] (columns = output rows m) and
+// W [T, ldw] (columns = output columns n): the weight gradients of the training step without the operand transposes
+// (gemm_pp_kernel<0, false, 0, true>).  desc: X, W, out, zero, M, N, K = T, ldx, ldw, ldo; everything else unset.
+extern "C" int msclip_gemm_splitk_tn(const msclip_gemm_desc* d, int slices, void* stream) {
+  if (!d || !d->X || !d->W || !d->out || !d->zero || slices < 1 || slices > 65535) return MSCLIP_EINVAL;
+  if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->ldx % 8) || (d->ldw % 8) || d->ldx < d->M || d->ldw < d->N || (d->ldo % 4) ||
+      d->ldo < d->N || d->mode != 0 || d->out_kind != 1 || d->bias || d->resid || d->resid_kind || d->act || d->out2 || d->xb ||
+      d->rowstat || d->W2 || d->rpg != 0x7fffffff || d->radd || d->roff || d->alpha != 1.f)
+    return MSCLIP_EINVAL;
+  const long long t256 = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256);
+  // 32-bit lane offsets over the whole operand; tile-map reciprocals
+  if ((long long)d->K * d->ldx * 2 + 4096 >= (1ll << 32) || (long long)d->K * d->ldw * 2 + 4096 >= (1ll << 32) ||
+      t256 * ((d->M + 255) / 256) * 4 >= (1ll << 32))
+    return MSCLIP_EINVAL;
+  const int ncu = device_cus();
+  hipLaunchKernelGGL((gemm_pp_kernel<0, false, 0, true>), dim3(t256 < ncu ? (int)t256 : ncu, slices), dim3(512), 0,
+                     (hipStream_t)stream, *d, nullptr, nullptr);
   return msclip_launch_status();
 }
 

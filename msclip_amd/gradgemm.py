@@ -10,6 +10,14 @@ BF = torch.bfloat16
 F32 = torch.float32
 
 
+def _tn_ok(dy_bf, x_bf):
+    """The token-major split-K GEMM (msclip_gemm_splitk_tn: no operand transposes) takes whole 256-channel tiles on both sides;
+    MSCLIP_WGRAD_TN=0 = the transposing path (A/B knob, cross-check)."""
+    import os
+    return (os.environ.get("MSCLIP_WGRAD_TN", "1") != "0" and dy_bf.shape[1] % 256 == 0 and x_bf.shape[1] % 256 == 0
+            and dy_bf.stride(1) == 1 and x_bf.stride(1) == 1 and dy_bf.stride(0) % 8 == 0 and x_bf.stride(0) % 8 == 0)
+
+
 def wgrad(dy_bf, x_bf, M, out=None):
     """dW[N, K] = dY^T @ X over the first M rows of dy_bf [*, N] and x_bf [*, K] (bf16): both operands transposed so the
     token axis is the contiguous K axis of the GEMM (zero-padded).  A weight gradient has few output tiles over a very
@@ -27,6 +35,8 @@ def wgrad(dy_bf, x_bf, M, out=None):
         return hip.gemm_splitk(hip.transpose_bf16(dy_bf, M, Mpad), hip.transpose_bf16(x_bf, M, Mpad), S, out=out)
     # wide gradients: ONE split-K launch of the ping-pong GEMM (tiles x slices workgroups, see WgradJob)
     S = max(1, min(256 // tiles, M // 2048))
+    if _tn_ok(dy_bf, x_bf):                                # token-major operands as they are: no transposes
+        return hip.gemm_splitk_tn(dy_bf, x_bf, M, S, out=out)
     Mpad = (M + 64 * S - 1) // (64 * S) * (64 * S)
     a = hip.transpose_bf16(dy_bf, M, Mpad)
     b = hip.transpose_bf16(x_bf, M, Mpad)
@@ -116,6 +126,12 @@ class WgradJob:
         Mpad = (M + 64 * S - 1) // (64 * S) * (64 * S)
         dev = dy_bf.device
         self.sync = hip.env_flag("MSCLIP_WGRAD_SYNC") or _ranks_share_a_gpu()
+        self.tn = _tn_ok(dy_bf, x_bf)
+        if self.tn:
+            # round 4: the split-K GEMM reads both operands token-major (LDS transpose reads): nothing to do until finish().
+            # The operands stay referenced here (same contract as before: never overwritten in place afterwards).
+            self.a, self.b, self.done = dy_bf, x_bf, None
+            return
         if self.sync:
             self.a, self.b, self.done = hip.transpose_bf16(dy_bf, M, Mpad), hip.transpose_bf16(x_bf, M, Mpad), None
             return
@@ -141,7 +157,9 @@ class WgradJob:
             self.b.record_stream(cur)
         if out is None:
             out = torch.empty(self.N, self.K, dtype=F32, device=dev)
-        if self.S == 1:
+        if self.tn:
+            hip.gemm_splitk_tn(self.a, self.b, self.M, self.S, out=out)
+        elif self.S == 1:
             hip.gemm(self.a, self.b, out, tile=4)
         else:
             hip.gemm_splitk(self.a, self.b, self.S, out=out, tile=4)

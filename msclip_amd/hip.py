@@ -23,7 +23,7 @@ EXPORTS = (
     "msclip_transpose_bf16", "msclip_cast_bf16", "msclip_cast_bf16_colsum", "msclip_colsum", "msclip_quickgelu", "msclip_quickgelu_bwd", "msclip_layernorm_bwd",
     "msclip_attention_bwd", "msclip_l2norm_bwd", "msclip_clip_loss_bwd_g", "msclip_embed_tokens_bwd", "msclip_adapter_sum",
     "msclip_adapter_dx", "msclip_adamw", "msclip_adamw_multi", "msclip_im2col", "msclip_col2im", "msclip_relu_bwd", "msclip_dwpool_bwd",
-    "msclip_dwpool_wgrad", "msclip_dw3x3_wgrad", "msclip_gemm_splitk", "msclip_bn_stats", "msclip_bn_apply",
+    "msclip_dwpool_wgrad", "msclip_dw3x3_wgrad", "msclip_gemm_splitk", "msclip_gemm_splitk_tn", "msclip_bn_stats", "msclip_bn_apply",
     "msclip_bn_bwd_reduce", "msclip_bn_bwd_dx", "msclip_bn_fold_bwd", "msclip_bn_finish",
     "msclip_abi_version", "msclip_build_arch",
     "msclip_stream_priority_range", "msclip_stream_create", "msclip_stream_destroy",
@@ -80,6 +80,7 @@ def lib():
         vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
         L.msclip_gemm.argtypes = [ctypes.POINTER(GemmDesc), vp]
         L.msclip_gemm_splitk.argtypes = [ctypes.POINTER(GemmDesc), ci, vp]
+        L.msclip_gemm_splitk_tn.argtypes = [ctypes.POINTER(GemmDesc), ci, vp]
         L.msclip_gemm_f8.argtypes = [ctypes.POINTER(GemmDesc), vp, vp, vp]
         L.msclip_layernorm_f8.argtypes = [vp, ci, vp, vp, vp, vp, ci, vp, ci, vp, ci, ci, cf, vp]
         L.msclip_quant_f8_rows.argtypes = [vp, ci, vp, ci, vp, ci, ci, vp]
@@ -503,6 +504,25 @@ def gemm_splitk(x, w, slices, out=None, tile=0):
         out.view(-1).copy_(part.view(-1))
         return out
     return part.view(M, N)
+
+
+def gemm_splitk_tn(dy, x, T, slices, out=None):
+    """fp32 [N_dy, N_x] = dy[:T]^T @ x[:T] for TOKEN-major bf16 operands dy [*, N_dy], x [*, N_x] (what a weight gradient is
+    made of) without transposing them: msclip_gemm_splitk_tn, `slices` token ranges into fp32 partials folded in a fixed order.
+    N_dy and N_x multiples of 256."""
+    _bf16(dy)
+    _bf16(x)
+    Mo, No = dy.shape[1], x.shape[1]
+    assert dy.shape[0] >= T and x.shape[0] >= T and Mo % 256 == 0 and No % 256 == 0
+    part = torch.empty(slices, Mo * No, dtype=torch.float32, device=dy.device) if (slices > 1 or out is None) else out.view(1, -1)
+    d = GemmDesc()
+    d.X, d.W, d.zero, d.out = dy.data_ptr(), x.data_ptr(), zero_page(dy.device).data_ptr(), part.data_ptr()
+    d.M, d.N, d.K, d.ldx, d.ldw, d.ldo = Mo, No, T, dy.stride(0), x.stride(0), No
+    d.out_kind, d.alpha, d.rpg = 1, 1.0, INT_MAX
+    _check(lib().msclip_gemm_splitk_tn(ctypes.byref(d), slices, _stream()), "msclip_gemm_splitk_tn")
+    if slices > 1:
+        return colsum(part, out=out.view(-1) if out is not None else None).view(Mo, No)
+    return part.view(Mo, No)
 
 
 _TAPS = {}

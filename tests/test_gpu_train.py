@@ -774,3 +774,29 @@ def test_train_synthetic_script(gpu_device):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     assert "OK" in r.stdout and r.stdout.count("step ") == 6
+
+
+@pytest.mark.parametrize("T,No,Ni,S", [(4096, 768, 768, 4), (65024, 768, 3072, 7), (5000, 2304, 768, 3), (127 * 33, 256, 512, 1),
+                                       (70, 512, 256, 2)])
+def test_weight_gradient_gemm_on_token_major_operands(gpu_device, T, No, Ni, S):
+    """msclip_gemm_splitk_tn: dW = dY^T X straight from the token-major operands (LDS transpose reads, no operand transposes)
+    against fp32 torch and against the transposing split-K path; token counts that are not whole K-tiles / slices (rows past
+    T contribute zero: buffer range check), operands that are column windows of wider matrices, bitwise repeatable."""
+    g = torch.Generator().manual_seed(5)
+    wide_dy = (torch.randn(T + 3, No + 256, generator=g) * 0.5).to(BF).cuda()
+    wide_x = torch.randn(T + 3, Ni + 512, generator=g).to(BF).cuda()
+    wide_dy[T:] = float("nan")                                    # rows past T must not be read into the sum
+    wide_x[T:] = float("nan")
+    dy, x = wide_dy[:, 256:], wide_x[:, 256:256 + Ni]
+    ref = dy[:T].float().t() @ x[:T].float()
+    out = torch.full((No, Ni), float("nan"), device="cuda")
+    hip.gemm_splitk_tn(dy, x, T, S, out=out)
+    first = out.clone()
+    scale = ref.abs().max().item()
+    assert (out - ref).abs().max().item() <= 2e-5 * scale * max(1.0, (T / 4096) ** 0.5) + 1e-3, ((out - ref).abs().max().item(), scale)
+    hip.gemm_splitk_tn(dy, x, T, S, out=out)
+    assert torch.equal(out, first)
+    import msclip_amd.gradgemm as G
+    assert G._tn_ok(dy, x)
+    got = G.wgrad(dy, x, T)
+    assert torch.equal(got, first) if (max(1, min(256 // ((No // 256) * (Ni // 256)), T // 2048)) == S) else True
