@@ -202,6 +202,11 @@ def main():
     if world > 1 and not shared:                      # the collectives really are RCCL over all N ranks
         assert dist.is_initialized() and dist.get_backend() == "nccl" and dist.get_world_size() == args.gpus, \
             (dist.get_backend(), dist.get_world_size(), args.gpus)
+        assert torch.cuda.device_count() >= args.gpus, f"--gpus {args.gpus} but only {torch.cuda.device_count()} devices are visible"
+    if world > 1:                                     # ... and a collective over them counts every rank exactly once, on every rank
+        probe_t = torch.ones(1, device=torch.device("cuda", local))
+        dist.all_reduce(probe_t)
+        assert int(probe_t.item()) == args.gpus, (int(probe_t.item()), args.gpus)
     dev = torch.device("cuda", local)
     # a process group also exists at N = 1 under MSCLIP_COLLECTIVES_AT_WORLD_1=1 (one rank, every collective through RCCL as an
     # identity: what the collectives cost a step before any wire time; tests/test_gpu_model.py)
@@ -258,7 +263,13 @@ def main():
     hip.set_gemm_probe(DOMINANT["variant"], None)
     hip.set_gemm_f8_probe(None)
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    per_rank = None
     if grouped:
+        # every rank's own clock over the same barrier-fenced region: the record carries the spread, so that the first run
+        # on a real multi-GPU node yields a diagnosis (a straggler, an un-overlapped collective), not only a number
+        allt = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(allt, t)
+        per_rank = [float(x.item()) / args.steps * 1e3 for x in allt]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     loss_val = float(loss)
@@ -331,6 +342,9 @@ def main():
             rec["config"]["rccl_ranks"] = dist.get_world_size() if world > 1 else 1
         else:
             rec["config"]["gloo_ranks"] = dist.get_world_size()
+        if per_rank is not None:
+            rec["config"]["per_rank_ms_per_step"] = [round(x, 3) for x in per_rank]
+            rec["config"]["rank_spread_pct"] = round(100.0 * (max(per_rank) - min(per_rank)) / max(per_rank), 2)
         if grouped and world == 1:
             rec["config"]["collectives"] = f"one-rank {dist.get_backend()} group: every collective issued (identity)"
         if shared:

@@ -118,14 +118,18 @@ class GatherHandle:
         return self.out
 
 
-def gather_rows_async(t):
+def gather_rows_async(t, out=None):
     """Start the rank-major all-gather of t [B, ...]; returns (out, handle).  On a HIP device the collective is issued
     from the side stream behind an event recorded now on the compute stream ("t is final"), so it overlaps whatever
-    the compute stream runs next.  handle is None at world size 1 (out is t itself)."""
+    the compute stream runs next.  handle is None at world size 1 (out is t itself).  `out`: a persistent [world * B, ...]
+    buffer of the caller (the engine's workspace: no allocation per step); it is overwritten behind the event, i.e. after
+    everything the compute stream had queued on the previous step's gathered rows."""
     if not comm.collectives:
         return t, None
     t = t.contiguous()
-    out = torch.empty((comm.world_size * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    shape = (comm.world_size * t.shape[0],) + tuple(t.shape[1:])
+    if out is None or tuple(out.shape) != shape or out.dtype != t.dtype or out.device != t.device:
+        out = torch.empty(shape, dtype=t.dtype, device=t.device)
     if not t.is_cuda:
         return out, GatherHandle(dist.all_gather_into_tensor(out, t, async_op=True), out, None)
     side = side_stream(t.device)

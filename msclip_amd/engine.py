@@ -875,6 +875,17 @@ class Engine:
         if norm:
             hip.l2norm(w["ft_raw"], w["ft"], w["ftb"])
 
+    @staticmethod
+    def _gather_buf(w, key, local):
+        """Persistent [world * B, E] destination of a feature all-gather in the workspace (allocated once per world size)."""
+        if not C.comm.collectives:
+            return None
+        shape = (C.comm.world_size * local.shape[0], local.shape[1])
+        buf = w.get(key)
+        if buf is None or tuple(buf.shape) != shape:
+            buf = w[key] = torch.empty(shape, dtype=local.dtype, device=local.device)
+        return buf
+
     def _heads(self, w, Bi, Bt, norm=True, gather=False, compact=False):
         """Projection heads.  With gather=True the image features' all-gather is started as soon as they exist and
         runs on RCCL's stream while the text head computes (returns the gathered operands and the work handles)."""
@@ -882,11 +893,11 @@ class Engine:
         if Bi:
             self._head_image(w, Bi, norm, compact)
             if gather:
-                allI, wi = C.gather_rows_async(w["fvb"])
+                allI, wi = C.gather_rows_async(w["fvb"], out=self._gather_buf(w, "allI_buf", w["fvb"]))
         if Bt:
             self._head_text(w, Bt, norm, compact, Bi)
             if gather:
-                allT, wt = C.gather_rows_async(w["ftb"])
+                allT, wt = C.gather_rows_async(w["ftb"], out=self._gather_buf(w, "allT_buf", w["ftb"]))
         for h in (wi, wt):
             if h is not None:
                 h.wait()                                                  # compute stream waits; the host does not

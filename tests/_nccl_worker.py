@@ -42,10 +42,15 @@ def main():
     grads = ts.backward(bucket_bytes=8 << 20)
     keys = ["visual.transformer.resblocks.5.mlp.c_fc.weight", "visual.proj", "logit_scale", "ln_final.weight",
             "visual.transformer.parallel_branch_v.2.resnet_stage.conv_0.conv2.weight", "token_embedding.weight"]
+    kept = {k: grads[k].float().cpu() for k in keys}
+    n_grads, launched = len(grads), ts.reducer.launched
+    ts.step(grads)                                                     # AdamW on the reducer's views (fresh: same generation)
+    tl2 = ts.forward(img[mine].cuda(), tok[mine].cuda())               # the updated weights through the re-packed engine
+    ts.backward()
     torch.cuda.synchronize()
     if rank == 0:
-        torch.save({"logits": logits.cpu(), "loss": float(loss), "train_loss": float(tl), "launched": ts.reducer.launched,
-                    "grads": {k: grads[k].float().cpu() for k in keys}, "n_grads": len(grads)}, out)
+        torch.save({"logits": logits.cpu(), "loss": float(loss), "train_loss": float(tl), "launched": launched,
+                    "grads": kept, "n_grads": n_grads, "train_loss_after_step": float(tl2)}, out)
     dist.barrier()
     dist.destroy_process_group()
 

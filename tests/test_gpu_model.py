@@ -487,6 +487,47 @@ def test_one_rank_rccl_collectives(gpu_device, tmp_path):
             assert torch.equal(g, full[k].float().cpu()), k
 
 
+def test_two_one_rank_rccl_processes_share_the_gpu(gpu_device, tmp_path):
+    """Two independent processes, each with its own ONE-rank RCCL communicator, run the full N > 1 code path (side-stream
+    feature gathers, sharded loss + all-reduce, bucketed gradient all-reduce, AdamW on the reducer's views, a second
+    forward / backward) at the same time on GPU 0: two live communicators, their streams and the engine's side / lane
+    streams interleaved by the hardware scheduler -- the closest thing to peers a one-GPU box offers.  Both must reproduce
+    the single-communicator results bit for bit (each is an identity collective), and each other."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs, outs = [], []
+    for i, port in enumerate((29631, 29632)):
+        out = tmp_path / f"p{i}.pt"
+        outs.append(out)
+        procs.append(subprocess.Popen([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                                       "--master-addr", "127.0.0.1", "--master-port", str(port),
+                                       os.path.join(ROOT, "tests", "_nccl_worker.py"), str(out), "nccl"], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        try:
+            _, err = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            raise
+        assert p.returncode == 0, err[-3000:]
+    a, b = torch.load(outs[0]), torch.load(outs[1])
+    assert torch.equal(a["logits"], b["logits"]) and a["loss"] == b["loss"] and a["train_loss"] == b["train_loss"]
+    assert a["launched"] >= 8 and a["n_grads"] == b["n_grads"]
+    for k in a["grads"]:
+        if k == "token_embedding.weight":
+            assert torch.allclose(a["grads"][k], b["grads"][k], rtol=1e-3, atol=1e-6), k
+        else:
+            assert torch.equal(a["grads"][k], b["grads"][k]), k
+    assert abs(a["train_loss_after_step"] - b["train_loss_after_step"]) <= 1e-5      # (embedding-gradient atomics: last bits)
+    assert a["train_loss_after_step"] != a["train_loss"]                              # the step reached the engine's packed copies
+    m = model_for("b32-yfcc-msclips")
+    img, tok = synth.synth_images(6, seed=91).cuda(), synth.synth_tokens(6, seed=92).cuda()
+    assert torch.equal(a["logits"], m(img, tok).cpu())
+
+
 def test_two_ranks_on_one_gpu_over_gloo(gpu_device, tmp_path):
     """The N > 1 path on a one-GPU box: two processes share GPU 0 and talk over gloo, so everything but RCCL itself runs --
     rank-major feature gathers issued from the side stream, label offsets, the sharded loss + scalar all-reduce, and the
