@@ -471,6 +471,18 @@ class TrainStep:
             return reducer.finish(clone=clone) if reducer is not None else dict(grads)
 
     # ------------------------------------------------------------------ optimizer
+    def set_epoch(self, epoch):
+        """Apply the yaml's learning-rate schedule (self.schedule, train.from_config) for `epoch` to both parameter groups'
+        base rates; the next step() re-points the optimizer table's rates.  No-op without a schedule."""
+        sch = getattr(self, "schedule", None)
+        if sch is None:
+            return
+        if not hasattr(self, "_base_lr"):
+            self._base_lr = (self.lr, self.lr_share)
+        base, base_sh = self._base_lr
+        self.lr = sch.lr_at(base, epoch)
+        self.lr_share = None if base_sh is None else sch.lr_at(base_sh, epoch)
+
     def param_groups(self):
         """(name, parameter, lr, weight_decay) for every parameter: module-level param_groups() with this step's settings."""
         return param_groups(self.model, self.lr, self.lr_share, self.wd, self.wd_share, self.without_wd)
@@ -655,7 +667,49 @@ def from_config(model, config, bn="batch"):
     CUSTOM.LR_SHARE / WD_SHARE for the modality-shared tensors (already scaled with the world size by update_config,
     lib/config/default.py:299-304).
     bn = "batch" (default): train-mode BatchNorm as the reference's modules run in train(); "frozen": running statistics."""
-    return TrainStep(model, bn=bn, **optimizer_settings(config))
+    ts = TrainStep(model, bn=bn, **optimizer_settings(config))
+    ts.schedule = lr_schedule(config)            # TRAIN.LR_SCHEDULER of the yaml (None when the config has none)
+    return ts
+
+
+class CosineSchedule:
+    """TRAIN.LR_SCHEDULER {METHOD: 'timm', ARGS: {sched: 'cosine', ...}} of the reference yamls (experiments/model/b32.yaml:40-48;
+    lib/config/default.py:306-308 adds ARGS.epochs = TRAIN.END_EPOCH and hands ARGS to timm's create_scheduler in the unreleased
+    trainer).  timm's CosineLRScheduler stepped once per EPOCH (t_in_epochs), one cycle, no warm-up prefix:
+        t <  warmup_epochs:  lr = warmup_lr + t * (base - warmup_lr) / warmup_epochs
+        t <  epochs:         lr = min_lr + 0.5 * (base - min_lr) * (1 + cos(pi * t / epochs))
+        t >= epochs:         lr = min_lr        (the cooldown_epochs run at min_lr; the run lasts epochs + cooldown_epochs)
+    applied to every parameter group's own base rate (TRAIN.LR for the modality-specific tensors, CUSTOM.LR_SHARE for the shared)."""
+
+    def __init__(self, epochs, warmup_epochs=0, warmup_lr=0.0, min_lr=0.0, cooldown_epochs=0, decay_rate=0.1):
+        self.epochs, self.warmup_epochs, self.warmup_lr, self.min_lr = int(epochs), int(warmup_epochs), float(warmup_lr), float(min_lr)
+        self.cooldown_epochs, self.decay_rate = int(cooldown_epochs), float(decay_rate)      # (decay_rate only acts on later cycles: one cycle here)
+        self.total_epochs = self.epochs + self.cooldown_epochs
+
+    def lr_at(self, base, epoch):
+        import math
+        t = int(epoch)
+        if t < self.warmup_epochs:
+            return self.warmup_lr + t * (base - self.warmup_lr) / self.warmup_epochs
+        if t < self.epochs:
+            return self.min_lr + 0.5 * (base - self.min_lr) * (1.0 + math.cos(math.pi * t / self.epochs))
+        return self.min_lr
+
+
+def lr_schedule(config):
+    """The scheduler block of a reference config (needs no GPU); None when TRAIN.LR_SCHEDULER is absent."""
+    tr = config.TRAIN
+    sch = tr.get("LR_SCHEDULER", None)
+    if not sch or not sch.get("METHOD", None):
+        return None
+    if str(sch.METHOD) != "timm":
+        raise NotImplementedError(f"TRAIN.LR_SCHEDULER.METHOD = {sch.METHOD!r}: the released configs use 'timm' (cosine)")
+    a = dict(sch.get("ARGS", None) or {})
+    if str(a.get("sched", "cosine")) != "cosine":
+        raise NotImplementedError(f"TRAIN.LR_SCHEDULER.ARGS.sched = {a.get('sched')!r}: only timm's cosine schedule is implemented")
+    return CosineSchedule(epochs=a.get("epochs", tr.get("END_EPOCH", 0)), warmup_epochs=a.get("warmup_epochs", 0),
+                          warmup_lr=a.get("warmup_lr", 0.0), min_lr=a.get("min_lr", 0.0),
+                          cooldown_epochs=a.get("cooldown_epochs", 0), decay_rate=a.get("decay_rate", 0.1))
 
 
 def optimizer_settings(config):

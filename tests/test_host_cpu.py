@@ -344,3 +344,23 @@ def test_optimizer_block_matches_reference_yaml_literals():
     oa = named_config("b32-yfcc-msclips", ["TRAIN.OPTIMIZER_ARGS.betas", "[0.9, 0.98]", "TRAIN.OPTIMIZER_ARGS.eps", "1e-6"])
     st2 = train.optimizer_settings(oa)
     assert st2["betas"] == (0.9, 0.98) and st2["eps"] == 1e-6
+
+
+def test_lr_schedule_matches_timm_cosine_with_the_reference_yaml_literals():
+    """TRAIN.LR_SCHEDULER of the reference yaml (experiments/model/b32.yaml:40-48: timm cosine, warm-up 5 epochs from 1e-6,
+    floor 1e-5, 10 cool-down epochs; lib/config/default.py:306-308 sets ARGS.epochs = END_EPOCH = 50) through
+    train.lr_schedule: expected values are timm's CosineLRScheduler formula evaluated by hand on the yaml's literals."""
+    import math
+    from msclip_amd import train
+    sch = train.lr_schedule(named_config("b32-yfcc-msclips"))
+    assert (sch.epochs, sch.warmup_epochs, sch.warmup_lr, sch.min_lr, sch.cooldown_epochs, sch.total_epochs) == (50, 5, 1e-6, 1e-5, 10, 60)
+    base = 1e-4
+    assert sch.lr_at(base, 0) == 1e-6                                            # warm-up starts at warmup_lr ...
+    assert abs(sch.lr_at(base, 3) - (1e-6 + 3 * (1e-4 - 1e-6) / 5)) < 1e-12      # ... and climbs linearly
+    assert abs(sch.lr_at(base, 5) - (1e-5 + 0.5 * 9e-5 * (1 + math.cos(math.pi * 5 / 50)))) < 1e-12   # no warm-up prefix: t is the epoch
+    assert abs(sch.lr_at(base, 25) - (1e-5 + 0.5 * 9e-5)) < 1e-12                # half way down the cosine
+    assert sch.lr_at(base, 50) == 1e-5 and sch.lr_at(base, 59) == 1e-5           # cool-down at the floor
+    assert abs(sch.lr_at(0.0016, 25) - (1e-5 + 0.5 * (0.0016 - 1e-5))) < 1e-12   # each group's own base rate (CUSTOM.LR_SHARE)
+    cfg = named_config("b32-yfcc-msclips", ["TRAIN.LR_SCHEDULER.METHOD", "MultiStep"])
+    with pytest.raises(NotImplementedError):
+        train.lr_schedule(cfg)

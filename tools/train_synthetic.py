@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--nbatches", type=int, default=2, help="distinct synthetic batches cycled through")
     ap.add_argument("--bn", choices=("batch", "frozen"), default="batch")
     ap.add_argument("--lr", type=float, default=2e-5)
+    ap.add_argument("--steps-per-epoch", type=int, default=0,
+                    help="> 0: follow the yaml's TRAIN.LR_SCHEDULER (timm cosine + warm-up, train.CosineSchedule) with this many steps per epoch")
     args = ap.parse_args()
     from msclip_amd import comm as C, synth, train
     from msclip_amd.clip_openai_pe_res_v1 import get_clip_model
@@ -38,13 +40,15 @@ def main():
     model.load_state_dict(synth.synth_state_dict(load_schema(args.model), seed=0), strict=True)
     model = model.to(dev).eval()
     ts = train.from_config(model, cfg, bn=args.bn)
-    ts.lr = ts.lr_share = args.lr
+    ts.lr = ts.lr_share = args.lr                          # (the schedule scales these base rates epoch by epoch)
     rank = C.comm.rank
     data = [(synth.synth_images(args.batch, seed=1000 * rank + 10 + i).to(dev),
              synth.synth_tokens(args.batch, seed=1000 * rank + 100 + i).to(dev)) for i in range(args.nbatches)]
     losses = []
     for step in range(args.steps):
         img, tok = data[step % args.nbatches]
+        if args.steps_per_epoch > 0 and step % args.steps_per_epoch == 0:
+            ts.set_epoch(step // args.steps_per_epoch)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         loss = ts.forward(img, tok)
