@@ -519,7 +519,16 @@ def test_gradients_against_reference_autograd(gpu_device, name):
           "conv cosine", min(coss[k] for k in conv_keys if k in coss), "/", dev["conv_side"]["cosine_lowest"])
     assert float(np.median([worst[k] for k in tok_keys])) <= 1.25 * dev["token_side"]["sample_err_median"] + 5e-3
     assert float(np.median([worst[k] for k in conv_keys])) <= 1.25 * dev["conv_side"]["sample_err_median"] + 5e-3
-    assert max(worst[k] for k in conv_keys) <= dev["conv_side"]["sample_err_worst"] + (0.0 if name.startswith("b32") else 5e-2)
+    top = sorted(((worst[k], k) for k in conv_keys), reverse=True)[:3]
+    print(name, "worst conv-side tensors:", top)
+    # no blanket slack.  Every conv-side tensor stays inside the reference's own worst bf16 deviation, except -- on
+    # ViT-B/16 -- the bias gradient shared by bn3 / residual_bn of the first bottleneck of the parallel branch (one number per
+    # channel: the sum of a bf16 gradient map over 4 x 56 x 56 pixels whose terms nearly cancel; 21 % against the reference's
+    # 18 % worst tensor): those two keys get 4 % of abs-max on top, by name.
+    scoped = {"visual.transformer.parallel_branch_v.1.resnet_stage.conv_0.residual_bn.bias": 4e-2,
+              "visual.transformer.parallel_branch_v.1.resnet_stage.conv_0.bn3.bias": 4e-2} if name.startswith("b16") else {}
+    for k in conv_keys:
+        assert worst[k] <= dev["conv_side"]["sample_err_worst"] + scoped.get(k, 0.0), (k, worst[k])
     assert min(coss[k] for k in conv_keys if k in coss) >= dev["conv_side"]["cosine_lowest"] - 5e-3
     # the shared tensors' gradients are sums over both towers: a text-only / image-only backward must give less
     assert len([k for k in expect if "visual.transformer.resblocks" in k and ".attn." in k]) == 11 * 4
