@@ -2,13 +2,10 @@
 # Build probe copies of libmsclip_hip.so with -D knobs on ONE source file (A/B runs in one GPU call; never shipped).
 #   usage: [ABL_FILE=front] build_ablations.sh name1 "-DX -DY" name2 "-DZ" ...     (default file: gemm)
 set -u
-SRC=/root/repo/msclip_amd/csrc   # gemm ablations (-DPP_*): build tools/probes/gemm_pp_probes.hip (the instrumented round-1/2 snapshot of gemm.hip) via ABL_SRC
+SRC=/root/repo/msclip_amd/csrc   # -D switches act on the PRODUCT source of the chosen file (round 4: the instrumented snapshots of rounds 1-3 are gone)
 OUT=/root/repo/tools/probes
 FILE=${ABL_FILE:-gemm}
-# the instrumented snapshots live beside this script: gemm_pp_probes.hip (-DPP_* / -DMSCLIP_ABLATE_* knobs of the ping-pong
-# kernel) and gemm_w4_probes.hip (-DW4_PROBE_NOEPI / _DROPSTORES / _RAWSTORE of the 4-wave kernel); the product sources
-# under msclip_amd/csrc carry no probe code.
-case $FILE in gemm) PSRC=$OUT/gemm_pp_probes.hip;; gemm_w4) PSRC=$OUT/gemm_w4_probes.hip;; *) PSRC=$SRC/$FILE.hip;; esac
+PSRC=$SRC/$FILE.hip
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffast-math -fno-finite-math-only -Wno-unused-value"
 OTHERS=$(ls $SRC/build/*.o | grep -v "/$FILE.o")
 build() {  # name, defines
