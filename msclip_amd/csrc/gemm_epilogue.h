@@ -204,7 +204,10 @@ __device__ __forceinline__ void epilogue_rows_stats(f32x4 (&acc)[2 * TN][2 * TM]
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const size_t row = (size_t)(mw0 + tm * 32 + i * 8 + srow);
-      dst[i] = ld_global_f4((const float*)a.resid + row * a.ldr + nw0 + tn * 32 + sch * 4);
+      // non-temporal: with the fold nobody re-reads the fp32 stream soon (no LayerNorm pass behind this launch), so it should
+      // not take the MALL from the bf16 operand the next projection reads (same-box A/B, loads + stores: +0.5-0.9 % on the step)
+      const f32x4 t = __builtin_nontemporal_load((const AS1 f32x4*)((const float*)a.resid + row * a.ldr + nw0 + tn * 32 + sch * 4));
+      dst[i] = make_float4(t[0], t[1], t[2], t[3]);
     }
   };
 #pragma unroll
@@ -261,7 +264,7 @@ __device__ __forceinline__ void epilogue_rows_stats(f32x4 (&acc)[2 * TN][2 * TM]
       const float4 v = make_float4(xb[i][0] + bias4[tn].x + r.x, xb[i][1] + bias4[tn].y + r.y, xb[i][2] + bias4[tn].z + r.z,
                                    xb[i][3] + bias4[tn].w + r.w);
       const size_t row = (size_t)(mw0 + tm * 32 + i * 8 + srow);
-      st_global((float*)a.out + row * a.ldo + n, v);
+      __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, (AS1 f32x4*)((float*)a.out + row * a.ldo + n));
       const float c = cen[i];
       const float d0 = v.x - c, d1 = v.y - c, d2 = v.z - c, d3 = v.w - c;
       uint2 o;

@@ -414,6 +414,10 @@ def gemm(x, w, out, *, M=None, bias=None, resid=None, resid_kind=0, act=0, alpha
         x_bytes = d.M * d.K * 2 if conv is None else (d.M // (conv[3] * conv[4])) * conv[0] * conv[1] * conv[2] * 2
         r_bytes = {RESID_NONE: 0, RESID_F32: d.M * d.N * 4, RESID_BF16: d.M * d.N * 2, RESID_TABLE: 0, RESID_GELUGRAD: d.M * d.N * 2}[resid_kind]
         nbytes = x_bytes + d.N * d.K * 2 + d.M * d.N * esz * (2 if out2 is not None else 1) + r_bytes + (d.N * 4 if bias is not None else 0)
+        if fold_out is not None:                      # bf16 centred copy + per-64-column partial sums + the rows' centres
+            nbytes += d.M * d.N * 2 + d.M * (d.N // 64) * 8 + d.M * 4
+        if fold_in is not None:                       # (rstd, mean * rstd) per row, per tile column; second weight
+            nbytes += d.M * 8 * ((d.N + 255) // 256) + (d.N * d.K * 2 if fold_in.w2 is not None else 0)
         probe.end(t0, 2.0 * d.M * d.N * k_alg, (d.M, d.N, d.K, k_alg, conv is not None, act, resid_kind, d.out_kind), nbytes)
         return out
     _check(lib().msclip_gemm(ctypes.byref(d), _stream()), "msclip_gemm")

@@ -21,7 +21,7 @@ rows.sort(key=lambda r:int(r["Start_Timestamp"]))
 d=collections.defaultdict(list)
 for r in rows:
     n=r["Kernel_Name"]
-    if "gemm_pp_kernel<0, false>" in n:
+    if "gemm_pp_kernel<0, false" in n:
         d["pp0"].append((int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3)
 v=sorted(d["pp0"]); n=len(v)
 print("$mode", n, "min %.0f p10 %.0f p25 %.0f med %.0f p75 %.0f p90 %.0f max %.0f mean %.1f"%(v[0],v[n//10],v[n//4],v[n//2],v[3*n//4],v[int(n*.9)],v[-1],sum(v)/n))
