@@ -504,7 +504,7 @@ template <int MODE, bool F8 = false, int EPI = 0, bool TNL = false>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a_in, const float* __restrict__ row_scale,
                                                       const float* __restrict__ col_scale) {
   static_assert(!(F8 && MODE == 1), "fp8 operands: dense GEMM only");
-  static_assert(EPI == 0 || (MODE == 0 && !F8), "LayerNorm fold: dense bf16 GEMM only");
+  static_assert(EPI == 0 || (MODE == 0 && (!F8 || EPI == 2)), "LayerNorm fold: dense GEMM; fp8 operands as the producer only");
   static_assert(!TNL || (MODE == 0 && !F8 && EPI == 0), "token-major operands: dense bf16 GEMM, plain epilogues");
   // Split-K launches (msclip_gemm_splitk with tile = 4; the weight gradients of the training step): blockIdx.y = K slice;
   // slice s contracts columns [s*K/S, (s+1)*K/S) of both operands into its own fp32 matrix out[s][M][ldo].  A weight
@@ -1130,7 +1130,8 @@ extern "C" int msclip_gemm_splitk_tn(const msclip_gemm_desc* d, int slices, void
 extern "C" int msclip_gemm_f8(const msclip_gemm_desc* d, const float* row_scale, const float* col_scale, void* stream) {
   if (!d || !d->X || !d->W || !d->out || !d->zero || !row_scale || !col_scale) return MSCLIP_EINVAL;
   if (d->mode != 0 || d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->K % 128) || (d->ldx % 16) || (d->ldw % 16) || d->ldx < d->K ||
-      d->ldw < d->K || d->rpg != 0x7fffffff || d->out2 || d->out_kind < 0 || d->out_kind > 2 || d->resid_kind < 0 || d->resid_kind > 2)
+      d->ldw < d->K || d->rpg != 0x7fffffff || d->out2 || d->out_kind < 0 || d->out_kind > 2 || d->resid_kind < 0 || d->resid_kind > 2 ||
+      d->rowstat || d->W2)
     return MSCLIP_EINVAL;
   if (d->out_kind == 2 && ((d->M % 256) || (d->N % 16) || (d->ldo % 16) || d->resid_kind || !(d->out_scale > 0.f)))
     return MSCLIP_EINVAL;
@@ -1139,6 +1140,14 @@ extern "C" int msclip_gemm_f8(const msclip_gemm_desc* d, const float* row_scale,
       tiles * ((d->M + 255) / 256) * 4 >= (1ll << 32))
     return MSCLIP_EINVAL;
   const int ncu = device_cus();
+  if (d->xb) {   // c_proj under PRECISION fp8 as the producer of the next block's folded ln_1 (whole tiles, in-place fp32 residual update)
+    if (d->resid_kind != 1 || d->out_kind != 1 || d->act || !d->center || !d->part || (d->M % 256) || (d->N % 256) || (d->ldxb % 4) ||
+        (d->ldo % 4) || (d->ldr % 4))
+      return MSCLIP_EINVAL;
+    hipLaunchKernelGGL((gemm_pp_kernel<0, true, 2>), dim3(tiles < ncu ? (int)tiles : ncu), dim3(512), 0, (hipStream_t)stream, *d,
+                       row_scale, col_scale);
+    return msclip_launch_status();
+  }
   hipLaunchKernelGGL((gemm_pp_kernel<0, true>), dim3(tiles < ncu ? (int)tiles : ncu), dim3(512), 0, (hipStream_t)stream, *d,
                      row_scale, col_scale);
   return msclip_launch_status();

@@ -548,7 +548,7 @@ class Engine:
             hip.gemm(LNC[r0:r1], bw.wfc, HIDC[r0:r1], bias=bw.bfc, act=hip.ACT_QUICKGELU)
             hip.gemm(HIDC[r0:r1], bw.wpr, XC[r0:r1], bias=bw.bpr, resid=XC[r0:r1], resid_kind=hip.RESID_F32)
 
-    def _mlp_f8(self, w, r0, r1, bw):
+    def _mlp_f8(self, w, r0, r1, bw, fold_out=None):
         """c_fc + QuickGELU + c_proj of the rows [r0, r1) under PRECISION fp8 (recipe: DESIGN.md s9, emulated by
         oracle/fp8_recipe.py).  c_fc (e4m3 LayerNorm output x e4m3 weight, per-token x per-channel scales) writes the hidden
         matrix as e4m3 with ONE static scale per layer -- its row maximum spans 16-32 column tiles, so a per-token scale cannot
@@ -565,7 +565,8 @@ class Engine:
         HQ = w["HIDQ"]
         hip.gemm_f8(LNQ[r0:r1], bw.wfc_q, HQ[r0:r1], RS[r0:r1], bw.wfc_s, bias=bw.bfc, act=hip.ACT_QUICKGELU,
                     out_scale=1.0 / bw.hid_scale)
-        hip.gemm_f8(HQ[r0:r1], bw.wpr_q, X[r0:r1], w["ONES"][r0:r1], bw.wpr_cs, bias=bw.bpr, resid=X[r0:r1], resid_kind=hip.RESID_F32)
+        hip.gemm_f8(HQ[r0:r1], bw.wpr_q, X[r0:r1], w["ONES"][r0:r1], bw.wpr_cs, bias=bw.bpr, resid=X[r0:r1], resid_kind=hip.RESID_F32,
+                    fold_out=fold_out)
 
     # ------------------------------------------------------------------ fp8 calibration (PRECISION fp8 / fp8-qkv)
     HID_HEADROOM = 1.25                                   # static hidden scale = HID_HEADROOM * calibrated max |hidden| / 448
@@ -643,7 +644,9 @@ class Engine:
     # ------------------------------------------------------------------ LayerNorm fold
     def _fold_eligible(self, w, Bi, Bt):
         """The fold runs on whole 256-row tiles of the ping-pong GEMM that never straddle the image / text boundary."""
-        if self.fp8 or os.environ.get("MSCLIP_LN_FOLD", "1") == "0" or self.D % 256:
+        # PRECISION fp8 (c_fc / c_proj on the fp8 MFMA): ln_1 still folds -- in_proj is a bf16 consumer, the fp8 c_proj produces;
+        # ln_2 feeds an e4m3 operand with per-token scales (a row maximum: needs the whole row) and keeps its pass.  fp8-qkv: no fold.
+        if self.fp8_qkv or os.environ.get("MSCLIP_LN_FOLD", "1") == "0" or self.D % 256:
             return False
         rows = [n for n in ((w["Mv"] if Bi else 0), (w["M"] - w["Mv"] if Bt else 0)) if n]
         return bool(rows) and all(n % 256 == 0 and n >= 256 * 16 for n in rows)
@@ -751,6 +754,19 @@ class Engine:
             nxt_fold = i + 1 <= n_last and not (i + 1 == n_last and compact and not hip.env_flag("MSCLIP_LAST_BLOCK_ALL_QUERIES"))
             for r0, r1, ms in groups:
                 bw = (self.vblk if ms[0][0] == "v" else self.tblk)[i]["w"]
+                if self.fp8:
+                    # out_proj plain (bf16), ln_2 as the e4m3 LayerNorm pass, MLP on the fp8 MFMA; a calibrated c_proj over whole
+                    # tiles produces the next block's ln_1 operands like the bf16 one
+                    hip.gemm(AO[r0:r1], bw.wo, X[r0:r1], bias=bw.bo, resid=X[r0:r1], resid_kind=hip.RESID_F32)
+                    segs2 = [(m[1], m[2], (self.vblk if m[0] == "v" else self.tblk)[i]) for m in ms]
+                    self._ln_f8(w, segs2, "ln2")
+                    prod = nxt_fold and bw.hid_scale is not None and self._calib is None
+                    self._mlp_f8(w, r0, r1, bw, fold_out=hip.FoldOut(LNO[r0:r1], CEN[r0:r1], PART[r0:r1]) if prod else None)
+                    if prod:
+                        hip.rowstat_finalize(PART[r0:r1], CEN[r0:r1], RST[r0:r1], r1 - r0, D)
+                        for m in ms:
+                            pend[m[0]] = True
+                    continue
                 hip.gemm(AO[r0:r1], bw.wo, X[r0:r1], bias=bw.bo, resid=X[r0:r1], resid_kind=hip.RESID_F32,
                          fold_out=hip.FoldOut(LNO[r0:r1], CEN[r0:r1], PART[r0:r1]))
                 hip.rowstat_finalize(PART[r0:r1], CEN[r0:r1], RST[r0:r1], r1 - r0, D)

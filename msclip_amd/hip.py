@@ -441,7 +441,8 @@ def quantize_rows_f8(w):
     return q.view(torch.uint8).contiguous(), s.contiguous()
 
 
-def gemm_f8(xq, wq, out, row_scale, col_scale, *, M=None, bias=None, resid=None, resid_kind=0, act=0, alpha=1.0, out_scale=1.0):
+def gemm_f8(xq, wq, out, row_scale, col_scale, *, M=None, bias=None, resid=None, resid_kind=0, act=0, alpha=1.0, out_scale=1.0,
+            fold_out=None):
     """out = epilogue(alpha * row_scale[m] * col_scale[n] * xq @ wq^T) on the fp8 MX MFMA; xq uint8 [M, K] / wq uint8 [N, K]
     hold OCP e4m3 bytes, K % 128 == 0.  out uint8: an e4m3 output, stored value = fp8(epilogue value * out_scale)."""
     assert xq.dtype == torch.uint8 and wq.dtype == torch.uint8 and xq.stride(-1) == 1 and wq.stride(-1) == 1
@@ -459,6 +460,11 @@ def gemm_f8(xq, wq, out, row_scale, col_scale, *, M=None, bias=None, resid=None,
     d.out_kind = 1 if out.dtype == torch.float32 else 2 if out.dtype == torch.uint8 else 0
     d.out_scale = out_scale
     d.wg_cap = _WG_CAP[0]
+    if fold_out is not None:                          # c_proj as the producer of the next block's folded ln_1 (FoldOut)
+        f = fold_out
+        _bf16(f.xb)
+        assert f.xb.shape[0] >= d.M and f.center.numel() >= d.M and f.part.numel() >= d.M * (d.N // 64) * 2
+        d.xb, d.ldxb, d.center, d.part = f.xb.data_ptr(), f.xb.stride(0), f.center.data_ptr(), f.part.data_ptr()
     assert row_scale.numel() >= d.M and col_scale.numel() >= d.N
     probe = _f8_probe[0]
     t0 = probe.begin() if probe is not None else None
