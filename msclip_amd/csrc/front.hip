@@ -686,6 +686,12 @@ __global__ __launch_bounds__(512) void front_ws_kernel(FrontArgs a) {
         if constexpr (PROD == 0) {
           const bool ok = 2 * oy0 + so_row[i] < a.Hm && 2 * ox0 + so_col[i] < a.Wm;
           __builtin_amdgcn_raw_buffer_store_b128(sreg[i], rs, ok ? (unsigned)so_off[i] : OOB, tbase, 0);
+          // gfx950 / ROCm 7.2: a buffer store of more than 8 bytes WITH an SGPR offset reads its data VGPRs after issue, and
+          // hipcc re-used the first data register for the next piece's address one instruction later (v_or v170 right behind
+          // buffer_store_dwordx4 v[170:173] ... s50 offen) without the two wait states the ISA asks for: under contention (text
+          // block 0 on another stream) single dwords of the stage-0 map came out wrong -- rare, timing-dependent, 1e-3 on the
+          // image features (round 4, tools/probes/repeat_probe.py).  The data stays live across two idle states instead.
+          asm volatile("s_nop 1" : "+v"(sreg[i]));
         }
       };
       f32x4 acc[MT][3];

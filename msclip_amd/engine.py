@@ -960,7 +960,7 @@ class Engine:
             side_ok = (taps is None and os.environ.get("MSCLIP_CONV_SIDE_STREAM", "1") != "0"
                        and not torch.cuda.is_current_stream_capturing())
             text0 = None
-            if Bi and Bt and side_ok and self.vblk[0] is None:
+            if Bi and Bt and side_ok and self.vblk[0] is None and os.environ.get("MSCLIP_TEXT0_STREAM", "1") != "0":
                 # Text block 0 is text-only (vision slot 0 is the conv stem, M.py:2040-2051) and depends on the captions only:
                 # the text front and that block run on a second side stream beside the image front (HBM-bound conv passes
                 # beside MFMA-bound projections on disjoint rows / buffers of the workspace); the layer loop waits for it.
@@ -981,7 +981,7 @@ class Engine:
                 # default (MSCLIP_CONV_SIDE_STREAM=0 turns it off): +1.6 % pairs/s on B/32, +2.2 % on B/16 same-box.  The GEMM
                 # launches it overlaps measure ~11 % longer each, so bench.py takes its per-kernel roofline from a probe
                 # pass with the inline schedule and reports the overlapped figure beside it.
-                if side_ok and self.lateral and self.lateral == sorted(self.lateral):
+                if side_ok and self.lateral and self.lateral == sorted(self.lateral) and os.environ.get("MSCLIP_BRANCH_STREAM", "1") != "0":
                     conv_events = self._conv_branch_on_side_stream(w, Bi)
             if Bt and text0 is None:
                 self._text_front(self._check_tok(tok), w, Bt)
