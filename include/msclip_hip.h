@@ -77,6 +77,9 @@ typedef struct msclip_gemm_desc {
   void* xb;              /* bf16 [M][ldxb]; NULL: off */
   const float* center;   /* [M] */
   float* part;           /* [M][N / 64][2] */
+  const void* resid2;    /* producer only: rows >= seg_split read their residual from resid2[m][ldr] (m the absolute row) instead of
+                          * resid -- the image rows' stream sits in the lateral adapter's output buffer behind an adapter (M.py:1777)
+                          * while the text rows' is `out` itself; NULL: every row from resid */
 } msclip_gemm_desc;
 
 int msclip_gemm(const msclip_gemm_desc* desc, void* stream);
@@ -159,6 +162,14 @@ int msclip_fill_cls(const float* cls, const float* pos, float* x, int ldx, int B
 int msclip_adapter_combine_ln(const float* xin, int ldx, const float* t, int ldt, const float* dww, const float* dwb,
                               const float* gamma, const float* beta, float* xout, int ldo, int B, int L, int g, int C,
                               int usecls, float eps, void* stream);
+
+/* The same pass followed by the transformer block's ln_1 of each row while it is still in registers (M.py:1777 then :1027):
+ * lno = bf16 LN(xout[m]; gamma1, beta1), and the LayerNorm fold's per-row state as msclip_layernorm_stats leaves it
+ * (center[m] = mean of xout[m], rowstat[m] = (1, 0)).  xout stays the block's fp32 residual stream for these rows. */
+int msclip_adapter_combine_ln_stats(const float* xin, int ldx, const float* t, int ldt, const float* dww, const float* dwb,
+                                    const float* gamma, const float* beta, float* xout, int ldo, const float* gamma1,
+                                    const float* beta1, void* lno, int ldl, float* center, float* rowstat, int B, int L, int g,
+                                    int C, int usecls, float eps, void* stream);
 
 /* y = x / ||x||_2 (M.py:2983, :3076); writes fp32 and/or bf16 copies. */
 int msclip_l2norm(const float* x, int ldx, float* out_f32, int ldf, void* out_bf16, int ldb, int M, int E,

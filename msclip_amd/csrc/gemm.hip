@@ -948,7 +948,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a_i
           epilogue_pack16<TM, TN, 1, true>(acc, a, stg, cm0 + wm, cn0 + wn, lane_e, bcol, a.out, ccol, rstat);   // c_fc + QuickGELU
       } else if constexpr (EPI == 2) {             // whole tiles, in-place fp32 residual update (host-checked)
         epi_stores = 52;                           // 32 fp32 + 16 bf16 full-line stores + 4 stores of row partials per wave
-        epilogue_rows_stats<TM, TN>(acc, a, stg, cm0 + wm, cn0 + wn, lane_e, bcol, rstat4[0], rstat4[2]);
+        // (a tile lies in one row segment: seg_split % 256 == 0; the second segment's residual stream may sit elsewhere)
+        const float* rs = a.resid2 && cm0 >= a.seg_split ? (const float*)a.resid2 : (const float*)a.resid;
+        epilogue_rows_stats<TM, TN>(acc, a, stg, cm0 + wm, cn0 + wn, lane_e, bcol, rstat4[0], rstat4[2], rs);
       } else
       if (vec && plain_rows && cm0 + 256 <= a.M)
       {
@@ -1047,8 +1049,10 @@ static GemmVariant pick_variant(const msclip_gemm_desc* d) {
                  (d->W2 && (!d->csum2 || d->seg_split <= 0 || (d->seg_split % 256) || d->seg_split >= d->M)) || fold_p))
     return GV_INVALID;
   if (fold_p && (d->mode != 0 || d->resid_kind != 1 || d->out_kind != 1 || d->act || d->out2 || !d->center || !d->part ||
-                 (d->M % 256) || (d->N % 256) || (d->ldxb % 4) || (d->ldo % 4) || (d->ldr % 4) || d->rpg != 0x7fffffff))
+                 (d->M % 256) || (d->N % 256) || (d->ldxb % 4) || (d->ldo % 4) || (d->ldr % 4) || d->rpg != 0x7fffffff ||
+                 (d->resid2 && (d->seg_split <= 0 || (d->seg_split % 256) || d->seg_split >= d->M))))
     return GV_INVALID;
+  if (d->resid2 && !fold_p) return GV_INVALID;
   if ((fold_c || fold_p) && d->tile != 4 && d->tile != 0) return GV_INVALID;
   // tile choice: the 256x256 / 8-wave config whenever the problem fills the chip with it, else 128x128
   const long long big_tiles = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256);
@@ -1142,7 +1146,7 @@ extern "C" int msclip_gemm_f8(const msclip_gemm_desc* d, const float* row_scale,
   const int ncu = device_cus();
   if (d->xb) {   // c_proj under PRECISION fp8 as the producer of the next block's folded ln_1 (whole tiles, in-place fp32 residual update)
     if (d->resid_kind != 1 || d->out_kind != 1 || d->act || !d->center || !d->part || (d->M % 256) || (d->N % 256) || (d->ldxb % 4) ||
-        (d->ldo % 4) || (d->ldr % 4))
+        (d->ldo % 4) || (d->ldr % 4) || (d->resid2 && (d->seg_split <= 0 || (d->seg_split % 256) || d->seg_split >= d->M)))
       return MSCLIP_EINVAL;
     hipLaunchKernelGGL((gemm_pp_kernel<0, true, 2>), dim3(tiles < ncu ? (int)tiles : ncu), dim3(512), 0, (hipStream_t)stream, *d,
                        row_scale, col_scale);

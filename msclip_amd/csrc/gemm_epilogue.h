@@ -188,7 +188,8 @@ __device__ __forceinline__ float sum8_dpp(float v) {
 
 template <int TM, int TN>
 __device__ __forceinline__ void epilogue_rows_stats(f32x4 (&acc)[2 * TN][2 * TM], const msclip_gemm_desc& a, unsigned stg,
-                                                    int mw0, int nw0, int lane, float bcol, float cen_lo, float cen_hi) {
+                                                    int mw0, int nw0, int lane, float bcol, float cen_lo, float cen_hi,
+                                                    const float* __restrict__ resid) {
   static_assert(TN == 2 && TM == 4, "wave tile = 128 rows x 64 columns = one statistics group per row");
   float4 bias4[TN];
   bias4_from_bcol<TN>(bcol, lane, bias4);
@@ -206,7 +207,7 @@ __device__ __forceinline__ void epilogue_rows_stats(f32x4 (&acc)[2 * TN][2 * TM]
       const size_t row = (size_t)(mw0 + tm * 32 + i * 8 + srow);
       // non-temporal: with the fold nobody re-reads the fp32 stream soon (no LayerNorm pass behind this launch), so it should
       // not take the MALL from the bf16 operand the next projection reads (same-box A/B, loads + stores: +0.5-0.9 % on the step)
-      const f32x4 t = __builtin_nontemporal_load((const AS1 f32x4*)((const float*)a.resid + row * a.ldr + nw0 + tn * 32 + sch * 4));
+      const f32x4 t = __builtin_nontemporal_load((const AS1 f32x4*)(resid + row * a.ldr + nw0 + tn * 32 + sch * 4));
       dst[i] = make_float4(t[0], t[1], t[2], t[3]);
     }
   };

@@ -332,10 +332,26 @@ __global__ __launch_bounds__(256) void adapter_gridrow_kernel(const float* __res
                                                               const float* __restrict__ dww, const float* __restrict__ dwb,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               float* __restrict__ xout, int ldo, int B, int L, int g,
-                                                              int usecls, float eps) {
+                                                              int usecls, float eps, const float* __restrict__ gamma1,
+                                                              const float* __restrict__ beta1, bf16_t* __restrict__ lno, int ldl,
+                                                              float* __restrict__ center, float* __restrict__ rowstat) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * WPB + (threadIdx.x >> 6);
   if (r >= B * g) return;
+  // msclip_adapter_combine_ln_stats: the block's ln_1 of the row just written, from the registers it is still in (the same
+  // fp32 values a LayerNorm pass would read back from xout), plus the LayerNorm fold's per-row state of msclip_layernorm_stats
+  auto second_ln = [&](float4 (&v)[NV], size_t row) {
+    // (-ffast-math would fold the first LayerNorm's scale / shift into this one's centring: pin the rounded fp32 values, the
+    //  ones xout holds, so that the result is bitwise the two-kernel chain's)
+#pragma unroll
+    for (int i = 0; i < NV; ++i) asm volatile("" : "+v"(v[i].x), "+v"(v[i].y), "+v"(v[i].z), "+v"(v[i].w));
+    const float mean = ln_core<NV>(v, gamma1, beta1, eps, lane);
+    store_row<NV>(v, lno, row, ldl, 0, lane);
+    if (lane == 0) {
+      center[row] = mean;
+      *(float2*)(rowstat + 2 * row) = make_float2(1.f, 0.f);
+    }
+  };
   const int b = r / g, gy = r - b * g;
   constexpr int C = NV * 256;
   float4 w[9][NV], bias[NV];
@@ -356,6 +372,7 @@ __global__ __launch_bounds__(256) void adapter_gridrow_kernel(const float* __res
     }
     ln_core<NV>(v, gamma, beta, eps, lane);
     store_row<NV>(v, xout, m, ldo, 1, lane);
+    if (gamma1) second_ln(v, m);
   }
   for (int gx = 0; gx < g; ++gx) {
     const int p = gy * g + gx;
@@ -384,6 +401,7 @@ __global__ __launch_bounds__(256) void adapter_gridrow_kernel(const float* __res
     }
     ln_core<NV>(v, gamma, beta, eps, lane);
     store_row<NV>(v, xout, (size_t)b * L + 1 + p, ldo, 1, lane);
+    if (gamma1) second_ln(v, (size_t)b * L + 1 + p);
   }
 }
 
@@ -504,12 +522,26 @@ extern "C" int msclip_adapter_combine_ln(const float* xin, int ldx, const float*
   const char* perrow = getenv("MSCLIP_ADAPTER_PER_TOKEN");       // the wave-per-token kernel, for cross-checks only
   if (!(perrow && perrow[0] == '1')) {
     const dim3 grid((B * g + WPB - 1) / WPB), blk(256);
-    NV_LAUNCH(C, adapter_gridrow_kernel, grid, blk, st, xin, ldx, t, ldt, dww, dwb, gamma, beta, xout, ldo, B, L, g, usecls, eps)
+    NV_LAUNCH(C, adapter_gridrow_kernel, grid, blk, st, xin, ldx, t, ldt, dww, dwb, gamma, beta, xout, ldo, B, L, g, usecls, eps,
+              (const float*)nullptr, (const float*)nullptr, (bf16_t*)nullptr, 0, (float*)nullptr, (float*)nullptr)
     return msclip_launch_status();
   }
   const int rows = B * L;
   const dim3 grid((rows + WPB - 1) / WPB), blk(256);
   NV_LAUNCH(C, adapter_kernel, grid, blk, st, xin, ldx, t, ldt, dww, dwb, gamma, beta, xout, ldo, B, L, g, usecls, eps)
+  return msclip_launch_status();
+}
+
+extern "C" int msclip_adapter_combine_ln_stats(const float* xin, int ldx, const float* t, int ldt, const float* dww,
+                                               const float* dwb, const float* gamma, const float* beta, float* xout, int ldo,
+                                               const float* gamma1, const float* beta1, void* lno, int ldl, float* center,
+                                               float* rowstat, int B, int L, int g, int C, int usecls, float eps, void* stream) {
+  if (!xin || !t || !dww || !dwb || !gamma || !beta || !xout || xin == xout || L != g * g + 1 || !gamma1 || !beta1 || !lno ||
+      !center || !rowstat || (ldl & 3))
+    return MSCLIP_EINVAL;
+  const dim3 grid((B * g + WPB - 1) / WPB), blk(256);
+  NV_LAUNCH(C, adapter_gridrow_kernel, grid, blk, (hipStream_t)stream, xin, ldx, t, ldt, dww, dwb, gamma, beta, xout, ldo, B, L, g,
+            usecls, eps, gamma1, beta1, (bf16_t*)lno, ldl, center, rowstat)
   return msclip_launch_status();
 }
 

@@ -93,14 +93,25 @@ class Engine:
             self._pack(model)
         self._stamp = self._fingerprint()
 
+    def _module_tensors(self):
+        """Every parameter / buffer object of the module tree, by a direct walk of the modules' own dicts (shared modules are
+        visited once per path: harmless for a fingerprint).  Module.parameters() / .buffers() build the same set through
+        named_modules + de-duplicating generators: 1.5 ms per call for this model's ~600 tensors against ~0.15 ms here, and
+        the training step asks four times per step on a host the GPU is waiting for at the step boundary."""
+        out, stack = [], [self.model]
+        while stack:
+            m = stack.pop()
+            out.extend(m._parameters.values())
+            out.extend(m._buffers.values())
+            stack.extend(m._modules.values())
+        return [t for t in out if t is not None]
+
     def _fingerprint(self):
         """Identity + in-place version of every parameter and buffer the packed copies were made from.  Any mutation
         the module hooks cannot see (submodule load_state_dict, param.copy_/fill_/clamp_, an optimizer step, a
         re-assigned .data) changes it; run() then re-packs instead of silently serving stale weights."""
         v = 0
-        for t in self.model.parameters():
-            v = (v * 1000003 + t._version * 31 + t.data_ptr()) & 0xFFFFFFFFFFFF
-        for t in self.model.buffers():
+        for t in self._module_tensors():
             v = (v * 1000003 + t._version * 31 + t.data_ptr()) & 0xFFFFFFFFFFFF
         return v
 
@@ -147,9 +158,7 @@ class Engine:
         """Which tensor OBJECTS the module holds (a parameter that has been re-assigned is another object): what cached
         views of them and cached optimizer tables are valid for."""
         v = 0
-        for t in self.model.parameters():
-            v = (v * 1000003 + id(t)) & 0xFFFFFFFFFFFF
-        for t in self.model.buffers():
+        for t in self._module_tensors():
             v = (v * 1000003 + id(t)) & 0xFFFFFFFFFFFF
         return v
 
@@ -452,12 +461,17 @@ class Engine:
         pw = a["pw"]
         hip.gemm(w["pool"][j], pw.weight, out, M=Bi * self.g * self.g, N=pw.cout, bias=pw.bias, ldx=pw.cin)
 
-    def _adapter(self, j, w, Bi, t=None):
-        """Lateral_Adapter (M.py:1752-1778): X[:Mv] -> XA.  `t`: the top-down half if it was already computed."""
+    def _adapter(self, j, w, Bi, t=None, ln1=None):
+        """Lateral_Adapter (M.py:1752-1778): X[:Mv] -> XA.  `t`: the top-down half if it was already computed.  `ln1`: the
+        LayerNorm of the block behind the adapter, applied to each row while it is in registers (-> LNO, CEN, RST; M.py:1027)."""
         a = self.adapters[j]
         if t is None:
             t = w["T"]
             self._adapter_top(j, w, Bi, t)
+        if ln1 is not None:
+            Mv = w["Mv"]
+            return hip.adapter_combine_ln_stats(w["X"][:Mv], t, a["dww"], a["dwb"], a["ln"].g, a["ln"].b, w["XA"], ln1.g, ln1.b,
+                                                w["LNO"][:Mv], w["CEN"][:Mv], w["RST"][:Mv], Bi, self.Lv, self.g, self.usecls)
         hip.adapter_combine_ln(w["X"][:w["Mv"]], t, a["dww"], a["dwb"], a["ln"].g, a["ln"].b, w["XA"], Bi,
                                self.Lv, self.g, self.usecls)
 
@@ -708,16 +722,20 @@ class Engine:
             last_live = i == n_last and compact
             # --- ln_1: folded where the previous c_proj produced these rows' operands, a LayerNorm pass elsewhere
             modes = []
+            xa_stream = False                               # the image rows' fp32 stream sits in XA until out_proj moves it back to X
             for tower, r0, r1, b in segs:
                 src, raw = X[r0:r1], None
                 if tower == "v" and i in self.lateral:
                     j = self.lateral.index(i)
+                    # the adapter applies ln_1 itself (rows in registers) unless this block's out_proj is not the producing kernel
+                    xa_stream = not last_live and not self.fp8 and not hip.env_flag("MSCLIP_ADAPTER_LN1_PASS")
+                    ln1 = b["ln1"] if xa_stream else None
                     if conv_events is not None:
                         torch.cuda.current_stream(self.dev).wait_event(conv_events[j])
-                        self._adapter(j, w, Bi, t=w["Ts"][j])
+                        self._adapter(j, w, Bi, t=w["Ts"][j], ln1=ln1)
                     else:
                         self._parallel_stage(j, w, Bi)
-                        self._adapter(j, w, Bi)
+                        self._adapter(j, w, Bi, ln1=ln1)
                     if taps is not None:
                         if j:
                             c3 = self.par_specs[j][3]
@@ -725,7 +743,9 @@ class Engine:
                         self._tap_tokens(taps, f"adapter{j}", w["XA"], Bi, self.Lv)
                     src, raw = w["XA"], X[:Mv]              # ln_1 reads the adapter output and moves it back into X
                     pend[tower] = False
-                if pend[tower]:
+                if xa_stream and tower == "v":
+                    modes.append((tower, r0, r1, False))
+                elif pend[tower]:
                     modes.append((tower, r0, r1, True))
                 else:
                     hip.layernorm_stats(src, b["ln1"].g, b["ln1"].b, LNO[r0:r1], r1 - r0, CEN[r0:r1], RST[r0:r1], raw_out=raw)
@@ -767,8 +787,13 @@ class Engine:
                         for m in ms:
                             pend[m[0]] = True
                     continue
-                hip.gemm(AO[r0:r1], bw.wo, X[r0:r1], bias=bw.bo, resid=X[r0:r1], resid_kind=hip.RESID_F32,
-                         fold_out=hip.FoldOut(LNO[r0:r1], CEN[r0:r1], PART[r0:r1]))
+                fo = hip.FoldOut(LNO[r0:r1], CEN[r0:r1], PART[r0:r1])
+                res = X[r0:r1]
+                if xa_stream and ms[0][0] == "v":           # (image rows come first: r0 == 0)
+                    res = w["XA"]
+                    if r1 > Mv:
+                        fo = hip.FoldOut(LNO[r0:r1], CEN[r0:r1], PART[r0:r1], resid2=X[r0:r1], split=Mv)
+                hip.gemm(AO[r0:r1], bw.wo, X[r0:r1], bias=bw.bo, resid=res, resid_kind=hip.RESID_F32, fold_out=fo)
                 hip.rowstat_finalize(PART[r0:r1], CEN[r0:r1], RST[r0:r1], r1 - r0, D)
                 self._fold_proj(w, i, "fc", r0, r1, [(m[0], m[1], m[2], True) for m in ms], HID, hip.ACT_QUICKGELU)
                 if nxt_fold:

@@ -17,7 +17,7 @@ INT_MAX = 2 ** 31 - 1
 
 EXPORTS = (
     "msclip_gemm", "msclip_gemm_f8", "msclip_layernorm_stats", "msclip_rowstat_finalize", "msclip_layernorm_f8", "msclip_quant_f8_rows", "msclip_gemm_variant", "msclip_attention", "msclip_attention_lastq", "msclip_layernorm", "msclip_layernorm_split", "msclip_embed_tokens", "msclip_fill_cls",
-    "msclip_adapter_combine_ln", "msclip_l2norm", "msclip_gather_rows", "msclip_stem_conv3x3s2_dual", "msclip_dwpool",
+    "msclip_adapter_combine_ln", "msclip_adapter_combine_ln_stats", "msclip_l2norm", "msclip_gather_rows", "msclip_stem_conv3x3s2_dual", "msclip_dwpool",
     "msclip_stem_dual_conv3x3s2", "msclip_conv1x1_conv3x3s2", "msclip_convresblock48_s2", "msclip_patchify",
     "msclip_lse_rows", "msclip_clip_loss_partial", "msclip_clip_lse_fused", "msclip_clip_loss_from_partials",
     "msclip_transpose_bf16", "msclip_cast_bf16", "msclip_cast_bf16_colsum", "msclip_colsum", "msclip_quickgelu", "msclip_quickgelu_bwd", "msclip_layernorm_bwd",
@@ -55,7 +55,7 @@ class GemmDesc(ctypes.Structure):
         # LayerNorm fold: consumer (W2, bias2, csum, csum2, rowstat, seg_split) and producer (ldxb, xb, center, part)
         ("W2", ctypes.c_void_p), ("bias2", ctypes.c_void_p), ("csum", ctypes.c_void_p), ("csum2", ctypes.c_void_p),
         ("rowstat", ctypes.c_void_p), ("seg_split", ctypes.c_int), ("ldxb", ctypes.c_int), ("xb", ctypes.c_void_p),
-        ("center", ctypes.c_void_p), ("part", ctypes.c_void_p),
+        ("center", ctypes.c_void_p), ("part", ctypes.c_void_p), ("resid2", ctypes.c_void_p),
     ]
 
 
@@ -95,6 +95,7 @@ def lib():
         L.msclip_embed_tokens.argtypes = [vp, vp, vp, vp, ci, vp, ci, ci, ci, ci, ci, vp]
         L.msclip_fill_cls.argtypes = [vp, vp, vp, ci, ci, ci, ci, vp]
         L.msclip_adapter_combine_ln.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, vp]
+        L.msclip_adapter_combine_ln_stats.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, ci, ci, ci, ci, ci, cf, vp]
         L.msclip_l2norm.argtypes = [vp, ci, vp, ci, vp, ci, ci, ci, vp]
         L.msclip_gather_rows.argtypes = [vp, ctypes.c_longlong, vp, ci, ci, vp, ctypes.c_longlong, ci, ci, vp]
         L.msclip_stem_conv3x3s2_dual.argtypes = [vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, vp]
@@ -353,8 +354,9 @@ class FoldOut:
     """Producer side (msclip_gemm_desc.xb ...): out_proj / c_proj also write xb = bf16(out - center[m]) and the per-64-column
     partial sums part [M, N / 64, 2] of (out - center) and its square."""
 
-    def __init__(self, xb, center, part):
+    def __init__(self, xb, center, part, resid2=None, split=0):
         self.xb, self.center, self.part = xb, center, part
+        self.resid2, self.split = resid2, split      # rows >= split read their fp32 residual from resid2[m] (absolute row m)
 
 
 def gemm(x, w, out, *, M=None, bias=None, resid=None, resid_kind=0, act=0, alpha=1.0, conv=None, ktab=None,
@@ -402,6 +404,10 @@ def gemm(x, w, out, *, M=None, bias=None, resid=None, resid_kind=0, act=0, alpha
         assert f.xb.shape[0] >= d.M and f.center.numel() >= d.M and f.part.numel() >= d.M * (d.N // 64) * 2
         assert f.center.dtype == torch.float32 and f.part.dtype == torch.float32
         d.xb, d.ldxb, d.center, d.part = f.xb.data_ptr(), f.xb.stride(0), f.center.data_ptr(), f.part.data_ptr()
+        if f.resid2 is not None:
+            _f32(f.resid2)
+            assert f.resid2.stride(0) == d.ldr and f.resid2.shape[0] >= d.M and 0 < f.split < d.M and f.split % 256 == 0
+            d.resid2, d.seg_split = f.resid2.data_ptr(), f.split
     if out2 is not None:
         assert out2.dtype == torch.bfloat16 and out2.stride(0) == d.ldo and out.dtype == torch.bfloat16
         d.out2 = out2.data_ptr()
@@ -626,6 +632,17 @@ def adapter_combine_ln(xin, t, dww, dwb, gamma, beta, xout, B, L, g, usecls, eps
     _check(lib().msclip_adapter_combine_ln(_p(xin), xin.stride(0), _p(t), t.stride(0), _p(dww), _p(dwb), _p(gamma),
                                            _p(beta), _p(xout), xout.stride(0), B, L, g, xin.shape[1], int(usecls), eps,
                                            _stream()), "msclip_adapter_combine_ln")
+
+
+def adapter_combine_ln_stats(xin, t, dww, dwb, gamma, beta, xout, gamma1, beta1, lno, center, rowstat, B, L, g, usecls, eps=1e-12):
+    """adapter_combine_ln plus the block's ln_1 of each row from registers: lno = bf16 LN(xout; gamma1, beta1), center = row
+    means of xout, rowstat = (1, 0) (what layernorm_stats(xout, ...) would leave)."""
+    _bf16(lno)
+    assert center.dtype == torch.float32 and rowstat.dtype == torch.float32 and center.numel() >= B * L and rowstat.numel() >= 2 * B * L
+    _check(lib().msclip_adapter_combine_ln_stats(_p(xin), xin.stride(0), _p(t), t.stride(0), _p(dww), _p(dwb), _p(gamma), _p(beta),
+                                                 _p(xout), xout.stride(0), _p(gamma1), _p(beta1), _p(lno), lno.stride(0),
+                                                 _p(center), _p(rowstat), B, L, g, xin.shape[1], int(usecls), eps, _stream()),
+           "msclip_adapter_combine_ln_stats")
 
 
 def patchify(img, out, B, S, P, kpad):

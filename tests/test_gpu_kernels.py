@@ -907,6 +907,51 @@ def test_layernorm_stats_rows(gpu_device):
     assert bool((rs[:, 0] == 1).all()) and bool((rs[:, 1] == 0).all())
 
 
+def test_layernorm_fold_producer_second_residual_stream(gpu_device):
+    """msclip_gemm_desc.resid2: the rows from seg_split on read their residual from a second matrix (the text rows' stream is
+    `out`, the image rows' sits in the lateral adapter's output buffer): bitwise the one-stream launch on the joined rows."""
+    M, Mv, D, K = 1536, 512, 768, 768
+    a, w, b = rnd(M, K, seed=71, dtype=BF), rnd(D, K, seed=72, scale=0.03, dtype=BF), rnd(D, seed=73)
+    x0, cen = rnd(M, D, seed=74) + 1.5, rnd(M, seed=76, scale=0.2) + 1.5
+    ref, xb0, p0 = x0.clone(), torch.empty(M, D, dtype=BF, device="cuda"), torch.empty(M, D // 64, 2, device="cuda")
+    hip.gemm(a, w, ref, bias=b, resid=ref, resid_kind=hip.RESID_F32, fold_out=hip.FoldOut(xb0, cen.clone(), p0))
+    xa = x0[:Mv].clone()                                                    # image rows' stream
+    out = x0.clone()
+    out[:Mv] = float("nan")                                                # ... and nothing of it in `out`
+    xb, part = torch.empty_like(xb0), torch.empty_like(p0)
+    hip.gemm(a, w, out, bias=b, resid=xa, resid_kind=hip.RESID_F32, fold_out=hip.FoldOut(xb, cen.clone(), part, resid2=out, split=Mv))
+    assert torch.equal(out, ref) and torch.equal(xb.view(torch.int16), xb0.view(torch.int16)) and torch.equal(part, p0)
+    assert torch.equal(xa, x0[:Mv])
+    with pytest.raises(AssertionError):                                    # a split inside a tile is rejected
+        hip.gemm(a, w, out, bias=b, resid=xa, resid_kind=hip.RESID_F32, fold_out=hip.FoldOut(xb, cen.clone(), part, resid2=out, split=300))
+
+
+@pytest.mark.parametrize("B,g_,C,usecls", [(5, 7, 768, True), (3, 14, 768, False), (2, 16, 1024, True)])
+def test_adapter_combine_ln_stats(gpu_device, B, g_, C, usecls):
+    """msclip_adapter_combine_ln_stats = msclip_adapter_combine_ln followed by msclip_layernorm_stats of its output (the second
+    LayerNorm runs on the fp32 values the first one stores)."""
+    L = g_ * g_ + 1
+    x, t = rnd(B * L, C, seed=61), rnd(B * g_ * g_, C, seed=62)
+    dww, dwb = rnd(9, C, seed=63, scale=0.3), rnd(C, seed=64, scale=0.1)
+    ga, be = 1.0 + rnd(C, seed=65, scale=0.1), rnd(C, seed=66, scale=0.1)
+    g1, b1 = 1.0 + rnd(C, seed=67, scale=0.1), rnd(C, seed=68, scale=0.1)
+    xa0 = torch.empty(B * L, C, device="cuda")
+    hip.adapter_combine_ln(x, t, dww, dwb, ga, be, xa0, B, L, g_, usecls)
+    l0, c0, r0 = torch.empty(B * L, C, dtype=BF, device="cuda"), torch.empty(B * L, device="cuda"), torch.empty(B * L, 2, device="cuda")
+    hip.layernorm_stats(xa0, g1, b1, l0, B * L, c0, r0)
+    xa = torch.full((B * L + 1, C), float("nan"), device="cuda")
+    lno = torch.full((B * L + 1, C), float("nan"), dtype=BF, device="cuda")
+    cen, rs = torch.full((B * L + 1,), float("nan"), device="cuda"), torch.full((B * L + 1, 2), float("nan"), device="cuda")
+    hip.adapter_combine_ln_stats(x, t, dww, dwb, ga, be, xa[:B * L], g1, b1, lno[:B * L], cen, rs, B, L, g_, usecls)
+    # the fp32 stream is bitwise; the second LayerNorm is the same code inlined into another kernel, and under -ffast-math the
+    # compiler orders its sums per kernel: last-bit differences of the statistics, i.e. rare one-ulp differences of the bf16 output
+    assert torch.equal(xa[:B * L], xa0) and torch.equal(rs[:B * L], r0)
+    close(cen[:B * L], c0, 1e-6, 1e-6)
+    a, b = lno[:B * L].float(), l0.float()
+    assert float(((a - b).abs() / b.abs().clamp_min(2.0 ** -6)).max()) <= 2.0 ** -7 and float((a != b).float().mean()) < 5e-3
+    assert bool(torch.isnan(xa[B * L:]).all()) and bool(torch.isnan(lno[B * L:].float()).all()) and bool(torch.isnan(cen[B * L:]).all())
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,S,P", [(3, 224, 14), (2, 224, 16), (1, 64, 32)])
 def test_patchify_and_patch_conv(gpu_device, dtype, B, S, P):
