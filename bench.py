@@ -15,7 +15,8 @@ import os
 import sys
 import time
 
-import torch
+os.environ.setdefault("HSA_KERNARG_POOL_SIZE", str(16 << 20))      # before the first HIP call (msclip_amd/__init__.py says why)
+import torch                                                        # noqa: E402
 import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -10,12 +10,19 @@ BF = torch.bfloat16
 F32 = torch.float32
 
 
-def _tn_ok(dy_bf, x_bf):
-    """The token-major split-K GEMM (msclip_gemm_splitk_tn: no operand transposes) takes whole 256-channel tiles on both sides;
-    MSCLIP_WGRAD_TN=0 = the transposing path (A/B knob, cross-check)."""
+def _tn_ok(dy_bf, x_bf, ragged=False):
+    """The token-major split-K GEMM (msclip_gemm_splitk_tn: no operand transposes).  The wide gradients (transformer
+    projections) are whole 256-channel tiles on both sides; ragged=True admits any channel counts (the conv side's 48-192
+    channels: an edge tile's extra channels only reach outputs that are not stored).  MSCLIP_WGRAD_TN=0 = the transposing path
+    (A/B knob, cross-check), MSCLIP_WGRAD_TN_RAGGED=0 = only for the conv side."""
     import os
-    return (os.environ.get("MSCLIP_WGRAD_TN", "1") != "0" and dy_bf.shape[1] % 256 == 0 and x_bf.shape[1] % 256 == 0
-            and dy_bf.stride(1) == 1 and x_bf.stride(1) == 1 and dy_bf.stride(0) % 8 == 0 and x_bf.stride(0) % 8 == 0)
+    if os.environ.get("MSCLIP_WGRAD_TN", "1") == "0" or (ragged and os.environ.get("MSCLIP_WGRAD_TN_RAGGED", "1") == "0"):
+        return False
+    if not (dy_bf.stride(1) == 1 and x_bf.stride(1) == 1 and dy_bf.stride(0) % 8 == 0 and x_bf.stride(0) % 8 == 0):
+        return False
+    if ragged:
+        return x_bf.shape[1] % 4 == 0
+    return dy_bf.shape[1] % 256 == 0 and x_bf.shape[1] % 256 == 0
 
 
 def wgrad(dy_bf, x_bf, M, out=None):
@@ -26,6 +33,11 @@ def wgrad(dy_bf, x_bf, M, out=None):
     where the gradient is written (a slot of a gradient bucket, comm.GradReducer.reserve)."""
     N, K = dy_bf.shape[1], x_bf.shape[1]
     tiles = ((N + 255) // 256) * ((K + 255) // 256)
+    if tiles <= 4 and M >= 65536 and _tn_ok(dy_bf, x_bf, ragged=True):
+        # narrow gradients over many pixels (the stem / parallel-branch convolutions: 0.4-1.6 M pixels at batch 512): token-major
+        # too -- 256 x 256 tiles waste MFMA rows on 48-192 channels, but the job is HBM-bound and the transposes were 2/3 of its
+        # traffic (1.6 M x (96 + 448): 501 us against 1116 us; below ~65 k tokens the transposing path's 128 x 128 tiles win)
+        return hip.gemm_splitk_tn(dy_bf, x_bf, M, max(1, min(256 // tiles, M // 2048)), out=out)
     if tiles <= 4:
         # narrow gradients (the convolutions: 48-192 channels over up to 6.4 M pixels): one split-K launch of 128 x 128
         # tiles, enough slices to put ~2 workgroups on every CU, at least 1024 deep each

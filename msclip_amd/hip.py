@@ -525,11 +525,12 @@ def gemm_splitk(x, w, slices, out=None, tile=0):
 def gemm_splitk_tn(dy, x, T, slices, out=None):
     """fp32 [N_dy, N_x] = dy[:T]^T @ x[:T] for TOKEN-major bf16 operands dy [*, N_dy], x [*, N_x] (what a weight gradient is
     made of) without transposing them: msclip_gemm_splitk_tn, `slices` token ranges into fp32 partials folded in a fixed order.
-    N_dy and N_x multiples of 256."""
+    Channel counts need not be whole tiles (N_x a multiple of 4, rows 16-byte aligned): an edge tile's extra channels are
+    whatever lies to the right of the operand in memory, and land only in outputs that are not stored."""
     _bf16(dy)
     _bf16(x)
     Mo, No = dy.shape[1], x.shape[1]
-    assert dy.shape[0] >= T and x.shape[0] >= T and Mo % 256 == 0 and No % 256 == 0
+    assert dy.shape[0] >= T and x.shape[0] >= T and No % 4 == 0 and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0
     part = torch.empty(slices, Mo * No, dtype=torch.float32, device=dy.device) if (slices > 1 or out is None) else out.view(1, -1)
     d = GemmDesc()
     d.X, d.W, d.zero, d.out = dy.data_ptr(), x.data_ptr(), zero_page(dy.device).data_ptr(), part.data_ptr()

@@ -785,6 +785,37 @@ def test_train_synthetic_script(gpu_device):
     assert "OK" in r.stdout and r.stdout.count("step ") == 6
 
 
+@pytest.mark.parametrize("T,No,Ni", [(70000, 96, 864), (66000, 48, 448), (8000, 192, 1728), (4097, 768, 96), (3000, 384, 192)])
+def test_weight_gradient_gemm_token_major_ragged_channels(gpu_device, T, No, Ni):
+    """msclip_gemm_splitk_tn on channel counts that are not whole 256-tiles (the conv side's narrow gradients, round 4): an edge
+    tile's extra channels are whatever lies right of the operand in memory -- NaN here -- and must reach no stored output;
+    rows past T are NaN too.  Against fp32 torch, bitwise repeatable, and gradgemm.wgrad takes this path from 65 536 tokens on."""
+    import msclip_amd.gradgemm as G
+    g = torch.Generator().manual_seed(5)
+    wide_dy = (torch.randn(T + 3, No + 16, generator=g) * 0.5).to(BF).cuda()
+    wide_x = torch.randn(T + 3, Ni + 64, generator=g).to(BF).cuda()
+    wide_dy[T:], wide_x[T:] = float("nan"), float("nan")
+    wide_dy[:, No:], wide_x[:, Ni:] = float("nan"), float("nan")
+    dy, x = wide_dy[:, :No], wide_x[:, :Ni]
+    tiles = ((No + 255) // 256) * ((Ni + 255) // 256)
+    S = max(1, min(256 // tiles, T // 2048))
+    ref = dy[:T].float().t() @ x[:T].float()
+    out = torch.full((No + 1, Ni), float("nan"), device="cuda")
+    hip.gemm_splitk_tn(dy, x, T, S, out=out[:No])
+    first = out.clone()
+    scale = ref.abs().max().item()
+    assert (out[:No] - ref).abs().max().item() <= 2e-5 * scale * max(1.0, (T / 4096) ** 0.5) + 1e-3
+    assert bool(torch.isnan(out[No:]).all())
+    hip.gemm_splitk_tn(dy, x, T, S, out=out[:No])
+    assert torch.equal(out[:No], first[:No])
+    assert G._tn_ok(dy, x, ragged=True) and not G._tn_ok(dy, x)
+    got = G.wgrad(dy, x, T)
+    if T >= 65536 and tiles <= 4:
+        assert torch.equal(got, first[:No])                               # the token-major launch
+    else:
+        assert (got - ref).abs().max().item() <= 2e-5 * scale * max(1.0, (T / 4096) ** 0.5) + 1e-3
+
+
 @pytest.mark.parametrize("T,No,Ni,S", [(4096, 768, 768, 4), (65024, 768, 3072, 7), (5000, 2304, 768, 3), (127 * 33, 256, 512, 1),
                                        (70, 512, 256, 2)])
 def test_weight_gradient_gemm_on_token_major_operands(gpu_device, T, No, Ni, S):
