@@ -62,11 +62,15 @@ class _Fold:
         out[self.prefix + ".bias"] = db
 
 
+_PARITY_PLANS = {}
+
+
 class ConvSideBackward:
     def __init__(self, train_step):
         self.ts = train_step
         self.e = train_step.eng
         self._wt = {}
+        self._pplan = _PARITY_PLANS                      # parity-class dgrad plans (geometry only: survive weight updates)
 
     # ------------------------------------------------------------------ generic pieces
     def _w_t(self, key, weight, cout, cin_cols):
@@ -78,6 +82,58 @@ class ConvSideBackward:
             t[:, :cout] = weight[:, :cin_cols].t()
             self._wt[key] = t
         return t
+
+    # ---- input gradient of the 3x3 / stride 2 / pad 1 convolutions without column matrices (round 4).  An input pixel
+    # (2i + py, 2j + px) receives from output pixel (i + a, j + b), a <= py, b <= px, through filter tap
+    # ky = 1 (py = 0) or (2, 0)[a] (py = 1), kx likewise: each parity class is a small stride-1 convolution of dY
+    # (1, 2, 2 or 4 taps -- 9 taps per 4 input pixels in total, the minimum), i.e. an implicit-GEMM launch
+    # (msclip_gemm mode 1 over the NHWC dY) whose output rows scatter to the class's pixels: dX viewed as rows of two pixels
+    # ([B * H * Wo, 2 * ci]), row m + (m / Wo) * Wo + py * Wo, column window px * ci (msclip_gemm_desc.rpg / radd / roff).
+    # Replaces dcol = dY . Wf^T (a [pixels, 9 * ci] matrix written and read back: 1.4 GB for each of the two 112 x 112
+    # layers at batch 512) + msclip_col2im: 1036 -> 698 us (48 -> 48 @ 112), 1453 -> 945 (48 -> 96 @ 112), 672 -> 273 (96 -> 96 @ 56),
+    # 829 -> 398 (96 -> 192 @ 56), 372 -> 181 (192 -> 192 @ 28); closer to fp32 torch than the bf16 column matrix was
+    # (tools/probes/dgrad_parity_probe.py).
+    def _parity_plan(self, key, spec):
+        # geometry only: shared by every ConvSideBackward of the process (the frozen-statistics backward builds one per step,
+        # and an index upload is a pageable host-to-device copy that waits for the stream to drain)
+        key = (str(spec.weight.device), spec.cout, spec.cin, spec.weight.shape[1], spec.w_out)
+        plan = self._pplan.get(key)
+        if plan is None:
+            co, ci, kp = spec.cout, spec.cin, spec.weight.shape[1]
+            src = torch.arange(co * kp).view(co, kp)[:, :9 * ci].view(co, 3, 3, ci)
+            zero_at = 9 * ci if kp > 9 * ci else None        # a pad column of the packed filter (zero) for K padding
+            idx, parts = [], []
+            for py in (0, 1):
+                for px in (0, 1):
+                    kys, kxs = ([1] if py == 0 else [2, 0]), ([1] if px == 0 else [2, 0])
+                    t = src[:, kys][:, :, kxs].permute(3, 1, 2, 0).reshape(ci, -1)       # [ci, (a, b, co)]
+                    K = t.shape[1]
+                    Kp = (K + 63) // 64 * 64
+                    if Kp != K:
+                        if zero_at is None:
+                            self._pplan[key] = False
+                            return False
+                        t = torch.cat([t, torch.full((ci, Kp - K), zero_at, dtype=t.dtype)], 1)
+                    parts.append((py, px, sum(x.numel() for x in idx), Kp))
+                    idx.append(t.reshape(-1))
+            dev = spec.weight.device
+            plan = self._pplan[key] = dict(idx=torch.cat(idx).to(dev), parts=parts,
+                                           ktab=[P.ktab_on(dev, 1 + py, 1 + px, co, spec.w_out) for py, px, _, _ in parts])
+        return plan
+
+    def _parity_ok(self, spec):
+        return ((spec.kh, spec.kw, spec.stride, spec.pad) == (3, 3, 2, 1) and spec.h_in % 2 == 0 and spec.w_in % 2 == 0
+                and spec.cout % 8 == 0 and spec.cin % 8 == 0 and spec.h_in == 2 * spec.h_out and spec.w_in == 2 * spec.w_out
+                and spec.h_in >= 28                  # (14 x 14 maps: the four launches cost more than the small column matrix)
+                and not hip.env_flag("MSCLIP_DGRAD_COL2IM"))
+
+    def _dgrad_parity(self, plan, spec, dpre, dx, B):
+        co, ci, Ho, Wo = spec.cout, spec.cin, spec.h_out, spec.w_out
+        wp = torch.index_select(spec.weight.reshape(-1), 0, plan["idx"])                  # the four class filters, one gather
+        dx2 = dx.view(B * spec.h_in * Wo, 2 * ci)
+        for (py, px, off, Kp), kt in zip(plan["parts"], plan["ktab"]):
+            hip.gemm(dpre, wp[off:off + ci * Kp].view(ci, Kp), dx2[:, px * ci:(px + 1) * ci], M=B * Ho * Wo, N=ci,
+                     conv=(Ho, Wo, co, Ho, Wo, 1, 0), ktab=kt, ldo=2 * ci, rpg=Wo, radd=Wo, roff=py * Wo)
 
     def _conv_bwd(self, key, spec, x_in, dpre, B, need_dx=True, col=None, lane=False):
         """dpre: bf16 [B*Ho*Wo, cout] (with slack) -> (G [cout, cin, kh, kw] fp32 wrt the folded filter, dbias [cout],
@@ -102,6 +158,9 @@ class ConvSideBackward:
                 wt = self._w_t(key, spec.weight, co, ci)
                 dx = _zbuf(pix, ci, dpre.device)
                 hip.gemm(dpre, wt, dx, M=pix, N=ci, ldx=co)
+            elif self._parity_ok(spec) and self._parity_plan(key, spec):
+                dx = _zbuf(B * spec.h_in * spec.w_in, ci, dpre.device)
+                self._dgrad_parity(self._parity_plan(key, spec), spec, dpre, dx, B)
             else:
                 kp = spec.weight.shape[1]
                 wt = self._w_t(key, spec.weight, co, kp)

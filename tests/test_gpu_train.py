@@ -785,6 +785,39 @@ def test_train_synthetic_script(gpu_device):
     assert "OK" in r.stdout and r.stdout.count("step ") == 6
 
 
+@pytest.mark.parametrize("ci,co,h,B", [(48, 48, 28, 3), (48, 96, 56, 2), (96, 192, 28, 3), (192, 192, 28, 2), (384, 384, 14, 2), (48, 48, 30, 2)])
+def test_conv_input_gradient_by_parity_classes(gpu_device, monkeypatch, ci, co, h, B):
+    """dX of a 3x3 / stride 2 / pad 1 convolution as four stride-1 implicit-GEMM launches over dY, one per input-pixel parity
+    class, scattered straight into dX (train_conv.ConvSideBackward._dgrad_parity, round 4): against fp32 conv_transpose2d of the
+    same bf16 operands, against the column-matrix path (dcol GEMM + msclip_col2im), every dX row written; 14 x 14 maps keep the
+    column-matrix path."""
+    from msclip_amd import packing as P, train_conv as TC
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(co, ci, 3, 3, generator=g) * (2.0 / (9 * ci)) ** 0.5
+    spec = P.ConvSpec(w, torch.zeros(co), h, h, 2, 1).to("cuda")
+    ho = spec.h_out
+    pix = B * ho * ho
+    dpre = TC._zbuf(pix, co, "cuda")
+    dpre.copy_((torch.randn(pix, co, generator=g) * 0.5).to(BF))
+    x_in = TC._zbuf(B * h * h, ci, "cuda")
+    x_in.copy_(torch.randn(B * h * h, ci, generator=g).to(BF))
+    bw = object.__new__(TC.ConvSideBackward)
+    bw._wt, bw._pplan = {}, TC._PARITY_PLANS
+    assert bw._parity_ok(spec) == (h >= 28)
+    col = hip.im2col(x_in, B, h, h, ci, 3, 3, 2, 1)
+    G, db, dx = bw._conv_bwd("t", spec, x_in, dpre, B, col=col)
+    monkeypatch.setenv("MSCLIP_DGRAD_COL2IM", "1")
+    G2, db2, dx2 = bw._conv_bwd("t", spec, x_in, dpre, B, col=col)
+    wq = spec.weight[:, :9 * ci].float().view(co, 3, 3, ci).permute(0, 3, 1, 2)               # the packed (bf16) filter
+    dy = dpre[:pix].float().view(B, ho, ho, co).permute(0, 3, 1, 2)
+    ref = F.conv_transpose2d(dy, wq, stride=2, padding=1, output_padding=1).permute(0, 2, 3, 1).reshape(B * h * h, ci)
+    sc = ref.abs().max().item()
+    assert bool(torch.isfinite(dx.float()).all())                        # (the fixture poisons fresh memory: every row was written)
+    assert (dx.float() - ref).abs().max().item() <= 6e-3 * sc            # one bf16 rounding of an fp32 sum
+    assert (dx2.float() - ref).abs().max().item() <= 1.2e-2 * sc         # (the column matrix rounds every tap's product first)
+    assert torch.equal(G, G2) and torch.equal(db, db2)
+
+
 @pytest.mark.parametrize("T,No,Ni", [(70000, 96, 864), (66000, 48, 448), (8000, 192, 1728), (4097, 768, 96), (3000, 384, 192)])
 def test_weight_gradient_gemm_token_major_ragged_channels(gpu_device, T, No, Ni):
     """msclip_gemm_splitk_tn on channel counts that are not whole 256-tiles (the conv side's narrow gradients, round 4): an edge
