@@ -97,21 +97,25 @@ def _ranks_share_a_gpu():
 
 def wgrad_async(dy_bf, x_bf, M, post=None, out=None):
     """wgrad(dy_bf, x_bf, M) on the lane stream.  The operands must not be overwritten in place afterwards (their memory
-    may be freed: the caching allocator is told about the lane's use); the result may only be touched after join()."""
+    may be freed: the caching allocator is told about the lane's use); the result may only be touched after join().
+    x_bf may be a callable that builds the operand: it runs on the lane as well."""
     dev = dy_bf.device
     if hip.env_flag("MSCLIP_WGRAD_SYNC") or _ranks_share_a_gpu():
-        out = wgrad(dy_bf, x_bf, M, out)                 # everything on the calling stream (A/B knob; gloo test setups)
+        out = wgrad(dy_bf, x_bf() if callable(x_bf) else x_bf, M, out)    # everything on the calling stream (A/B knob; gloo test setups)
         return post(out) if post is not None else out
     cur, ln = torch.cuda.current_stream(dev), lane(dev)
     ready = torch.cuda.Event()
     ready.record(cur)
     ln.wait_event(ready)
     with torch.cuda.stream(ln):
+        if callable(x_bf):                               # the operand itself is lane work (a convolution's column matrix)
+            x_bf = x_bf()
+        else:
+            x_bf.record_stream(ln)
         out = wgrad(dy_bf, x_bf, M, out)
         if post is not None:
             out = post(out)
     dy_bf.record_stream(ln)
-    x_bf.record_stream(ln)
     out.record_stream(cur)
     return out
 

@@ -144,7 +144,16 @@ class ConvSideBackward:
         K = kh * kw * ci
         pointwise = (kh, kw, spec.stride, spec.pad) == (1, 1, 1, 0)
         if col is None:
-            col = x_in[:pix] if pointwise else hip.im2col(x_in, B, spec.h_in, spec.w_in, ci, kh, kw, spec.stride, spec.pad)
+            if pointwise:
+                col = x_in[:pix]
+            elif lane and not hip.env_flag("MSCLIP_IM2COL_MAIN"):
+                # only the weight gradient reads the column matrix: it is built where that runs, on the lane stream, not
+                # in front of the input gradient on the critical path (x_in is a workspace map: nothing writes it before
+                # gradgemm.join at the end of the backward)
+                def col():
+                    return hip.im2col(x_in, B, spec.h_in, spec.w_in, ci, kh, kw, spec.stride, spec.pad)
+            else:
+                col = hip.im2col(x_in, B, spec.h_in, spec.w_in, ci, kh, kw, spec.stride, spec.pad)
 
         def to_filter(dwf):
             return dwf[:, :K].reshape(co, kh, kw, ci).permute(0, 3, 1, 2).contiguous()
