@@ -186,6 +186,9 @@ __global__ __launch_bounds__(SWV * 64) void gemm_stream_kernel(const msclip_gemm
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = v[j] / (1.f + __expf(-1.702f * v[j]));
         }
+        // store row: m + (m / rpg) * radd + roff (include/msclip_hip.h; the parity-class input gradients of the stride-2
+        // convolutions scatter their rows into dX this way, train_conv.py)
+        const size_t orow = a.rpg == 0x7fffffff ? (size_t)m : (size_t)(m + (m / a.rpg) * a.radd + a.roff);
         if (m < a.M && n < a.N) {
           if (vec) {
             if (a.resid_kind == 1) {
@@ -205,14 +208,14 @@ __global__ __launch_bounds__(SWV * 64) void gemm_stream_kernel(const msclip_gemm
               for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
             }
             if (a.out_kind == 1) {
-              float* o = (float*)a.out + (size_t)m * a.ldo + n;
+              float* o = (float*)a.out + orow * a.ldo + n;
               *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
               *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
             } else {
               uint4 o;
               o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
               o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
-              *(uint4*)((bf16_t*)a.out + (size_t)m * a.ldo + n) = o;
+              *(uint4*)((bf16_t*)a.out + orow * a.ldo + n) = o;
             }
           } else {                                              // ragged N / unaligned leading dimensions
 #pragma unroll
@@ -222,8 +225,8 @@ __global__ __launch_bounds__(SWV * 64) void gemm_stream_kernel(const msclip_gemm
               if (a.resid_kind == 1) y += ((const float*)a.resid)[(size_t)m * a.ldr + n + j];
               else if (a.resid_kind == 2) y += bf16_to_f32(((const bf16_t*)a.resid)[(size_t)m * a.ldr + n + j]);
               if (a.act == 2) y = fmaxf(y, 0.f);
-              if (a.out_kind == 1) ((float*)a.out)[(size_t)m * a.ldo + n + j] = y;
-              else ((bf16_t*)a.out)[(size_t)m * a.ldo + n + j] = f32_to_bf16(y);
+              if (a.out_kind == 1) ((float*)a.out)[orow * a.ldo + n + j] = y;
+              else ((bf16_t*)a.out)[orow * a.ldo + n + j] = f32_to_bf16(y);
             }
           }
         }
@@ -257,6 +260,12 @@ template <bool CONV>
 bool dispatch_stream(const msclip_gemm_desc* d, hipStream_t st, int ncu) {
   const int n32 = (d->N + 31) / 32;
   const int nkc = d->K / 64;
+  if (nkc == 6) {                                               // four taps over 96 channels (a parity class of a stride-2 dgrad)
+    if (!CONV || n32 > 3) return false;
+    if (n32 == 3) launch_stream<3, 6, CONV, 4>(d, st, ncu, 2);
+    else launch_stream<2, 6, CONV, 4>(d, st, ncu, 2);
+    return true;
+  }
   if (nkc == 7) {                                               // 3x3, 48 input channels: all of W resident, 8 waves
     if (!CONV || n32 > 3) return false;
     if (n32 == 3) launch_stream<3, 7, CONV, 8>(d, st, ncu, 1);
@@ -290,12 +299,12 @@ bool dispatch_stream(const msclip_gemm_desc* d, hipStream_t st, int ncu) {
 // msclip_gemm_variant() use.
 bool msclip_gemm_small_eligible(const msclip_gemm_desc* d) {
   if ((d->K % 64) || d->M < 4096) return false;
-  if (d->rpg != 0x7fffffff || d->radd || d->roff || d->resid_kind == 3) return false;
+  if (d->resid_kind == 3 || (d->rpg != 0x7fffffff && d->resid_kind)) return false;    // (row scatter: plain stores only)
   if (d->ldw % 8) return false;
   if (d->mode == 0) return d->K <= 192 && !(d->ldx % 8);
   if (d->mode == 1) {
-    if (!d->ktab || (d->Cin % 8) || !(d->K <= 192 || d->K == 448)) return false;
-    return d->K != 448 || (d->N + 31) / 32 <= 3;               // 3x3 over 48 channels: at most 96 output channels
+    if (!d->ktab || (d->Cin % 8) || !(d->K <= 192 || d->K == 448 || d->K == 384)) return false;
+    return d->K <= 192 || (d->N + 31) / 32 <= 3;               // 3x3 over 48 channels / four taps over 96: at most 96 output channels
   }
   return false;
 }

@@ -90,35 +90,48 @@ class ConvSideBackward:
     # (msclip_gemm mode 1 over the NHWC dY) whose output rows scatter to the class's pixels: dX viewed as rows of two pixels
     # ([B * H * Wo, 2 * ci]), row m + (m / Wo) * Wo + py * Wo, column window px * ci (msclip_gemm_desc.rpg / radd / roff).
     # Replaces dcol = dY . Wf^T (a [pixels, 9 * ci] matrix written and read back: 1.4 GB for each of the two 112 x 112
-    # layers at batch 512) + msclip_col2im: 1036 -> 698 us (48 -> 48 @ 112), 1453 -> 945 (48 -> 96 @ 112), 672 -> 273 (96 -> 96 @ 56),
-    # 829 -> 398 (96 -> 192 @ 56), 372 -> 181 (192 -> 192 @ 28); closer to fp32 torch than the bf16 column matrix was
-    # (tools/probes/dgrad_parity_probe.py).
+    # layers at batch 512) + msclip_col2im: 1069 -> 314 us (48 -> 48 @ 112), 1463 -> 524 (48 -> 96 @ 112), 669 -> 252 (96 -> 96 @ 56),
+    # 820 -> 367 (96 -> 192 @ 56), 367 -> 192 (192 -> 192 @ 28); closer to fp32 torch than the bf16 column matrix was
+    # (tools/probes/dgrad_parity_probe.py).  On the large maps the two pixels of a pair share a launch (_parity_plan).
     def _parity_plan(self, key, spec):
         # geometry only: shared by every ConvSideBackward of the process (the frozen-statistics backward builds one per step,
         # and an index upload is a pageable host-to-device copy that waits for the stream to drain)
-        key = (str(spec.weight.device), spec.cout, spec.cin, spec.weight.shape[1], spec.w_out)
+        # row pairs on the large maps (112 / 56: 543 -> 314 us, 758 -> 524, 419 -> 367), four classes on the 28 x 28 ones (192 vs 206 us)
+        rows = spec.h_in >= 56 and not hip.env_flag("MSCLIP_DGRAD_PARITY4")
+        key = (str(spec.weight.device), spec.cout, spec.cin, spec.weight.shape[1], spec.w_out, rows)
         plan = self._pplan.get(key)
         if plan is None:
             co, ci, kp = spec.cout, spec.cin, spec.weight.shape[1]
             src = torch.arange(co * kp).view(co, kp)[:, :9 * ci].view(co, 3, 3, ci)
-            zero_at = 9 * ci if kp > 9 * ci else None        # a pad column of the packed filter (zero) for K padding
-            idx, parts = [], []
+            idx, parts, ktabs = [], [], []
+
+            def add(t, py, px, ntaps_x, N):
+                K = t.shape[1]
+                Kp = (K + 63) // 64 * 64
+                if Kp != K:
+                    t = torch.cat([t, torch.full((t.shape[0], Kp - K), -1, dtype=t.dtype)], 1)
+                parts.append((py, px, sum(x.numel() for x in idx), Kp, N))
+                idx.append(t.reshape(-1))
+                ktabs.append((1 + py, ntaps_x))
             for py in (0, 1):
-                for px in (0, 1):
-                    kys, kxs = ([1] if py == 0 else [2, 0]), ([1] if px == 0 else [2, 0])
-                    t = src[:, kys][:, :, kxs].permute(3, 1, 2, 0).reshape(ci, -1)       # [ci, (a, b, co)]
-                    K = t.shape[1]
-                    Kp = (K + 63) // 64 * 64
-                    if Kp != K:
-                        if zero_at is None:
-                            self._pplan[key] = False
-                            return False
-                        t = torch.cat([t, torch.full((ci, Kp - K), zero_at, dtype=t.dtype)], 1)
-                    parts.append((py, px, sum(x.numel() for x in idx), Kp))
-                    idx.append(t.reshape(-1))
+                kys = [1] if py == 0 else [2, 0]
+                if rows:
+                    # ONE launch per input-row parity: both pixels of a pair (px = 0, 1) are 2 * ci output columns of the
+                    # same GEMM row over the taps b = 0, 1 (px = 0 has no b = 1 tap: zero filter block) -- dY is read twice
+                    # instead of four times and an output row is a full 2 * ci * 2-byte segment of dX
+                    t0 = src[:, kys][:, :, [1]]                                            # px = 0: tap b = 0 is kx = 1
+                    t0 = torch.cat([t0, torch.full_like(t0, -1)], 2)                       #         tap b = 1: nothing
+                    t1 = src[:, kys][:, :, [2, 0]]                                         # px = 1: b = 0 -> kx = 2, b = 1 -> kx = 0
+                    t = torch.cat([t0.permute(3, 1, 2, 0).reshape(ci, -1), t1.permute(3, 1, 2, 0).reshape(ci, -1)], 0)
+                    add(t, py, 0, 2, 2 * ci)
+                else:
+                    for px in (0, 1):
+                        kxs = [1] if px == 0 else [2, 0]
+                        add(src[:, kys][:, :, kxs].permute(3, 1, 2, 0).reshape(ci, -1), py, px, 1 + px, ci)   # [ci, (a, b, co)]
             dev = spec.weight.device
-            plan = self._pplan[key] = dict(idx=torch.cat(idx).to(dev), parts=parts,
-                                           ktab=[P.ktab_on(dev, 1 + py, 1 + px, co, spec.w_out) for py, px, _, _ in parts])
+            flat = torch.cat(idx)
+            plan = self._pplan[key] = dict(idx=flat.clamp_min(0).to(dev), mask=(flat >= 0).to(torch.bfloat16).to(dev), parts=parts,
+                                           ktab=[P.ktab_on(dev, kh_, kw_, co, spec.w_out) for kh_, kw_ in ktabs])
         return plan
 
     def _parity_ok(self, spec):
@@ -129,10 +142,10 @@ class ConvSideBackward:
 
     def _dgrad_parity(self, plan, spec, dpre, dx, B):
         co, ci, Ho, Wo = spec.cout, spec.cin, spec.h_out, spec.w_out
-        wp = torch.index_select(spec.weight.reshape(-1), 0, plan["idx"])                  # the four class filters, one gather
+        wp = torch.index_select(spec.weight.reshape(-1), 0, plan["idx"]).mul_(plan["mask"])      # the class filters: one gather, zero blocks masked
         dx2 = dx.view(B * spec.h_in * Wo, 2 * ci)
-        for (py, px, off, Kp), kt in zip(plan["parts"], plan["ktab"]):
-            hip.gemm(dpre, wp[off:off + ci * Kp].view(ci, Kp), dx2[:, px * ci:(px + 1) * ci], M=B * Ho * Wo, N=ci,
+        for (py, px, off, Kp, N), kt in zip(plan["parts"], plan["ktab"]):
+            hip.gemm(dpre, wp[off:off + N * Kp].view(N, Kp), dx2[:, px * ci:px * ci + N], M=B * Ho * Wo, N=N,
                      conv=(Ho, Wo, co, Ho, Wo, 1, 0), ktab=kt, ldo=2 * ci, rpg=Wo, radd=Wo, roff=py * Wo)
 
     def _conv_bwd(self, key, spec, x_in, dpre, B, need_dx=True, col=None, lane=False):

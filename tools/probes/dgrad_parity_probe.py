@@ -13,7 +13,7 @@ g = torch.Generator().manual_seed(3)
 bw = object.__new__(TC.ConvSideBackward)
 bw._wt, bw._pplan = {}, TC._PARITY_PLANS
 for name, ci, co, h in [("par1.conv2", 48, 48, 112), ("stem0.conv1", 48, 96, 112), ("par2.conv2", 96, 96, 56), ("stem1.conv1", 96, 192, 56),
-                        ("par3.conv2", 192, 192, 28), ("stem2.conv1", 192, 384, 28), ("par4.conv2", 384, 384, 14), ("stem3.conv1", 384, 768, 14)]:
+                        ("par3.conv2", 192, 192, 28), ("stem2.conv1", 192, 384, 28)]:
     w = torch.randn(co, ci, 3, 3, generator=g) * (2.0 / (9 * ci)) ** 0.5
     spec = P.ConvSpec(w, torch.zeros(co), h, h, 2, 1).to("cuda")
     ho = spec.h_out
