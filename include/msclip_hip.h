@@ -37,7 +37,9 @@ extern "C" {
  *   Training-step forms (ping-pong kernel only, dense X, N % 8 == 0): out2 != NULL additionally stores v BEFORE the
  *   activation (bf16, leading dimension ldo) -- c_fc writes the pre-activation the backward needs and QuickGELU(v) in one
  *   launch; resid_kind 4: v *= QuickGELU'(resid) with resid bf16 [m][n] -- the dgrad GEMM of c_proj applies the activation's
- *   derivative (d/dh h sigma(1.702 h)) on the saved pre-activation in its epilogue. */
+ *   derivative (d/dh h sigma(1.702 h)) on the saved pre-activation in its epilogue.
+ *   resid_kind 5 (mode 1, generic / streaming kernels): v = resid[store row][n] > 0 ? v : 0 with resid bf16 -- ReLU backward on the
+ *   saved activation, which is laid out like the output (same row scatter, ldr); the conv side's input gradients. */
 typedef struct msclip_gemm_desc {
   const void* X;
   const void* W;

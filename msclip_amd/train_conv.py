@@ -140,18 +140,25 @@ class ConvSideBackward:
                 and spec.h_in >= 28                  # (14 x 14 maps: the four launches cost more than the small column matrix)
                 and not hip.env_flag("MSCLIP_DGRAD_COL2IM"))
 
-    def _dgrad_parity(self, plan, spec, dpre, dx, B):
+    def _dgrad_parity(self, plan, spec, dpre, dx, B, relu_of=None):
+        """relu_of: the saved post-ReLU activation the convolution read (bf16, laid out like dx): the launches then store
+        dX * (activation > 0) -- the ReLU backward that follows in the chain, in the epilogue (msclip_gemm resid_kind 5)."""
         co, ci, Ho, Wo = spec.cout, spec.cin, spec.h_out, spec.w_out
         wp = torch.index_select(spec.weight.reshape(-1), 0, plan["idx"]).mul_(plan["mask"])      # the class filters: one gather, zero blocks masked
-        dx2 = dx.view(B * spec.h_in * Wo, 2 * ci)
+        rows = B * spec.h_in * Wo
+        dx2 = dx.view(rows, 2 * ci)
+        y2 = relu_of[:B * spec.h_in * spec.w_in].view(rows, 2 * ci) if relu_of is not None else None
         for (py, px, off, Kp, N), kt in zip(plan["parts"], plan["ktab"]):
             hip.gemm(dpre, wp[off:off + N * Kp].view(N, Kp), dx2[:, px * ci:px * ci + N], M=B * Ho * Wo, N=N,
-                     conv=(Ho, Wo, co, Ho, Wo, 1, 0), ktab=kt, ldo=2 * ci, rpg=Wo, radd=Wo, roff=py * Wo)
+                     conv=(Ho, Wo, co, Ho, Wo, 1, 0), ktab=kt, ldo=2 * ci, rpg=Wo, radd=Wo, roff=py * Wo,
+                     resid=y2[:, px * ci:px * ci + N] if y2 is not None else None, ldr=2 * ci,
+                     resid_kind=hip.RESID_RELUMASK if y2 is not None else 0)
 
-    def _conv_bwd(self, key, spec, x_in, dpre, B, need_dx=True, col=None, lane=False):
+    def _conv_bwd(self, key, spec, x_in, dpre, B, need_dx=True, col=None, lane=False, relu_of=None):
         """dpre: bf16 [B*Ho*Wo, cout] (with slack) -> (G [cout, cin, kh, kw] fp32 wrt the folded filter, dbias [cout],
         dx NHWC bf16 [B*H*W, cin] or None).  lane=True: the weight gradient runs on gradgemm's lane stream (G may only be
-        read after gradgemm.join) and no bias gradient is formed."""
+        read after gradgemm.join) and no bias gradient is formed.  relu_of: dx is returned through the backward of the ReLU
+        that produced this (bf16) activation -- in the parity launches' epilogues where they run, a msclip_relu_bwd pass else."""
         co, ci, kh, kw = spec.cout, spec.cin, spec.kh, spec.kw
         pix = B * spec.h_out * spec.w_out
         K = kh * kw * ci
@@ -182,7 +189,10 @@ class ConvSideBackward:
                 hip.gemm(dpre, wt, dx, M=pix, N=ci, ldx=co)
             elif self._parity_ok(spec) and self._parity_plan(key, spec):
                 dx = _zbuf(B * spec.h_in * spec.w_in, ci, dpre.device)
-                self._dgrad_parity(self._parity_plan(key, spec), spec, dpre, dx, B)
+                fuse = relu_of is not None and relu_of.dtype == BF and not hip.env_flag("MSCLIP_RELU_BWD_PASS")
+                self._dgrad_parity(self._parity_plan(key, spec), spec, dpre, dx, B, relu_of=relu_of if fuse else None)
+                if fuse:
+                    relu_of = None
             else:
                 kp = spec.weight.shape[1]
                 wt = self._w_t(key, spec.weight, co, kp)
@@ -191,6 +201,8 @@ class ConvSideBackward:
                 dx = _zbuf(B * spec.h_in * spec.w_in, ci, dpre.device)
                 hip.col2im(dcol, dx, B, spec.h_in, spec.w_in, ci, kh, kw, spec.stride, spec.pad)
                 del dcol
+            if relu_of is not None:
+                dx = self._relu_bwd(dx, relu_of)
         return G, db, dx
 
     def _fold_on_lane(self, grads, fold, conv_key, G, w_raw, dshift, also=None):
@@ -300,10 +312,9 @@ class ConvSideBackward:
         fold("residual_conv", "residual_bn", G, dpre, cr)
         del dpre
         dt2 = self._relu_bwd(dt2, t2)
-        G, _, dt1 = self._conv_bwd(("par", j, 2), c2, t1, dt2, Bi, lane=True)
+        G, _, dt1 = self._conv_bwd(("par", j, 2), c2, t1, dt2, Bi, lane=True, relu_of=t1)      # (through t1's ReLU)
         fold("conv2", "bn2", G, dt2, c2)
         del dt2
-        dt1 = self._relu_bwd(dt1, t1)
         G, _, dsrc_b = self._conv_bwd(("par", j, 1), c1, src, dt1, Bi, lane=True)
         fold("conv1", "bn1", G, dt1, c1)
         self.dpar = [dsrc_a, dsrc_b]
@@ -326,14 +337,15 @@ class ConvSideBackward:
             spec = e.stem_specs[i]
             q = f"{sp}.resnet_stage.conv_{i}"
             x_in = w["stem"][i - 1] if i else w["S1"]
-            dpre = self._relu_bwd(dy, w["stem"][i])
-            G, _, dy = self._conv_bwd(("stem", i), spec, x_in, dpre, Bi, lane=True)
+            # dy arrives through the ReLU of this stage's output: from the previous iteration's convolution backward
+            # (relu_of = its input map = this stage's output), or the pass below for the last stage
+            dpre = self._relu_bwd(dy, w["stem"][i]) if i == len(e.stem_specs) - 1 else dy
+            G, _, dy = self._conv_bwd(("stem", i), spec, x_in, dpre, Bi, lane=True, relu_of=x_in)
             dbias = hip.colsum(dpre, M=Bi * spec.h_out * spec.w_out)
             self._fold_on_lane(grads, _Fold(sd, q + ".bn1", 1e-5), q + ".conv1.weight", G, sd[q + ".conv1.weight"].float(), dbias,
                                also=(_Fold(sd, q + ".downsample.1", 1e-5), q + ".downsample.0.weight",
                                      sd[q + ".downsample.0.weight"].float()))
-        dpre = self._relu_bwd(dy, w["S1"])
-        self._first_conv(grads, sp + ".conv1.weight", sp + ".bn1", dpre)
+        self._first_conv(grads, sp + ".conv1.weight", sp + ".bn1", dy)          # (dy already went through S1's ReLU: relu_of above)
         self.col_img = None
 
 
@@ -534,8 +546,8 @@ class ConvSideBatchNorm:
         grads[prefix + ".weight"], grads[prefix + ".bias"] = dg, db
         return dx
 
-    def _conv(self, grads, key, spec, wkey, x_in, draw, need_dx=True):
-        G, _, dx = self.bw._conv_bwd(key, spec, x_in, draw, self.Bi, need_dx=need_dx, lane=True)
+    def _conv(self, grads, key, spec, wkey, x_in, draw, need_dx=True, relu_of=None):
+        G, _, dx = self.bw._conv_bwd(key, spec, x_in, draw, self.Bi, need_dx=need_dx, lane=True, relu_of=relu_of)
         grads[wkey] = G                                  # final after gradgemm.join (end of the backward / bucket flush)
         return dx
 
@@ -595,9 +607,9 @@ class ConvSideBatchNorm:
         dsrc_a = self._conv(grads, ("par", j, "r"), cr, q + ".residual_conv.weight", src, dr)
         del d3, dr
         d2 = self._bn_bwd(grads, q + ".bn2", self.bw._relu_bwd(dt2, t2))
-        dt1 = self._conv(grads, ("par", j, 2), c2, q + ".conv2.weight", t1, d2)
+        dt1 = self._conv(grads, ("par", j, 2), c2, q + ".conv2.weight", t1, d2, relu_of=t1)      # (through t1's ReLU)
         del d2, dt2
-        d1 = self._bn_bwd(grads, q + ".bn1", self.bw._relu_bwd(dt1, t1))
+        d1 = self._bn_bwd(grads, q + ".bn1", dt1)
         dsrc_b = self._conv(grads, ("par", j, 1), c1, q + ".conv1.weight", src, d1)
         self.bw.dpar = [dsrc_a, dsrc_b]
 

@@ -816,6 +816,10 @@ def test_conv_input_gradient_by_parity_classes(gpu_device, monkeypatch, ci, co, 
     assert (dx.float() - ref).abs().max().item() <= 6e-3 * sc            # one bf16 rounding of an fp32 sum
     assert (dx2.float() - ref).abs().max().item() <= 1.2e-2 * sc         # (the column matrix rounds every tap's product first)
     assert torch.equal(G, G2) and torch.equal(db, db2)
+    # through the ReLU that produced x_in: in the launches' epilogues (msclip_gemm resid_kind 5) = a msclip_relu_bwd pass over dx
+    monkeypatch.delenv("MSCLIP_DGRAD_COL2IM")
+    _, _, dxr = bw._conv_bwd("t", spec, x_in, dpre, B, col=col, relu_of=x_in)
+    assert torch.equal(dxr, torch.where(x_in[:B * h * h] > 0, dx, torch.zeros_like(dx)))
 
 
 @pytest.mark.parametrize("T,No,Ni", [(70000, 96, 864), (66000, 48, 448), (8000, 192, 1728), (4097, 768, 96), (3000, 384, 192)])
