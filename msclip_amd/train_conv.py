@@ -222,6 +222,13 @@ class ConvSideBackward:
                 for key in (k, f.prefix + ".weight", f.prefix + ".bias"):
                     grads[key].record_stream(cur)
 
+    def _colsum_on_lane(self, dpre, M):
+        """Bias gradient (column sums of dY) for a fold whose chain rule runs on the lane anyway (_fold_on_lane): the pass over
+        dY moves off the critical path with it (MSCLIP_COLSUM_MAIN=1: on the calling stream, as before)."""
+        if hip.env_flag("MSCLIP_COLSUM_MAIN"):
+            return hip.colsum(dpre, M=M)
+        return gradgemm.on_lane(lambda: hip.colsum(dpre, M=M), dpre)
+
     def _relu_bwd(self, dy, y, dy2=None):
         out = _zbuf(dy.shape[0], dy.shape[1], dy.device)
         hip.relu_bwd(dy, y[:dy.shape[0]], out, dy2=dy2)
@@ -304,7 +311,7 @@ class ConvSideBackward:
 
         def fold(conv, bn, G, dpre_, spec):
             # weight gradient + the fold's chain rule on the lane stream; the bias sum (main stream) feeds the latter
-            dbias = hip.colsum(dpre_, M=Bi * spec.h_out * spec.w_out)
+            dbias = self._colsum_on_lane(dpre_, Bi * spec.h_out * spec.w_out)
             self._fold_on_lane(grads, _Fold(sd, f"{q}.{bn}", 1e-6), f"{q}.{conv}.weight", G, sd[f"{q}.{conv}.weight"].float(), dbias)
         G, _, dt2 = self._conv_bwd(("par", j, 3), c3, t2, dpre, Bi, lane=True)
         fold("conv3", "bn3", G, dpre, c3)
@@ -341,7 +348,7 @@ class ConvSideBackward:
             # (relu_of = its input map = this stage's output), or the pass below for the last stage
             dpre = self._relu_bwd(dy, w["stem"][i]) if i == len(e.stem_specs) - 1 else dy
             G, _, dy = self._conv_bwd(("stem", i), spec, x_in, dpre, Bi, lane=True, relu_of=x_in)
-            dbias = hip.colsum(dpre, M=Bi * spec.h_out * spec.w_out)
+            dbias = self._colsum_on_lane(dpre, Bi * spec.h_out * spec.w_out)
             self._fold_on_lane(grads, _Fold(sd, q + ".bn1", 1e-5), q + ".conv1.weight", G, sd[q + ".conv1.weight"].float(), dbias,
                                also=(_Fold(sd, q + ".downsample.1", 1e-5), q + ".downsample.0.weight",
                                      sd[q + ".downsample.0.weight"].float()))
