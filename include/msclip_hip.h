@@ -344,6 +344,12 @@ int msclip_dw3x3_wgrad(const float* dsum, int lds, const float* x, int ldx, floa
 int msclip_bn_stats(const void* x, int ld, int x_f32, float* part, int M, int C, int chunks, void* stream);
 int msclip_bn_apply(const void* x, int ld, int x_f32, const float* scale, const float* shift, const void* resid, int ldr,
                     void* y, int ldy, int y_f32, int M, int C, int relu, void* stream);
+/* msclip_bn_finish with every output vector written `rep` times back to back (out [5][rep * C]): the tiled per-channel vectors the
+ * passes over r-folded narrow maps read.  msclip_bn_bwd_finish: part [chunks][2][r * C] of msclip_bn_bwd_reduce ->
+ * out [3][r * C] = (dbeta, dgamma, gamma), each tiled r times (fixed summation order). */
+int msclip_bn_finish_tiled(const float* sums, int r, int C, long long n, const float* gamma, const float* beta, float eps,
+                           float* out, int rep, void* stream);
+int msclip_bn_bwd_finish(const float* part, int chunks, int r, int C, const float* gamma, float* out, void* stream);
 int msclip_bn_bwd_reduce(const void* dy, int lddy, int dy_f32, const void* x, int ld, int x_f32, const float* mean,
                          const float* rstd, float* part, int M, int C, int chunks, void* stream);
 int msclip_bn_bwd_dx(const void* dy, int lddy, int dy_f32, const void* x, int ld, int x_f32, const float* mean,

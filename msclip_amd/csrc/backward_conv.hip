@@ -644,7 +644,7 @@ namespace {
 // -> out[0] = mean, out[1] = biased variance, out[2] = rstd, out[3] = scale = gamma rstd, out[4] = shift = beta - mean scale.
 __global__ __launch_bounds__(256) void bn_finish_kernel(const float* __restrict__ sums, int r, int C, float inv_n,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                                        float* __restrict__ out) {
+                                                        float* __restrict__ out, int rep) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   float s1 = 0.f, s2 = 0.f;
@@ -656,11 +656,52 @@ __global__ __launch_bounds__(256) void bn_finish_kernel(const float* __restrict_
   const float var = fmaxf(s2 * inv_n - mean * mean, 0.f);
   const float rstd = 1.f / sqrtf(var + eps);
   const float sc = gamma[c] * rstd;
-  out[c] = mean;
-  out[C + c] = var;
-  out[2 * C + c] = rstd;
-  out[3 * C + c] = sc;
-  out[4 * C + c] = beta[c] - mean * sc;
+  // every vector is written `rep` times back to back (row stride rep * C): the passes over a narrow map read r rows as one wide
+  // row and take their per-channel vectors tiled r times -- from here instead of five ATen repeat launches per BatchNorm
+  for (int j = 0; j < rep; ++j) {
+    const size_t o = (size_t)j * C + c, ld = (size_t)rep * C;
+    out[o] = mean;
+    out[ld + o] = var;
+    out[2 * ld + o] = rstd;
+    out[3 * ld + o] = sc;
+    out[4 * ld + o] = beta[c] - mean * sc;
+  }
+}
+
+// Tail of the train-mode BatchNorm backward: part [chunks][2][r * C] (msclip_bn_bwd_reduce over r-folded rows) ->
+// out[0] = dbeta, out[1] = dgamma, out[2] = gamma, each [C] tiled `r` times (row stride r * C): what msclip_bn_bwd_dx reads.
+__global__ __launch_bounds__(256) void bn_bwd_finish_kernel(const float* __restrict__ part, int chunks, int r, int C,
+                                                            const float* __restrict__ gamma, float* __restrict__ out) {
+  // one workgroup per channel: up to 512 chunks x 16 folds of partials per channel -- 256 threads stride over them, then a
+  // fixed-order tree in LDS (deterministic)
+  __shared__ float red[2][256];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const size_t ld = (size_t)r * C;
+  float sb = 0.f, sg = 0.f;
+  for (int i = tid; i < chunks * r; i += 256) {
+    const int k = i / r, j = i - k * r;
+    sb += part[(size_t)k * 2 * ld + (size_t)j * C + c];
+    sg += part[(size_t)k * 2 * ld + ld + (size_t)j * C + c];
+  }
+  red[0][tid] = sb;
+  red[1][tid] = sg;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (tid < w) {
+      red[0][tid] += red[0][tid + w];
+      red[1][tid] += red[1][tid + w];
+    }
+    __syncthreads();
+  }
+  sb = red[0][0];
+  sg = red[1][0];
+  const float g = gamma[c];
+  for (int j = tid; j < r; j += 256) {
+    const size_t o = (size_t)j * C + c;
+    out[o] = sb;
+    out[ld + o] = sg;
+    out[2 * ld + o] = g;
+  }
 }
 }  // namespace
 
@@ -668,6 +709,20 @@ extern "C" int msclip_bn_finish(const float* sums, int r, int C, long long n, co
                                 float* out, void* stream) {
   if (!sums || !gamma || !beta || !out || r <= 0 || C <= 0 || n <= 0) return MSCLIP_EINVAL;
   hipLaunchKernelGGL(bn_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, r, C, 1.f / (float)n, gamma,
-                     beta, eps, out);
+                     beta, eps, out, 1);
+  return msclip_launch_status();
+}
+
+extern "C" int msclip_bn_finish_tiled(const float* sums, int r, int C, long long n, const float* gamma, const float* beta, float eps,
+                                      float* out, int rep, void* stream) {
+  if (!sums || !gamma || !beta || !out || r <= 0 || C <= 0 || n <= 0 || rep <= 0) return MSCLIP_EINVAL;
+  hipLaunchKernelGGL(bn_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, r, C, 1.f / (float)n, gamma,
+                     beta, eps, out, rep);
+  return msclip_launch_status();
+}
+
+extern "C" int msclip_bn_bwd_finish(const float* part, int chunks, int r, int C, const float* gamma, float* out, void* stream) {
+  if (!part || !gamma || !out || chunks <= 0 || r <= 0 || C <= 0) return MSCLIP_EINVAL;
+  hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, part, chunks, r, C, gamma, out);
   return msclip_launch_status();
 }

@@ -24,7 +24,7 @@ EXPORTS = (
     "msclip_attention_bwd", "msclip_l2norm_bwd", "msclip_clip_loss_bwd_g", "msclip_embed_tokens_bwd", "msclip_adapter_sum",
     "msclip_adapter_dx", "msclip_adamw", "msclip_adamw_multi", "msclip_im2col", "msclip_col2im", "msclip_relu_bwd", "msclip_dwpool_bwd",
     "msclip_dwpool_wgrad", "msclip_dw3x3_wgrad", "msclip_gemm_splitk", "msclip_gemm_splitk_tn", "msclip_bn_stats", "msclip_bn_apply",
-    "msclip_bn_bwd_reduce", "msclip_bn_bwd_dx", "msclip_bn_fold_bwd", "msclip_bn_finish",
+    "msclip_bn_bwd_reduce", "msclip_bn_bwd_dx", "msclip_bn_fold_bwd", "msclip_bn_finish", "msclip_bn_finish_tiled", "msclip_bn_bwd_finish",
     "msclip_abi_version", "msclip_build_arch",
     "msclip_stream_priority_range", "msclip_stream_create", "msclip_stream_destroy",
 )
@@ -135,6 +135,8 @@ def lib():
         L.msclip_bn_bwd_reduce.argtypes = [vp, ci, ci, vp, ci, ci, vp, vp, vp, ci, ci, ci, vp]
         L.msclip_bn_bwd_dx.argtypes = [vp, ci, ci, vp, ci, ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ll, vp]
         L.msclip_bn_finish.argtypes = [vp, ci, ci, ll, vp, vp, cf, vp, vp]
+        L.msclip_bn_finish_tiled.argtypes = [vp, ci, ci, ll, vp, vp, cf, vp, ci, vp]
+        L.msclip_bn_bwd_finish.argtypes = [vp, ci, ci, ci, vp, vp, vp]
         L.msclip_bn_fold_bwd.argtypes = [vp, ll, vp, ci, ci, vp, vp, vp, vp, cf, vp, vp, vp, vp]
         L.msclip_abi_version.restype = ci
         L.msclip_build_arch.restype = ctypes.c_char_p
@@ -974,9 +976,14 @@ def bn_stats(x, M=None, gamma=None, beta=None, eps=1e-5):
     plain = gamma is None
     if plain:
         gamma, beta = _bn_unit(C, x.device)
-    out = torch.empty(5, C, dtype=torch.float32, device=x.device)
-    _check(lib().msclip_bn_finish(_p(sums), r, C, M, _p(gamma), _p(beta), eps, _p(out), _stream()), "msclip_bn_finish")
-    return (out[0], out[1]) if plain else (out[0], out[1], out[2], out[3], out[4])
+    # every vector tiled r times (out [5][r * C]): bn_apply / bn_bwd over the same r-folded map take the tiled rows as they are
+    # (instead of a repeat() launch per vector per pass); the tensors handed back are the first C entries
+    out = torch.empty(5, r * C, dtype=torch.float32, device=x.device)
+    _check(lib().msclip_bn_finish_tiled(_p(sums), r, C, M, _p(gamma), _p(beta), eps, _p(out), r, _stream()), "msclip_bn_finish_tiled")
+    vecs = tuple(out[k, :C] for k in range(5))
+    for v in vecs:
+        v._bn_tiled = (out, r)
+    return vecs[:2] if plain else vecs
 
 
 _BN_UNIT = {}
@@ -997,7 +1004,11 @@ def bn_apply(x, scale, shift, out, M=None, relu=False, resid=None):
     if r > 1:                                            # narrow maps: r rows as one row of r*C columns (full cache lines per wave)
         xs, os_ = xs.view(M // r, C * r), os_.view(M // r, C * r)
         rs = rs.view(M // r, C * r) if rs is not None else None
-        scale, shift = scale.repeat(r), shift.repeat(r)
+        t = getattr(scale, "_bn_tiled", None)
+        if t is not None and t[1] == r and getattr(shift, "_bn_tiled", (None,))[0] is t[0]:
+            scale, shift = t[0][3], t[0][4]              # bn_stats' own tiled rows
+        else:
+            scale, shift = scale.repeat(r), shift.repeat(r)
     _check(lib().msclip_bn_apply(_p(xs), xs.stride(0), int(x.dtype == torch.float32), _p(scale), _p(shift),
                                  _p(rs) if rs is not None else None, rs.stride(0) if rs is not None else 0,
                                  _p(os_), os_.stride(0), int(out.dtype == torch.float32), M // r, C * r, int(relu), _stream()),
@@ -1015,20 +1026,25 @@ def bn_bwd(dy, x, mean, rstd, gamma, dx, M=None):
     x, dy = x[:M], dy[:M]
     r = _bn_fold_rows(M, C, x, dy)
     xw, dyw = (x.view(M // r, C * r), dy.view(M // r, C * r)) if r > 1 else (x, dy)
-    mw, rw = (mean.repeat(r), rstd.repeat(r)) if r > 1 else (mean, rstd)
+    t = getattr(mean, "_bn_tiled", None)
+    if r > 1 and t is not None and t[1] == r and getattr(rstd, "_bn_tiled", (None,))[0] is t[0]:
+        mw, rw = t[0][0], t[0][2]                        # bn_stats' own tiled rows
+    else:
+        mw, rw = (mean.repeat(r), rstd.repeat(r)) if r > 1 else (mean, rstd)
     Mw, Cw = xw.shape
     ch = _bn_chunks(Mw)
     part = torch.empty(ch, 2 * Cw, dtype=torch.float32, device=x.device)
     _check(lib().msclip_bn_bwd_reduce(_p(dyw), dyw.stride(0), df, _p(xw), xw.stride(0), xf, _p(mw), _p(rw), _p(part), Mw, Cw,
                                       ch, _stream()), "msclip_bn_bwd_reduce")
-    s = (colsum(part) if ch > 1 else part[0]).view(2, r, C).sum(1)
-    dbeta, dgamma = s[0].contiguous(), s[1].contiguous()
+    # the per-channel tail in ONE launch: chunk / fold sums, and (dbeta, dgamma, gamma) tiled r times for the dx pass
+    tail = torch.empty(3, r * C, dtype=torch.float32, device=x.device)
+    _check(lib().msclip_bn_bwd_finish(_p(part), ch, r, C, _p(gamma), _p(tail), _stream()), "msclip_bn_bwd_finish")
+    dbeta, dgamma = tail[0, :C], tail[1, :C]
     dxs = dx[:M]
     if r > 1 and dxs.is_contiguous():
         dxw = dxs.view(M // r, C * r)
-        gw, bw_, dgw = gamma.repeat(r), dbeta.repeat(r), dgamma.repeat(r)     # named: a dropped temporary's block is re-used at once
-        _check(lib().msclip_bn_bwd_dx(_p(dyw), dyw.stride(0), df, _p(xw), xw.stride(0), xf, _p(mw), _p(rw), _p(gw), _p(bw_),
-                                      _p(dgw), _p(dxw), dxw.stride(0), Mw, Cw, M, _stream()), "msclip_bn_bwd_dx")
+        _check(lib().msclip_bn_bwd_dx(_p(dyw), dyw.stride(0), df, _p(xw), xw.stride(0), xf, _p(mw), _p(rw), _p(tail[2]), _p(tail[0]),
+                                      _p(tail[1]), _p(dxw), dxw.stride(0), Mw, Cw, M, _stream()), "msclip_bn_bwd_dx")
     else:
         _check(lib().msclip_bn_bwd_dx(_p(dy), dy.stride(0), df, _p(x), x.stride(0), xf, _p(mean), _p(rstd), _p(gamma),
                                       _p(dbeta), _p(dgamma), _p(dx), dx.stride(0), M, C, M, _stream()), "msclip_bn_bwd_dx")

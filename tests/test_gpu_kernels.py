@@ -907,6 +907,24 @@ def test_layernorm_stats_rows(gpu_device):
     assert bool((rs[:, 0] == 1).all()) and bool((rs[:, 1] == 0).all())
 
 
+@pytest.mark.parametrize("M,N,K,out_f32", [(8192, 96, 128, False), (5000, 48, 64, True), (4100, 192, 192, False)])
+def test_stream_gemm_row_scatter(gpu_device, M, N, K, out_f32):
+    """The streaming small-K kernel with the descriptor's row scatter (store row m + (m / rpg) * radd + roff; round 4: the input
+    gradients of the stride-2 convolutions scatter their parity classes this way).  Rows that are not store targets stay untouched."""
+    x, w = rnd(M, K, seed=3, dtype=BF), rnd(N, K, seed=4, scale=0.1, dtype=BF)
+    assert hip.gemm_variant(hip.describe_gemm(0, M, N, K, 0, None, rpg=49)) == "stream"
+    rows = M + (M // 49) * 3 + 2
+    out = torch.full((rows, N), float("nan"), dtype=torch.float32 if out_f32 else BF, device="cuda")
+    hip.gemm(x, w, out, M=M, rpg=49, radd=3, roff=2)
+    m = torch.arange(M, device="cuda")
+    tgt = m + (m // 49) * 3 + 2
+    ref = x.float() @ w.float().t()
+    close(out[tgt], ref, 2e-2 if not out_f32 else 1e-3, 1e-2 if not out_f32 else 1e-4)
+    rest = torch.ones(rows, dtype=torch.bool, device="cuda")
+    rest[tgt] = False
+    assert bool(torch.isnan(out[rest].float()).all())
+
+
 def test_layernorm_fold_producer_second_residual_stream(gpu_device):
     """msclip_gemm_desc.resid2: the rows from seg_split on read their residual from a second matrix (the text rows' stream is
     `out`, the image rows' sits in the lateral adapter's output buffer): bitwise the one-stream launch on the joined rows."""

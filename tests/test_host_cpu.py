@@ -242,7 +242,8 @@ def test_gemm_dispatch_rule_is_the_librarys_own():
     assert v(1, 401408, 96, 0, 896, c3(512, 56, 96)) == "conv128"
     assert v(1, 1000, 64, 0, 576, (10, 10, 64, 10, 10, 1, 1)) == "conv128"
     assert v(0, 65024, 768, 0, 100) == "invalid"        # K % 64
-    assert v(0, 25088, 768, 0, 64, rpg=49) == "pp"      # row scatter never streams
+    assert v(0, 25088, 768, 0, 64, rpg=49) == "stream"  # plain row scatter streams too (round 4: the parity-class input gradients)
+    assert v(0, 25088, 768, 0, 768, rpg=49) == "pp"
 
 
 def test_reference_shim_layout_import(tmp_path):
