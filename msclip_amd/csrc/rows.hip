@@ -336,7 +336,12 @@ __global__ __launch_bounds__(256) void adapter_gridrow_kernel(const float* __res
                                                               const float* __restrict__ beta1, bf16_t* __restrict__ lno, int ldl,
                                                               float* __restrict__ center, float* __restrict__ rowstat) {
   const int lane = threadIdx.x & 63;
-  const int r = blockIdx.x * WPB + (threadIdx.x >> 6);
+  // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2), and neighbouring grid rows -- which read each other's
+  // tokens for the 3 x 3 filter -- sit in neighbouring workgroups: consecutive ROWS go to one XCD (bijective remap of the
+  // workgroup id), so a token row is fetched from the fabric once instead of by up to three L2s
+  const int nb = gridDim.x, q = nb >> 3, rem = nb & 7, xcd = blockIdx.x & 7;
+  const int bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (blockIdx.x >> 3);
+  const int r = bid * WPB + (threadIdx.x >> 6);
   if (r >= B * g) return;
   // msclip_adapter_combine_ln_stats: the block's ln_1 of the row just written, from the registers it is still in (the same
   // fp32 values a LayerNorm pass would read back from xout), plus the LayerNorm fold's per-row state of msclip_layernorm_stats
