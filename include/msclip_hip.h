@@ -39,7 +39,9 @@ extern "C" {
  *   launch; resid_kind 4: v *= QuickGELU'(resid) with resid bf16 [m][n] -- the dgrad GEMM of c_proj applies the activation's
  *   derivative (d/dh h sigma(1.702 h)) on the saved pre-activation in its epilogue.
  *   resid_kind 5 (mode 1, generic / streaming kernels): v = resid[store row][n] > 0 ? v : 0 with resid bf16 -- ReLU backward on the
- *   saved activation, which is laid out like the output (same row scatter, ldr); the conv side's input gradients. */
+ *   saved activation, which is laid out like the output (same row scatter, ldr); the conv side's input gradients.
+ *   resid_kind 6 (bf16 out, generic / streaming kernels): v += resid[store row][n] (bf16) -- a scattered launch accumulating into
+ *   an existing map (resid == out: in place); the stride-2 shortcuts' input gradients into their block's main-path gradient. */
 typedef struct msclip_gemm_desc {
   const void* X;
   const void* W;

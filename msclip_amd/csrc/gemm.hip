@@ -183,6 +183,10 @@ __device__ __forceinline__ void epilogue_generic(f32x16 (&acc)[TN][TM], const ms
             const uint2 rv = *(const uint2*)((const bf16_t*)a.resid + rrow * a.ldr + n);
             v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
             v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
+          } else if (a.resid_kind == 6) {        // accumulate: + the bf16 value already at the STORE row (in-place out += v)
+            const uint2 rv = *(const uint2*)((const bf16_t*)a.resid + orow * a.ldr + n);
+            v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
+            v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
           } else if (a.resid_kind == 5) {        // ReLU backward: keep v where the saved activation (bf16, at the STORE row) is > 0
             const uint2 rv = *(const uint2*)((const bf16_t*)a.resid + orow * a.ldr + n);
             v[0] = __uint_as_float(rv.x << 16) > 0.f ? v[0] : 0.f; v[1] = __uint_as_float(rv.x & 0xffff0000u) > 0.f ? v[1] : 0.f;
@@ -210,6 +214,7 @@ __device__ __forceinline__ void epilogue_generic(f32x16 (&acc)[TN][TM], const ms
             if (a.resid_kind == 1 || a.resid_kind == 3) y += ((const float*)a.resid)[rrow * a.ldr + n + j];
             else if (a.resid_kind == 2) y += bf16_to_f32(((const bf16_t*)a.resid)[rrow * a.ldr + n + j]);
             else if (a.resid_kind == 5) y = bf16_to_f32(((const bf16_t*)a.resid)[orow * a.ldr + n + j]) > 0.f ? y : 0.f;
+            else if (a.resid_kind == 6) y += bf16_to_f32(((const bf16_t*)a.resid)[orow * a.ldr + n + j]);
             if (a.act == 2) y = fmaxf(y, 0.f);
             if (a.out_kind == 1) ((float*)a.out)[orow * a.ldo + n + j] = y;
             else ((bf16_t*)a.out)[orow * a.ldo + n + j] = f32_to_bf16(y);
@@ -322,7 +327,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const msclip_gemm
   const int fsw = (lane >> 1) & 7;
   const int fhi = lane >> 5;
   const bool vec = !((a.N | a.ldo | (a.resid_kind ? a.ldr : 0)) & 3);
-  const bool plain_rows = a.rpg == 0x7fffffff && a.resid_kind != 3 && a.resid_kind != 5;
+  const bool plain_rows = a.rpg == 0x7fffffff && a.resid_kind != 3 && a.resid_kind < 5;
   const int nk = a.K / BK;
 
   int t = blockIdx.x;
@@ -698,7 +703,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a_i
   // (+ 4 for the second k-step); la[ks] = byte offset of that chunk in a 128-byte LDS row (same swizzle as the image)
   const int r16 = lane & 15, quad = lane >> 4;
   const bool vec = !((a.N | a.ldo | (a.resid_kind ? a.ldr : 0)) & 3);
-  const bool plain_rows = a.rpg == 0x7fffffff && a.resid_kind != 3 && a.resid_kind != 5;
+  const bool plain_rows = a.rpg == 0x7fffffff && a.resid_kind != 3 && a.resid_kind < 5;
   // bf16: la[ks] = k-step ks (16-byte chunk ks*4 + quad of the 128-byte row); fp8: the lane's 32 bytes of the one k-step are
   // chunks 2*quad (la[0]) and 2*quad + 1 (la[1]) -- A and B use the same lane -> k assignment, so the contraction is exact
   int la[2];
@@ -1039,7 +1044,10 @@ static GemmVariant pick_variant(const msclip_gemm_desc* d) {
   if (d->mode == 1 && (!d->ktab || (d->Cin % 8))) return GV_INVALID;
   if (d->mode != 0 && d->mode != 1) return GV_INVALID;
   if (d->rpg <= 0) return GV_INVALID;
-  if (d->resid_kind < 0 || d->resid_kind > 5 || d->out_kind < 0 || d->out_kind > 1) return GV_INVALID;   // (e4m3 outputs: msclip_gemm_f8)
+  if (d->resid_kind < 0 || d->resid_kind > 6 || d->out_kind < 0 || d->out_kind > 1) return GV_INVALID;   // (e4m3 outputs: msclip_gemm_f8)
+  // resid_kind 6 (+ the bf16 value at the store row: a scattered launch accumulating into an existing map): generic / streaming kernels
+  if (d->resid_kind == 6 && (!d->resid || (d->ldr & 3) || d->tile == 4 || d->out2 || d->rowstat || d->W2 || d->xb || d->out_kind != 0))
+    return GV_INVALID;
   // resid_kind 5 (ReLU mask at the store row; the conv side's input gradients): implicit-conv launches of the generic / streaming
   // kernels only
   if (d->resid_kind == 5 && (d->mode != 1 || !d->resid || (d->ldr & 3) || d->tile == 4 || d->out2 || d->rowstat || d->W2 || d->xb))
@@ -1077,7 +1085,7 @@ static GemmVariant pick_variant(const msclip_gemm_desc* d) {
     const bool pp_ok = (long long)d->ldx * 2 * 256 + (long long)d->K * 2 < (1ll << 31) &&
                        (long long)d->ldw * 2 * 256 + (long long)d->K * 2 < (1ll << 31) &&
                        big_tiles * ((d->M + 255) / 256) * 4 < (1ll << 32);
-    if (pp_ok && (d->tile == 4 || (d->tile == 0 && big))) return GV_PP;     // ping-pong kernel (default for the projections)
+    if (pp_ok && d->resid_kind < 5 && (d->tile == 4 || (d->tile == 0 && big))) return GV_PP;     // ping-pong kernel (default for the projections)
     if (train_epi || fold_c || fold_p) return GV_INVALID;   // (offsets beyond the ping-pong kernel's 32-bit addressing)
     return GV_DENSE128;                        // small problems, heads, logits (and tile 1)
   }
@@ -1085,7 +1093,7 @@ static GemmVariant pick_variant(const msclip_gemm_desc* d) {
   const long long in_bytes = (long long)(d->M / (d->Ho * d->Wo)) * d->H * d->Wd * d->Cin * 2;
   if ((d->tile == 0 || d->tile == 4) && d->Cin % 64 == 0 && d->K % d->Cin == 0 && in_bytes < (1ll << 31) &&
       (long long)d->ldw * 2 * 256 + (long long)d->K * 2 < (1ll << 31) && d->rpg == 0x7fffffff && d->resid_kind != 3 &&
-      d->resid_kind != 5 && d->M % (d->Ho * d->Wo) == 0 && (big_tiles >= 128 || d->tile == 4) && big_tiles * ((d->M + 255) / 256) * 4 < (1ll << 32))
+      d->resid_kind < 5 && d->M % (d->Ho * d->Wo) == 0 && (big_tiles >= 128 || d->tile == 4) && big_tiles * ((d->M + 255) / 256) * 4 < (1ll << 32))
     return GV_PPCONV;
   // N a multiple of 192 (192 / 384 / 768 output channels): 256 x 192 tiles leave no idle columns
   const long long t192 = (long long)((d->M + 255) / 256) * ((d->N + 191) / 192);

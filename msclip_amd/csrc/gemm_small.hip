@@ -202,6 +202,12 @@ __global__ __launch_bounds__(SWV * 64) void gemm_stream_kernel(const msclip_gemm
               unpack_bf16x8(u, f);
 #pragma unroll
               for (int j = 0; j < 8; ++j) v[j] += f[j];
+            } else if (a.resid_kind == 6) {                     // accumulate into the bf16 map at the store row
+              const uint4 u = *(const uint4*)((const bf16_t*)a.resid + orow * a.ldr + n);
+              float f[8];
+              unpack_bf16x8(u, f);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[j] += f[j];
             } else if (a.resid_kind == 5) {                     // ReLU backward: mask by the saved activation at the store row
               const uint4 u = *(const uint4*)((const bf16_t*)a.resid + orow * a.ldr + n);
               float f[8];
@@ -231,6 +237,7 @@ __global__ __launch_bounds__(SWV * 64) void gemm_stream_kernel(const msclip_gemm
               if (a.resid_kind == 1) y += ((const float*)a.resid)[(size_t)m * a.ldr + n + j];
               else if (a.resid_kind == 2) y += bf16_to_f32(((const bf16_t*)a.resid)[(size_t)m * a.ldr + n + j]);
               else if (a.resid_kind == 5) y = bf16_to_f32(((const bf16_t*)a.resid)[orow * a.ldr + n + j]) > 0.f ? y : 0.f;
+              else if (a.resid_kind == 6) y += bf16_to_f32(((const bf16_t*)a.resid)[orow * a.ldr + n + j]);
               if (a.act == 2) y = fmaxf(y, 0.f);
               if (a.out_kind == 1) ((float*)a.out)[orow * a.ldo + n + j] = y;
               else ((bf16_t*)a.out)[orow * a.ldo + n + j] = f32_to_bf16(y);
@@ -306,7 +313,7 @@ bool dispatch_stream(const msclip_gemm_desc* d, hipStream_t st, int ncu) {
 // msclip_gemm_variant() use.
 bool msclip_gemm_small_eligible(const msclip_gemm_desc* d) {
   if ((d->K % 64) || d->M < 4096) return false;
-  if (d->resid_kind == 3 || d->resid_kind == 4 || (d->rpg != 0x7fffffff && d->resid_kind && d->resid_kind != 5)) return false;    // (row scatter: plain stores or the ReLU mask)
+  if (d->resid_kind == 3 || d->resid_kind == 4 || (d->rpg != 0x7fffffff && d->resid_kind && d->resid_kind < 5)) return false;    // (row scatter: plain stores or the ReLU mask)
   if (d->ldw % 8) return false;
   if (d->mode == 0) return d->K <= 192 && !(d->ldx % 8);
   if (d->mode == 1) {

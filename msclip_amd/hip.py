@@ -340,7 +340,7 @@ def set_wg_cap(n):
     _WG_CAP[0] = int(n)
     return prev
 
-RESID_NONE, RESID_F32, RESID_BF16, RESID_TABLE, RESID_GELUGRAD, RESID_RELUMASK = 0, 1, 2, 3, 4, 5
+RESID_NONE, RESID_F32, RESID_BF16, RESID_TABLE, RESID_GELUGRAD, RESID_RELUMASK, RESID_ACCUM = 0, 1, 2, 3, 4, 5, 6
 
 
 class FoldIn:
@@ -421,7 +421,7 @@ def gemm(x, w, out, *, M=None, bias=None, resid=None, resid_kind=0, act=0, alpha
         esz = 4 if d.out_kind else 2
         x_bytes = d.M * d.K * 2 if conv is None else (d.M // (conv[3] * conv[4])) * conv[0] * conv[1] * conv[2] * 2
         r_bytes = {RESID_NONE: 0, RESID_F32: d.M * d.N * 4, RESID_BF16: d.M * d.N * 2, RESID_TABLE: 0, RESID_GELUGRAD: d.M * d.N * 2,
-                   RESID_RELUMASK: d.M * d.N * 2}[resid_kind]
+                   RESID_RELUMASK: d.M * d.N * 2, RESID_ACCUM: d.M * d.N * 2}[resid_kind]
         nbytes = x_bytes + d.N * d.K * 2 + d.M * d.N * esz * (2 if out2 is not None else 1) + r_bytes + (d.N * 4 if bias is not None else 0)
         if fold_out is not None:                      # bf16 centred copy + per-64-column partial sums + the rows' centres
             nbytes += d.M * d.N * 2 + d.M * (d.N // 64) * 8 + d.M * 4

@@ -154,6 +154,21 @@ class ConvSideBackward:
                      resid=y2[:, px * ci:px * ci + N] if y2 is not None else None, ldr=2 * ci,
                      resid_kind=hip.RESID_RELUMASK if y2 is not None else 0)
 
+    def _shortcut_ok(self, spec):
+        return ((spec.kh, spec.kw, spec.stride, spec.pad) == (1, 1, 2, 0) and spec.h_in == 2 * spec.h_out
+                and spec.w_in == 2 * spec.w_out and spec.cin % 8 == 0 and not hip.env_flag("MSCLIP_DGRAD_COL2IM")
+                and not hip.env_flag("MSCLIP_SHORTCUT_COL2IM"))
+
+    def _shortcut_dgrad_into(self, key, spec, dpre, dx, B):
+        """dx[even pixels] += dY . W for a 1x1 / stride-2 convolution (the bottleneck's shortcut), in place into the input
+        gradient `dx` another path has already written: one GEMM whose rows scatter to the pixels (2i, 2j) and add what is there
+        (msclip_gemm resid_kind 6) -- no column matrix, no col2im into a zero-filled map, no second operand for the ReLU pass."""
+        co, ci, Ho, Wo = spec.cout, spec.cin, spec.h_out, spec.w_out
+        wt = self._w_t(key, spec.weight, co, ci)
+        dx2 = dx.view(B * spec.h_in * Wo, 2 * ci)[:, :ci]
+        hip.gemm(dpre, wt, dx2, M=B * Ho * Wo, N=ci, ldx=co, ldo=2 * ci, rpg=Wo, radd=Wo, roff=0,
+                 resid=dx2, ldr=2 * ci, resid_kind=hip.RESID_ACCUM)
+
     def _conv_bwd(self, key, spec, x_in, dpre, B, need_dx=True, col=None, lane=False, relu_of=None):
         """dpre: bf16 [B*Ho*Wo, cout] (with slack) -> (G [cout, cin, kh, kw] fp32 wrt the folded filter, dbias [cout],
         dx NHWC bf16 [B*H*W, cin] or None).  lane=True: the weight gradient runs on gradgemm's lane stream (G may only be
@@ -315,15 +330,20 @@ class ConvSideBackward:
             self._fold_on_lane(grads, _Fold(sd, f"{q}.{bn}", 1e-6), f"{q}.{conv}.weight", G, sd[f"{q}.{conv}.weight"].float(), dbias)
         G, _, dt2 = self._conv_bwd(("par", j, 3), c3, t2, dpre, Bi, lane=True)
         fold("conv3", "bn3", G, dpre, c3)
-        G, _, dsrc_a = self._conv_bwd(("par", j, "r"), cr, src, dpre, Bi, lane=True)
+        short = self._shortcut_ok(cr)        # the shortcut's input gradient is added into conv1's below (no map of its own)
+        G, _, dsrc_a = self._conv_bwd(("par", j, "r"), cr, src, dpre, Bi, lane=True, need_dx=not short)
         fold("residual_conv", "residual_bn", G, dpre, cr)
-        del dpre
+        if not short:
+            del dpre
         dt2 = self._relu_bwd(dt2, t2)
         G, _, dt1 = self._conv_bwd(("par", j, 2), c2, t1, dt2, Bi, lane=True, relu_of=t1)      # (through t1's ReLU)
         fold("conv2", "bn2", G, dt2, c2)
         del dt2
         G, _, dsrc_b = self._conv_bwd(("par", j, 1), c1, src, dt1, Bi, lane=True)
         fold("conv1", "bn1", G, dt1, c1)
+        if short:
+            self._shortcut_dgrad_into(("par", j, "r"), cr, dpre, dsrc_b, Bi)
+            dsrc_a, dsrc_b = dsrc_b, None
         self.dpar = [dsrc_a, dsrc_b]
 
     # ------------------------------------------------------------------ stem
@@ -611,13 +631,19 @@ class ConvSideBatchNorm:
         dr = self._bn_bwd(grads, q + ".residual_bn", dpre)
         del dpre
         dt2 = self._conv(grads, ("par", j, 3), c3, q + ".conv3.weight", t2, d3)
-        dsrc_a = self._conv(grads, ("par", j, "r"), cr, q + ".residual_conv.weight", src, dr)
-        del d3, dr
+        short = self.bw._shortcut_ok(cr)     # the shortcut's input gradient is added into conv1's below (no map of its own)
+        dsrc_a = self._conv(grads, ("par", j, "r"), cr, q + ".residual_conv.weight", src, dr, need_dx=not short)
+        del d3
+        if not short:
+            del dr
         d2 = self._bn_bwd(grads, q + ".bn2", self.bw._relu_bwd(dt2, t2))
         dt1 = self._conv(grads, ("par", j, 2), c2, q + ".conv2.weight", t1, d2, relu_of=t1)      # (through t1's ReLU)
         del d2, dt2
         d1 = self._bn_bwd(grads, q + ".bn1", dt1)
         dsrc_b = self._conv(grads, ("par", j, 1), c1, q + ".conv1.weight", src, d1)
+        if short:
+            self.bw._shortcut_dgrad_into(("par", j, "r"), cr, dr, dsrc_b, self.Bi)
+            dsrc_a, dsrc_b = dsrc_b, None
         self.bw.dpar = [dsrc_a, dsrc_b]
 
     def stem(self, grads, dtok):
@@ -639,7 +665,12 @@ class ConvSideBatchNorm:
             ds = self._bn_bwd(grads, q + ".downsample.1", dpre)
             del dpre
             dy = self._conv(grads, ("stem", i, "m"), main, q + ".conv1.weight", x_in, dm)
-            dy2 = self._conv(grads, ("stem", i, "s"), short, q + ".downsample.0.weight", x_in, ds)
+            if self.bw._shortcut_ok(short):              # the 1x1 / stride-2 shortcut's input gradient: added into the main path's map
+                self._conv(grads, ("stem", i, "s"), short, q + ".downsample.0.weight", x_in, ds, need_dx=False)
+                self.bw._shortcut_dgrad_into(("stem", i, "s"), short, ds, dy, Bi)
+                dy2 = None
+            else:
+                dy2 = self._conv(grads, ("stem", i, "s"), short, q + ".downsample.0.weight", x_in, ds)
         self._first(grads, sp + ".conv1.weight", sp + ".bn1", self.bw._relu_bwd(dy, w["S1"], dy2=dy2))
         self.bw.col_img = None
         self.saved = {}                                  # the raw maps (several GB at batch 512) are not kept between steps

@@ -923,6 +923,13 @@ def test_stream_gemm_row_scatter(gpu_device, M, N, K, out_f32):
     rest = torch.ones(rows, dtype=torch.bool, device="cuda")
     rest[tgt] = False
     assert bool(torch.isnan(out[rest].float()).all())
+    if not out_f32:
+        # resid_kind 6: the launch adds what is already at the store row (in place): the stride-2 shortcuts' input gradients
+        base = rnd(rows, N, seed=5, dtype=BF)
+        acc = base.clone()
+        hip.gemm(x, w, acc, M=M, rpg=49, radd=3, roff=2, resid=acc, resid_kind=hip.RESID_ACCUM)
+        close(acc[tgt], ref + base[tgt].float(), 3e-2, 1e-2)
+        assert torch.equal(acc[rest], base[rest])
 
 
 def test_layernorm_fold_producer_second_residual_stream(gpu_device):
