@@ -23,13 +23,6 @@ for name, ci, co, h in [("par1.conv2", 48, 48, 112), ("stem0.conv1", 48, 96, 112
     x_in = TC._zbuf(B * h * h, ci, "cuda")
     x_in.zero_()
 
-    def run(col2im):
-        if col2im:
-            os.environ["MSCLIP_DGRAD_COL2IM"] = "1"
-        else:
-            os.environ.pop("MSCLIP_DGRAD_COL2IM", None)
-        return bw._conv_bwd(name, spec, x_in, dpre, B, need_dx=True, col=x_in[:1], lane=None) if False else None
-
     # dgrad only (the weight gradient is not part of this probe)
     def dgrad_new():
         dx = TC._zbuf(B * h * h, ci, "cuda")
