@@ -303,7 +303,8 @@ int msclip_l2norm_bwd(const float* x, int ldx, const float* dy, int lddy, float*
 int msclip_clip_loss_bwd_g(const float* S, int lds, const float* lse_row, const float* lse_col, int label_off, float w,
                            void* G, int ldg, float* dscale_part, int R, int N, int Npad, void* stream);
 
-/* Token + positional embedding backward (M.py:3047-3048): dEmb[token] += dx row (fp32 atomics), dPos[l] += dx row. */
+/* Token + positional embedding backward (M.py:3047-3048): dEmb[token] += dx row (fp32 atomics), dPos[l] += dx row (dpos NULL: not
+ * formed -- the training step takes it as a fixed-order column sum over the batch instead, msclip_colsum). */
 int msclip_embed_tokens_bwd(const long long* tokens, const float* dx, int lddx, float* demb, float* dpos, int B, int L,
                             int C, int vocab, void* stream);
 

@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* __restr
   for (int c = threadIdx.x; c < C; c += 256) {
     const float v = dx[(size_t)row * lddx + c];
     atomicAdd(demb + (size_t)t * C + c, v);
-    atomicAdd(dpos + (size_t)l * C + c, v);
+    if (dpos) atomicAdd(dpos + (size_t)l * C + c, v);           // (NULL: the caller sums over the batch itself, in a fixed order)
   }
 }
 
@@ -661,7 +661,7 @@ extern "C" int msclip_clip_loss_bwd_g(const float* S, int lds, const float* lse_
 
 extern "C" int msclip_embed_tokens_bwd(const long long* tokens, const float* dx, int lddx, float* demb, float* dpos, int B,
                                        int L, int C, int vocab, void* stream) {
-  if (!tokens || !dx || !demb || !dpos || B <= 0 || L <= 0 || C <= 0) return MSCLIP_EINVAL;
+  if (!tokens || !dx || !demb || B <= 0 || L <= 0 || C <= 0) return MSCLIP_EINVAL;
   hipLaunchKernelGGL(embed_bwd_kernel, dim3(B * L), dim3(256), 0, (hipStream_t)stream, tokens, dx, lddx, demb, dpos, B, L, C,
                      vocab);
   return msclip_launch_status();

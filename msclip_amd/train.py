@@ -453,7 +453,13 @@ class TrainStep:
 
             def embed_bwd():
                 flat = torch.zeros(ne + e.Lt * D, dtype=F32, device=dev)                     # one tensor: on_lane's contract
-                hip.embed_tokens_bwd(tok_ids, dX_text, flat[:ne].view_as(e.emb), flat[ne:].view(e.Lt, D))
+                # the positional embedding's gradient is a sum over the batch: a column sum in a fixed order (bitwise repeatable),
+                # not the kernel's atomics; the token embedding's scatter-add stays atomic (captions share ids)
+                if dX_text.is_contiguous():
+                    hip.embed_tokens_bwd(tok_ids, dX_text, flat[:ne].view_as(e.emb), None)
+                    hip.colsum(dX_text.view(Bt, e.Lt * D), out=flat[ne:])
+                else:
+                    hip.embed_tokens_bwd(tok_ids, dX_text, flat[:ne].view_as(e.emb), flat[ne:].view(e.Lt, D))
                 return flat
             both = gradgemm.on_lane(embed_bwd, dX_text, tok_ids)
             grads["token_embedding.weight"], grads["positional_embedding"] = both[:ne].view_as(e.emb), both[ne:].view(e.Lt, D)
