@@ -158,6 +158,41 @@ int msclip_layernorm_split(const float* x, int ldx, const float* gamma, const fl
 int msclip_embed_tokens(const long long* tokens, const float* emb, const float* pos, float* x, int ldx, int* eot_row,
                         int B, int L, int C, int vocab, int row_base, void* stream);
 
+/* ---- Packed (pad-free) captions.  The causal mask (M.py:2965-2971) lets a token see only earlier positions, and encode_text
+ * returns the row at the EOT position argmax_l tokens[b,l] (M.py:3057-3060): rows behind that position cannot influence any
+ * output (or receive any gradient) in ANY block.  Caption b therefore owns n_b = argmax_l tokens[b,l] + 1 consecutive rows of
+ * the token matrix, at cu[b] = sum_{j<b} n_j, instead of L.
+ * msclip_text_lengths: len[b] = n_b (first maximum, like torch.argmax); cu[0..B-1] as above, cu[B] = total live rows,
+ * cu[B+1] = max_b n_b (cu holds B + 2 ints); eot_row[b] = row_base + cu[b] + n_b - 1 (optional).  tokens int64 [B, L]. */
+int msclip_text_lengths(const long long* tokens, int B, int L, int row_base, int* len, int* cu, int* eot_row, void* stream);
+
+/* x[row_base + cu[b] + l] = emb[tokens[b,l]] + pos[l] for l < n_b (M.py:3047-3048 on the live rows); the rows
+ * [row_base + cu[B], row_base + rows_padded) -- tile padding of the GEMMs over the packed segment, < 256 rows -- are zeroed. */
+int msclip_embed_tokens_packed(const long long* tokens, const float* emb, const float* pos, float* x, int ldx, const int* cu,
+                               int B, int L, int C, int vocab, int row_base, int rows_padded, void* stream);
+
+/* msclip_attention over packed captions: sample b's tokens are rows cu[b] .. cu[b+1] of qkv / out (both start at the text
+ * segment), Lmax >= every length (<= 96: picks the tile count).  The pad_rows (< 256) output rows behind cu[nsamples] are
+ * zeroed.  Replaces M.py:707-738 with the mask of :2965-2971 on the rows that can matter. */
+int msclip_attention_varlen(const void* qkv, void* out, const int* cu, int nsamples, int Lmax, int heads, int ldq, int ldo,
+                            int causal, int pad_rows, void* stream);
+
+/* msclip_attention_lastq over packed captions: sample b's keys are the rows row_base + cu[b] .. row_base + cu[b+1] of qkv
+ * (all of them: the query is the caption's last live row, the EOT position). */
+int msclip_attention_lastq_varlen(const void* q, int ldqc, const void* qkv, int ldq, void* out, int ldo, int nsamples, int Lmax,
+                                  int heads, const int* cu, int row_base, void* stream);
+
+/* msclip_attention_bwd over packed captions (Lmax <= 96); the pad_rows rows of dqkv behind cu[nsamples] are zeroed (the
+ * in_proj weight gradient contracts over them). */
+int msclip_attention_bwd_varlen(const void* qkv, const void* o, const void* dout, void* dqkv, const int* cu, int nsamples, int Lmax,
+                                int heads, int ldq, int ldo, int causal, int pad_rows, void* stream);
+
+/* msclip_embed_tokens_bwd over packed captions: dx row cu[b] + l belongs to tokens[b,l].  dEmb[token] += row (fp32 atomics);
+ * dPos[l] = sum over the captions with n_b > l of their row l, in caption order (bitwise repeatable; dpos is overwritten,
+ * rows l >= max n_b become zero; NULL: not formed). */
+int msclip_embed_tokens_bwd_packed(const long long* tokens, const float* dx, int lddx, const int* cu, float* demb, float* dpos,
+                                   int B, int L, int C, int vocab, void* stream);
+
 /* x[b*L] = class_embedding + positional_embedding[0] (M.py:2421-2425). */
 int msclip_fill_cls(const float* cls, const float* pos, float* x, int ldx, int B, int L, int C, void* stream);
 

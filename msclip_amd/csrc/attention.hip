@@ -27,7 +27,8 @@ namespace {
 
 template <int NT, bool CAUSAL, int WPB>
 __global__ __launch_bounds__(WPB * 64) void attn_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                   int nsamples, int L, int H, int ldq, int ldo) {
+                                                   int nsamples, int Lfix, int H, int ldq, int ldo,
+                                                   const int* __restrict__ cu, int pad_rows) {
   constexpr int KP = NT * 32;      // padded key count
   constexpr int KPS = KP + 8;      // LDS row stride (elements): 16-B aligned, odd multiple of 16 B
   extern __shared__ __attribute__((aligned(16))) bf16_t vt_all[];
@@ -35,11 +36,23 @@ __global__ __launch_bounds__(WPB * 64) void attn_kernel(const bf16_t* __restrict
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int pair = blockIdx.x * WPB + wave;
-  if (pair >= nsamples * H) return;
+  if (pair >= nsamples * H) {
+    // packed captions (msclip_attention_varlen): the workgroups behind the last (sample, head) pair zero the output rows of
+    // the tile padding [cu[nsamples], cu[nsamples] + pad_rows) -- one wave per row
+    const int r = pair - nsamples * H;
+    if (cu && r < pad_rows) {
+      bf16_t* orow = out + (size_t)(cu[nsamples] + r) * ldo;
+      for (int c = lane * 8; c < H * 64; c += 512) *(uint4*)(orow + c) = make_uint4(0, 0, 0, 0);
+    }
+    return;
+  }
   const int b = pair / H, h = pair - b * H;
   bf16_t* vt = vt_all + wave * (64 * KPS);
 
-  const size_t row0 = (size_t)b * L;
+  // fixed-length samples: rows b*L .. ; packed captions: rows cu[b] .. cu[b + 1] (wave-uniform either way)
+  const int c0 = cu ? __builtin_amdgcn_readfirstlane(cu[b]) : b * Lfix;
+  const int L = cu ? min(__builtin_amdgcn_readfirstlane(cu[b + 1]) - c0, KP) : Lfix;
+  const size_t row0 = (size_t)c0;
   const bf16_t* qbase = qkv + row0 * ldq + h * 64;
   const bf16_t* kbase = qbase + H * 64;
   const bf16_t* vbase = qbase + 2 * H * 64;
@@ -64,10 +77,15 @@ __global__ __launch_bounds__(WPB * 64) void attn_kernel(const bf16_t* __restrict
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int row = min(t * 32 + fr, L - 1);       // clamped: padded queries are never stored, padded keys masked
+      if (t * 32 < L) {                              // (wave-uniform: a short packed caption skips its empty tiles' loads)
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        qf[t][kk] = *(const bf16x8*)(qbase + (size_t)row * ldq + (kk * 2 + fhi) * 8);
-        kf[t][kk] = *(const bf16x8*)(kbase + (size_t)row * ldq + (kk * 2 + fhi) * 8);
+        for (int kk = 0; kk < 4; ++kk) {
+          qf[t][kk] = *(const bf16x8*)(qbase + (size_t)row * ldq + (kk * 2 + fhi) * 8);
+          kf[t][kk] = *(const bf16x8*)(kbase + (size_t)row * ldq + (kk * 2 + fhi) * 8);
+        }
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) qf[t][kk] = kf[t][kk] = bf16x8{};
       }
     }
     {
@@ -529,13 +547,13 @@ int launch_wg(const void* qkv, void* out, int nsamples, int L, int H, int ldq, i
 template <int MAXI>                                  // iterations of 8 keys: L <= 8 * MAXI
 __global__ __launch_bounds__(256) void attn_lastq_kernel(const bf16_t* __restrict__ qc, int ldqc, const bf16_t* __restrict__ kv,
                                                     int ldkv, bf16_t* __restrict__ out, int ldo, int nsamples, int L, int H,
-                                                    const int* __restrict__ last_row, int row_base) {
+                                                    const int* __restrict__ last_row, int row_base, const int* __restrict__ cu) {
   const int lane = threadIdx.x & 63;
   const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (pair >= nsamples * H) return;
   const int b = pair / H, h = pair - b * H;
-  const int row0 = row_base + b * L;
-  int nk = last_row ? last_row[b] - row0 + 1 : L;
+  const int row0 = row_base + (cu ? cu[b] : b * L);           // packed captions: sample b's keys are rows cu[b] .. cu[b + 1]
+  int nk = cu ? cu[b + 1] - cu[b] : (last_row ? last_row[b] - row0 + 1 : L);
   nk = min(max(nk, 1), L);
   const int g = lane >> 3, c = lane & 7;
   const bf16_t* kbase = kv + (size_t)row0 * ldkv + H * 64 + h * 64 + c * 8;
@@ -602,17 +620,18 @@ __global__ __launch_bounds__(256) void attn_lastq_kernel(const bf16_t* __restric
 }
 
 template <int NT>
-int launch(const void* qkv, void* out, int nsamples, int L, int H, int ldq, int ldo, int causal, hipStream_t st) {
+int launch(const void* qkv, void* out, int nsamples, int L, int H, int ldq, int ldo, int causal, hipStream_t st,
+           const int* cu = nullptr, int pad_rows = 0) {
   constexpr int WPB = NT > 4 ? 2 : 4;  // keep dynamic LDS under 64 KiB
-  const int pairs = nsamples * H;
+  const int pairs = nsamples * H + (cu ? pad_rows : 0);         // (one wave per padding row behind the real pairs)
   const int grid = (pairs + WPB - 1) / WPB;
   const size_t lds = WPB * 64 * (NT * 32 + 8) * sizeof(bf16_t);
   if (causal)
     hipLaunchKernelGGL((attn_kernel<NT, true, WPB>), dim3(grid), dim3(WPB * 64), lds, st, (const bf16_t*)qkv,
-                       (bf16_t*)out, nsamples, L, H, ldq, ldo);
+                       (bf16_t*)out, nsamples, L, H, ldq, ldo, cu, pad_rows);
   else
     hipLaunchKernelGGL((attn_kernel<NT, false, WPB>), dim3(grid), dim3(WPB * 64), lds, st, (const bf16_t*)qkv,
-                       (bf16_t*)out, nsamples, L, H, ldq, ldo);
+                       (bf16_t*)out, nsamples, L, H, ldq, ldo, cu, pad_rows);
   return msclip_launch_status();
 }
 
@@ -633,20 +652,43 @@ extern "C" int msclip_attention(const void* qkv, void* out, int nsamples, int L,
   return MSCLIP_EINVAL;
 }
 
-extern "C" int msclip_attention_lastq(const void* q, int ldqc, const void* qkv, int ldq, void* out, int ldo, int nsamples, int L,
-                                      int heads, const int* last_row, int row_base, void* stream) {
+static int lastq_launch(const void* q, int ldqc, const void* qkv, int ldq, void* out, int ldo, int nsamples, int L, int heads,
+                        const int* last_row, int row_base, const int* cu, void* stream) {
   if (!q || !qkv || !out || nsamples <= 0 || L <= 0 || L > 288 || heads <= 0 || (ldqc % 8) || (ldq % 8) || (ldo % 8) || ldo < heads * 64 || row_base < 0)
     return MSCLIP_EINVAL;
   const int grid = (nsamples * heads + 3) / 4;
   hipStream_t st = (hipStream_t)stream;
 #define LASTQ(MAXI)                                                                                                            \
   hipLaunchKernelGGL(attn_lastq_kernel<MAXI>, dim3(grid), dim3(256), 0, st, (const bf16_t*)q, ldqc, (const bf16_t*)qkv, ldq,   \
-                     (bf16_t*)out, ldo, nsamples, L, heads, last_row, row_base)
-  if (L <= 64) LASTQ(8);
+                     (bf16_t*)out, ldo, nsamples, L, heads, last_row, row_base, cu)
+  if (L <= 32) LASTQ(4);
+  else if (L <= 64) LASTQ(8);
   else if (L <= 80) LASTQ(10);
   else if (L <= 128) LASTQ(16);
   else if (L <= 256) LASTQ(32);
   else LASTQ(36);
 #undef LASTQ
   return msclip_launch_status();
+}
+
+extern "C" int msclip_attention_lastq(const void* q, int ldqc, const void* qkv, int ldq, void* out, int ldo, int nsamples, int L,
+                                      int heads, const int* last_row, int row_base, void* stream) {
+  return lastq_launch(q, ldqc, qkv, ldq, out, ldo, nsamples, L, heads, last_row, row_base, nullptr, stream);
+}
+
+extern "C" int msclip_attention_lastq_varlen(const void* q, int ldqc, const void* qkv, int ldq, void* out, int ldo, int nsamples,
+                                             int Lmax, int heads, const int* cu, int row_base, void* stream) {
+  if (!cu) return MSCLIP_EINVAL;
+  return lastq_launch(q, ldqc, qkv, ldq, out, ldo, nsamples, Lmax, heads, nullptr, row_base, cu, stream);
+}
+
+extern "C" int msclip_attention_varlen(const void* qkv, void* out, const int* cu, int nsamples, int Lmax, int heads, int ldq,
+                                       int ldo, int causal, int pad_rows, void* stream) {
+  if (!qkv || !out || !cu || nsamples <= 0 || Lmax <= 0 || Lmax > 96 || heads <= 0 || (ldq % 8) || (ldo % 8) || pad_rows < 0 ||
+      pad_rows > 255)
+    return MSCLIP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (Lmax <= 32) return launch<1>(qkv, out, nsamples, Lmax, heads, ldq, ldo, causal, st, cu, pad_rows);
+  if (Lmax <= 64) return launch<2>(qkv, out, nsamples, Lmax, heads, ldq, ldo, causal, st, cu, pad_rows);
+  return launch<3>(qkv, out, nsamples, Lmax, heads, ldq, ldo, causal, st, cu, pad_rows);
 }

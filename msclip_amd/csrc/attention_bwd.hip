@@ -32,8 +32,9 @@ constexpr int BWD_WAVES = 8;
 
 template <int NT16, bool CAUSAL>            // NT16 = padded length / 16 (4: 64 tokens, 6: 96 tokens)
 __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
-                                                       const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqkv, int L,
-                                                       int H, int ldq, int ldo) {
+                                                       const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqkv, int Lfix,
+                                                       int H, int ldq, int ldo, const int* __restrict__ cu, int nsamples,
+                                                       int pad_rows) {
   constexpr int LP = NT16 * 16, LS = LP + 8;          // padded length, row stride of the [..][token] images
   extern __shared__ __attribute__((aligned(16))) bf16_t sm[];
   bf16_t* Q = sm;                                      // [LP][RS]
@@ -50,8 +51,20 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_kernel(const bf16_t* 
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if ((int)blockIdx.x >= nsamples * H) {
+    // packed captions (msclip_attention_bwd_varlen): the workgroups behind the last (sample, head) pair zero the q | k | v gradient
+    // rows of the tile padding [cu[nsamples], + pad_rows): the weight-gradient GEMM contracts over them
+    const int r = (blockIdx.x - nsamples * H) * BWD_WAVES + wave;
+    if (cu && r < pad_rows) {
+      bf16_t* g = dqkv + (size_t)(cu[nsamples] + r) * ldq;
+      for (int c = lane * 8; c < 3 * H * 64; c += 512) *(uint4*)(g + c) = make_uint4(0, 0, 0, 0);
+    }
+    return;
+  }
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
-  const size_t row0 = (size_t)b * L;
+  const int c0 = cu ? cu[b] : b * Lfix;               // packed captions: rows cu[b] .. cu[b + 1]
+  const int L = cu ? min(cu[b + 1] - c0, LP) : Lfix;
+  const size_t row0 = (size_t)c0;
   const bf16_t* qb = qkv + row0 * ldq + h * 64;
   const bf16_t* ob = o + row0 * ldo + h * 64;
   const bf16_t* db = dout + row0 * ldo + h * 64;
@@ -218,7 +231,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_kernel(const bf16_t* 
 
 template <int NT16, bool CAUSAL>
 int launch_bwd(const void* qkv, const void* o, const void* dout, void* dqkv, int nsamples, int L, int H, int ldq, int ldo,
-               hipStream_t st) {
+               hipStream_t st, const int* cu = nullptr, int pad_rows = 0) {
   constexpr int LP = NT16 * 16, LS = LP + 8;
   const size_t lds = (size_t)(4 * LP * RS + 3 * 64 * LS + 3 * LP * LS) * 2 + LP * 4;
   static bool done = false;
@@ -227,8 +240,9 @@ int launch_bwd(const void* qkv, const void* o, const void* dout, void* dqkv, int
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     done = true;
   }
-  hipLaunchKernelGGL((attn_bwd_kernel<NT16, CAUSAL>), dim3(nsamples * H), dim3(64 * BWD_WAVES), lds, st, (const bf16_t*)qkv,
-                     (const bf16_t*)o, (const bf16_t*)dout, (bf16_t*)dqkv, L, H, ldq, ldo);
+  const int extra = cu ? (pad_rows + BWD_WAVES - 1) / BWD_WAVES : 0;
+  hipLaunchKernelGGL((attn_bwd_kernel<NT16, CAUSAL>), dim3(nsamples * H + extra), dim3(64 * BWD_WAVES), lds, st, (const bf16_t*)qkv,
+                     (const bf16_t*)o, (const bf16_t*)dout, (bf16_t*)dqkv, L, H, ldq, ldo, cu, nsamples, pad_rows);
   return msclip_launch_status();
 }
 
@@ -497,4 +511,18 @@ extern "C" int msclip_attention_bwd(const void* qkv, const void* o, const void* 
                              : launch_bwd<4, false>(qkv, o, dout, dqkv, nsamples, L, heads, ldq, ldo, st);
   return causal ? launch_bwd<6, true>(qkv, o, dout, dqkv, nsamples, L, heads, ldq, ldo, st)
                 : launch_bwd<6, false>(qkv, o, dout, dqkv, nsamples, L, heads, ldq, ldo, st);
+}
+
+extern "C" int msclip_attention_bwd_varlen(const void* qkv, const void* o, const void* dout, void* dqkv, const int* cu, int nsamples,
+                                           int Lmax, int heads, int ldq, int ldo, int causal, int pad_rows, void* stream) {
+  if (!qkv || !o || !dout || !dqkv || !cu || nsamples <= 0 || Lmax <= 0 || Lmax > 96 || heads <= 0 || (ldq % 8) || (ldo % 8) ||
+      pad_rows < 0 || pad_rows > 255)
+    return MSCLIP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (Lmax <= 32) return causal ? launch_bwd<2, true>(qkv, o, dout, dqkv, nsamples, Lmax, heads, ldq, ldo, st, cu, pad_rows)
+                                : launch_bwd<2, false>(qkv, o, dout, dqkv, nsamples, Lmax, heads, ldq, ldo, st, cu, pad_rows);
+  if (Lmax <= 64) return causal ? launch_bwd<4, true>(qkv, o, dout, dqkv, nsamples, Lmax, heads, ldq, ldo, st, cu, pad_rows)
+                                : launch_bwd<4, false>(qkv, o, dout, dqkv, nsamples, Lmax, heads, ldq, ldo, st, cu, pad_rows);
+  return causal ? launch_bwd<6, true>(qkv, o, dout, dqkv, nsamples, Lmax, heads, ldq, ldo, st, cu, pad_rows)
+                : launch_bwd<6, false>(qkv, o, dout, dqkv, nsamples, Lmax, heads, ldq, ldo, st, cu, pad_rows);
 }

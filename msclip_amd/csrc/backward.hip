@@ -374,6 +374,39 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* __restr
   }
 }
 
+// Packed captions (msclip_embed_tokens_packed): dX row cu[b] + l belongs to token tokens[b][l], l < n_b.  demb: the same atomic
+// scatter-add over the live rows only; dpos[l] = sum over the captions that HAVE a position l of their row, in caption
+// order (fixed order: bitwise repeatable), one block per (position, 256-column chunk), lanes = 4 columns each.
+__global__ __launch_bounds__(256) void embed_bwd_packed_kernel(const long long* __restrict__ tokens, const float* __restrict__ dx,
+                                                               int lddx, const int* __restrict__ cu, float* __restrict__ demb, int L,
+                                                               int C, int vocab) {
+  const int slot = blockIdx.x;                       // b * L + l
+  const int b = slot / L, l = slot - b * L;
+  const int base = cu[b];
+  if (l >= cu[b + 1] - base) return;
+  long long t = tokens[slot];
+  t = t < 0 ? 0 : (t >= vocab ? vocab - 1 : t);
+  const float* src = dx + (size_t)(base + l) * lddx;
+  for (int c = threadIdx.x; c < C; c += 256) atomicAdd(demb + (size_t)t * C + c, src[c]);
+}
+
+__global__ __launch_bounds__(64) void pos_bwd_packed_kernel(const float* __restrict__ dx, int lddx, const int* __restrict__ cu,
+                                                            float* __restrict__ dpos, int B, int C) {
+  const int l = blockIdx.x, col = blockIdx.y * 256 + threadIdx.x * 4;
+  if (col >= C) return;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  int base = cu[0];
+  for (int b = 0; b < B; ++b) {
+    const int next = cu[b + 1];
+    if (l < next - base) {
+      const float4 v = *(const float4*)(dx + (size_t)(base + l) * lddx + col);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    base = next;
+  }
+  *(float4*)(dpos + (size_t)l * C + col) = acc;
+}
+
 // ---- lateral adapter (M.py:1752-1778), the pieces the backward needs.
 // adapter_sum: pre-LayerNorm sum  [cls; BN(dw3x3(grid))] + [cls * usecls; t]  (fp32 [B*L, C]), saved by the training
 // forward;  adapter_dx: gradient wrt the incoming tokens from the gradient of that sum: cls row (1 + usecls) * d[0],
@@ -664,6 +697,15 @@ extern "C" int msclip_embed_tokens_bwd(const long long* tokens, const float* dx,
   if (!tokens || !dx || !demb || B <= 0 || L <= 0 || C <= 0) return MSCLIP_EINVAL;
   hipLaunchKernelGGL(embed_bwd_kernel, dim3(B * L), dim3(256), 0, (hipStream_t)stream, tokens, dx, lddx, demb, dpos, B, L, C,
                      vocab);
+  return msclip_launch_status();
+}
+
+extern "C" int msclip_embed_tokens_bwd_packed(const long long* tokens, const float* dx, int lddx, const int* cu, float* demb,
+                                              float* dpos, int B, int L, int C, int vocab, void* stream) {
+  if (!tokens || !dx || !cu || !demb || B <= 0 || L <= 0 || C <= 0 || (C % 4) || (lddx % 4)) return MSCLIP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(embed_bwd_packed_kernel, dim3(B * L), dim3(256), 0, st, tokens, dx, lddx, cu, demb, L, C, vocab);
+  if (dpos) hipLaunchKernelGGL(pos_bwd_packed_kernel, dim3(L, (C + 255) / 256), dim3(64), 0, st, dx, lddx, cu, dpos, B, C);
   return msclip_launch_status();
 }
 

@@ -252,6 +252,100 @@ __global__ __launch_bounds__(64) void eot_kernel(const long long* __restrict__ t
   if (lane == 0) eot_row[b] = row_base + b * L + bi;
 }
 
+// ---- Packed captions.  Under the causal mask (reference :2965-2971) a token after a caption's EOT position cannot reach the
+// EOT row that encode_text returns (:3057-3060) in ANY block, so only the n_b = argmax_l tok[b, l] + 1 leading rows of caption
+// b are live.  len_kernel: n_b (first maximum, like torch.argmax); scan_kernel: cu[b] = sum_{j < b} n_j, cu[B] = total,
+// cu[B + 1] = max_b n_b, eot_row[b] = row_base + cu[b] + n_b - 1 (one workgroup: B is a batch, not a dataset).
+__global__ __launch_bounds__(64) void len_kernel(const long long* __restrict__ tok, int* __restrict__ len, int B, int L) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  long long best = -0x7fffffffffffffffLL;
+  int bi = 0x7fffffff;
+  for (int l = lane; l < L; l += 64) {
+    const long long t = tok[(size_t)b * L + l];
+    if (t > best) { best = t; bi = l; }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const long long ob = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  if (lane == 0) len[b] = bi + 1;
+}
+
+__global__ __launch_bounds__(1024) void scan_kernel(const int* __restrict__ len, int* __restrict__ cu, int* __restrict__ eot_row,
+                                                    int B, int row_base) {
+  __shared__ int wsum[16], wmax[16];
+  __shared__ int carry_s, max_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) { carry_s = 0; max_s = 0; }
+  __syncthreads();
+  for (int b0 = 0; b0 < B; b0 += 1024) {
+    const int b = b0 + tid;
+    const int n = b < B ? len[b] : 0;
+    int inc = n;                                       // inclusive scan inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += up;
+    }
+    int mx = n;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+    if (lane == 63) wsum[wave] = inc;
+    if (lane == 0) wmax[wave] = mx;
+    __syncthreads();
+    int before = carry_s;
+    for (int w2 = 0; w2 < wave; ++w2) before += wsum[w2];
+    if (b < B) {
+      const int base = before + inc - n;
+      cu[b] = base;
+      if (eot_row) eot_row[b] = row_base + base + n - 1;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int s = carry_s, m = max_s;
+      for (int w2 = 0; w2 < 16; ++w2) { s += wsum[w2]; m = max(m, wmax[w2]); }
+      carry_s = s;
+      max_s = m;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) { cu[B] = carry_s; cu[B + 1] = max_s; }
+}
+
+// x[row_base + cu[b] + l] = emb[tok[b, l]] + pos[l] for l < n_b; rows [cu[B], rows_padded) of the text segment are zeroed
+// (the tile padding the GEMMs run over: finite, never read back).  Grid: B*L caption slots, then the padding rows.
+template <int NV>
+__global__ __launch_bounds__(256) void embed_packed_kernel(const long long* __restrict__ tok, const float* __restrict__ emb,
+                                                           const float* __restrict__ pos, float* __restrict__ x, int ldx,
+                                                           const int* __restrict__ cu, int B, int L, int vocab, int rows_padded) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * WPB + (threadIdx.x >> 6);
+  if (m >= B * L) {
+    const int r = cu[B] + (m - B * L);
+    if (r < rows_padded) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) *(float4*)(x + (size_t)r * ldx + i * 256 + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    return;
+  }
+  const int b = m / L, l = m - b * L;
+  const int base = cu[b];
+  if (l >= cu[b + 1] - base) return;
+  long long t = tok[m];
+  t = t < 0 ? 0 : (t >= vocab ? vocab - 1 : t);
+  const float* e = emb + (size_t)t * (NV * 256);
+  const float* p = pos + (size_t)l * (NV * 256);
+  float* xr = x + (size_t)(base + l) * ldx;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float4 a = *(const float4*)(e + i * 256 + lane * 4);
+    const float4 c = *(const float4*)(p + i * 256 + lane * 4);
+    *(float4*)(xr + i * 256 + lane * 4) = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
+  }
+}
+
 // x[b*L + 0] = cls + pos[0]   (reference :2421-2425, before ln_pre)
 template <int NV>
 __global__ __launch_bounds__(256) void cls_kernel(const float* __restrict__ cls, const float* __restrict__ pos,
@@ -507,6 +601,29 @@ extern "C" int msclip_embed_tokens(const long long* tokens, const float* emb, co
   float* xb = x + (size_t)row_base * ldx;
   NV_LAUNCH(C, embed_kernel, grid, blk, st, tokens, emb, pos, xb, ldx, rows, L, vocab)
   if (eot_row) hipLaunchKernelGGL(eot_kernel, dim3(B), dim3(64), 0, st, tokens, eot_row, B, L, row_base);
+  return msclip_launch_status();
+}
+
+extern "C" int msclip_text_lengths(const long long* tokens, int B, int L, int row_base, int* len, int* cu, int* eot_row,
+                                   void* stream) {
+  if (!tokens || !len || !cu || B <= 0 || L <= 0 || row_base < 0) return MSCLIP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(len_kernel, dim3(B), dim3(64), 0, st, tokens, len, B, L);
+  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, (const int*)len, cu, eot_row, B, row_base);
+  return msclip_launch_status();
+}
+
+extern "C" int msclip_embed_tokens_packed(const long long* tokens, const float* emb, const float* pos, float* x, int ldx,
+                                          const int* cu, int B, int L, int C, int vocab, int row_base, int rows_padded,
+                                          void* stream) {
+  if (!tokens || !emb || !pos || !x || !cu || B <= 0 || L <= 0 || (ldx % 4) || row_base < 0 || rows_padded < 0 ||
+      rows_padded > B * L + 255)
+    return MSCLIP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int slots = B * L + 256;                     // every caption slot + at most 255 padding rows (+1: rounding)
+  const dim3 grid((slots + WPB - 1) / WPB), blk(256);
+  float* xb = x + (size_t)row_base * ldx;
+  NV_LAUNCH(C, embed_packed_kernel, grid, blk, st, tokens, emb, pos, xb, ldx, cu, B, L, vocab, rows_padded)
   return msclip_launch_status();
 }
 

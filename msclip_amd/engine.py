@@ -348,6 +348,11 @@ class Engine:
             w["fv_raw"], w["fv"] = buf(Bi, E, dtype=f32), buf(Bi, E, dtype=f32)
         if Bt:
             w["eot"] = torch.empty(Bt, dtype=torch.int32, device=dev)
+            # packed captions (_text_pack): live length per caption, exclusive prefix sums (+ total, + maximum), their host copy
+            w["len"] = torch.empty(Bt, dtype=torch.int32, device=dev)
+            w["cu"] = torch.zeros(Bt + 2, dtype=torch.int32, device=dev)
+            w["cu_host"] = torch.zeros(2, dtype=torch.int32).pin_memory()
+            w["packed"] = False
             w["ht"] = buf(Bt, D)
             w["ft_raw"], w["ft"] = buf(Bt, E, dtype=f32), buf(Bt, E, dtype=f32)
         # compact matrices of the rows that are still read after the last block's attention (cls / EOT rows, _last_block_tail)
@@ -508,8 +513,62 @@ class Engine:
             w["S1"] = torch.zeros(n + 64, dtype=torch.bfloat16, device=self.dev)[:n].view(-1, self.D // 16)
         return w["S1"]
 
+    # ------------------------------------------------------------------ packed (pad-free) captions
+    def text_pack_enabled(self):
+        """Captions run PACKED by default: under the causal mask (M.py:2965-2971) no row behind a caption's EOT position can
+        reach the EOT row encode_text returns (M.py:3057-3060), in any block, so caption b owns n_b = argmax + 1 rows of the
+        token matrix instead of 77.  Identical features / logits / loss / gradients; the token matrix's row count becomes
+        data-dependent, which costs ONE small host read per call (the total), taken while the image front is already queued.
+        MSCLIP_TEXT_PACK=0: every caption computes all context_length rows (the A/B switch; also what a hipGraph capture
+        records, since a capture cannot read the host)."""
+        return (os.environ.get("MSCLIP_TEXT_PACK", "1") != "0" and not torch.cuda.is_current_stream_capturing() and self.Lt <= 96)
+
+    def _text_lengths_begin(self, tok, w, Bt):
+        """Queue the length / prefix-sum kernels and the 8-byte read-back on the current stream; -> the event to wait for."""
+        hip.text_lengths(tok, w["len"], w["cu"], w["eot"], row_base=w["Mv"])
+        w["cu_host"].copy_(w["cu"][Bt:Bt + 2], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev))
+        return ev
+
+    def _text_lengths_end(self, ev, w, Bt):
+        """The host read: total live rows and the longest caption -> this call's row counts (w["Mt"], w["M"], w["pad"])."""
+        ev.synchronize()
+        total, lmax = int(w["cu_host"][0]), int(w["cu_host"][1])
+        padded = -(-total // 256) * 256              # whole 256-row GEMM tiles (the LayerNorm fold's modality split never straddles one)
+        if padded > Bt * self.Lt or padded < 256 * 16:
+            padded = total
+        w.update(packed=True, Mt_live=total, Lmax=lmax, pad=padded - total, Mt=padded, M=w["Mv"] + padded)
+
+    def _text_unpacked(self, w, Bt):
+        w.update(packed=False, Mt_live=Bt * self.Lt, Lmax=self.Lt, pad=0, Mt=Bt * self.Lt, M=w["Mv"] + Bt * self.Lt)
+
     def _text_front(self, tok, w, Bt):
+        if w.get("packed"):
+            return hip.embed_tokens_packed(tok, self.emb, self.tpos, w["X"], w["cu"], w["Mv"], w["Mt"])
         hip.embed_tokens(tok, self.emb, self.tpos, w["X"], w["eot"], w["Mv"])
+
+    def _attention_text(self, w, QKV, AO, Bt):
+        Mv, M = w["Mv"], w["M"]
+        if w.get("packed"):
+            return hip.attention_varlen(QKV[Mv:M], AO[Mv:M], w["cu"], Bt, w["Lmax"], self.heads, True, pad_rows=w["pad"])
+        hip.attention(QKV[Mv:M], AO[Mv:M], Bt, self.Lt, self.heads, True)
+
+    def _tap_text(self, taps, name, t, w, Bt):
+        """Text-block tap in the reference's [B, L, C] layout; packed captions: live rows in place, the others zero, and
+        taps["text_lengths"] says which are which."""
+        if taps is None:
+            return
+        if not w.get("packed"):
+            return self._tap_tokens(taps, name, t, Bt, self.Lt)
+        lens = w["len"].long()
+        cu = w["cu"][:Bt].long()
+        pos = torch.arange(self.Lt, device=self.dev)[None, :]
+        live = pos < lens[:, None]
+        rows = (cu[:, None] + pos).clamp_(max=w["Mt_live"] - 1)
+        out = t[:w["Mt"]].float()[rows.reshape(-1)].view(Bt, self.Lt, -1)
+        taps[name] = out * live[:, :, None]
+        taps["text_lengths"] = w["len"].clone()
 
     def _last_block_attention(self, w, Bi, Bt, groups):
         """The last block's attention when only the class / EOT rows are read afterwards: keys and values are still projected
@@ -530,7 +589,9 @@ class Engine:
                 hip.gemm(LNC[r0:r1], bw.wqkv[:D], QC[r0:r1], bias=bw.bqkv[:D])
         if Bi:
             hip.attention_lastq(QC[:Bi], QKV, AOC[:Bi], Bi, self.Lv, self.heads)
-        if Bt:
+        if Bt and w.get("packed"):
+            hip.attention_lastq_varlen(QC[Bi:], QKV, AOC[Bi:], Bt, w["Lmax"], self.heads, w["cu"], row_base=Mv)
+        elif Bt:
             hip.attention_lastq(QC[Bi:], QKV, AOC[Bi:], Bt, self.Lt, self.heads, last_row=w["eot"], row_base=Mv)
 
     def _last_block_tail(self, w, Bi, Bt, vb, tb, attended=False):
@@ -609,14 +670,23 @@ class Engine:
             return {}
         if img is None or tok is None:
             raise ValueError("calibrate_fp8 needs images AND captions: the shared layers' hidden scale must cover both modalities")
+        self.refresh()                                       # weights changed outside TrainStep.step: re-pack BEFORE clearing (the
+        saved, self._fp8_saved = self._fp8_saved, {}         # re-pack would otherwise restore the old scales into fresh copies)
         blocks = self._fp8_blocks()
         for bw in blocks.values():
             bw.hid_scale, bw.wpr_cs = None, None
         self._calib = {}
         try:
             self.run(img, tok)
+            if not self._calib:
+                raise RuntimeError("calibrate_fp8: no layer recorded a hidden-matrix maximum (did the batch reach the fp8 MLP?)")
             objs = [bw for bw, _ in self._calib.values()]
             amax = torch.stack([torch.stack(vals).amax() for _, vals in self._calib.values()])
+        except BaseException:
+            self._calib = None
+            if saved:                                        # a failed re-calibration keeps the previous scales
+                self.load_fp8_state(saved)
+            raise
         finally:
             self._calib = None
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
@@ -764,7 +834,7 @@ class Engine:
             if vb is not None:
                 hip.attention(QKV[:Mv], AO[:Mv], Bi, self.Lv, self.heads, False)
             if tb is not None:
-                hip.attention(QKV[Mv:M], AO[Mv:M], Bt, self.Lt, self.heads, True)
+                self._attention_text(w, QKV, AO, Bt)
             if last_live:
                 self._last_block_tail(w, Bi, Bt, vb, tb)
                 continue
@@ -808,7 +878,7 @@ class Engine:
                 if vb is not None:
                     self._tap_tokens(taps, f"vblock{i}", X[:Mv], Bi, self.Lv)
                 if tb is not None:
-                    self._tap_tokens(taps, f"tblock{i}", X[Mv:M], Bt, self.Lt)
+                    self._tap_text(taps, f"tblock{i}", X[Mv:M], w, Bt)
 
     def _blocks(self, w, Bi, Bt, taps=None, conv_events=None, compact=False, layers=None):
         if self._fold_eligible(w, Bi, Bt):
@@ -873,7 +943,7 @@ class Engine:
             if vb is not None:
                 hip.attention(QKV[:Mv], AO[:Mv], Bi, self.Lv, self.heads, False)
             if tb is not None:
-                hip.attention(QKV[Mv:M], AO[Mv:M], Bt, self.Lt, self.heads, True)
+                self._attention_text(w, QKV, AO, Bt)
             if last_live:
                 self._last_block_tail(w, Bi, Bt, vb, tb)
                 continue
@@ -896,7 +966,7 @@ class Engine:
                 if vb is not None:
                     self._tap_tokens(taps, f"vblock{i}", X[:Mv], Bi, self.Lv)
                 if tb is not None:
-                    self._tap_tokens(taps, f"tblock{i}", X[Mv:M], Bt, self.Lt)
+                    self._tap_text(taps, f"tblock{i}", X[Mv:M], w, Bt)
 
     def _head_image(self, w, Bi, norm=True, compact=False):               # M.py:2685-2690, 2983
         if compact:                                                       # cls rows already sit in XC[:Bi] (_last_block_tail)
@@ -984,7 +1054,12 @@ class Engine:
             conv_events = None
             side_ok = (taps is None and os.environ.get("MSCLIP_CONV_SIDE_STREAM", "1") != "0"
                        and not torch.cuda.is_current_stream_capturing())
-            text0 = None
+            text0 = ts = lens_ev = tokc = None
+            pack = bool(Bt) and self.text_pack_enabled()
+            if Bt:
+                tokc = self._check_tok(tok)
+                if not pack:
+                    self._text_unpacked(w, Bt)
             if Bi and Bt and side_ok and self.vblk[0] is None and os.environ.get("MSCLIP_TEXT0_STREAM", "1") != "0":
                 # Text block 0 is text-only (vision slot 0 is the conv stem, M.py:2040-2051) and depends on the captions only:
                 # the text front and that block run on a second side stream beside the image front (HBM-bound conv passes
@@ -994,13 +1069,23 @@ class Engine:
                 start = torch.cuda.Event()
                 start.record(cur)                               # the workspace is free: the previous step's work is queued
                 ts.wait_event(start)
-                tokc = self._check_tok(tok)
+                tokc.record_stream(ts)
+            if pack:
+                # packed captions: the per-caption lengths are needed on the HOST (they size every launch over the text rows).
+                # Their kernels are queued first, the image front behind them; the host waits for 8 bytes while the GPU
+                # already has the image front to work on.
+                with torch.cuda.stream(ts if ts is not None else torch.cuda.current_stream(self.dev)):
+                    lens_ev = self._text_lengths_begin(tokc, w, Bt)
+
+            def text_side():
+                nonlocal text0
                 with torch.cuda.stream(ts):
                     self._text_front(tokc, w, Bt)
                     self._blocks(w, 0, Bt, layers=(0,))
                     text0 = torch.cuda.Event()
                     text0.record(ts)
-                tokc.record_stream(ts)
+            if ts is not None and not pack:
+                text_side()
             if Bi:
                 self._vision_front(self._check_img(img), w, Bi, taps)
                 # default (MSCLIP_CONV_SIDE_STREAM=0 turns it off): +1.6 % pairs/s on B/32, +2.2 % on B/16 same-box.  The GEMM
@@ -1008,8 +1093,12 @@ class Engine:
                 # pass with the inline schedule and reports the overlapped figure beside it.
                 if side_ok and self.lateral and self.lateral == sorted(self.lateral) and os.environ.get("MSCLIP_BRANCH_STREAM", "1") != "0":
                     conv_events = self._conv_branch_on_side_stream(w, Bi)
+            if pack:
+                self._text_lengths_end(lens_ev, w, Bt)
+                if ts is not None:
+                    text_side()
             if Bt and text0 is None:
-                self._text_front(self._check_tok(tok), w, Bt)
+                self._text_front(tokc, w, Bt)
             # the last block's row-wise tail on the live rows only (MSCLIP_FULL_LAST_BLOCK=1: every row, as the taps need it)
             compact = taps is None and not hip.env_flag("MSCLIP_FULL_LAST_BLOCK") and not self.lateral_on_last()
             if text0 is not None:
@@ -1031,6 +1120,9 @@ class Engine:
         key = ("graph", Bi, Bt, img_dtype)
         if key in self._ws:
             return self._ws[key]
+        if self.fp8 and not self.fp8_calibrated():
+            # the warm-up below runs on an all-zero image and dummy tokens: it must never become the calibration batch
+            raise RuntimeError("PRECISION fp8: call engine.calibrate_fp8(images, captions) (or load_fp8_state) before capturing a hipGraph")
         with torch.cuda.device(self.dev):
             simg = torch.zeros(Bi, 3, self.S, self.S, dtype=img_dtype, device=self.dev) if Bi else None
             stok = torch.zeros(Bt, self.Lt, dtype=torch.int64, device=self.dev) if Bt else None

@@ -25,6 +25,8 @@ EXPORTS = (
     "msclip_adapter_dx", "msclip_adamw", "msclip_adamw_multi", "msclip_im2col", "msclip_col2im", "msclip_relu_bwd", "msclip_dwpool_bwd",
     "msclip_dwpool_wgrad", "msclip_dw3x3_wgrad", "msclip_gemm_splitk", "msclip_gemm_splitk_tn", "msclip_bn_stats", "msclip_bn_apply",
     "msclip_bn_bwd_reduce", "msclip_bn_bwd_dx", "msclip_bn_fold_bwd", "msclip_bn_finish", "msclip_bn_finish_tiled", "msclip_bn_bwd_finish",
+    "msclip_text_lengths", "msclip_embed_tokens_packed", "msclip_attention_varlen", "msclip_attention_lastq_varlen",
+    "msclip_attention_bwd_varlen", "msclip_embed_tokens_bwd_packed",
     "msclip_abi_version", "msclip_build_arch",
     "msclip_stream_priority_range", "msclip_stream_create", "msclip_stream_destroy",
 )
@@ -138,6 +140,12 @@ def lib():
         L.msclip_bn_finish_tiled.argtypes = [vp, ci, ci, ll, vp, vp, cf, vp, ci, vp]
         L.msclip_bn_bwd_finish.argtypes = [vp, ci, ci, ci, vp, vp, vp]
         L.msclip_bn_fold_bwd.argtypes = [vp, ll, vp, ci, ci, vp, vp, vp, vp, cf, vp, vp, vp, vp]
+        L.msclip_text_lengths.argtypes = [vp, ci, ci, ci, vp, vp, vp, vp]
+        L.msclip_embed_tokens_packed.argtypes = [vp, vp, vp, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp]
+        L.msclip_attention_varlen.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]
+        L.msclip_attention_lastq_varlen.argtypes = [vp, ci, vp, ci, vp, ci, ci, ci, ci, vp, ci, vp]
+        L.msclip_attention_bwd_varlen.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]
+        L.msclip_embed_tokens_bwd_packed.argtypes = [vp, vp, ci, vp, vp, vp, ci, ci, ci, ci, vp]
         L.msclip_abi_version.restype = ci
         L.msclip_build_arch.restype = ctypes.c_char_p
         for name in EXPORTS:
@@ -628,6 +636,48 @@ def embed_tokens(tokens, emb, pos, x, eot_row, row_base):
                                      emb.shape[0], row_base, _stream()), "msclip_embed_tokens")
 
 
+def text_lengths(tokens, length, cu, eot_row=None, row_base=0):
+    """Packed captions: length[b] = argmax_l tokens[b, l] + 1 (the rows that can influence the EOT row under the causal mask),
+    cu[:B] = exclusive prefix sums, cu[B] = total, cu[B + 1] = max length; eot_row[b] = row_base + cu[b] + length[b] - 1."""
+    B, L = tokens.shape
+    assert tokens.dtype == torch.int64 and tokens.is_contiguous() and tokens.is_cuda
+    assert length.dtype == torch.int32 and length.numel() >= B and cu.dtype == torch.int32 and cu.numel() >= B + 2
+    assert eot_row is None or (eot_row.dtype == torch.int32 and eot_row.numel() >= B)
+    _check(lib().msclip_text_lengths(_p(tokens), B, L, row_base, _p(length), _p(cu), _p(eot_row), _stream()), "msclip_text_lengths")
+
+
+def embed_tokens_packed(tokens, emb, pos, x, cu, row_base, rows_padded):
+    """x[row_base + cu[b] + l] = emb[tokens[b, l]] + pos[l] for the live positions; rows up to row_base + rows_padded zeroed."""
+    B, L = tokens.shape
+    assert tokens.dtype == torch.int64 and tokens.is_contiguous() and cu.dtype == torch.int32 and cu.numel() >= B + 2
+    assert x.shape[0] >= row_base + rows_padded
+    _check(lib().msclip_embed_tokens_packed(_p(tokens), _p(emb), _p(pos), _p(x), x.stride(0), _p(cu), B, L, x.shape[1], emb.shape[0],
+                                            row_base, rows_padded, _stream()), "msclip_embed_tokens_packed")
+
+
+def attention_varlen(qkv, out, cu, nsamples, Lmax, heads, causal, pad_rows=0):
+    """attention() over packed captions: sample b = rows cu[b] .. cu[b + 1] of qkv / out (views that start at the text
+    segment); the pad_rows output rows behind cu[nsamples] are zeroed."""
+    _bf16(qkv)
+    _bf16(out)
+    assert cu.dtype == torch.int32 and cu.numel() >= nsamples + 2 and 0 <= pad_rows < 256
+    _check(lib().msclip_attention_varlen(_p(qkv), _p(out), _p(cu), nsamples, Lmax, heads, qkv.stride(0), out.stride(0), int(causal),
+                                         pad_rows, _stream()), "msclip_attention_varlen")
+    return out
+
+
+def attention_lastq_varlen(q, qkv, out, nsamples, Lmax, heads, cu, row_base=0):
+    """attention_lastq over packed captions: sample b's keys are rows row_base + cu[b] .. row_base + cu[b + 1] of qkv."""
+    _bf16(q)
+    _bf16(qkv)
+    _bf16(out)
+    assert q.shape[0] >= nsamples and out.shape[0] >= nsamples and qkv.shape[1] == 3 * heads * 64
+    assert cu.dtype == torch.int32 and cu.numel() >= nsamples + 2
+    _check(lib().msclip_attention_lastq_varlen(_p(q), q.stride(0), _p(qkv), qkv.stride(0), _p(out), out.stride(0), nsamples, Lmax,
+                                               heads, _p(cu), row_base, _stream()), "msclip_attention_lastq_varlen")
+    return out
+
+
 def fill_cls(cls, pos, x, B, L):
     _check(lib().msclip_fill_cls(_p(cls), _p(pos), _p(x), x.stride(0), B, L, x.shape[1], _stream()), "msclip_fill_cls")
 
@@ -849,6 +899,24 @@ def attention_bwd(qkv, o, dout, dqkv, nsamples, L, heads, causal):
     _check(lib().msclip_attention_bwd(_p(qkv), _p(o), _p(dout), _p(dqkv), nsamples, L, heads, qkv.stride(0), o.stride(0),
                                       int(causal), _stream()), "msclip_attention_bwd")
     return dqkv
+
+
+def attention_bwd_varlen(qkv, o, dout, dqkv, cu, nsamples, Lmax, heads, causal, pad_rows=0):
+    """attention_bwd over packed captions (views that start at the text segment); dqkv's pad_rows rows behind cu[nsamples] zeroed."""
+    for t in (qkv, o, dout, dqkv):
+        _bf16(t)
+    assert cu.dtype == torch.int32 and cu.numel() >= nsamples + 2 and 0 <= pad_rows < 256
+    _check(lib().msclip_attention_bwd_varlen(_p(qkv), _p(o), _p(dout), _p(dqkv), _p(cu), nsamples, Lmax, heads, qkv.stride(0),
+                                             o.stride(0), int(causal), pad_rows, _stream()), "msclip_attention_bwd_varlen")
+    return dqkv
+
+
+def embed_tokens_bwd_packed(tokens, dx, cu, demb, dpos):
+    """Embedding backward over packed captions: demb += rows (atomics), dpos[l] = fixed-order sum of the captions' rows l."""
+    B, L = tokens.shape
+    assert dx.dtype == torch.float32 and dx.stride(-1) == 1 and cu.dtype == torch.int32
+    _check(lib().msclip_embed_tokens_bwd_packed(_p(tokens), _p(dx), dx.stride(0), _p(cu), _p(demb), _p(dpos), B, L, dx.shape[1],
+                                                demb.shape[0], _stream()), "msclip_embed_tokens_bwd_packed")
 
 
 def l2norm_bwd(x, dy, dx):
