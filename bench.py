@@ -60,6 +60,10 @@ def pmc_passes(args, kernel):
         cmd = ["rocprofv3", "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", d, "-o", "run", "--",
                sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--batch", str(args.batch),
                "--model", args.model, "--no-cpu-baseline", "--no-probe", "--no-pmc"]
+        if args.caption_tokens:
+            cmd += ["--caption-tokens", str(args.caption_tokens)]
+        if args.precision:
+            cmd += ["--precision", args.precision]
         if args.train_slice:                        # the counters of a training record come from a training child
             cmd += ["--train", "--bn", args.bn]
         try:
@@ -85,7 +89,7 @@ def pmc_passes(args, kernel):
 HBM_PEAK_TBPS = 8.0                                                           # MI355X_MICROARCH.md: HBM3E spec peak (6.3 measured achievable)
 
 
-def hbm_kernel_rates(args, B, width, Lv, Lt, g):
+def hbm_kernel_rates(args, B, width, Lv, Lt, g, Mt_live=None, Mt_rows=None):
     """Achieved HBM rate of the largest bandwidth-bound kernels of the step ("per-kernel HBM GB/s for the
     bandwidth-bound kernels"): average launch time from a rocprofv3 --kernel-trace child pass of this command (inline
     schedule: nothing else on the chip), algorithmic bytes per launch from the shapes (s8(d) "algorithmic bytes")."""
@@ -97,11 +101,16 @@ def hbm_kernel_rates(args, B, width, Lv, Lt, g):
     if shutil.which("rocprofv3") is None:
         return None
     Mv, Mt, D = B * Lv, B * Lt, width
+    Mt_live = Mt if Mt_live is None else Mt_live      # packed captions: the rows that exist / the rows the GEMM tiles cover
+    Mt_rows = Mt if Mt_rows is None else Mt_rows
+    txt = f"text attention core (causal, packed captions: {Mt_live / B:.1f} live rows of {Lt} on average): q|k|v read + output written, bf16"
     alg = {   # kernel-name prefix -> (what, algorithmic bytes per launch)
-        "attn_kernel<3, true": ("text attention core (causal, 77 tokens): q|k|v read + output written, bf16", 4 * Mt * D * 2),
+        "attn_kernel<3, true": (txt, 4 * Mt_live * D * 2),
+        "attn_kernel<2, true": (txt, 4 * Mt_live * D * 2),
+        "attn_kernel<1, true": (txt, 4 * Mt_live * D * 2),
         "attn_kernel<2, false": ("image attention core (50 tokens)", 4 * Mv * D * 2),
         "attn_wg_kernel": ("image attention core (197 tokens)", 4 * Mv * D * 2),
-        "ln_pair_kernel": ("LayerNorm over all token rows: fp32 in, bf16 out", (Mv + Mt) * D * 6),
+        "ln_pair_kernel": ("LayerNorm over all token rows: fp32 in, bf16 out", (Mv + Mt_rows) * D * 6),
         "ln_stats_kernel": ("LayerNorm pass of one tower's rows (+ fold state; adapter layers also copy the fp32 row)", None),
         "front_ws_kernel<0": ("stem conv1 + parallel stage 0 + stem stage 0 in one pass: fp32 image in, two bf16 maps out",
                               B * (3 * 224 * 224 * 4 + 112 * 112 * (D // 16) * 2 + 56 * 56 * (D // 8) * 2)),
@@ -112,20 +121,29 @@ def hbm_kernel_rates(args, B, width, Lv, Lt, g):
     cmd = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "-o", "run", "--",
            sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "2", "--batch", str(args.batch),
            "--model", args.model, "--no-cpu-baseline", "--no-probe", "--no-pmc", "--no-hbm-kernels"]
+    if args.caption_tokens:
+        cmd += ["--caption-tokens", str(args.caption_tokens)]
+    if args.precision:
+        cmd += ["--precision", args.precision]
     try:
         subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", MSCLIP_CONV_SIDE_STREAM="0"), timeout=900,
                        capture_output=True, check=True)
         f = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)[0]
         rows = []
-        for r in csv.DictReader(open(f)):
-            name = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+        table = [(r["Name"].replace("(anonymous namespace)::", "").replace("void ", ""), r) for r in csv.DictReader(open(f))]
+        # passes in the trace = launches of a once-per-pass kernel (3 steps + 2 warm-up; an uncalibrated fp8 model adds its
+        # calibration pass): the loss kernel runs once per step, the text head's L2 norm once per tower and pass
+        marks = [int(r["Calls"]) for n, r in table if n.startswith("loss_from_partials_kernel")]
+        passes = max(marks[0] if marks else 5, 1)
+        for name, r in table:
             for pre, (what, nbytes) in alg.items():
                 if name.startswith(pre) and nbytes:
                     us = float(r["AverageNs"]) / 1e3
-                    rows.append({"kernel": name.split("(")[0], "what": what, "launches_per_step": int(r["Calls"]) // 5,
+                    per_step = round(int(r["Calls"]) / passes, 2)
+                    rows.append({"kernel": name.split("(")[0], "what": what, "launches_per_step": per_step,
                                  "avg_us": round(us, 1), "algorithmic_MB": round(nbytes / 1e6, 1),
                                  "achieved_TBps": round(nbytes / us / 1e6, 2), "frac_of_hbm_peak": round(nbytes / us / 1e6 / HBM_PEAK_TBPS, 3),
-                                 "step_share_us": round(us * (int(r["Calls"]) // 5), 1)})
+                                 "step_share_us": round(us * per_step, 1)})
         rows.sort(key=lambda r: -r["step_share_us"])
         return rows[:4]
     except Exception as e:
@@ -183,6 +201,9 @@ def main():
                     help="--train only: train-mode BatchNorm with per-GPU batch statistics (default, the reference's train() "
                          "semantics) or frozen running statistics")
     ap.add_argument("--shapes", action="store_true", help="add the per-shape table of the dominant kernel to the record")
+    ap.add_argument("--caption-tokens", type=int, default=0,
+                    help="every caption has exactly this many content tokens (75 = all 77 rows live: the line that shows what the "
+                         "step costs when packing removes nothing); default 0 = SURVEY s8(d)'s synthetic captions, U{4..60} content tokens")
     args = ap.parse_args()
 
     from msclip_amd import comm as C, hip, synth
@@ -221,7 +242,11 @@ def main():
     eng = model.engine()
     B = args.batch
     img = synth.synth_images(B, seed=10 + rank).to(dev)                      # fp32 pixels (reference API), resident in HBM
-    tok = synth.synth_tokens(B, seed=100 + rank).to(dev)
+    if args.caption_tokens:
+        tok = synth.synth_tokens(B, seed=100 + rank, min_len=args.caption_tokens, max_len=args.caption_tokens).to(dev)
+    else:
+        tok = synth.synth_tokens(B, seed=100 + rank).to(dev)
+    lens_host = (tok.argmax(dim=-1) + 1).cpu()                               # live rows per caption (EOT position + 1, M.py:3057)
 
     ts = None
     if args.train_slice:
@@ -309,7 +334,20 @@ def main():
             lv = SKIPPED_ROWS_PER_PAIR[args.model] + 2 - 77
             skipped += (SKIPPED_ROWS_PER_PAIR[args.model] * 2 * WIDTH[args.model] ** 2 +
                         ((lv - 1) * lv + 76 * 77) * 4 * WIDTH[args.model]) / 1e9
-        gf = gf_ref - skipped                      # executed algorithmic FLOPs per pair
+        # Packed captions (engine.text_pack_enabled): the rows behind a caption's EOT position do not exist.  Per text layer a
+        # caption with n live rows executes 24 d^2 n (projections) + 4 d n^2 (attention over n keys) instead of the reference's
+        # 24 d^2 77 + 4 d 77^2; in the compact last block only the k | v projection (4 d^2 per row) and one query's attention
+        # (4 d per key) ran on every row.  Counted from this rank's actual caption lengths.
+        packed = eng.text_pack_enabled()
+        dead = 0.0
+        if packed:
+            d_, nl, Lt = WIDTH[args.model], eng.n_layers, eng.Lt
+            n = lens_host.double()
+            full_layers = nl if skipped == 0.0 else nl - 1
+            dead = float((full_layers * ((Lt - n) * 24 * d_ * d_ + 4 * d_ * (Lt * Lt - n * n))).mean()) / 1e9
+            if skipped:
+                dead += float(((Lt - n) * (4 * d_ * d_ + 4 * d_)).mean()) / 1e9
+        gf = gf_ref - skipped - dead               # executed algorithmic FLOPs per pair
         fmul = 3 if ts is not None else 1          # backward counted as 2x forward
         rec = {
             "metric": {"b32": "image-text pairs/sec ViT-B/32 bf16", "b16": "image-text pairs/sec ViT-B/16 bf16",
@@ -326,11 +364,18 @@ def main():
             "config": {"workload": f"MS-CLIP-S {args.model} fwd + contrastive step (both towers, gather, logits, "
                                    f"symmetric CE), per-GPU batch {B}, 224x224 images + 77-token captions, "
                                    f"random-init weights", "per_gpu_batch": B, "global_batch": B * world,
-                       "parallelism": f"dp{world}", "bn": "eval (folded running statistics)"},
+                       "parallelism": f"dp{world}", "bn": "eval (folded running statistics)",
+                       "captions": (f"[SOT, {args.caption_tokens} ids, EOT, zero pad]" if args.caption_tokens else
+                                    "[SOT, l ~ U{4..60} random ids, EOT, zero pad] (SURVEY s8(d), synth.synth_tokens)") +
+                                   f": {float(lens_host.double().mean()):.2f} live rows of {eng.Lt} per caption on average (max {int(lens_host.max())})",
+                       "text_rows": ("packed: only the rows up to each caption's EOT position exist (the causal mask makes the rest "
+                                     "unreachable from every output); MSCLIP_TEXT_PACK=0 computes all 77" if packed else
+                                     "all 77 rows of every caption computed (MSCLIP_TEXT_PACK=0)")},
             "step_tflops_per_gpu": round(pairs_s / world * gf / 1e3 * fmul, 1),
             "whole_step_mfma_frac": round(pairs_s / world * gf / 1e3 * fmul / PEAK_BF16_TFLOPS, 4),   # (fp8 models: re-stated against the mixed peak below)
             "gflop_per_pair": {"reference_forward": gf_ref, "executed": round(gf * fmul, 3),
-                               "not_executed_dead_rows_of_last_block": round(skipped, 3)},
+                               "not_executed_dead_rows_of_last_block": round(skipped * fmul, 3),
+                               "not_executed_rows_behind_eot": round(dead * fmul, 3)},
             "loss": round(loss_val, 5),
         }
         if ts is not None:
@@ -431,7 +476,9 @@ def main():
             if key in rec and "mfma_busy_pct_whole_step" in rec[key]:
                 rec["mfma_util_pct"] = rec[key]["mfma_busy_pct_whole_step"]      # BASELINE metric's second half (all kernels of a step)
         if world == 1 and ts is None and not args.no_hbm_kernels and not args.no_pmc:
-            rec["hbm_bound_kernels"] = hbm_kernel_rates(args, B, WIDTH[args.model], eng.Lv, eng.Lt, eng.g)
+            wsp = eng._workspace(B, B)
+            rec["hbm_bound_kernels"] = hbm_kernel_rates(args, B, WIDTH[args.model], eng.Lv, eng.Lt, eng.g,
+                                                        Mt_live=wsp.get("Mt_live"), Mt_rows=wsp.get("Mt"))
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(args.model, sd)
         if grouped:                     # RCCL's version banner sits in libc's stdout buffer: out with it BEFORE the record, so

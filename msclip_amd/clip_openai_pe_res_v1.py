@@ -355,6 +355,12 @@ class CLIP(nn.Module):
         assert action is None
         return self.engine().encode_text(text, norm=norm)
 
+    def stage_captions(self, text):
+        """Stage a token batch for encode_text / forward / contrastive_loss (engine.Engine.stage_captions): its per-caption live
+        lengths are computed on the device now, so the call that consumes the result never waits for them.  Optional: every
+        entry point also takes the plain int64 tensor of the reference API."""
+        return self.engine().stage_captions(text)
+
     @torch.no_grad()
     def forward(self, image, text):
         """logits = exp(logit_scale) * I_all @ T_all^T after the rank-major feature all-gather (M.py:3126-3155).

@@ -38,6 +38,27 @@ def _text0_stream(device):
     return s
 
 
+class Captions:
+    """A caption batch staged for the engine (Engine.stage_captions): the int64 token ids [B, L] plus, computed on the device
+    when the batch was staged, every caption's live length n_b = argmax + 1, the exclusive prefix sums `cu` (+ total, +
+    maximum) and the EOT row of each caption relative to the packed text segment; the two host-side numbers the engine needs
+    (total live rows, longest caption) travel through pinned memory behind `event`.  Staging a batch while the previous one
+    is still being computed (an input pipeline's prefetch stage) means the engine never waits for them."""
+
+    def __init__(self, tok, length, cu, eot, host, event):
+        self.tok, self.len, self.cu, self.eot, self._host, self._event = tok, length, cu, eot, host, event
+        self._totals = None
+        self.shape = tok.shape
+
+    def totals(self):
+        """(total live rows, longest caption): the one host read, taken once."""
+        if self._totals is None:
+            self._event.synchronize()
+            self._totals = (int(self._host[0]), int(self._host[1]))
+            self._host = None
+        return self._totals
+
+
 class _BlockW:
     """Packed weights of one ResidualAttentionBlock's shareable part."""
 
@@ -348,11 +369,7 @@ class Engine:
             w["fv_raw"], w["fv"] = buf(Bi, E, dtype=f32), buf(Bi, E, dtype=f32)
         if Bt:
             w["eot"] = torch.empty(Bt, dtype=torch.int32, device=dev)
-            # packed captions (_text_pack): live length per caption, exclusive prefix sums (+ total, + maximum), their host copy
-            w["len"] = torch.empty(Bt, dtype=torch.int32, device=dev)
-            w["cu"] = torch.zeros(Bt + 2, dtype=torch.int32, device=dev)
-            w["cu_host"] = torch.zeros(2, dtype=torch.int32).pin_memory()
-            w["packed"] = False
+            w["packed"] = False                             # packed captions: w["cap"] = the staged batch (Captions) of this call
             w["ht"] = buf(Bt, D)
             w["ft_raw"], w["ft"] = buf(Bt, E, dtype=f32), buf(Bt, E, dtype=f32)
         # compact matrices of the rows that are still read after the last block's attention (cls / EOT rows, _last_block_tail)
@@ -523,28 +540,41 @@ class Engine:
         records, since a capture cannot read the host)."""
         return (os.environ.get("MSCLIP_TEXT_PACK", "1") != "0" and not torch.cuda.is_current_stream_capturing() and self.Lt <= 96)
 
-    def _text_lengths_begin(self, tok, w, Bt):
-        """Queue the length / prefix-sum kernels and the 8-byte read-back on the current stream; -> the event to wait for."""
-        hip.text_lengths(tok, w["len"], w["cu"], w["eot"], row_base=w["Mv"])
-        w["cu_host"].copy_(w["cu"][Bt:Bt + 2], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.dev))
-        return ev
+    def stage_captions(self, tok):
+        """-> Captions: queue the length / prefix-sum kernels of a token batch and the 8-byte read-back on the CURRENT stream
+        (ordered behind whatever produced `tok` there).  run() / forward_* / encode_text / TrainStep.forward take the result in
+        place of the token tensor; called on a tensor they stage it themselves and wait for the read-back at once."""
+        tok = self._check_tok(tok)
+        Bt = tok.shape[0]
+        with torch.cuda.device(self.dev):
+            length = torch.empty(Bt, dtype=torch.int32, device=self.dev)
+            cu = torch.empty(Bt + 2, dtype=torch.int32, device=self.dev)
+            eot = torch.empty(Bt, dtype=torch.int32, device=self.dev)
+            hip.text_lengths(tok, length, cu, eot, row_base=0)
+            if getattr(self, "_cap_pin", None) is None:
+                self._cap_pin, self._cap_slot = torch.zeros(64, 2, dtype=torch.int32).pin_memory(), 0
+            host = self._cap_pin[self._cap_slot % 64]         # (a ring: a staged batch is consumed long before 64 more are staged)
+            self._cap_slot += 1
+            host.copy_(cu[Bt:Bt + 2], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.dev))
+        return Captions(tok, length, cu, eot, host, ev)
 
-    def _text_lengths_end(self, ev, w, Bt):
-        """The host read: total live rows and the longest caption -> this call's row counts (w["Mt"], w["M"], w["pad"])."""
-        ev.synchronize()
-        total, lmax = int(w["cu_host"][0]), int(w["cu_host"][1])
+    def _text_sizes(self, cap, w, Bt):
+        """The host read of a staged batch -> this call's row counts (w["Mt"], w["M"], w["pad"])."""
+        total, lmax = cap.totals()
         padded = -(-total // 256) * 256              # whole 256-row GEMM tiles (the LayerNorm fold's modality split never straddles one)
         if padded > Bt * self.Lt or padded < 256 * 16:
             padded = total
-        w.update(packed=True, Mt_live=total, Lmax=lmax, pad=padded - total, Mt=padded, M=w["Mv"] + padded)
+        w.update(packed=True, cap=cap, cu=cap.cu, len=cap.len, Mt_live=total, Lmax=lmax, pad=padded - total, Mt=padded,
+                 M=w["Mv"] + padded)
 
     def _text_unpacked(self, w, Bt):
-        w.update(packed=False, Mt_live=Bt * self.Lt, Lmax=self.Lt, pad=0, Mt=Bt * self.Lt, M=w["Mv"] + Bt * self.Lt)
+        w.update(packed=False, cap=None, Mt_live=Bt * self.Lt, Lmax=self.Lt, pad=0, Mt=Bt * self.Lt, M=w["Mv"] + Bt * self.Lt)
 
     def _text_front(self, tok, w, Bt):
         if w.get("packed"):
+            torch.add(w["cap"].eot, w["Mv"], out=w["eot"])           # EOT rows of the packed segment -> rows of the token matrix
             return hip.embed_tokens_packed(tok, self.emb, self.tpos, w["X"], w["cu"], w["Mv"], w["Mt"])
         hip.embed_tokens(tok, self.emb, self.tpos, w["X"], w["eot"], w["Mv"])
 
@@ -1040,7 +1070,7 @@ class Engine:
             if not torch.cuda.is_current_stream_capturing():
                 self.refresh()
             Bi = img.shape[0] if img is not None else 0
-            Bt = tok.shape[0] if tok is not None else 0
+            Bt = tok.shape[0] if tok is not None else 0            # (a tensor or a staged Captions batch)
             if self.fp8 and self._calib is None and not self.fp8_calibrated() and not torch.cuda.is_current_stream_capturing():
                 if Bi and Bt:
                     self.calibrate_fp8(img, tok)          # first two-modality batch = the calibration batch (explicit call: calibrate_fp8)
@@ -1054,10 +1084,13 @@ class Engine:
             conv_events = None
             side_ok = (taps is None and os.environ.get("MSCLIP_CONV_SIDE_STREAM", "1") != "0"
                        and not torch.cuda.is_current_stream_capturing())
-            text0 = ts = lens_ev = tokc = None
+            text0 = ts = cap = tokc = None
             pack = bool(Bt) and self.text_pack_enabled()
             if Bt:
-                tokc = self._check_tok(tok)
+                if isinstance(tok, Captions):
+                    cap, tokc = (tok if pack else None), tok.tok
+                else:
+                    tokc = self._check_tok(tok)
                 if not pack:
                     self._text_unpacked(w, Bt)
             if Bi and Bt and side_ok and self.vblk[0] is None and os.environ.get("MSCLIP_TEXT0_STREAM", "1") != "0":
@@ -1070,12 +1103,11 @@ class Engine:
                 start.record(cur)                               # the workspace is free: the previous step's work is queued
                 ts.wait_event(start)
                 tokc.record_stream(ts)
-            if pack:
-                # packed captions: the per-caption lengths are needed on the HOST (they size every launch over the text rows).
-                # Their kernels are queued first, the image front behind them; the host waits for 8 bytes while the GPU
-                # already has the image front to work on.
-                with torch.cuda.stream(ts if ts is not None else torch.cuda.current_stream(self.dev)):
-                    lens_ev = self._text_lengths_begin(tokc, w, Bt)
+            if pack and cap is None:
+                # packed captions: the total live row count is needed on the HOST (it sizes every launch over the text rows).
+                # A batch that was not staged ahead (stage_captions) is staged here, in front of the image front: the host then
+                # waits for 8 bytes while the GPU already has the image front to work on.
+                cap = self.stage_captions(tokc)
 
             def text_side():
                 nonlocal text0
@@ -1094,8 +1126,10 @@ class Engine:
                 if side_ok and self.lateral and self.lateral == sorted(self.lateral) and os.environ.get("MSCLIP_BRANCH_STREAM", "1") != "0":
                     conv_events = self._conv_branch_on_side_stream(w, Bi)
             if pack:
-                self._text_lengths_end(lens_ev, w, Bt)
+                self._text_sizes(cap, w, Bt)
                 if ts is not None:
+                    for t in (cap.len, cap.cu, cap.eot):
+                        t.record_stream(ts)
                     text_side()
             if Bt and text0 is None:
                 self._text_front(tokc, w, Bt)

@@ -88,10 +88,21 @@ class TrainStep:
             # the conv side's maps (w["stem"], w["par"], w["pool"], S1, P0) are read again by backward(): until then the
             # engine's inference entry points (an eval / logging call of the same shape in between) get another workspace
             w["held"] = True
-            Mv, M = w["Mv"], w["M"]
+            # captions run packed like the inference path (engine.text_pack_enabled): rows behind a caption's EOT position
+            # neither influence an output nor receive a gradient.  `tok` may be a batch staged ahead (engine.stage_captions).
+            from .engine import Captions
+            pack = e.text_pack_enabled()
+            cap = tok if isinstance(tok, Captions) else None
+            tokc = cap.tok if cap is not None else e._check_tok(tok)
+            if pack and cap is None:
+                cap = e.stage_captions(tokc)               # (the host read happens below, behind the queued image front)
+            if not pack:
+                cap = None
+                e._text_unpacked(w, Bt)
+            Mv = w["Mv"]
             D = e.D
             X = w["X"]
-            sv = dict(Bi=Bi, Bt=Bt, Mv=Mv, M=M, layers=[None] * e.n_layers, tok=e._check_tok(tok), w=w)
+            sv = dict(Bi=Bi, Bt=Bt, Mv=Mv, layers=[None] * e.n_layers, tok=tokc, w=w, cap=cap)
             # ---- fronts (the conv side's maps stay in the workspace `w`; the tokens in front of ln_pre are cloned)
             keep = []
             sv["img"] = e._check_img(img)
@@ -131,6 +142,10 @@ class TrainStep:
                         ev = torch.cuda.Event()
                         ev.record(side)
                         conv_events.append(ev)
+            if cap is not None:
+                e._text_sizes(cap, w, Bt)
+            M = sv["M"] = w["M"]
+            sv.update(Lmax=w["Lmax"], pad=w["pad"], Mt_live=w["Mt_live"])
             e._text_front(sv["tok"], w, Bt)
             # ---- blocks.  Xc = the residual matrix the next layer reads: the workspace's X at first; every layer that runs over
             # all rows writes its two residual updates into fresh matrices (the backward needs the layer's input and its
@@ -178,7 +193,7 @@ class TrainStep:
                     hip.gemm(lno1[r0:r1], bw.wqkv, qkv[r0:r1], bias=bw.bqkv)
                 if vb is not None:
                     hip.attention(qkv[:Mv], ao[:Mv], Bi, e.Lv, e.heads, False)
-                hip.attention(qkv[Mv:M], ao[Mv:M], Bt, e.Lt, e.heads, True)
+                e._attention_text(w, qkv, ao, Bt)
                 for r0, r1, bw in groups:
                     hip.gemm(ao[r0:r1], bw.wo, XM[r0:r1], bias=bw.bo, resid=Xc[r0:r1], resid_kind=hip.RESID_F32)
                 L["x_mid"] = XM if fresh else XM[r_lo:M].clone()
@@ -410,7 +425,11 @@ class TrainStep:
                     _dgrad(dY2[r0:r1], bw.wo.t().contiguous(), dao[r0:r1])
                 if e.vblk[i] is not None:
                     hip.attention_bwd(L["qkv"][:Mv], L["ao"][:Mv], dao[:Mv], dqkv[:Mv], Bi, e.Lv, e.heads, False)
-                hip.attention_bwd(L["qkv"][Mv:M], L["ao"][Mv:M], dao[Mv:M], dqkv[Mv:M], Bt, e.Lt, e.heads, True)
+                if sv["cap"] is not None:
+                    hip.attention_bwd_varlen(L["qkv"][Mv:M], L["ao"][Mv:M], dao[Mv:M], dqkv[Mv:M], sv["cap"].cu, Bt, sv["Lmax"],
+                                             e.heads, True, pad_rows=sv["pad"])
+                else:
+                    hip.attention_bwd(L["qkv"][Mv:M], L["ao"][Mv:M], dao[Mv:M], dqkv[Mv:M], Bt, e.Lt, e.heads, True)
                 for r0, r1, bw in groups:
                     p = names[id(bw)]
                     def unscale_q(g):                                                          # packed q rows = 64^-0.5 * W_q
@@ -447,7 +466,7 @@ class TrainStep:
             # ---- fronts: text embedding, image cls / positional embeddings, ln_pre
             # the text rows of dX are final here and nothing below reads the result: the scatter-add (0.67 ms of atomics at
             # batch 512) runs on the lane, beside the stem's backward
-            dX_text, tok_ids = dX[Mv:M], sv["tok"]
+            dX_text, tok_ids, sv_cap, n_live = dX[Mv:M], sv["tok"], sv["cap"], sv["Mt_live"]
 
             ne = e.emb.numel()
 
@@ -455,13 +474,16 @@ class TrainStep:
                 flat = torch.zeros(ne + e.Lt * D, dtype=F32, device=dev)                     # one tensor: on_lane's contract
                 # the positional embedding's gradient is a sum over the batch: a column sum in a fixed order (bitwise repeatable),
                 # not the kernel's atomics; the token embedding's scatter-add stays atomic (captions share ids)
-                if dX_text.is_contiguous():
+                if sv_cap is not None:
+                    # packed rows: scatter-add over the live rows, positional sums over the captions that have the position
+                    hip.embed_tokens_bwd_packed(tok_ids, dX_text[:n_live], sv_cap.cu, flat[:ne].view_as(e.emb), flat[ne:].view(e.Lt, D))
+                elif dX_text.is_contiguous():
                     hip.embed_tokens_bwd(tok_ids, dX_text, flat[:ne].view_as(e.emb), None)
                     hip.colsum(dX_text.view(Bt, e.Lt * D), out=flat[ne:])
                 else:
                     hip.embed_tokens_bwd(tok_ids, dX_text, flat[:ne].view_as(e.emb), flat[ne:].view(e.Lt, D))
                 return flat
-            both = gradgemm.on_lane(embed_bwd, dX_text, tok_ids)
+            both = gradgemm.on_lane(embed_bwd, dX_text, tok_ids, *([sv_cap.cu] if sv_cap is not None else []))
             grads["token_embedding.weight"], grads["positional_embedding"] = both[:ne].view_as(e.emb), both[ne:].view(e.Lt, D)
             dtok = torch.empty(Mv, D, dtype=F32, device=dev)
             dg, db = hip.layernorm_bwd(sv["tok_pre"], dX[:Mv], e.ln_pre.g, dtok, Mv, accumulate=False)

@@ -283,3 +283,38 @@ def test_text_block_taps_on_live_rows(gpu_device, monkeypatch):
     for k in t0:
         if k.startswith("vblock") or k.startswith("adapter"):
             assert (t0[k] - t1[k]).abs().max().item() <= 1.5e-2 * max(t0[k].abs().max().item(), 1e-3), k
+
+
+def test_training_gradients_packed_equal_full_rows(gpu_device, monkeypatch):
+    """Every gradient of the training step with packed captions against the same step over all 77 rows per caption
+    (MSCLIP_TEXT_PACK=0; that path is pinned to the reference's autograd by tests/test_gpu_train.py, which itself runs packed
+    by default): a row behind the EOT position has zero upstream gradient, so the two agree to bf16-operand noise -- on a ragged
+    batch with the edge captions (EOT at 0 / 1, 77 live rows, a second EOT id)."""
+    from msclip_amd import train
+    m = _model("b32-yfcc-msclips")
+    B = 12
+    img = synth.synth_images(B, seed=81).cuda()
+    tok = edge_tokens(B, seed=82).cuda()
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MSCLIP_TEXT_PACK", mode)
+        ts = train.TrainStep(m, lr=1e-4)
+        loss = ts.forward(img, tok if mode == "0" else m.stage_captions(tok))      # (packed: through a staged batch)
+        assert (ts.saved["cap"] is not None) == (mode == "1")
+        out[mode] = (loss.item(), {k: v.float().clone() for k, v in ts.backward().items()})
+    (l0, g0), (l1, g1) = out["0"], out["1"]
+    assert abs(l0 - l1) <= 2e-3 * max(1.0, abs(l0))
+    assert sorted(g0) == sorted(g1) and len(g0) == 325
+    worst = {}
+    for k in g0:
+        a, b = g0[k].flatten(), g1[k].flatten()
+        scale = max(a.abs().max().item(), 1e-12)
+        worst[k] = (a - b).abs().max().item() / scale
+        cos = F.cosine_similarity(a, b, dim=0).item() if a.numel() > 1 else 1.0
+        assert worst[k] <= 6e-2 and cos >= 0.995, (k, worst[k], cos)
+    print("packed vs full-row gradients: worst", sorted(worst.items(), key=lambda kv: -kv[1])[:4],
+          "median", float(np.median(list(worst.values()))))
+    assert float(np.median(list(worst.values()))) <= 1e-2
+    # the positional embedding's gradient rows that no caption reaches are exactly zero in both
+    lmax = int(lengths(tok.cpu()).max())
+    assert lmax == 77 or bool((g1["positional_embedding"][lmax:] == 0).all())
