@@ -1135,8 +1135,11 @@ extern "C" int msclip_gemm_splitk_tn(const msclip_gemm_desc* d, int slices, void
       d->rowstat || d->W2 || d->rpg != 0x7fffffff || d->radd || d->roff || d->alpha != 1.f)
     return MSCLIP_EINVAL;
   const long long t256 = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256);
-  // 32-bit lane offsets over the whole operand; tile-map reciprocals
-  if ((long long)d->K * d->ldx * 2 + 4096 >= (1ll << 32) || (long long)d->K * d->ldw * 2 + 4096 >= (1ll << 32) ||
+  // 32-bit lane offsets over the whole operand -- INCLUDING the rows an over-hanging last slice addresses (its row index reaches
+  // K rounded up to a K-tile plus one K-tile per slice; they must fall outside the descriptor's range, not wrap around into
+  // valid memory); tile-map reciprocals
+  const long long krows = ((long long)d->K + 63) / 64 * 64 + 64ll * (slices + 1);
+  if (krows * d->ldx * 2 + 4096 >= (1ll << 32) || krows * d->ldw * 2 + 4096 >= (1ll << 32) ||
       t256 * ((d->M + 255) / 256) * 4 >= (1ll << 32))
     return MSCLIP_EINVAL;
   const int ncu = device_cus();

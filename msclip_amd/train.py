@@ -735,7 +735,13 @@ def lr_schedule(config):
     a = dict(sch.get("ARGS", None) or {})
     if str(a.get("sched", "cosine")) != "cosine":
         raise NotImplementedError(f"TRAIN.LR_SCHEDULER.ARGS.sched = {a.get('sched')!r}: only timm's cosine schedule is implemented")
-    return CosineSchedule(epochs=a.get("epochs", tr.get("END_EPOCH", 0)), warmup_epochs=a.get("warmup_epochs", 0),
+    # the reference's update_config sets ARGS.epochs = TRAIN.END_EPOCH unconditionally (lib/config/default.py:306-311): the yaml's
+    # END_EPOCH wins over an `epochs` key under ARGS
+    epochs = int(tr.get("END_EPOCH", 0) or 0) or int(a.get("epochs", 0) or 0)
+    warm = int(a.get("warmup_epochs", 0) or 0)
+    if epochs <= 0 or epochs <= warm:
+        raise ValueError(f"TRAIN.LR_SCHEDULER: the cosine schedule needs TRAIN.END_EPOCH ({epochs}) > ARGS.warmup_epochs ({warm})")
+    return CosineSchedule(epochs=epochs, warmup_epochs=warm,
                           warmup_lr=a.get("warmup_lr", 0.0), min_lr=a.get("min_lr", 0.0),
                           cooldown_epochs=a.get("cooldown_epochs", 0), decay_rate=a.get("decay_rate", 0.1))
 

@@ -292,15 +292,27 @@ def test_emulated_8_rank_contrastive_head(gpu_device):
 TAP_TOL = {"stem": 3e-2, "parallel": 3e-2, "tokens": 3e-2, "adapter": 3e-2, "vblock": 4e-2, "tblock": 4e-2}
 
 
+def _live_sample_mask(shape, lens):
+    """Which of summarize()'s 64 strided sample points of a [B, L, C] text tap lie on live rows (l < lens[b])."""
+    n = int(np.prod(shape))
+    idx = torch.linspace(0, n - 1, 64).long().clamp_(max=n - 1)
+    row = idx // shape[2]
+    b, l = row // shape[1], row % shape[1]
+    return (l < lens.cpu().long()[b]).numpy()
+
+
 @pytest.mark.parametrize("name", ["b32-yfcc-msclips", "b16-yfcc-msclips"])
-@pytest.mark.parametrize("fused", [True, False])
-def test_reference_taps_on_gpu(gpu_device, monkeypatch, name, fused):
+@pytest.mark.parametrize("fused,pack", [(True, True), (False, True), (True, False)])
+def test_reference_taps_on_gpu(gpu_device, monkeypatch, name, fused, pack):
     """Every intermediate the reference exposes through forward hooks (tests/golden tap_*: stem stages, parallel
     stages 0-4, tokens after ln_pre, lateral adapters 0-4, blocks 1 / 2 / 11 of both towers), HIP path vs the values
     captured from the REAL reference: a compensating error in the stem / adapter kernels cannot hide behind the end
     features.  Compared on the golden's 64-point strided sample + mean + abs-mean, relative to the tap's own scale
-    (bf16 activations: 3e-2 of the sample's abs-max; blocks 4e-2)."""
+    (bf16 activations: 3e-2 of the sample's abs-max; blocks 4e-2).  pack: the text rows packed (default; the text-block taps
+    then exist on the live rows only: their sample points on live rows are compared, the whole-tensor means are not) or all
+    77 rows per caption (MSCLIP_TEXT_PACK=0: the complete comparison)."""
     from conftest import summarize
+    monkeypatch.setenv("MSCLIP_TEXT_PACK", "1" if pack else "0")
     if not fused:
         monkeypatch.setenv("MSCLIP_FRONT_UNFUSED", "1")
         monkeypatch.setenv("MSCLIP_BLOCK_UNFUSED", "1")
@@ -325,10 +337,17 @@ def test_reference_taps_on_gpu(gpu_device, monkeypatch, name, fused):
         got, ref = summarize(t), g["tap_" + k]
         scale = max(np.abs(ref[2:]).max(), 1e-3)
         tol = TAP_TOL[[p for p in TAP_TOL if k.startswith(p)][0]]
-        err = np.abs(got[2:] - ref[2:]).max() / scale
+        if k.startswith("tblock") and pack:
+            assert "text_lengths" in taps
+            live = _live_sample_mask(t.shape, taps["text_lengths"])
+            assert live.sum() >= 16, (k, live.sum())
+            err = np.abs(got[2:] - ref[2:])[live].max() / scale
+            assert bool((got[2:][~live] == 0).all())
+        else:
+            err = np.abs(got[2:] - ref[2:]).max() / scale
+            assert abs(got[0] - ref[0]) <= tol * max(ref[1], 1e-3) and abs(got[1] - ref[1]) <= tol * max(ref[1], 1e-3), (k, got[:2], ref[:2])
         worst[k] = float(err)
         assert err <= tol, (k, err)
-        assert abs(got[0] - ref[0]) <= tol * max(ref[1], 1e-3) and abs(got[1] - ref[1]) <= tol * max(ref[1], 1e-3), (k, got[:2], ref[:2])
         checked += 1
     assert checked == (21 if fused else 22)
     print(name, "fused" if fused else "unfused", "worst taps:", sorted(worst.items(), key=lambda kv: -kv[1])[:4])
@@ -703,7 +722,12 @@ def test_l14_patch_conv_model_bf16_against_reference_golden(gpu_device):
         assert tuple(t.shape) == tuple(g["tapshape_" + k]), (k, t.shape)
         got, ref = summarize(t), g["tap_" + k]
         scale = max(np.abs(ref[2:]).max(), 1e-3)
-        assert np.abs(got[2:] - ref[2:]).max() / scale <= 4e-2, k
+        err = np.abs(got[2:] - ref[2:])
+        if k.startswith("tblock") and "text_lengths" in taps:        # packed captions: the sample points on live rows
+            live = _live_sample_mask(t.shape, taps["text_lengths"])
+            assert live.sum() >= 16 and bool((got[2:][~live] == 0).all())
+            err = err[live]
+        assert err.max() / scale <= 4e-2, k
     # batch 256 (Mv = 257 * 256 rows: the LayerNorm fold and the 257-token attention at full size) against the oracle on a few samples
     sd, arch = synth_sd(name), O.arch_l14()
     B = 256

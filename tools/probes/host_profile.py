@@ -1,65 +1,69 @@
-"""cProfile of the training step's host side (which Python / ATen calls the step boundary spends its time in).
-    python tools/probes/host_profile.py [frozen|batch] [B]"""
+"""Where the HOST spends a training step (or a forward step): cProfile over K steps that are issued against a GPU queue kept
+non-empty, so the times are issue costs (ctypes calls, torch allocations, stream / event bookkeeping), not waits.
+    python tools/probes/host_profile.py [--train --bn frozen] [--steps 6] [--top 45]"""
+import argparse
 import cProfile
+import io
+import os
 import pstats
 import sys
 import time
 
+os.environ.setdefault("HSA_KERNARG_POOL_SIZE", str(16 << 20))
 import torch
 
-sys.path.insert(0, ".")
-from msclip_amd import synth, train                                       # noqa: E402
-from msclip_amd.config import named_config                                # noqa: E402
-from msclip_amd.clip_openai_pe_res_v1 import get_clip_model               # noqa: E402
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
 
-bn = sys.argv[1] if len(sys.argv) > 1 else "frozen"
-B = int(sys.argv[2]) if len(sys.argv) > 2 else 512
-m = get_clip_model(named_config("b32-yfcc-msclips"))
-m.load_state_dict(synth.synth_state_dict(synth.schema_of(m)), strict=True)
-m = m.cuda().eval()
-img, tok = synth.synth_images(B, seed=1).cuda(), synth.synth_tokens(B, seed=2).cuda()
-ts = train.from_config(m, named_config("b32-yfcc-msclips"), bn=bn)
-for _ in range(4):
-    ts.forward(img, tok)
-    ts.step(ts.backward())
-torch.cuda.synchronize()
-# un-profiled host time of the three calls
-n = 6
-acc = [0.0, 0.0, 0.0]
-for _ in range(n):
-    t0 = time.perf_counter(); ts.forward(img, tok)
-    t1 = time.perf_counter(); g = ts.backward()
-    t2 = time.perf_counter(); ts.step(g)
-    t3 = time.perf_counter()
-    acc[0] += t1 - t0; acc[1] += t2 - t1; acc[2] += t3 - t2
-torch.cuda.synchronize()
-print(f"host ms per step: forward {1e3 * acc[0] / n:.2f}, backward {1e3 * acc[1] / n:.2f}, optimizer step {1e3 * acc[2] / n:.2f}")
-for name, fn in (("step", None), ("forward", None)):
-    pr = cProfile.Profile()
-    for _ in range(n):
-        g = None
-        if name == "forward":
-            pr.enable(); ts.forward(img, tok); pr.disable()
-            g = ts.backward()
-            ts.step(g)
-        else:
-            ts.forward(img, tok)
-            g = ts.backward()
-            pr.enable(); ts.step(g); pr.disable()
-    torch.cuda.synchronize()
-    print(f"==== {name}: {n} calls")
-    pstats.Stats(pr).sort_stats("tottime").print_stats(22)
 
-# the optimizer step's host time with an EMPTY queue (is the time in AdamwPlan.run launch cost or back-pressure?)
-pr = cProfile.Profile()
-tt = 0.0
-for _ in range(n):
-    ts.forward(img, tok)
-    g = ts.backward()
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--train", action="store_true")
+    ap.add_argument("--bn", default="frozen")
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--batch", type=int, default=512)
+    ap.add_argument("--top", type=int, default=45)
+    ap.add_argument("--sort", default="tottime")
+    a = ap.parse_args()
+    from bench import load_schema
+    from msclip_amd import synth, train
+    from msclip_amd.clip_openai_pe_res_v1 import get_clip_model
+    from msclip_amd.config import named_config
+    name = "b32-yfcc-msclips"
+    m = get_clip_model(named_config(name))
+    m.load_state_dict(synth.synth_state_dict(load_schema(name), seed=0), strict=True)
+    m = m.cuda().eval()
+    eng = m.engine()
+    img, tok = synth.synth_images(a.batch, seed=10).cuda(), synth.synth_tokens(a.batch, seed=100).cuda()
+    ts = train.from_config(m, named_config(name), bn=a.bn) if a.train else None
+
+    def step():
+        if ts is None:
+            return eng.forward_loss(img, tok, gather=True)
+        loss = ts.forward(img, tok)
+        ts.step(ts.backward())
+        return loss
+    for _ in range(3):
+        step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    pr.enable(); ts.step(g); pr.disable()
-    tt += time.perf_counter() - t0
-torch.cuda.synchronize()
-print(f"==== step with the GPU idle: host {1e3 * tt / n:.2f} ms per call")
-pstats.Stats(pr).sort_stats("tottime").print_stats(12)
+    for _ in range(a.steps):
+        step()
+    t_issue = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    t_all = time.perf_counter() - t0
+    print(f"unprofiled: host issued {a.steps} steps in {t_issue / a.steps * 1e3:.2f} ms/step, finished in {t_all / a.steps * 1e3:.2f} ms/step")
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(a.steps):
+        step()
+    pr.disable()
+    torch.cuda.synchronize()
+    s = io.StringIO()
+    st = pstats.Stats(pr, stream=s)
+    st.sort_stats(a.sort).print_stats(a.top)
+    print(s.getvalue()[:14000])
+
+
+if __name__ == "__main__":
+    main()
