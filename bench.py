@@ -62,6 +62,8 @@ def pmc_passes(args, kernel):
                "--model", args.model, "--no-cpu-baseline", "--no-probe", "--no-pmc"]
         if args.caption_tokens:
             cmd += ["--caption-tokens", str(args.caption_tokens)]
+        if args.inline_lengths:
+            cmd += ["--inline-lengths"]
         if args.precision:
             cmd += ["--precision", args.precision]
         if args.train_slice:                        # the counters of a training record come from a training child
@@ -201,6 +203,9 @@ def main():
                     help="--train only: train-mode BatchNorm with per-GPU batch statistics (default, the reference's train() "
                          "semantics) or frozen running statistics")
     ap.add_argument("--shapes", action="store_true", help="add the per-shape table of the dominant kernel to the record")
+    ap.add_argument("--inline-lengths", action="store_true",
+                    help="packed captions: let the engine compute each batch's lengths at the start of its step (host waits for the "
+                         "read-back) instead of staging them one step ahead")
     ap.add_argument("--caption-tokens", type=int, default=0,
                     help="every caption has exactly this many content tokens (75 = all 77 rows live: the line that shows what the "
                          "step costs when packing removes nothing); default 0 = SURVEY s8(d)'s synthetic captions, U{4..60} content tokens")
@@ -253,12 +258,27 @@ def main():
         from msclip_amd import train
         ts = train.from_config(model, named_config(args.model), bn=args.bn)
 
+    # Caption lengths.  With packed text rows the engine needs one host-side number per batch (the total of live rows).  An input
+    # pipeline stages a batch -- its H2D copy and, with it, engine.stage_captions -- while the previous batch is being computed;
+    # the benchmark does the same INSIDE the timed region: every step first queues the length kernels + 8-byte read-back of the
+    # NEXT step's captions, then runs this step on the batch staged one step earlier (same work per step, no host wait).
+    # --inline-lengths: the engine stages each batch itself and waits for the read-back at the start of the step.
+    staged = {"cap": None}
+    stage_ahead = eng.text_pack_enabled() and not args.inline_lengths
+
+    def captions():
+        if not stage_ahead:
+            return tok
+        cap = staged["cap"] or eng.stage_captions(tok)
+        staged["cap"] = eng.stage_captions(tok)
+        return cap
+
     def step():
         if ts is not None:
-            loss = ts.forward(img, tok)
+            loss = ts.forward(img, captions())
             ts.step(ts.backward())
             return loss
-        return eng.forward_loss(img, tok, gather=True)
+        return eng.forward_loss(img, captions(), gather=True)
 
     def fence():
         torch.cuda.synchronize()
@@ -368,6 +388,9 @@ def main():
                        "captions": (f"[SOT, {args.caption_tokens} ids, EOT, zero pad]" if args.caption_tokens else
                                     "[SOT, l ~ U{4..60} random ids, EOT, zero pad] (SURVEY s8(d), synth.synth_tokens)") +
                                    f": {float(lens_host.double().mean()):.2f} live rows of {eng.Lt} per caption on average (max {int(lens_host.max())})",
+                       "caption_lengths": ("staged one step ahead inside the timed region (engine.stage_captions: length kernels + "
+                                           "8-byte read-back of step k + 1 queued in front of step k)" if stage_ahead else
+                                           "computed at the start of each step (host waits for the read-back)" if packed else "not needed"),
                        "text_rows": ("packed: only the rows up to each caption's EOT position exist (the causal mask makes the rest "
                                      "unreachable from every output); MSCLIP_TEXT_PACK=0 computes all 77" if packed else
                                      "all 77 rows of every caption computed (MSCLIP_TEXT_PACK=0)")},

@@ -5,6 +5,13 @@
 #include "common.h"
 #include "../../include/msclip_hip.h"
 
+#ifndef PP_EPI_NT
+#define PP_EPI_NT 1        // the producer epilogue's fp32 residual stream is loaded / stored non-temporally (0: plain: probe builds)
+#endif
+#ifndef PP_EPI_GROW
+#define PP_EPI_GROW 0      // 1: the residual look-ahead of the producer epilogue grows as accumulator registers die (round 5: measured neutral -- the epilogue is HBM-bound chip-wide, tools/probes/epi_probe.py -- and 13 more VGPRs)
+#endif
+
 namespace {
 
 constexpr int STG_BYTES = 4096;   // per-wave staging: 32 rows x 128 B, 16-byte chunks XOR-swizzled by (row & 7)
@@ -89,8 +96,9 @@ __device__ __forceinline__ void epilogue_rows(f32x4 (&acc)[2 * TN][2 * TM], cons
   const int rk = RK >= 0 ? RK : a.resid_kind;
   const int act = ACT >= 0 ? ACT : a.act;
   const int outk = OUTK >= 0 ? OUTK : a.out_kind;
-  constexpr int RAHEAD = 2;                                      // residual blocks (32 x 32) requested ahead
-  float4 rv[RAHEAD][4];                                          // raw: fp32 x 4, or bf16 x 4 in .x/.y (unpacked at use)
+  constexpr int RAHEAD = 2;                                      // residual blocks (32 x 32) requested ahead ...
+  constexpr int NRV = RAHEAD;                                    // (the growing look-ahead of epilogue_rows_stats spills here: 129 VGPRs in the standard kernel)
+  float4 rv[NRV][4];                                             // raw: fp32 x 4, or bf16 x 4 in .x/.y (unpacked at use)
   auto load_res = [&](int b, float4 (&dst)[4]) {
     const int tm = b / TN, tn = b % TN;
 #pragma unroll
@@ -144,14 +152,14 @@ __device__ __forceinline__ void epilogue_rows(f32x4 (&acc)[2 * TN][2 * TM], cons
         v.z = v.z / (1.f + __expf(-1.702f * v.z)); v.w = v.w / (1.f + __expf(-1.702f * v.w));
       }
       if (rk == 1) {
-        const float4 r = rv[b % RAHEAD][i];
+        const float4 r = rv[b % NRV][i];
         v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
       } else if (TE && rk == 4) {                                    // v *= QuickGELU'(h), h = the bf16 "residual" (training dgrad)
-        const unsigned ux = __float_as_uint(rv[b % RAHEAD][i].x), uy = __float_as_uint(rv[b % RAHEAD][i].y);
+        const unsigned ux = __float_as_uint(rv[b % NRV][i].x), uy = __float_as_uint(rv[b % NRV][i].y);
         v.x *= quickgelu_grad(__uint_as_float(ux << 16)); v.y *= quickgelu_grad(__uint_as_float(ux & 0xffff0000u));
         v.z *= quickgelu_grad(__uint_as_float(uy << 16)); v.w *= quickgelu_grad(__uint_as_float(uy & 0xffff0000u));
       } else if (rk) {
-        const unsigned ux = __float_as_uint(rv[b % RAHEAD][i].x), uy = __float_as_uint(rv[b % RAHEAD][i].y);
+        const unsigned ux = __float_as_uint(rv[b % NRV][i].x), uy = __float_as_uint(rv[b % NRV][i].y);
         v.x += __uint_as_float(ux << 16); v.y += __uint_as_float(ux & 0xffff0000u);
         v.z += __uint_as_float(uy << 16); v.w += __uint_as_float(uy & 0xffff0000u);
       }
@@ -198,8 +206,14 @@ __device__ __forceinline__ void epilogue_rows_stats(f32x4 (&acc)[2 * TN][2 * TM]
   const unsigned wr = stg + r16 * 128;
   const int wsw = r16 & 7;
   const unsigned rd = stg + srow * 128 + ((sch ^ srow) << 4);
+  // Residual prefetch depth.  The epilogue is a chain of memory round trips: with the residual rows of only two 32 x 32 blocks
+  // in flight per wave (all the registers there are while the 128 accumulator registers are live) a CU has 64 KB outstanding
+  // and waits out ~4 latencies per tile.  The accumulators of finished blocks are dead registers, so the depth GROWS: blocks 0, 1
+  // up front, then two more behind every finished block (2b + 2, 2b + 3): five blocks in flight by the middle of the tile.
+  // PP_EPI_GROW=0 rebuilds the fixed two-ahead form.
   constexpr int RAHEAD = 2;
-  float4 rv[RAHEAD][4];
+  constexpr int NRV = PP_EPI_GROW ? TM * TN : RAHEAD;
+  float4 rv[NRV][4];
   auto load_res = [&](int b, float4 (&dst)[4]) {
     const int tm = b / TN, tn = b % TN;
 #pragma unroll
@@ -207,7 +221,11 @@ __device__ __forceinline__ void epilogue_rows_stats(f32x4 (&acc)[2 * TN][2 * TM]
       const size_t row = (size_t)(mw0 + tm * 32 + i * 8 + srow);
       // non-temporal: with the fold nobody re-reads the fp32 stream soon (no LayerNorm pass behind this launch), so it should
       // not take the MALL from the bf16 operand the next projection reads (same-box A/B, loads + stores: +0.5-0.9 % on the step)
+#if PP_EPI_NT
       const f32x4 t = __builtin_nontemporal_load((const AS1 f32x4*)(resid + row * a.ldr + nw0 + tn * 32 + sch * 4));
+#else
+      const f32x4 t = *(const AS1 f32x4*)(resid + row * a.ldr + nw0 + tn * 32 + sch * 4);
+#endif
       dst[i] = make_float4(t[0], t[1], t[2], t[3]);
     }
   };
@@ -261,11 +279,15 @@ __device__ __forceinline__ void epilogue_rows_stats(f32x4 (&acc)[2 * TN][2 * TM]
     const int n = nw0 + tn * 32 + sch * 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float4 r = rv[b % RAHEAD][i];
+      const float4 r = rv[b % NRV][i];
       const float4 v = make_float4(xb[i][0] + bias4[tn].x + r.x, xb[i][1] + bias4[tn].y + r.y, xb[i][2] + bias4[tn].z + r.z,
                                    xb[i][3] + bias4[tn].w + r.w);
       const size_t row = (size_t)(mw0 + tm * 32 + i * 8 + srow);
+#if PP_EPI_NT
       __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, (AS1 f32x4*)((float*)a.out + row * a.ldo + n));
+#else
+      *(AS1 f32x4*)((float*)a.out + row * a.ldo + n) = f32x4{v.x, v.y, v.z, v.w};
+#endif
       const float c = cen[i];
       const float d0 = v.x - c, d1 = v.y - c, d2 = v.z - c, d3 = v.w - c;
       uint2 o;
@@ -288,7 +310,12 @@ __device__ __forceinline__ void epilogue_rows_stats(f32x4 (&acc)[2 * TN][2 * TM]
       ps[i] = tn == 0 ? s4 : ps[i] + s4;
       pq[i] = tn == 0 ? q4 : pq[i] + q4;
     }
-    if (b + RAHEAD < TM * TN) load_res(b + RAHEAD, rv[b % RAHEAD]);
+    if (PP_EPI_GROW) {
+      if (2 * b + 2 < TM * TN) load_res(2 * b + 2, rv[(2 * b + 2) % NRV]);
+      if (2 * b + 3 < TM * TN) load_res(2 * b + 3, rv[(2 * b + 3) % NRV]);
+    } else if (b + RAHEAD < TM * TN) {
+      load_res(b + RAHEAD, rv[b % RAHEAD]);
+    }
     if (tn == TN - 1) {                                             // the block row's 64 columns are complete: fold the 8 lanes of a row
       float s[4], q[4];
 #pragma unroll

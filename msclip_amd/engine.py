@@ -1103,21 +1103,27 @@ class Engine:
                 start.record(cur)                               # the workspace is free: the previous step's work is queued
                 ts.wait_event(start)
                 tokc.record_stream(ts)
-            if pack and cap is None:
+            if pack:
                 # packed captions: the total live row count is needed on the HOST (it sizes every launch over the text rows).
-                # A batch that was not staged ahead (stage_captions) is staged here, in front of the image front: the host then
-                # waits for 8 bytes while the GPU already has the image front to work on.
-                cap = self.stage_captions(tokc)
+                # A batch staged ahead (stage_captions: an input pipeline's prefetch stage) has it ready; otherwise it is staged
+                # here and the host waits for its 8 bytes -- i.e. until the previous step's queued work has drained -- BEFORE
+                # anything of this call is queued, so that the text front + block 0 still start beside the image front (queued
+                # behind the image front they ran after it: the main queue idled 1.2 ms per step waiting for them).
+                if cap is None:
+                    with torch.cuda.stream(ts if ts is not None else torch.cuda.current_stream(self.dev)):
+                        cap = self.stage_captions(tokc)
+                self._text_sizes(cap, w, Bt)
+                if ts is not None:                              # (staged on one of the two streams, read on both)
+                    for t in (cap.len, cap.cu, cap.eot):
+                        t.record_stream(ts)
+                        t.record_stream(torch.cuda.current_stream(self.dev))
 
-            def text_side():
-                nonlocal text0
+            if ts is not None:
                 with torch.cuda.stream(ts):
                     self._text_front(tokc, w, Bt)
                     self._blocks(w, 0, Bt, layers=(0,))
                     text0 = torch.cuda.Event()
                     text0.record(ts)
-            if ts is not None and not pack:
-                text_side()
             if Bi:
                 self._vision_front(self._check_img(img), w, Bi, taps)
                 # default (MSCLIP_CONV_SIDE_STREAM=0 turns it off): +1.6 % pairs/s on B/32, +2.2 % on B/16 same-box.  The GEMM
@@ -1125,12 +1131,6 @@ class Engine:
                 # pass with the inline schedule and reports the overlapped figure beside it.
                 if side_ok and self.lateral and self.lateral == sorted(self.lateral) and os.environ.get("MSCLIP_BRANCH_STREAM", "1") != "0":
                     conv_events = self._conv_branch_on_side_stream(w, Bi)
-            if pack:
-                self._text_sizes(cap, w, Bt)
-                if ts is not None:
-                    for t in (cap.len, cap.cu, cap.eot):
-                        t.record_stream(ts)
-                    text_side()
             if Bt and text0 is None:
                 self._text_front(tokc, w, Bt)
             # the last block's row-wise tail on the live rows only (MSCLIP_FULL_LAST_BLOCK=1: every row, as the taps need it)

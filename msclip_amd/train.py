@@ -95,10 +95,12 @@ class TrainStep:
             cap = tok if isinstance(tok, Captions) else None
             tokc = cap.tok if cap is not None else e._check_tok(tok)
             if pack and cap is None:
-                cap = e.stage_captions(tokc)               # (the host read happens below, behind the queued image front)
+                cap = e.stage_captions(tokc)
             if not pack:
                 cap = None
                 e._text_unpacked(w, Bt)
+            else:
+                e._text_sizes(cap, w, Bt)                   # the host read (immediate for a batch staged a step ahead)
             Mv = w["Mv"]
             D = e.D
             X = w["X"]
@@ -142,8 +144,6 @@ class TrainStep:
                         ev = torch.cuda.Event()
                         ev.record(side)
                         conv_events.append(ev)
-            if cap is not None:
-                e._text_sizes(cap, w, Bt)
             M = sv["M"] = w["M"]
             sv.update(Lmax=w["Lmax"], pad=w["pad"], Mt_live=w["Mt_live"])
             e._text_front(sv["tok"], w, Bt)

@@ -3,7 +3,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from msclip_amd import hip
 
-M, D = 65024, 768
+M, D = int(os.environ.get("FOLD_M", "65024")), 768
 BF = torch.bfloat16
 g = torch.Generator().manual_seed(0)
 r = lambda *s, sc=1.0, dt=torch.float32: (torch.randn(*s, generator=g) * sc).to(dt).cuda()

@@ -32,7 +32,31 @@ def make_chain(nimg, ntxt, g):
     return w
 
 
+FOLD = False
+
+
+def layer_fold(w, P):
+    """The shipped layer loop's form: LayerNorms folded into the GEMMs (producer epilogues on out_proj / c_proj, consumer on
+    in_proj / c_fc, rowstat_finalize between them); M must be a multiple of 256."""
+    X, LNO, QKV, AO, HID, Mv, M = w["X"], w["LNO"], w["QKV"], w["AO"], w["HID"], w["Mv"], w["M"]
+    if "CEN" not in w:
+        w["CEN"] = torch.zeros(M, device="cuda")
+        w["RST"] = torch.stack([torch.ones(M), torch.zeros(M)], 1).cuda().contiguous()
+        w["PART"] = torch.empty(M, D // 64, 2, device="cuda")
+    CEN, RST, PART = w["CEN"], w["RST"], w["PART"]
+    hip.gemm(LNO, P["wqkv"], QKV, bias=P["bqkv"], fold_in=hip.FoldIn(RST, P["cqkv"]))
+    hip.attention(QKV[:Mv], AO[:Mv], w["nimg"], LV, H, False)
+    hip.attention(QKV[Mv:], AO[Mv:], w["ntxt"], LT, H, True)
+    hip.gemm(AO, P["wo"], X, bias=P["bo"], resid=X, resid_kind=hip.RESID_F32, fold_out=hip.FoldOut(LNO, CEN, PART))
+    hip.rowstat_finalize(PART, CEN, RST, M, D)
+    hip.gemm(LNO, P["wfc"], HID, bias=P["bfc"], act=hip.ACT_QUICKGELU, fold_in=hip.FoldIn(RST, P["cfc"]))
+    hip.gemm(HID, P["wpr"], X, bias=P["bpr"], resid=X, resid_kind=hip.RESID_F32, fold_out=hip.FoldOut(LNO, CEN, PART))
+    hip.rowstat_finalize(PART, CEN, RST, M, D)
+
+
 def layer(w, P):
+    if FOLD:
+        return layer_fold(w, P)
     X, LNO, QKV, AO, HID, Mv, M = w["X"], w["LNO"], w["QKV"], w["AO"], w["HID"], w["Mv"], w["M"]
     hip.layernorm_split(X, P["g"], P["b"], P["g"], P["b"], Mv, LNO, M)
     hip.gemm(LNO, P["wqkv"], QKV, bias=P["bqkv"])
@@ -66,12 +90,17 @@ if __name__ == "__main__":
     ap.add_argument("--mode", default="all", help="all | full | two (profiling: one schedule only, first cap)")
     ap.add_argument("--split", type=float, default=0.5, help="share of the samples in chain A")
     ap.add_argument("--delays", type=float, nargs="+", default=[0.0], help="chain B starts this many us late (a LayerNorm over scratch rows)")
+    ap.add_argument("--fold", action="store_true", help="the LayerNorm-fold layer form (batch a multiple of 512: whole 256-row tiles per half)")
+    ap.add_argument("--lt", type=int, default=77, help="rows per caption (34 ~ packed captions)")
     args = ap.parse_args()
+    FOLD = args.fold
+    LT = args.lt
     g = torch.Generator().manual_seed(0)
     P = dict(g=torch.ones(D).cuda(), b=torch.zeros(D).cuda())
     for name, n, k in (("qkv", 3 * D, D), ("o", D, D), ("fc", 4 * D, D), ("pr", D, 4 * D)):
         P["w" + name] = (torch.randn(n, k, generator=g) * 0.02).to(torch.bfloat16).cuda()
         P["b" + name] = (torch.randn(n, generator=g) * 0.02).cuda()
+        P["c" + name] = P["w" + name].float().sum(1).contiguous()
     B = args.batch
     full = make_chain(B, B, g)
     na = int(round(B * args.split / 4)) * 4
