@@ -15,12 +15,13 @@ import os
 import sys
 import time
 
-os.environ.setdefault("HSA_KERNARG_POOL_SIZE", str(16 << 20))      # before the first HIP call (msclip_amd/__init__.py says why)
-import torch                                                        # noqa: E402
-import torch.distributed as dist
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+import msclip_amd                                                   # noqa: E402
+
+msclip_amd.configure_runtime()                                      # HSA_KERNARG_POOL_SIZE, before the first HIP call (its docstring says why)
+import torch                                                        # noqa: E402
+import torch.distributed as dist                                    # noqa: E402
 
 GFLOP_PER_PAIR = {"b32-yfcc-msclips": 23.549, "b16-yfcc-msclips": 49.617,    # SURVEY.md s8(d), counted on the reference
                   "l16-fp8-msclips": 172.436,   # torch.utils.flop_counter on the reference built from experiments/model/l16-fp8-msclips.yaml (image 125.345 + text 47.091)

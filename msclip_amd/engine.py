@@ -1031,6 +1031,23 @@ class Engine:
         """Projection heads.  With gather=True the image features' all-gather is started as soon as they exist and
         runs on RCCL's stream while the text head computes (returns the gathered operands and the work handles)."""
         allI = allT = wi = wt = None
+        if gather and Bi and Bi == Bt and norm and hip.env_flag("MSCLIP_GATHER_PACKED"):
+            # SURVEY s8(e)'s form: ONE all-gather of the packed [B, 2, E] unit features after both heads (half the collectives,
+            # twice the payload; it cannot start before the text head).  The default below starts the image gather under the
+            # text head instead.  Behind a flag so that the first run on a real node can A/B the two (DESIGN.md s6).
+            E = self.E
+            if w.get("pk") is None or w["pk"].shape[0] != Bi:
+                w["pk"] = torch.zeros(Bi, 2 * E, dtype=torch.bfloat16, device=self.dev)
+                w["fvb_own"], w["ftb_own"] = w["fvb"], w["ftb"]
+            w["fvb"], w["ftb"] = w["pk"][:, :E], w["pk"][:, E:]          # the heads' L2 norm writes the halves in place
+            self._head_image(w, Bi, norm, compact)
+            self._head_text(w, Bt, norm, compact, Bi)
+            allpk, h = C.gather_rows_async(w["pk"], out=self._gather_buf(w, "allpk_buf", w["pk"]))
+            if h is not None:
+                h.wait()
+            return allpk[:, :E], allpk[:, E:]
+        if w.get("pk") is not None:                                      # (a previous call ran packed: back to the dense buffers)
+            w["fvb"], w["ftb"] = w["fvb_own"], w["ftb_own"]
         if Bi:
             self._head_image(w, Bi, norm, compact)
             if gather:

@@ -202,35 +202,37 @@ _COMPUTE = {}
 
 
 def off_default_stream(fn):
-    """Method decorator (the object carries `.dev`): while a torch.distributed process group exists, a caller that is on
-    the legacy default (null) stream is moved -- ONCE, for good: torch.cuda.set_stream on the calling thread, after the new
-    stream has been ordered behind the null stream -- to the per-device compute stream (highest priority, a hardware queue
-    of its own).  Why: with an RCCL communicator in the process every launch on the null stream pays for the legacy
-    default stream's implicit synchronisation with the communicator's streams.  ViT-B/32 training step, one-rank RCCL
-    group alive (tools/probes/reducer_probe.py): 110 -> 145 ms at batch 512 and 30 -> 55 ms at batch 32 on the null
-    stream, 110 / 33 ms on the compute stream; with the collectives issued, 112 ms.  Switching per call (in and out of
-    the null stream around every forward / backward / step) was measured too and is worse than not switching (167 ms), so
-    the move is permanent; everything the caller issues afterwards on its current stream stays ordered with this
-    library's work.  Pass-through without a process group, on a caller-chosen stream, or with MSCLIP_KEEP_DEFAULT_STREAM=1."""
+    """Method decorator (the object carries `.dev`) of the engine's / training step's entry points.  A pass-through unless the
+    host application opted in with MSCLIP_AUTO_COMPUTE_STREAM=1: then, while a torch.distributed process group exists, a caller
+    that is on the legacy default (null) stream is moved -- ONCE, for good: torch.cuda.set_stream on the calling thread, after
+    the new stream has been ordered behind the null stream -- to the per-device compute stream (use_compute_stream).
+    Why anyone would want that: with an RCCL communicator in the process every launch on the null stream pays for the legacy
+    default stream's implicit synchronisation with the communicator's streams.  ViT-B/32 training step, one-rank RCCL group
+    alive (tools/probes/reducer_probe.py): 110 -> 145 ms at batch 512 and 30 -> 55 ms at batch 32 on the null stream, 110 / 33 ms
+    on the compute stream.  Switching per call was measured too and is worse than not switching (167 ms), so the move is
+    permanent -- which is why it is the HOST's decision: bench.py and tools/train_synthetic.py call hip.use_compute_stream()
+    once at start-up (round 5; up to round 4 this decorator moved every caller implicitly)."""
     import functools
 
     @functools.wraps(fn)
     def wrapped(self, *args, **kwargs):
-        import torch.distributed as dist
-        dev = self.dev
-        if dev.type == "cuda" and dist.is_available() and dist.is_initialized() and not env_flag("MSCLIP_KEEP_DEFAULT_STREAM"):
-            cur = torch.cuda.current_stream(dev)
-            if cur == torch.cuda.default_stream(dev) and not torch.cuda.is_current_stream_capturing():
-                cs = compute_stream(dev)
-                cs.wait_stream(cur)
-                torch.cuda.set_stream(cs)
+        if env_flag("MSCLIP_AUTO_COMPUTE_STREAM"):
+            import torch.distributed as dist
+            dev = self.dev
+            if dev.type == "cuda" and dist.is_available() and dist.is_initialized():
+                cur = torch.cuda.current_stream(dev)
+                if cur == torch.cuda.default_stream(dev) and not torch.cuda.is_current_stream_capturing():
+                    use_compute_stream(dev)
         return fn(self, *args, **kwargs)
     return wrapped
 
 
 def use_compute_stream(device=None):
-    """Explicit, once-at-start-up form of what off_default_stream does implicitly: make the per-device compute stream the
-    calling thread's current stream (ordered behind whatever the previous current stream has queued).  Returns it."""
+    """Make the per-device compute stream (highest priority, a hardware queue of its own) the calling thread's current stream,
+    ordered behind whatever the previous current stream has queued; returns it.  Call once at start-up in a process that has
+    (or will have) an RCCL process group: launches on the legacy default stream synchronise implicitly with the communicator's
+    streams (off_default_stream's docstring has the numbers).  Everything the caller issues afterwards on its current stream
+    stays ordered with this library's work."""
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     cs = compute_stream(device)
     cs.wait_stream(torch.cuda.current_stream(device))

@@ -377,6 +377,35 @@ class TrainStep:
                 hip.cast_bf16(dX[r_lo:M], dY[r_lo:M])
                 return {id(bw): hip.colsum(dX[r0:r1]) for r0, r1, bw in groups}
 
+            # ---- the dgrad GEMMs' W operands: W^T of every projection (bf16 [K, N]; the weights changed in the last optimizer
+            # step), all of them up front on the lane stream with this library's transpose kernel, last block first, one event
+            # per block -- not four ATen transposed copies per block on the main queue (74 launches, 1.8 ms per step)
+            wts, wt_ready = {}, {}
+            if not (hip.env_flag("MSCLIP_WGRAD_SYNC") or gradgemm._ranks_share_a_gpu()):
+                cur_s, ln_s = torch.cuda.current_stream(dev), gradgemm.lane(dev)
+                ev0 = torch.cuda.Event()
+                ev0.record(cur_s)
+                ln_s.wait_event(ev0)
+                with torch.cuda.stream(ln_s):
+                    for i in reversed(range(e.n_layers)):
+                        for blk in (e.tblk[i], e.vblk[i]):
+                            if blk is not None and id(blk["w"]) not in wts:
+                                bw = blk["w"]
+                                wts[id(bw)] = tuple(hip.transpose_bf16(t, t.shape[0], t.shape[0]) for t in (bw.wpr, bw.wfc, bw.wo, bw.wqkv))
+                                for t in wts[id(bw)]:
+                                    t.record_stream(cur_s)
+                                wt_ready[id(bw)] = torch.cuda.Event()
+                                wt_ready[id(bw)].record(ln_s)
+
+            def w_t(bw, which):
+                """W^T of block weights bw: 0 c_proj [4D, D]^T.., 1 c_fc, 2 out_proj, 3 in_proj (packed: q rows scaled)."""
+                if id(bw) in wts:
+                    ev = wt_ready.pop(id(bw), None)
+                    if ev is not None:
+                        torch.cuda.current_stream(dev).wait_event(ev)
+                    return wts[id(bw)][which]
+                return (bw.wpr, bw.wfc, bw.wo, bw.wqkv)[which].t().contiguous()
+
             # ---- blocks, last to first
             for i in reversed(range(e.n_layers)):
                 L = sv["layers"][i]
@@ -398,16 +427,16 @@ class TrainStep:
                 for r0, r1, bw in groups:
                     if (r1 - r0) % 256 == 0:
                         # dh = (dY . W_proj) * QuickGELU'(h): the activation's derivative in the dgrad GEMM's epilogue
-                        hip.gemm(dY[r0:r1], bw.wpr.t().contiguous(), dh[r0:r1], resid=L["h"][r0:r1], resid_kind=hip.RESID_GELUGRAD)
+                        hip.gemm(dY[r0:r1], w_t(bw, 0), dh[r0:r1], resid=L["h"][r0:r1], resid_kind=hip.RESID_GELUGRAD)
                     else:
-                        dhid = _dgrad(dY[r0:r1], bw.wpr.t().contiguous())
+                        dhid = _dgrad(dY[r0:r1], w_t(bw, 0))
                         hip.quickgelu_bwd(L["h"][r0:r1], dhid, dh[r0:r1])
                 del hid
                 for r0, r1, bw in groups:
                     p = names[id(bw)]
                     wide_wgrad(p + ".mlp.c_fc.weight", dh[r0:r1], L["lno2"][r0:r1], r1 - r0, (4 * D, D))
                     grads[p + ".mlp.c_fc.bias"] = gradgemm.on_lane(lambda a=dh[r0:r1]: hip.colsum(a), dh)
-                    _dgrad(dh[r0:r1], bw.wfc.t().contiguous(), dlno[r0:r1])
+                    _dgrad(dh[r0:r1], w_t(bw, 1), dlno[r0:r1])
                 del dh
                 for r0, r1, b in segs:
                     pre = f"visual.transformer.resblocks.{i}" if b is e.vblk[i] else f"transformer.resblocks.{i}"
@@ -422,7 +451,7 @@ class TrainStep:
                     p = names[id(bw)]
                     wide_wgrad(p + ".attn.out_proj.weight", dY2[r0:r1], L["ao"][r0:r1], r1 - r0, (D, D))
                     grads[p + ".attn.out_proj.bias"] = bsum[id(bw)]
-                    _dgrad(dY2[r0:r1], bw.wo.t().contiguous(), dao[r0:r1])
+                    _dgrad(dY2[r0:r1], w_t(bw, 2), dao[r0:r1])
                 if e.vblk[i] is not None:
                     hip.attention_bwd(L["qkv"][:Mv], L["ao"][:Mv], dao[:Mv], dqkv[:Mv], Bi, e.Lv, e.heads, False)
                 if sv["cap"] is not None:
@@ -442,7 +471,7 @@ class TrainStep:
                         g[:D] *= 0.125
                         return g
                     grads[p + ".attn.in_proj_bias"] = gradgemm.on_lane(bias_q, dqkv)
-                    _dgrad(dqkv[r0:r1], bw.wqkv.t().contiguous(), dlno[r0:r1])
+                    _dgrad(dqkv[r0:r1], w_t(bw, 3), dlno[r0:r1])
                 for r0, r1, b in segs:
                     pre = f"visual.transformer.resblocks.{i}" if b is e.vblk[i] else f"transformer.resblocks.{i}"
                     dg, db = hip.layernorm_bwd(L["x_in"][r0 - r_lo:r1 - r_lo], dlno[r0:r1], b["ln1"].g, dX[r0:r1], r1 - r0)

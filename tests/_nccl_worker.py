@@ -35,6 +35,14 @@ def main():
     mine = slice(rank * B, (rank + 1) * B)
     logits = m(img[mine].cuda(), tok[mine].cuda())                    # gather=True from the yaml (GATHER_TENSORS)
     loss = m.contrastive_loss(img[mine].cuda(), tok[mine].cuda())
+    # SURVEY s8(e)'s single packed [B, 2, E] gather (behind a flag) against the default two per-modality gathers
+    os.environ["MSCLIP_GATHER_PACKED"] = "1"
+    logits_pk = m(img[mine].cuda(), tok[mine].cuda())
+    loss_pk = m.contrastive_loss(img[mine].cuda(), tok[mine].cuda())
+    assert m.engine()._ws[(B, B, "inference") if (B, B, "inference") in m.engine()._ws else (B, B)].get("pk") is not None
+    del os.environ["MSCLIP_GATHER_PACKED"]
+    logits_back = m(img[mine].cuda(), tok[mine].cuda())               # ... and back to the dense buffers
+    assert torch.equal(logits_back, logits)
     # training step: gradients averaged over the ranks through comm.GradReducer (small buckets: several collectives)
     from msclip_amd import train
     ts = train.TrainStep(m, lr=1e-4, bn="frozen")
@@ -49,7 +57,7 @@ def main():
     ts.backward()
     torch.cuda.synchronize()
     if rank == 0:
-        torch.save({"logits": logits.cpu(), "loss": float(loss), "train_loss": float(tl), "launched": launched,
+        torch.save({"logits": logits.cpu(), "loss": float(loss), "logits_packed_gather": logits_pk.cpu(), "loss_packed_gather": float(loss_pk), "train_loss": float(tl), "launched": launched,
                     "grads": kept, "n_grads": n_grads, "train_loss_after_step": float(tl2)}, out)
     dist.barrier()
     dist.destroy_process_group()

@@ -2,9 +2,15 @@ import json
 import os
 import sys
 
-import numpy as np
-import pytest
-import torch
+ROOT_ = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT_ not in sys.path:
+    sys.path.insert(0, ROOT_)
+import msclip_amd                                        # noqa: E402
+
+msclip_amd.configure_runtime()                           # the benchmark's runtime settings, before the first HIP call
+import numpy as np                                       # noqa: E402
+import pytest                                            # noqa: E402
+import torch                                             # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

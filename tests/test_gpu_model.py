@@ -495,6 +495,8 @@ def test_one_rank_rccl_collectives(gpu_device, tmp_path):
     img, tok = synth.synth_images(6, seed=91).cuda(), synth.synth_tokens(6, seed=92).cuda()
     assert torch.equal(got["logits"], m(img, tok).cpu())
     assert got["loss"] == float(m.contrastive_loss(img, tok))
+    # the single packed [B, 2, E] gather (MSCLIP_GATHER_PACKED=1): same features through strided views of one buffer
+    assert torch.equal(got["logits_packed_gather"], got["logits"]) and got["loss_packed_gather"] == got["loss"]
     ts = train.TrainStep(m, lr=1e-4, bn="frozen")
     assert got["train_loss"] == float(ts.forward(img, tok))
     full = ts.backward()
@@ -571,6 +573,7 @@ def test_two_ranks_on_one_gpu_over_gloo(gpu_device, tmp_path):
     ref_loss = float(m.contrastive_loss(img, tok))
     assert (got["logits"] - ref_logits).abs().max().item() <= 2e-2
     assert abs(got["loss"] - ref_loss) <= 2e-3
+    assert torch.equal(got["logits_packed_gather"], got["logits"]) and got["loss_packed_gather"] == got["loss"]      # one packed gather == two
     ts = train.TrainStep(m, lr=1e-4, bn="frozen")
     full_loss = float(ts.forward(img, tok))
     full = ts.backward()

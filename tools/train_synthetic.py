@@ -10,9 +10,11 @@ import os
 import sys
 import time
 
-import torch
-
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import msclip_amd                                        # noqa: E402
+
+msclip_amd.configure_runtime()                           # HSA_KERNARG_POOL_SIZE: before the first HIP call of the process
+import torch                                             # noqa: E402
 
 
 def main():
@@ -34,6 +36,10 @@ def main():
     torch.cuda.set_device(local)
     C.init_distributed("nccl")
     dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if dist.is_initialized():                              # a process group exists: leave the legacy default stream (once, explicitly)
+        from msclip_amd import hip
+        hip.use_compute_stream(dev)
     cfg = named_config(args.model)
     from bench import load_schema
     model = get_clip_model(cfg)
