@@ -466,6 +466,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const msclip_gemm
 // tile's buffer descriptor (read as zero).
 // ------------------------------------------------------------------------------------------------------------
 constexpr int PSLOTS = 10, PREG = 128 * 64;   // ring regions, bf16 elements per region
+#ifndef PP_NOEPI
+#define PP_NOEPI 0
+#endif
 
 __device__ __forceinline__ bf16x8 pp_ld(const void* p) { return *(const bf16x8*)p; }
 
@@ -927,6 +930,19 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a_i
       int lane_e;
       asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
       epi_stores = 0;
+#if PP_NOEPI
+      // probe builds only (tools/probes/build_ablations.sh noepi "-DPP_NOEPI=1"): the tile's epilogue is skipped -- no loads, no
+      // stores -- with the accumulators kept alive by a store that never happens: what is left of a launch is the main loop +
+      // tile transitions, i.e. launch time minus this = the epilogue's share (profiles/r05_gemm_epilogue_share.md)
+      {
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) sacc += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
+        if (sacc == 1.2345678e-30f) ((float*)a.zero)[lane_e] = sacc;
+      }
+#else
       if (F8) {
         // per-row operand scales: acc[ni][mi][r] = C[row mi*16 + lane%16][column ni*16 + 4*(lane/16) + r]
         const int er = lane_e & 15, eq = lane_e >> 4;
@@ -989,6 +1005,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a_i
       }
       else
         epilogue_generic16<TM, TN>(acc, a, vec, cm0 + wm, cn0 + wn, lane_e);
+#endif
     }
     if (grp) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");

@@ -43,3 +43,9 @@ for name, K in (("out", 768), ("proj", 3072)):
 rs = torch.empty(M, 2, device="cuda")
 print("finalize", round(t(lambda: hip.rowstat_finalize(part, cen, rs, M, D)), 1), "us;  ln_pair",
       round(t(lambda: hip.layernorm_split(X, b, b, b, b, 25600, xb, M)), 1), "us")
+# one line per launch form for profiles/: name, us, TFLOP/s
+import json
+flops = {"qkv": 2.0 * M * 2304 * D, "fc": 2.0 * M * 3072 * D, "out": 2.0 * M * D * D, "proj": 2.0 * M * D * 3072}
+print("JSON", json.dumps({"M": M, "lib": os.environ.get("MSCLIP_HIP_LIB") or "product",
+                          "us": {k: round(v, 1) for k, v in res.items()},
+                          "tflops": {k: round(flops[k.split()[0]] / v / 1e6, 1) for k, v in res.items()}}))
