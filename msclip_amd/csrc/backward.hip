@@ -10,6 +10,8 @@
 // tokens are rows of one matrix, so one wgrad GEMM contracts over image and text rows together.
 // Everything here is HBM-bound elementwise / reduction work: 16-byte accesses, one wave per row where a row reduction
 // is needed, fp32 statistics and accumulation, bf16 only for tensors that feed an MFMA GEMM.
+#include <mutex>
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/msclip_hip.h"
 
@@ -69,9 +71,53 @@ __global__ __launch_bounds__(256) void transpose_vec_kernel(const bf16_t* __rest
 
 // ---- out[n] (+)= sum_m x[m][n]: bias gradients and the second stage of the LayerNorm parameter gradients.
 // One block per 64 columns; 4 waves stride the rows, lanes own columns; fixed summation order (deterministic).
+// Single-launch form of the chunked sums (round 5: the training step issued 260 second-stage launches per step).  Every
+// workgroup of a column block publishes its chunk's partial row in `scratch` (release fence at device scope: the XCDs' L2s
+// are not coherent with each other), takes a ticket from the column block's counter, and the workgroup that draws the LAST
+// ticket folds all `chunks` partial rows -- in chunk order, whichever workgroup that is: the result is bitwise independent of
+// the arrival order -- and re-arms the counter.  ncols columns starting at col0; 256 threads.
+__device__ __forceinline__ void colsum_fold_last(const float* __restrict__ scratch, float* __restrict__ out, unsigned* counter,
+                                                 int chunks, int N, int col0, int ncols, int accumulate) {
+  __shared__ int last_flag;
+  __shared__ float fpart[4][256];
+  __threadfence();                                   // this thread's partial sums are visible device-wide ...
+  __syncthreads();                                   // ... for every thread of the workgroup, before the ticket is drawn
+  if (threadIdx.x == 0)
+    last_flag = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(chunks - 1);
+  __syncthreads();
+  if (!last_flag) return;
+  __threadfence();                                   // acquire: the other workgroups' partial rows, not a stale L2 line
+  for (int c0 = 0; c0 < ncols; c0 += 64) {           // 64 columns at a time: 4 waves stride the chunks, lanes own columns
+    const int cl = c0 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (cl < ncols && col0 + cl < N) {
+      const float* p = scratch + col0 + cl;
+      int m = w;
+      for (; m + 12 < chunks; m += 16) {
+        s0 += __builtin_nontemporal_load(p + (size_t)m * N);
+        s1 += __builtin_nontemporal_load(p + (size_t)(m + 4) * N);
+        s2 += __builtin_nontemporal_load(p + (size_t)(m + 8) * N);
+        s3 += __builtin_nontemporal_load(p + (size_t)(m + 12) * N);
+      }
+      for (; m < chunks; m += 4) s0 += __builtin_nontemporal_load(p + (size_t)m * N);
+    }
+    fpart[w][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (w == 0 && cl < ncols && col0 + cl < N) {
+      const int l = threadIdx.x;
+      const float t = (fpart[0][l] + fpart[1][l]) + (fpart[2][l] + fpart[3][l]);
+      float* o = out + col0 + cl;
+      *o = accumulate ? *o + t : t;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the ring's next round
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int ld, float* __restrict__ out, int M, int N,
-                                                     int accumulate, int rows_per_chunk) {
+                                                     int accumulate, int rows_per_chunk, float* __restrict__ final_out = nullptr,
+                                                     unsigned* __restrict__ counters = nullptr, int final_accumulate = 0) {
   // blockIdx.y = row chunk: chunk c sums rows [c * rows_per_chunk, ...) into out[c * N + n] (a [chunks, N] partial matrix
   // that a second launch with one chunk folds); one chunk: out[n] directly.
   __shared__ float part[4][64];
@@ -104,13 +150,16 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
     float* o = out + (size_t)blockIdx.y * N + n;
     *o = accumulate ? *o + t : t;
   }
+  if (counters) colsum_fold_last(out, final_out, counters + blockIdx.x, (int)gridDim.y, N, blockIdx.x * 64, 64, final_accumulate);
 }
 
 // bf16 matrices with 16-byte row pieces (N % 8 == 0, ld % 8 == 0): a lane owns 8 columns; `cpr` lanes (a power of two
 // <= 32) cover up to 256 columns of a row, the block's 256 / cpr row groups are folded through LDS.  Same chunking and
 // fixed summation order as the scalar kernel.
 __global__ __launch_bounds__(256) void colsum_bf16x8_kernel(const bf16_t* __restrict__ x, int ld, float* __restrict__ out,
-                                                            int M, int N, int accumulate, int rows_per_chunk, int cpr) {
+                                                            int M, int N, int accumulate, int rows_per_chunk, int cpr,
+                                                            float* __restrict__ final_out = nullptr,
+                                                            unsigned* __restrict__ counters = nullptr, int final_accumulate = 0) {
   __shared__ float part[256][9];
   const int tx = threadIdx.x & (cpr - 1), ty = threadIdx.x / cpr, ngrp = 256 / cpr;
   const int n = (blockIdx.x * cpr + tx) * 8;
@@ -140,6 +189,8 @@ __global__ __launch_bounds__(256) void colsum_bf16x8_kernel(const bf16_t* __rest
       *o = accumulate ? *o + t : t;
     }
   }
+  if (counters)
+    colsum_fold_last(out, final_out, counters + blockIdx.x, (int)gridDim.y, N, blockIdx.x * cpr * 8, cpr * 8, final_accumulate);
 }
 
 // Few rows, very many columns (the S <= 32 fp32 partials of a split-K weight gradient, 0.6-2.4 M columns): one thread per
@@ -615,6 +666,35 @@ extern "C" int msclip_cast_bf16_colsum(const float* x, int ldx, void* y, int ldy
   return msclip_launch_status();
 }
 
+// Ticket counters of the single-launch column sums: one ring of 2^18 zero words per device, allocated on first use.
+static bool colsum_two_stage() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("MSCLIP_COLSUM_TWO_STAGE");
+    v = e && e[0] == '1';
+  }
+  return v != 0;
+}
+static unsigned* colsum_counters(int n) {
+  constexpr int RING = 1 << 18, MAXDEV = 16;
+  static unsigned* ring[MAXDEV] = {};
+  static int next[MAXDEV] = {};
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV || n > RING) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!ring[dev]) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    (void)cs;
+    if (hipMalloc((void**)&ring[dev], RING * sizeof(unsigned)) != hipSuccess) { ring[dev] = nullptr; return nullptr; }
+    if (hipMemset(ring[dev], 0, RING * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return nullptr;
+  }
+  if (next[dev] + n > RING) next[dev] = 0;
+  unsigned* p = ring[dev] + next[dev];
+  next[dev] += n;
+  return p;
+}
+
 extern "C" int msclip_colsum(const void* x, int ld, int is_f32, float* out, int M, int N, int accumulate, float* scratch,
                              int chunks, void* stream) {
   if (!x || !out || M <= 0 || N <= 0 || ld < N || chunks < 1 || (chunks > 1 && !scratch)) return MSCLIP_EINVAL;
@@ -626,19 +706,24 @@ extern "C" int msclip_colsum(const void* x, int ld, int is_f32, float* out, int 
   }
   const int rpc = (M + chunks - 1) / chunks;
   float* first = chunks > 1 ? scratch : out;         // [chunks, N] partials, or the result itself
+  int cpr = 1;
+  while (cpr < 32 && cpr * 8 < N) cpr *= 2;
+  const bool wide = !is_f32 && !(N % 8) && !(ld % 8) && !((size_t)x % 16);
+  const int colblocks = wide ? (N + cpr * 8 - 1) / (cpr * 8) : (N + 63) / 64;
+  // chunks > 1: ONE launch -- the last workgroup of a column block folds the partial rows (colsum_fold_last); its ticket counters
+  // come from a per-device ring of zero-initialised words (a launch's counters are re-armed by the launch itself; a slot comes
+  // round again 2^18 / colblocks launches later).  MSCLIP_COLSUM_TWO_STAGE=1: the two-launch form of rounds 1-4.
+  unsigned* counters = chunks > 1 && !colsum_two_stage() ? colsum_counters(colblocks) : nullptr;
   if (is_f32)
-    hipLaunchKernelGGL(colsum_kernel<float>, dim3((N + 63) / 64, chunks), dim3(256), 0, st, (const float*)x, ld, first, M, N,
-                       chunks > 1 ? 0 : accumulate, rpc);
-  else if (!(N % 8) && !(ld % 8) && !((size_t)x % 16)) {
-    int cpr = 1;
-    while (cpr < 32 && cpr * 8 < N) cpr *= 2;
-    hipLaunchKernelGGL(colsum_bf16x8_kernel, dim3((N + cpr * 8 - 1) / (cpr * 8), chunks), dim3(256), 0, st, (const bf16_t*)x,
-                       ld, first, M, N, chunks > 1 ? 0 : accumulate, rpc, cpr);
-  }
+    hipLaunchKernelGGL(colsum_kernel<float>, dim3(colblocks, chunks), dim3(256), 0, st, (const float*)x, ld, first, M, N,
+                       chunks > 1 ? 0 : accumulate, rpc, out, counters, accumulate);
+  else if (wide)
+    hipLaunchKernelGGL(colsum_bf16x8_kernel, dim3(colblocks, chunks), dim3(256), 0, st, (const bf16_t*)x,
+                       ld, first, M, N, chunks > 1 ? 0 : accumulate, rpc, cpr, out, counters, accumulate);
   else
-    hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3((N + 63) / 64, chunks), dim3(256), 0, st, (const bf16_t*)x, ld, first, M,
-                       N, chunks > 1 ? 0 : accumulate, rpc);
-  if (chunks > 1)
+    hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(colblocks, chunks), dim3(256), 0, st, (const bf16_t*)x, ld, first, M,
+                       N, chunks > 1 ? 0 : accumulate, rpc, out, counters, accumulate);
+  if (chunks > 1 && !counters)
     hipLaunchKernelGGL(colsum_kernel<float>, dim3((N + 63) / 64, 1), dim3(256), 0, st, (const float*)scratch, N, out, chunks, N,
                        accumulate, chunks);
   return msclip_launch_status();

@@ -1050,8 +1050,8 @@ static int device_cus() {
 }
 
 // ---- kernel choice: ONE function decides, msclip_gemm launches what it says and msclip_gemm_variant reports it
-enum GemmVariant { GV_INVALID = 0, GV_STREAM, GV_PP, GV_DENSE128, GV_PPCONV, GV_CONV192, GV_CONV128 };
-static const char* const kVariantName[] = {"invalid", "stream", "pp", "dense128", "ppconv", "conv192", "conv128"};
+enum GemmVariant { GV_INVALID = 0, GV_STREAM, GV_PP, GV_DENSE128, GV_PPCONV, GV_CONV192, GV_CONV128, GV_DENSE192 };
+static const char* const kVariantName[] = {"invalid", "stream", "pp", "dense128", "ppconv", "conv192", "conv128", "dense192"};
 
 static GemmVariant pick_variant(const msclip_gemm_desc* d) {
   if (!d || !d->X || !d->W || !d->out || !d->zero) return GV_INVALID;
@@ -1104,6 +1104,7 @@ static GemmVariant pick_variant(const msclip_gemm_desc* d) {
                        big_tiles * ((d->M + 255) / 256) * 4 < (1ll << 32);
     if (pp_ok && d->resid_kind < 5 && (d->tile == 4 || (d->tile == 0 && big))) return GV_PP;     // ping-pong kernel (default for the projections)
     if (train_epi || fold_c || fold_p) return GV_INVALID;   // (offsets beyond the ping-pong kernel's 32-bit addressing)
+    if (d->tile == 6) return GV_DENSE192;      // 256 x 192 two-buffer tiles on dense operands (calibration of the fused QKV + attention kernel's main loop)
     return GV_DENSE128;                        // small problems, heads, logits (and tile 1)
   }
   // input channels a multiple of 64 (a K-tile stays inside one filter tap): the ping-pong kernel gathers the rows itself
@@ -1211,6 +1212,7 @@ extern "C" int msclip_gemm(const msclip_gemm_desc* d, void* stream) {
     case GV_PPCONV: hipLaunchKernelGGL((gemm_pp_kernel<1, false>), dim3(grid), dim3(512), 0, st, *d, nullptr, nullptr); break;
     case GV_DENSE128: launch_cfg<0, 128, 128, 2, 2>(d, st, 2); break;
     case GV_CONV192: launch_cfg<1, 256, 192, 4, 2>(d, st, 1); break;
+    case GV_DENSE192: launch_cfg<0, 256, 192, 4, 2>(d, st, 1); break;
     case GV_CONV128: launch_cfg<1, 128, 128, 2, 2>(d, st, 2); break;
     default: return MSCLIP_EINVAL;
   }

@@ -14,6 +14,9 @@
 
 namespace {
 
+#ifndef PP_QKV_TEMPORAL
+#define PP_QKV_TEMPORAL 0
+#endif
 constexpr int STG_BYTES = 4096;   // per-wave staging: 32 rows x 128 B, 16-byte chunks XOR-swizzled by (row & 7)
 
 // Interior tile of the ping-pong kernel.  Every 32x32 accumulator tile goes through the wave's 4-KiB staging block
@@ -448,6 +451,9 @@ __device__ __forceinline__ void epilogue_pack16(f32x4 (&acc)[2 * TN][2 * TM], co
     const size_t row = (size_t)(mw0 + tm * 32 + i * 8 + srow);
     // non-temporal: the tile leaves faster (QKV 262 -> 249 us, c_fc 378 -> 365 us; +0.7 % on the step), the fp32
     // stream of out_proj / c_proj stays cacheable for the LayerNorm that follows
+#if PP_QKV_TEMPORAL   // probe builds only: the q|k|v matrix of the packed step (199 MB) fits the 256 MB MALL -- does attention find it there?
+    if (ACT == 0) { if (n < a.N) *(AS1 u32x4*)((bf16_t*)outp + row * a.ldo + n) = v; } else
+#endif
     if (n < a.N) __builtin_nontemporal_store(v, (AS1 u32x4*)((bf16_t*)outp + row * a.ldo + n));
   };
 #pragma unroll

@@ -91,6 +91,37 @@ def test_transpose_cast_colsum_gelu(gpu_device):
     assert rel(dh, hf.grad) < 1e-2
 
 
+def test_colsum_single_launch_last_block_fold(gpu_device):
+    """Chunked column sums are ONE launch since round 5: the workgroup that draws a column block's last ticket folds the partial
+    rows in chunk order.  Against fp64 torch sums; bitwise repeatable over many launches (the arrival order of the workgroups
+    changes, the result does not); the same from two streams at once (ticket counters come from a ring: no sharing); the
+    accumulate form; and equal to the two-stage form's sum up to fp32 rounding."""
+    for mm, nn, dt in ((43264, 2304, BF), (43264, 768, torch.float32), (17664, 3072, BF), (9000, 104, BF), (3000, 27, BF),
+                       (2000, 1536, torch.float32), (800, 768, torch.float32)):
+        x = rnd(mm, nn, seed=11, dtype=dt)
+        ref = x.double().sum(0).float()
+        first = hip.colsum(x)
+        assert rel(first, ref) < 3e-6 * (8 if dt == BF else 1), (mm, nn, rel(first, ref))
+        for _ in range(20):
+            assert torch.equal(hip.colsum(x), first), (mm, nn)
+        acc = torch.full((nn,), 2.0, device="cuda")
+        hip.colsum(x, out=acc, accumulate=True)
+        assert rel(acc, ref + 2) < 3e-6 * (8 if dt == BF else 1)
+    # two streams: interleaved launches must not share ticket counters
+    a, b = rnd(43264, 768, seed=12, dtype=BF), rnd(30000, 3072, seed=13, dtype=BF)
+    ra, rb = hip.colsum(a), hip.colsum(b)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for _ in range(10):
+        with torch.cuda.stream(s1):
+            outs.append((hip.colsum(a), ra))
+        with torch.cuda.stream(s2):
+            outs.append((hip.colsum(b), rb))
+    torch.cuda.synchronize()
+    assert all(torch.equal(g, r) for g, r in outs)
+
+
 @pytest.mark.parametrize("M,C", [(65024, 768), (1000, 768), (37, 512), (5000, 1024)])
 def test_cast_with_column_sums(gpu_device, M, C):
     """msclip_cast_bf16_colsum: the bf16 copy of msclip_cast_bf16 (bitwise) and the fp32 column sums of the same pass, on a
