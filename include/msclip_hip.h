@@ -61,7 +61,7 @@ typedef struct msclip_gemm_desc {
   int rpg, radd, roff;   /* rpg > 0; use rpg = INT_MAX, radd = roff = 0 for the identity */
   void* out2;            /* optional second bf16 output: the epilogue value before the activation (NULL: none) */
   float out_scale;       /* out_kind 2 (e4m3 output, msclip_gemm_f8 only): stored value = fp8(epilogue value * out_scale), saturating */
-  int tile;              /* 0 = auto, 1 = 128x128 (4 waves), 4 = 256x256 ping-pong (what auto picks for large problems; dense X, or implicit conv with Cin % 64 == 0), 5 = streaming kernel with LDS-resident weights (K <= 192, or the 3x3 convolutions with 48 input channels; M >= 4096; auto picks it there), 6 = 256x192 two-buffer (implicit conv with N % 192 == 0), (7 and 8, the two epilogue-hiding kernels of rounds 2-3, were measured slower and retired in round 4: EINVAL) */
+  int tile;              /* 0 = auto, 1 = 128x128 (4 waves), 4 = 256x256 ping-pong (what auto picks for large problems; dense X, or implicit conv with Cin % 64 == 0), 5 = streaming kernel with LDS-resident weights (K <= 192, or the 3x3 convolutions with 48 input channels; M >= 4096; auto picks it there), 6 = 256x192 two-buffer (implicit conv with N % 192 == 0; on dense operands: the main loop a fused in_proj + attention kernel would run, kept for its calibration -- tools/probes/fused_calib.py), (7 and 8, the two epilogue-hiding kernels of rounds 2-3, were measured slower and retired in round 4: EINVAL) */
   int wg_cap;            /* 0 = the launch may take every CU; > 0: at most this many persistent workgroups (CUs) for the dense / implicit-conv MFMA kernels (round-4 probe of two half-batch chains on two streams, tools/probes/two_chain_probe.py: measured neutral, the engine leaves it 0) */
   /* ---- LayerNorm fold (dense ping-pong kernel only; M, seg_split and N multiples of 256; DESIGN.md "LayerNorm fold").
    * Consumer (a projection that follows a LayerNorm, M.py:1027-1028 + 204-219): X holds bf16 (x - center[m]) instead of the
@@ -299,7 +299,9 @@ int msclip_cast_bf16(const float* x, int ldx, void* y, int ldy, int M, int C, vo
 int msclip_cast_bf16_colsum(const float* x, int ldx, void* y, int ldy, int M, int C, float* part, int part_blocks, void* stream);
 
 /* out[n] (+)= sum_m x[m][n] (x bf16 or fp32): bias gradients, LayerNorm parameter gradients' second stage.  chunks > 1:
- * two deterministic stages through scratch [chunks, N] (row chunks in parallel, then folded); chunks == 1: one launch. */
+ * row chunks in parallel into scratch [chunks, N], folded in chunk order (deterministic) by the workgroup of each column block
+ * that finishes last -- ONE launch (ticket counters from a per-device ring; MSCLIP_COLSUM_TWO_STAGE=1: a second launch folds);
+ * chunks == 1: one launch straight into out. */
 int msclip_colsum(const void* x, int ld, int is_f32, float* out, int M, int N, int accumulate, float* scratch, int chunks,
                   void* stream);
 

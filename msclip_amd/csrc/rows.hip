@@ -504,6 +504,85 @@ __global__ __launch_bounds__(256) void adapter_gridrow_kernel(const float* __res
   }
 }
 
+// The same pass with a WORKGROUP per sample (round 5; MSCLIP_ADAPTER_SAMPLE=0: the grid-row kernel).  The grid-row kernel is
+// latency-bound: a wave walks its 7 tokens one after the other -- 30 loads, two LayerNorms (four wave reductions), two stores per
+// token, nothing overlapping -- with 108 VGPRs of filter rows keeping the occupancy at 2-3 waves per SIMD (86 us per launch at
+// batch 512 for 272 MB = 3.2 TB/s).  Here the nine filter rows + the bias sit in LDS (30 KB per workgroup, read as conflict-free
+// 16-byte pieces), the 8 waves of the workgroup take the sample's tokens round-robin, and all of a sample's neighbour re-reads
+// hit the CU's own L1 / the XCD's L2.  Same arithmetic (under -ffast-math the compiler orders the nine-tap sums per kernel:
+// last-bit differences against the grid-row kernel).
+template <int NV>
+__global__ __launch_bounds__(512) void adapter_sample_kernel(const float* __restrict__ xin, int ldx,
+                                                             const float* __restrict__ t, int ldt,
+                                                             const float* __restrict__ dww, const float* __restrict__ dwb,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float* __restrict__ xout, int ldo, int B, int L, int g,
+                                                             int usecls, float eps, const float* __restrict__ gamma1,
+                                                             const float* __restrict__ beta1, bf16_t* __restrict__ lno, int ldl,
+                                                             float* __restrict__ center, float* __restrict__ rowstat) {
+  constexpr int C = NV * 256;
+  __shared__ float4 wl[10][NV * 64];                 // taps 0..8, then the bias; [k][i * 64 + lane] = columns i*256 + lane*4 .. +3
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int idx = threadIdx.x; idx < 10 * NV * 64; idx += 512) {
+    const int k = idx / (NV * 64), j = idx - k * (NV * 64);
+    wl[k][j] = *(const float4*)((k < 9 ? dww + (size_t)k * C : dwb) + j * 4);
+  }
+  __syncthreads();
+  const int b = blockIdx.x;
+  for (int l = wave; l < L; l += 8) {
+    const size_t m = (size_t)b * L + l;
+    float4 v[NV];
+    if (l == 0) {
+      const float f = usecls ? 2.f : 1.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const float4 a = *(const float4*)(xin + m * ldx + i * 256 + lane * 4);
+        v[i] = make_float4(a.x * f, a.y * f, a.z * f, a.w * f);
+      }
+    } else {
+      const int p = l - 1, gy = p / g, gx = p - gy * g;
+      const float* tr = t + ((size_t)b * g * g + p) * ldt;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const float4 a = *(const float4*)(tr + i * 256 + lane * 4);
+        const float4 c = wl[9][i * 64 + lane];
+        v[i] = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
+      }
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int yy = gy + ky - 1;
+        if (yy < 0 || yy >= g) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int xx = gx + kx - 1;
+          if (xx < 0 || xx >= g) continue;
+          const float* nb = xin + ((size_t)b * L + 1 + yy * g + xx) * ldx;
+#pragma unroll
+          for (int i = 0; i < NV; ++i) {
+            const float4 a = *(const float4*)(nb + i * 256 + lane * 4);
+            const float4 ww = wl[ky * 3 + kx][i * 64 + lane];
+            v[i].x += a.x * ww.x; v[i].y += a.y * ww.y; v[i].z += a.z * ww.z; v[i].w += a.w * ww.w;
+          }
+        }
+      }
+    }
+    ln_core<NV>(v, gamma, beta, eps, lane);
+    store_row<NV>(v, xout, m, ldo, 1, lane);
+    if (gamma1) {
+      // the block's ln_1 from the registers the row is still in (see adapter_gridrow_kernel: the rounded fp32 values are pinned
+      // so that -ffast-math cannot fold the two LayerNorms into each other)
+#pragma unroll
+      for (int i = 0; i < NV; ++i) asm volatile("" : "+v"(v[i].x), "+v"(v[i].y), "+v"(v[i].z), "+v"(v[i].w));
+      const float mean = ln_core<NV>(v, gamma1, beta1, eps, lane);
+      store_row<NV>(v, lno, m, ldl, 0, lane);
+      if (lane == 0) {
+        center[m] = mean;
+        *(float2*)(rowstat + 2 * m) = make_float2(1.f, 0.f);
+      }
+    }
+  }
+}
+
 // y = x / ||x||_2 per row, fp32 math; writes fp32 and (optionally) a bf16 copy for the logits GEMM
 __global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ x, int ldx, float* __restrict__ of,
                                                      int ldf, bf16_t* __restrict__ ob, int ldb, int M, int E) {
@@ -636,12 +715,27 @@ extern "C" int msclip_fill_cls(const float* cls, const float* pos, float* x, int
   return msclip_launch_status();
 }
 
+// workgroup-per-sample form of the adapter pass (default): 16-byte accesses, C <= 1024 (40 KB of filter rows in LDS)
+// (measured, tools/probes/adapter_bench.py: 7 x 7 grids 84 -> 73 us at batch 512, 167 -> 152 us at batch 1024; 14 x 14 grids --
+//  197 tokens per workgroup, one workgroup per CU at batch 256 -- 165 -> 183 us: they keep the grid-row kernel)
+static bool adapter_sample_form(int C, int L, int ldx, int ldt, int ldo) {
+  const char* e = getenv("MSCLIP_ADAPTER_SAMPLE");
+  if (e && e[0] == '0') return false;
+  if (!(C <= 1024 && !((ldx | ldt | ldo) & 3))) return false;
+  return L <= 64 || (e && e[0] == '1');              // "1" forces it (tests cover the large grids with it)
+}
+
 extern "C" int msclip_adapter_combine_ln(const float* xin, int ldx, const float* t, int ldt, const float* dww,
                                          const float* dwb, const float* gamma, const float* beta, float* xout,
                                          int ldo, int B, int L, int g, int C, int usecls, float eps, void* stream) {
   if (!xin || !t || !dww || !dwb || !gamma || !beta || !xout || xin == xout || L != g * g + 1) return MSCLIP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const char* perrow = getenv("MSCLIP_ADAPTER_PER_TOKEN");       // the wave-per-token kernel, for cross-checks only
+  if (!(perrow && perrow[0] == '1') && adapter_sample_form(C, L, ldx, ldt, ldo)) {
+    NV_LAUNCH(C, adapter_sample_kernel, dim3(B), dim3(512), st, xin, ldx, t, ldt, dww, dwb, gamma, beta, xout, ldo, B, L, g, usecls, eps,
+              (const float*)nullptr, (const float*)nullptr, (bf16_t*)nullptr, 0, (float*)nullptr, (float*)nullptr)
+    return msclip_launch_status();
+  }
   if (!(perrow && perrow[0] == '1')) {
     const dim3 grid((B * g + WPB - 1) / WPB), blk(256);
     NV_LAUNCH(C, adapter_gridrow_kernel, grid, blk, st, xin, ldx, t, ldt, dww, dwb, gamma, beta, xout, ldo, B, L, g, usecls, eps,
@@ -661,6 +755,11 @@ extern "C" int msclip_adapter_combine_ln_stats(const float* xin, int ldx, const 
   if (!xin || !t || !dww || !dwb || !gamma || !beta || !xout || xin == xout || L != g * g + 1 || !gamma1 || !beta1 || !lno ||
       !center || !rowstat || (ldl & 3))
     return MSCLIP_EINVAL;
+  if (adapter_sample_form(C, L, ldx, ldt, ldo)) {
+    NV_LAUNCH(C, adapter_sample_kernel, dim3(B), dim3(512), (hipStream_t)stream, xin, ldx, t, ldt, dww, dwb, gamma, beta, xout, ldo, B, L,
+              g, usecls, eps, gamma1, beta1, (bf16_t*)lno, ldl, center, rowstat)
+    return msclip_launch_status();
+  }
   const dim3 grid((B * g + WPB - 1) / WPB), blk(256);
   NV_LAUNCH(C, adapter_gridrow_kernel, grid, blk, (hipStream_t)stream, xin, ldx, t, ldt, dww, dwb, gamma, beta, xout, ldo, B, L, g,
             usecls, eps, gamma1, beta1, (bf16_t*)lno, ldl, center, rowstat)

@@ -461,12 +461,14 @@ def test_fill_cls_adapter_l2norm(gpu_device):
     assert float(packed[:, 0].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("kernel", ["gridrow", "per_token"])
+@pytest.mark.parametrize("kernel", ["sample", "gridrow", "per_token"])
 @pytest.mark.parametrize("B,g_,C,usecls", [(5, 7, 768, True), (3, 14, 768, False), (2, 1, 768, True), (9, 3, 256, True)])
 def test_adapter_combine_ln(gpu_device, monkeypatch, B, g_, C, usecls, kernel):
-    """Lateral adapter bottom half + sum + LayerNorm (M.py:1763-1777): the wave-per-grid-row kernel (filters in
-    registers) and the wave-per-token one, grids 1 / 3 / 7 / 14, both class-token modes."""
+    """Lateral adapter bottom half + sum + LayerNorm (M.py:1763-1777): the workgroup-per-sample kernel (filters in LDS: the
+    default), the wave-per-grid-row kernel (filters in registers) and the wave-per-token one, grids 1 / 3 / 7 / 14, both
+    class-token modes."""
     monkeypatch.setenv("MSCLIP_ADAPTER_PER_TOKEN", "1" if kernel == "per_token" else "0")
+    monkeypatch.setenv("MSCLIP_ADAPTER_SAMPLE", "1" if kernel == "sample" else "0")
     L = g_ * g_ + 1
     x, t = rnd(B * L, C, seed=61), rnd(B * g_ * g_, C, seed=62)
     dww, dwb = rnd(9, C, seed=63, scale=0.3), rnd(C, seed=64, scale=0.1)
@@ -951,10 +953,12 @@ def test_layernorm_fold_producer_second_residual_stream(gpu_device):
         hip.gemm(a, w, out, bias=b, resid=xa, resid_kind=hip.RESID_F32, fold_out=hip.FoldOut(xb, cen.clone(), part, resid2=out, split=300))
 
 
+@pytest.mark.parametrize("form", ["sample", "gridrow"])
 @pytest.mark.parametrize("B,g_,C,usecls", [(5, 7, 768, True), (3, 14, 768, False), (2, 16, 1024, True)])
-def test_adapter_combine_ln_stats(gpu_device, B, g_, C, usecls):
+def test_adapter_combine_ln_stats(gpu_device, monkeypatch, B, g_, C, usecls, form):
     """msclip_adapter_combine_ln_stats = msclip_adapter_combine_ln followed by msclip_layernorm_stats of its output (the second
-    LayerNorm runs on the fp32 values the first one stores)."""
+    LayerNorm runs on the fp32 values the first one stores); both launch forms (workgroup per sample / wave per grid row)."""
+    monkeypatch.setenv("MSCLIP_ADAPTER_SAMPLE", "1" if form == "sample" else "0")
     L = g_ * g_ + 1
     x, t = rnd(B * L, C, seed=61), rnd(B * g_ * g_, C, seed=62)
     dww, dwb = rnd(9, C, seed=63, scale=0.3), rnd(C, seed=64, scale=0.1)
@@ -975,6 +979,32 @@ def test_adapter_combine_ln_stats(gpu_device, B, g_, C, usecls):
     a, b = lno[:B * L].float(), l0.float()
     assert float(((a - b).abs() / b.abs().clamp_min(2.0 ** -6)).max()) <= 2.0 ** -7 and float((a != b).float().mean()) < 5e-3
     assert bool(torch.isnan(xa[B * L:]).all()) and bool(torch.isnan(lno[B * L:].float()).all()) and bool(torch.isnan(cen[B * L:]).all())
+
+
+def test_adapter_sample_form_against_the_gridrow_form(gpu_device, monkeypatch):
+    """The workgroup-per-sample adapter kernel does the grid-row kernel's arithmetic in the same order: the fp32 stream bitwise."""
+    B, g_, C = 37, 7, 768
+    L = g_ * g_ + 1
+    x, t = rnd(B * L, C, seed=71), rnd(B * g_ * g_, C, seed=72)
+    dww, dwb = rnd(9, C, seed=73, scale=0.3), rnd(C, seed=74, scale=0.1)
+    ga, be = 1.0 + rnd(C, seed=75, scale=0.1), rnd(C, seed=76, scale=0.1)
+    g1, b1 = 1.0 + rnd(C, seed=77, scale=0.1), rnd(C, seed=78, scale=0.1)
+    res = {}
+    for form in ("1", "0"):
+        monkeypatch.setenv("MSCLIP_ADAPTER_SAMPLE", form)
+        xa, lno = torch.empty(B * L, C, device="cuda"), torch.empty(B * L, C, dtype=BF, device="cuda")
+        cen, rs = torch.empty(B * L, device="cuda"), torch.empty(B * L, 2, device="cuda")
+        hip.adapter_combine_ln_stats(x, t, dww, dwb, ga, be, xa, g1, b1, lno, cen, rs, B, L, g_, True)
+        plain = torch.empty(B * L, C, device="cuda")
+        hip.adapter_combine_ln(x, t, dww, dwb, ga, be, plain, B, L, g_, True)
+        res[form] = (xa, lno.float(), cen, rs, plain)
+    (xa1, l1, c1, r1, p1), (xa0, l0, c0, r0, p0) = res["1"], res["0"]
+    # within a form the fp32 stream of the stats launch is bitwise the plain launch's; across forms the same sums are ordered per
+    # kernel under -ffast-math: last-bit differences of the fp32 stream and the statistics, rare one-ulp differences of the bf16 operand
+    assert torch.equal(xa1, p1) and torch.equal(xa0, p0) and torch.equal(r1, r0)
+    close(xa1, xa0, 5e-6, 5e-6)
+    close(c1, c0, 5e-6, 5e-6)
+    assert float(((l1 - l0).abs() / l0.abs().clamp_min(2.0 ** -6)).max()) <= 2.0 ** -7 and float((l1 != l0).float().mean()) < 5e-3
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
