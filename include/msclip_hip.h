@@ -177,6 +177,48 @@ int msclip_embed_tokens_packed(const long long* tokens, const float* emb, const 
 int msclip_attention_varlen(const void* qkv, void* out, const int* cu, int nsamples, int Lmax, int heads, int ldq, int ldo,
                             int causal, int pad_rows, void* stream);
 
+/* ---- Fused in_proj + attention (BASELINE.json north_star: "fused QKV-projection + SDPA"; replaces F.linear with in_proj_weight /
+ * in_proj_bias, M.py:612, and the attention core of M.py:707-738 with the causal mask of :2965-2971 for captions) in ONE kernel:
+ * q|k|v never reach HBM.  Opt-in (engine: MSCLIP_FUSED_QKV_ATTN=1): measured slower than the ping-pong GEMM + attention launches
+ * (DESIGN.md s0 item 4).  A tile = whole samples, at most 256 token rows, x one head's 192 columns [q | k | v]:
+ *   W      bf16 [heads * 192, ldw]: the packed in_proj weight re-ordered head-major, rows h * 192 + {0..63: q_h (pre-scaled by
+ *          head_dim^-0.5), 64..127: k_h, 128..191: v_h}; bias (and csum) fp32 [heads * 192] in the same order, 16-byte aligned;
+ *   cu     [nsamples + 1] first row of every sample in X / out (ascending; cu[nsamples] = end of the live rows);
+ *   rowseg [M][2] (first row, end row) of the sample that owns each live row; tile_first [ntiles + 1] first sample of every tile
+ *          (both from msclip_qkvattn_tables); ntiles_dev (optional) = device copy of the tile count, read by the kernel when the
+ *          host does not know it (packed captions);
+ *   rows of samples that start at or behind causal_from_row attend causally (INT_MAX: none; 0: all);
+ *   LayerNorm fold (optional, as msclip_gemm's consumer form): rowstat [M][2], csum; rows >= seg_split take W2 / bias2 / csum2.
+ * out bf16 [M, ldo] receives the attention output (heads concatenated) of the live rows; samples of up to 96 rows. */
+typedef struct msclip_qkvattn_desc {
+  const void* X;
+  const void* W;
+  const void* zero;      /* >= 16 bytes of zeros */
+  void* out;
+  const float* bias;
+  const int* cu;
+  const int* tile_first;
+  const int* rowseg;
+  const int* ntiles_dev; /* or NULL: ntiles below */
+  int M, K, heads, ntiles;
+  int ldx, ldw, ldo;
+  int causal_from_row;
+  const float* rowstat;  /* NULL: X holds the LayerNorm output itself */
+  const float* csum;
+  const void* W2;        /* NULL: one row segment */
+  const float* bias2;
+  const float* csum2;
+  int seg_split;
+} msclip_qkvattn_desc;
+
+int msclip_qkv_attention(const msclip_qkvattn_desc* desc, void* stream);
+
+/* rowseg / tile_first / *ntiles of msclip_qkv_attention from the samples' first rows cu [nsamples + 1]: whole samples packed
+ * greedily into tiles of at most 256 rows, no tile straddling sample index split_sample (the image / text boundary; <= 0 or
+ * >= nsamples: none).  *ntiles = -1 when more than max_tiles tiles would be needed (tile_first holds max_tiles + 1 ints). */
+int msclip_qkvattn_tables(const int* cu, int nsamples, int split_sample, int* rowseg, int* tile_first, int* ntiles, int max_tiles,
+                          void* stream);
+
 /* msclip_attention_lastq over packed captions: sample b's keys are the rows row_base + cu[b] .. row_base + cu[b+1] of qkv
  * (all of them: the query is the caption's last live row, the EOT position). */
 int msclip_attention_lastq_varlen(const void* q, int ldqc, const void* qkv, int ldq, void* out, int ldo, int nsamples, int Lmax,

@@ -7,7 +7,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffast-math -fno-finite-math-o
 mkdir -p build
 objs=()
 pids=()
-for f in gemm gemm_small attention attention_bwd backward backward_conv rows conv front loss api; do
+for f in gemm gemm_small attention qkv_attention attention_bwd backward backward_conv rows conv front loss api; do
   if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ gemm_epilogue.h -nt build/$f.o ] || [ ../../include/msclip_hip.h -nt build/$f.o ]; then
     $HIPCC $FLAGS -c $f.hip -o build/$f.o &
     pids+=($!)

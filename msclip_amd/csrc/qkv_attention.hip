@@ -1,0 +1,396 @@
+// Fused in_proj (q|k|v projection) + scaled-dot-product attention: one kernel, q|k|v never reach HBM.
+// Replaces F.linear(x, in_proj_weight, in_proj_bias) + the bmm / mask / softmax / bmm of Attention_CUST
+// (reference lib/models/clip_openai_pe_res_v1.py:612, 707-738; causal mask of :2965-2971 for the captions).
+//
+// What BASELINE.json's north_star names ("fused QKV-projection + SDPA"), built in round 5 as an OPT-IN path
+// (MSCLIP_FUSED_QKV_ATTN=1 in the engine): measured slower than the ping-pong GEMM + attention launches it replaces
+// (DESIGN.md s0 item 4 has the numbers), because the attention needs one head's q|k|v of whole samples in ONE workgroup:
+//   * a tile is 256 token rows (whole samples: 5 images of 50 tokens, or a run of packed captions) x 192 columns (one head's
+//     q | k | v: the packed weight is re-ordered head-major), contracted over K = width by the two-buffer 256 x 192 main loop
+//     of gemm.hip's gemm_kernel (8 waves 4 x 2, 32x32x16 MFMAs, LDS-DMA of slab s+1 between the MFMAs of slab s);
+//   * the tile's accumulators (+ bias, or the LayerNorm fold's rstd / mean / column-sum form) are written to LDS as bf16 --
+//     Q|K rows of 272 B, V rows of 136 B: 104 KB, the consumed operand buffer plus the 48 KB beside it, while the other buffer
+//     already holds the next tile's first K-slab -- and the ping-pong kernel's LDS ring has no room for that;
+//   * wave w then attends the tile's query rows 32 w .. 32 w + 31 against the key tiles that its rows' samples span, with a
+//     block-diagonal (+ causal) mask from a per-row (sample start, sample end) table: S^T = K Q^T and O^T = V^T P^T on
+//     32x32x16 MFMAs as in attention.hip, V^T fragments straight from the row-major V rows by ds_read_b64_tr_b16.
+// Rows of a tile behind its last whole sample belong to the next tile: computed, never stored.
+#include <stdlib.h>
+#include "common.h"
+#include "../../include/msclip_hip.h"
+
+namespace {
+
+constexpr int BK = 64, BM = 256, BN = 192, NW = 8, NTH = 512;
+constexpr int TM = 2, TN = 3;                      // 32 x 32 accumulator tiles per wave: 64 rows x 96 columns
+constexpr int XI = BM * 8 / NTH, WI = BN * 8 / NTH;   // LDS-DMA pieces per lane and K-slab: 4 + 3
+constexpr int NPC = XI + WI;
+constexpr int BUF_BYTES = (BM + BN) * BK * 2;      // 57 344
+constexpr int EXTRA_BYTES = 49152;                 // between the two operand buffers: [buf 0 | extra | buf 1] = 160 KB
+constexpr int QK_STRIDE = 272, V_STRIDE = 136;     // bytes per staged row (Q|K: 128 bf16 + 16 B pad; V: 64 bf16 + 8 B pad)
+constexpr int QK_BYTES = BM * QK_STRIDE;           // 69 632
+static_assert(QK_BYTES + BM * V_STRIDE <= BUF_BYTES + EXTRA_BYTES, "q|k|v staging = one operand buffer + the extra region");
+constexpr int MAXKT = 5;                           // key tiles a 32-query tile can span: samples <= 96 rows -> <= 127 rows unaligned
+
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4v;
+
+__device__ __forceinline__ bf16x8 ld_tr8(const char* p0, const char* p1) {   // tokens T0..T0+3 (p0) and T0+8..T0+11 (p1) of this lane's channel
+  const bf16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((AS3 bf16x4v*)p0);
+  const bf16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((AS3 bf16x4v*)p1);
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__global__ __launch_bounds__(NTH) void qkv_attn_kernel(const msclip_qkvattn_desc a) {
+  __shared__ __attribute__((aligned(1024))) char lds[2 * BUF_BYTES + EXTRA_BYTES];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = a.heads;
+  const int ntiles = a.ntiles_dev ? __builtin_amdgcn_readfirstlane(*a.ntiles_dev) : a.ntiles;
+  const int nwork = ntiles * H;
+  const int Mtot = a.M;
+  const int nk = a.K / BK;
+
+  const bf16_t* __restrict__ X = (const bf16_t*)a.X;
+  const bf16_t* __restrict__ Z = (const bf16_t*)a.zero;
+  auto buf = [&](int b) -> bf16_t* { return (bf16_t*)(lds + (b ? BUF_BYTES + EXTRA_BYTES : 0)); };
+
+  // work item -> (tile, head): XCD-aware bijective remap (consecutive ids -- the heads of one tile, which share its X rows --
+  // run on one XCD), as gemm_kernel's tile_origin
+  auto work_origin = [&](int t, int& m0, int& rows, int& head) {
+    const int q = nwork >> 3, r = nwork & 7, x = t & 7;
+    const int id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (t >> 3);
+    const int tile = id / H;
+    head = id - tile * H;
+    const int s0 = a.tile_first[tile], s1 = a.tile_first[tile + 1];
+    m0 = a.cu[s0];
+    rows = a.cu[s1] - m0;
+  };
+
+  const int pc = lane & 7;
+  const int lc = pc ^ ((lane >> 4) | ((wave & 1) << 2));
+  const int rsub = lane >> 3;
+  const bf16_t* xrow[XI];
+  const bf16_t* wrow[WI];
+  auto setup_rows = [&](int m0, int head) {
+    const bf16_t* Wseg = (const bf16_t*)((a.W2 && m0 >= a.seg_split) ? a.W2 : a.W);
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+      const int n = head * BN + (i * NW + wave) * 8 + rsub;
+      wrow[i] = Wseg + (size_t)n * a.ldw + lc * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      const int m = m0 + (i * NW + wave) * 8 + rsub;
+      xrow[i] = (m < Mtot) ? X + (size_t)m * a.ldx + lc * 8 : nullptr;
+    }
+  };
+  auto slab_sources = [&](int kt, const bf16_t* (&src)[NPC]) {
+#pragma unroll
+    for (int i = 0; i < XI; ++i) src[i] = xrow[i] ? xrow[i] + kt * BK : Z;
+#pragma unroll
+    for (int i = 0; i < WI; ++i) src[XI + i] = wrow[i] + kt * BK;
+  };
+  auto piece_dst = [&](int b, int j) -> bf16_t* {
+    return j < XI ? buf(b) + (j * NW + wave) * 8 * BK : buf(b) + BM * BK + ((j - XI) * NW + wave) * 8 * BK;
+  };
+
+  const int wm = (wave >> 1) * (TM * 32), wn = (wave & 1) * (TN * 32);
+  const int fr = lane & 31, fsw = (lane >> 1) & 7, fhi = lane >> 5;
+
+  int t = blockIdx.x;
+  int m0 = 0, rows = 0, head = 0;
+  if (t < nwork) {
+    work_origin(t, m0, rows, head);
+    setup_rows(m0, head);
+    const bf16_t* src[NPC];
+    slab_sources(0, src);
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) glds16(src[j], piece_dst(0, j));
+  }
+  int it = 0;
+  bool landed = false;
+  for (; t < nwork; t += gridDim.x) {
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int cm0 = m0, crows = rows, chead = head;
+    const bool has_next = t + (int)gridDim.x < nwork;
+    for (int kt = 0; kt < nk; ++kt, ++it) {
+      if (kt == 0 && landed) {
+        __builtin_amdgcn_s_barrier();              // orders every wave's staging reads before the LDS-DMA into that region
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+      const bf16_t* src[NPC];
+      const bool last = kt + 1 == nk;
+      if (last && has_next) {
+        work_origin(t + gridDim.x, m0, rows, head);
+        setup_rows(m0, head);
+      }
+      if (!last || has_next) {
+        slab_sources(last ? 0 : kt + 1, src);
+      } else {
+#pragma unroll
+        for (int j = 0; j < NPC; ++j) src[j] = Z;
+      }
+      const int nb = (it + 1) & 1;
+      const bf16_t* xs = buf(it & 1) + (wm + fr) * BK;
+      const bf16_t* ws = buf(it & 1) + BM * BK + (wn + fr) * BK;
+      bf16x8 wf[2][TN], xf[2][TM];
+      {
+        const int ph = (fhi ^ fsw) * 8;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) wf[0][i] = *(const bf16x8*)(ws + i * 32 * BK + ph);
+#pragma unroll
+        for (int j = 0; j < TM; ++j) xf[0][j] = *(const bf16x8*)(xs + j * 32 * BK + ph);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        if (kk < 3) {
+          const int ph = (((kk + 1) * 2 + fhi) ^ fsw) * 8;
+#pragma unroll
+          for (int i = 0; i < TN; ++i) wf[(kk + 1) & 1][i] = *(const bf16x8*)(ws + i * 32 * BK + ph);
+#pragma unroll
+          for (int j = 0; j < TM; ++j) xf[(kk + 1) & 1][j] = *(const bf16x8*)(xs + j * 32 * BK + ph);
+        }
+        constexpr int NV0 = NPC / 4, NVR = NPC % 4;
+        const int nvk = NV0 + (kk < NVR ? 1 : 0);
+        const int pv0 = kk * NV0 + (kk < NVR ? kk : NVR);
+#pragma unroll
+        for (int v = 0; v < NV0 + 1; ++v)
+          if (v < nvk) glds16(src[pv0 + v], piece_dst(nb, pv0 + v));
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int j = 0; j < TM; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk & 1][i], xf[kk & 1][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < TM * TN; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (kk < 3 && q < TM + TN) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          if (q >= TM * TN - nvk) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                               // the consumed buffer (it - 1) & 1 is free; the next tile's first slab has landed in it & 1
+    landed = true;
+
+    // ---- staging: q | k | v of this tile and head as bf16 rows in [consumed buffer | extra] (buffer 0) or [extra | buffer 1]
+    char* stg = lds + (((it + 1) & 1) ? BUF_BYTES : 0);
+    char* qk = stg;
+    char* vv = stg + QK_BYTES;
+    {
+      const bool seg2 = a.W2 && cm0 >= a.seg_split;
+      const float* bias = seg2 ? a.bias2 : a.bias;
+      const float* csum = a.rowstat ? (seg2 ? a.csum2 : a.csum) : nullptr;
+      float rs[TM], sh[TM];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const int m = cm0 + wm + tm * 32 + fr;
+        if (a.rowstat && m < Mtot) {
+          const float2 st = *(const float2*)(a.rowstat + 2 * (size_t)m);
+          rs[tm] = st.x; sh[tm] = st.y;
+        } else {
+          rs[tm] = 1.f; sh[tm] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int cb = wn + tn * 32;               // first column of this 32-column block within the head's 192 (wave-uniform)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int c = cb + g * 8 + fhi * 4;
+          const float4 b4 = *(const float4*)(bias + chead * BN + c);
+          float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (csum) c4 = *(const float4*)(csum + chead * BN + c);
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm) {
+            const int row = wm + tm * 32 + fr;
+            const float v0 = acc[tn][tm][g * 4 + 0] * rs[tm] + (b4.x - sh[tm] * c4.x);
+            const float v1 = acc[tn][tm][g * 4 + 1] * rs[tm] + (b4.y - sh[tm] * c4.y);
+            const float v2 = acc[tn][tm][g * 4 + 2] * rs[tm] + (b4.z - sh[tm] * c4.z);
+            const float v3 = acc[tn][tm][g * 4 + 3] * rs[tm] + (b4.w - sh[tm] * c4.w);
+            uint2 o;
+            o.x = pack_bf16x2(v0, v1);
+            o.y = pack_bf16x2(v2, v3);
+            if (cb < 128) *(uint2*)(qk + row * QK_STRIDE + c * 2) = o;
+            else *(uint2*)(vv + row * V_STRIDE + (c - 128) * 2) = o;
+          }
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- attention: wave w takes the tile's query rows 32 w .. 32 w + 31
+    const int q0 = wave * 32;
+    if (q0 < crows) {
+      const int qrow = min(q0 + fr, crows - 1);    // clamped: rows behind the tile's last whole sample are never stored
+      const int2 seg = *(const int2*)(a.rowseg + 2 * (size_t)(cm0 + qrow));
+      const bool causal = seg.x >= a.causal_from_row;
+      const int lo = seg.x - cm0;
+      const int hi = causal ? qrow + 1 : seg.y - cm0;
+      const int klo = __builtin_amdgcn_readfirstlane(lo);
+      const int khi = __builtin_amdgcn_readlane(hi, 31);
+      const int kt0 = klo >> 5;
+      const int nkt = min(((khi + 31) >> 5) - kt0, MAXKT);
+      bf16x8 qf[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const bf16x8*)(qk + (q0 + fr) * QK_STRIDE + (kk * 2 + fhi) * 16);
+      f32x16 s[MAXKT];
+#pragma unroll
+      for (int j = 0; j < MAXKT; ++j) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[j][r] = 0.f;
+        if (j < nkt) {
+          const char* kr = qk + ((kt0 + j) * 32 + fr) * QK_STRIDE + 128;
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            const bf16x8 kf = *(const bf16x8*)(kr + (kk * 2 + fhi) * 16);
+            s[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[j], 0, 0, 0);
+          }
+        }
+      }
+      float mx = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < MAXKT; ++j)
+        if (j < nkt) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = (kt0 + j) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
+            const bool ok = key >= lo && key < hi;
+            s[j][r] = ok ? s[j][r] : -INFINITY;
+            mx = fmaxf(mx, s[j][r]);
+          }
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < MAXKT; ++j)
+        if (j < nkt) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float p = __expf(s[j][r] - mx);
+            s[j][r] = p;
+            sum += p;
+          }
+        }
+      sum += __shfl_xor(sum, 32, 64);
+      const float inv = 1.f / sum;
+      f32x16 o[2];
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+      // V^T fragment of k-step (key0 .. key0 + 15): lane (d = dt*32 + lane%32, half fhi) needs keys key0 + 4 fhi + {0..3, 8..11};
+      // a 16-lane group reads a 4-token x 16-channel block, lane i supplying (token i / 4, channels 4 (i % 4) ..) and receiving channel i
+      const int li = lane & 15, dh = (lane >> 4) & 1;
+      const char* vlane = vv + (4 * fhi + (li >> 2)) * V_STRIDE + (16 * dh + 4 * (li & 3)) * 2;
+#pragma unroll
+      for (int j = 0; j < MAXKT; ++j)
+        if (j < nkt) {
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            bf16x8 pf;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pf[e] = (__bf16)s[j][half * 8 + e];
+            const char* vk = vlane + ((kt0 + j) * 32 + half * 16) * V_STRIDE;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+              const bf16x8 vf = ld_tr8(vk + dt * 64, vk + dt * 64 + 8 * V_STRIDE);
+              o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
+            }
+          }
+        }
+      {
+        const int q = q0 + fr;
+        bf16_t* orow = (bf16_t*)a.out + (size_t)(cm0 + qrow) * a.ldo + chead * 64;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          unsigned pk[4][2];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            pk[g][0] = pack_bf16x2(o[dt][g * 4 + 0] * inv, o[dt][g * 4 + 1] * inv);
+            pk[g][1] = pack_bf16x2(o[dt][g * 4 + 2] * inv, o[dt][g * 4 + 3] * inv);
+          }
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {         // 8 consecutive d per lane (see attention.hip)
+            const auto x = __builtin_amdgcn_permlane32_swap(pk[2 * s2][0], pk[2 * s2 + 1][0], false, false);
+            const auto y = __builtin_amdgcn_permlane32_swap(pk[2 * s2][1], pk[2 * s2 + 1][1], false, false);
+            if (q < crows) *(uint4*)(orow + dt * 32 + s2 * 16 + fhi * 8) = make_uint4(x[0], y[0], x[1], y[1]);
+          }
+        }
+      }
+    }
+    // (the next tile's first barrier orders these staging reads before the LDS-DMA into the region)
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// rowseg[m] = (first row, end row) of the sample that owns row m; tile_first / *ntiles: greedy packing of whole samples into tiles
+// of at most 256 rows, a tile never straddling `split_sample` (the image / text boundary: own LayerNorm parameters per modality).
+__global__ __launch_bounds__(256) void qkvattn_tables_kernel(const int* __restrict__ cu, int nsamples, int split_sample,
+                                                             int* __restrict__ rowseg, int* __restrict__ tile_first,
+                                                             int* __restrict__ ntiles, int max_tiles) {
+  const int total = cu[nsamples];
+  for (int m = blockIdx.x * 256 + threadIdx.x; m < total; m += gridDim.x * 256) {
+    int lo = 0, hi = nsamples;                     // largest s with cu[s] <= m
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (cu[mid] <= m) lo = mid; else hi = mid;
+    }
+    rowseg[2 * m] = cu[lo];
+    rowseg[2 * m + 1] = cu[lo + 1];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    int nt = 0, s = 0;
+    while (s < nsamples && nt < max_tiles) {
+      tile_first[nt++] = s;
+      const int base = cu[s];
+      int e = s + 1;
+      while (e < nsamples && cu[e + 1] - base <= 256 && e != split_sample) ++e;
+      s = e;
+    }
+    tile_first[nt] = nsamples;
+    *ntiles = s < nsamples ? -1 : nt;              // -1: max_tiles too small (the launch then does nothing)
+  }
+}
+
+}  // namespace
+
+extern "C" int msclip_qkvattn_tables(const int* cu, int nsamples, int split_sample, int* rowseg, int* tile_first, int* ntiles,
+                                     int max_tiles, void* stream) {
+  if (!cu || !rowseg || !tile_first || !ntiles || nsamples <= 0 || max_tiles <= 0) return MSCLIP_EINVAL;
+  hipLaunchKernelGGL(qkvattn_tables_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, cu, nsamples, split_sample, rowseg,
+                     tile_first, ntiles, max_tiles);
+  return msclip_launch_status();
+}
+
+extern "C" int msclip_qkv_attention(const msclip_qkvattn_desc* d, void* stream) {
+  if (!d || !d->X || !d->W || !d->bias || !d->out || !d->cu || !d->tile_first || !d->rowseg || !d->zero) return MSCLIP_EINVAL;
+  if (d->heads <= 0 || d->K <= 0 || (d->K % BK) || (d->ldx % 8) || (d->ldw % 8) || d->ldw < d->K || (d->ldo % 8) ||
+      d->ldo < d->heads * 64 || d->M <= 0 || (!d->ntiles_dev && d->ntiles <= 0))
+    return MSCLIP_EINVAL;
+  if (d->rowstat && !d->csum) return MSCLIP_EINVAL;
+  if (d->W2 && (!d->bias2 || (d->rowstat && !d->csum2) || d->seg_split <= 0)) return MSCLIP_EINVAL;
+  if (((size_t)d->bias | (size_t)d->csum | (size_t)d->bias2 | (size_t)d->csum2) & 15) return MSCLIP_EINVAL;
+  static int ncu = 0;
+  if (!ncu) {
+    hipDeviceProp_t p;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    ncu = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+  }
+  int grid = ncu;
+  if (!d->ntiles_dev && d->ntiles * d->heads < grid) grid = d->ntiles * d->heads;
+  hipLaunchKernelGGL(qkv_attn_kernel, dim3(grid), dim3(NTH), 0, (hipStream_t)stream, *d);
+  return msclip_launch_status();
+}

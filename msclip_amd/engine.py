@@ -785,6 +785,63 @@ class Engine:
             self._foldw[key] = (Wf, Wf.float().sum(dim=1).contiguous(), (b + W.float() @ ln.b).contiguous())
         return self._foldw[key]
 
+    # ------------------------------------------------------------------ fused in_proj + attention (opt-in)
+    def fused_qkv_attn_enabled(self):
+        """MSCLIP_FUSED_QKV_ATTN=1: the layers whose attention tensors both towers share run in_proj + attention as ONE kernel
+        (msclip_qkv_attention: q|k|v staged in LDS, never in HBM) -- what BASELINE.json's north_star names.  Off by default:
+        its two-buffer 256 x 192 main loop is slower than the ping-pong GEMM by more than the attention launches cost
+        (228 vs 204 us per layer at the packed C2 shapes)."""
+        return hip.env_flag("MSCLIP_FUSED_QKV_ATTN") and self.heads * 64 == self.D and self.Lv <= 96 and self.Lt <= 96
+
+    def _fused_tables(self, w, Bi, Bt):
+        """Row / tile tables of this call's token matrix: image samples of Lv rows, then the captions (packed: cu of the staged
+        batch; full rows: Lt each).  Rebuilt per call (the captions change); two small launches."""
+        Mv = w["Mv"]
+        img = torch.arange(0, Mv, self.Lv, dtype=torch.int32, device=self.dev) if Bi else None
+        if Bt and w.get("packed"):
+            txt = w["cu"][:Bt] + Mv
+            live = Mv + w["Mt_live"]
+        elif Bt:
+            txt = torch.arange(Mv, Mv + Bt * self.Lt, self.Lt, dtype=torch.int32, device=self.dev)
+            live = Mv + Bt * self.Lt
+        else:
+            txt, live = None, Mv
+        end = torch.full((1,), live, dtype=torch.int32, device=self.dev)
+        cu = torch.cat([t for t in (img, txt, end) if t is not None]).contiguous()
+        return hip.QkvAttnTables(cu, Bi + Bt, split_sample=Bi if (Bi and Bt) else 0, total_rows=live)
+
+    def _fused_qkv_weights(self, i, tower, folded):
+        """Head-major (weight, bias, csum) of layer i's in_proj for one tower's rows: gamma-folded (LNO holds x - centre) or
+        plain (LNO holds the LayerNorm output; zero column sums)."""
+        key = (i, tower, "qkv_hm", folded)
+        if key not in self._foldw:
+            if folded:
+                W, c, b = self._fold_weights(i, tower, "qkv")
+            else:
+                bw = (self.vblk if tower == "v" else self.tblk)[i]["w"]
+                W, b, c = bw.wqkv, bw.bqkv, torch.zeros(3 * self.D, dtype=torch.float32, device=self.dev)
+            self._foldw[key] = hip.head_major_qkv(W, b, self.heads, c)
+        return self._foldw[key]
+
+    def _fused_qkv_attention(self, w, i, r0, r1, modes, Bi, Bt):
+        """in_proj + attention of layer i over rows [r0, r1) = both towers (modes as in _fold_proj), one launch."""
+        if w.get("fused_tabs") is None:
+            w["fused_tabs"] = self._fused_tables(w, Bi, Bt)
+            if w["M"] > w["fused_tabs"].rowseg.shape[0]:
+                w["AO"][w["fused_tabs"].rowseg.shape[0]:w["M"]].zero_()     # tile padding behind the last caption: finite operand rows of out_proj
+        Mv = w["Mv"]
+        W1, b1, c1 = self._fused_qkv_weights(i, modes[0][0], modes[0][3])
+        use_fold = any(m[3] for m in modes)
+        fi = None
+        if len(modes) == 2:
+            W2, b2, c2 = self._fused_qkv_weights(i, modes[1][0], modes[1][3])
+            fi = hip.FoldIn(w["RST"][r0:r1], c1, W2, b2, c2, modes[1][1] - r0)
+        elif use_fold:
+            fi = hip.FoldIn(w["RST"][r0:r1], c1)
+        assert r0 == 0
+        hip.qkv_attention(w["LNO"][r0:r1], W1, b1, w["AO"][r0:r1], w["fused_tabs"], self.heads,
+                          causal_from_row=Mv if Bt else hip.INT_MAX, fold_in=fi, M=r1 - r0)
+
     def _fold_proj(self, w, i, which, r0, r1, modes, out, act):
         """One projection over rows [r0, r1) behind a LayerNorm.  modes = [(tower, row0, row1, folded)]: a folded segment's rows
         of LNO hold bf16 (x - centre) and take the gamma-folded weight; a plain segment's rows hold a LayerNorm output (RST rows
@@ -866,12 +923,15 @@ class Engine:
                 self._last_block_attention(w, Bi, Bt, cg)
                 self._last_block_tail(w, Bi, Bt, vb, tb, attended=True)
                 continue
-            for r0, r1, ms in groups:
-                self._fold_proj(w, i, "qkv", r0, r1, ms, QKV, hip.ACT_NONE)
-            if vb is not None:
-                hip.attention(QKV[:Mv], AO[:Mv], Bi, self.Lv, self.heads, False)
-            if tb is not None:
-                self._attention_text(w, QKV, AO, Bt)
+            if shared and not last_live and self.fused_qkv_attn_enabled():
+                self._fused_qkv_attention(w, i, groups[0][0], groups[0][1], groups[0][2], Bi, Bt)
+            else:
+                for r0, r1, ms in groups:
+                    self._fold_proj(w, i, "qkv", r0, r1, ms, QKV, hip.ACT_NONE)
+                if vb is not None:
+                    hip.attention(QKV[:Mv], AO[:Mv], Bi, self.Lv, self.heads, False)
+                if tb is not None:
+                    self._attention_text(w, QKV, AO, Bt)
             if last_live:
                 self._last_block_tail(w, Bi, Bt, vb, tb)
                 continue
@@ -972,15 +1032,19 @@ class Engine:
                 self._last_block_attention(w, Bi, Bt, groups)
                 self._last_block_tail(w, Bi, Bt, vb, tb, attended=True)
                 continue
-            for r0, r1, bw in groups:
-                if f8_qkv:
-                    hip.gemm_f8(w["LNQ"][r0:r1], bw.wqkv_q, QKV[r0:r1], w["RS"][r0:r1], bw.wqkv_s, bias=bw.bqkv)
-                else:
-                    hip.gemm(LNO[r0:r1], bw.wqkv, QKV[r0:r1], bias=bw.bqkv)
-            if vb is not None:
-                hip.attention(QKV[:Mv], AO[:Mv], Bi, self.Lv, self.heads, False)
-            if tb is not None:
-                self._attention_text(w, QKV, AO, Bt)
+            if (len(groups) == 1 and len(segs) == 2 and not last_live and not f8_qkv and self.fused_qkv_attn_enabled()):
+                # opt-in: in_proj + attention of both towers' rows in one kernel (plain weights: LNO holds the LayerNorm outputs)
+                self._fused_qkv_attention(w, i, 0, M, [("v", 0, Mv, False)], Bi, Bt)
+            else:
+                for r0, r1, bw in groups:
+                    if f8_qkv:
+                        hip.gemm_f8(w["LNQ"][r0:r1], bw.wqkv_q, QKV[r0:r1], w["RS"][r0:r1], bw.wqkv_s, bias=bw.bqkv)
+                    else:
+                        hip.gemm(LNO[r0:r1], bw.wqkv, QKV[r0:r1], bias=bw.bqkv)
+                if vb is not None:
+                    hip.attention(QKV[:Mv], AO[:Mv], Bi, self.Lv, self.heads, False)
+                if tb is not None:
+                    self._attention_text(w, QKV, AO, Bt)
             if last_live:
                 self._last_block_tail(w, Bi, Bt, vb, tb)
                 continue
@@ -1105,6 +1169,7 @@ class Engine:
                                   "single-modality calls run c_proj in bf16 until then")
             w = self._workspace(Bi, Bt, inference=True)
             w["fold_pending"] = {"v": False, "t": False}
+            w["fused_tabs"] = None
             conv_events = None
             side_ok = (taps is None and os.environ.get("MSCLIP_CONV_SIDE_STREAM", "1") != "0"
                        and not torch.cuda.is_current_stream_capturing())

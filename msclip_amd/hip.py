@@ -27,6 +27,7 @@ EXPORTS = (
     "msclip_bn_bwd_reduce", "msclip_bn_bwd_dx", "msclip_bn_fold_bwd", "msclip_bn_finish", "msclip_bn_finish_tiled", "msclip_bn_bwd_finish",
     "msclip_text_lengths", "msclip_embed_tokens_packed", "msclip_attention_varlen", "msclip_attention_lastq_varlen",
     "msclip_attention_bwd_varlen", "msclip_embed_tokens_bwd_packed",
+    "msclip_qkv_attention", "msclip_qkvattn_tables",
     "msclip_abi_version", "msclip_build_arch",
     "msclip_stream_priority_range", "msclip_stream_create", "msclip_stream_destroy",
 )
@@ -58,6 +59,19 @@ class GemmDesc(ctypes.Structure):
         ("W2", ctypes.c_void_p), ("bias2", ctypes.c_void_p), ("csum", ctypes.c_void_p), ("csum2", ctypes.c_void_p),
         ("rowstat", ctypes.c_void_p), ("seg_split", ctypes.c_int), ("ldxb", ctypes.c_int), ("xb", ctypes.c_void_p),
         ("center", ctypes.c_void_p), ("part", ctypes.c_void_p), ("resid2", ctypes.c_void_p),
+    ]
+
+
+class QkvAttnDesc(ctypes.Structure):
+    """Mirror of struct msclip_qkvattn_desc."""
+    _fields_ = [
+        ("X", ctypes.c_void_p), ("W", ctypes.c_void_p), ("zero", ctypes.c_void_p), ("out", ctypes.c_void_p),
+        ("bias", ctypes.c_void_p), ("cu", ctypes.c_void_p), ("tile_first", ctypes.c_void_p), ("rowseg", ctypes.c_void_p),
+        ("ntiles_dev", ctypes.c_void_p),
+        ("M", ctypes.c_int), ("K", ctypes.c_int), ("heads", ctypes.c_int), ("ntiles", ctypes.c_int),
+        ("ldx", ctypes.c_int), ("ldw", ctypes.c_int), ("ldo", ctypes.c_int), ("causal_from_row", ctypes.c_int),
+        ("rowstat", ctypes.c_void_p), ("csum", ctypes.c_void_p), ("W2", ctypes.c_void_p), ("bias2", ctypes.c_void_p),
+        ("csum2", ctypes.c_void_p), ("seg_split", ctypes.c_int),
     ]
 
 
@@ -146,6 +160,8 @@ def lib():
         L.msclip_attention_lastq_varlen.argtypes = [vp, ci, vp, ci, vp, ci, ci, ci, ci, vp, ci, vp]
         L.msclip_attention_bwd_varlen.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]
         L.msclip_embed_tokens_bwd_packed.argtypes = [vp, vp, ci, vp, vp, vp, ci, ci, ci, ci, vp]
+        L.msclip_qkv_attention.argtypes = [ctypes.POINTER(QkvAttnDesc), vp]
+        L.msclip_qkvattn_tables.argtypes = [vp, ci, ci, vp, vp, vp, ci, vp]
         L.msclip_abi_version.restype = ci
         L.msclip_build_arch.restype = ctypes.c_char_p
         for name in EXPORTS:
@@ -677,6 +693,52 @@ def attention_lastq_varlen(q, qkv, out, nsamples, Lmax, heads, cu, row_base=0):
     assert cu.dtype == torch.int32 and cu.numel() >= nsamples + 2
     _check(lib().msclip_attention_lastq_varlen(_p(q), q.stride(0), _p(qkv), qkv.stride(0), _p(out), out.stride(0), nsamples, Lmax,
                                                heads, _p(cu), row_base, _stream()), "msclip_attention_lastq_varlen")
+    return out
+
+
+def head_major_qkv(w, b, heads, *extra):
+    """Packed in_proj rows [q (heads*64) | k | v] -> head-major [q_h | k_h | v_h] per head: the row order msclip_qkv_attention
+    expects.  w [3*heads*64, K], b (and every tensor in `extra`, e.g. the fold's column sums) [3*heads*64]."""
+    D = heads * 64
+    idx = torch.arange(3 * D, device=w.device).view(3, heads, 64).permute(1, 0, 2).reshape(-1)
+    return (w[idx].contiguous(), b[idx].contiguous()) + tuple(t[idx].contiguous() for t in extra)
+
+
+class QkvAttnTables:
+    """Row / tile tables of msclip_qkv_attention for one batch layout: cu int32 [nsamples + 1] = first row of every sample
+    (device); split_sample = first sample of the second modality (0: none)."""
+
+    def __init__(self, cu, nsamples, split_sample=0, total_rows=None):
+        dev = cu.device
+        assert cu.dtype == torch.int32 and cu.numel() >= nsamples + 1
+        rows = int(total_rows) if total_rows is not None else int(cu[nsamples])
+        self.cu, self.nsamples = cu, nsamples
+        self.max_tiles = nsamples + 1
+        self.rowseg = torch.zeros(max(rows, 1), 2, dtype=torch.int32, device=dev)
+        self.tile_first = torch.zeros(self.max_tiles + 1, dtype=torch.int32, device=dev)
+        self.ntiles = torch.zeros(1, dtype=torch.int32, device=dev)
+        _check(lib().msclip_qkvattn_tables(_p(cu), nsamples, split_sample, _p(self.rowseg), _p(self.tile_first), _p(self.ntiles),
+                                           self.max_tiles, _stream()), "msclip_qkvattn_tables")
+
+
+def qkv_attention(x, w_hm, b_hm, out, tables, heads, *, causal_from_row=INT_MAX, fold_in=None, M=None):
+    """out = attention(in_proj(x)) in one launch (msclip_qkv_attention).  w_hm / b_hm: head-major weight / bias (head_major_qkv);
+    fold_in: hip.FoldIn whose csum / W2 / bias2 / csum2 are head-major too."""
+    _bf16(x); _bf16(out); _bf16(w_hm); _f32(b_hm)
+    d = QkvAttnDesc()
+    d.X, d.W, d.zero, d.out, d.bias = x.data_ptr(), w_hm.data_ptr(), zero_page(x.device).data_ptr(), out.data_ptr(), b_hm.data_ptr()
+    d.cu, d.tile_first, d.rowseg, d.ntiles_dev = tables.cu.data_ptr(), tables.tile_first.data_ptr(), tables.rowseg.data_ptr(), tables.ntiles.data_ptr()
+    d.M = M if M is not None else x.shape[0]
+    d.K, d.heads, d.ntiles = w_hm.shape[1], heads, 0
+    d.ldx, d.ldw, d.ldo = x.stride(0), w_hm.stride(0), out.stride(0)
+    d.causal_from_row = causal_from_row
+    assert w_hm.shape[0] == heads * 192
+    if fold_in is not None:
+        f = fold_in
+        d.rowstat, d.csum = f.rowstat.data_ptr(), f.csum.data_ptr()
+        if f.w2 is not None:
+            d.W2, d.bias2, d.csum2, d.seg_split = f.w2.data_ptr(), f.bias2.data_ptr(), f.csum2.data_ptr(), f.split
+    _check(lib().msclip_qkv_attention(ctypes.byref(d), _stream()), "msclip_qkv_attention")
     return out
 
 

@@ -1032,3 +1032,72 @@ def test_patchify_and_patch_conv(gpu_device, dtype, B, S, P):
     conv = F.conv2d(img.float().to(BF).float(), w.to(BF).float(), stride=P).flatten(2).transpose(1, 2)           # [B, g*g, D]
     close(X.view(B, L, D)[:, 1:], conv + pos[1:], 2e-2, 1e-3)
     assert bool((X.view(B, L, D)[:, 0] == 0).all())                                              # the cls rows are not the GEMM's
+
+@pytest.mark.parametrize("case", ["image", "captions", "both_fold"])
+def test_fused_qkv_attention_against_gemm_plus_attention(gpu_device, case):
+    """msclip_qkv_attention (in_proj + attention in one kernel, q|k|v staged in LDS, block-diagonal / causal mask from the row
+    table) against the two-launch chain it replaces on the same inputs: msclip_gemm (+ the LayerNorm fold's consumer form) into a
+    q|k|v matrix, then msclip_attention / msclip_attention_varlen.  Image samples of 50 tokens (tiles of 5 samples, a partial last
+    tile), packed captions of 3..77 rows (causal), and both modalities in one launch with per-modality folded weights."""
+    H, D = 12, 768
+    Bi, Lv = (0, 50) if case == "captions" else (128, 50) if case == "both_fold" else (23, 50)   # 128 x 50 = 25 whole GEMM tiles
+    Bt = 0 if case == "image" else 41
+    g = torch.Generator().manual_seed(7)
+    lens = torch.randint(3, 78, (Bt,), generator=g).tolist() if Bt else []
+    if Bt:
+        lens[0], lens[1] = 77, 3
+    starts = [i * Lv for i in range(Bi)]
+    Mv = Bi * Lv
+    r = Mv
+    for n in lens:
+        starts.append(r)
+        r += n
+    live = r
+    M = -(-live // 256) * 256 if case == "both_fold" else live
+    cu = torch.tensor(starts + [live], dtype=torch.int32, device="cuda")
+    x = rnd(M, D, seed=81, dtype=BF)
+    w, b = rnd(3 * D, D, seed=82, scale=0.03, dtype=BF), rnd(3 * D, seed=83, scale=0.1)
+    fold = case == "both_fold"
+    qkv = torch.empty(M, 3 * D, dtype=BF, device="cuda")
+    if fold:
+        w2, b2 = rnd(3 * D, D, seed=84, scale=0.03, dtype=BF), rnd(3 * D, seed=85, scale=0.1)
+        rstat = torch.stack([1.0 + 0.1 * torch.rand(M, generator=g), 0.1 * torch.randn(M, generator=g)], 1).cuda().contiguous()
+        c1, c2 = w.float().sum(1).contiguous(), w2.float().sum(1).contiguous()
+        split = Mv                                            # the modality boundary: a whole GEMM tile for the two-launch form
+        assert split % 256 == 0
+        hip.gemm(x, w, qkv, bias=b, fold_in=hip.FoldIn(rstat, c1, w2, b2, c2, split))
+    else:
+        hip.gemm(x, w, qkv, bias=b)
+    ref = torch.zeros(M, D, dtype=BF, device="cuda")
+    if Bi:
+        hip.attention(qkv[:Mv], ref[:Mv], Bi, Lv, H, False)
+    if Bt:
+        cut = torch.tensor([s - Mv for s in starts[Bi:]] + [live - Mv, max(lens)], dtype=torch.int32, device="cuda")
+        hip.attention_varlen(qkv[Mv:], ref[Mv:], cut, Bt, max(lens), H, True)
+    tabs = hip.QkvAttnTables(cu, Bi + Bt, split_sample=Bi if (Bi and Bt) else 0, total_rows=live)
+    torch.cuda.synchronize()
+    nt = int(tabs.ntiles)
+    assert nt > 0
+    tf = tabs.tile_first[:nt + 1].tolist()
+    cul = cu.tolist()
+    assert tf[0] == 0 and tf[-1] == Bi + Bt and all(cul[tf[i + 1]] - cul[tf[i]] <= 256 for i in range(nt))
+    assert not (Bi and Bt) or Bi in tf                            # no tile straddles the modality boundary
+    out = torch.full((M + 1, D), float("nan"), dtype=BF, device="cuda")
+    wh, bh = hip.head_major_qkv(w, b, H)
+    fi = None
+    if fold:
+        w2h, b2h, c2h = hip.head_major_qkv(w2, b2, H, c2)
+        _, _, c1h = hip.head_major_qkv(w, b, H, c1)
+        fi = hip.FoldIn(rstat, c1h, w2h, b2h, c2h, split)
+    hip.qkv_attention(x, wh, bh, out[:M], tabs, H, causal_from_row=Mv if Bt else hip.INT_MAX, fold_in=fi, M=M)
+    torch.cuda.synchronize()
+    a, e = out[:live].float(), ref[:live].float()
+    assert bool(torch.isfinite(a).all())
+    # both paths round q|k|v to bf16 (the fused one from the same fp32 accumulators, summed in another order) and P to bf16
+    err = (a - e).abs()
+    assert float(err.max()) <= 0.03 * float(e.abs().max()) + 2e-3, (case, float(err.max()), float(e.abs().max()))
+    assert float(err.mean()) <= 2e-3 * float(e.abs().mean()) + 2e-4
+    assert bool(torch.isnan(out[M:].float()).all())
+    again = torch.empty(M, D, dtype=BF, device="cuda")
+    hip.qkv_attention(x, wh, bh, again, tabs, H, causal_from_row=Mv if Bt else hip.INT_MAX, fold_in=fi, M=M)
+    assert torch.equal(again[:live].view(torch.int16), out[:live].view(torch.int16))      # race screen: bitwise repeatable

@@ -969,3 +969,64 @@ def test_bitwise_repeatable_across_fresh_workspaces_with_side_streams(gpu_device
         if ref is None:
             ref = (fi, ft)
         assert torch.equal(fi, ref[0]) and torch.equal(ft, ref[1]), rep
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 5: the fused in_proj + attention kernel as an opt-in engine path (MSCLIP_FUSED_QKV_ATTN=1)
+# ---------------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("pack", [True, False])
+def test_fused_qkv_attention_engine_path_against_reference_goldens(gpu_device, monkeypatch, pack):
+    """MSCLIP_FUSED_QKV_ATTN=1 (msclip_qkv_attention in the layers whose attention tensors are shared) on the golden batch of
+    the REAL reference: features, logits and the reference's block taps (blocks 1 / 2 / 11 of both towers) within the same
+    tolerances as the default path, packed captions and full rows."""
+    from conftest import summarize
+    from msclip_amd import hip
+    monkeypatch.setenv("MSCLIP_FUSED_QKV_ATTN", "1")
+    monkeypatch.setenv("MSCLIP_TEXT_PACK", "1" if pack else "0")
+    name = "b32-yfcc-msclips"
+    g = golden(name)
+    m = model_for(name)
+    b = int(g["batch"])
+    img = synth.synth_images(b, seed=int(g["seed"])).cuda()
+    tok = synth.synth_tokens(b, seed=int(g["seed"]) + 1).cuda()
+    calls = []
+    real = hip.qkv_attention
+    monkeypatch.setattr(hip, "qkv_attention", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    taps = {}
+    w = m.engine().run(img, tok, taps=taps)
+    assert len(calls) == m.engine().n_layers - 1                      # every shared layer took the fused kernel (taps: full last block)
+    fi, ft = w["fv"].float().cpu().numpy(), w["ft"].float().cpu().numpy()
+    assert np.abs(fi - g["image_features"]).max() <= 5e-3 and np.abs(ft - g["text_features"]).max() <= 5e-3
+    for k in [k[4:] for k in g.files if k.startswith("tap_") and ("block" in k)]:
+        t = taps[k]
+        got, ref = summarize(t), g["tap_" + k]
+        scale = max(np.abs(ref[2:]).max(), 1e-3)
+        if k.startswith("tblock") and pack:
+            live = _live_sample_mask(t.shape, taps["text_lengths"])
+            err = np.abs(got[2:] - ref[2:])[live].max() / scale
+        else:
+            err = np.abs(got[2:] - ref[2:]).max() / scale
+        assert err <= 4e-2, (k, err)
+    calls.clear()
+    logits = m(img, tok).float().cpu().numpy()                        # the shipped schedule (side streams, live-row last block)
+    assert calls and np.abs(logits - g["logits"]).max() <= 0.05
+
+
+def test_fused_qkv_attention_engine_path_with_the_layernorm_fold(gpu_device, monkeypatch):
+    """The same opt-in path at batch 256, where the LayerNorm fold runs (per-modality gamma-folded weights, rstd / mean in the
+    fused kernel's staging step): features against the default path on the same inputs, bitwise repeatable."""
+    name, B = "b32-yfcc-msclips", 256
+    m = model_for(name)
+    img = synth.synth_images(B, seed=61).cuda()
+    tok = synth.synth_tokens(B, seed=62).cuda()
+    eng = m.engine()
+    w = eng.run(img, tok)
+    f0i, f0t = w["fv"].clone(), w["ft"].clone()
+    monkeypatch.setenv("MSCLIP_FUSED_QKV_ATTN", "1")
+    w = eng.run(img, tok)
+    f1i, f1t = w["fv"].clone(), w["ft"].clone()
+    for a, b in ((f0i, f1i), (f0t, f1t)):
+        assert (a - b).abs().max().item() <= 2e-3
+        assert torch.nn.functional.cosine_similarity(a, b, dim=-1).min().item() >= 0.99995
+    w = eng.run(img, tok)
+    assert torch.equal(w["fv"], f1i) and torch.equal(w["ft"], f1t)
