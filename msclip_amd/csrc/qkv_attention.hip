@@ -2,15 +2,14 @@
 // Replaces F.linear(x, in_proj_weight, in_proj_bias) + the bmm / mask / softmax / bmm of Attention_CUST
 // (reference lib/models/clip_openai_pe_res_v1.py:612, 707-738; causal mask of :2965-2971 for the captions).
 //
-// What BASELINE.json's north_star names ("fused QKV-projection + SDPA"), built in round 5 as an OPT-IN path
-// (MSCLIP_FUSED_QKV_ATTN=1 in the engine): measured slower than the ping-pong GEMM + attention launches it replaces
-// (DESIGN.md s0 item 4 has the numbers), because the attention needs one head's q|k|v of whole samples in ONE workgroup:
+// What BASELINE.json's north_star names ("fused QKV-projection + SDPA"), built in round 5 (engine: MSCLIP_FUSED_QKV_ATTN;
+// DESIGN.md s0 item 4 has the numbers).  The attention needs one head's q|k|v of whole samples in ONE workgroup:
 //   * a tile is 256 token rows (whole samples: 5 images of 50 tokens, or a run of packed captions) x 192 columns (one head's
-//     q | k | v: the packed weight is re-ordered head-major), contracted over K = width by the two-buffer 256 x 192 main loop
-//     of gemm.hip's gemm_kernel (8 waves 4 x 2, 32x32x16 MFMAs, LDS-DMA of slab s+1 between the MFMAs of slab s);
-//   * the tile's accumulators (+ bias, or the LayerNorm fold's rstd / mean / column-sum form) are written to LDS as bf16 --
-//     Q|K rows of 272 B, V rows of 136 B: 104 KB, the consumed operand buffer plus the 48 KB beside it, while the other buffer
-//     already holds the next tile's first K-slab -- and the ping-pong kernel's LDS ring has no room for that;
+//     q | k | v: the packed weight is re-ordered head-major), contracted over K = width: 8 waves 4 x 2, 32x32x16 MFMAs, K-slabs
+//     of 64 filled by LDS-DMA with counted waits, X two slabs ahead and W one (see the LDS map below);
+//   * the tile's accumulators (+ bias, or the LayerNorm fold's rstd / mean / column-sum form) are written to LDS as bf16, three
+//     areas of 256 rows x 128 B (q, k, v) in the slabs the tile has consumed -- the ping-pong kernel's LDS ring has no room
+//     for that, which is why this kernel has a main loop of its own;
 //   * wave w then attends the tile's query rows 32 w .. 32 w + 31 against the key tiles that its rows' samples span, with a
 //     block-diagonal (+ causal) mask from a per-row (sample start, sample end) table: S^T = K Q^T and O^T = V^T P^T on
 //     32x32x16 MFMAs as in attention.hip, V^T fragments straight from the row-major V rows by ds_read_b64_tr_b16.
@@ -23,13 +22,15 @@ namespace {
 
 constexpr int BK = 64, BM = 256, BN = 192, NW = 8, NTH = 512;
 constexpr int TM = 2, TN = 3;                      // 32 x 32 accumulator tiles per wave: 64 rows x 96 columns
-constexpr int XI = BM * 8 / NTH, WI = BN * 8 / NTH;   // LDS-DMA pieces per lane and K-slab: 4 + 3
-constexpr int NPC = XI + WI;
-constexpr int BUF_BYTES = (BM + BN) * BK * 2;      // 57 344
-constexpr int EXTRA_BYTES = 49152;                 // between the two operand buffers: [buf 0 | extra | buf 1] = 160 KB
-constexpr int QK_STRIDE = 272, V_STRIDE = 136;     // bytes per staged row (Q|K: 128 bf16 + 16 B pad; V: 64 bf16 + 8 B pad)
-constexpr int QK_BYTES = BM * QK_STRIDE;           // 69 632
-static_assert(QK_BYTES + BM * V_STRIDE <= BUF_BYTES + EXTRA_BYTES, "q|k|v staging = one operand buffer + the extra region");
+constexpr int XI = BM * 8 / NTH, WI = BN * 8 / NTH;   // LDS-DMA pieces per lane and K-slab: 4 (X rows) + 3 (W rows)
+// LDS map (160 KB): three X slabs of 32 KB (256 rows x 128 B), two W slabs of 24 KB (192 rows x 128 B) with 16 KB between them.
+// The X operand runs TWO K-slabs ahead of the MFMAs, W one: 88 KB in flight instead of the two-buffer loop's 56 KB (the loop is
+// bound by the latency of the LDS-DMA round trip: bytes in flight / latency).  At a tile's end two X slabs and one W slab + the
+// 16 KB beside it are free: three 32 KB areas = the staged q, k and v of the tile (256 rows x 128 B each, same chunk swizzle as
+// the operand slabs), while the third X slab and the other W slab already hold the next tile's first K-slab.
+constexpr int XB_BYTES = BM * BK * 2, WB_BYTES = BN * BK * 2, SPARE_BYTES = 16384;
+constexpr int W0_OFF = 3 * XB_BYTES, W1_OFF = W0_OFF + WB_BYTES + SPARE_BYTES;
+static_assert(W1_OFF + WB_BYTES == 163840 && WB_BYTES + SPARE_BYTES >= XB_BYTES, "LDS map");
 constexpr int MAXKT = 5;                           // key tiles a 32-query tile can span: samples <= 96 rows -> <= 127 rows unaligned
 
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4v;
@@ -39,9 +40,11 @@ __device__ __forceinline__ bf16x8 ld_tr8(const char* p0, const char* p1) {   // 
   const bf16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((AS3 bf16x4v*)p1);
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
+// byte offset of (row, 16-byte chunk) in a 128-byte-row area with the operand slabs' swizzle
+__device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 __global__ __launch_bounds__(NTH) void qkv_attn_kernel(const msclip_qkvattn_desc a) {
-  __shared__ __attribute__((aligned(1024))) char lds[2 * BUF_BYTES + EXTRA_BYTES];
+  __shared__ __attribute__((aligned(1024))) char lds[163840];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -49,11 +52,11 @@ __global__ __launch_bounds__(NTH) void qkv_attn_kernel(const msclip_qkvattn_desc
   const int ntiles = a.ntiles_dev ? __builtin_amdgcn_readfirstlane(*a.ntiles_dev) : a.ntiles;
   const int nwork = ntiles * H;
   const int Mtot = a.M;
-  const int nk = a.K / BK;
+  const int nk = a.K / BK;                         // >= 3 (host-checked)
 
   const bf16_t* __restrict__ X = (const bf16_t*)a.X;
-  const bf16_t* __restrict__ Z = (const bf16_t*)a.zero;
-  auto buf = [&](int b) -> bf16_t* { return (bf16_t*)(lds + (b ? BUF_BYTES + EXTRA_BYTES : 0)); };
+  auto xbuf = [&](int i) -> char* { return lds + i * XB_BYTES; };
+  auto wbuf = [&](int i) -> char* { return lds + (i ? W1_OFF : W0_OFF); };
 
   // work item -> (tile, head): XCD-aware bijective remap (consecutive ids -- the heads of one tile, which share its X rows --
   // run on one XCD), as gemm_kernel's tile_origin
@@ -67,32 +70,33 @@ __global__ __launch_bounds__(NTH) void qkv_attn_kernel(const msclip_qkvattn_desc
     rows = a.cu[s1] - m0;
   };
 
+  // loader: lane owns (row = (i * 8 + wave) * 8 + lane / 8, physical 16-byte chunk lane % 8 = logical chunk ^ ((row >> 1) & 7)).
+  // Buffer-addressed LDS-DMA (SGPR descriptor of the tile's rows + 32-bit lane offset + scalar K offset), like the ping-pong
+  // kernel: rows past the matrix are out of the descriptor's range (read as zero), and -- unlike global_load_lds, behind which
+  // hipcc guards every LDS read with s_waitcnt vmcnt(0) -- the counted waits below stay what they are.
   const int pc = lane & 7;
   const int lc = pc ^ ((lane >> 4) | ((wave & 1) << 2));
   const int rsub = lane >> 3;
-  const bf16_t* xrow[XI];
-  const bf16_t* wrow[WI];
-  auto setup_rows = [&](int m0, int head) {
-    const bf16_t* Wseg = (const bf16_t*)((a.W2 && m0 >= a.seg_split) ? a.W2 : a.W);
+  unsigned vx[XI], vw[WI];
 #pragma unroll
-    for (int i = 0; i < WI; ++i) {
-      const int n = head * BN + (i * NW + wave) * 8 + rsub;
-      wrow[i] = Wseg + (size_t)n * a.ldw + lc * 8;
-    }
+  for (int i = 0; i < XI; ++i) vx[i] = (unsigned)((i * NW + wave) * 8 + rsub) * (unsigned)a.ldx * 2u + (unsigned)lc * 16u;
 #pragma unroll
-    for (int i = 0; i < XI; ++i) {
-      const int m = m0 + (i * NW + wave) * 8 + rsub;
-      xrow[i] = (m < Mtot) ? X + (size_t)m * a.ldx + lc * 8 : nullptr;
-    }
+  for (int i = 0; i < WI; ++i) vw[i] = (unsigned)((i * NW + wave) * 8 + rsub) * (unsigned)a.ldw * 2u + (unsigned)lc * 16u;
+  auto x_rsrc = [&](int m0, bool live) {
+    const long long bytes = live ? (long long)(Mtot - m0) * a.ldx * 2 : 0;
+    return make_rsrc((const char*)X + (size_t)m0 * a.ldx * 2, bytes > 0xffffffffll ? 0xffffffffu : (unsigned)bytes);
   };
-  auto slab_sources = [&](int kt, const bf16_t* (&src)[NPC]) {
-#pragma unroll
-    for (int i = 0; i < XI; ++i) src[i] = xrow[i] ? xrow[i] + kt * BK : Z;
-#pragma unroll
-    for (int i = 0; i < WI; ++i) src[XI + i] = wrow[i] + kt * BK;
+  auto w_rsrc = [&](int m0, int head, bool live) {
+    const char* Wseg = (const char*)((a.W2 && m0 >= a.seg_split) ? a.W2 : a.W);
+    return make_rsrc(Wseg + (size_t)head * BN * a.ldw * 2, live ? (unsigned)(BN * a.ldw * 2) : 0u);
   };
-  auto piece_dst = [&](int b, int j) -> bf16_t* {
-    return j < XI ? buf(b) + (j * NW + wave) * 8 * BK : buf(b) + BM * BK + ((j - XI) * NW + wave) * 8 * BK;
+  auto issue_x = [&](__amdgpu_buffer_rsrc_t r, int kt, char* dst) {      // 4 pieces: the tile's 256 X rows of K-slab kt
+#pragma unroll
+    for (int i = 0; i < XI; ++i) blds16(r, vx[i], (unsigned)kt * 128u, dst + (i * NW + wave) * 1024);
+  };
+  auto issue_w = [&](__amdgpu_buffer_rsrc_t r, int kt, char* dst) {      // 3 pieces: the head's 192 W rows of K-slab kt
+#pragma unroll
+    for (int i = 0; i < WI; ++i) blds16(r, vw[i], (unsigned)kt * 128u, dst + (i * NW + wave) * 1024);
   };
 
   const int wm = (wave >> 1) * (TM * 32), wn = (wave & 1) * (TN * 32);
@@ -100,16 +104,15 @@ __global__ __launch_bounds__(NTH) void qkv_attn_kernel(const msclip_qkvattn_desc
 
   int t = blockIdx.x;
   int m0 = 0, rows = 0, head = 0;
+  int xc = 0, wc = 0;                              // buffers of X slab 0 / W slab 0 of the current tile
+  __amdgpu_buffer_rsrc_t rx = x_rsrc(0, false), rw = w_rsrc(0, 0, false);
   if (t < nwork) {
     work_origin(t, m0, rows, head);
-    setup_rows(m0, head);
-    const bf16_t* src[NPC];
-    slab_sources(0, src);
-#pragma unroll
-    for (int j = 0; j < NPC; ++j) glds16(src[j], piece_dst(0, j));
+    rx = x_rsrc(m0, true);
+    rw = w_rsrc(m0, head, true);
+    issue_x(rx, 0, xbuf(0));
+    issue_w(rw, 0, wbuf(0));
   }
-  int it = 0;
-  bool landed = false;
   for (; t < nwork; t += gridDim.x) {
     f32x16 acc[TN][TM];
 #pragma unroll
@@ -120,28 +123,24 @@ __global__ __launch_bounds__(NTH) void qkv_attn_kernel(const msclip_qkvattn_desc
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int cm0 = m0, crows = rows, chead = head;
     const bool has_next = t + (int)gridDim.x < nwork;
-    for (int kt = 0; kt < nk; ++kt, ++it) {
-      if (kt == 0 && landed) {
-        __builtin_amdgcn_s_barrier();              // orders every wave's staging reads before the LDS-DMA into that region
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-      }
-      const bf16_t* src[NPC];
-      const bool last = kt + 1 == nk;
-      if (last && has_next) {
-        work_origin(t + gridDim.x, m0, rows, head);
-        setup_rows(m0, head);
-      }
-      if (!last || has_next) {
-        slab_sources(last ? 0 : kt + 1, src);
-      } else {
-#pragma unroll
-        for (int j = 0; j < NPC; ++j) src[j] = Z;
-      }
-      const int nb = (it + 1) & 1;
-      const bf16_t* xs = buf(it & 1) + (wm + fr) * BK;
-      const bf16_t* ws = buf(it & 1) + BM * BK + (wn + fr) * BK;
+    // the next work item's origin is fetched HERE (two dependent loads) and pinned in scalar registers: its use near the end of
+    // the K loop must not turn into a wait for every LDS-DMA piece in flight
+    int nm0 = 0, nrows = 0, nhead = 0;
+    if (has_next) work_origin(t + gridDim.x, nm0, nrows, nhead);
+    nm0 = __builtin_amdgcn_readfirstlane(nm0);
+    nrows = __builtin_amdgcn_readfirstlane(nrows);
+    nhead = __builtin_amdgcn_readfirstlane(nhead);
+    int xi = xc, wi = wc;                          // buffers of the slab being computed
+    for (int kt = 0; kt < nk; ++kt) {
+      // X(kt), W(kt) have landed: at a tile's first slab nothing younger is in flight (and the barrier also orders the previous
+      // tile's staging reads before the LDS-DMA into those areas); later the 4 pieces of X(kt + 1) are
+      if (kt == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                // (raw: __syncthreads()' fence would drain the VM counter, i.e. every piece in flight)
+      asm volatile("" ::: "memory");
+      const int x1 = xi == 2 ? 0 : xi + 1, x2 = x1 == 2 ? 0 : x1 + 1;
+      const bf16_t* xs = (const bf16_t*)xbuf(xi) + (wm + fr) * BK;
+      const bf16_t* ws = (const bf16_t*)wbuf(wi) + (wn + fr) * BK;
       bf16x8 wf[2][TN], xf[2][TM];
       {
         const int ph = (fhi ^ fsw) * 8;
@@ -150,6 +149,11 @@ __global__ __launch_bounds__(NTH) void qkv_attn_kernel(const msclip_qkvattn_desc
 #pragma unroll
         for (int j = 0; j < TM; ++j) xf[0][j] = *(const bf16x8*)(xs + j * 32 * BK + ph);
       }
+      // ---- issued under this slab's MFMAs, in this order (the counted waits depend on it):
+      //   kt == 0:        X(1)                        (a tile's second slab: one slab of lead only)
+      //   always:         W(kt + 1)   | at the last slab: W(0) of the next tile
+      //   kt + 2 < nk:    X(kt + 2)   | kt == nk - 2: X(0) of the next tile | last slab: nothing (both X areas become staging)
+      if (kt == 0) issue_x(rx, 1, xbuf(x1));
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
@@ -160,34 +164,44 @@ __global__ __launch_bounds__(NTH) void qkv_attn_kernel(const msclip_qkvattn_desc
 #pragma unroll
           for (int j = 0; j < TM; ++j) xf[(kk + 1) & 1][j] = *(const bf16x8*)(xs + j * 32 * BK + ph);
         }
-        constexpr int NV0 = NPC / 4, NVR = NPC % 4;
-        const int nvk = NV0 + (kk < NVR ? 1 : 0);
-        const int pv0 = kk * NV0 + (kk < NVR ? kk : NVR);
-#pragma unroll
-        for (int v = 0; v < NV0 + 1; ++v)
-          if (v < nvk) glds16(src[pv0 + v], piece_dst(nb, pv0 + v));
+        if (kk == 0) {
+          if (kt + 1 < nk) {
+            issue_w(rw, kt + 1, wbuf(wi ^ 1));
+          } else {                                 // the next tile's W(0) (an empty descriptor behind the last work item)
+            m0 = nm0; rows = nrows; head = nhead;
+            rw = w_rsrc(m0, head, has_next);
+            issue_w(rw, 0, wbuf(wi ^ 1));
+          }
+        }
+        if (kk == 1) {
+          if (kt + 2 < nk) {
+            issue_x(rx, kt + 2, xbuf(x2));
+          } else if (kt + 2 == nk) {               // X(0) of the next tile: the X descriptor moves on one slab before the W one
+            rx = x_rsrc(nm0, has_next);
+            issue_x(rx, 0, xbuf(x2));
+          }
+        }
 #pragma unroll
         for (int i = 0; i < TN; ++i)
 #pragma unroll
           for (int j = 0; j < TM; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk & 1][i], xf[kk & 1][j], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int q = 0; q < TM * TN; ++q) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          if (kk < 3 && q < TM + TN) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          if (q >= TM * TN - nvk) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        }
         __builtin_amdgcn_sched_barrier(0);
       }
+      xi = x1;
+      wi ^= 1;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                               // the consumed buffer (it - 1) & 1 is free; the next tile's first slab has landed in it & 1
-    landed = true;
+    // after the loop: xi = buffer of the next tile's X(0) (= (xc + nk) % 3), wi = buffer of its W(0)
+    const int xfree1 = xi == 0 ? 2 : xi - 1;       // X(nk - 1): consumed last
+    const int xfree2 = xfree1 == 0 ? 2 : xfree1 - 1;   // X(nk - 2): consumed before; X(nk + 1) was never issued
+    xc = xi;
+    wc = wi;
+    __syncthreads();                               // every wave is done with the last slab: its areas become the staging
 
-    // ---- staging: q | k | v of this tile and head as bf16 rows in [consumed buffer | extra] (buffer 0) or [extra | buffer 1]
-    char* stg = lds + (((it + 1) & 1) ? BUF_BYTES : 0);
-    char* qk = stg;
-    char* vv = stg + QK_BYTES;
+    // ---- staging: q | k | v of this tile and head as bf16, three areas of 256 rows x 128 B (swizzled like the operand slabs)
+    char* sq = xbuf(xfree1);
+    char* sk = xbuf(xfree2);
+    char* sv = (wi ^ 1) ? lds + W0_OFF + WB_BYTES : lds + W0_OFF;     // free W slab 1: [spare | W1]; free W slab 0: [W0 | spare]
     {
       const bool seg2 = a.W2 && cm0 >= a.seg_split;
       const float* bias = seg2 ? a.bias2 : a.bias;
@@ -206,6 +220,8 @@ __global__ __launch_bounds__(NTH) void qkv_attn_kernel(const msclip_qkvattn_desc
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) {
         const int cb = wn + tn * 32;               // first column of this 32-column block within the head's 192 (wave-uniform)
+        char* area = cb < 64 ? sq : cb < 128 ? sk : sv;
+        const int c0 = cb & 63;                    // column within the 64-column area
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int c = cb + g * 8 + fhi * 4;
@@ -222,8 +238,7 @@ __global__ __launch_bounds__(NTH) void qkv_attn_kernel(const msclip_qkvattn_desc
             uint2 o;
             o.x = pack_bf16x2(v0, v1);
             o.y = pack_bf16x2(v2, v3);
-            if (cb < 128) *(uint2*)(qk + row * QK_STRIDE + c * 2) = o;
-            else *(uint2*)(vv + row * V_STRIDE + (c - 128) * 2) = o;
+            *(uint2*)(area + swz(row, (c0 >> 3) + g) + fhi * 8) = o;      // columns c0 + 8 g + 4 fhi .. + 3: chunk c0 / 8 + g, half fhi
           }
         }
       }
@@ -244,17 +259,17 @@ __global__ __launch_bounds__(NTH) void qkv_attn_kernel(const msclip_qkvattn_desc
       const int nkt = min(((khi + 31) >> 5) - kt0, MAXKT);
       bf16x8 qf[4];
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const bf16x8*)(qk + (q0 + fr) * QK_STRIDE + (kk * 2 + fhi) * 16);
+      for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const bf16x8*)(sq + swz(q0 + fr, kk * 2 + fhi));
       f32x16 s[MAXKT];
 #pragma unroll
       for (int j = 0; j < MAXKT; ++j) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[j][r] = 0.f;
         if (j < nkt) {
-          const char* kr = qk + ((kt0 + j) * 32 + fr) * QK_STRIDE + 128;
+          const int krow = (kt0 + j) * 32 + fr;
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk) {
-            const bf16x8 kf = *(const bf16x8*)(kr + (kk * 2 + fhi) * 16);
+            const bf16x8 kf = *(const bf16x8*)(sk + swz(krow, kk * 2 + fhi));
             s[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[j], 0, 0, 0);
           }
         }
@@ -291,9 +306,10 @@ __global__ __launch_bounds__(NTH) void qkv_attn_kernel(const msclip_qkvattn_desc
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
       // V^T fragment of k-step (key0 .. key0 + 15): lane (d = dt*32 + lane%32, half fhi) needs keys key0 + 4 fhi + {0..3, 8..11};
-      // a 16-lane group reads a 4-token x 16-channel block, lane i supplying (token i / 4, channels 4 (i % 4) ..) and receiving channel i
+      // a 16-lane group reads a 4-token x 16-channel block, lane i supplying (token i / 4, channels 4 (i % 4) ..) and receiving
+      // channel i: channels dt*32 + 16 dh + 4 (i % 4) = 16-byte chunk dt*4 + 2 dh + (i % 4) / 2, half (i % 4) % 2
       const int li = lane & 15, dh = (lane >> 4) & 1;
-      const char* vlane = vv + (4 * fhi + (li >> 2)) * V_STRIDE + (16 * dh + 4 * (li & 3)) * 2;
+      const int vtok = 4 * fhi + (li >> 2), vch = 2 * dh + ((li & 3) >> 1), vhalf = (li & 1) * 8;
 #pragma unroll
       for (int j = 0; j < MAXKT; ++j)
         if (j < nkt) {
@@ -302,10 +318,10 @@ __global__ __launch_bounds__(NTH) void qkv_attn_kernel(const msclip_qkvattn_desc
             bf16x8 pf;
 #pragma unroll
             for (int e = 0; e < 8; ++e) pf[e] = (__bf16)s[j][half * 8 + e];
-            const char* vk = vlane + ((kt0 + j) * 32 + half * 16) * V_STRIDE;
+            const int t0 = (kt0 + j) * 32 + half * 16 + vtok;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
-              const bf16x8 vf = ld_tr8(vk + dt * 64, vk + dt * 64 + 8 * V_STRIDE);
+              const bf16x8 vf = ld_tr8(sv + swz(t0, dt * 4 + vch) + vhalf, sv + swz(t0 + 8, dt * 4 + vch) + vhalf);
               o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
             }
           }
@@ -330,7 +346,7 @@ __global__ __launch_bounds__(NTH) void qkv_attn_kernel(const msclip_qkvattn_desc
         }
       }
     }
-    // (the next tile's first barrier orders these staging reads before the LDS-DMA into the region)
+    // (the next tile's first barrier orders these staging reads before the LDS-DMA into the areas)
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -376,7 +392,7 @@ extern "C" int msclip_qkvattn_tables(const int* cu, int nsamples, int split_samp
 
 extern "C" int msclip_qkv_attention(const msclip_qkvattn_desc* d, void* stream) {
   if (!d || !d->X || !d->W || !d->bias || !d->out || !d->cu || !d->tile_first || !d->rowseg || !d->zero) return MSCLIP_EINVAL;
-  if (d->heads <= 0 || d->K <= 0 || (d->K % BK) || (d->ldx % 8) || (d->ldw % 8) || d->ldw < d->K || (d->ldo % 8) ||
+  if (d->heads <= 0 || d->K <= 0 || (d->K % BK) || d->K < 3 * BK || (d->ldx % 8) || (d->ldw % 8) || d->ldw < d->K || (d->ldo % 8) ||
       d->ldo < d->heads * 64 || d->M <= 0 || (!d->ntiles_dev && d->ntiles <= 0))
     return MSCLIP_EINVAL;
   if (d->rowstat && !d->csum) return MSCLIP_EINVAL;
