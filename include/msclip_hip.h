@@ -185,7 +185,7 @@ int msclip_attention_varlen(const void* qkv, void* out, const int* cu, int nsamp
  *          head_dim^-0.5), 64..127: k_h, 128..191: v_h}; bias (and csum) fp32 [heads * 192] in the same order, 16-byte aligned;
  *   cu     [nsamples + 1] first row of every sample in X / out (ascending; cu[nsamples] = end of the live rows);
  *   rowseg [M][2] (first row, end row) of the sample that owns each live row; tile_first [ntiles + 1] first sample of every tile
- *          (both from msclip_qkvattn_tables); ntiles_dev (optional) = device copy of the tile count, read by the kernel when the
+ *          (both from msclip_qkvattn_tables with max_rows = 256); ntiles_dev (optional) = device copy of the tile count, read by the kernel when the
  *          host does not know it (packed captions);
  *   rows of samples that start at or behind causal_from_row attend causally (INT_MAX: none; 0: all);
  *   LayerNorm fold (optional, as msclip_gemm's consumer form): rowstat [M][2], csum; rows >= seg_split take W2 / bias2 / csum2.
@@ -214,10 +214,10 @@ typedef struct msclip_qkvattn_desc {
 int msclip_qkv_attention(const msclip_qkvattn_desc* desc, void* stream);
 
 /* rowseg / tile_first / *ntiles of msclip_qkv_attention from the samples' first rows cu [nsamples + 1]: whole samples packed
- * greedily into tiles of at most 256 rows, no tile straddling sample index split_sample (the image / text boundary; <= 0 or
+ * greedily into tiles of at most max_rows (256 or 128) rows, no tile straddling sample index split_sample (the image / text boundary; <= 0 or
  * >= nsamples: none).  *ntiles = -1 when more than max_tiles tiles would be needed (tile_first holds max_tiles + 1 ints). */
 int msclip_qkvattn_tables(const int* cu, int nsamples, int split_sample, int* rowseg, int* tile_first, int* ntiles, int max_tiles,
-                          void* stream);
+                          int max_rows, void* stream);
 
 /* msclip_attention_lastq over packed captions: sample b's keys are the rows row_base + cu[b] .. row_base + cu[b+1] of qkv
  * (all of them: the query is the caption's last live row, the EOT position). */

@@ -31,7 +31,6 @@ constexpr int XI = BM * 8 / NTH, WI = BN * 8 / NTH;   // LDS-DMA pieces per lane
 constexpr int XB_BYTES = BM * BK * 2, WB_BYTES = BN * BK * 2, SPARE_BYTES = 16384;
 constexpr int W0_OFF = 3 * XB_BYTES, W1_OFF = W0_OFF + WB_BYTES + SPARE_BYTES;
 static_assert(W1_OFF + WB_BYTES == 163840 && WB_BYTES + SPARE_BYTES >= XB_BYTES, "LDS map");
-constexpr int MAXKT = 5;                           // key tiles a 32-query tile can span: samples <= 96 rows -> <= 127 rows unaligned
 
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4v;
 
@@ -42,6 +41,119 @@ __device__ __forceinline__ bf16x8 ld_tr8(const char* p0, const char* p1) {   // 
 }
 // byte offset of (row, 16-byte chunk) in a 128-byte-row area with the operand slabs' swizzle
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+// The attention of one staged tile (areas of q, k, v: 128 bytes per row, chunk-swizzled): the workgroup's waves take the tile's
+// SAMPLES round-robin (sample = rows cu[s] .. cu[s + 1] of the token matrix, at most 96), one wave per (sample, head) like
+// attention.hip's attn_kernel but with every operand in LDS: per 32-query tile S^T = K Q^T over the sample's own key tiles only
+// (the causal ones for a caption), softmax in registers, O^T = V^T P^T with the V^T fragments read straight from the row-major
+// v rows by ds_read_b64_tr_b16.  (First version: wave w took the tile's rows 32 w .. 32 w + 31 whatever samples they belonged
+// to, with a block-diagonal mask -- a 32-row slice of 50-row samples spans two of them, so 60 % of its scores were masked and all
+// eight waves shared the SIMDs' VALU: ~4 us per tile and head against ~1 us here.)
+__device__ __forceinline__ void attend_samples(const char* sq, const char* sk, const char* sv, const int* __restrict__ cu, int s0,
+                                               int s1, int causal_from_row, bf16_t* __restrict__ out, int ldo, int m0, int area_rows,
+                                               int chead, int wave, int nwaves, int lane) {
+  const int fr = lane & 31, fhi = lane >> 5;
+  const int li = lane & 15, dh = (lane >> 4) & 1;
+  const int vtok = 4 * fhi + (li >> 2), vch = 2 * dh + ((li & 3) >> 1), vhalf = (li & 1) * 8;
+  for (int smp = s0 + wave; smp < s1; smp += nwaves) {
+    const int c0 = __builtin_amdgcn_readfirstlane(cu[smp]);
+    const int L = min(__builtin_amdgcn_readfirstlane(cu[smp + 1]) - c0, 96);
+    const int r0 = c0 - m0;                        // first row of the sample inside the staged tile
+    const bool causal = c0 >= causal_from_row;
+    const int ntq = (L + 31) >> 5;
+    bf16x8 kf[3][4];
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt)
+      if (kt < ntq) {
+        const int krow = r0 + min(kt * 32 + fr, L - 1);      // clamped: padded keys are masked
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) kf[kt][kk] = *(const bf16x8*)(sk + swz(krow, kk * 2 + fhi));
+      }
+#pragma unroll
+    for (int qt = 0; qt < 3; ++qt)
+      if (qt < ntq) {
+        const int q = qt * 32 + fr;
+        const int qrow = r0 + min(q, L - 1);       // clamped: padded queries are never stored
+        bf16x8 qf[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const bf16x8*)(sq + swz(qrow, kk * 2 + fhi));
+        const int nkt = causal ? qt + 1 : ntq;
+        f32x16 s[3];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt)
+          if (kt < nkt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][kk], qf[kk], s[kt], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
+              const bool ok = key < L && (!causal || key <= q);
+              s[kt][r] = ok ? s[kt][r] : -INFINITY;
+              mx = fmaxf(mx, s[kt][r]);
+            }
+          }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt)
+          if (kt < nkt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float p = __expf(s[kt][r] - mx);
+              s[kt][r] = p;
+              sum += p;
+            }
+          }
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.f / sum;
+        f32x16 o[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+        // V^T fragment of k-step (key0 .. key0 + 15): lane (d = dt*32 + lane%32, half fhi) needs keys key0 + 4 fhi + {0..3, 8..11};
+        // a 16-lane group reads a 4-token x 16-channel block, lane i supplying (token i / 4, channels 4 (i % 4) ..) and receiving
+        // channel i: channels dt*32 + 16 dh + 4 (i % 4) = 16-byte chunk dt*4 + 2 dh + (i % 4) / 2, half (i % 4) % 2.  Token rows
+        // behind the staged area belong to masked keys (P = 0): clamped to the area's last row.
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt)
+          if (kt < nkt) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+              bf16x8 pf;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) pf[e] = (__bf16)s[kt][half * 8 + e];
+              const int t0 = min(r0 + kt * 32 + half * 16 + vtok, area_rows - 1);
+              const int t1 = min(r0 + kt * 32 + half * 16 + vtok + 8, area_rows - 1);
+#pragma unroll
+              for (int dt = 0; dt < 2; ++dt) {
+                const bf16x8 vf = ld_tr8(sv + swz(t0, dt * 4 + vch) + vhalf, sv + swz(t1, dt * 4 + vch) + vhalf);
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
+              }
+            }
+          }
+        bf16_t* orow = out + (size_t)(c0 + min(q, L - 1)) * ldo + chead * 64;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          unsigned pk[4][2];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            pk[g][0] = pack_bf16x2(o[dt][g * 4 + 0] * inv, o[dt][g * 4 + 1] * inv);
+            pk[g][1] = pack_bf16x2(o[dt][g * 4 + 2] * inv, o[dt][g * 4 + 3] * inv);
+          }
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {         // 8 consecutive d per lane (see attention.hip)
+            const auto x = __builtin_amdgcn_permlane32_swap(pk[2 * s2][0], pk[2 * s2 + 1][0], false, false);
+            const auto y = __builtin_amdgcn_permlane32_swap(pk[2 * s2][1], pk[2 * s2 + 1][1], false, false);
+            if (q < L) *(uint4*)(orow + dt * 32 + s2 * 16 + fhi * 8) = make_uint4(x[0], y[0], x[1], y[1]);
+          }
+        }
+      }
+  }
+}
 
 __global__ __launch_bounds__(NTH) void qkv_attn_kernel(const msclip_qkvattn_desc a) {
   __shared__ __attribute__((aligned(1024))) char lds[163840];
@@ -60,14 +172,14 @@ __global__ __launch_bounds__(NTH) void qkv_attn_kernel(const msclip_qkvattn_desc
 
   // work item -> (tile, head): XCD-aware bijective remap (consecutive ids -- the heads of one tile, which share its X rows --
   // run on one XCD), as gemm_kernel's tile_origin
-  auto work_origin = [&](int t, int& m0, int& rows, int& head) {
+  auto work_origin = [&](int t, int& m0, int& smp0, int& smp1, int& head) {
     const int q = nwork >> 3, r = nwork & 7, x = t & 7;
     const int id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (t >> 3);
     const int tile = id / H;
     head = id - tile * H;
-    const int s0 = a.tile_first[tile], s1 = a.tile_first[tile + 1];
-    m0 = a.cu[s0];
-    rows = a.cu[s1] - m0;
+    smp0 = a.tile_first[tile];
+    smp1 = a.tile_first[tile + 1];
+    m0 = a.cu[smp0];
   };
 
   // loader: lane owns (row = (i * 8 + wave) * 8 + lane / 8, physical 16-byte chunk lane % 8 = logical chunk ^ ((row >> 1) & 7)).
@@ -103,11 +215,11 @@ __global__ __launch_bounds__(NTH) void qkv_attn_kernel(const msclip_qkvattn_desc
   const int fr = lane & 31, fsw = (lane >> 1) & 7, fhi = lane >> 5;
 
   int t = blockIdx.x;
-  int m0 = 0, rows = 0, head = 0;
+  int m0 = 0, smp0 = 0, smp1 = 0, head = 0;
   int xc = 0, wc = 0;                              // buffers of X slab 0 / W slab 0 of the current tile
   __amdgpu_buffer_rsrc_t rx = x_rsrc(0, false), rw = w_rsrc(0, 0, false);
   if (t < nwork) {
-    work_origin(t, m0, rows, head);
+    work_origin(t, m0, smp0, smp1, head);
     rx = x_rsrc(m0, true);
     rw = w_rsrc(m0, head, true);
     issue_x(rx, 0, xbuf(0));
@@ -121,14 +233,15 @@ __global__ __launch_bounds__(NTH) void qkv_attn_kernel(const msclip_qkvattn_desc
       for (int j = 0; j < TM; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const int cm0 = m0, crows = rows, chead = head;
+    const int cm0 = m0, csmp0 = smp0, csmp1 = smp1, chead = head;
     const bool has_next = t + (int)gridDim.x < nwork;
     // the next work item's origin is fetched HERE (two dependent loads) and pinned in scalar registers: its use near the end of
     // the K loop must not turn into a wait for every LDS-DMA piece in flight
-    int nm0 = 0, nrows = 0, nhead = 0;
-    if (has_next) work_origin(t + gridDim.x, nm0, nrows, nhead);
+    int nm0 = 0, nsmp0 = 0, nsmp1 = 0, nhead = 0;
+    if (has_next) work_origin(t + gridDim.x, nm0, nsmp0, nsmp1, nhead);
     nm0 = __builtin_amdgcn_readfirstlane(nm0);
-    nrows = __builtin_amdgcn_readfirstlane(nrows);
+    nsmp0 = __builtin_amdgcn_readfirstlane(nsmp0);
+    nsmp1 = __builtin_amdgcn_readfirstlane(nsmp1);
     nhead = __builtin_amdgcn_readfirstlane(nhead);
     int xi = xc, wi = wc;                          // buffers of the slab being computed
     for (int kt = 0; kt < nk; ++kt) {
@@ -168,7 +281,7 @@ __global__ __launch_bounds__(NTH) void qkv_attn_kernel(const msclip_qkvattn_desc
           if (kt + 1 < nk) {
             issue_w(rw, kt + 1, wbuf(wi ^ 1));
           } else {                                 // the next tile's W(0) (an empty descriptor behind the last work item)
-            m0 = nm0; rows = nrows; head = nhead;
+            m0 = nm0; smp0 = nsmp0; smp1 = nsmp1; head = nhead;
             rw = w_rsrc(m0, head, has_next);
             issue_w(rw, 0, wbuf(wi ^ 1));
           }
@@ -245,117 +358,17 @@ __global__ __launch_bounds__(NTH) void qkv_attn_kernel(const msclip_qkvattn_desc
     }
     __syncthreads();
 
-    // ---- attention: wave w takes the tile's query rows 32 w .. 32 w + 31
-    const int q0 = wave * 32;
-    if (q0 < crows) {
-      const int qrow = min(q0 + fr, crows - 1);    // clamped: rows behind the tile's last whole sample are never stored
-      const int2 seg = *(const int2*)(a.rowseg + 2 * (size_t)(cm0 + qrow));
-      const bool causal = seg.x >= a.causal_from_row;
-      const int lo = seg.x - cm0;
-      const int hi = causal ? qrow + 1 : seg.y - cm0;
-      const int klo = __builtin_amdgcn_readfirstlane(lo);
-      const int khi = __builtin_amdgcn_readlane(hi, 31);
-      const int kt0 = klo >> 5;
-      const int nkt = min(((khi + 31) >> 5) - kt0, MAXKT);
-      bf16x8 qf[4];
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const bf16x8*)(sq + swz(q0 + fr, kk * 2 + fhi));
-      f32x16 s[MAXKT];
-#pragma unroll
-      for (int j = 0; j < MAXKT; ++j) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[j][r] = 0.f;
-        if (j < nkt) {
-          const int krow = (kt0 + j) * 32 + fr;
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk) {
-            const bf16x8 kf = *(const bf16x8*)(sk + swz(krow, kk * 2 + fhi));
-            s[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[j], 0, 0, 0);
-          }
-        }
-      }
-      float mx = -INFINITY;
-#pragma unroll
-      for (int j = 0; j < MAXKT; ++j)
-        if (j < nkt) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int key = (kt0 + j) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
-            const bool ok = key >= lo && key < hi;
-            s[j][r] = ok ? s[j][r] : -INFINITY;
-            mx = fmaxf(mx, s[j][r]);
-          }
-        }
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      float sum = 0.f;
-#pragma unroll
-      for (int j = 0; j < MAXKT; ++j)
-        if (j < nkt) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float p = __expf(s[j][r] - mx);
-            s[j][r] = p;
-            sum += p;
-          }
-        }
-      sum += __shfl_xor(sum, 32, 64);
-      const float inv = 1.f / sum;
-      f32x16 o[2];
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-      // V^T fragment of k-step (key0 .. key0 + 15): lane (d = dt*32 + lane%32, half fhi) needs keys key0 + 4 fhi + {0..3, 8..11};
-      // a 16-lane group reads a 4-token x 16-channel block, lane i supplying (token i / 4, channels 4 (i % 4) ..) and receiving
-      // channel i: channels dt*32 + 16 dh + 4 (i % 4) = 16-byte chunk dt*4 + 2 dh + (i % 4) / 2, half (i % 4) % 2
-      const int li = lane & 15, dh = (lane >> 4) & 1;
-      const int vtok = 4 * fhi + (li >> 2), vch = 2 * dh + ((li & 3) >> 1), vhalf = (li & 1) * 8;
-#pragma unroll
-      for (int j = 0; j < MAXKT; ++j)
-        if (j < nkt) {
-#pragma unroll
-          for (int half = 0; half < 2; ++half) {
-            bf16x8 pf;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) pf[e] = (__bf16)s[j][half * 8 + e];
-            const int t0 = (kt0 + j) * 32 + half * 16 + vtok;
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-              const bf16x8 vf = ld_tr8(sv + swz(t0, dt * 4 + vch) + vhalf, sv + swz(t0 + 8, dt * 4 + vch) + vhalf);
-              o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
-            }
-          }
-        }
-      {
-        const int q = q0 + fr;
-        bf16_t* orow = (bf16_t*)a.out + (size_t)(cm0 + qrow) * a.ldo + chead * 64;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          unsigned pk[4][2];
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            pk[g][0] = pack_bf16x2(o[dt][g * 4 + 0] * inv, o[dt][g * 4 + 1] * inv);
-            pk[g][1] = pack_bf16x2(o[dt][g * 4 + 2] * inv, o[dt][g * 4 + 3] * inv);
-          }
-#pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) {         // 8 consecutive d per lane (see attention.hip)
-            const auto x = __builtin_amdgcn_permlane32_swap(pk[2 * s2][0], pk[2 * s2 + 1][0], false, false);
-            const auto y = __builtin_amdgcn_permlane32_swap(pk[2 * s2][1], pk[2 * s2 + 1][1], false, false);
-            if (q < crows) *(uint4*)(orow + dt * 32 + s2 * 16 + fhi * 8) = make_uint4(x[0], y[0], x[1], y[1]);
-          }
-        }
-      }
-    }
+    attend_samples(sq, sk, sv, a.cu, csmp0, csmp1, a.causal_from_row, (bf16_t*)a.out, a.ldo, cm0, BM, chead, wave, NW, lane);
     // (the next tile's first barrier orders these staging reads before the LDS-DMA into the areas)
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // rowseg[m] = (first row, end row) of the sample that owns row m; tile_first / *ntiles: greedy packing of whole samples into tiles
-// of at most 256 rows, a tile never straddling `split_sample` (the image / text boundary: own LayerNorm parameters per modality).
+// of at most max_rows rows, a tile never straddling `split_sample` (the image / text boundary: own LayerNorm parameters per modality).
 __global__ __launch_bounds__(256) void qkvattn_tables_kernel(const int* __restrict__ cu, int nsamples, int split_sample,
                                                              int* __restrict__ rowseg, int* __restrict__ tile_first,
-                                                             int* __restrict__ ntiles, int max_tiles) {
+                                                             int* __restrict__ ntiles, int max_tiles, int max_rows) {
   const int total = cu[nsamples];
   for (int m = blockIdx.x * 256 + threadIdx.x; m < total; m += gridDim.x * 256) {
     int lo = 0, hi = nsamples;                     // largest s with cu[s] <= m
@@ -372,7 +385,7 @@ __global__ __launch_bounds__(256) void qkvattn_tables_kernel(const int* __restri
       tile_first[nt++] = s;
       const int base = cu[s];
       int e = s + 1;
-      while (e < nsamples && cu[e + 1] - base <= 256 && e != split_sample) ++e;
+      while (e < nsamples && cu[e + 1] - base <= max_rows && e != split_sample) ++e;
       s = e;
     }
     tile_first[nt] = nsamples;
@@ -383,10 +396,11 @@ __global__ __launch_bounds__(256) void qkvattn_tables_kernel(const int* __restri
 }  // namespace
 
 extern "C" int msclip_qkvattn_tables(const int* cu, int nsamples, int split_sample, int* rowseg, int* tile_first, int* ntiles,
-                                     int max_tiles, void* stream) {
-  if (!cu || !rowseg || !tile_first || !ntiles || nsamples <= 0 || max_tiles <= 0) return MSCLIP_EINVAL;
+                                     int max_tiles, int max_rows, void* stream) {
+  if (!cu || !rowseg || !tile_first || !ntiles || nsamples <= 0 || max_tiles <= 0 || (max_rows != 256 && max_rows != 128))
+    return MSCLIP_EINVAL;
   hipLaunchKernelGGL(qkvattn_tables_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, cu, nsamples, split_sample, rowseg,
-                     tile_first, ntiles, max_tiles);
+                     tile_first, ntiles, max_tiles, max_rows);
   return msclip_launch_status();
 }
 

@@ -161,7 +161,7 @@ def lib():
         L.msclip_attention_bwd_varlen.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]
         L.msclip_embed_tokens_bwd_packed.argtypes = [vp, vp, ci, vp, vp, vp, ci, ci, ci, ci, vp]
         L.msclip_qkv_attention.argtypes = [ctypes.POINTER(QkvAttnDesc), vp]
-        L.msclip_qkvattn_tables.argtypes = [vp, ci, ci, vp, vp, vp, ci, vp]
+        L.msclip_qkvattn_tables.argtypes = [vp, ci, ci, vp, vp, vp, ci, ci, vp]
         L.msclip_abi_version.restype = ci
         L.msclip_build_arch.restype = ctypes.c_char_p
         for name in EXPORTS:
@@ -708,17 +708,17 @@ class QkvAttnTables:
     """Row / tile tables of msclip_qkv_attention for one batch layout: cu int32 [nsamples + 1] = first row of every sample
     (device); split_sample = first sample of the second modality (0: none)."""
 
-    def __init__(self, cu, nsamples, split_sample=0, total_rows=None):
+    def __init__(self, cu, nsamples, split_sample=0, total_rows=None, max_rows=256):
         dev = cu.device
         assert cu.dtype == torch.int32 and cu.numel() >= nsamples + 1
         rows = int(total_rows) if total_rows is not None else int(cu[nsamples])
-        self.cu, self.nsamples = cu, nsamples
+        self.cu, self.nsamples, self.max_rows = cu, nsamples, max_rows
         self.max_tiles = nsamples + 1
         self.rowseg = torch.zeros(max(rows, 1), 2, dtype=torch.int32, device=dev)
         self.tile_first = torch.zeros(self.max_tiles + 1, dtype=torch.int32, device=dev)
         self.ntiles = torch.zeros(1, dtype=torch.int32, device=dev)
         _check(lib().msclip_qkvattn_tables(_p(cu), nsamples, split_sample, _p(self.rowseg), _p(self.tile_first), _p(self.ntiles),
-                                           self.max_tiles, _stream()), "msclip_qkvattn_tables")
+                                           self.max_tiles, max_rows, _stream()), "msclip_qkvattn_tables")
 
 
 def qkv_attention(x, w_hm, b_hm, out, tables, heads, *, causal_from_row=INT_MAX, fold_in=None, M=None):
