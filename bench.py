@@ -113,12 +113,14 @@ def hbm_kernel_rates(args, B, width, Lv, Lt, g, Mt_live=None, Mt_rows=None):
         "attn_kernel<1, true": (txt, 4 * Mt_live * D * 2),
         "attn_kernel<2, false": ("image attention core (50 tokens)", 4 * Mv * D * 2),
         "attn_wg_kernel": ("image attention core (197 tokens)", 4 * Mv * D * 2),
-        "ln_pair_kernel": ("LayerNorm over all token rows: fp32 in, bf16 out", (Mv + Mt_rows) * D * 6),
+        "ln_pair_kernel": ("LayerNorm pass (row count differs per call site since the LayerNorm fold: not rated)", None),
         "ln_stats_kernel": ("LayerNorm pass of one tower's rows (+ fold state; adapter layers also copy the fp32 row)", None),
         "front_ws_kernel<0": ("stem conv1 + parallel stage 0 + stem stage 0 in one pass: fp32 image in, two bf16 maps out",
                               B * (3 * 224 * 224 * 4 + 112 * 112 * (D // 16) * 2 + 56 * 56 * (D // 8) * 2)),
         "adapter_gridrow_kernel": ("lateral adapter bottom half + sum + ln_adapt + the block's ln_1: x, t fp32 in, fp32 stream + bf16 operand out",
                                    Mv * D * (4 * 3 + 2)),
+        "adapter_sample_kernel": ("lateral adapter bottom half + sum + ln_adapt + the block's ln_1 (workgroup per sample): x, t fp32 in, fp32 stream + bf16 operand out",
+                                  Mv * D * (4 * 3 + 2)),
     }
     d = tempfile.mkdtemp(prefix="msclip_ktrace_", dir="/tmp")
     cmd = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "-o", "run", "--",
