@@ -447,38 +447,14 @@ __global__ __launch_bounds__(256, 2) void attn_wg_kernel(const bf16_t* __restric
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float mxl = mx * 1.44269504f;
     float sum = 0.f;
-    if constexpr (CAUSAL) {
-      // (no configuration runs causal sequences this long; the packed form below costs this instantiation 60 bytes of scratch,
-      //  and scratch accesses would sit in the hand-counted VM queue of the Q prefetch)
 #pragma unroll
-      for (int kt = 0; kt < NT; ++kt)
+    for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], 1.44269504f, -mxl));
-          s[kt][r] = p;
-          sum += p;
-        }
-    } else {
-      // the scale + shift and the row sum on PAIRS of values (v_pk_fma_f32 / v_pk_add_f32: two values per VALU slot); the
-      // exponential itself is the quarter-rate instruction it is.  Per value: 0.5 + 4 + 0.5 slots instead of 1 + 4 + 1.
-      typedef __attribute__((ext_vector_type(2))) float f32x2v;
-      const f32x2v l2e = {1.44269504f, 1.44269504f}, nmx = {-mxl, -mxl};
-      f32x2v sum2 = {0.f, 0.f};
-#pragma unroll
-      for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          const f32x2v sv = {s[kt][r], s[kt][r + 1]};
-          const f32x2v y = __builtin_elementwise_fma(sv, l2e, nmx);
-          f32x2v p;
-          p[0] = __builtin_amdgcn_exp2f(y[0]);
-          p[1] = __builtin_amdgcn_exp2f(y[1]);
-          s[kt][r] = p[0];
-          s[kt][r + 1] = p[1];
-          sum2 += p;
-        }
-      sum = sum2[0] + sum2[1];
-    }
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], 1.44269504f, -mxl));
+        s[kt][r] = p;
+        sum += p;
+      }
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.f / sum;
     f32x16 o[2];
