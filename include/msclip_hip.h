@@ -484,6 +484,7 @@ int msclip_bn_fold_bwd(const float* G, long long ldg, const float* w_raw, int co
 int msclip_bn_finish(const float* sums, int r, int C, long long n, const float* gamma, const float* beta, float eps, float* out,
                      void* stream);
 
+#define MSCLIP_ABI_VERSION 5   /* 5 (round 5): packed-caption entry points, msclip_qkv_attention / msclip_qkvattn_tables, single-launch msclip_colsum */
 int msclip_abi_version(void);
 const char* msclip_build_arch(void);
 

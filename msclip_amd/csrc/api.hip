@@ -3,7 +3,7 @@
 
 #include "../../include/msclip_hip.h"
 
-extern "C" int msclip_abi_version(void) { return 4; }
+extern "C" int msclip_abi_version(void) { return MSCLIP_ABI_VERSION; }
 extern "C" const char* msclip_build_arch(void) { return "gfx950"; }
 
 extern "C" int msclip_stream_priority_range(int* least, int* greatest) {

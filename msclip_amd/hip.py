@@ -14,6 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MSCLIP_HIP_LIB") or os.path.join(_HERE, "csrc", "libmsclip_hip.so")   # override: kernel A/B probes only
 INT_MAX = 2 ** 31 - 1
+ABI_VERSION = 5                                          # include/msclip_hip.h MSCLIP_ABI_VERSION
 
 EXPORTS = (
     "msclip_gemm", "msclip_gemm_f8", "msclip_layernorm_stats", "msclip_rowstat_finalize", "msclip_layernorm_f8", "msclip_quant_f8_rows", "msclip_gemm_variant", "msclip_attention", "msclip_attention_lastq", "msclip_layernorm", "msclip_layernorm_split", "msclip_embed_tokens", "msclip_fill_cls",
@@ -163,6 +164,9 @@ def lib():
         L.msclip_qkv_attention.argtypes = [ctypes.POINTER(QkvAttnDesc), vp]
         L.msclip_qkvattn_tables.argtypes = [vp, ci, ci, vp, vp, vp, ci, ci, vp]
         L.msclip_abi_version.restype = ci
+        if L.msclip_abi_version() != ABI_VERSION:          # a stale build of the library (the struct layouts / entry points moved on)
+            raise HipUnavailable(f"{LIB_PATH} has ABI version {L.msclip_abi_version()}, this binding needs {ABI_VERSION}: rebuild "
+                                 "(bash msclip_amd/csrc/build.sh)")
         L.msclip_build_arch.restype = ctypes.c_char_p
         for name in EXPORTS:
             if name not in ("msclip_build_arch", "msclip_gemm_variant"):
