@@ -462,6 +462,28 @@ int msclip_adamw(float* p, const float* g, float* m, float* v, long long n, floa
 int msclip_adamw_multi(const msclip_adamw_tensor* tensors, int count, float beta1, float beta2, float eps, int step,
                        void* stream);
 
+/* ---- Re-packing the convolutional side's derived weights after an optimizer step in ONE launch (msclip_amd/packing.py's folds:
+ * eval-mode BatchNorm into the filter, M.py:1825-1861 / 1920-1936; the stem stages' 1x1 shortcut into the 3x3 centre tap; layouts).
+ * One item per derived tensor, the table and the per-item first-block table live in DEVICE memory (built once: sources are the
+ * module's parameter storage, destinations the engine's persistent operands).  BatchNorm 1 = (g, b, mu, var, eps) over the
+ * output channels: scale = g / sqrt(var + eps), shift = b - mu scale (IEEE fp32, no contraction).
+ *   out, mode 0: bf16 [co][kpad], k = (kh, kw, ci), zero padded: w scale (+ w2 [co][ci] scale2 at the centre tap);
+ *        mode 1: fp32 transposed out[k * ld + col0 + o], k = (ci, kh, kw): w scale;          out NULL: no weight output;
+ *   bias_out[bias_col0 + o], bias_mode 1: shift; 2: shift + shift2 (BatchNorm 2); 3: sum_c w[o][c] shift[c] with BatchNorm 1
+ *   over the INPUT channels (a pointwise conv behind a BatchNorm); 0 / bias_out NULL: none.
+ * blk_start [n_items + 1]: first workgroup of every item (ceil(weight elements / 1024), at least 1), ascending. */
+typedef struct msclip_pack_item {
+  const float* w;
+  const float *g, *b, *mu, *var;
+  const float* w2;
+  const float *g2, *b2, *mu2, *var2;
+  void* out;
+  float* bias_out;
+  float eps, eps2;
+  int co, ci, kh, kw, kpad, mode, col0, ld, bias_mode, bias_col0;
+} msclip_pack_item;
+int msclip_pack_weights(const msclip_pack_item* items_dev, const int* blk_start_dev, int n_items, int n_blocks, void* stream);
+
 /* HIP streams with an explicit priority on the current device.  The training step runs its weight-gradient jobs beside the
  * dgrad chain (the role torch DDP's / autograd's side streams play under the reference's lib/core/function.py:66-77
  * backward); streams of the LOWEST priority draw their hardware queue from a pool of their own, so the overlap does not
@@ -484,7 +506,7 @@ int msclip_bn_fold_bwd(const float* G, long long ldg, const float* w_raw, int co
 int msclip_bn_finish(const float* sums, int r, int C, long long n, const float* gamma, const float* beta, float eps, float* out,
                      void* stream);
 
-#define MSCLIP_ABI_VERSION 5   /* 5 (round 5): packed-caption entry points, msclip_qkv_attention / msclip_qkvattn_tables, single-launch msclip_colsum */
+#define MSCLIP_ABI_VERSION 5   /* 5 (round 5): packed-caption entry points, msclip_qkv_attention / msclip_qkvattn_tables, msclip_pack_weights, single-launch msclip_colsum */
 int msclip_abi_version(void);
 const char* msclip_build_arch(void);
 

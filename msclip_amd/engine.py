@@ -160,7 +160,20 @@ class Engine:
         if self.fp8 or getattr(self, "_sdv", None) is None or self.tensor_identity() != self._sdv_ident:
             return self.refresh(force=True)          # (a re-assigned parameter: the blocks' copies / aliases are of the old tensor)
         with torch.cuda.device(self.dev), torch.no_grad():
-            self._pack(self.model, blocks=False)
+            plan = getattr(self, "_pack_plan", None)
+            if plan is not None and not self.patch and os.environ.get("MSCLIP_REPACK_TABLE", "1") != "0":
+                # round 5: every derived conv-side tensor rewritten in place by ONE launch (msclip_pack_weights), the two
+                # projection heads by a transposing copy each; everything else the launches read is a view of the parameters
+                plan.run()
+                sd = self._sdv
+                self.w_vproj.copy_(sd["visual.proj"].t())
+                self.w_tproj.copy_(sd["text_projection"].t())
+                self._foldw = {}                     # (the LayerNorm fold's gamma-folded weights are of the old values)
+                self._ls_host.copy_(self.model.logit_scale.detach().exp().reshape(1), non_blocking=True)
+                self._ls_event = torch.cuda.Event()
+                self._ls_event.record(torch.cuda.current_stream(self.dev))
+            else:
+                self._pack(self.model, blocks=False)
         self._stamp = self._fingerprint()
         self._ws = {k: w for k, w in self._ws.items() if not (isinstance(k, tuple) and k and k[0] == "graph")}
         return True
@@ -292,6 +305,45 @@ class Engine:
             assert self.par_hw[j] == self.g * k, (self.par_hw[j], self.g, k)
             self.adapters.append(dict(pool=pool.to(dev), k=k, pw=pw.to(dev), dww=dww.to(dev), dwb=dwb.to(dev),
                                       ln=_LN(vt.parallel_lateral_adapter[j].ln_adapt), C=pool.shape[1]))
+        self._pack_plan = self._build_pack_plan(sd, dev)
+
+    def _build_pack_plan(self, sd, dev):
+        """The item table of msclip_pack_weights for every derived conv-side tensor packed above (same folds, same layouts, written
+        IN PLACE into the tensors the launches read): what repack_after_optimizer runs instead of ~170 ATen launches.  None when a
+        source is not plain fp32 device storage (then the tensor-algebra pack stays)."""
+        def bn(prefix):
+            return tuple(sd[prefix + k] for k in (".weight", ".bias", ".running_mean", ".running_var"))
+        try:
+            plan = hip.PackPlan(dev)
+            sp, pp = "visual.transformer.resblocks.0", "visual.transformer.parallel_branch_v.0"
+            c1 = self.dual_w.shape[1] // 2
+            plan.add(sd[sp + ".conv1.weight"], self.dual_w, bn=bn(sp + ".bn1"), mode=1, col0=0, ld=2 * c1, bias_out=self.dual_b, bias_mode=1)
+            plan.add(sd[pp + ".conv.weight"], self.dual_w, bn=bn(pp + ".bn"), mode=1, col0=c1, ld=2 * c1, bias_out=self.dual_b, bias_mode=1,
+                     bias_col0=c1)
+            for i, spec in enumerate(self.stem_specs):
+                pre = f"{sp}.resnet_stage.conv_{i}"
+                plan.add(sd[pre + ".conv1.weight"], spec.weight, bn=bn(pre + ".bn1"), w2=sd[pre + ".downsample.0.weight"],
+                         bn2=bn(pre + ".downsample.1"), bias_out=spec.bias, bias_mode=2)
+            plan.add(sd[sp + ".last_conv.weight"], self.w_last)
+            for j in range(1, 5):
+                pre = f"visual.transformer.parallel_branch_v.{j}.resnet_stage.conv_0"
+                k1, k2, kr, k3 = self.par_specs[j]
+                for spec, conv, b in ((k1, "conv1", "bn1"), (k2, "conv2", "bn2"), (kr, "residual_conv", "residual_bn"), (k3, "conv3", "bn3")):
+                    plan.add(sd[f"{pre}.{conv}.weight"], spec.weight, bn=bn(f"{pre}.{b}"), eps=1e-6, bias_out=spec.bias, bias_mode=1)
+                plan.add(sd[pre + ".conv3.weight"], None, bn=bn(pre + ".bn3"), eps=1e-6, bn2=bn(pre + ".residual_bn"), eps2=1e-6,
+                         bias_out=self.par_b3r[j], bias_mode=2)
+            for j, a in enumerate(self.adapters):
+                pre = f"visual.transformer.parallel_lateral_adapter.{j}"
+                C = a["C"]
+                plan.add(sd[pre + ".top2bottom_dw_conv.conv.weight"], a["pool"], bn=bn(pre + ".top2bottom_dw_conv.bn"), mode=1, ld=C)
+                plan.add(sd[pre + ".top2bottom_pw_conv.conv.weight"], a["pw"].weight)
+                plan.add(sd[pre + ".top2bottom_pw_conv.conv.weight"], None, bn=bn(pre + ".top2bottom_dw_conv.bn"), bias_out=a["pw"].bias,
+                         bias_mode=3)
+                plan.add(sd[pre + ".bottom_dw_conv.conv.weight"], a["dww"], bn=bn(pre + ".bottom_dw_conv.bn"), mode=1, ld=self.D,
+                         bias_out=a["dwb"], bias_mode=1)
+            return plan.finalize()
+        except (AssertionError, KeyError):
+            return None
 
 
     @property

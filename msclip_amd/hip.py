@@ -28,7 +28,7 @@ EXPORTS = (
     "msclip_bn_bwd_reduce", "msclip_bn_bwd_dx", "msclip_bn_fold_bwd", "msclip_bn_finish", "msclip_bn_finish_tiled", "msclip_bn_bwd_finish",
     "msclip_text_lengths", "msclip_embed_tokens_packed", "msclip_attention_varlen", "msclip_attention_lastq_varlen",
     "msclip_attention_bwd_varlen", "msclip_embed_tokens_bwd_packed",
-    "msclip_qkv_attention", "msclip_qkvattn_tables",
+    "msclip_qkv_attention", "msclip_qkvattn_tables", "msclip_pack_weights",
     "msclip_abi_version", "msclip_build_arch",
     "msclip_stream_priority_range", "msclip_stream_create", "msclip_stream_destroy",
 )
@@ -163,6 +163,7 @@ def lib():
         L.msclip_embed_tokens_bwd_packed.argtypes = [vp, vp, ci, vp, vp, vp, ci, ci, ci, ci, vp]
         L.msclip_qkv_attention.argtypes = [ctypes.POINTER(QkvAttnDesc), vp]
         L.msclip_qkvattn_tables.argtypes = [vp, ci, ci, vp, vp, vp, ci, ci, vp]
+        L.msclip_pack_weights.argtypes = [vp, vp, ci, ci, vp]
         L.msclip_abi_version.restype = ci
         if L.msclip_abi_version() != ABI_VERSION:          # a stale build of the library (the struct layouts / entry points moved on)
             raise HipUnavailable(f"{LIB_PATH} has ABI version {L.msclip_abi_version()}, this binding needs {ABI_VERSION}: rebuild "
@@ -1201,6 +1202,81 @@ def bn_fold_bwd(G, w_raw, dshift, gamma, mean, var, eps):
     _check(lib().msclip_bn_fold_bwd(_p(Gm), Gm.stride(0), _p(w_raw), cout, K, _p(dshift), _p(gamma), _p(mean), _p(var), eps, _p(dW),
                                     _p(dgb[0]), _p(dgb[1]), _stream()), "msclip_bn_fold_bwd")
     return dW, dgb[0], dgb[1]
+
+
+class PackItem(ctypes.Structure):
+    """msclip_pack_item (include/msclip_hip.h)."""
+    _fields_ = [("w", ctypes.c_void_p), ("g", ctypes.c_void_p), ("b", ctypes.c_void_p), ("mu", ctypes.c_void_p), ("var", ctypes.c_void_p),
+                ("w2", ctypes.c_void_p), ("g2", ctypes.c_void_p), ("b2", ctypes.c_void_p), ("mu2", ctypes.c_void_p), ("var2", ctypes.c_void_p),
+                ("out", ctypes.c_void_p), ("bias_out", ctypes.c_void_p), ("eps", ctypes.c_float), ("eps2", ctypes.c_float),
+                ("co", ctypes.c_int), ("ci", ctypes.c_int), ("kh", ctypes.c_int), ("kw", ctypes.c_int), ("kpad", ctypes.c_int),
+                ("mode", ctypes.c_int), ("col0", ctypes.c_int), ("ld", ctypes.c_int), ("bias_mode", ctypes.c_int), ("bias_col0", ctypes.c_int)]
+
+
+class PackPlan:
+    """Device-resident item table of msclip_pack_weights: every derived conv-side tensor described once (sources = the module's
+    parameter storage, destinations = the engine's persistent operand tensors), re-run after every optimizer step."""
+
+    def __init__(self, device):
+        self.device, self.items, self.keep = device, [], []
+
+    def add(self, w, out=None, *, bn=None, eps=1e-5, w2=None, bn2=None, eps2=1e-5, mode=0, col0=0, ld=0, bias_out=None, bias_mode=0,
+            bias_col0=0, co=None):
+        """w fp32 [co, ci, kh, kw] (contiguous parameter storage); bn / bn2 = (gamma, beta, running_mean, running_var)."""
+        it = PackItem()
+        w4 = w if w.dim() == 4 else w.view(w.shape[0], -1, 1, 1)
+        assert w4.dtype == torch.float32 and w4.is_contiguous()
+        it.w = w4.data_ptr()
+        it.co, it.ci, it.kh, it.kw = (co if co is not None else w4.shape[0]), w4.shape[1], w4.shape[2], w4.shape[3]
+        tensors = [w4]
+        if bn is not None:
+            for t in bn:
+                assert t.dtype == torch.float32 and t.is_contiguous()
+            it.g, it.b, it.mu, it.var = (t.data_ptr() for t in bn)
+            it.eps = eps
+            tensors += list(bn)
+        if w2 is not None:
+            assert w2.dtype == torch.float32 and w2.is_contiguous() and w2.numel() == it.co * it.ci
+            it.w2 = w2.data_ptr()
+            tensors.append(w2)
+        if bn2 is not None:
+            it.g2, it.b2, it.mu2, it.var2 = (t.data_ptr() for t in bn2)
+            it.eps2 = eps2
+            tensors += list(bn2)
+        if out is not None:
+            assert out.is_contiguous() or mode == 1
+            it.out = out.data_ptr()
+            it.mode, it.col0, it.ld = mode, col0, ld
+            if mode == 0:
+                assert out.dtype == torch.bfloat16 and out.shape[0] == it.co and out.shape[1] >= it.ci * it.kh * it.kw
+                it.kpad = out.shape[1]
+            else:
+                assert out.dtype == torch.float32 and ld >= col0 + it.co
+            tensors.append(out)
+        if bias_out is not None:
+            assert bias_out.dtype == torch.float32 and bias_out.is_contiguous() and bias_mode in (1, 2, 3)
+            it.bias_out, it.bias_mode, it.bias_col0 = bias_out.data_ptr(), bias_mode, bias_col0
+            tensors.append(bias_out)
+        self.items.append(it)
+        self.keep.append(tensors)
+
+    def finalize(self):
+        n = len(self.items)
+        arr = (PackItem * n)(*self.items)
+        raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
+        self.table = raw.to(self.device)
+        starts, tot = [], 0
+        for it in self.items:
+            starts.append(tot)
+            elems = (it.co * it.kpad if it.mode == 0 else it.co * it.ci * it.kh * it.kw) if it.out else 0
+            tot += max(1, -(-elems // 1024))
+        starts.append(tot)
+        self.blk_start = torch.tensor(starts, dtype=torch.int32).to(self.device)
+        self.n_items, self.n_blocks = n, tot
+        return self
+
+    def run(self):
+        _check(lib().msclip_pack_weights(_p(self.table), _p(self.blk_start), self.n_items, self.n_blocks, _stream()), "msclip_pack_weights")
 
 
 class AdamwTensor(ctypes.Structure):
