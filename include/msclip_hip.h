@@ -471,7 +471,8 @@ int msclip_adamw_multi(const msclip_adamw_tensor* tensors, int count, float beta
  *        mode 1: fp32 transposed out[k * ld + col0 + o], k = (ci, kh, kw): w scale;          out NULL: no weight output;
  *   bias_out[bias_col0 + o], bias_mode 1: shift; 2: shift + shift2 (BatchNorm 2); 3: sum_c w[o][c] shift[c] with BatchNorm 1
  *   over the INPUT channels (a pointwise conv behind a BatchNorm); 0 / bias_out NULL: none.
- * blk_start [n_items + 1]: first workgroup of every item (ceil(weight elements / 1024), at least 1), ascending. */
+ * blk_start [n_items + 1]: first workgroup of every item (co * ceil(row length / 1024) workgroups, row length = kpad (mode 0) or
+ * ci kh kw (mode 1); at least 1), ascending. */
 typedef struct msclip_pack_item {
   const float* w;
   const float *g, *b, *mu, *var;

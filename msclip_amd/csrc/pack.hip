@@ -35,38 +35,58 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const msclip_pack_ite
   const msclip_pack_item it = items[lo];
   const int b = blockIdx.x - blk_start[lo];
   const int taps = it.kh * it.kw, kreal = taps * it.ci;
+  // a workgroup takes 1024 consecutive elements of ONE output-channel row (row length kpad / kreal): one division per workgroup
+  // for the row, 32-bit tap arithmetic per element (the first version decoded a flat 64-bit index per element: 0.5 ms per launch)
   if (it.out) {
-    const long long total = it.mode == 0 ? (long long)it.co * it.kpad : (long long)it.co * kreal;
-    for (long long idx = (long long)b * 1024 + threadIdx.x; idx < total && idx < (long long)(b + 1) * 1024; idx += 256) {
-      if (it.mode == 0) {                            // bf16 [co][kpad], k = (kh, kw, ci) (the NHWC gather order), zero padded
-        const int o = (int)(idx / it.kpad), k = (int)(idx - (long long)o * it.kpad);
-        float v = 0.f;
-        if (k < kreal) {
-          const int tap = k / it.ci, c = k - tap * it.ci, y = tap / it.kw, x = tap - y * it.kw;
-          v = it.w[(((size_t)o * it.ci + c) * it.kh + y) * it.kw + x];
-          if (it.g) v = __fmul_rn(v, bn_scale(it.g, it.var, it.eps, o));
-          if (it.w2 && y == it.kh / 2 && x == it.kw / 2)      // the stem stage's 1x1 shortcut samples the 3x3 window's centre tap
-            v = __fadd_rn(v, __fmul_rn(it.w2[(size_t)o * it.ci + c], bn_scale(it.g2, it.var2, it.eps2, o)));
+    const int rowlen = it.mode == 0 ? it.kpad : kreal;
+    const int cpr = (rowlen + 1023) >> 10;           // chunks per row
+    const int o = b / cpr, k0 = (b - o * cpr) << 10;
+    if (o < it.co) {
+      const float sc = it.g ? bn_scale(it.g, it.var, it.eps, o) : 1.f;
+      const float sc2 = it.w2 ? bn_scale(it.g2, it.var2, it.eps2, o) : 0.f;
+      const float* wrow = it.w + (size_t)o * kreal;
+      for (int k = k0 + threadIdx.x; k < rowlen && k < k0 + 1024; k += 256) {
+        if (it.mode == 0) {                          // bf16 [co][kpad], k = (kh, kw, ci) (the NHWC gather order), zero padded
+          float v = 0.f;
+          if (k < kreal) {
+            const int tap = k / it.ci, c = k - tap * it.ci, y = tap / it.kw, x = tap - y * it.kw;
+            v = wrow[(c * it.kh + y) * it.kw + x];
+            if (it.g) v = __fmul_rn(v, sc);
+            if (it.w2 && y == it.kh / 2 && x == it.kw / 2)    // the stem stage's 1x1 shortcut samples the 3x3 window's centre tap
+              v = __fadd_rn(v, __fmul_rn(it.w2[(size_t)o * it.ci + c], sc2));
+          }
+          ((bf16_t*)it.out)[(size_t)o * it.kpad + k] = f32_to_bf16(v);
+        } else {                                     // fp32, transposed: out[k][col0 + o], k = (ci, kh, kw) as the filter lies in memory
+          float v = wrow[k];
+          if (it.g) v = __fmul_rn(v, sc);
+          ((float*)it.out)[(size_t)k * it.ld + it.col0 + o] = v;
         }
-        ((bf16_t*)it.out)[idx] = f32_to_bf16(v);
-      } else {                                       // fp32, transposed: out[k][col0 + o], k = (ci, kh, kw) as the filter lies in memory
-        const int o = (int)(idx / kreal), k = (int)(idx - (long long)o * kreal);
-        float v = it.w[(size_t)o * kreal + k];
-        if (it.g) v = __fmul_rn(v, bn_scale(it.g, it.var, it.eps, o));
-        ((float*)it.out)[(size_t)k * it.ld + it.col0 + o] = v;
       }
     }
   }
-  if (b == 0 && it.bias_out) {
-    for (int o = threadIdx.x; o < it.co; o += 256) {
-      float v;
-      if (it.bias_mode == 3) {                       // pointwise conv behind a BatchNorm (adapter): bias = W shift, shift over the INPUT channels
-        v = 0.f;
-        for (int c = 0; c < it.ci; ++c) v += it.w[(size_t)o * it.ci + c] * bn_shift(it.g, it.b, it.mu, it.var, it.eps, c);
-      } else {
-        v = bn_shift(it.g, it.b, it.mu, it.var, it.eps, o);
-        if (it.bias_mode == 2) v = __fadd_rn(v, bn_shift(it.g2, it.b2, it.mu2, it.var2, it.eps2, o));
+  if (it.bias_out && it.bias_mode == 3) {
+    // pointwise conv behind a BatchNorm (adapter): bias[o] = sum_c W[o][c] shift[c], shift over the INPUT channels (ci <= 1024).  A
+    // workgroup takes 8 outputs (the item has ceil(co / 8) workgroups): the shifts once into LDS, a wave per two outputs.  (First
+    // version: ONE workgroup per item walked all co x ci products with a division and a square root each -- the 0.5 ms tail of
+    // the launch.)
+    __shared__ float sh[1024];
+    for (int c = threadIdx.x; c < it.ci; c += 256) sh[c] = bn_shift(it.g, it.b, it.mu, it.var, it.eps, c);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int o = b * 8 + wave * 2 + j;
+      if (o < it.co) {
+        float v = 0.f;
+        for (int c = lane; c < it.ci; c += 64) v += it.w[(size_t)o * it.ci + c] * sh[c];
+        v = wave_sum(v);
+        if (lane == 0) it.bias_out[it.bias_col0 + o] = v;
       }
+    }
+  } else if (b == 0 && it.bias_out) {
+    for (int o = threadIdx.x; o < it.co; o += 256) {
+      float v = bn_shift(it.g, it.b, it.mu, it.var, it.eps, o);
+      if (it.bias_mode == 2) v = __fadd_rn(v, bn_shift(it.g2, it.b2, it.mu2, it.var2, it.eps2, o));
       it.bias_out[it.bias_col0 + o] = v;
     }
   }

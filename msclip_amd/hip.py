@@ -1255,6 +1255,7 @@ class PackPlan:
             tensors.append(out)
         if bias_out is not None:
             assert bias_out.dtype == torch.float32 and bias_out.is_contiguous() and bias_mode in (1, 2, 3)
+            assert bias_mode != 3 or (out is None and it.ci <= 1024)
             it.bias_out, it.bias_mode, it.bias_col0 = bias_out.data_ptr(), bias_mode, bias_col0
             tensors.append(bias_out)
         self.items.append(it)
@@ -1268,8 +1269,11 @@ class PackPlan:
         starts, tot = [], 0
         for it in self.items:
             starts.append(tot)
-            elems = (it.co * it.kpad if it.mode == 0 else it.co * it.ci * it.kh * it.kw) if it.out else 0
-            tot += max(1, -(-elems // 1024))
+            rowlen = it.kpad if it.mode == 0 else it.ci * it.kh * it.kw
+            if it.out:
+                tot += max(1, it.co * -(-rowlen // 1024))
+            else:
+                tot += -(-it.co // 8) if it.bias_mode == 3 else 1         # the matrix-vector bias: 8 outputs per workgroup
         starts.append(tot)
         self.blk_start = torch.tensor(starts, dtype=torch.int32).to(self.device)
         self.n_items, self.n_blocks = n, tot
