@@ -29,12 +29,21 @@ constexpr int RS = 72;                      // row stride (elements) of the [tok
 // one round: isolated 195 us (77 tokens, causal) / 130 us (50 tokens) at batch 512; inside the training step, beside the
 // weight-gradient lane, 537 -> 352 us and 303 -> 256 us.
 constexpr int BWD_WAVES = 8;
+// Workgroup barrier for LDS hand-overs inside the persistent loop: the waves' LDS writes are complete (lgkmcnt), then the raw
+// barrier.  __syncthreads() would also fence global memory, i.e. wait (vmcnt(0)) for the NEXT pair's prefetch that is meant to
+// stay in flight under this pair's work.
+#define LDS_BARRIER()                                   \
+  do {                                                  \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  \
+    __builtin_amdgcn_s_barrier();                       \
+    asm volatile("" ::: "memory");                      \
+  } while (0)
 
 template <int NT16, bool CAUSAL>            // NT16 = padded length / 16 (4: 64 tokens, 6: 96 tokens)
 __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                        const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqkv, int Lfix,
                                                        int H, int ldq, int ldo, const int* __restrict__ cu, int nsamples,
-                                                       int pad_rows) {
+                                                       int pad_rows, int pblocks) {
   constexpr int LP = NT16 * 16, LS = LP + 8;          // padded length, row stride of the [..][token] images
   extern __shared__ __attribute__((aligned(16))) bf16_t sm[];
   bf16_t* Q = sm;                                      // [LP][RS]
@@ -51,35 +60,62 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_kernel(const bf16_t* 
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if ((int)blockIdx.x >= nsamples * H) {
-    // packed captions (msclip_attention_bwd_varlen): the workgroups behind the last (sample, head) pair zero the q | k | v gradient
+  if ((int)blockIdx.x >= pblocks) {
+    // packed captions (msclip_attention_bwd_varlen): the workgroups behind the persistent ones zero the q | k | v gradient
     // rows of the tile padding [cu[nsamples], + pad_rows): the weight-gradient GEMM contracts over them
-    const int r = (blockIdx.x - nsamples * H) * BWD_WAVES + wave;
+    const int r = (blockIdx.x - pblocks) * BWD_WAVES + wave;
     if (cu && r < pad_rows) {
       bf16_t* g = dqkv + (size_t)(cu[nsamples] + r) * ldq;
       for (int c = lane * 8; c < 3 * H * 64; c += 512) *(uint4*)(g + c) = make_uint4(0, 0, 0, 0);
     }
     return;
   }
-  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
-  const int c0 = cu ? cu[b] : b * Lfix;               // packed captions: rows cu[b] .. cu[b + 1]
-  const int L = cu ? min(cu[b + 1] - c0, LP) : Lfix;
-  const size_t row0 = (size_t)c0;
-  const bf16_t* qb = qkv + row0 * ldq + h * 64;
-  const bf16_t* ob = o + row0 * ldo + h * 64;
-  const bf16_t* db = dout + row0 * ldo + h * 64;
-
-  // ---- load: thread -> (token r, 16-byte chunk c); row-major and transposed images, delta
-  for (int idx = tid; idx < LP * 8; idx += 64 * BWD_WAVES) {
-    const int r = idx >> 3, c = idx & 7;
-    uint4 q4 = make_uint4(0, 0, 0, 0), k4 = q4, v4 = q4, d4 = q4, o4 = q4;
-    if (r < L) {
-      q4 = *(const uint4*)(qb + (size_t)r * ldq + c * 8);
-      k4 = *(const uint4*)(qb + (size_t)r * ldq + H * 64 + c * 8);
-      v4 = *(const uint4*)(qb + (size_t)r * ldq + 2 * H * 64 + c * 8);
-      d4 = *(const uint4*)(db + (size_t)r * ldo + c * 8);
-      o4 = *(const uint4*)(ob + (size_t)r * ldo + c * 8);
+  // Round 5: PERSISTENT workgroups with a register prefetch.  The head's images fill 92-155 KB of LDS, so a CU holds one
+  // workgroup, and with one (sample, head) pair per workgroup the ~3 us of its global loads were exposed in front of ~2.5 us of
+  // work, 24-48 times per CU and launch.  Now a workgroup walks pairs blockIdx.x, + pblocks, ...: the five 16-byte pieces per
+  // thread of pair i + 1 (q, k, v, dO, O) are requested right after pair i's images are in LDS and land under its two phases.
+  constexpr int NI = (LP * 8 + 64 * BWD_WAVES - 1) / (64 * BWD_WAVES);      // load iterations per thread (1: 64 tokens, 2: 96)
+  const int npairs = nsamples * H;
+  uint4 pq[NI], pk[NI], pv[NI], pd[NI], po[NI];
+  auto pair_rows = [&](int pair, int& c0, int& L, int& h) {
+    const int b = pair / H;
+    h = pair - b * H;
+    c0 = cu ? cu[b] : b * Lfix;                       // packed captions: rows cu[b] .. cu[b + 1]
+    L = cu ? min(cu[b + 1] - c0, LP) : Lfix;
+  };
+  auto fetch = [&](int c0, int L, int h) {
+    const bf16_t* qb = qkv + (size_t)c0 * ldq + h * 64;
+    const bf16_t* ob = o + (size_t)c0 * ldo + h * 64;
+    const bf16_t* db = dout + (size_t)c0 * ldo + h * 64;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int idx = tid + i * 64 * BWD_WAVES, r = idx >> 3, c = idx & 7;
+      pq[i] = pk[i] = pv[i] = pd[i] = po[i] = make_uint4(0, 0, 0, 0);
+      if (idx < LP * 8 && r < L) {
+        pq[i] = *(const uint4*)(qb + (size_t)r * ldq + c * 8);
+        pk[i] = *(const uint4*)(qb + (size_t)r * ldq + H * 64 + c * 8);
+        pv[i] = *(const uint4*)(qb + (size_t)r * ldq + 2 * H * 64 + c * 8);
+        pd[i] = *(const uint4*)(db + (size_t)r * ldo + c * 8);
+        po[i] = *(const uint4*)(ob + (size_t)r * ldo + c * 8);
+      }
     }
+  };
+  int c0 = 0, L = 0, h = 0;
+  int pair = blockIdx.x;
+  if (pair < npairs) {
+    pair_rows(pair, c0, L, h);
+    fetch(c0, L, h);
+  }
+  for (; pair < npairs; pair += pblocks) {
+  const size_t row0 = (size_t)c0;
+  const int hcur = h;
+  // ---- the prefetched pieces -> LDS: thread -> (token r, 16-byte chunk c); row-major and transposed images, delta
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int idx = tid + i * 64 * BWD_WAVES;
+    if (idx >= LP * 8) continue;
+    const int r = idx >> 3, c = idx & 7;
+    const uint4 q4 = pq[i], k4 = pk[i], v4 = pv[i], d4 = pd[i], o4 = po[i];
     *(uint4*)(Q + r * RS + c * 8) = q4;
     *(uint4*)(K + r * RS + c * 8) = k4;
     *(uint4*)(V + r * RS + c * 8) = v4;
@@ -105,8 +141,16 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_kernel(const bf16_t* 
     s += __shfl_xor(s, 4, 64);
     if (c == 0) delta[r] = s;
   }
+  const int Lcur = L;
+  {                                                    // the next pair's pieces: in flight under this pair's two phases
+    const int nxt = pair + pblocks;
+    if (nxt < npairs) {
+      pair_rows(nxt, c0, L, h);
+      fetch(c0, L, h);
+    }
+  }
   // zero the padding columns [LP, LS) of the token-contiguous images is unnecessary: k-steps never read past LP.
-  __syncthreads();
+  LDS_BARRIER();
 
   const int r16 = lane & 15, quad = lane >> 4;
   // Fragment reads are issued as a batch in front of the MFMAs that use them (and pinned there: the scheduler otherwise
@@ -153,7 +197,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_kernel(const bf16_t* 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = kt * 16 + quad * 4 + r;
-        const bool ok = key < L && (!CAUSAL || key <= query);
+        const bool ok = key < Lcur && (!CAUSAL || key <= query);
         st[kt][r] = ok ? st[kt][r] : -INFINITY;
         mx = fmaxf(mx, st[kt][r]);
       }
@@ -208,10 +252,10 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_kernel(const bf16_t* 
       *(uint2*)(dS + query * LS + kt * 16 + quad * 4) = u;
     }
   }
-  __syncthreads();
+  LDS_BARRIER();
 
   // ---- phase 2: dV^T = dO^T-rows x P^T-rows (over queries), dK^T = Q^T x dS^T (over queries), dQ^T = K^T x dS (over keys)
-  bf16_t* gb = dqkv + row0 * ldq + h * 64;
+  bf16_t* gb = dqkv + row0 * ldq + hcur * 64;
   for (int t = wave; t < 3 * 4 * NT16; t += BWD_WAVES) {
     const int which = t / (4 * NT16), rem = t - which * 4 * NT16;
     const int dt = rem / NT16, tt = rem - dt * NT16;            // head-dim tile, token tile
@@ -219,13 +263,15 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_kernel(const bf16_t* 
     const bf16_t* pb = which == 0 ? PT : (which == 1 ? dST : dS);
     const f32x4 acc = mma(f32x4{0.f, 0.f, 0.f, 0.f}, pa + dt * 16 * LS, LS, pb + tt * 16 * LS, LS, std::integral_constant<int, LP / 32>{});
     const int tok = tt * 16 + r16;
-    if (tok < L) {
+    if (tok < Lcur) {
       uint2 u;
       u.x = pack_bf16x2(acc[0], acc[1]);
       u.y = pack_bf16x2(acc[2], acc[3]);
       const int col = (which == 0 ? 2 * H * 64 : (which == 1 ? H * 64 : 0)) + dt * 16 + quad * 4;
       *(uint2*)(gb + (size_t)tok * ldq + col) = u;
     }
+  }
+  LDS_BARRIER();                                       // every wave is done with this pair's images before the next pair's are written
   }
 }
 
@@ -241,8 +287,17 @@ int launch_bwd(const void* qkv, const void* o, const void* dout, void* dqkv, int
     done = true;
   }
   const int extra = cu ? (pad_rows + BWD_WAVES - 1) / BWD_WAVES : 0;
-  hipLaunchKernelGGL((attn_bwd_kernel<NT16, CAUSAL>), dim3(nsamples * H + extra), dim3(64 * BWD_WAVES), lds, st, (const bf16_t*)qkv,
-                     (const bf16_t*)o, (const bf16_t*)dout, (bf16_t*)dqkv, L, H, ldq, ldo, cu, nsamples, pad_rows);
+  static int ncu = 0;
+  if (!ncu) {
+    hipDeviceProp_t p;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    ncu = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+  }
+  const int pairs = nsamples * H;
+  const int pblocks = pairs < ncu ? pairs : ncu;       // one persistent workgroup per CU (the LDS footprint allows no second)
+  hipLaunchKernelGGL((attn_bwd_kernel<NT16, CAUSAL>), dim3(pblocks + extra), dim3(64 * BWD_WAVES), lds, st, (const bf16_t*)qkv,
+                     (const bf16_t*)o, (const bf16_t*)dout, (bf16_t*)dqkv, L, H, ldq, ldo, cu, nsamples, pad_rows, pblocks);
   return msclip_launch_status();
 }
 
