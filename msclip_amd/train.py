@@ -183,8 +183,11 @@ class TrainStep:
                 L["x_in"] = Xc if fresh else Xc[r_lo:M].clone()
                 XM = torch.empty(M, D, dtype=F32, device=e.dev) if fresh else Xc
                 lno1 = torch.empty(M, D, dtype=BF, device=e.dev)
-                for r0, r1, b in segs:
-                    hip.layernorm(Xc[r0:r1], b["ln1"].g, b["ln1"].b, lno1[r0:r1], r1 - r0)
+                if len(segs) == 2:                          # both towers' rows in one launch (modality-specific gamma / beta per row segment)
+                    hip.layernorm_split(Xc[:M], vb["ln1"].g, vb["ln1"].b, tb["ln1"].g, tb["ln1"].b, Mv, lno1[:M], M)
+                else:
+                    for r0, r1, b in segs:
+                        hip.layernorm(Xc[r0:r1], b["ln1"].g, b["ln1"].b, lno1[r0:r1], r1 - r0)
                 groups = [(r_lo, M, segs[0][2]["w"])] if len(segs) == 2 and vb["w"] is tb["w"] else \
                          [(r0, r1, b["w"]) for r0, r1, b in segs]
                 qkv = torch.empty(M, 3 * D, dtype=BF, device=e.dev)
@@ -199,8 +202,11 @@ class TrainStep:
                 L["x_mid"] = XM if fresh else XM[r_lo:M].clone()
                 XN = torch.empty(M, D, dtype=F32, device=e.dev) if fresh else Xc
                 lno2 = torch.empty(M, D, dtype=BF, device=e.dev)
-                for r0, r1, b in segs:
-                    hip.layernorm(XM[r0:r1], b["ln2"].g, b["ln2"].b, lno2[r0:r1], r1 - r0)
+                if len(segs) == 2:
+                    hip.layernorm_split(XM[:M], vb["ln2"].g, vb["ln2"].b, tb["ln2"].g, tb["ln2"].b, Mv, lno2[:M], M)
+                else:
+                    for r0, r1, b in segs:
+                        hip.layernorm(XM[r0:r1], b["ln2"].g, b["ln2"].b, lno2[r0:r1], r1 - r0)
                 h = torch.empty(M, 4 * D, dtype=BF, device=e.dev)
                 hid = torch.empty(M, 4 * D, dtype=BF, device=e.dev)
                 for r0, r1, bw in groups:
