@@ -23,12 +23,13 @@ namespace {
 
 constexpr int RS = 72;                      // row stride (elements) of the [token][64] images: 144 B, 16-B aligned
 
-// Waves per workgroup of attn_bwd_kernel.  The head's images fill 92-155 KB of LDS, so a CU holds ONE workgroup: with 4
-// waves that is one wave per SIMD -- nothing to overlap the LDS round trips of the 72 three-MFMA tile jobs with, and the six
-// query tiles of a 77-token caption took two rounds with half the waves idle in the second.  Eight waves: two per SIMD,
-// one round: isolated 195 us (77 tokens, causal) / 130 us (50 tokens) at batch 512; inside the training step, beside the
-// weight-gradient lane, 537 -> 352 us and 303 -> 256 us.
-constexpr int BWD_WAVES = 8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4v;
+__device__ __forceinline__ bf16x8 ld_tr8(const char* p0, const char* p1) {   // tokens T0..T0+3 (p0) and T0+4..T0+7 (p1) of this lane's channel
+  const bf16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((AS3 bf16x4v*)p0);
+  const bf16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((AS3 bf16x4v*)p1);
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
 // Workgroup barrier for LDS hand-overs inside the persistent loop: the waves' LDS writes are complete (lgkmcnt), then the raw
 // barrier.  __syncthreads() would also fence global memory, i.e. wait (vmcnt(0)) for the NEXT pair's prefetch that is meant to
 // stay in flight under this pair's work.
@@ -39,8 +40,8 @@ constexpr int BWD_WAVES = 8;
     asm volatile("" ::: "memory");                      \
   } while (0)
 
-template <int NT16, bool CAUSAL>            // NT16 = padded length / 16 (4: 64 tokens, 6: 96 tokens)
-__global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+template <int NT16, bool CAUSAL, int BW>    // NT16 = padded length / 16 (4: 64 tokens, 6: 96 tokens); BW = waves per workgroup
+__global__ __launch_bounds__(64 * BW) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                        const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqkv, int Lfix,
                                                        int H, int ldq, int ldo, const int* __restrict__ cu, int nsamples,
                                                        int pad_rows, int pblocks) {
@@ -50,20 +51,19 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_kernel(const bf16_t* 
   bf16_t* K = Q + LP * RS;
   bf16_t* V = K + LP * RS;
   bf16_t* dO = V + LP * RS;
-  bf16_t* QT = dO + LP * RS;                           // [64][LS]
-  bf16_t* KT = QT + 64 * LS;
-  bf16_t* dOT = KT + 64 * LS;
-  bf16_t* PT = dOT + 64 * LS;                          // [key][query]   (LP x LS)
-  bf16_t* dS = PT + LP * LS;                           // [query][key]
-  bf16_t* dST = dS + LP * LS;                          // [key][query]
-  float* delta = (float*)(dST + LP * LS);              // [LP]
+  // (rounds 3-4 kept transposed copies Q^T, K^T, dO^T [64][LS] beside the row-major images, built with 24 two-byte LDS writes per
+  //  thread while loading: 23 of a launch's 118 us, and the 28 KB that made the footprint one workgroup per CU.  Phase 2 now reads
+  //  its token-contracting operands from the row-major images with ds_read_b64_tr_b16.)
+  bf16_t* P = dO + LP * RS;                            // [query][key]   (LP x LS)  (P^T / dS^T are read through ds_read_b64_tr_b16 too)
+  bf16_t* dS = P + LP * LS;                            // [query][key]
+  float* delta = (float*)(dS + LP * LS);               // [LP]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if ((int)blockIdx.x >= pblocks) {
     // packed captions (msclip_attention_bwd_varlen): the workgroups behind the persistent ones zero the q | k | v gradient
     // rows of the tile padding [cu[nsamples], + pad_rows): the weight-gradient GEMM contracts over them
-    const int r = (blockIdx.x - pblocks) * BWD_WAVES + wave;
+    const int r = (blockIdx.x - pblocks) * BW + wave;
     if (cu && r < pad_rows) {
       bf16_t* g = dqkv + (size_t)(cu[nsamples] + r) * ldq;
       for (int c = lane * 8; c < 3 * H * 64; c += 512) *(uint4*)(g + c) = make_uint4(0, 0, 0, 0);
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_kernel(const bf16_t* 
   // workgroup, and with one (sample, head) pair per workgroup the ~3 us of its global loads were exposed in front of ~2.5 us of
   // work, 24-48 times per CU and launch.  Now a workgroup walks pairs blockIdx.x, + pblocks, ...: the five 16-byte pieces per
   // thread of pair i + 1 (q, k, v, dO, O) are requested right after pair i's images are in LDS and land under its two phases.
-  constexpr int NI = (LP * 8 + 64 * BWD_WAVES - 1) / (64 * BWD_WAVES);      // load iterations per thread (1: 64 tokens, 2: 96)
+  constexpr int NI = (LP * 8 + 64 * BW - 1) / (64 * BW);      // load iterations per thread (1: 64 tokens, 2: 96)
   const int npairs = nsamples * H;
   uint4 pq[NI], pk[NI], pv[NI], pd[NI], po[NI];
   auto pair_rows = [&](int pair, int& c0, int& L, int& h) {
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_kernel(const bf16_t* 
     const bf16_t* db = dout + (size_t)c0 * ldo + h * 64;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int idx = tid + i * 64 * BWD_WAVES, r = idx >> 3, c = idx & 7;
+      const int idx = tid + i * 64 * BW, r = idx >> 3, c = idx & 7;
       pq[i] = pk[i] = pv[i] = pd[i] = po[i] = make_uint4(0, 0, 0, 0);
       if (idx < LP * 8 && r < L) {
         pq[i] = *(const uint4*)(qb + (size_t)r * ldq + c * 8);
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_kernel(const bf16_t* 
   // ---- the prefetched pieces -> LDS: thread -> (token r, 16-byte chunk c); row-major and transposed images, delta
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
-    const int idx = tid + i * 64 * BWD_WAVES;
+    const int idx = tid + i * 64 * BW;
     if (idx >= LP * 8) continue;
     const int r = idx >> 3, c = idx & 7;
     const uint4 q4 = pq[i], k4 = pk[i], v4 = pv[i], d4 = pd[i], o4 = po[i];
@@ -120,16 +120,6 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_kernel(const bf16_t* 
     *(uint4*)(K + r * RS + c * 8) = k4;
     *(uint4*)(V + r * RS + c * 8) = v4;
     *(uint4*)(dO + r * RS + c * 8) = d4;
-    const unsigned qw[4] = {q4.x, q4.y, q4.z, q4.w}, kw[4] = {k4.x, k4.y, k4.z, k4.w}, dw[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      QT[(c * 8 + 2 * e) * LS + r] = (bf16_t)(qw[e] & 0xffff);
-      QT[(c * 8 + 2 * e + 1) * LS + r] = (bf16_t)(qw[e] >> 16);
-      KT[(c * 8 + 2 * e) * LS + r] = (bf16_t)(kw[e] & 0xffff);
-      KT[(c * 8 + 2 * e + 1) * LS + r] = (bf16_t)(kw[e] >> 16);
-      dOT[(c * 8 + 2 * e) * LS + r] = (bf16_t)(dw[e] & 0xffff);
-      dOT[(c * 8 + 2 * e + 1) * LS + r] = (bf16_t)(dw[e] >> 16);
-    }
     float fd[8], fo[8];
     unpack_bf16x8(d4, fd);
     unpack_bf16x8(o4, fo);
@@ -157,22 +147,8 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_kernel(const bf16_t* 
   // sinks every ds_read to its MFMA with an lgkmcnt(0) in between, one exposed LDS round trip per MFMA -- what made the
   // 197-token forward kernel latency-bound).
   auto frag = [&](const bf16_t* p, int stride, int ks) { return *(const bf16x8*)(p + r16 * stride + ks * 32 + quad * 8); };
-  auto mma = [&](f32x4 acc, const bf16_t* pa, int sa, const bf16_t* pb, int sb, auto ksc) {
-    constexpr int KS = decltype(ksc)::value;
-    bf16x8 a[KS], bb[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      a[ks] = frag(pa, sa, ks);
-      bb[ks] = frag(pb, sb, ks);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks], bb[ks], acc, 0, 0, 0);
-    return acc;
-  };
-
   // ---- phase 1: per 16-query tile: S^T, softmax over keys, dP^T, dS^T -> P^T, dS, dS^T in LDS
-  for (int qt = wave; qt < NT16; qt += BWD_WAVES) {
+  for (int qt = wave; qt < NT16; qt += BW) {
     const int query = qt * 16 + r16;
     f32x4 st[NT16];
     float mx = -INFINITY;
@@ -237,31 +213,47 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void attn_bwd_kernel(const bf16_t* 
 #pragma unroll
     for (int kt = 0; kt < NT16; ++kt) {
       const f32x4 dp = dpt[kt];
-      float ds[4];
+      float ds[4], pp[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = st[kt][r] * inv;
-        ds[r] = p * (dp[r] - dl);
-        const int key = kt * 16 + quad * 4 + r;
-        PT[key * LS + query] = f32_to_bf16(p);
-        dST[key * LS + query] = f32_to_bf16(ds[r]);
+        pp[r] = st[kt][r] * inv;
+        ds[r] = pp[r] * (dp[r] - dl);
       }
-      uint2 u;
+      uint2 u, w;
       u.x = pack_bf16x2(ds[0], ds[1]);
       u.y = pack_bf16x2(ds[2], ds[3]);
+      w.x = pack_bf16x2(pp[0], pp[1]);
+      w.y = pack_bf16x2(pp[2], pp[3]);
       *(uint2*)(dS + query * LS + kt * 16 + quad * 4) = u;
+      *(uint2*)(P + query * LS + kt * 16 + quad * 4) = w;
     }
   }
   LDS_BARRIER();
 
   // ---- phase 2: dV^T = dO^T-rows x P^T-rows (over queries), dK^T = Q^T x dS^T (over queries), dQ^T = K^T x dS (over keys)
   bf16_t* gb = dqkv + row0 * ldq + hcur * 64;
-  for (int t = wave; t < 3 * 4 * NT16; t += BWD_WAVES) {
+  for (int t = wave; t < 3 * 4 * NT16; t += BW) {
     const int which = t / (4 * NT16), rem = t - which * 4 * NT16;
     const int dt = rem / NT16, tt = rem - dt * NT16;            // head-dim tile, token tile
-    const bf16_t* pa = which == 0 ? dOT : (which == 1 ? QT : KT);
-    const bf16_t* pb = which == 0 ? PT : (which == 1 ? dST : dS);
-    const f32x4 acc = mma(f32x4{0.f, 0.f, 0.f, 0.f}, pa + dt * 16 * LS, LS, pb + tt * 16 * LS, LS, std::integral_constant<int, LP / 32>{});
+    const bf16_t* pa = which == 0 ? dO : (which == 1 ? Q : K);          // row-major [token][64]: read transposed
+    const bf16_t* pb = which == 0 ? P : dS;            // [query][key]: dV^T and dK^T contract over queries (read transposed), dQ^T over keys
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    {
+      constexpr int KS = LP / 32;
+      bf16x8 a[KS], bb[KS];
+      // A fragment (head-dim row dt*16 + r16, tokens ks*32 + quad*8 .. + 7): a 16-lane group reads a 4-token x 16-channel block
+      // of the row-major image, lane i supplying (token i / 4, channels 4 (i % 4) ..) and receiving channel i's four tokens
+      const char* abase = (const char*)(pa + (quad * 8 + (r16 >> 2)) * RS + dt * 16 + 4 * (r16 & 3));
+      const char* bbase = (const char*)(pb + (quad * 8 + (r16 >> 2)) * LS + tt * 16 + 4 * (r16 & 3));   // B rows = keys tt*16 + r16, k = queries
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        a[ks] = ld_tr8(abase + ks * 32 * RS * 2, abase + (ks * 32 + 4) * RS * 2);
+        bb[ks] = which == 2 ? frag(pb + tt * 16 * LS, LS, ks) : ld_tr8(bbase + ks * 32 * LS * 2, bbase + (ks * 32 + 4) * LS * 2);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks], bb[ks], acc, 0, 0, 0);
+    }
     const int tok = tt * 16 + r16;
     if (tok < Lcur) {
       uint2 u;
@@ -279,14 +271,18 @@ template <int NT16, bool CAUSAL>
 int launch_bwd(const void* qkv, const void* o, const void* dout, void* dqkv, int nsamples, int L, int H, int ldq, int ldo,
                hipStream_t st, const int* cu = nullptr, int pad_rows = 0) {
   constexpr int LP = NT16 * 16, LS = LP + 8;
-  const size_t lds = (size_t)(4 * LP * RS + 3 * 64 * LS + 3 * LP * LS) * 2 + LP * 4;
+  // 64 tokens: 54 KB of LDS -> TWO workgroups of 4 waves per CU (the kernel's ~250 VGPRs allow 8 waves per CU either way: as one
+  // 8-wave workgroup its four query tiles left half the waves idle in phase 1, and nothing ran under its barriers and loads);
+  // 96 tokens: 94 KB -> one workgroup of 8 waves
+  constexpr int BW = NT16 <= 4 ? 4 : 8;
+  const size_t lds = (size_t)(4 * LP * RS + 2 * LP * LS) * 2 + LP * 4;
   static bool done = false;
   if (!done && lds > 65536) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<NT16, CAUSAL>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<NT16, CAUSAL, BW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     done = true;
   }
-  const int extra = cu ? (pad_rows + BWD_WAVES - 1) / BWD_WAVES : 0;
+  const int extra = cu ? (pad_rows + BW - 1) / BW : 0;
   static int ncu = 0;
   if (!ncu) {
     hipDeviceProp_t p;
@@ -295,8 +291,9 @@ int launch_bwd(const void* qkv, const void* o, const void* dout, void* dqkv, int
     ncu = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
   }
   const int pairs = nsamples * H;
-  const int pblocks = pairs < ncu ? pairs : ncu;       // one persistent workgroup per CU (the LDS footprint allows no second)
-  hipLaunchKernelGGL((attn_bwd_kernel<NT16, CAUSAL>), dim3(pblocks + extra), dim3(64 * BWD_WAVES), lds, st, (const bf16_t*)qkv,
+  const int per_cu = NT16 <= 4 ? 2 : 1;
+  const int pblocks = pairs < ncu * per_cu ? pairs : ncu * per_cu;
+  hipLaunchKernelGGL((attn_bwd_kernel<NT16, CAUSAL, BW>), dim3(pblocks + extra), dim3(64 * BW), lds, st, (const bf16_t*)qkv,
                      (const bf16_t*)o, (const bf16_t*)dout, (bf16_t*)dqkv, L, H, ldq, ldo, cu, nsamples, pad_rows, pblocks);
   return msclip_launch_status();
 }
@@ -312,7 +309,7 @@ int launch_bwd(const void* qkv, const void* o, const void* dout, void* dqkv, int
 // tile, one of QB_WAVES / 2 parts of the key tiles) and the parts exchange the row maximum and the row sum through LDS.
 // The key axis is padded to a multiple of 32 (one MFMA k-step) with zero columns in K^T and dS.
 // ------------------------------------------------------------------------------------------------------------
-// Waves per workgroup of the query-blocked kernel: its 153 KB of LDS also mean one workgroup per CU (see BWD_WAVES).
+// Waves per workgroup of the query-blocked kernel: its 153 KB of LDS also mean one workgroup per CU.
 constexpr int QB_WAVES = 8;
 
 template <int NT16, bool CAUSAL>
