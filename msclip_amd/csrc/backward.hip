@@ -11,6 +11,7 @@
 // Everything here is HBM-bound elementwise / reduction work: 16-byte accesses, one wave per row where a row reduction
 // is needed, fp32 statistics and accumulation, bf16 only for tensors that feed an MFMA GEMM.
 #include <mutex>
+#include <type_traits>
 #include <stdlib.h>
 #include "common.h"
 #include "../../include/msclip_hip.h"
@@ -307,22 +308,42 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
     dg[v] = make_float4(0.f, 0.f, 0.f, 0.f);
     db[v] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  for (int m = blockIdx.x * 4 + wave; m < M; m += gridDim.x * 4) {
+  // Software-pipelined over the wave's rows (round 5): the x, dy and (when accumulating) dx pieces of the NEXT row are requested
+  // before the current row's four wave reductions run -- one row at a time the kernel waited out two memory round trips per row
+  // (3.5 TB/s of its bytes); the old dx value in particular was only asked for after the last reduction.
+  typedef typename std::conditional<sizeof(TDY) == 2, uint2, float4>::type dy_t;
+  float4 nx[V4], nold[V4];
+  dy_t ndy[V4];
+  const int stride = gridDim.x * 4;
+  auto request = [&](int m) {
     const size_t src = row_idx ? (size_t)row_idx[m] : (size_t)m * row_mul;
-    float4 xv[V4], dv[V4];
+#pragma unroll
+    for (int v = 0; v < V4; ++v) {
+      nx[v] = *(const float4*)(x + src * ldx + v * 256 + lane * 4);
+      ndy[v] = *(const dy_t*)((const TDY*)dy + (size_t)m * lddy + v * 256 + lane * 4);
+      if (accumulate) nold[v] = *(const float4*)(dx + src * lddx + v * 256 + lane * 4);
+    }
+  };
+  int m = blockIdx.x * 4 + wave;
+  if (m < M) request(m);
+  for (; m < M; m += stride) {
+    const size_t src = row_idx ? (size_t)row_idx[m] : (size_t)m * row_mul;
+    float4 xv[V4], dv[V4], old[V4];
     float s = 0.f;
 #pragma unroll
     for (int v = 0; v < V4; ++v) {
-      xv[v] = *(const float4*)(x + src * ldx + v * 256 + lane * 4);
+      xv[v] = nx[v];
+      old[v] = nold[v];
       s += xv[v].x + xv[v].y + xv[v].z + xv[v].w;
       if constexpr (sizeof(TDY) == 2) {
-        const uint2 u = *(const uint2*)((const bf16_t*)dy + (size_t)m * lddy + v * 256 + lane * 4);
+        const uint2 u = ndy[v];
         dv[v] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
                             __uint_as_float(u.y & 0xffff0000u));
       } else {
-        dv[v] = *(const float4*)((const float*)dy + (size_t)m * lddy + v * 256 + lane * 4);
+        dv[v] = ndy[v];
       }
     }
+    if (m + stride < M) request(m + stride);
     const float mu = wave_sum(s) * (1.f / C);
     float q = 0.f;
 #pragma unroll
@@ -348,12 +369,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
       float4 r;
       r.x = rstd * (dv[v].x - a - xv[v].x * b); r.y = rstd * (dv[v].y - a - xv[v].y * b);
       r.z = rstd * (dv[v].z - a - xv[v].z * b); r.w = rstd * (dv[v].w - a - xv[v].w * b);
-      float4* dst = (float4*)(dx + src * lddx + v * 256 + lane * 4);
-      if (accumulate) {
-        const float4 o = *dst;
-        r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w;
-      }
-      *dst = r;
+      if (accumulate) { r.x += old[v].x; r.y += old[v].y; r.z += old[v].z; r.w += old[v].w; }
+      *(float4*)(dx + src * lddx + v * 256 + lane * 4) = r;
     }
   }
   if (part) {
