@@ -80,7 +80,10 @@ typedef struct msclip_gemm_desc {
   int ldxb;
   void* xb;              /* bf16 [M][ldxb]; NULL: off */
   const float* center;   /* [M] */
-  float* part;           /* [M][N / 64][2] */
+  float* part;           /* [M][N / 64][2].  Without xb, resid_kind 4 only (the training step's dgrad launch that writes
+                          * dh = (dY W) * QuickGELU'(h)): fp32 [M / 128][N], row r = the column sums of the values stored to
+                          * out over rows [128 r, 128 r + 128) -- the caller folds them (msclip_colsum) into c_fc's bias
+                          * gradient instead of re-reading out; NULL: off */
   const void* resid2;    /* producer only: rows >= seg_split read their residual from resid2[m][ldr] (m the absolute row) instead of
                           * resid -- the image rows' stream sits in the lateral adapter's output buffer behind an adapter (M.py:1777)
                           * while the text rows' is `out` itself; NULL: every row from resid */
@@ -225,9 +228,9 @@ int msclip_attention_lastq_varlen(const void* q, int ldqc, const void* qkv, int 
                                   int heads, const int* cu, int row_base, void* stream);
 
 /* msclip_attention_bwd over packed captions (Lmax <= 96); the pad_rows rows of dqkv behind cu[nsamples] are zeroed (the
- * in_proj weight gradient contracts over them). */
+ * in_proj weight gradient contracts over them).  colsum_part as in msclip_attention_bwd. */
 int msclip_attention_bwd_varlen(const void* qkv, const void* o, const void* dout, void* dqkv, const int* cu, int nsamples, int Lmax,
-                                int heads, int ldq, int ldo, int causal, int pad_rows, void* stream);
+                                int heads, int ldq, int ldo, int causal, int pad_rows, float* colsum_part, void* stream);
 
 /* msclip_embed_tokens_bwd over packed captions: dx row cu[b] + l belongs to tokens[b,l].  dEmb[token] += row (fp32 atomics);
  * dPos[l] = sum over the captions with n_b > l of their row l, in caption order (bitwise repeatable; dpos is overwritten,
@@ -369,9 +372,12 @@ int msclip_attention_lastq(const void* q, int ldqc, const void* qkv, int ldq, vo
 
 /* Backward of msclip_attention for L <= 208: dqkv [q | k | v gradients] from qkv, the forward output o and its
  * gradient dout (all bf16, same layouts as the forward).  L <= 96: the whole head resident in LDS; 97-208 (the 197-token
- * grid of ViT-B/16): query axis in blocks of 32, dK / dV accumulated in registers across the blocks. */
+ * grid of ViT-B/16): query axis in blocks of 32, dK / dV accumulated in registers across the blocks.
+ * colsum_part (NULL: off; L <= 96 only): fp32 [nsamples][3 * heads * 64], row b = the sums over sample b's tokens of its dqkv
+ * rows (fp32 values, fixed order) -- folded over the samples (msclip_colsum) they are the in_proj bias gradient, without a second
+ * pass over dqkv. */
 int msclip_attention_bwd(const void* qkv, const void* o, const void* dout, void* dqkv, int nsamples, int L, int heads,
-                         int ldq, int ldo, int causal, void* stream);
+                         int ldq, int ldo, int causal, float* colsum_part, void* stream);
 
 /* dx = (dy - y (y . dy)) / ||x||,  y = x / ||x||   (M.py:2983, :3076). */
 int msclip_l2norm_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, int M, int E, void* stream);
@@ -507,7 +513,7 @@ int msclip_bn_fold_bwd(const float* G, long long ldg, const float* w_raw, int co
 int msclip_bn_finish(const float* sums, int r, int C, long long n, const float* gamma, const float* beta, float eps, float* out,
                      void* stream);
 
-#define MSCLIP_ABI_VERSION 5   /* 5 (round 5): packed-caption entry points, msclip_qkv_attention / msclip_qkvattn_tables, msclip_pack_weights, single-launch msclip_colsum */
+#define MSCLIP_ABI_VERSION 6   /* 5 (round 5): packed-caption entry points, msclip_qkv_attention / msclip_qkvattn_tables, msclip_pack_weights, single-launch msclip_colsum */
 int msclip_abi_version(void);
 const char* msclip_build_arch(void);
 

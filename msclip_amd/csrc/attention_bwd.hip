@@ -44,7 +44,7 @@ template <int NT16, bool CAUSAL, int BW>    // NT16 = padded length / 16 (4: 64 
 __global__ __launch_bounds__(64 * BW) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                        const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqkv, int Lfix,
                                                        int H, int ldq, int ldo, const int* __restrict__ cu, int nsamples,
-                                                       int pad_rows, int pblocks) {
+                                                       int pad_rows, int pblocks, float* __restrict__ csum_part) {
   constexpr int LP = NT16 * 16, LS = LP + 8;          // padded length, row stride of the [..][token] images
   extern __shared__ __attribute__((aligned(16))) bf16_t sm[];
   bf16_t* Q = sm;                                      // [LP][RS]
@@ -57,6 +57,11 @@ __global__ __launch_bounds__(64 * BW) void attn_bwd_kernel(const bf16_t* __restr
   bf16_t* P = dO + LP * RS;                            // [query][key]   (LP x LS)  (P^T / dS^T are read through ds_read_b64_tr_b16 too)
   bf16_t* dS = P + LP * LS;                            // [query][key]
   float* delta = (float*)(dS + LP * LS);               // [LP]
+  // csum_part: the token sums of every phase-2 output tile (16 head-dim columns each), two buffers (pair parity): the in_proj
+  // bias gradient's share of this (sample, head) leaves with the pair instead of a second pass over dqkv [M, 3 D]
+  constexpr int TSUM = 3 * 4 * NT16 * 16;
+  float* tsum = delta + LP;                            // [2][which][head-dim tile][token tile][16]
+  int tbuf = 0;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(64 * BW) void attn_bwd_kernel(const bf16_t* __restr
   }
   for (; pair < npairs; pair += pblocks) {
   const size_t row0 = (size_t)c0;
-  const int hcur = h;
+  const int hcur = h, bcur = pair / H;
   // ---- the prefetched pieces -> LDS: thread -> (token r, 16-byte chunk c); row-major and transposed images, delta
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
@@ -262,20 +267,48 @@ __global__ __launch_bounds__(64 * BW) void attn_bwd_kernel(const bf16_t* __restr
       const int col = (which == 0 ? 2 * H * 64 : (which == 1 ? H * 64 : 0)) + dt * 16 + quad * 4;
       *(uint2*)(gb + (size_t)tok * ldq + col) = u;
     }
+    if (csum_part) {
+      // the tile's sums over its 16 tokens (lane bits 0..3), fixed order: lane exchanges on the DPP path
+      f32x4 sv = tok < Lcur ? acc : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = sv[r];
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1, 0, 3, 2]
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2, 3, 0, 1]
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));   // row_mirror
+        sv[r] = v;
+      }
+      if (r16 == 0) *(f32x4*)(tsum + tbuf * TSUM + ((which * 4 + dt) * NT16 + tt) * 16 + quad * 4) = sv;
+    }
   }
   LDS_BARRIER();                                       // every wave is done with this pair's images before the next pair's are written
+  if (csum_part) {
+    // wave 0 folds the pair's token tiles (in tile order) while the others start on the next pair, whose sums go to the other
+    // buffer; this buffer is written again two barriers further on, behind this read
+    if (wave == 0) {
+#pragma unroll
+      for (int which = 0; which < 3; ++which) {
+        float v = 0.f;
+#pragma unroll
+        for (int tt = 0; tt < NT16; ++tt) v += tsum[tbuf * TSUM + ((which * 4 + (lane >> 4)) * NT16 + tt) * 16 + (lane & 15)];
+        csum_part[(size_t)bcur * 3 * H * 64 + (which == 0 ? 2 * H * 64 : (which == 1 ? H * 64 : 0)) + hcur * 64 + lane] = v;
+      }
+    }
+    tbuf ^= 1;
+  }
   }
 }
 
 template <int NT16, bool CAUSAL>
 int launch_bwd(const void* qkv, const void* o, const void* dout, void* dqkv, int nsamples, int L, int H, int ldq, int ldo,
-               hipStream_t st, const int* cu = nullptr, int pad_rows = 0) {
+               hipStream_t st, const int* cu = nullptr, int pad_rows = 0, float* csum_part = nullptr) {
   constexpr int LP = NT16 * 16, LS = LP + 8;
   // 64 tokens: 54 KB of LDS -> TWO workgroups of 4 waves per CU (the kernel's ~250 VGPRs allow 8 waves per CU either way: as one
   // 8-wave workgroup its four query tiles left half the waves idle in phase 1, and nothing ran under its barriers and loads);
   // 96 tokens: 94 KB -> one workgroup of 8 waves
   constexpr int BW = NT16 <= 4 ? 4 : 8;
-  const size_t lds = (size_t)(4 * LP * RS + 2 * LP * LS) * 2 + LP * 4;
+  const size_t lds = (size_t)(4 * LP * RS + 2 * LP * LS) * 2 + LP * 4 + 2 * (3 * 4 * NT16 * 16) * 4;
   static bool done = false;
   if (!done && lds > 65536) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<NT16, CAUSAL, BW>),
@@ -294,7 +327,7 @@ int launch_bwd(const void* qkv, const void* o, const void* dout, void* dqkv, int
   const int per_cu = NT16 <= 4 ? 2 : 1;
   const int pblocks = pairs < ncu * per_cu ? pairs : ncu * per_cu;
   hipLaunchKernelGGL((attn_bwd_kernel<NT16, CAUSAL, BW>), dim3(pblocks + extra), dim3(64 * BW), lds, st, (const bf16_t*)qkv,
-                     (const bf16_t*)o, (const bf16_t*)dout, (bf16_t*)dqkv, L, H, ldq, ldo, cu, nsamples, pad_rows, pblocks);
+                     (const bf16_t*)o, (const bf16_t*)dout, (bf16_t*)dqkv, L, H, ldq, ldo, cu, nsamples, pad_rows, pblocks, csum_part);
   return msclip_launch_status();
 }
 
@@ -551,30 +584,32 @@ int launch_bwd_qb(const void* qkv, const void* o, const void* dout, void* dqkv, 
 }  // namespace
 
 extern "C" int msclip_attention_bwd(const void* qkv, const void* o, const void* dout, void* dqkv, int nsamples, int L,
-                                    int heads, int ldq, int ldo, int causal, void* stream) {
+                                    int heads, int ldq, int ldo, int causal, float* colsum_part, void* stream) {
   if (!qkv || !o || !dout || !dqkv || nsamples <= 0 || L <= 0 || L > 208 || heads <= 0 || (ldq % 8) || (ldo % 8))
     return MSCLIP_EINVAL;
+  if (colsum_part && L > 96) return MSCLIP_EINVAL;      // the query-blocked form does not carry the per-sample column sums
   hipStream_t st = (hipStream_t)stream;
   if (L > 160) return causal ? launch_bwd_qb<13, true>(qkv, o, dout, dqkv, nsamples, L, heads, ldq, ldo, st)
                              : launch_bwd_qb<13, false>(qkv, o, dout, dqkv, nsamples, L, heads, ldq, ldo, st);
   if (L > 96) return causal ? launch_bwd_qb<10, true>(qkv, o, dout, dqkv, nsamples, L, heads, ldq, ldo, st)
                             : launch_bwd_qb<10, false>(qkv, o, dout, dqkv, nsamples, L, heads, ldq, ldo, st);
-  if (L <= 64) return causal ? launch_bwd<4, true>(qkv, o, dout, dqkv, nsamples, L, heads, ldq, ldo, st)
-                             : launch_bwd<4, false>(qkv, o, dout, dqkv, nsamples, L, heads, ldq, ldo, st);
-  return causal ? launch_bwd<6, true>(qkv, o, dout, dqkv, nsamples, L, heads, ldq, ldo, st)
-                : launch_bwd<6, false>(qkv, o, dout, dqkv, nsamples, L, heads, ldq, ldo, st);
+  if (L <= 64) return causal ? launch_bwd<4, true>(qkv, o, dout, dqkv, nsamples, L, heads, ldq, ldo, st, nullptr, 0, colsum_part)
+                             : launch_bwd<4, false>(qkv, o, dout, dqkv, nsamples, L, heads, ldq, ldo, st, nullptr, 0, colsum_part);
+  return causal ? launch_bwd<6, true>(qkv, o, dout, dqkv, nsamples, L, heads, ldq, ldo, st, nullptr, 0, colsum_part)
+                : launch_bwd<6, false>(qkv, o, dout, dqkv, nsamples, L, heads, ldq, ldo, st, nullptr, 0, colsum_part);
 }
 
 extern "C" int msclip_attention_bwd_varlen(const void* qkv, const void* o, const void* dout, void* dqkv, const int* cu, int nsamples,
-                                           int Lmax, int heads, int ldq, int ldo, int causal, int pad_rows, void* stream) {
+                                           int Lmax, int heads, int ldq, int ldo, int causal, int pad_rows, float* colsum_part,
+                                           void* stream) {
   if (!qkv || !o || !dout || !dqkv || !cu || nsamples <= 0 || Lmax <= 0 || Lmax > 96 || heads <= 0 || (ldq % 8) || (ldo % 8) ||
       pad_rows < 0 || pad_rows > 255)
     return MSCLIP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  if (Lmax <= 32) return causal ? launch_bwd<2, true>(qkv, o, dout, dqkv, nsamples, Lmax, heads, ldq, ldo, st, cu, pad_rows)
-                                : launch_bwd<2, false>(qkv, o, dout, dqkv, nsamples, Lmax, heads, ldq, ldo, st, cu, pad_rows);
-  if (Lmax <= 64) return causal ? launch_bwd<4, true>(qkv, o, dout, dqkv, nsamples, Lmax, heads, ldq, ldo, st, cu, pad_rows)
-                                : launch_bwd<4, false>(qkv, o, dout, dqkv, nsamples, Lmax, heads, ldq, ldo, st, cu, pad_rows);
-  return causal ? launch_bwd<6, true>(qkv, o, dout, dqkv, nsamples, Lmax, heads, ldq, ldo, st, cu, pad_rows)
-                : launch_bwd<6, false>(qkv, o, dout, dqkv, nsamples, Lmax, heads, ldq, ldo, st, cu, pad_rows);
+  if (Lmax <= 32) return causal ? launch_bwd<2, true>(qkv, o, dout, dqkv, nsamples, Lmax, heads, ldq, ldo, st, cu, pad_rows, colsum_part)
+                                : launch_bwd<2, false>(qkv, o, dout, dqkv, nsamples, Lmax, heads, ldq, ldo, st, cu, pad_rows, colsum_part);
+  if (Lmax <= 64) return causal ? launch_bwd<4, true>(qkv, o, dout, dqkv, nsamples, Lmax, heads, ldq, ldo, st, cu, pad_rows, colsum_part)
+                                : launch_bwd<4, false>(qkv, o, dout, dqkv, nsamples, Lmax, heads, ldq, ldo, st, cu, pad_rows, colsum_part);
+  return causal ? launch_bwd<6, true>(qkv, o, dout, dqkv, nsamples, Lmax, heads, ldq, ldo, st, cu, pad_rows, colsum_part)
+                : launch_bwd<6, false>(qkv, o, dout, dqkv, nsamples, Lmax, heads, ldq, ldo, st, cu, pad_rows, colsum_part);
 }

@@ -498,7 +498,8 @@ __device__ __forceinline__ f32x4 pp_mma(const bf16x8 (&w)[2], const bf16x8 (&x)[
 // EPI (dense bf16 only): the LayerNorm fold's two epilogue kinds are instantiations of their own, so that the standard kernel's
 // register allocation stays what it was (with all forms in one kernel hipcc spilled inside the K loop): 1 = consumer (the
 // projection behind a folded LayerNorm: per-row rstd / mean, per-column weight sums, two row segments), 2 = producer
-// (out_proj / c_proj: residual update + bf16 centred copy + per-row partial statistics).
+// (out_proj / c_proj: residual update + bf16 centred copy + per-row partial statistics).  3 = the training step's dgrad behind
+// QuickGELU (resid_kind 4: out = bf16(acc * QuickGELU'(resid)), optionally + the stored values' column sums per 128 rows).
 // TNL (dense bf16, msclip_gemm_splitk_tn: the weight gradients dW = dY^T X of the training step): both operands are TOKEN-major,
 // X [K, ldx] holds the output rows m as COLUMNS and W [K, ldw] the output columns n as columns; the contraction runs over rows.
 // A region is 64 token rows x 128 channels (256-byte row segments: full lines), four 1-KiB DMA pieces of 4 rows per wave, and a
@@ -518,6 +519,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a_i
                                                       const float* __restrict__ col_scale) {
   static_assert(!(F8 && MODE == 1), "fp8 operands: dense GEMM only");
   static_assert(EPI == 0 || (MODE == 0 && (!F8 || EPI == 2)), "LayerNorm fold: dense GEMM; fp8 operands as the producer only");
+  static_assert(EPI != 3 || !F8, "training dgrad epilogue: bf16 operands");
   static_assert(!TNL || (MODE == 0 && !F8 && EPI == 0), "token-major operands: dense bf16 GEMM, plain epilogues");
   // Split-K launches (msclip_gemm_splitk with tile = 4; the weight gradients of the training step): blockIdx.y = K slice;
   // slice s contracts columns [s*K/S, (s+1)*K/S) of both operands into its own fp32 matrix out[s][M][ldo].  A weight
@@ -541,7 +543,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a_i
   constexpr unsigned ES = F8 ? 1u : 2u;            // operand element size in bytes
   constexpr int KT = F8 ? 128 : 64;                // elements per K-tile (128 bytes)
   constexpr int TM = 4, TN = 2;
-  constexpr bool TE = MODE == 0 && !F8 && EPI == 0;              // training-step epilogue forms (out2, resid_kind 4) compiled in
+  constexpr bool TE = MODE == 0 && !F8 && EPI == 0;              // training-step forward form (out2) compiled in
   __shared__ __attribute__((aligned(1024))) bf16_t smem[PSLOTS * PREG];
 
   const int tid = threadIdx.x;
@@ -879,7 +881,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a_i
       }
       issue(I2{});
       issue(I3{});
-      if constexpr (EPI != 0) {
+      if constexpr (EPI == 1 || EPI == 2) {
         // The row statistics / centres a tile asks for at its start were written by the previous kernel on other XCDs: a miss
         // to the MALL takes longer than the 0.65 us to the first counted wait of the K loop, which retires in order.  So each
         // wave touches the NEXT tile's lines here (lanes 0-7: one 128-byte line each; value discarded), a K-tile away from the
@@ -891,10 +893,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a_i
           asm volatile("global_load_dword %0, %1, off" : "=&v"(pf_sink) : "v"(q));
         }
       }
-      if (EPI != 0 && kt == 2) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+      if ((EPI == 1 || EPI == 2) && kt == 2) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
       else
       if (kt == 0 && nk >= 3 && epi_stores == 16) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
       else if (kt == 0 && nk >= 3 && epi_stores == 32) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+      else if (EPI == 3 && kt == 0 && nk >= 3 && epi_stores == 34) asm volatile("s_waitcnt vmcnt(42)" ::: "memory");
       else if (kt == 0 && nk >= 3 && epi_stores == 52) asm volatile("s_waitcnt vmcnt(60)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       PP_SYNC_IN();
@@ -972,6 +975,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a_i
           epilogue_pack16<TM, TN, 0, true>(acc, a, stg, cm0 + wm, cn0 + wn, lane_e, bcol, a.out, ccol, rstat);   // QKV behind a folded LayerNorm
         else
           epilogue_pack16<TM, TN, 1, true>(acc, a, stg, cm0 + wm, cn0 + wn, lane_e, bcol, a.out, ccol, rstat);   // c_fc + QuickGELU
+      } else if constexpr (EPI == 3) {             // whole 256-row tiles, bf16 output (host-checked)
+        const bool full_n = cn0 + 256 <= a.N;
+        if (full_n) epi_stores = a.part ? 4 * TM * TN + TN : 4 * TM * TN;    // 32 row stores (+ 2 of the column-sum partials) per wave
+        epilogue_rows<TM, TN, 4, 0, 0, true>(acc, a, stg, cm0 + wm, cn0 + wn, lane_e, bcol);
       } else if constexpr (EPI == 2) {             // whole tiles, in-place fp32 residual update (host-checked)
         epi_stores = 52;                           // 32 fp32 + 16 bf16 full-line stores + 4 stores of row partials per wave
         // (a tile lies in one row segment: seg_split % 256 == 0; the second segment's residual stream may sit elsewhere)
@@ -1000,7 +1007,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a_i
         else if (a.resid_kind == 1 && a.act == 0 && a.out_kind == 1)
           epilogue_rows<TM, TN, 1, 0, 1>(acc, a, stg, mw0, nw0, lane_e, bcol);           // out_proj / c_proj into the fp32 stream
         else
-          epilogue_rows<TM, TN, -1, -1, -1, TE>(acc, a, stg, mw0, nw0, lane_e, bcol);    // pointwise convolutions, heads, training forms
+          epilogue_rows<TM, TN, -1, -1, -1>(acc, a, stg, mw0, nw0, lane_e, bcol);        // pointwise convolutions, heads
         }
       }
       else
@@ -1073,9 +1080,10 @@ static GemmVariant pick_variant(const msclip_gemm_desc* d) {
   // whole 256-row tiles only (the guarded edge-tile epilogue does not carry them)
   const bool train_epi = d->out2 || d->resid_kind == 4;
   if (train_epi && (d->mode != 0 || d->out_kind != 0 || ((d->N | d->ldo) & 7) || (d->M % 256) || (d->out2 && d->resid_kind) ||
-                    (d->resid_kind == 4 && (!d->resid || (d->ldr & 3))) || d->rpg != 0x7fffffff))
+                    (d->resid_kind == 4 && (!d->resid || (d->ldr & 3) || d->act)) || d->rpg != 0x7fffffff))
     return GV_INVALID;
   if (train_epi && d->tile != 4 && d->tile != 0) return GV_INVALID;
+  if (d->part && !d->xb && (d->resid_kind != 4 || (d->N & 3))) return GV_INVALID;   // column-sum partials: the resid_kind 4 epilogue only
   // LayerNorm fold (consumer: rowstat / W2; producer: xb): whole 256 x 256 tiles of the dense ping-pong kernel only
   const bool fold_c = d->rowstat || d->W2, fold_p = d->xb != nullptr;
   if (fold_c && (d->mode != 0 || !d->rowstat || !d->csum || d->out_kind != 0 || d->resid_kind || d->act > 1 || d->out2 ||
@@ -1207,6 +1215,7 @@ extern "C" int msclip_gemm(const msclip_gemm_desc* d, void* stream) {
     case GV_PP:
       if (d->rowstat) hipLaunchKernelGGL((gemm_pp_kernel<0, false, 1>), dim3(grid), dim3(512), 0, st, *d, nullptr, nullptr);
       else if (d->xb) hipLaunchKernelGGL((gemm_pp_kernel<0, false, 2>), dim3(grid), dim3(512), 0, st, *d, nullptr, nullptr);
+      else if (d->resid_kind == 4) hipLaunchKernelGGL((gemm_pp_kernel<0, false, 3>), dim3(grid), dim3(512), 0, st, *d, nullptr, nullptr);
       else hipLaunchKernelGGL((gemm_pp_kernel<0, false>), dim3(grid), dim3(512), 0, st, *d, nullptr, nullptr);
       break;
     case GV_PPCONV: hipLaunchKernelGGL((gemm_pp_kernel<1, false>), dim3(grid), dim3(512), 0, st, *d, nullptr, nullptr); break;

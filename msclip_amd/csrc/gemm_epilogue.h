@@ -123,6 +123,11 @@ __device__ __forceinline__ void epilogue_rows(f32x4 (&acc)[2 * TN][2 * TM], cons
     for (int b = 0; b < RAHEAD; ++b) load_res(b, rv[b]);
   }
   f32x4 x[2][4];
+  // resid_kind 4 with a.part: this lane's share of the COLUMN sums of the stored values over the wave's 128 rows (the bias
+  // gradient of the projection whose output gradient this launch writes: no second pass over the [M, N] tensor)
+  float4 cs[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) cs[tn] = make_float4(0.f, 0.f, 0.f, 0.f);
   auto stage = [&](int b, f32x4 (&dst)[4]) {                     // block b = tm * TN + tn -> LDS -> row-major registers
     const int tm = b / TN, tn = b % TN;
 #pragma unroll
@@ -161,6 +166,7 @@ __device__ __forceinline__ void epilogue_rows(f32x4 (&acc)[2 * TN][2 * TM], cons
         const unsigned ux = __float_as_uint(rv[b % NRV][i].x), uy = __float_as_uint(rv[b % NRV][i].y);
         v.x *= quickgelu_grad(__uint_as_float(ux << 16)); v.y *= quickgelu_grad(__uint_as_float(ux & 0xffff0000u));
         v.z *= quickgelu_grad(__uint_as_float(uy << 16)); v.w *= quickgelu_grad(__uint_as_float(uy & 0xffff0000u));
+        cs[tn].x += v.x; cs[tn].y += v.y; cs[tn].z += v.z; cs[tn].w += v.w;
       } else if (rk) {
         const unsigned ux = __float_as_uint(rv[b % NRV][i].x), uy = __float_as_uint(rv[b % NRV][i].y);
         v.x += __uint_as_float(ux << 16); v.y += __uint_as_float(ux & 0xffff0000u);
@@ -179,6 +185,21 @@ __device__ __forceinline__ void epilogue_rows(f32x4 (&acc)[2 * TN][2 * TM], cons
       }
     }
     if (rk && b + RAHEAD < TM * TN) load_res(b + RAHEAD, rv[b % RAHEAD]);
+  }
+  if (TE && rk == 4 && a.part) {
+    // fold the 8 lanes that hold the same 4 columns (srow = lane / 8: lane bits 3..5), fixed order; lanes 0..7 write the wave's
+    // row of the partials: part[mw0 / 128][N] fp32, a full 128-byte line per 32-column block.  (The staging code's hand-counted
+    // LDS-pipe operations are all retired here: the last block waited lgkmcnt(0).)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+#pragma unroll
+      for (int sh = 8; sh <= 32; sh <<= 1) {
+        cs[tn].x += __shfl_xor(cs[tn].x, sh); cs[tn].y += __shfl_xor(cs[tn].y, sh);
+        cs[tn].z += __shfl_xor(cs[tn].z, sh); cs[tn].w += __shfl_xor(cs[tn].w, sh);
+      }
+      const int n = nw0 + tn * 32 + sch * 4;
+      if (srow == 0 && n < a.N) st_global(a.part + (size_t)(mw0 >> 7) * a.N + n, cs[tn]);
+    }
   }
 }
 

@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MSCLIP_HIP_LIB") or os.path.join(_HERE, "csrc", "libmsclip_hip.so")   # override: kernel A/B probes only
 INT_MAX = 2 ** 31 - 1
-ABI_VERSION = 5                                          # include/msclip_hip.h MSCLIP_ABI_VERSION
+ABI_VERSION = 6                                          # include/msclip_hip.h MSCLIP_ABI_VERSION
 
 EXPORTS = (
     "msclip_gemm", "msclip_gemm_f8", "msclip_layernorm_stats", "msclip_rowstat_finalize", "msclip_layernorm_f8", "msclip_quant_f8_rows", "msclip_gemm_variant", "msclip_attention", "msclip_attention_lastq", "msclip_layernorm", "msclip_layernorm_split", "msclip_embed_tokens", "msclip_fill_cls",
@@ -133,7 +133,7 @@ def lib():
         L.msclip_quickgelu.argtypes = [vp, vp, ll, vp]
         L.msclip_quickgelu_bwd.argtypes = [vp, vp, vp, ll, vp]
         L.msclip_layernorm_bwd.argtypes = [vp, ci, vp, ci, vp, ci, ci, vp, vp, ci, ci, vp, ci, ci, ci, cf, vp]
-        L.msclip_attention_bwd.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
+        L.msclip_attention_bwd.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp]
         L.msclip_l2norm_bwd.argtypes = [vp, ci, vp, ci, vp, ci, ci, ci, vp]
         L.msclip_clip_loss_bwd_g.argtypes = [vp, ci, vp, vp, ci, cf, vp, ci, vp, ci, ci, ci, vp]
         L.msclip_embed_tokens_bwd.argtypes = [vp, vp, ci, vp, vp, ci, ci, ci, ci, vp]
@@ -159,7 +159,7 @@ def lib():
         L.msclip_embed_tokens_packed.argtypes = [vp, vp, vp, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp]
         L.msclip_attention_varlen.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]
         L.msclip_attention_lastq_varlen.argtypes = [vp, ci, vp, ci, vp, ci, ci, ci, ci, vp, ci, vp]
-        L.msclip_attention_bwd_varlen.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]
+        L.msclip_attention_bwd_varlen.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]
         L.msclip_embed_tokens_bwd_packed.argtypes = [vp, vp, ci, vp, vp, vp, ci, ci, ci, ci, vp]
         L.msclip_qkv_attention.argtypes = [ctypes.POINTER(QkvAttnDesc), vp]
         L.msclip_qkvattn_tables.argtypes = [vp, ci, ci, vp, vp, vp, ci, ci, vp]
@@ -403,10 +403,12 @@ class FoldOut:
 
 
 def gemm(x, w, out, *, M=None, bias=None, resid=None, resid_kind=0, act=0, alpha=1.0, conv=None, ktab=None,
-         ldx=None, ldo=None, ldr=None, rpg=INT_MAX, radd=0, roff=0, N=None, tile=0, out2=None, fold_in=None, fold_out=None):
+         ldx=None, ldo=None, ldr=None, rpg=INT_MAX, radd=0, roff=0, N=None, tile=0, out2=None, fold_in=None, fold_out=None,
+         colsum_part=None):
     """out = epilogue(alpha * x @ w^T).  x: bf16 [M, K] (or NHWC activation when conv=(H, W, Cin, Ho, Wo, stride, pad)),
     w: bf16 [N, Kpad]; out: bf16 or fp32 2-D buffer.  Training-step forms (ping-pong kernel): out2 = second bf16 output that
-    receives the value before the activation; resid_kind = RESID_GELUGRAD multiplies by QuickGELU'(resid) (resid bf16)."""
+    receives the value before the activation; resid_kind = RESID_GELUGRAD multiplies by QuickGELU'(resid) (resid bf16) and,
+    with colsum_part (fp32 [M / 128, N]), also leaves the column sums of every 128 stored rows there."""
     _bf16(w)
     d = GemmDesc()
     d.X, d.W, d.zero, d.out = x.data_ptr(), w.data_ptr(), zero_page(x.device).data_ptr(), out.data_ptr()
@@ -454,6 +456,11 @@ def gemm(x, w, out, *, M=None, bias=None, resid=None, resid_kind=0, act=0, alpha
     if out2 is not None:
         assert out2.dtype == torch.bfloat16 and out2.stride(0) == d.ldo and out.dtype == torch.bfloat16
         d.out2 = out2.data_ptr()
+    if colsum_part is not None:
+        _f32(colsum_part)
+        assert fold_out is None and resid_kind == RESID_GELUGRAD and d.M % 128 == 0
+        assert colsum_part.is_contiguous() and colsum_part.shape == (d.M // 128, d.N)
+        d.part = colsum_part.data_ptr()
     probe = (_gemm_probe.get(d.mode) or _gemm_probe.get(gemm_variant(d))) if _gemm_probe else None
     if probe is not None:
         k_alg = d.K if conv is None else conv[2] * (ktab_taps(ktab) if ktab is not None else 1)
@@ -972,21 +979,30 @@ def layernorm_bwd(x, dy, gamma, dx, M, *, row_idx=None, row_mul=1, accumulate=Tr
     return both[:C], both[C:]
 
 
-def attention_bwd(qkv, o, dout, dqkv, nsamples, L, heads, causal):
+def _colsum_part(part, nsamples, heads):
+    if part is not None:
+        _f32(part)
+        assert part.shape == (nsamples, 3 * heads * 64)
+    return _p(part)
+
+
+def attention_bwd(qkv, o, dout, dqkv, nsamples, L, heads, causal, colsum_part=None):
+    """colsum_part (fp32 [nsamples, 3 D], L <= 96): also the per-sample token sums of dqkv (the in_proj bias gradient's partials)."""
     _bf16(qkv); _bf16(o); _bf16(dout); _bf16(dqkv)
     assert o.stride(0) == dout.stride(0) and qkv.stride(0) == dqkv.stride(0)
     _check(lib().msclip_attention_bwd(_p(qkv), _p(o), _p(dout), _p(dqkv), nsamples, L, heads, qkv.stride(0), o.stride(0),
-                                      int(causal), _stream()), "msclip_attention_bwd")
+                                      int(causal), _colsum_part(colsum_part, nsamples, heads), _stream()), "msclip_attention_bwd")
     return dqkv
 
 
-def attention_bwd_varlen(qkv, o, dout, dqkv, cu, nsamples, Lmax, heads, causal, pad_rows=0):
+def attention_bwd_varlen(qkv, o, dout, dqkv, cu, nsamples, Lmax, heads, causal, pad_rows=0, colsum_part=None):
     """attention_bwd over packed captions (views that start at the text segment); dqkv's pad_rows rows behind cu[nsamples] zeroed."""
     for t in (qkv, o, dout, dqkv):
         _bf16(t)
     assert cu.dtype == torch.int32 and cu.numel() >= nsamples + 2 and 0 <= pad_rows < 256
     _check(lib().msclip_attention_bwd_varlen(_p(qkv), _p(o), _p(dout), _p(dqkv), _p(cu), nsamples, Lmax, heads, qkv.stride(0),
-                                             o.stride(0), int(causal), pad_rows, _stream()), "msclip_attention_bwd_varlen")
+                                             o.stride(0), int(causal), pad_rows, _colsum_part(colsum_part, nsamples, heads),
+                                             _stream()), "msclip_attention_bwd_varlen")
     return dqkv
 
 

@@ -430,10 +430,15 @@ class TrainStep:
                     wide_wgrad(p + ".mlp.c_proj.weight", dY[r0:r1], hid[r0:r1], r1 - r0, (D, 4 * D))
                     grads[p + ".mlp.c_proj.bias"] = bsum[id(bw)]
                 dh = torch.empty(M, 4 * D, dtype=BF, device=dev)
+                dh_part = {}
                 for r0, r1, bw in groups:
                     if (r1 - r0) % 256 == 0:
-                        # dh = (dY . W_proj) * QuickGELU'(h): the activation's derivative in the dgrad GEMM's epilogue
-                        hip.gemm(dY[r0:r1], w_t(bw, 0), dh[r0:r1], resid=L["h"][r0:r1], resid_kind=hip.RESID_GELUGRAD)
+                        # dh = (dY . W_proj) * QuickGELU'(h): the activation's derivative in the dgrad GEMM's epilogue, which
+                        # also leaves dh's column sums per 128 rows (c_fc's bias gradient without a second pass over dh)
+                        if not hip.env_flag("MSCLIP_BIAS_COLSUM_PASS"):
+                            dh_part[id(bw)] = torch.empty((r1 - r0) // 128, 4 * D, dtype=F32, device=dev)
+                        hip.gemm(dY[r0:r1], w_t(bw, 0), dh[r0:r1], resid=L["h"][r0:r1], resid_kind=hip.RESID_GELUGRAD,
+                                 colsum_part=dh_part.get(id(bw)))
                     else:
                         dhid = _dgrad(dY[r0:r1], w_t(bw, 0))
                         hip.quickgelu_bwd(L["h"][r0:r1], dhid, dh[r0:r1])
@@ -441,7 +446,8 @@ class TrainStep:
                 for r0, r1, bw in groups:
                     p = names[id(bw)]
                     wide_wgrad(p + ".mlp.c_fc.weight", dh[r0:r1], L["lno2"][r0:r1], r1 - r0, (4 * D, D))
-                    grads[p + ".mlp.c_fc.bias"] = gradgemm.on_lane(lambda a=dh[r0:r1]: hip.colsum(a), dh)
+                    src = dh_part.get(id(bw), dh[r0:r1])
+                    grads[p + ".mlp.c_fc.bias"] = gradgemm.on_lane(lambda a=src: hip.colsum(a), src)
                     _dgrad(dh[r0:r1], w_t(bw, 1), dlno[r0:r1])
                 del dh
                 for r0, r1, b in segs:
@@ -458,13 +464,21 @@ class TrainStep:
                     wide_wgrad(p + ".attn.out_proj.weight", dY2[r0:r1], L["ao"][r0:r1], r1 - r0, (D, D))
                     grads[p + ".attn.out_proj.bias"] = bsum[id(bw)]
                     _dgrad(dY2[r0:r1], w_t(bw, 2), dao[r0:r1])
+                # the attention backward also leaves every sample's token sums of its dqkv rows (in_proj's bias gradient = their
+                # sum over the samples: 1 024 x 3 D fp32 to fold instead of a second pass over dqkv [M, 3 D]); the query-blocked
+                # form of the long sequences does not carry them
+                qpart = None
+                if e.Lv <= 96 and (sv["cap"] is not None or e.Lt <= 96) and not hip.env_flag("MSCLIP_BIAS_COLSUM_PASS"):
+                    qpart = torch.empty(Bi + Bt, 3 * D, dtype=F32, device=dev)
                 if e.vblk[i] is not None:
-                    hip.attention_bwd(L["qkv"][:Mv], L["ao"][:Mv], dao[:Mv], dqkv[:Mv], Bi, e.Lv, e.heads, False)
+                    hip.attention_bwd(L["qkv"][:Mv], L["ao"][:Mv], dao[:Mv], dqkv[:Mv], Bi, e.Lv, e.heads, False,
+                                      colsum_part=qpart[:Bi] if qpart is not None else None)
                 if sv["cap"] is not None:
                     hip.attention_bwd_varlen(L["qkv"][Mv:M], L["ao"][Mv:M], dao[Mv:M], dqkv[Mv:M], sv["cap"].cu, Bt, sv["Lmax"],
-                                             e.heads, True, pad_rows=sv["pad"])
+                                             e.heads, True, pad_rows=sv["pad"], colsum_part=qpart[Bi:] if qpart is not None else None)
                 else:
-                    hip.attention_bwd(L["qkv"][Mv:M], L["ao"][Mv:M], dao[Mv:M], dqkv[Mv:M], Bt, e.Lt, e.heads, True)
+                    hip.attention_bwd(L["qkv"][Mv:M], L["ao"][Mv:M], dao[Mv:M], dqkv[Mv:M], Bt, e.Lt, e.heads, True,
+                                      colsum_part=qpart[Bi:] if qpart is not None else None)
                 for r0, r1, bw in groups:
                     p = names[id(bw)]
                     def unscale_q(g):                                                          # packed q rows = 64^-0.5 * W_q
@@ -472,11 +486,12 @@ class TrainStep:
                         return g
                     wide_wgrad(p + ".attn.in_proj_weight", dqkv[r0:r1], L["lno1"][r0:r1], r1 - r0, (3 * D, D),
                                post=unscale_q)                                          # wrt the PACKED weight, scaled back
-                    def bias_q(a=dqkv[r0:r1]):
+                    src = dqkv[r0:r1] if qpart is None else qpart[(0 if r0 < Mv else Bi):(Bi + Bt if r1 > Mv else Bi)]
+                    def bias_q(a=src):
                         g = hip.colsum(a)
                         g[:D] *= 0.125
                         return g
-                    grads[p + ".attn.in_proj_bias"] = gradgemm.on_lane(bias_q, dqkv)
+                    grads[p + ".attn.in_proj_bias"] = gradgemm.on_lane(bias_q, src)
                     _dgrad(dqkv[r0:r1], w_t(bw, 3), dlno[r0:r1])
                 for r0, r1, b in segs:
                     pre = f"visual.transformer.resblocks.{i}" if b is e.vblk[i] else f"transformer.resblocks.{i}"

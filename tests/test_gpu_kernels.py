@@ -775,6 +775,18 @@ def test_gemm_training_epilogue_forms(gpu_device, tile, M, N, K):
     hip.gemm(x, w, dh[:M], resid=h, resid_kind=hip.RESID_GELUGRAD, tile=tile)
     close(dh[:M], ref, 2e-2, 1e-2)
     assert bool(torch.isnan(dh[M:].float()).all())
+    # ... and with colsum_part the same launch leaves the stored values' column sums per 128 rows (c_fc's bias gradient without a
+    # second pass over dh): same dh bit for bit; partials = the fp32 values' sums, i.e. the bf16 output's up to its rounding
+    dh2 = torch.full((M + 1, N), float("nan"), dtype=BF, device="cuda")
+    part = torch.full((M // 128 + 1, N), float("nan"), dtype=torch.float32, device="cuda")
+    hip.gemm(x, w, dh2[:M], resid=h, resid_kind=hip.RESID_GELUGRAD, tile=tile, colsum_part=part[:M // 128])
+    assert torch.equal(dh2[:M], dh[:M]) and bool(torch.isnan(dh2[M:].float()).all())
+    assert bool(torch.isnan(part[M // 128:]).all())
+    want = dh[:M].float().view(M // 128, 128, N).sum(1)
+    scale = dh[:M].float().abs().view(M // 128, 128, N).sum(1)
+    assert float(((part[:M // 128] - want).abs() / (scale * 2.0 ** -8 + 1e-6)).max()) < 1.0      # 128 roundings of <= 2^-8 relative each (bf16 unit roundoff)
+    close(part[:M // 128], ref.view(M // 128, 128, N).sum(1), 2e-2, 1e-1)
+    close(hip.colsum(part[:M // 128]), ref.sum(0), 2e-2, 3e-1)
     assert hip.gemm_variant(hip.describe_gemm(0, M, N, K, tile=1, resid_kind=hip.RESID_GELUGRAD)) == "invalid"   # other kernels reject it
     assert hip.gemm_variant(hip.describe_gemm(0, M + 8, N, K, resid_kind=hip.RESID_GELUGRAD)) == "invalid"       # ... and so do ragged M
 

@@ -170,6 +170,16 @@ def test_attention_backward_varlen(gpu_device, lens, causal):
         if L > 1:
             assert F.cosine_similarity(got.flatten(), qf.grad.flatten(), dim=0).item() > 0.999, b
     assert bool((dqkv[total:total + pad] == 0).all()) and bool((dqkv[total + pad:] == 7.0).all())
+    # with the per-caption token sums of dqkv (in_proj bias-gradient partials): same dqkv, sums over each caption's live rows
+    d2 = torch.full_like(qkv, 7.0)
+    part = torch.full((B + 1, 3 * D), float("nan"), dtype=torch.float32, device="cuda")
+    hip.attention_bwd_varlen(qkv, o, dout, d2, cu, B, int(n.max()), Hh, causal, pad_rows=pad, colsum_part=part[:B])
+    assert torch.equal(d2, dqkv) and bool(torch.isnan(part[B:]).all())
+    for b in range(B):
+        r0, L = int(cu[b]), lens[b]
+        want = dqkv[r0:r0 + L].float().sum(0)
+        bound = dqkv[r0:r0 + L].float().abs().sum(0) * 2.0 ** -8 + 1e-6
+        assert bool(((part[b] - want).abs() <= bound).all()), b
 
 
 def test_embedding_backward_packed(gpu_device):

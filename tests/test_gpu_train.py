@@ -185,6 +185,25 @@ def test_attention_backward(gpu_device, L, causal):
     assert rel(dqkv, qf.grad) < 3e-2
     cos = F.cosine_similarity(dqkv.float().flatten(), qf.grad.flatten(), dim=0).item()
     assert cos > 0.999, cos
+    if L <= 96:
+        # the same launch with the per-sample token sums of dqkv (in_proj bias-gradient partials): dqkv bit for bit, the sums of the
+        # fp32 values = the stored bf16 values' up to their rounding; many pairs per workgroup (persistent loop, two LDS buffers)
+        ns2 = 67
+        qkv2 = rnd(ns2 * L, 3 * H * 64, seed=19, scale=0.7, dtype=BF)
+        dout2 = rnd(ns2 * L, H * 64, seed=20, dtype=BF)
+        o2 = torch.empty(ns2 * L, H * 64, dtype=BF, device="cuda")
+        hip.attention(qkv2, o2, ns2, L, H, causal)
+        d_a, d_b = torch.full_like(qkv2, float("nan")), torch.full_like(qkv2, float("nan"))
+        part = torch.full((ns2 + 1, 3 * H * 64), float("nan"), dtype=torch.float32, device="cuda")
+        hip.attention_bwd(qkv2, o2, dout2, d_a, ns2, L, H, causal)
+        hip.attention_bwd(qkv2, o2, dout2, d_b, ns2, L, H, causal, colsum_part=part[:ns2])
+        assert torch.equal(d_a, d_b) and bool(torch.isnan(part[ns2:]).all())
+        want = d_a.float().view(ns2, L, -1).sum(1)
+        bound = d_a.float().abs().view(ns2, L, -1).sum(1) * 2.0 ** -8 + 1e-6
+        assert bool(((part[:ns2] - want).abs() <= bound).all()), ((part[:ns2] - want).abs() / bound).max().item()
+    else:
+        with pytest.raises(hip.HipError):
+            hip.attention_bwd(qkv, o, dout, dqkv, ns, L, H, causal, colsum_part=torch.empty(ns, 3 * H * 64, device="cuda"))
 
 
 def _adapter_token_path_case(B, g, Cc, usecls):
