@@ -357,10 +357,14 @@ int msclip_quickgelu_bwd(const void* h, const void* dy, void* dh, long long n, v
 
 /* LayerNorm backward (M.py:204-219).  Row m of the op reads x[src(m)], src(m) = row_idx ? row_idx[m] : m * row_mul;
  * dy [M, C] bf16 or fp32; dx[src(m)] = (or +=) the input gradient.  part (optional) [part_blocks][2][C] receives per-block
- * partial sums of dgamma (= sum dy * xhat) and dbeta (= sum dy): fold with msclip_colsum.  C in {512, 768}. */
+ * partial sums of dgamma (= sum dy * xhat) and dbeta (= sum dy): fold with msclip_colsum.  C in {512, 768}.
+ * dxb + sum_part (both or neither; row_idx NULL, row_mul 1): the written dx rows also leave as bf16 dxb [M][lddxb] -- in the
+ * training step the residual-stream gradient behind a LayerNorm backward is the next projection's output gradient, the operand
+ * of its dgrad / wgrad GEMMs -- with their per-block column sums in sum_part [part_blocks][C] (= or, with sum_accumulate, +=
+ * what the previous row segment's launch left there; folded by msclip_colsum they are that projection's bias gradient). */
 int msclip_layernorm_bwd(const float* x, int ldx, const int* row_idx, int row_mul, const void* dy, int lddy, int dy_is_f32,
                          const float* gamma, float* dx, int lddx, int accumulate, float* part, int part_blocks, int M,
-                         int C, float eps, void* stream);
+                         int C, float eps, void* dxb, int lddxb, float* sum_part, int sum_accumulate, void* stream);
 
 /* msclip_attention for ONE query per sample: the last block, where only the class row of an image (M.py:2685) / the EOT row
  * of a caption (M.py:3057-3060) is read afterwards.  q: bf16 [nsamples, ldqc] = the (pre-scaled) query rows; qkv: the token

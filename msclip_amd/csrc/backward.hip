@@ -297,16 +297,19 @@ template <int V4, typename TDY>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, int ldx, const int* __restrict__ row_idx,
                                                      int row_mul, const TDY* __restrict__ dy, int lddy,
                                                      const float* __restrict__ gamma, float* __restrict__ dx, int lddx,
-                                                     int accumulate, float* __restrict__ part, int M, float eps) {
+                                                     int accumulate, float* __restrict__ part, int M, float eps,
+                                                     bf16_t* __restrict__ dxb, int lddxb, float* __restrict__ sum_part,
+                                                     int sum_accumulate) {
   constexpr int C = 256 * V4;
-  __shared__ float red[4][2][C];
+  __shared__ float red[4][3][C];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float4 g[V4], dg[V4], db[V4];
+  float4 g[V4], dg[V4], db[V4], ds[V4];
 #pragma unroll
   for (int v = 0; v < V4; ++v) {
     g[v] = *(const float4*)(gamma + v * 256 + lane * 4);
     dg[v] = make_float4(0.f, 0.f, 0.f, 0.f);
     db[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    ds[v] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   // Software-pipelined over the wave's rows (round 5): the x, dy and (when accumulating) dx pieces of the NEXT row are requested
   // before the current row's four wave reductions run -- one row at a time the kernel waited out two memory round trips per row
@@ -371,6 +374,25 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
       r.z = rstd * (dv[v].z - a - xv[v].z * b); r.w = rstd * (dv[v].w - a - xv[v].w * b);
       if (accumulate) { r.x += old[v].x; r.y += old[v].y; r.z += old[v].z; r.w += old[v].w; }
       *(float4*)(dx + src * lddx + v * 256 + lane * 4) = r;
+      if (dxb) {
+        // the new residual-stream gradient is the NEXT projection's output gradient: its bf16 copy (the operand of that
+        // projection's dgrad / wgrad GEMMs) and its column sums (that projection's bias gradient) leave with this pass
+        uint2 o;
+        o.x = pack_bf16x2(r.x, r.y);
+        o.y = pack_bf16x2(r.z, r.w);
+        *(uint2*)(dxb + (size_t)m * lddxb + v * 256 + lane * 4) = o;
+        ds[v].x += r.x; ds[v].y += r.y; ds[v].z += r.z; ds[v].w += r.w;
+      }
+    }
+  }
+  if (sum_part) {
+#pragma unroll
+    for (int v = 0; v < V4; ++v) *(float4*)&red[wave][2][v * 256 + lane * 4] = ds[v];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+      const float t = red[0][2][c] + red[1][2][c] + red[2][2][c] + red[3][2][c];
+      float* o = sum_part + (size_t)blockIdx.x * C + c;
+      *o = sum_accumulate ? *o + t : t;
     }
   }
   if (part) {
@@ -770,17 +792,25 @@ extern "C" int msclip_quickgelu_bwd(const void* h, const void* dy, void* dh, lon
 
 extern "C" int msclip_layernorm_bwd(const float* x, int ldx, const int* row_idx, int row_mul, const void* dy, int lddy,
                                     int dy_is_f32, const float* gamma, float* dx, int lddx, int accumulate, float* part,
-                                    int part_blocks, int M, int C, float eps, void* stream) {
+                                    int part_blocks, int M, int C, float eps, void* dxb, int lddxb, float* sum_part,
+                                    int sum_accumulate, void* stream) {
   if (!x || !dy || !gamma || !dx || M <= 0 || (C != 512 && C != 768) || part_blocks < 1) return MSCLIP_EINVAL;
+  // bf16 copy + column sums of the written dx rows: the plain row mapping only (dxb row m = dx row m), both or neither
+  if ((dxb != nullptr) != (sum_part != nullptr) || (dxb && (row_idx || row_mul != 1 || (lddxb % 4)))) return MSCLIP_EINVAL;
   int blocks = (M + 3) / 4;
   if (blocks > part_blocks) blocks = part_blocks;
+  if (sum_part && !sum_accumulate && blocks < part_blocks) {
+    if (hipMemsetAsync(sum_part + (size_t)blocks * C, 0, (size_t)(part_blocks - blocks) * C * sizeof(float),
+                       (hipStream_t)stream) != hipSuccess) return MSCLIP_ELAUNCH;
+  }
   if (part && blocks < part_blocks) {                // unused partial rows must not hold garbage
     if (hipMemsetAsync(part + (size_t)blocks * 2 * C, 0, (size_t)(part_blocks - blocks) * 2 * C * sizeof(float),
                        (hipStream_t)stream) != hipSuccess) return MSCLIP_ELAUNCH;
   }
   hipStream_t st = (hipStream_t)stream;
 #define LNB(V4, T) hipLaunchKernelGGL((ln_bwd_kernel<V4, T>), dim3(blocks), dim3(256), 0, st, x, ldx, row_idx, row_mul, \
-                                      (const T*)dy, lddy, gamma, dx, lddx, accumulate, part, M, eps)
+                                      (const T*)dy, lddy, gamma, dx, lddx, accumulate, part, M, eps, (bf16_t*)dxb, lddxb, \
+                                      sum_part, sum_accumulate)
   if (C == 768) { if (dy_is_f32) LNB(3, float); else LNB(3, bf16_t); }
   else { if (dy_is_f32) LNB(2, float); else LNB(2, bf16_t); }
 #undef LNB

@@ -132,7 +132,7 @@ def lib():
         L.msclip_colsum.argtypes = [vp, ci, ci, vp, ci, ci, ci, vp, ci, vp]
         L.msclip_quickgelu.argtypes = [vp, vp, ll, vp]
         L.msclip_quickgelu_bwd.argtypes = [vp, vp, vp, ll, vp]
-        L.msclip_layernorm_bwd.argtypes = [vp, ci, vp, ci, vp, ci, ci, vp, vp, ci, ci, vp, ci, ci, ci, cf, vp]
+        L.msclip_layernorm_bwd.argtypes = [vp, ci, vp, ci, vp, ci, ci, vp, vp, ci, ci, vp, ci, ci, ci, cf, vp, ci, vp, ci, vp]
         L.msclip_attention_bwd.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp]
         L.msclip_l2norm_bwd.argtypes = [vp, ci, vp, ci, vp, ci, ci, ci, vp]
         L.msclip_clip_loss_bwd_g.argtypes = [vp, ci, vp, vp, ci, cf, vp, ci, vp, ci, ci, ci, vp]
@@ -965,14 +965,20 @@ def quickgelu_bwd(h, dy, dh):
 LN_PART_BLOCKS = 1024
 
 
-def layernorm_bwd(x, dy, gamma, dx, M, *, row_idx=None, row_mul=1, accumulate=True, want_param_grads=True, eps=1e-12):
+def layernorm_bwd(x, dy, gamma, dx, M, *, row_idx=None, row_mul=1, accumulate=True, want_param_grads=True, eps=1e-12,
+                  dxb=None, sum_part=None, sum_accumulate=False):
     """-> (dgamma, dbeta) fp32 [C] (or None).  x fp32 [*, C]; dy [M, C] bf16 / fp32; dx fp32 gets (+=) the input gradient
-    at the rows the forward read."""
+    at the rows the forward read.  dxb (bf16 [M, C]) + sum_part (fp32 [LN_PART_BLOCKS, C]): the written dx rows also as bf16,
+    their per-block column sums into (sum_accumulate: onto) sum_part -- colsum(sum_part) = the column sums of the new dx rows."""
     C = x.shape[-1]
     part = torch.empty(LN_PART_BLOCKS, 2, C, dtype=torch.float32, device=x.device) if want_param_grads else None
+    if dxb is not None:
+        _bf16(dxb); _f32(sum_part)
+        assert dxb.shape[0] >= M and sum_part.shape == (LN_PART_BLOCKS, C) and row_idx is None and row_mul == 1
     _check(lib().msclip_layernorm_bwd(_p(x), x.stride(0), _p(row_idx), row_mul, _p(dy), dy.stride(0),
                                       int(dy.dtype == torch.float32), _p(gamma), _p(dx), dx.stride(0), int(accumulate),
-                                      _p(part), LN_PART_BLOCKS, M, C, eps, _stream()), "msclip_layernorm_bwd")
+                                      _p(part), LN_PART_BLOCKS, M, C, eps, _p(dxb), dxb.stride(0) if dxb is not None else 0,
+                                      _p(sum_part), int(sum_accumulate), _stream()), "msclip_layernorm_bwd")
     if not want_param_grads:
         return None, None
     both = colsum(part.view(LN_PART_BLOCKS, 2 * C))

@@ -412,7 +412,29 @@ class TrainStep:
                     return wts[id(bw)][which]
                 return (bw.wpr, bw.wfc, bw.wo, bw.wqkv)[which].t().contiguous()
 
+            def ln_bwd_segments(x_saved, dlno, segs, groups, r_lo, which, i, dY_next):
+                """LayerNorm backward (`which` = "ln1" / "ln2" of block i) of every row segment: dX += its input gradient.  With
+                dY_next (bf16 [M, D]) the same pass leaves bf16(new dX) there -- the output gradient of the projection in front of
+                this LayerNorm point, operand of its dgrad / wgrad GEMMs -- and returns {id(block weights): that projection's bias
+                gradient} from per-block column sums (no cast_bf16_colsum pass over dX); else returns None."""
+                parts = {}
+                for r0, r1, b in segs:
+                    kw = {}
+                    if dY_next is not None:
+                        gid = next(id(bw) for g0, g1, bw in groups if g0 <= r0 and r1 <= g1)
+                        first = gid not in parts
+                        if first:
+                            parts[gid] = torch.empty(hip.LN_PART_BLOCKS, D, dtype=F32, device=dev)
+                        kw = dict(dxb=dY_next[r0:r1], sum_part=parts[gid], sum_accumulate=not first)
+                    pre = f"visual.transformer.resblocks.{i}" if b is e.vblk[i] else f"transformer.resblocks.{i}"
+                    dg, db = hip.layernorm_bwd(x_saved[r0 - r_lo:r1 - r_lo], dlno[r0:r1], b[which].g, dX[r0:r1], r1 - r0, **kw)
+                    n = "ln_1" if which == "ln1" else "ln_2"
+                    grads[f"{pre}.{n}.weight"], grads[f"{pre}.{n}.bias"] = dg, db
+                return {gid: hip.colsum(p) for gid, p in parts.items()} if dY_next is not None else None
+
             # ---- blocks, last to first
+            fuse_cast = not hip.env_flag("MSCLIP_LN_BWD_UNFUSED")
+            carry = None                      # (dY, bias sums) of this block's MLP half, left by the block above's ln_1 backward
             for i in reversed(range(e.n_layers)):
                 L = sv["layers"][i]
                 r_lo, segs, groups = L["r_lo"], L["segs"], L["groups"]
@@ -420,8 +442,12 @@ class TrainStep:
                 if e.vblk[i] is not None:                    # shared tensors live under their visual.* name (one Parameter)
                     names[id(e.vblk[i]["w"])] = f"visual.transformer.resblocks.{i}"
                 hid = L["hid"]
-                dY = torch.empty(M, D, dtype=BF, device=dev)
-                bsum = cast_with_bias_sums(dX, dY, r_lo, groups)
+                if carry is not None:
+                    dY, bsum = carry
+                    carry = None
+                else:
+                    dY = torch.empty(M, D, dtype=BF, device=dev)
+                    bsum = cast_with_bias_sums(dX, dY, r_lo, groups)
                 # gradients of the LayerNorm outputs stay fp32: they are only read by the LayerNorm backward, whose dbeta /
                 # dgamma are column sums of nearly cancelling terms (a bf16 dy costs 10-30 % on those sums at small batch)
                 dlno = torch.empty(M, D, dtype=F32, device=dev)
@@ -450,13 +476,11 @@ class TrainStep:
                     grads[p + ".mlp.c_fc.bias"] = gradgemm.on_lane(lambda a=src: hip.colsum(a), src)
                     _dgrad(dh[r0:r1], w_t(bw, 1), dlno[r0:r1])
                 del dh
-                for r0, r1, b in segs:
-                    pre = f"visual.transformer.resblocks.{i}" if b is e.vblk[i] else f"transformer.resblocks.{i}"
-                    dg, db = hip.layernorm_bwd(L["x_mid"][r0 - r_lo:r1 - r_lo], dlno[r0:r1], b["ln2"].g, dX[r0:r1], r1 - r0)
-                    grads[pre + ".ln_2.weight"], grads[pre + ".ln_2.bias"] = dg, db
-                # attention half
+                # attention half.  dX behind the ln_2 backward is out_proj's output gradient: its bf16 copy and bias sums leave with that pass
                 dY2 = torch.empty(M, D, dtype=BF, device=dev)          # not dY again: the lane stream may still read it (c_proj wgrad)
-                bsum = cast_with_bias_sums(dX, dY2, r_lo, groups)
+                bsum = ln_bwd_segments(L["x_mid"], dlno, segs, groups, r_lo, "ln2", i, dY2 if fuse_cast else None)
+                if bsum is None:
+                    bsum = cast_with_bias_sums(dX, dY2, r_lo, groups)
                 dao = torch.empty(M, D, dtype=BF, device=dev)
                 dqkv = torch.empty(M, 3 * D, dtype=BF, device=dev)      # attention_bwd writes every row of the towers that ran
                 for r0, r1, bw in groups:
@@ -493,10 +517,18 @@ class TrainStep:
                         return g
                     grads[p + ".attn.in_proj_bias"] = gradgemm.on_lane(bias_q, src)
                     _dgrad(dqkv[r0:r1], w_t(bw, 3), dlno[r0:r1])
-                for r0, r1, b in segs:
-                    pre = f"visual.transformer.resblocks.{i}" if b is e.vblk[i] else f"transformer.resblocks.{i}"
-                    dg, db = hip.layernorm_bwd(L["x_in"][r0 - r_lo:r1 - r_lo], dlno[r0:r1], b["ln1"].g, dX[r0:r1], r1 - r0)
-                    grads[pre + ".ln_1.weight"], grads[pre + ".ln_1.bias"] = dg, db
+                # dX behind the ln_1 backward is the output gradient of the block below's c_proj -- unless a lateral adapter's token
+                # path adds to the image rows first, or the block below runs other rows
+                below = sv["layers"][i - 1] if i > 0 else None
+                same = (below is not None and L["adapter"] is None and below["r_lo"] == r_lo and
+                        [(a, b_) for a, b_, _ in below["segs"]] == [(a, b_) for a, b_, _ in segs] and
+                        [(a, b_) for a, b_, _ in below["groups"]] == [(a, b_) for a, b_, _ in groups])
+                dY_below = torch.empty(M, D, dtype=BF, device=dev) if (fuse_cast and same) else None
+                bs = ln_bwd_segments(L["x_in"], dlno, segs, groups, r_lo, "ln1", i, dY_below)
+                if bs is not None:
+                    # keyed by THIS block's weight sets; the block below holds its own: same row ranges, so map by range
+                    by_range = {(g0, g1): bs[id(bw)] for g0, g1, bw in groups}
+                    carry = (dY_below, {id(bw): by_range[(g0, g1)] for g0, g1, bw in below["groups"]})
                 if L["adapter"] is not None:                                                   # token path of the lateral adapter
                     ad = L["adapter"]
                     a = e.adapters[ad["j"]]

@@ -162,6 +162,24 @@ def test_layernorm_backward(gpu_device, C, dy_f32, gather):
     dx2 = torch.full_like(x, 7.0)
     hip.layernorm_bwd(x, dy, gam, dx2, M, row_idx=idx, accumulate=False, want_param_grads=False)
     assert rel(dx2[idx.long()] if gather else dx2, xa.grad) < 2e-4
+    if not gather:
+        # the same pass with the bf16 copy of the written dx rows and their per-block column sums (training step: the next
+        # projection's output gradient and bias gradient without a cast_bf16_colsum pass): dx, dgamma, dbeta bit for bit; two row
+        # segments into one set of partials (second launch accumulates)
+        dx3 = torch.full_like(x, 0.5)
+        dxb = torch.full((M + 3, C), 7.0, dtype=BF, device="cuda")
+        part = torch.full((hip.LN_PART_BLOCKS, C), float("nan"), dtype=torch.float32, device="cuda")
+        cut = 336
+        dg1, db1 = hip.layernorm_bwd(x[:cut], dy[:cut], gam, dx3[:cut], cut, dxb=dxb[:cut], sum_part=part)
+        dg2, db2 = hip.layernorm_bwd(x[cut:], dy[cut:], gam, dx3[cut:], M - cut, dxb=dxb[cut:M], sum_part=part, sum_accumulate=True)
+        assert torch.equal(dx3, dx) and bool((dxb[M:] == 7.0).all())
+        assert torch.equal(dxb[:M], hip.cast_bf16(dx)) and bool(torch.isfinite(part).all())
+        assert rel(dg1 + dg2, ga.grad) < 2e-4 and rel(db1 + db2, ba.grad) < 2e-4
+        ref = dx.double().sum(0)
+        assert (hip.colsum(part).double() - ref).abs().max().item() <= 2e-6 * dx.abs().double().sum(0).max().item()
+        rc = hip.lib().msclip_layernorm_bwd(hip._p(x), x.stride(0), None, 1, hip._p(dy), dy.stride(0), int(dy_f32), hip._p(gam), hip._p(dx3),
+                                            dx3.stride(0), 1, None, hip.LN_PART_BLOCKS, M, C, 1e-12, hip._p(dxb), C, None, 0, None)
+        assert rc == -1                                                      # dxb without sum_part: refused
 
 
 @pytest.mark.parametrize("L,causal", [(50, False), (77, True), (64, False), (33, True), (96, True), (1, False),
