@@ -1052,13 +1052,15 @@ def adapter_dx(dsum, dww, dx, B, L, g, usecls):
     return dx
 
 
-def im2col(x, B, H, W, C, KH, KW, stride, pad, image=False):
+def im2col(x, B, H, W, C, KH, KW, stride, pad, image=False, kalign=64):
     """Patch matrix [B*Ho*Wo, Kp] bf16 of an NHWC bf16 activation (or of the NCHW fp32 / bf16 input image), Kp = KH*KW*C
-    rounded up to 64, column (kh*KW + kw)*C + ci."""
+    rounded up to kalign (64: a GEMM's K axis; a multiple of 8 is enough for the token-major weight-gradient GEMM, whose
+    operand rows only have to be 16-byte aligned), column (kh*KW + kw)*C + ci."""
+    assert kalign % 8 == 0
     Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
-    Kp = (KH * KW * C + 63) // 64 * 64
+    Kp = (KH * KW * C + kalign - 1) // kalign * kalign
     n = B * Ho * Wo * Kp
-    flat = torch.empty(n + 64, dtype=torch.bfloat16, device=x.device)      # 64 elements of slack behind the matrix
+    flat = torch.empty(n + 128, dtype=torch.bfloat16, device=x.device)     # slack behind the matrix: a 128-channel region read from the last row
     col = flat[:n].view(B * Ho * Wo, Kp)
     kind = (1 if x.dtype == torch.float32 else 2) if image else 0
     if not image:

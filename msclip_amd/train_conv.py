@@ -65,6 +65,10 @@ class _Fold:
 _PARITY_PLANS = {}
 
 
+def _image_kalign():
+    return 64 if hip.env_flag("MSCLIP_IMAGE_COLS_64") else 32
+
+
 class ConvSideBackward:
     def __init__(self, train_step):
         self.ts = train_step
@@ -256,10 +260,13 @@ class ConvSideBackward:
         self.col_img = None
         self.dpar = [None, None]                     # gradient of par[j] handed down to stage j: [shortcut path, conv1 path]
 
-    def _image_cols(self):
+    def _image_cols(self, gemm_operand=False):
+        """The image's 3 x 3 / stride 2 patch matrix (both Cin = 3 convolutions share it).  gemm_operand: it will be the X operand
+        of a forward GEMM (train-mode BatchNorm's raw convolutions), whose K axis is 64 wide; whoever asks first decides."""
         if self.col_img is None:
             S = self.e.S
-            self.col_img = hip.im2col(self.img, self.Bi, S, S, 3, 3, 3, 2, 1, image=True)
+            # 27 columns padded to 32, not 64: the token-major wgrad GEMM reads it as it is (half the bytes, written and read twice)
+            self.col_img = hip.im2col(self.img, self.Bi, S, S, 3, 3, 3, 2, 1, image=True, kalign=64 if gemm_operand else _image_kalign())
         return self.col_img
 
     def _first_conv(self, grads, conv_key, bn_prefix, dpre):
@@ -482,7 +489,7 @@ class ConvSideBatchNorm:
         w["stem"][i]."""
         e, w, Bi = self.e, self.w, self.Bi
         sp = "visual.transformer.resblocks.0"
-        col = self.bw._image_cols()
+        col = self.bw._image_cols(gemm_operand=True)
         pix = Bi * e.h1 * e.h1
         for wt, prefix, out in ((self.raw.w_conv1, sp + ".bn1", e._s1(w, Bi)),
                                 (self.raw.w_par0, "visual.transformer.parallel_branch_v.0.bn", w["P0"])):

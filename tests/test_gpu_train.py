@@ -362,7 +362,8 @@ def test_adamw_multi_packed_copies(gpu_device):
             assert bool((pk[n:] == 7.0).all())
 
 
-@pytest.mark.parametrize("geom", [(2, 12, 16, 3, 2, 1), (3, 9, 8, 1, 2, 0), (2, 8, 24, 3, 1, 1), (2, 10, 3, 3, 2, 1)])
+@pytest.mark.parametrize("geom", [(2, 12, 16, 3, 2, 1), (3, 9, 8, 1, 2, 0), (2, 8, 24, 3, 1, 1), (2, 10, 3, 3, 2, 1), (3, 32, 3, 3, 2, 1),
+                                  (2, 14, 3, 5, 1, 2)])
 def test_im2col_col2im_against_conv_autograd(gpu_device, geom):
     """dW = dY^T . im2col(X) and dX = col2im(dY . W) against autograd of F.conv2d (fp32 on the same bf16 values);
     the last geometry is the 3-channel NCHW image path (no input gradient)."""
@@ -378,6 +379,10 @@ def test_im2col_col2im_against_conv_autograd(gpu_device, geom):
     F.conv2d(xr, wr, stride=s, padding=pad).backward(dy)
     if image:
         col = hip.im2col(x.contiguous(), B, H, H, C, k, k, s, pad, image=True)
+        # the bf16 image and the narrower padding (what the token-major wgrad GEMM reads) hold the same columns
+        assert torch.equal(hip.im2col(x.to(BF).contiguous(), B, H, H, C, k, k, s, pad, image=True), col)
+        narrow = hip.im2col(x.contiguous(), B, H, H, C, k, k, s, pad, image=True, kalign=8)
+        assert narrow.shape[1] == (k * k * C + 7) // 8 * 8 and torch.equal(narrow, col[:, :narrow.shape[1]])
     else:
         col = hip.im2col(x.permute(0, 2, 3, 1).contiguous().to(BF).view(B * H * H, C), B, H, H, C, k, k, s, pad)
     K = k * k * C
