@@ -335,6 +335,18 @@ int msclip_clip_loss_partial(const float* lse_img, const float* lse_txt, const f
 /* out[c][m] = in[m][c] (bf16); columns m in [M, Mpad) are zero-filled (Mpad % 64 == 0: the K axis of a wgrad GEMM). */
 int msclip_transpose_bf16(const void* in, int ldi, void* out, int ldo, int M, int C, int Mpad, void* stream);
 
+/* The same for MANY matrices in one launch (the training step's W^T operands of the dgrad GEMMs, 48 per step): items [n_items]
+ * and blk_start [n_items + 1] (blk_start[i] = first workgroup of item i = the sum of (M / 64) * ceil(C / 64) over the items
+ * before it; n_blocks = blk_start[n_items]) are DEVICE arrays, built once for tensors whose storage persists.  Per item:
+ * out [C][ldo] = in [M][ldi]^T, bf16; M % 64 == 0, C % 8 == 0, ldi % 8 == 0, ldo % 8 == 0, ldo >= M, 16-byte aligned bases. */
+typedef struct msclip_transpose_item {
+  const void* in;
+  void* out;
+  int ldi, ldo, M, C;
+} msclip_transpose_item;
+int msclip_transpose_bf16_multi(const msclip_transpose_item* items_dev, const int* blk_start_dev, int n_items, int n_blocks,
+                                void* stream);
+
 /* y = bf16(x) for an fp32 matrix (C, ldx, ldy multiples of 4): gradient streams are fp32, GEMM operands bf16. */
 int msclip_cast_bf16(const float* x, int ldx, void* y, int ldy, int M, int C, void* stream);
 /* msclip_cast_bf16 that also leaves the column sums of x: part [part_blocks][C] fp32 receives per-block partial sums (block b

@@ -70,6 +70,49 @@ __global__ __launch_bounds__(256) void transpose_vec_kernel(const bf16_t* __rest
   }
 }
 
+// Many matrices in ONE launch (the training step's W^T operands of the dgrad GEMMs: 48 weight matrices per step, issued one
+// by one they kept the HOST busy for 0.6 ms at the start of the backward with the main queue idle behind it): a device-resident
+// table of items, blk_start[i] = first workgroup of item i (ascending, n_items + 1 entries); every item as transpose_vec_kernel
+// (M, C multiples of 64 / 8; 16-byte aligned rows).
+__global__ __launch_bounds__(256) void transpose_multi_kernel(const msclip_transpose_item* __restrict__ items,
+                                                              const int* __restrict__ blk_start, int n_items) {
+  __shared__ bf16_t tile[64][66];
+  int lo = 0, hi = n_items;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (blk_start[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
+  }
+  const msclip_transpose_item it = items[lo];
+  const int b = blockIdx.x - blk_start[lo], tx = it.M >> 6;
+  const int by = b / tx, bx = b - by * tx;
+  const int m0 = bx * 64, c0 = by * 64;
+  const bf16_t* in = (const bf16_t*)it.in;
+  bf16_t* out = (bf16_t*)it.out;
+  const int sub = threadIdx.x >> 3, ch = threadIdx.x & 7;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = sub + 32 * i, m = m0 + r, c = c0 + ch * 8;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (c < it.C) v = *(const uint4*)(in + (size_t)m * it.ldi + c);
+    unsigned* d = (unsigned*)&tile[r][ch * 8];
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = sub + 32 * i, c = c0 + r;
+    if (c < it.C) {
+      unsigned short e[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e[j] = tile[ch * 8 + j][r];
+      uint4 v;
+      v.x = e[0] | ((unsigned)e[1] << 16); v.y = e[2] | ((unsigned)e[3] << 16);
+      v.z = e[4] | ((unsigned)e[5] << 16); v.w = e[6] | ((unsigned)e[7] << 16);
+      *(uint4*)(out + (size_t)c * it.ldo + m0 + ch * 8) = v;
+    }
+  }
+}
+
 // ---- out[n] (+)= sum_m x[m][n]: bias gradients and the second stage of the LayerNorm parameter gradients.
 // One block per 64 columns; 4 waves stride the rows, lanes own columns; fixed summation order (deterministic).
 // Single-launch form of the chunked sums (round 5: the training step issued 260 second-stage launches per step).  Every
@@ -695,6 +738,13 @@ extern "C" int msclip_transpose_bf16(const void* in, int ldi, void* out, int ldo
   else
     hipLaunchKernelGGL(transpose_kernel, dim3((Mpad + 63) / 64, (C + 63) / 64), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)in, ldi, (bf16_t*)out, ldo, M, C, Mpad);
+  return msclip_launch_status();
+}
+
+extern "C" int msclip_transpose_bf16_multi(const msclip_transpose_item* items_dev, const int* blk_start_dev, int n_items,
+                                           int n_blocks, void* stream) {
+  if (!items_dev || !blk_start_dev || n_items <= 0 || n_blocks <= 0) return MSCLIP_EINVAL;
+  hipLaunchKernelGGL(transpose_multi_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, items_dev, blk_start_dev, n_items);
   return msclip_launch_status();
 }
 

@@ -28,7 +28,7 @@ EXPORTS = (
     "msclip_bn_bwd_reduce", "msclip_bn_bwd_dx", "msclip_bn_fold_bwd", "msclip_bn_finish", "msclip_bn_finish_tiled", "msclip_bn_bwd_finish",
     "msclip_text_lengths", "msclip_embed_tokens_packed", "msclip_attention_varlen", "msclip_attention_lastq_varlen",
     "msclip_attention_bwd_varlen", "msclip_embed_tokens_bwd_packed",
-    "msclip_qkv_attention", "msclip_qkvattn_tables", "msclip_pack_weights",
+    "msclip_qkv_attention", "msclip_qkvattn_tables", "msclip_pack_weights", "msclip_transpose_bf16_multi",
     "msclip_abi_version", "msclip_build_arch",
     "msclip_stream_priority_range", "msclip_stream_create", "msclip_stream_destroy",
 )
@@ -164,6 +164,7 @@ def lib():
         L.msclip_qkv_attention.argtypes = [ctypes.POINTER(QkvAttnDesc), vp]
         L.msclip_qkvattn_tables.argtypes = [vp, ci, ci, vp, vp, vp, ci, ci, vp]
         L.msclip_pack_weights.argtypes = [vp, vp, ci, ci, vp]
+        L.msclip_transpose_bf16_multi.argtypes = [vp, vp, ci, ci, vp]
         L.msclip_abi_version.restype = ci
         if L.msclip_abi_version() != ABI_VERSION:          # a stale build of the library (the struct layouts / entry points moved on)
             raise HipUnavailable(f"{LIB_PATH} has ABI version {L.msclip_abi_version()}, this binding needs {ABI_VERSION}: rebuild "
@@ -1315,6 +1316,45 @@ class PackPlan:
 
     def run(self):
         _check(lib().msclip_pack_weights(_p(self.table), _p(self.blk_start), self.n_items, self.n_blocks, _stream()), "msclip_pack_weights")
+
+
+class TransposeItem(ctypes.Structure):
+    """msclip_transpose_item (include/msclip_hip.h)."""
+    _fields_ = [("in_", ctypes.c_void_p), ("out", ctypes.c_void_p), ("ldi", ctypes.c_int), ("ldo", ctypes.c_int), ("M", ctypes.c_int),
+                ("C", ctypes.c_int)]
+
+
+class TransposePlan:
+    """W^T of many bf16 matrices in ONE launch (msclip_transpose_bf16_multi): the sources' storage must persist (the engine's
+    packed block weights, rewritten in place by the optimizer kernel); the outputs [C, M] are owned by the plan and rewritten
+    by every run() -- on the stream run() is called on, so whoever still reads the previous run's outputs must be ordered in
+    front of it.  `key` = the sources' addresses (a plan is valid while they do not move)."""
+
+    def __init__(self, tensors):
+        self.device = tensors[0].device
+        self.key = tuple(t.data_ptr() for t in tensors)
+        items, starts, tot, self.outs = [], [], 0, []
+        for t in tensors:
+            _bf16(t)
+            M, C = t.shape
+            assert M % 64 == 0 and C % 8 == 0 and t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0
+            out = torch.empty(C, M, dtype=torch.bfloat16, device=self.device)
+            it = TransposeItem()
+            it.in_, it.out, it.ldi, it.ldo, it.M, it.C = t.data_ptr(), out.data_ptr(), t.stride(0), M, M, C
+            items.append(it)
+            self.outs.append(out)
+            starts.append(tot)
+            tot += (M // 64) * ((C + 63) // 64)
+        starts.append(tot)
+        arr = (TransposeItem * len(items))(*items)
+        self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone().to(self.device)
+        self.blk_start = torch.tensor(starts, dtype=torch.int32).to(self.device)
+        self.n_items, self.n_blocks = len(items), tot
+
+    def run(self):
+        _check(lib().msclip_transpose_bf16_multi(_p(self.table), _p(self.blk_start), self.n_items, self.n_blocks, _stream()),
+               "msclip_transpose_bf16_multi")
+        return self.outs
 
 
 class AdamwTensor(ctypes.Structure):

@@ -60,6 +60,17 @@ def test_transpose_cast_colsum_gelu(gpu_device):
     x3 = rnd(130, 27, seed=5, dtype=BF)                               # odd width: the scalar tile kernel
     t3 = hip.transpose_bf16(x3)
     assert t3.shape == (27, 192) and torch.equal(t3[:, :130], x3.t()) and bool((t3[:, 130:] == 0).all())
+    # many matrices in one launch (the training step's W^T operands); a row-range view as a source; repeated runs rewrite the outputs
+    big = rnd(900, 3080, seed=6, dtype=BF)
+    mats = [rnd(768, 3072, seed=7, dtype=BF), rnd(3072, 768, seed=8, dtype=BF), rnd(64, 8, seed=9, dtype=BF), big[64:832, 8:2312],
+            rnd(2304, 776, seed=10, dtype=BF)[:, :768]]
+    plan = hip.TransposePlan(mats)
+    for rep in range(2):
+        outs = plan.run()
+        for m, o in zip(mats, outs):
+            assert o.shape == (m.shape[1], m.shape[0]) and torch.equal(o, m.t())
+        mats[0].mul_(2.0)
+        mats[3].add_(1.0)
     f = rnd(300, 768, seed=2)
     assert torch.equal(hip.cast_bf16(f), f.to(BF))
     assert rel(hip.colsum(f), f.sum(0)) < 1e-5 and rel(hip.colsum(x), x.float().sum(0)) < 1e-5
