@@ -425,6 +425,15 @@ int msclip_adapter_dx(const float* dsum, int lds, const float* dww, float* dx, i
  * msclip_relu_bwd: out = (dy [+ dy2]) * (y > 0) over n bf16 elements (n % 8 == 0; dy2 may be null). */
 int msclip_im2col(const void* x, int x_kind, void* col, int B, int H, int W, int C, int KH, int KW, int stride, int pad,
                   int Ho, int Wo, int Kp, void* stream);
+
+/* Weight + bias gradient of a 3 x 3 / stride 2 / pad 1 convolution on the fp32 NCHW input image [B, 3, S, S] (the stem's conv1,
+ * parallel stage 0: M.py:1898-1905, 1812-1830) WITHOUT a patch matrix: dy bf16 [B * Ho * Ho, lddy] (Ho = S / 2 rounded up), co
+ * <= 64 channels (a multiple of 8).  part fp32 [part_blocks][co_pad = 16 ceil(co / 16)][32]: block partials of
+ * dW[co][(kh * 3 + kw) * 3 + ci] (columns 0..26; the image rounded to bf16 like msclip_im2col's patch matrix), column 27 = sum
+ * of dy (the bias gradient), 28..31 zero; rows co.. of a partial are zero.  Fold with msclip_colsum over [part_blocks, co_pad *
+ * 32].  S % 4 == 0, S <= 256; blocks beyond the work write zeros. */
+int msclip_image_conv_wgrad(const float* img, const void* dy, int lddy, float* part, int part_blocks, int B, int S, int co,
+                            void* stream);
 int msclip_col2im(const void* dcol, int ld, void* dx, int B, int H, int W, int C, int KH, int KW, int stride, int pad, int Ho,
                   int Wo, int accumulate, void* stream);
 int msclip_relu_bwd(const void* dy, const void* dy2, const void* y, void* out, long long n, void* stream);

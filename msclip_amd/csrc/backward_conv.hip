@@ -128,6 +128,112 @@ __global__ __launch_bounds__(256) void im2col_image_rows_kernel(const void* __re
   }
 }
 
+// ---- Weight (and bias) gradient of a 3 x 3 / stride 2 / pad 1 convolution ON THE INPUT IMAGE, without a patch matrix
+// (msclip_image_conv_wgrad; the stem's conv1 and parallel stage 0, M.py:1898-1905 / 1812-1830: 3 input channels, 224 x 224 ->
+// 112 x 112, 6.4 M output pixels at batch 512).  dW[co][tap] = sum_pix dY[pix][co] col[pix][tap] is a 48 x 27 result over a
+// 6.4 M-deep contraction: a streaming reduction whose floor is one read of dY.  Through the generic path it was three passes --
+// the patch matrix written (im2col, 0.32 ms) and read by a split-K GEMM built for wide operands (256-byte row pieces of a
+// 64-byte row: 1.15 ms for 48 channels), the bias sums a third (0.19 ms) -- all on the main queue at the end of the backward.
+// Here a workgroup takes (image, output row) units: the row's dY [Wo][co] and the three image rows x three channels it reads go
+// to LDS; wave w contracts pixels 32 w .. 32 w + 31 (Wo <= 128, padded with zero dY rows) on v_mfma_f32_16x16x32_bf16 --
+// A = dY^T fragments by ds_read_b64_tr_b16 from the row-major tile, B[tap][pixel] gathered from the fp32 image rows (stride-2
+// LDS reads, rounded to bf16 as the patch matrix was); tap 27 is the constant 1, so column 27 of the result is sum dY, the bias
+// gradient.  Accumulators stay in registers across a workgroup's units; part[block][co_pad][32] fp32, folded by msclip_colsum
+// (fixed order).  ~20 KB of LDS and < 96 VGPRs: 5-6 workgroups per CU hide the load -> LDS -> MFMA chain of each other.
+typedef __attribute__((ext_vector_type(4))) __bf16 icw_bf16x4;
+__device__ __forceinline__ bf16x8 icw_ld_tr8(const char* p0, const char* p1) {
+  const icw_bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((AS3 icw_bf16x4*)p0);
+  const icw_bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((AS3 icw_bf16x4*)p1);
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int MT>                                      // co padded to 16 * MT output channels
+__global__ __launch_bounds__(256) void image_conv_wgrad_kernel(const float* __restrict__ img, const bf16_t* __restrict__ dy, int lddy,
+                                                               float* __restrict__ part, int B, int S, int Ho, int co,
+                                                               int units_per_block) {
+  constexpr int CP = 16 * MT, RS = CP + 8;             // dY tile row stride (elements): 16-byte aligned rows, tr-read friendly
+  constexpr int IW = 264;                              // image row stride (floats): pixel iw sits at [iw + 4]
+  __shared__ __attribute__((aligned(16))) bf16_t dyt[128 * RS];
+  __shared__ __attribute__((aligned(16))) float rows[9 * IW];
+  __shared__ float red[CP * 32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, quad = lane >> 4;
+  const int Wo = Ho, W = S, H = S;
+  // zero once: the dY rows of pixels >= Wo (and the channel padding), the image rows' borders
+  for (int i = tid; i < 128 * RS / 2; i += 256) ((unsigned*)dyt)[i] = 0;
+  for (int i = tid; i < 9 * IW; i += 256) rows[i] = 0.f;
+  __syncthreads();
+  f32x4 acc[MT][2];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) acc[mt][0] = acc[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // this lane's two taps n = r16, 16 + r16: column (kh * 3 + kw) * 3 + ci of the patch matrix; 27 = the constant 1; 28.. = 0
+  int roff[2], kind[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int n = nt * 16 + r16;
+    const int tap = n / 3, ci = n - tap * 3, kh = tap / 3, kw = tap - kh * 3;
+    kind[nt] = n < 27 ? 0 : (n == 27 ? 1 : 2);
+    roff[nt] = n < 27 ? (ci * 3 + kh) * IW + kw - 1 + 4 : 0;
+  }
+  const int co8 = co >> 3, w4 = W >> 2;
+  const int total = B * Ho;
+  const int u0 = blockIdx.x * units_per_block, u1 = min(total, u0 + units_per_block);
+  for (int u = u0; u < u1; ++u) {
+    const int b = u / Ho, oh = u - b * Ho;
+    // ---- this unit's dY row block and image rows -> LDS
+    const bf16_t* dsrc = dy + (size_t)u * Wo * lddy;
+    for (int i = tid; i < Wo * co8; i += 256) {
+      const int px = i / co8, c8 = i - px * co8;
+      *(uint4*)(dyt + px * RS + c8 * 8) = *(const uint4*)(dsrc + (size_t)px * lddy + c8 * 8);
+    }
+    const int ih0 = oh * 2 - 1;
+    for (int i = tid; i < 9 * w4; i += 256) {
+      const int r = i / w4, x4 = i - r * w4;
+      const int ci = r / 3, kh = r - ci * 3, ih = ih0 + kh;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((unsigned)ih < (unsigned)H) v = *(const float4*)(img + (((size_t)b * 3 + ci) * H + ih) * W + x4 * 4);
+      *(float4*)(rows + r * IW + 4 + x4 * 4) = v;
+    }
+    __syncthreads();
+    // ---- wave w: pixels 32 w .. 32 w + 31
+    bf16x8 bf[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      float f[8];
+      const float* rp = rows + roff[nt] + 2 * (wave * 32 + quad * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = kind[nt] == 0 ? rp[2 * e] : (kind[nt] == 1 ? 1.f : 0.f);
+      uint4 pk;
+      pk.x = pack_bf16x2(f[0], f[1]); pk.y = pack_bf16x2(f[2], f[3]); pk.z = pack_bf16x2(f[4], f[5]); pk.w = pack_bf16x2(f[6], f[7]);
+      bf[nt] = *reinterpret_cast<bf16x8*>(&pk);
+    }
+    const char* abase = (const char*)(dyt + (wave * 32 + quad * 8 + (r16 >> 2)) * RS + 4 * (r16 & 3));
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const bf16x8 a = icw_ld_tr8(abase + mt * 32, abase + mt * 32 + 4 * RS * 2);
+      acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[0], acc[mt][0], 0, 0, 0);
+      acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[1], acc[mt][1], 0, 0, 0);
+    }
+    __syncthreads();                                   // every wave is done with the tiles before the next unit's are written
+  }
+  // ---- the four waves' accumulators, added in wave order; acc[mt][nt][r] = dW[mt * 16 + quad * 4 + r][nt * 16 + r16]
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float* q = red + (mt * 16 + quad * 4 + r) * 32 + nt * 16 + r16;
+            *q = w ? *q + acc[mt][nt][r] : acc[mt][nt][r];
+          }
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < CP * 32; i += 256) part[(size_t)blockIdx.x * CP * 32 + i] = red[i];
+}
+
 // one thread = one input pixel's 8-channel chunk; sums the patch-matrix entries of every (output pixel, tap) that read it
 __global__ __launch_bounds__(256) void col2im_kernel(const bf16_t* __restrict__ dcol, int ld, bf16_t* __restrict__ dx, int B,
                                                      int H, int W, int C, int KH, int KW, int stride, int pad, int Ho, int Wo,
@@ -534,6 +640,26 @@ extern "C" int msclip_im2col(const void* x, int x_kind, void* col, int B, int H,
   else if (C % 8 == 0) IM2COL(0);
   else IM2COL(3);
 #undef IM2COL
+  return msclip_launch_status();
+}
+
+extern "C" int msclip_image_conv_wgrad(const float* img, const void* dy, int lddy, float* part, int part_blocks, int B, int S,
+                                       int co, void* stream) {
+  const int Ho = (S + 2 - 3) / 2 + 1;
+  if (!img || !dy || !part || B <= 0 || S <= 0 || (S & 3) || S > 256 || Ho > 128 || co <= 0 || co > 64 || (co & 7) || (lddy & 7) ||
+      lddy < co || part_blocks < 1 || ((size_t)img & 15) || ((size_t)dy & 15))
+    return MSCLIP_EINVAL;
+  const int total = B * Ho;
+  const int upb = (total + part_blocks - 1) / part_blocks;
+  hipStream_t st = (hipStream_t)stream;
+#define ICW(MT)                                                                                                              \
+  hipLaunchKernelGGL(image_conv_wgrad_kernel<MT>, dim3(part_blocks), dim3(256), 0, st, img, (const bf16_t*)dy, lddy, part, B, S, \
+                     Ho, co, upb)
+  if (co <= 16) ICW(1);
+  else if (co <= 32) ICW(2);
+  else if (co <= 48) ICW(3);
+  else ICW(4);
+#undef ICW
   return msclip_launch_status();
 }
 

@@ -28,7 +28,7 @@ EXPORTS = (
     "msclip_bn_bwd_reduce", "msclip_bn_bwd_dx", "msclip_bn_fold_bwd", "msclip_bn_finish", "msclip_bn_finish_tiled", "msclip_bn_bwd_finish",
     "msclip_text_lengths", "msclip_embed_tokens_packed", "msclip_attention_varlen", "msclip_attention_lastq_varlen",
     "msclip_attention_bwd_varlen", "msclip_embed_tokens_bwd_packed",
-    "msclip_qkv_attention", "msclip_qkvattn_tables", "msclip_pack_weights", "msclip_transpose_bf16_multi",
+    "msclip_qkv_attention", "msclip_qkvattn_tables", "msclip_pack_weights", "msclip_transpose_bf16_multi", "msclip_image_conv_wgrad",
     "msclip_abi_version", "msclip_build_arch",
     "msclip_stream_priority_range", "msclip_stream_create", "msclip_stream_destroy",
 )
@@ -165,6 +165,7 @@ def lib():
         L.msclip_qkvattn_tables.argtypes = [vp, ci, ci, vp, vp, vp, ci, ci, vp]
         L.msclip_pack_weights.argtypes = [vp, vp, ci, ci, vp]
         L.msclip_transpose_bf16_multi.argtypes = [vp, vp, ci, ci, vp]
+        L.msclip_image_conv_wgrad.argtypes = [vp, vp, ci, vp, ci, ci, ci, ci, vp]
         L.msclip_abi_version.restype = ci
         if L.msclip_abi_version() != ABI_VERSION:          # a stale build of the library (the struct layouts / entry points moved on)
             raise HipUnavailable(f"{LIB_PATH} has ABI version {L.msclip_abi_version()}, this binding needs {ABI_VERSION}: rebuild "
@@ -1068,6 +1069,32 @@ def im2col(x, B, H, W, C, KH, KW, stride, pad, image=False, kalign=64):
         _bf16(x)
     _check(lib().msclip_im2col(_p(x), kind, _p(col), B, H, W, C, KH, KW, stride, pad, Ho, Wo, Kp, _stream()), "msclip_im2col")
     return col
+
+
+IMAGE_WGRAD_BLOCKS = 1280
+
+
+def image_conv_wgrad_ok(img, dy):
+    """Can msclip_image_conv_wgrad take this image / output gradient (fp32 NCHW image of 3 channels, side <= 256 and a multiple
+    of 4; <= 64 output channels, a multiple of 8)?"""
+    return (img.dtype == torch.float32 and img.dim() == 4 and img.shape[1] == 3 and img.shape[2] == img.shape[3] and
+            img.is_contiguous() and img.shape[2] % 4 == 0 and img.shape[2] <= 256 and dy.dtype == torch.bfloat16 and
+            dy.stride(1) == 1 and dy.shape[1] % 8 == 0 and dy.shape[1] <= 64 and dy.stride(0) % 8 == 0)
+
+
+def image_conv_wgrad(img, dy):
+    """3 x 3 / stride 2 / pad 1 convolution on the input image: -> (dW fp32 [co, 27] with column (kh * 3 + kw) * 3 + ci, sum of
+    dy fp32 [co]) from ONE pass over dy [B * Ho * Ho, co] and the image -- no patch matrix, no separate bias-sum pass."""
+    assert image_conv_wgrad_ok(img, dy)
+    B, S, co = img.shape[0], img.shape[2], dy.shape[1]
+    Ho = (S - 1) // 2 + 1
+    assert dy.shape[0] >= B * Ho * Ho
+    cp = (co + 15) // 16 * 16
+    part = torch.empty(IMAGE_WGRAD_BLOCKS, cp * 32, dtype=torch.float32, device=dy.device)
+    _check(lib().msclip_image_conv_wgrad(_p(img), _p(dy), dy.stride(0), _p(part), IMAGE_WGRAD_BLOCKS, B, S, co, _stream()),
+           "msclip_image_conv_wgrad")
+    both = colsum(part).view(cp, 32)
+    return both[:co, :27], both[:co, 27]
 
 
 def col2im(dcol, dx, B, H, W, C, KH, KW, stride, pad, accumulate=False):

@@ -273,9 +273,13 @@ class ConvSideBackward:
         """wgrad of a 3x3 / stride 2 convolution on the input image (no input gradient)."""
         pix = self.Bi * self.e.h1 * self.e.h1
         co = dpre.shape[1]
-        dwf = _wgrad(dpre, self._image_cols(), pix)[:, :27]
+        if hip.image_conv_wgrad_ok(self.img, dpre) and self.e.h1 <= 128 and not hip.env_flag("MSCLIP_FIRST_CONV_GEMM"):
+            # one pass over dpre and the image: no patch matrix, the bias sums in the same contraction (round 5)
+            dwf, dbias = hip.image_conv_wgrad(self.img, dpre)
+        else:
+            dwf, dbias = _wgrad(dpre, self._image_cols(), pix)[:, :27], hip.colsum(dpre, M=pix)
         G = dwf.reshape(co, 3, 3, 3).permute(0, 3, 1, 2).contiguous()          # (kh, kw, ci) -> [co, ci, kh, kw]
-        _Fold(self.sd, bn_prefix, 1e-5).grads(grads, conv_key, G, self.sd[conv_key].float(), hip.colsum(dpre, M=pix))
+        _Fold(self.sd, bn_prefix, 1e-5).grads(grads, conv_key, G, self.sd[conv_key].float(), dbias)
 
     # ------------------------------------------------------------------ lateral adapter j + parallel stage j
     def adapter(self, grads, j, dsum, x_pre):

@@ -373,6 +373,30 @@ def test_adamw_multi_packed_copies(gpu_device):
             assert bool((pk[n:] == 7.0).all())
 
 
+@pytest.mark.parametrize("B,S,co", [(3, 32, 48), (2, 224, 24), (5, 36, 16), (2, 64, 64), (1, 256, 40)])
+def test_image_conv_wgrad_without_a_patch_matrix(gpu_device, B, S, co):
+    """msclip_image_conv_wgrad (the stem's conv1 / parallel stage 0 on the input image): dW and the bias sums from one pass over dy
+    and the image, against autograd of F.conv2d on the bf16-rounded image and against the patch-matrix path; odd output sides,
+    channel counts below a 16-tile, the image borders."""
+    Ho = (S - 1) // 2 + 1
+    img = rnd(B, 3, S, S, seed=41)
+    dy = rnd(B * Ho * Ho + 5, co, seed=42, dtype=BF)[:B * Ho * Ho]
+    assert hip.image_conv_wgrad_ok(img, dy)
+    dw, db = hip.image_conv_wgrad(img, dy)
+    assert dw.shape == (co, 27) and db.shape == (co,)
+    xr = img.to(BF).float()
+    wr = torch.zeros(co, 3, 3, 3, device="cuda", requires_grad=True)
+    F.conv2d(xr, wr, stride=2, padding=1).backward(dy.float().view(B, Ho, Ho, co).permute(0, 3, 1, 2))
+    ref = wr.grad.permute(0, 2, 3, 1).reshape(co, 27)                          # [co, ci, kh, kw] -> column (kh * 3 + kw) * 3 + ci
+    assert rel(dw, ref) < 2e-5, rel(dw, ref)
+    assert rel(db, dy.float().sum(0)) < 2e-5
+    col = hip.im2col(img, B, S, S, 3, 3, 3, 2, 1, image=True)
+    assert rel(dw, dy.float().t() @ col.float()[:, :27]) < 2e-5
+    dw2, db2 = hip.image_conv_wgrad(img, dy)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)                     # fixed summation order
+    assert not hip.image_conv_wgrad_ok(img.to(BF), dy) and not hip.image_conv_wgrad_ok(img, dy[:, :co - 4])
+
+
 @pytest.mark.parametrize("geom", [(2, 12, 16, 3, 2, 1), (3, 9, 8, 1, 2, 0), (2, 8, 24, 3, 1, 1), (2, 10, 3, 3, 2, 1), (3, 32, 3, 3, 2, 1),
                                   (2, 14, 3, 5, 1, 2)])
 def test_im2col_col2im_against_conv_autograd(gpu_device, geom):
