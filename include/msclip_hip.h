@@ -271,6 +271,13 @@ int msclip_gather_rows(const void* x, long long ldx_bytes, const int* row_idx, i
 int msclip_stem_conv3x3s2_dual(const void* img, int img_is_bf16, const float* w, const float* bias, void* out_a,
                                void* out_b, int B, int H, int W, int C1, void* stream);
 
+/* The same pass WITHOUT BatchNorm fold, bias and ReLU, fp32 outputs [B * Ho * Wo][48] each: the raw convolution outputs that
+ * train-mode BatchNorm normalises with batch statistics (the training step's forward; nn.BatchNorm2d in train(), M.py:1993-1995,
+ * 2260-2273).  w: fp32 [27][96], row ci * 9 + kh * 3 + kw, columns = conv1's 48 output channels then parallel stage 0's; image and
+ * filters are rounded to bf16 for the MFMA like every convolution operand here.  No patch matrix. */
+int msclip_stem_conv3x3s2_dual_raw(const void* img, int img_is_bf16, const float* w, float* out_a, float* out_b, int B, int H, int W,
+                                   void* stream);
+
 /* The same pass fused with the 3x3/s2/p1 convolution that consumes branch a (stem resnet_stage.conv_0 with its folded
  * 1x1 shortcut and ReLU, M.py:1920-1936): branch a's 48-channel map stays in LDS (8x8 output tiles, 17x17 windows),
  * branch b (parallel stage 0) is written as before.  w2: bf16 [Cout][448] (K = (kh*3+kw)*48 + c, zero padded),

@@ -76,18 +76,23 @@ __global__ __launch_bounds__(256) void stem_dual_kernel(const InT* __restrict__ 
 // 96 x 32 filter bank held in registers as bf16 (6 v_mfma_f32_32x32x16_bf16) and writes the two NHWC outputs through
 // a 6-KiB staging block as two contiguous 3-KiB runs (consecutive pixels are adjacent in NHWC).
 // The pass is HBM-bound: 4 B/pixel/channel in, 2 x 96 B per output pixel out.
-template <typename InT>
+// RAW (msclip_stem_conv3x3s2_dual_raw; the training step under train-mode BatchNorm, which normalises the RAW convolution outputs
+// with batch statistics): no bias, no ReLU, fp32 outputs [pixels][48] -- the staging planes and the output runs are twice as long.
+template <typename InT, bool RAW = false>
 __global__ __launch_bounds__(256) void stem_dual_mfma_kernel(const InT* __restrict__ img, const float* __restrict__ w,
-                                                             const float* __restrict__ bias, bf16_t* __restrict__ out_a,
-                                                             bf16_t* __restrict__ out_b, int B, int H, int W, int Ho,
+                                                             const float* __restrict__ bias, void* __restrict__ out_a_,
+                                                             void* __restrict__ out_b_, int B, int H, int W, int Ho,
                                                              int Wo) {
-  __shared__ __attribute__((aligned(16))) char stg_all[4 * 6144];
+  constexpr int PLANE = RAW ? 6144 : 3072;            // bytes of one staged output: 32 pixels x 48 channels
+  __shared__ __attribute__((aligned(16))) char stg_all[4 * 2 * PLANE];
   __shared__ __attribute__((aligned(16))) float bias_l[96];
-  if (threadIdx.x < 96) bias_l[threadIdx.x] = bias[threadIdx.x];
+  if (threadIdx.x < 96) bias_l[threadIdx.x] = RAW ? 0.f : bias[threadIdx.x];
   __syncthreads();
+  char* out_a = (char*)out_a_;
+  char* out_b = (char*)out_b_;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  char* stg = stg_all + wave * 6144;
+  char* stg = stg_all + wave * 2 * PLANE;
   const int fr = lane & 31, fhi = lane >> 5;
 
   // filter bank as A fragments: tile t (32 output channels), k-step s (16 taps): lane (fr, fhi) holds taps
@@ -159,19 +164,25 @@ __global__ __launch_bounds__(256) void stem_dual_mfma_kernel(const InT* __restri
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int c = t * 32 + g * 8 + fhi * 4;                  // never straddles 48
-        uint2 o;
-        o.x = pack_bf16x2(fmaxf(acc[t][g * 4 + 0], 0.f), fmaxf(acc[t][g * 4 + 1], 0.f));
-        o.y = pack_bf16x2(fmaxf(acc[t][g * 4 + 2], 0.f), fmaxf(acc[t][g * 4 + 3], 0.f));
         const int plane = c >= 48, cc = c - plane * 48;
-        *(uint2*)(stg + plane * 3072 + fr * 96 + cc * 2) = o;
+        if constexpr (RAW) {
+          *(float4*)(stg + plane * PLANE + fr * 192 + cc * 4) =
+              make_float4(acc[t][g * 4 + 0], acc[t][g * 4 + 1], acc[t][g * 4 + 2], acc[t][g * 4 + 3]);
+        } else {
+          uint2 o;
+          o.x = pack_bf16x2(fmaxf(acc[t][g * 4 + 0], 0.f), fmaxf(acc[t][g * 4 + 1], 0.f));
+          o.y = pack_bf16x2(fmaxf(acc[t][g * 4 + 2], 0.f), fmaxf(acc[t][g * 4 + 3], 0.f));
+          *(uint2*)(stg + plane * PLANE + fr * 96 + cc * 2) = o;
+        }
       }
     const long long p0 = blk * 32;
+    constexpr int PXB = RAW ? 192 : 96;                          // bytes per pixel of one output; PXB / 16 chunks per pixel
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int ch = i * 64 + lane;                              // 16-byte chunk of the 3-KiB run; 6 chunks per pixel
-      if (p0 + ch / 6 < total) {
-        *(uint4*)((char*)(out_a + (size_t)p0 * 48) + ch * 16) = *(const uint4*)(stg + ch * 16);
-        *(uint4*)((char*)(out_b + (size_t)p0 * 48) + ch * 16) = *(const uint4*)(stg + 3072 + ch * 16);
+    for (int i = 0; i < PLANE / 1024; ++i) {
+      const int ch = i * 64 + lane;                              // 16-byte chunk of the plane's contiguous run
+      if (p0 + ch / (PXB / 16) < total) {
+        *(uint4*)(out_a + (size_t)p0 * PXB + ch * 16) = *(const uint4*)(stg + ch * 16);
+        *(uint4*)(out_b + (size_t)p0 * PXB + ch * 16) = *(const uint4*)(stg + PLANE + ch * 16);
       }
     }
 #pragma unroll
@@ -342,6 +353,24 @@ __global__ __launch_bounds__(256) void patchify_kernel(const T* __restrict__ img
 }
 }  // namespace
 
+extern "C" int msclip_stem_conv3x3s2_dual_raw(const void* img, int img_is_bf16, const float* w, float* out_a, float* out_b, int B,
+                                              int H, int W, void* stream) {
+  if (!img || !w || !out_a || !out_b || B <= 0 || H < 2 || W < 2 || (H & 1) || (W & 1)) return MSCLIP_EINVAL;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const long long nblk = ((long long)B * Ho * Wo + 31) / 32;
+  long long g = (nblk + 3) / 4;
+  if (g > 256 * 3) g = 256 * 3;                                  // 48 KB of staging per workgroup: three per CU
+  const dim3 grid((unsigned)g), blk(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (img_is_bf16)
+    hipLaunchKernelGGL((stem_dual_mfma_kernel<bf16_t, true>), grid, blk, 0, st, (const bf16_t*)img, w, (const float*)nullptr,
+                       (void*)out_a, (void*)out_b, B, H, W, Ho, Wo);
+  else
+    hipLaunchKernelGGL((stem_dual_mfma_kernel<float, true>), grid, blk, 0, st, (const float*)img, w, (const float*)nullptr,
+                       (void*)out_a, (void*)out_b, B, H, W, Ho, Wo);
+  return msclip_launch_status();
+}
+
 extern "C" int msclip_stem_conv3x3s2_dual(const void* img, int img_is_bf16, const float* w, const float* bias,
                                           void* out_a, void* out_b, int B, int H, int W, int C1, void* stream) {
   if (!img || !w || !bias || !out_a || !out_b || B <= 0 || (C1 != 48 && C1 != 64) || H < 2 || W < 2 || (H & 1) || (W & 1)) return MSCLIP_EINVAL;
@@ -374,8 +403,8 @@ extern "C" int msclip_stem_conv3x3s2_dual(const void* img, int img_is_bf16, cons
   if (g > 256 * 8) g = 256 * 8;                                  // persistent: up to 8 workgroups of 4 waves per CU
   const dim3 grid((unsigned)g), blk(256);
   if (img_is_bf16)
-    hipLaunchKernelGGL((stem_dual_mfma_kernel<bf16_t>), grid, blk, 0, st, (const bf16_t*)img, w, bias, (bf16_t*)out_a,
-                       (bf16_t*)out_b, B, H, W, Ho, Wo);
+    hipLaunchKernelGGL((stem_dual_mfma_kernel<bf16_t>), grid, blk, 0, st, (const bf16_t*)img, w, bias, out_a, out_b, B, H, W, Ho,
+                       Wo);
   else
     hipLaunchKernelGGL((stem_dual_mfma_kernel<float>), grid, blk, 0, st, (const float*)img, w, bias, (bf16_t*)out_a,
                        (bf16_t*)out_b, B, H, W, Ho, Wo);

@@ -18,7 +18,7 @@ ABI_VERSION = 6                                          # include/msclip_hip.h 
 
 EXPORTS = (
     "msclip_gemm", "msclip_gemm_f8", "msclip_layernorm_stats", "msclip_rowstat_finalize", "msclip_layernorm_f8", "msclip_quant_f8_rows", "msclip_gemm_variant", "msclip_attention", "msclip_attention_lastq", "msclip_layernorm", "msclip_layernorm_split", "msclip_embed_tokens", "msclip_fill_cls",
-    "msclip_adapter_combine_ln", "msclip_adapter_combine_ln_stats", "msclip_l2norm", "msclip_gather_rows", "msclip_stem_conv3x3s2_dual", "msclip_dwpool",
+    "msclip_adapter_combine_ln", "msclip_adapter_combine_ln_stats", "msclip_l2norm", "msclip_gather_rows", "msclip_stem_conv3x3s2_dual", "msclip_stem_conv3x3s2_dual_raw", "msclip_dwpool",
     "msclip_stem_dual_conv3x3s2", "msclip_conv1x1_conv3x3s2", "msclip_convresblock48_s2", "msclip_patchify",
     "msclip_lse_rows", "msclip_clip_loss_partial", "msclip_clip_lse_fused", "msclip_clip_loss_from_partials",
     "msclip_transpose_bf16", "msclip_cast_bf16", "msclip_cast_bf16_colsum", "msclip_colsum", "msclip_quickgelu", "msclip_quickgelu_bwd", "msclip_layernorm_bwd",
@@ -116,6 +116,7 @@ def lib():
         L.msclip_l2norm.argtypes = [vp, ci, vp, ci, vp, ci, ci, ci, vp]
         L.msclip_gather_rows.argtypes = [vp, ctypes.c_longlong, vp, ci, ci, vp, ctypes.c_longlong, ci, ci, vp]
         L.msclip_stem_conv3x3s2_dual.argtypes = [vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, vp]
+        L.msclip_stem_conv3x3s2_dual_raw.argtypes = [vp, ci, vp, vp, vp, ci, ci, ci, vp]
         L.msclip_dwpool.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
         L.msclip_stem_dual_conv3x3s2.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
         L.msclip_conv1x1_conv3x3s2.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
@@ -818,6 +819,18 @@ def stem_conv_dual(img, w, bias, out_a, out_b):
     assert img.is_contiguous() and img.dtype in (torch.float32, torch.bfloat16)
     _check(lib().msclip_stem_conv3x3s2_dual(_p(img), int(img.dtype == torch.bfloat16), _p(w), _p(bias), _p(out_a),
                                             _p(out_b), B, H, W, w.shape[1] // 2, _stream()), "msclip_stem_conv3x3s2_dual")
+
+
+def stem_conv_dual_raw(img, w, out_a, out_b):
+    """Both Cin = 3 convolutions' RAW outputs (no BatchNorm, bias or ReLU), fp32 [B * Ho * Wo, 48] each, from one pass over the
+    image; w fp32 [27, 96] (row ci * 9 + kh * 3 + kw; conv1's channels, then parallel stage 0's)."""
+    B, _, H, W = img.shape
+    assert img.is_contiguous() and img.dtype in (torch.float32, torch.bfloat16) and H % 2 == 0 and W % 2 == 0
+    _f32(w); _f32(out_a); _f32(out_b)
+    assert tuple(w.shape) == (27, 96) and out_a.shape[1] == 48 and out_b.shape[1] == 48
+    assert out_a.shape[0] >= B * (H // 2) * (W // 2) and out_b.shape[0] >= B * (H // 2) * (W // 2)
+    _check(lib().msclip_stem_conv3x3s2_dual_raw(_p(img), int(img.dtype == torch.bfloat16), _p(w), _p(out_a), _p(out_b), B, H, W,
+                                                _stream()), "msclip_stem_conv3x3s2_dual_raw")
 
 
 def stem_dual_conv3x3s2(img, w, bias, out_b, w2, b2, out2):

@@ -449,6 +449,10 @@ class _RawSpecs:
             return P.pad_k(P.conv_weight_matrix(sd[key].float())).to(BF).contiguous()
         self.w_conv1 = first(sp + ".conv1.weight")
         self.w_par0 = first("visual.transformer.parallel_branch_v.0.conv.weight")
+        # both filters as the fused pass reads them: fp32 [27][96], row ci * 9 + kh * 3 + kw (msclip_stem_conv3x3s2_dual_raw)
+        wa, wb = sd[sp + ".conv1.weight"], sd["visual.transformer.parallel_branch_v.0.conv.weight"]
+        self.w_dual = (torch.cat([wa.reshape(wa.shape[0], 27), wb.reshape(wb.shape[0], 27)], 0).t().float().contiguous()
+                       if wa.shape[0] == 48 and wb.shape[0] == 48 else None)
         self.pool, self.dww = [], []
         for j in range(5):
             p = f"visual.transformer.parallel_lateral_adapter.{j}"
@@ -493,12 +497,20 @@ class ConvSideBatchNorm:
         w["stem"][i]."""
         e, w, Bi = self.e, self.w, self.Bi
         sp = "visual.transformer.resblocks.0"
-        col = self.bw._image_cols(gemm_operand=True)
         pix = Bi * e.h1 * e.h1
-        for wt, prefix, out in ((self.raw.w_conv1, sp + ".bn1", e._s1(w, Bi)),
-                                (self.raw.w_par0, "visual.transformer.parallel_branch_v.0.bn", w["P0"])):
-            r = torch.empty(pix, wt.shape[0], dtype=F32, device=e.dev)      # raw conv outputs stay fp32 until normalised
-            hip.gemm(col, wt, r)
+        heads = ((self.raw.w_conv1, sp + ".bn1", e._s1(w, Bi)), (self.raw.w_par0, "visual.transformer.parallel_branch_v.0.bn", w["P0"]))
+        if self.raw.w_dual is not None and e.S % 2 == 0 and not hip.env_flag("MSCLIP_FIRST_CONV_GEMM"):
+            # both raw convolutions from ONE pass over the image (round 5): no patch matrix, no two GEMMs over it
+            raws = [torch.empty(pix, 48, dtype=F32, device=e.dev) for _ in heads]
+            hip.stem_conv_dual_raw(self.img, self.raw.w_dual, raws[0], raws[1])
+        else:
+            col = self.bw._image_cols(gemm_operand=True)
+            raws = []
+            for wt, _, _ in heads:
+                r = torch.empty(pix, wt.shape[0], dtype=F32, device=e.dev)  # raw conv outputs stay fp32 until normalised
+                hip.gemm(col, wt, r)
+                raws.append(r)
+        for (wt, prefix, out), r in zip(heads, raws):
             self._bn(r, prefix, 1e-5, out, pix, relu=True)
         x = w["S1"]
         for i, (main, short, q) in enumerate(self.raw.stem):
@@ -593,8 +605,13 @@ class ConvSideBatchNorm:
         draw = self._bn_bwd(grads, prefix, dpre)
         pix = self.Bi * self.e.h1 * self.e.h1
         co = draw.shape[1]
-        grads[wkey] = _wgrad_async(draw, self.bw._image_cols(), pix,
-                                   post=lambda d: d[:, :27].reshape(co, 3, 3, 3).permute(0, 3, 1, 2).contiguous())
+        if hip.image_conv_wgrad_ok(self.img, draw) and self.e.h1 <= 128 and not hip.env_flag("MSCLIP_FIRST_CONV_GEMM"):
+            # one pass over draw and the image on the lane: no patch matrix (the bias column is not needed: dbeta comes from the BatchNorm backward)
+            grads[wkey] = gradgemm.on_lane(
+                lambda: hip.image_conv_wgrad(self.img, draw)[0].reshape(co, 3, 3, 3).permute(0, 3, 1, 2).contiguous(), draw)
+        else:
+            grads[wkey] = _wgrad_async(draw, self.bw._image_cols(), pix,
+                                       post=lambda d: d[:, :27].reshape(co, 3, 3, 3).permute(0, 3, 1, 2).contiguous())
 
     def adapter(self, grads, j, dsum, x_pre):
         """-> the gradient matrix to hand to msclip_adapter_dx together with the RAW depthwise filter."""

@@ -373,6 +373,30 @@ def test_adamw_multi_packed_copies(gpu_device):
             assert bool((pk[n:] == 7.0).all())
 
 
+@pytest.mark.parametrize("B,S,dt", [(3, 32, torch.float32), (2, 224, torch.float32), (5, 38, BF)])
+def test_stem_dual_conv_raw_outputs(gpu_device, B, S, dt):
+    """msclip_stem_conv3x3s2_dual_raw (train-mode BatchNorm's forward of the two convolutions on the image): RAW fp32 outputs of both
+    from one pass -- against F.conv2d on the bf16-rounded image and filters, and against the patch-matrix GEMM it replaces."""
+    Ho = S // 2
+    img = rnd(B, 3, S, S, seed=51).to(dt)
+    wa, wb = rnd(48, 3, 3, 3, seed=52, scale=0.3), rnd(48, 3, 3, 3, seed=53, scale=0.3)
+    w = torch.cat([wa.reshape(48, 27), wb.reshape(48, 27)], 0).t().contiguous()
+    oa = torch.full((B * Ho * Ho + 3, 48), 7.0, device="cuda")
+    ob = torch.full((B * Ho * Ho + 3, 48), 7.0, device="cuda")
+    hip.stem_conv_dual_raw(img, w, oa, ob)
+    xr = img.to(BF).float()
+    for o, wt in ((oa, wa), (ob, wb)):
+        ref = F.conv2d(xr, wt.to(BF).float(), stride=2, padding=1).permute(0, 2, 3, 1).reshape(B * Ho * Ho, 48)
+        assert rel(o[:B * Ho * Ho], ref) < 2e-5, rel(o[:B * Ho * Ho], ref)
+        assert bool((o[B * Ho * Ho:] == 7.0).all())
+    col = hip.im2col(img, B, S, S, 3, 3, 3, 2, 1, image=True)
+    wm = torch.zeros(48, 64, dtype=BF, device="cuda")
+    wm[:, :27] = wa.permute(0, 2, 3, 1).reshape(48, 27).to(BF)
+    r = torch.empty(B * Ho * Ho, 48, device="cuda")
+    hip.gemm(col, wm, r)
+    assert rel(oa[:B * Ho * Ho], r) < 2e-5
+
+
 @pytest.mark.parametrize("B,S,co", [(3, 32, 48), (2, 224, 24), (5, 36, 16), (2, 64, 64), (1, 256, 40)])
 def test_image_conv_wgrad_without_a_patch_matrix(gpu_device, B, S, co):
     """msclip_image_conv_wgrad (the stem's conv1 / parallel stage 0 on the input image): dW and the bias sums from one pass over dy
@@ -683,9 +707,20 @@ def test_gradients_with_train_mode_batchnorm(gpu_device, name):
     print("train-mode BN: conv side median sample error", float(np.median([worst[k] for k in conv_keys])), "worst",
           max(worst[k] for k in conv_keys), "worst abs-mean", max(am[k] for k in conv_keys), "lowest cosine",
           min(coss[k] for k in conv_keys if k in coss), "| token side median", float(np.median([worst[k] for k in expect if k not in conv_keys])))
+    dev = _reference_bf16_deviation("train_bn_batch16" if name.startswith("b32") else "train_bn_batch8", name)
     for k in expect:
         lnb = k.endswith(("ln_1.bias", "ln_2.bias", "ln_final.bias", "ln_post.bias", "ln_pre.bias", "ln_adapt.bias"))
-        tol = (LNB_SAMPLE_TOL, LNB_ABSMEAN_TOL, LNB_COS_TOL) if lnb else (0.40, 0.10, 0.95) if k in conv_keys else (0.10, 0.08, 0.99)
+        # (conv side: the abs-mean bound is 10 % or, where the reference's own bf16-autocast run moves a conv-side tensor further than
+        #  that on this batch -- 18.2 % on ViT-B/16 batch 8 --, that yardstick: with 8 samples a per-channel adapter filter's gradient
+        #  moves by several percent with the summation order of the first convolutions, measured 5.9 % / 11.5 % for the two orders)
+        tol = (LNB_SAMPLE_TOL, LNB_ABSMEAN_TOL, LNB_COS_TOL) if lnb else \
+              (0.40, max(0.10, dev["conv_side"]["absmean_dev_worst"]), 0.95) if k in conv_keys else (0.10, 0.08, 0.99)
+        if k == "logit_scale":
+            # a SCALAR whose gradient is a sum of nearly cancelling terms (sum G S): under train-mode BatchNorm every rounding in
+            # the conv side moves it -- the reference's own bf16-autocast run is 15.2 % off its fp32 run on this batch (the worst
+            # token-side tensor of the yardstick file IS this scalar); measured here 7-10 % depending on the summation order of the
+            # first convolutions.  Bounded by the yardstick instead of the 8 % of the tensor-valued gradients.
+            tol = (max(tol[0], dev["token_side"]["sample_err_worst"]), max(tol[1], dev["token_side"]["absmean_dev_worst"]), tol[2])
         assert worst[k] <= tol[0], (k, worst[k])
         assert am[k] <= tol[1], (k, am[k])
         if k in coss:
@@ -693,7 +728,6 @@ def test_gradients_with_train_mode_batchnorm(gpu_device, name):
     # ... and no further from the fp32 reference than the reference's own bf16-autocast run in train() mode on this batch
     # (ViT-B/32, batch 16: median 3.9 % token side / 11.7 % conv side, worst conv-side tensor 31 %, lowest conv-side cosine
     # 0.959; ViT-B/16, batch 8: 3.6 % / 9.9 %, worst 29 %, cosine 0.958)
-    dev = _reference_bf16_deviation("train_bn_batch16" if name.startswith("b32") else "train_bn_batch8", name)
     lnb_keys = [k for k in expect if k.endswith(("ln_1.bias", "ln_2.bias", "ln_final.bias", "ln_post.bias", "ln_pre.bias", "ln_adapt.bias"))]
     tok_keys = [k for k in expect if k not in conv_keys and k not in lnb_keys]
     assert float(np.median([worst[k] for k in tok_keys])) <= 1.25 * dev["token_side"]["sample_err_median"] + 5e-3
@@ -774,7 +808,10 @@ def test_optimizer_step_keeps_the_engine_copies_current(gpu_device, bn):
     def same(a, b):
         if a.dtype == torch.bfloat16:
             af, bf_ = a.float(), b.float()
-            ok = bool(((af - bf_).abs() <= 2.0 ** -6 * bf_.abs() + 1e-30).all()) and (af != bf_).float().mean().item() < 1e-3
+            # (the stem stages' centre taps are w s + w_shortcut s_shortcut: where the two nearly cancel, an fp32 ulp of a scale is
+            #  several bf16 ulps of the sum -- an absolute slack of 2^-12 of the tensor's largest entry covers them)
+            ok = (bool(((af - bf_).abs() <= 2.0 ** -6 * bf_.abs() + 2.0 ** -12 * bf_.abs().max()).all()) and
+                  (af != bf_).float().mean().item() < 1e-3)
         else:
             ok = bool(((a - b).abs() <= 4e-6 * (b.abs() + b.abs().max())).all())
         if not ok:
