@@ -369,6 +369,18 @@ int msclip_cast_bf16_colsum(const float* x, int ldx, void* y, int ldy, int M, in
 int msclip_colsum(const void* x, int ld, int is_f32, float* out, int M, int N, int accumulate, float* scratch, int chunks,
                   void* stream);
 
+/* Many fp32 column sums in one launch per 96 items (the training step's deferred folds of per-block partial matrices: LayerNorm
+ * parameter gradients, bias gradients): dst[n] = sum_m src[m][n] for n < N, rows added in a fixed order; the first scale_n results
+ * are multiplied by scale.  `items` is a HOST array (copied into the kernel arguments); src / dst are device pointers. */
+typedef struct msclip_fold_item {
+  const float* src;
+  float* dst;
+  int M, N, ld;
+  int scale_n;
+  float scale;
+} msclip_fold_item;
+int msclip_colsum_multi(const msclip_fold_item* items, int n_items, void* stream);
+
 /* QuickGELU on a saved pre-activation and its backward (M.py:222-224): y = h sigma(1.702 h);
  * dh = dy (sigma + 1.702 h sigma (1 - sigma)).  bf16, n % 8 == 0. */
 int msclip_quickgelu(const void* h, void* y, long long n, void* stream);

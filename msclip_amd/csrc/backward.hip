@@ -261,6 +261,49 @@ __global__ __launch_bounds__(256) void fold_rows_kernel(const float* __restrict_
   }
 }
 
+// ---- Many column sums in ONE launch (msclip_colsum_multi; round 5: the training step folded ~130 per-block partial matrices --
+// LayerNorm parameter gradients, bias gradients -- with one msclip_colsum launch each, 1.1 ms of short launches on the main queue).
+// The items travel in the kernel arguments (<= 96 per launch, no table upload); workgroup -> (item, 64-column block) by walking
+// the items' block counts; thread (row group w, column c) adds rows w, w + 4, ... in order, the four row groups are added in
+// order: a fixed summation order.  Optional scale of the first scale_n outputs (the packed in_proj bias: q rows carry 64^-0.5).
+struct FoldArgs {
+  msclip_fold_item it[96];
+  int n;
+};
+__global__ __launch_bounds__(256) void colsum_multi_kernel(const FoldArgs a) {
+  __shared__ float red[4][64];
+  int b = blockIdx.x, i = 0;
+  for (; i < a.n - 1; ++i) {
+    const int nb = (a.it[i].N + 63) >> 6;
+    if (b < nb) break;
+    b -= nb;
+  }
+  const float* __restrict__ src = a.it[i].src;
+  const int M = a.it[i].M, N = a.it[i].N;
+  const size_t ld = (size_t)a.it[i].ld;
+  const int c = threadIdx.x & 63, w = threadIdx.x >> 6, col = b * 64 + c;
+  float s = 0.f;
+  if (col < N) {
+    int m = w;
+#pragma unroll 1
+    for (; m + 28 < M; m += 32) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(m + 4 * j) * ld + col];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[j];
+    }
+    for (; m < M; m += 4) s += src[(size_t)m * ld + col];
+  }
+  red[w][c] = s;
+  __syncthreads();
+  if (w == 0 && col < N) {
+    float t = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+    if (col < a.it[i].scale_n) t *= a.it[i].scale;
+    a.it[i].dst[col] = t;
+  }
+}
+
 // ---- fp32 -> bf16 copy of a gradient matrix (the operand of its dgrad / wgrad GEMMs).
 __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ x, int ldx, bf16_t* __restrict__ y, int ldy, int M,
                                                    int C4) {
@@ -738,6 +781,26 @@ extern "C" int msclip_transpose_bf16(const void* in, int ldi, void* out, int ldo
   else
     hipLaunchKernelGGL(transpose_kernel, dim3((Mpad + 63) / 64, (C + 63) / 64), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)in, ldi, (bf16_t*)out, ldo, M, C, Mpad);
+  return msclip_launch_status();
+}
+
+extern "C" int msclip_colsum_multi(const msclip_fold_item* items, int n_items, void* stream) {
+  if (!items || n_items <= 0) return MSCLIP_EINVAL;
+  for (int i = 0; i < n_items; ++i)
+    if (!items[i].src || !items[i].dst || items[i].M <= 0 || items[i].N <= 0 || items[i].ld < items[i].N || items[i].scale_n < 0 ||
+        items[i].scale_n > items[i].N)
+      return MSCLIP_EINVAL;
+  for (int i0 = 0; i0 < n_items; i0 += 96) {
+    FoldArgs a;
+    a.n = n_items - i0 < 96 ? n_items - i0 : 96;
+    long long blocks = 0;
+    for (int i = 0; i < a.n; ++i) {
+      a.it[i] = items[i0 + i];
+      blocks += (items[i0 + i].N + 63) / 64;
+    }
+    if (blocks > 0x7fffffffll) return MSCLIP_EINVAL;
+    hipLaunchKernelGGL(colsum_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  }
   return msclip_launch_status();
 }
 

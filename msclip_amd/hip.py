@@ -28,7 +28,7 @@ EXPORTS = (
     "msclip_bn_bwd_reduce", "msclip_bn_bwd_dx", "msclip_bn_fold_bwd", "msclip_bn_finish", "msclip_bn_finish_tiled", "msclip_bn_bwd_finish",
     "msclip_text_lengths", "msclip_embed_tokens_packed", "msclip_attention_varlen", "msclip_attention_lastq_varlen",
     "msclip_attention_bwd_varlen", "msclip_embed_tokens_bwd_packed",
-    "msclip_qkv_attention", "msclip_qkvattn_tables", "msclip_pack_weights", "msclip_transpose_bf16_multi", "msclip_image_conv_wgrad",
+    "msclip_qkv_attention", "msclip_qkvattn_tables", "msclip_pack_weights", "msclip_transpose_bf16_multi", "msclip_image_conv_wgrad", "msclip_colsum_multi",
     "msclip_abi_version", "msclip_build_arch",
     "msclip_stream_priority_range", "msclip_stream_create", "msclip_stream_destroy",
 )
@@ -166,6 +166,7 @@ def lib():
         L.msclip_qkvattn_tables.argtypes = [vp, ci, ci, vp, vp, vp, ci, ci, vp]
         L.msclip_pack_weights.argtypes = [vp, vp, ci, ci, vp]
         L.msclip_transpose_bf16_multi.argtypes = [vp, vp, ci, ci, vp]
+        L.msclip_colsum_multi.argtypes = [vp, ci, vp]
         L.msclip_image_conv_wgrad.argtypes = [vp, vp, ci, vp, ci, ci, ci, ci, vp]
         L.msclip_abi_version.restype = ci
         if L.msclip_abi_version() != ABI_VERSION:          # a stale build of the library (the struct layouts / entry points moved on)
@@ -916,8 +917,9 @@ def cast_bf16(x, out=None):
     return out
 
 
-def cast_bf16_colsum(x, out=None):
-    """-> (bf16 copy of the fp32 matrix x, its column sums fp32 [C]) from one pass over x."""
+def cast_bf16_colsum(x, out=None, fold=True):
+    """-> (bf16 copy of the fp32 matrix x, its column sums fp32 [C]) from one pass over x (fold=False: the per-block partial sums
+    [blocks, C] instead, for a FoldPlan)."""
     assert x.dtype == torch.float32 and x.stride(-1) == 1
     M, C = x.shape
     if out is None:
@@ -926,7 +928,52 @@ def cast_bf16_colsum(x, out=None):
     part = torch.empty(blocks, C, dtype=torch.float32, device=x.device)
     _check(lib().msclip_cast_bf16_colsum(_p(x), x.stride(0), _p(out), out.stride(0), M, C, _p(part), blocks, _stream()),
            "msclip_cast_bf16_colsum")
-    return out, colsum(part)
+    return out, (colsum(part) if fold else part)
+
+
+class FoldItem(ctypes.Structure):
+    """msclip_fold_item (include/msclip_hip.h)."""
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("M", ctypes.c_int), ("N", ctypes.c_int), ("ld", ctypes.c_int),
+                ("scale_n", ctypes.c_int), ("scale", ctypes.c_float)]
+
+
+class FoldPlan:
+    """Deferred column sums of one backward pass: producers leave per-block partial matrices (fp32 [M, N]), add() books their fold,
+    run() folds ALL of them with msclip_colsum_multi (one launch per 96) into one fresh result buffer and hands every caller its
+    slice.  Nothing on the backward's critical path reads these sums (LayerNorm parameter gradients, bias gradients): ~130 short
+    msclip_colsum launches per training step become two."""
+
+    def __init__(self, device):
+        self.device, self.items, self.then, self.keep, self.total = device, [], [], [], 0
+
+    def add(self, part, then, scale_n=0, scale=1.0):
+        """part: fp32 [M, N] (row stride >= N); then(result fp32 [N]) is called by run() once the fold is queued."""
+        _f32_2d = part.dtype == torch.float32 and part.dim() == 2 and part.stride(1) == 1
+        assert _f32_2d and part.is_cuda
+        M, N = part.shape
+        it = FoldItem()
+        it.src, it.M, it.N, it.ld, it.scale_n, it.scale = part.data_ptr(), M, N, part.stride(0), scale_n, scale
+        self.items.append((it, self.total))
+        self.then.append((self.total, N, then))
+        self.keep.append(part)
+        self.total += (N + 3) // 4 * 4
+
+    def run(self):
+        if not self.items:
+            return
+        out = torch.empty(self.total, dtype=torch.float32, device=self.device)
+        base = out.data_ptr()
+        arr = (FoldItem * len(self.items))()
+        for i, (it, off) in enumerate(self.items):
+            it.dst = base + 4 * off
+            arr[i] = it
+        _check(lib().msclip_colsum_multi(ctypes.cast(arr, ctypes.c_void_p), len(self.items), _stream()), "msclip_colsum_multi")
+        cur = torch.cuda.current_stream(self.device)
+        for p in self.keep:
+            p.record_stream(cur)                      # (a partial produced on another stream's allocation pool is read here)
+        for off, N, then in self.then:
+            then(out[off:off + N])
+        self.items, self.then, self.keep, self.total = [], [], [], 0
 
 
 def colsum(x, out=None, M=None, accumulate=False):
@@ -981,7 +1028,7 @@ LN_PART_BLOCKS = 1024
 
 
 def layernorm_bwd(x, dy, gamma, dx, M, *, row_idx=None, row_mul=1, accumulate=True, want_param_grads=True, eps=1e-12,
-                  dxb=None, sum_part=None, sum_accumulate=False):
+                  dxb=None, sum_part=None, sum_accumulate=False, fold=True):
     """-> (dgamma, dbeta) fp32 [C] (or None).  x fp32 [*, C]; dy [M, C] bf16 / fp32; dx fp32 gets (+=) the input gradient
     at the rows the forward read.  dxb (bf16 [M, C]) + sum_part (fp32 [LN_PART_BLOCKS, C]): the written dx rows also as bf16,
     their per-block column sums into (sum_accumulate: onto) sum_part -- colsum(sum_part) = the column sums of the new dx rows."""
@@ -996,6 +1043,8 @@ def layernorm_bwd(x, dy, gamma, dx, M, *, row_idx=None, row_mul=1, accumulate=Tr
                                       _p(sum_part), int(sum_accumulate), _stream()), "msclip_layernorm_bwd")
     if not want_param_grads:
         return None, None
+    if not fold:                                         # the caller folds (FoldPlan): the partials [LN_PART_BLOCKS, 2 C] = (dgamma | dbeta)
+        return part.view(LN_PART_BLOCKS, 2 * C), None
     both = colsum(part.view(LN_PART_BLOCKS, 2 * C))
     return both[:C], both[C:]
 

@@ -319,6 +319,33 @@ class TrainStep:
                     """Where gradient k should be written if it can be born inside its all-reduce bucket (else None)."""
                     return reducer.reserve(k, shape, dev) if reducer is not None else None
             grads = _Grads()
+            # Column sums nothing on the critical path reads (LayerNorm parameter gradients, bias gradients): their producers leave
+            # per-block partial matrices, ONE msclip_colsum_multi launch folds all of them behind the transformer's backward (round 5:
+            # ~120 msclip_colsum launches per step, 1.1 ms of the main queue; MSCLIP_FOLDS_EAGER=1 = one launch each, at once)
+            folds = None if hip.env_flag("MSCLIP_FOLDS_EAGER") else hip.FoldPlan(dev)
+
+            def fold_into(part, then, scale_n=0, scale=1.0):
+                if folds is not None:
+                    folds.add(part, then, scale_n=scale_n, scale=scale)
+                    return
+                r = hip.colsum(part)
+                if scale_n:
+                    r[:scale_n] *= scale
+                then(r)
+
+            def ln_param_grads(part, key):
+                """part: (dgamma | dbeta) partials [blocks, 2 C] of a LayerNorm backward -> grads[key.weight], grads[key.bias]."""
+                def then(r):
+                    c = r.shape[0] // 2
+                    grads[key + ".weight"], grads[key + ".bias"] = r[:c], r[c:]
+                fold_into(part, then)
+
+            def set_bias(key, val):
+                """val: the bias gradient itself, or a 2-D matrix of partial sums still to be folded."""
+                if val.dim() == 2:
+                    fold_into(val, lambda r: grads.__setitem__(key, r))
+                else:
+                    grads[key] = val
             # the four wide weight gradients of a block: operand transposes on the lane at once, the split-K GEMM of job k
             # on THIS stream when job k + 1 is created (its transposes have run under the kernels issued in between)
             pending = []
@@ -368,8 +395,8 @@ class TrainStep:
                 grads[key_proj] = _wgrad(hrow, dfr_b, hrow.shape[0])                           # [D, E] like the parameter
                 dh = torch.empty(hrow.shape[0], D, dtype=F32, device=dev)                      # fp32: it feeds column sums
                 hip.gemm(dfr_b, w_proj.t().contiguous(), dh)                                   # dfr [B, E] @ W [E, D]
-                dg, db = hip.layernorm_bwd(sv["x_out"], dh, ln.g, dX, hrow.shape[0], row_idx=row_idx, row_mul=row_mul)
-                grads[key_ln + ".weight"], grads[key_ln + ".bias"] = dg, db
+                part, _ = hip.layernorm_bwd(sv["x_out"], dh, ln.g, dX, hrow.shape[0], row_idx=row_idx, row_mul=row_mul, fold=False)
+                ln_param_grads(part, key_ln)
             head(sv["fv_raw"], dfi, sv["hv"], e.w_vproj, e.ln_post, "visual.proj", "visual.ln_post", row_mul=e.Lv)
             head(sv["ft_raw"], dft, sv["ht"], e.w_tproj, e.ln_final, "text_projection", "ln_final", row_idx=sv["eot"])
 
@@ -378,7 +405,7 @@ class TrainStep:
                 weights): column sums of the group's rows} = that projection's bias gradient; one pass over dX when a
                 single (shared) weight set covers all rows."""
                 if len(groups) == 1 and groups[0][0] == r_lo and groups[0][1] == M:
-                    _, s = hip.cast_bf16_colsum(dX[r_lo:M], dY[r_lo:M])
+                    _, s = hip.cast_bf16_colsum(dX[r_lo:M], dY[r_lo:M], fold=False)    # partial sums: folded with the others (set_bias)
                     return {id(groups[0][2]): s}
                 hip.cast_bf16(dX[r_lo:M], dY[r_lo:M])
                 return {id(bw): hip.colsum(dX[r0:r1]) for r0, r1, bw in groups}
@@ -444,10 +471,9 @@ class TrainStep:
                             parts[gid] = torch.empty(hip.LN_PART_BLOCKS, D, dtype=F32, device=dev)
                         kw = dict(dxb=dY_next[r0:r1], sum_part=parts[gid], sum_accumulate=not first)
                     pre = f"visual.transformer.resblocks.{i}" if b is e.vblk[i] else f"transformer.resblocks.{i}"
-                    dg, db = hip.layernorm_bwd(x_saved[r0 - r_lo:r1 - r_lo], dlno[r0:r1], b[which].g, dX[r0:r1], r1 - r0, **kw)
-                    n = "ln_1" if which == "ln1" else "ln_2"
-                    grads[f"{pre}.{n}.weight"], grads[f"{pre}.{n}.bias"] = dg, db
-                return {gid: hip.colsum(p) for gid, p in parts.items()} if dY_next is not None else None
+                    part, _ = hip.layernorm_bwd(x_saved[r0 - r_lo:r1 - r_lo], dlno[r0:r1], b[which].g, dX[r0:r1], r1 - r0, fold=False, **kw)
+                    ln_param_grads(part, f"{pre}.{'ln_1' if which == 'ln1' else 'ln_2'}")
+                return parts if dY_next is not None else None          # (partial sums: set_bias folds them)
 
             # ---- blocks, last to first
             fuse_cast = not hip.env_flag("MSCLIP_LN_BWD_UNFUSED")
@@ -471,7 +497,7 @@ class TrainStep:
                 for r0, r1, bw in groups:
                     p = names[id(bw)]
                     wide_wgrad(p + ".mlp.c_proj.weight", dY[r0:r1], hid[r0:r1], r1 - r0, (D, 4 * D))
-                    grads[p + ".mlp.c_proj.bias"] = bsum[id(bw)]
+                    set_bias(p + ".mlp.c_proj.bias", bsum[id(bw)])
                 dh = torch.empty(M, 4 * D, dtype=BF, device=dev)
                 dh_part = {}
                 for r0, r1, bw in groups:
@@ -489,8 +515,10 @@ class TrainStep:
                 for r0, r1, bw in groups:
                     p = names[id(bw)]
                     wide_wgrad(p + ".mlp.c_fc.weight", dh[r0:r1], L["lno2"][r0:r1], r1 - r0, (4 * D, D))
-                    src = dh_part.get(id(bw), dh[r0:r1])
-                    grads[p + ".mlp.c_fc.bias"] = gradgemm.on_lane(lambda a=src: hip.colsum(a), src)
+                    if id(bw) in dh_part:
+                        set_bias(p + ".mlp.c_fc.bias", dh_part[id(bw)])
+                    else:
+                        grads[p + ".mlp.c_fc.bias"] = gradgemm.on_lane(lambda a=dh[r0:r1]: hip.colsum(a), dh)
                     _dgrad(dh[r0:r1], w_t(bw, 1), dlno[r0:r1])
                 del dh
                 # attention half.  dX behind the ln_2 backward is out_proj's output gradient: its bf16 copy and bias sums leave with that pass
@@ -503,7 +531,7 @@ class TrainStep:
                 for r0, r1, bw in groups:
                     p = names[id(bw)]
                     wide_wgrad(p + ".attn.out_proj.weight", dY2[r0:r1], L["ao"][r0:r1], r1 - r0, (D, D))
-                    grads[p + ".attn.out_proj.bias"] = bsum[id(bw)]
+                    set_bias(p + ".attn.out_proj.bias", bsum[id(bw)])
                     _dgrad(dY2[r0:r1], w_t(bw, 2), dao[r0:r1])
                 # the attention backward also leaves every sample's token sums of its dqkv rows (in_proj's bias gradient = their
                 # sum over the samples: 1 024 x 3 D fp32 to fold instead of a second pass over dqkv [M, 3 D]); the query-blocked
@@ -527,12 +555,15 @@ class TrainStep:
                         return g
                     wide_wgrad(p + ".attn.in_proj_weight", dqkv[r0:r1], L["lno1"][r0:r1], r1 - r0, (3 * D, D),
                                post=unscale_q)                                          # wrt the PACKED weight, scaled back
-                    src = dqkv[r0:r1] if qpart is None else qpart[(0 if r0 < Mv else Bi):(Bi + Bt if r1 > Mv else Bi)]
-                    def bias_q(a=src):
-                        g = hip.colsum(a)
-                        g[:D] *= 0.125
-                        return g
-                    grads[p + ".attn.in_proj_bias"] = gradgemm.on_lane(bias_q, src)
+                    if qpart is not None:
+                        fold_into(qpart[(0 if r0 < Mv else Bi):(Bi + Bt if r1 > Mv else Bi)],
+                                  lambda r, k=p + ".attn.in_proj_bias": grads.__setitem__(k, r), scale_n=D, scale=0.125)
+                    else:
+                        def bias_q(a=dqkv[r0:r1]):
+                            g = hip.colsum(a)
+                            g[:D] *= 0.125
+                            return g
+                        grads[p + ".attn.in_proj_bias"] = gradgemm.on_lane(bias_q, dqkv)
                     _dgrad(dqkv[r0:r1], w_t(bw, 3), dlno[r0:r1])
                 # dX behind the ln_1 backward is the output gradient of the block below's c_proj -- unless a lateral adapter's token
                 # path adds to the image rows first, or the block below runs other rows
@@ -550,9 +581,8 @@ class TrainStep:
                     ad = L["adapter"]
                     a = e.adapters[ad["j"]]
                     dsum = torch.empty(Mv, D, dtype=F32, device=dev)
-                    dg, db = hip.layernorm_bwd(ad["sum"], dX[:Mv], a["ln"].g, dsum, Mv, accumulate=False)
-                    pre = f"visual.transformer.parallel_lateral_adapter.{ad['j']}.ln_adapt"
-                    grads[pre + ".weight"], grads[pre + ".bias"] = dg, db
+                    part, _ = hip.layernorm_bwd(ad["sum"], dX[:Mv], a["ln"].g, dsum, Mv, accumulate=False, fold=False)
+                    ln_param_grads(part, f"visual.transformer.parallel_lateral_adapter.{ad['j']}.ln_adapt")
                     if self.bn == "batch":                               # adapter convs + parallel stage j (train_conv.py)
                         dgrid, dww = conv.adapter(grads, ad["j"], dsum, ad["x_pre"])
                     else:
@@ -585,11 +615,13 @@ class TrainStep:
             both = gradgemm.on_lane(embed_bwd, dX_text, tok_ids, *([sv_cap.cu] if sv_cap is not None else []))
             grads["token_embedding.weight"], grads["positional_embedding"] = both[:ne].view_as(e.emb), both[ne:].view(e.Lt, D)
             dtok = torch.empty(Mv, D, dtype=F32, device=dev)
-            dg, db = hip.layernorm_bwd(sv["tok_pre"], dX[:Mv], e.ln_pre.g, dtok, Mv, accumulate=False)
-            grads["visual.ln_pre.weight"], grads["visual.ln_pre.bias"] = dg, db
+            part, _ = hip.layernorm_bwd(sv["tok_pre"], dX[:Mv], e.ln_pre.g, dtok, Mv, accumulate=False, fold=False)
+            ln_param_grads(part, "visual.ln_pre")
             dvpos = hip.colsum(dtok.view(Bi, e.Lv * D)).view(e.Lv, D)                           # sum over the batch
             grads["visual.positional_embedding"] = dvpos
             grads["visual.class_embedding"] = dvpos[0].clone()
+            if folds is not None:
+                folds.run()                                      # every deferred column sum of the transformer's backward, two launches
             conv.stem(grads, dtok)
             flush_wgrads()
             gradgemm.join(dev)                                   # the gradients queued on the lane stream

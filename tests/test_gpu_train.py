@@ -148,6 +148,34 @@ def test_cast_with_column_sums(gpu_device, M, C):
     assert torch.equal(s, hip.cast_bf16_colsum(x, out[:M])[1])                      # fixed order
 
 
+def test_fold_plan_many_column_sums_in_one_launch(gpu_device):
+    """hip.FoldPlan / msclip_colsum_multi (the training step's deferred folds of per-block partial matrices): > 96 items (two
+    launches), row-range / column-range views, ragged widths, the scaled head of the packed in_proj bias; fixed summation order."""
+    shapes = [(1024, 1536), (1024, 768), (320, 3072), (1024, 2304), (7, 5), (1, 64), (33, 100), (512, 2304)] * 13      # 104 items
+    big = rnd(1100, 3100, seed=70)
+    got = {}
+    def build():
+        plan = hip.FoldPlan(big.device)
+        srcs = []
+        for i, (M, N) in enumerate(shapes):
+            src = big[i % 50:i % 50 + M, i % 20:i % 20 + N] if M <= 1024 and N <= 3072 else rnd(M, N, seed=i)
+            kw = dict(scale_n=N // 3, scale=0.125) if i % 4 == 3 else {}
+            plan.add(src, lambda r, i=i: got.__setitem__(i, r), **kw)
+            srcs.append((src, kw))
+        plan.run()
+        return srcs
+    srcs = build()
+    first = {i: r.clone() for i, r in got.items()}
+    for i, (src, kw) in enumerate(srcs):
+        ref = src.double().sum(0)
+        if kw:
+            ref[:kw["scale_n"]] *= kw["scale"]
+        assert got[i].shape == (src.shape[1],)
+        assert (got[i].double() - ref).abs().max().item() <= 2e-6 * src.abs().double().sum(0).max().item() + 1e-12, i
+    build()
+    assert all(torch.equal(got[i], first[i]) for i in first)                    # bitwise repeatable
+
+
 @pytest.mark.parametrize("C,dy_f32,gather", [(768, False, False), (768, True, False), (512, False, False), (768, False, True)])
 def test_layernorm_backward(gpu_device, C, dy_f32, gather):
     M = 1000
