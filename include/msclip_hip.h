@@ -359,8 +359,10 @@ int msclip_cast_bf16(const float* x, int ldx, void* y, int ldy, int M, int C, vo
 /* msclip_cast_bf16 that also leaves the column sums of x: part [part_blocks][C] fp32 receives per-block partial sums (block b
  * sums the rows b, b + part_blocks, ...); fold them with msclip_colsum.  The training step's residual-stream gradient is both
  * the bf16 operand of its projection's dgrad / wgrad GEMMs and, summed over the tokens, that projection's bias gradient.
- * C <= 1024, C % 4 == 0. */
-int msclip_cast_bf16_colsum(const float* x, int ldx, void* y, int ldy, int M, int C, float* part, int part_blocks, void* stream);
+ * C <= 1024, C % 4 == 0.  skip_group g > 0: x holds g + 1 rows per sample and the first of each (the class token) is skipped --
+ * output row m is x row m + m / g + 1 (the lateral adapters' backward: the top-down term has no class row, M.py:1768-1771). */
+int msclip_cast_bf16_colsum(const float* x, int ldx, void* y, int ldy, int M, int C, float* part, int part_blocks, int skip_group,
+                            void* stream);
 
 /* out[n] (+)= sum_m x[m][n] (x bf16 or fp32): bias gradients, LayerNorm parameter gradients' second stage.  chunks > 1:
  * row chunks in parallel into scratch [chunks, N], folded in chunk order (deterministic) by the workgroup of each column block

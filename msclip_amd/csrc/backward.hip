@@ -323,12 +323,14 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ x, 
 // the rows b, b + gridDim.x, ...; thread t the columns 4t .. 4t+3 of every one of them (blockDim.x >= C/4); part[b][C] receives
 // the block's sums (folded by msclip_colsum, fixed order: deterministic).
 __global__ __launch_bounds__(256) void cast_colsum_kernel(const float* __restrict__ x, int ldx, bf16_t* __restrict__ y, int ldy,
-                                                          int M, int C4, float* __restrict__ part) {
+                                                          int M, int C4, float* __restrict__ part, int skip_group) {
   const int t = threadIdx.x;
   if (t >= C4) return;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int m = blockIdx.x; m < M; m += gridDim.x) {
-    const float4 v = *(const float4*)(x + (size_t)m * ldx + t * 4);
+    // skip_group g > 0: x holds g + 1 rows per sample, the first of which (the class token) is skipped: output row m reads row m + m / g + 1
+    const size_t src = skip_group ? (size_t)m + m / skip_group + 1 : (size_t)m;
+    const float4 v = *(const float4*)(x + src * ldx + t * 4);
     uint2 o;
     o.x = pack_bf16x2(v.x, v.y);
     o.y = pack_bf16x2(v.z, v.w);
@@ -819,12 +821,12 @@ extern "C" int msclip_cast_bf16(const float* x, int ldx, void* y, int ldy, int M
 }
 
 extern "C" int msclip_cast_bf16_colsum(const float* x, int ldx, void* y, int ldy, int M, int C, float* part, int part_blocks,
-                                       void* stream) {
+                                       int skip_group, void* stream) {
   if (!x || !y || !part || M <= 0 || C <= 0 || C > 1024 || (C & 3) || (ldx & 3) || (ldy & 3) || part_blocks < 1 ||
-      ((size_t)part & 15))
+      ((size_t)part & 15) || skip_group < 0 || (skip_group && M % skip_group))
     return MSCLIP_EINVAL;
   hipLaunchKernelGGL(cast_colsum_kernel, dim3(part_blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, (bf16_t*)y, ldy, M, C / 4,
-                     part);
+                     part, skip_group);
   return msclip_launch_status();
 }
 

@@ -129,7 +129,7 @@ def lib():
         ll = ctypes.c_longlong
         L.msclip_transpose_bf16.argtypes = [vp, ci, vp, ci, ci, ci, ci, vp]
         L.msclip_cast_bf16.argtypes = [vp, ci, vp, ci, ci, ci, vp]
-        L.msclip_cast_bf16_colsum.argtypes = [vp, ci, vp, ci, ci, ci, vp, ci, vp]
+        L.msclip_cast_bf16_colsum.argtypes = [vp, ci, vp, ci, ci, ci, vp, ci, ci, vp]
         L.msclip_colsum.argtypes = [vp, ci, ci, vp, ci, ci, ci, vp, ci, vp]
         L.msclip_quickgelu.argtypes = [vp, vp, ll, vp]
         L.msclip_quickgelu_bwd.argtypes = [vp, vp, vp, ll, vp]
@@ -917,16 +917,19 @@ def cast_bf16(x, out=None):
     return out
 
 
-def cast_bf16_colsum(x, out=None, fold=True):
+def cast_bf16_colsum(x, out=None, fold=True, skip_group=0):
     """-> (bf16 copy of the fp32 matrix x, its column sums fp32 [C]) from one pass over x (fold=False: the per-block partial sums
     [blocks, C] instead, for a FoldPlan)."""
     assert x.dtype == torch.float32 and x.stride(-1) == 1
     M, C = x.shape
+    if skip_group:                                       # x: skip_group + 1 rows per sample, the first one (class token) skipped
+        assert M % (skip_group + 1) == 0
+        M = M // (skip_group + 1) * skip_group
     if out is None:
         out = torch.empty(M, C, dtype=torch.bfloat16, device=x.device)
     blocks = max(1, min(1024, M // 16))
     part = torch.empty(blocks, C, dtype=torch.float32, device=x.device)
-    _check(lib().msclip_cast_bf16_colsum(_p(x), x.stride(0), _p(out), out.stride(0), M, C, _p(part), blocks, _stream()),
+    _check(lib().msclip_cast_bf16_colsum(_p(x), x.stride(0), _p(out), out.stride(0), M, C, _p(part), blocks, skip_group, _stream()),
            "msclip_cast_bf16_colsum")
     return out, (colsum(part) if fold else part)
 

@@ -289,9 +289,14 @@ class ConvSideBackward:
         g, D, C, k, hw = e.g, e.D, a["C"], a["k"], e.par_hw[j]
         g2 = g * g
         p = f"visual.transformer.parallel_lateral_adapter.{j}"
-        dT = dsum.view(Bi, e.Lv, D)[:, 1:].reshape(Bi * g2, D)                   # grid rows (the cls row has no top-down term)
-        cs = hip.colsum(dT)
-        dT_bf = hip.cast_bf16(dT)
+        # grid rows (the cls row has no top-down term): their bf16 copy and column sums from ONE pass over dsum (round 5; was a
+        # gathering copy, a column-sum pass and a cast)
+        if dsum.is_contiguous() and dsum.shape[0] == Bi * e.Lv and e.Lv == g2 + 1 and not hip.env_flag("MSCLIP_ADAPTER_BWD_UNFUSED"):
+            dT_bf, cs = hip.cast_bf16_colsum(dsum, skip_group=g2)
+        else:
+            dT = dsum.view(Bi, e.Lv, D)[:, 1:].reshape(Bi * g2, D)
+            cs = hip.colsum(dT)
+            dT_bf = hip.cast_bf16(dT)
         # bottom depthwise 3x3 + BN on the token grid
         fb = _Fold(sd, p + ".bottom_dw_conv.bn", 1e-5)
         ddww = hip.dw3x3_wgrad(dsum, x_pre, Bi, e.Lv, g)                         # [9, D]

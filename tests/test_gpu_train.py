@@ -146,6 +146,13 @@ def test_cast_with_column_sums(gpu_device, M, C):
     ref = x.double().sum(0)
     assert (s.double() - ref).abs().max().item() <= 2e-6 * x.abs().double().sum(0).max().item()
     assert torch.equal(s, hip.cast_bf16_colsum(x, out[:M])[1])                      # fixed order
+    # skip_group: g + 1 rows per sample, the class row skipped (the lateral adapters' backward reads the grid rows of dsum)
+    g = 7
+    xs = torch.randn(9 * (g + 1), C, device="cuda", generator=torch.Generator(device="cuda").manual_seed(4))
+    ys, ss = hip.cast_bf16_colsum(xs, skip_group=g)
+    grid = xs.view(9, g + 1, C)[:, 1:].reshape(9 * g, C)
+    assert ys.shape == (9 * g, C) and torch.equal(ys, grid.to(torch.bfloat16))
+    assert (ss.double() - grid.double().sum(0)).abs().max().item() <= 2e-6 * grid.abs().double().sum(0).max().item()
 
 
 def test_fold_plan_many_column_sums_in_one_launch(gpu_device):
