@@ -267,7 +267,10 @@ def main():
     # NEXT step's captions, then runs this step on the batch staged one step earlier (same work per step, no host wait).
     # --inline-lengths: the engine stages each batch itself and waits for the read-back at the start of the step.
     staged = {"cap": None}
-    stage_ahead = eng.text_pack_enabled() and not args.inline_lengths
+    # round 6: with EngineOptions.dynamic_rows (default) the row count of a packed batch never leaves the device, so there is
+    # nothing to stage: the step takes the plain token tensor (the reference's API) and no host read exists anywhere in it
+    dynamic = bool(eng.dynamic_rows(B, B)) and ts is None
+    stage_ahead = eng.text_pack_enabled() and not args.inline_lengths and not dynamic
 
     def captions():
         if not stage_ahead:
@@ -300,18 +303,46 @@ def main():
             for t in (v if isinstance(v, (list, tuple)) else [v]):
                 if torch.is_tensor(t) and t.is_floating_point():
                     t.normal_()
-    probe = None if args.no_probe else hip.KernelProbe()
-    probe8 = None if args.no_probe else hip.KernelProbe()                   # the fp8 launches of PRECISION fp8 models
-    hip.set_gemm_probe(DOMINANT["variant"], probe)
-    hip.set_gemm_f8_probe(probe8)
+    # Per-launch durations of the dominant kernel INSIDE the timed region.  The shipped forward step is a replay of a native
+    # launch table (engine "plan"): its probes are HIP timing events the table's executor records around the chosen entries on
+    # their own stream (Plan.enable_probe).  The eager launch loop (training step, MSCLIP_PLAN=0) brackets the same launches from
+    # the Python binding (hip.KernelProbe), as in rounds 1-5.
+    planned = ts is None and eng.last_plan is not None
+
+    def attach_probes():
+        if args.no_probe:
+            return None, None
+        if planned:
+            plan = eng.last_plan
+            plan.enable_probe({"gemm:" + DOMINANT["variant"], "gemm_f8"}, args.steps)
+            return ("plan", plan), None
+        pr, pr8 = hip.KernelProbe(), hip.KernelProbe()                        # (pr8: the fp8 launches of PRECISION fp8 models)
+        hip.set_gemm_probe(DOMINANT["variant"], pr)
+        hip.set_gemm_f8_probe(pr8)
+        return pr, pr8
+
+    def detach_probes(pr, pr8):
+        """-> (KernelProbe-like for the bf16 GEMM, for the fp8 GEMM); after the fence."""
+        if pr is None:
+            return None, None
+        if isinstance(pr, tuple):
+            res = pr[1].probe_results()
+            return (hip.PlanProbeResults([r[1:] for r in res if r[0] != "gemm_f8"]),
+                    hip.PlanProbeResults([r[1:] for r in res if r[0] == "gemm_f8"]))
+        hip.set_gemm_probe(DOMINANT["variant"], None)
+        hip.set_gemm_f8_probe(None)
+        pr.resolve_rows()
+        pr8.resolve_rows()
+        return pr, pr8
+
+    probe, probe8 = attach_probes()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     fence()
     dt = time.perf_counter() - t0
-    hip.set_gemm_probe(DOMINANT["variant"], None)
-    hip.set_gemm_f8_probe(None)
+    probe, probe8 = detach_probes(probe, probe8)
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     per_rank = None
     if grouped:
@@ -327,31 +358,31 @@ def main():
     # pairs/s): a GEMM launch that shares the chip measures longer than the kernel takes alone.  The per-kernel roofline is
     # therefore taken from a second pass of the same K steps with the inline schedule (nothing concurrent with the kernel
     # being timed); the timed region's own (overlapped) figure is reported beside it.
-    overlapped = (ts is None and os.environ.get("MSCLIP_CONV_SIDE_STREAM", "1") != "0")
+    overlapped = ts is None and eng.opt.conv_side_stream
     probe_timed, probe8_timed, dt_probe = probe, probe8, dt
     if probe is not None and overlapped:
-        os.environ["MSCLIP_CONV_SIDE_STREAM"] = "0"
+        shipped_opt = eng.opt
+        eng.opt = eng.opt.replace(conv_side_stream=False)
+        step()                                           # (records the inline schedule's launch table)
         step()
-        probe, probe8 = hip.KernelProbe(), hip.KernelProbe()
-        hip.set_gemm_probe(DOMINANT["variant"], probe)
-        hip.set_gemm_f8_probe(probe8)
+        planned = ts is None and eng.last_plan is not None
+        probe, probe8 = attach_probes()
         fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
         fence()
         dt_probe = time.perf_counter() - t0
-        hip.set_gemm_probe(DOMINANT["variant"], None)
-        hip.set_gemm_f8_probe(None)
-        del os.environ["MSCLIP_CONV_SIDE_STREAM"]
+        probe, probe8 = detach_probes(probe, probe8)
+        eng.opt = shipped_opt
 
     if rank == 0:
         ms = dt / args.steps * 1e3
         pairs_s = B * world * args.steps / dt
         gf_ref = GFLOP_PER_PAIR[args.model]
-        skipped = 0.0 if (ts is not None or hip.env_flag("MSCLIP_FULL_LAST_BLOCK")) else \
+        skipped = 0.0 if (ts is not None or eng.opt.full_last_block) else \
             SKIPPED_ROWS_PER_PAIR[args.model] * 18 * WIDTH[args.model] ** 2 / 1e9
-        if skipped and model.precision != "fp8-qkv" and not hip.env_flag("MSCLIP_LAST_BLOCK_ALL_QUERIES"):
+        if skipped and model.precision != "fp8-qkv" and not eng.opt.last_block_all_queries:
             # ... and the last block's query projection (2 d^2 per skipped row) and attention (4 L d per skipped query) of
             # the rows that are not read afterwards (engine._last_block_attention)
             lv = SKIPPED_ROWS_PER_PAIR[args.model] + 2 - 77
@@ -391,7 +422,9 @@ def main():
                        "captions": (f"[SOT, {args.caption_tokens} ids, EOT, zero pad]" if args.caption_tokens else
                                     "[SOT, l ~ U{4..60} random ids, EOT, zero pad] (SURVEY s8(d), synth.synth_tokens)") +
                                    f": {float(lens_host.double().mean()):.2f} live rows of {eng.Lt} per caption on average (max {int(lens_host.max())})",
-                       "caption_lengths": ("staged one step ahead inside the timed region (engine.stage_captions: length kernels + "
+                       "caption_lengths": ("computed inside the step and kept on the device (msclip_text_lengths' dims -> M_dev of every "
+                                           "launch over the text rows): no host read, plain token tensors in" if dynamic else
+                                           "staged one step ahead inside the timed region (engine.stage_captions: length kernels + "
                                            "8-byte read-back of step k + 1 queued in front of step k)" if stage_ahead else
                                            "computed at the start of each step (host waits for the read-back)" if packed else "not needed"),
                        "text_rows": ("packed: only the rows up to each caption's EOT position exist (the causal mask makes the rest "
@@ -403,6 +436,9 @@ def main():
                                "not_executed_dead_rows_of_last_block": round(skipped * fmul, 3),
                                "not_executed_rows_behind_eot": round(dead * fmul, 3)},
             "loss": round(loss_val, 5),
+            "launch_loop": ({"kind": "native launch table (msclip_plan_run), recorded on the first step", "entries": eng.last_plan.n_ops,
+                             "launches": eng.last_plan.n_launches, "events": eng.last_plan.n_events}
+                            if (ts is None and eng.last_plan is not None) else {"kind": "Python / ctypes, one call per launch"}),
         }
         if ts is not None:
             rec["metric"] = f"training step (forward + backward + AdamW, BatchNorm: {args.bn} statistics) pairs/sec " + args.model

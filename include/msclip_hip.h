@@ -87,6 +87,10 @@ typedef struct msclip_gemm_desc {
   const void* resid2;    /* producer only: rows >= seg_split read their residual from resid2[m][ldr] (m the absolute row) instead of
                           * resid -- the image rows' stream sits in the lateral adapter's output buffer behind an adapter (M.py:1777)
                           * while the text rows' is `out` itself; NULL: every row from resid */
+  const int* M_dev;      /* dense ping-pong kernel (msclip_gemm's "pp" variant, msclip_gemm_f8) only: when not NULL the kernel
+                          * runs min(M, *M_dev) rows -- the row count of a packed caption batch lives on the device
+                          * (msclip_text_lengths' dims), M is the upper bound the launch is sized and validated for; the value
+                          * must satisfy the same divisibility rules as M (whole 256-row tiles for the fold forms) */
 } msclip_gemm_desc;
 
 int msclip_gemm(const msclip_gemm_desc* desc, void* stream);
@@ -115,7 +119,7 @@ int msclip_gemm_f8(const msclip_gemm_desc* desc, const float* row_scale, const f
 /* LayerNorm (M.py:204-219; parameters (gamma, beta) for rows < split, (gamma2, beta2) from there on) straight to e4m3 with one
  * fp32 scale per row: q[m][c] = fp8(y / s[m]), s[m] = max_c |y| / 448.  The quantising producer of msclip_gemm_f8's X operand. */
 int msclip_layernorm_f8(const float* x, int ldx, const float* gamma, const float* beta, const float* gamma2, const float* beta2,
-                        int split, void* q, int ldq, float* row_scale, int M, int C, float eps, void* stream);
+                        int split, void* q, int ldq, float* row_scale, int M, int C, float eps, const int* m_dev, void* stream);
 
 /* bf16 [M, C] rows -> e4m3 + per-row scale (same convention).  C % 8 == 0. */
 int msclip_quant_f8_rows(const void* x, int ldx, void* q, int ldq, float* row_scale, int M, int C, void* stream);
@@ -140,14 +144,17 @@ int msclip_layernorm(const float* x, int ldx, const int* row_idx, int row_mul, i
 
 /* msclip_layernorm over contiguous rows that also leaves what the LayerNorm fold needs about these rows: center[m] = the row's
  * mean (the next producing GEMM centres its bf16 copy on it) and rowstat[m] = (1, 0) (the consuming GEMM takes `out` as it
- * is).  Either pointer may be NULL. */
+ * is).  Either pointer may be NULL.  m_dev (optional, here and in msclip_rowstat_finalize / msclip_layernorm_f8): a device int;
+ * the kernel runs min(M, *m_dev) rows (packed captions: the row count never visits the host, M sizes the launch). */
 int msclip_layernorm_stats(const float* x, int ldx, const float* gamma, const float* beta, void* out, int ldo, int out_kind,
-                           float* raw_out, int ld_raw, float* center, float* rowstat, int M, int C, float eps, void* stream);
+                           float* raw_out, int ld_raw, float* center, float* rowstat, int M, int C, float eps, const int* m_dev,
+                           void* stream);
 
 /* Row statistics of a producing GEMM's partial sums (msclip_gemm_desc.part): for rows [0, M)
  *   mu = sum_g part[m][g][0] / C,  var = sum_g part[m][g][1] / C - mu^2  (sums of x - center[m]: the subtraction is benign),
  *   rowstat[m] = (1 / sqrt(var + eps), mu / sqrt(var + eps)),  center[m] += mu.   groups = C / 64, folded in index order. */
-int msclip_rowstat_finalize(const float* part, int groups, float* center, float* rowstat, int M, int C, float eps, void* stream);
+int msclip_rowstat_finalize(const float* part, int groups, float* center, float* rowstat, int M, int C, float eps, const int* m_dev,
+                            void* stream);
 
 /* The same over one [M, C] matrix whose rows [0, split) and [split, M) carry different parameters: the image and
  * the text tokens of the shared residual matrix with their modality-specific LayerNorms (M.py:1027-1028 run per
@@ -166,19 +173,27 @@ int msclip_embed_tokens(const long long* tokens, const float* emb, const float* 
  * output (or receive any gradient) in ANY block.  Caption b therefore owns n_b = argmax_l tokens[b,l] + 1 consecutive rows of
  * the token matrix, at cu[b] = sum_{j<b} n_j, instead of L.
  * msclip_text_lengths: len[b] = n_b (first maximum, like torch.argmax); cu[0..B-1] as above, cu[B] = total live rows,
- * cu[B+1] = max_b n_b (cu holds B + 2 ints); eot_row[b] = row_base + cu[b] + n_b - 1 (optional).  tokens int64 [B, L]. */
-int msclip_text_lengths(const long long* tokens, int B, int L, int row_base, int* len, int* cu, int* eot_row, void* stream);
+ * cu[B+1] = max_b n_b (cu holds B + 2 ints); eot_row[b] = row_base + cu[b] + n_b - 1 (optional).  tokens int64 [B, L].
+ * dims (optional, 8 ints): the row counts the launches over the text rows read ON THE DEVICE (msclip_gemm_desc.M_dev, the m_dev /
+ * rows_dev / dims arguments below), so that neither the host nor a hipGraph capture ever needs the batch's total:
+ *   dims[0] = total live rows, [1] = longest caption, [2] = padded = total rounded up to a multiple of pad_to (pad_to 0: total),
+ *   [3] = row_base + padded (rows of the whole token matrix when the text segment starts at row_base), [4] = padded - total,
+ *   [5] = row_base + total, [6] = row_base.  cap_rows >= B * L = the rows the caller's buffers hold behind row_base. */
+int msclip_text_lengths(const long long* tokens, int B, int L, int row_base, int* len, int* cu, int* eot_row, int* dims, int pad_to,
+                        int cap_rows, void* stream);
 
 /* x[row_base + cu[b] + l] = emb[tokens[b,l]] + pos[l] for l < n_b (M.py:3047-3048 on the live rows); the rows
- * [row_base + cu[B], row_base + rows_padded) -- tile padding of the GEMMs over the packed segment, < 256 rows -- are zeroed. */
+ * [row_base + cu[B], row_base + rows_padded) -- tile padding of the GEMMs over the packed segment, < 256 rows -- are zeroed.
+ * rows_dev (optional): device int, the padded row count (dims + 2 of msclip_text_lengths); rows_padded is then its upper bound. */
 int msclip_embed_tokens_packed(const long long* tokens, const float* emb, const float* pos, float* x, int ldx, const int* cu,
-                               int B, int L, int C, int vocab, int row_base, int rows_padded, void* stream);
+                               int B, int L, int C, int vocab, int row_base, int rows_padded, const int* rows_dev, void* stream);
 
 /* msclip_attention over packed captions: sample b's tokens are rows cu[b] .. cu[b+1] of qkv / out (both start at the text
  * segment), Lmax >= every length (<= 96: picks the tile count).  The pad_rows (< 256) output rows behind cu[nsamples] are
- * zeroed.  Replaces M.py:707-738 with the mask of :2965-2971 on the rows that can matter. */
+ * zeroed.  Replaces M.py:707-738 with the mask of :2965-2971 on the rows that can matter.  dims (optional): msclip_text_lengths'
+ * device block; the padding rows zeroed are then min(pad_rows, dims[4]) (pad_rows = the launch's bound, 255). */
 int msclip_attention_varlen(const void* qkv, void* out, const int* cu, int nsamples, int Lmax, int heads, int ldq, int ldo,
-                            int causal, int pad_rows, void* stream);
+                            int causal, int pad_rows, const int* dims, void* stream);
 
 /* ---- Fused in_proj + attention (BASELINE.json north_star: "fused QKV-projection + SDPA"; replaces F.linear with in_proj_weight /
  * in_proj_bias, M.py:612, and the attention core of M.py:707-738 with the causal mask of :2965-2971 for captions) in ONE kernel:
@@ -559,7 +574,59 @@ int msclip_bn_fold_bwd(const float* G, long long ldg, const float* w_raw, int co
 int msclip_bn_finish(const float* sums, int r, int C, long long n, const float* gamma, const float* beta, float eps, float* out,
                      void* stream);
 
-#define MSCLIP_ABI_VERSION 6   /* 5 (round 5): packed-caption entry points, msclip_qkv_attention / msclip_qkvattn_tables, msclip_pack_weights, single-launch msclip_colsum */
+/* ---- Launch plans (round 6; no reference counterpart: the reference's step is a Python loop over ATen calls, M.py:2388-2459,
+ * 3126-3141).  A plan is the launch table of one step: while a plan is recording on the calling thread every stream-ordered entry
+ * point of this library appends (itself, a copy of its arguments, the slot of its stream) before doing its work -- the recording
+ * pass is a real step -- and msclip_plan_run replays the table: the same entry points with the stored arguments on the streams
+ * the caller passes, no host-side argument marshalling.  Data-dependent row counts must be device-side (M_dev / m_dev / dims).
+ *   msclip_plan_begin(plan, streams, n): start recording; streams[i] is slot i (slot 0 = the caller's main stream).  A launch on
+ *     any other stream makes msclip_plan_end fail.  One recording per thread at a time.
+ *   msclip_plan_bind_external(plan, base, nbytes) -> index: pointer arguments inside [base, base + nbytes) (inputs that live in
+ *     caller buffers: images, token ids) are re-based at run time on ext[index] of msclip_plan_run.
+ *   msclip_plan_record_event(plan, stream) -> event id; msclip_plan_wait_event(plan, stream, id): the cross-stream edges of the
+ *     step (the caller performs the same record / wait on its own events for the recording pass itself).
+ *   msclip_plan_end -> number of table entries (< 0: unusable).  msclip_plan_abort: give up a recording.
+ *   msclip_plan_run(plan, streams, n, ext, n_ext): replay.  Legal under a stream capture whose origin stream is slot 0 provided
+ *     every other slot is first touched by a recorded wait on an event of a captured stream (the engine's schedules are).
+ *   Entry points that read HOST arrays (msclip_colsum_multi, msclip_adamw_multi) cannot be recorded: the recording fails. */
+typedef struct msclip_plan_s msclip_plan_s;
+int msclip_plan_create(msclip_plan_s** plan);
+int msclip_plan_destroy(msclip_plan_s* plan);
+int msclip_plan_begin(msclip_plan_s* plan, void* const* streams, int nstreams);
+int msclip_plan_bind_external(msclip_plan_s* plan, const void* base, long long nbytes);
+int msclip_plan_record_event(msclip_plan_s* plan, void* stream);
+int msclip_plan_wait_event(msclip_plan_s* plan, void* stream, int event);
+int msclip_plan_end(msclip_plan_s* plan);
+int msclip_plan_abort(msclip_plan_s* plan);
+int msclip_plan_info(const msclip_plan_s* plan, int* n_ops, int* n_launches, int* n_events, int* n_streams, int* n_ext);
+const char* msclip_plan_op_name(const msclip_plan_s* plan, int i);
+int msclip_plan_run(msclip_plan_s* plan, void* const* streams, int nstreams, const void* const* ext, int next);
+int msclip_plan_size(const msclip_plan_s* plan);                     /* entries so far (also while recording) */
+/* Launch probes: HIP timing events around table entries op_idx[0..n) on each entry's own stream for the next `runs` replays (the
+ * per-kernel durations of bench.py's roofline leg, measured inside the timed region); elapsed(run, i) after a synchronise. */
+int msclip_plan_probe_enable(msclip_plan_s* plan, const int* op_idx, int n, int runs);
+int msclip_plan_probe_disable(msclip_plan_s* plan);
+int msclip_plan_probe_runs(const msclip_plan_s* plan);
+int msclip_plan_probe_elapsed(msclip_plan_s* plan, int run, int i, float* ms);
+
+/* A non-blocking stream whose kernels may only run on n_cus compute units (hipExtStreamCreateWithCUMask), the first n_cus bits of
+ * the mask (from_top = 0) or the last (1); gfx950 enumerates CUs XCD-interleaved, so either is an even spread over the XCDs. */
+int msclip_stream_create_cu_masked(int n_cus, int from_top, void** stream);
+
+/* ---- RCCL behind the C ABI.  Replaces torch.distributed's all_gather of reference lib/utils/comm.py:140-154
+ * (called from M.py:3138-3141) and the all-reduce of lib/utils/utils.py:66-73 with stream-ordered calls on the caller's stream.
+ *   msclip_comm_unique_id(id128): 128 bytes naming a new communicator (one rank creates, the host distributes them);
+ *   msclip_comm_init(rank, world, id128, &comm): collective; msclip_comm_destroy; msclip_comm_async_error (0 = healthy);
+ *   msclip_allgather_feats: recv[r][count] = rank r's send[count] (rank-major, comm.py:150-153); dtype 0 bf16, 1 fp32, 2 bytes, 3 int32;
+ *   msclip_allreduce: element-wise sum (op 0) / max (op 1) over the ranks. */
+int msclip_comm_unique_id(void* id128);
+int msclip_comm_init(int rank, int world, const void* id128, void** comm);
+int msclip_comm_destroy(void* comm);
+int msclip_comm_async_error(void* comm);
+int msclip_allgather_feats(void* comm, const void* send, void* recv, long long count, int dtype, void* stream);
+int msclip_allreduce(void* comm, const void* send, void* recv, long long count, int dtype, int op, void* stream);
+
+#define MSCLIP_ABI_VERSION 7   /* 7 (round 6): device-side row counts (M_dev / m_dev / dims), the plan executor, RCCL entry points; 6 /  5 (round 5): packed-caption entry points, msclip_qkv_attention / msclip_qkvattn_tables, msclip_pack_weights, single-launch msclip_colsum */
 int msclip_abi_version(void);
 const char* msclip_build_arch(void);
 

@@ -333,3 +333,58 @@ def init_distributed(backend=None):
         torch.cuda.set_device(local)
         comm.local_rank = local
     dist.init_process_group(backend=backend, init_method="env://", timeout=datetime.timedelta(minutes=30))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# RCCL through the library's C ABI (include/msclip_hip.h: msclip_comm_init / msclip_allgather_feats / msclip_allreduce;
+# SURVEY.md s8(b)).  The collectives above go through torch.distributed's ProcessGroupNCCL -- a Python-side object with its own
+# streams and watchdog; these run on the CALLER's stream, which makes them table entries of a launch plan (hip.Plan) and legal
+# inside a hipGraph capture, and lets a host without Python drive the same path.  Opt-in: EngineOptions.native_collectives
+# (MSCLIP_NATIVE_COLLECTIVES=1) + init_native_comm() once per process, after init_distributed().
+# ---------------------------------------------------------------------------------------------------------------------
+_NATIVE = {"comm": None, "world": 1, "rank": 0}
+
+
+def native_comm():
+    """The C-ABI communicator handle (ctypes.c_void_p) of this process, or None before init_native_comm()."""
+    return _NATIVE["comm"]
+
+
+def init_native_comm(device=None):
+    """Collective over the ranks of the torch.distributed group (or a one-rank communicator without one): rank 0 creates the
+    128-byte RCCL unique id (msclip_comm_unique_id), the existing process group's store carries it to the others
+    (broadcast_object_list), every rank joins (msclip_comm_init).  Replaces nothing of the reference: its rendezvous is
+    torch.distributed.init_process_group (lib/utils/utils.py:61-73), which stays the bootstrap here."""
+    import ctypes
+    from . import hip
+    if _NATIVE["comm"] is not None:
+        return _NATIVE["comm"]
+    grouped = dist.is_available() and dist.is_initialized()
+    rank, world = (dist.get_rank(), dist.get_world_size()) if grouped else (0, 1)
+    L = hip.lib()
+    buf = ctypes.create_string_buffer(128)
+    if rank == 0:
+        hip._check(L.msclip_comm_unique_id(buf), "msclip_comm_unique_id")
+    ident = [bytes(buf.raw)]
+    if grouped and world > 1:
+        dist.broadcast_object_list(ident, src=0)
+    handle = ctypes.c_void_p()
+    with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
+        hip._check(L.msclip_comm_init(rank, world, ctypes.create_string_buffer(ident[0], 128), ctypes.byref(handle)), "msclip_comm_init")
+    _NATIVE.update(comm=handle, world=world, rank=rank)
+    return handle
+
+
+def destroy_native_comm():
+    from . import hip
+    h, _NATIVE["comm"] = _NATIVE["comm"], None
+    if h is not None:
+        hip._check(hip.lib().msclip_comm_destroy(h), "msclip_comm_destroy")
+
+
+def native_world():
+    return _NATIVE["world"]
+
+
+def native_rank():
+    return _NATIVE["rank"]

@@ -21,6 +21,7 @@
 //   accumulator layout yields: key 16s + w  ->  slot 16s + 8*((w>>2)&1) + (w&3) + 4*(w>>3).
 #include <stdlib.h>
 #include "common.h"
+#include "plan.h"
 #include "../../include/msclip_hip.h"
 
 namespace {
@@ -28,7 +29,7 @@ namespace {
 template <int NT, bool CAUSAL, int WPB>
 __global__ __launch_bounds__(WPB * 64) void attn_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                    int nsamples, int Lfix, int H, int ldq, int ldo,
-                                                   const int* __restrict__ cu, int pad_rows) {
+                                                   const int* __restrict__ cu, int pad_rows, const int* __restrict__ dims) {
   constexpr int KP = NT * 32;      // padded key count
   constexpr int KPS = KP + 8;      // LDS row stride (elements): 16-B aligned, odd multiple of 16 B
   extern __shared__ __attribute__((aligned(16))) bf16_t vt_all[];
@@ -40,6 +41,7 @@ __global__ __launch_bounds__(WPB * 64) void attn_kernel(const bf16_t* __restrict
     // packed captions (msclip_attention_varlen): the workgroups behind the last (sample, head) pair zero the output rows of
     // the tile padding [cu[nsamples], cu[nsamples] + pad_rows) -- one wave per row
     const int r = pair - nsamples * H;
+    if (dims) pad_rows = min(pad_rows, dims[4]);     // device-side count of the tile-padding rows (msclip_text_lengths)
     if (cu && r < pad_rows) {
       bf16_t* orow = out + (size_t)(cu[nsamples] + r) * ldo;
       for (int c = lane * 8; c < H * 64; c += 512) *(uint4*)(orow + c) = make_uint4(0, 0, 0, 0);
@@ -621,17 +623,17 @@ __global__ __launch_bounds__(256) void attn_lastq_kernel(const bf16_t* __restric
 
 template <int NT>
 int launch(const void* qkv, void* out, int nsamples, int L, int H, int ldq, int ldo, int causal, hipStream_t st,
-           const int* cu = nullptr, int pad_rows = 0) {
+           const int* cu = nullptr, int pad_rows = 0, const int* dims = nullptr) {
   constexpr int WPB = NT > 4 ? 2 : 4;  // keep dynamic LDS under 64 KiB
   const int pairs = nsamples * H + (cu ? pad_rows : 0);         // (one wave per padding row behind the real pairs)
   const int grid = (pairs + WPB - 1) / WPB;
   const size_t lds = WPB * 64 * (NT * 32 + 8) * sizeof(bf16_t);
   if (causal)
     hipLaunchKernelGGL((attn_kernel<NT, true, WPB>), dim3(grid), dim3(WPB * 64), lds, st, (const bf16_t*)qkv,
-                       (bf16_t*)out, nsamples, L, H, ldq, ldo, cu, pad_rows);
+                       (bf16_t*)out, nsamples, L, H, ldq, ldo, cu, pad_rows, dims);
   else
     hipLaunchKernelGGL((attn_kernel<NT, false, WPB>), dim3(grid), dim3(WPB * 64), lds, st, (const bf16_t*)qkv,
-                       (bf16_t*)out, nsamples, L, H, ldq, ldo, cu, pad_rows);
+                       (bf16_t*)out, nsamples, L, H, ldq, ldo, cu, pad_rows, dims);
   return msclip_launch_status();
 }
 
@@ -639,6 +641,7 @@ int launch(const void* qkv, void* out, int nsamples, int L, int H, int ldq, int 
 
 extern "C" int msclip_attention(const void* qkv, void* out, int nsamples, int L, int heads, int ldq, int ldo,
                                 int causal, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_attention, stream, qkv, out, nsamples, L, heads, ldq, ldo, causal);
   if (!qkv || !out || nsamples <= 0 || L <= 0 || heads <= 0 || (ldq % 8) || (ldo % 8)) return MSCLIP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   if (L <= 64) return launch<2>(qkv, out, nsamples, L, heads, ldq, ldo, causal, st);
@@ -673,22 +676,25 @@ static int lastq_launch(const void* q, int ldqc, const void* qkv, int ldq, void*
 
 extern "C" int msclip_attention_lastq(const void* q, int ldqc, const void* qkv, int ldq, void* out, int ldo, int nsamples, int L,
                                       int heads, const int* last_row, int row_base, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_attention_lastq, stream, q, ldqc, qkv, ldq, out, ldo, nsamples, L, heads, last_row, row_base);
   return lastq_launch(q, ldqc, qkv, ldq, out, ldo, nsamples, L, heads, last_row, row_base, nullptr, stream);
 }
 
 extern "C" int msclip_attention_lastq_varlen(const void* q, int ldqc, const void* qkv, int ldq, void* out, int ldo, int nsamples,
                                              int Lmax, int heads, const int* cu, int row_base, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_attention_lastq_varlen, stream, q, ldqc, qkv, ldq, out, ldo, nsamples, Lmax, heads, cu, row_base);
   if (!cu) return MSCLIP_EINVAL;
   return lastq_launch(q, ldqc, qkv, ldq, out, ldo, nsamples, Lmax, heads, nullptr, row_base, cu, stream);
 }
 
 extern "C" int msclip_attention_varlen(const void* qkv, void* out, const int* cu, int nsamples, int Lmax, int heads, int ldq,
-                                       int ldo, int causal, int pad_rows, void* stream) {
+                                       int ldo, int causal, int pad_rows, const int* dims, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_attention_varlen, stream, qkv, out, cu, nsamples, Lmax, heads, ldq, ldo, causal, pad_rows, dims);
   if (!qkv || !out || !cu || nsamples <= 0 || Lmax <= 0 || Lmax > 96 || heads <= 0 || (ldq % 8) || (ldo % 8) || pad_rows < 0 ||
       pad_rows > 255)
     return MSCLIP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  if (Lmax <= 32) return launch<1>(qkv, out, nsamples, Lmax, heads, ldq, ldo, causal, st, cu, pad_rows);
-  if (Lmax <= 64) return launch<2>(qkv, out, nsamples, Lmax, heads, ldq, ldo, causal, st, cu, pad_rows);
-  return launch<3>(qkv, out, nsamples, Lmax, heads, ldq, ldo, causal, st, cu, pad_rows);
+  if (Lmax <= 32) return launch<1>(qkv, out, nsamples, Lmax, heads, ldq, ldo, causal, st, cu, pad_rows, dims);
+  if (Lmax <= 64) return launch<2>(qkv, out, nsamples, Lmax, heads, ldq, ldo, causal, st, cu, pad_rows, dims);
+  return launch<3>(qkv, out, nsamples, Lmax, heads, ldq, ldo, causal, st, cu, pad_rows, dims);
 }

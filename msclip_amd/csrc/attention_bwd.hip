@@ -17,6 +17,7 @@
 // per lane and token: 8-byte global stores.
 #include <type_traits>
 #include "common.h"
+#include "plan.h"
 #include "../../include/msclip_hip.h"
 
 namespace {
@@ -585,6 +586,7 @@ int launch_bwd_qb(const void* qkv, const void* o, const void* dout, void* dqkv, 
 
 extern "C" int msclip_attention_bwd(const void* qkv, const void* o, const void* dout, void* dqkv, int nsamples, int L,
                                     int heads, int ldq, int ldo, int causal, float* colsum_part, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_attention_bwd, stream, qkv, o, dout, dqkv, nsamples, L, heads, ldq, ldo, causal, colsum_part);
   if (!qkv || !o || !dout || !dqkv || nsamples <= 0 || L <= 0 || L > 208 || heads <= 0 || (ldq % 8) || (ldo % 8))
     return MSCLIP_EINVAL;
   if (colsum_part && L > 96) return MSCLIP_EINVAL;      // the query-blocked form does not carry the per-sample column sums
@@ -602,6 +604,7 @@ extern "C" int msclip_attention_bwd(const void* qkv, const void* o, const void* 
 extern "C" int msclip_attention_bwd_varlen(const void* qkv, const void* o, const void* dout, void* dqkv, const int* cu, int nsamples,
                                            int Lmax, int heads, int ldq, int ldo, int causal, int pad_rows, float* colsum_part,
                                            void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_attention_bwd_varlen, stream, qkv, o, dout, dqkv, cu, nsamples, Lmax, heads, ldq, ldo, causal, pad_rows, colsum_part);
   if (!qkv || !o || !dout || !dqkv || !cu || nsamples <= 0 || Lmax <= 0 || Lmax > 96 || heads <= 0 || (ldq % 8) || (ldo % 8) ||
       pad_rows < 0 || pad_rows > 255)
     return MSCLIP_EINVAL;

@@ -14,6 +14,7 @@
 #include <type_traits>
 #include <stdlib.h>
 #include "common.h"
+#include "plan.h"
 #include "../../include/msclip_hip.h"
 
 namespace {
@@ -794,6 +795,7 @@ static int grid_for(size_t n, int per_block, int cap = 4096) {
 }
 
 extern "C" int msclip_transpose_bf16(const void* in, int ldi, void* out, int ldo, int M, int C, int Mpad, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_transpose_bf16, stream, in, ldi, out, ldo, M, C, Mpad);
   if (!in || !out || M <= 0 || C <= 0 || Mpad < M || ldo < Mpad || ldi < C) return MSCLIP_EINVAL;
   if (!(C % 8) && !(ldi % 8) && !(ldo % 8) && !(Mpad % 64) && !((size_t)in % 16) && !((size_t)out % 16))
     hipLaunchKernelGGL(transpose_vec_kernel, dim3(Mpad / 64, (C + 63) / 64), dim3(256), 0, (hipStream_t)stream,
@@ -805,6 +807,7 @@ extern "C" int msclip_transpose_bf16(const void* in, int ldi, void* out, int ldo
 }
 
 extern "C" int msclip_colsum_multi(const msclip_fold_item* items, int n_items, void* stream) {
+  MSCLIP_PLAN_UNSUPPORTED(msclip_colsum_multi);
   if (!items || n_items <= 0) return MSCLIP_EINVAL;
   for (int i = 0; i < n_items; ++i)
     if (!items[i].src || !items[i].dst || items[i].M <= 0 || items[i].N <= 0 || items[i].ld < items[i].N || items[i].scale_n < 0 ||
@@ -826,12 +829,14 @@ extern "C" int msclip_colsum_multi(const msclip_fold_item* items, int n_items, v
 
 extern "C" int msclip_transpose_bf16_multi(const msclip_transpose_item* items_dev, const int* blk_start_dev, int n_items,
                                            int n_blocks, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_transpose_bf16_multi, stream, items_dev, blk_start_dev, n_items, n_blocks);
   if (!items_dev || !blk_start_dev || n_items <= 0 || n_blocks <= 0) return MSCLIP_EINVAL;
   hipLaunchKernelGGL(transpose_multi_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, items_dev, blk_start_dev, n_items);
   return msclip_launch_status();
 }
 
 extern "C" int msclip_cast_bf16(const float* x, int ldx, void* y, int ldy, int M, int C, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_cast_bf16, stream, x, ldx, y, ldy, M, C);
   if (!x || !y || M <= 0 || C <= 0 || (C & 3) || (ldx & 3) || (ldy & 3)) return MSCLIP_EINVAL;
   hipLaunchKernelGGL(cast_kernel, dim3(grid_for((size_t)M * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, x, ldx,
                      (bf16_t*)y, ldy, M, C / 4);
@@ -840,6 +845,7 @@ extern "C" int msclip_cast_bf16(const float* x, int ldx, void* y, int ldy, int M
 
 extern "C" int msclip_cast_bf16_colsum(const float* x, int ldx, void* y, int ldy, int M, int C, float* part, int part_blocks,
                                        int skip_group, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_cast_bf16_colsum, stream, x, ldx, y, ldy, M, C, part, part_blocks, skip_group);
   if (!x || !y || !part || M <= 0 || C <= 0 || C > 1024 || (C & 3) || (ldx & 3) || (ldy & 3) || part_blocks < 1 ||
       ((size_t)part & 15) || skip_group < 0 || (skip_group && M % skip_group))
     return MSCLIP_EINVAL;
@@ -877,6 +883,7 @@ static unsigned* colsum_counters(int n) {
 
 extern "C" int msclip_colsum(const void* x, int ld, int is_f32, float* out, int M, int N, int accumulate, float* scratch,
                              int chunks, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_colsum, stream, x, ld, is_f32, out, M, N, accumulate, scratch, chunks);
   if (!x || !out || M <= 0 || N <= 0 || ld < N || chunks < 1 || (chunks > 1 && !scratch)) return MSCLIP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   if (is_f32 && M <= 32 && N >= 16384 && !(N % 4) && !(ld % 4) && !((size_t)x % 16) && !((size_t)out % 16)) {
@@ -910,6 +917,7 @@ extern "C" int msclip_colsum(const void* x, int ld, int is_f32, float* out, int 
 }
 
 extern "C" int msclip_quickgelu(const void* h, void* y, long long n, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_quickgelu, stream, h, y, n);
   if (!h || !y || n <= 0 || (n & 7)) return MSCLIP_EINVAL;
   hipLaunchKernelGGL(quickgelu_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h,
                      (bf16_t*)y, (size_t)(n / 8));
@@ -917,6 +925,7 @@ extern "C" int msclip_quickgelu(const void* h, void* y, long long n, void* strea
 }
 
 extern "C" int msclip_quickgelu_bwd(const void* h, const void* dy, void* dh, long long n, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_quickgelu_bwd, stream, h, dy, dh, n);
   if (!h || !dy || !dh || n <= 0 || (n & 7)) return MSCLIP_EINVAL;
   hipLaunchKernelGGL(quickgelu_bwd_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h,
                      (const bf16_t*)dy, (bf16_t*)dh, (size_t)(n / 8));
@@ -927,6 +936,7 @@ extern "C" int msclip_layernorm_bwd(const float* x, int ldx, const int* row_idx,
                                     int dy_is_f32, const float* gamma, float* dx, int lddx, int accumulate, float* part,
                                     int part_blocks, int M, int C, float eps, void* dxb, int lddxb, float* sum_part,
                                     int sum_accumulate, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_layernorm_bwd, stream, x, ldx, row_idx, row_mul, dy, lddy, dy_is_f32, gamma, dx, lddx, accumulate, part, part_blocks, M, C, eps, dxb, lddxb, sum_part, sum_accumulate);
   if (!x || !dy || !gamma || !dx || M <= 0 || (C != 512 && C != 768) || part_blocks < 1) return MSCLIP_EINVAL;
   // bf16 copy + column sums of the written dx rows: the plain row mapping only (dxb row m = dx row m), both or neither
   if ((dxb != nullptr) != (sum_part != nullptr) || (dxb && (row_idx || row_mul != 1 || (lddxb % 4)))) return MSCLIP_EINVAL;
@@ -952,6 +962,7 @@ extern "C" int msclip_layernorm_bwd(const float* x, int ldx, const int* row_idx,
 
 extern "C" int msclip_l2norm_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, int M, int E,
                                  void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_l2norm_bwd, stream, x, ldx, dy, lddy, dx, lddx, M, E);
   if (!x || !dy || !dx || M <= 0 || E <= 0) return MSCLIP_EINVAL;
   hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, dy, lddy, dx, lddx, M, E);
   return msclip_launch_status();
@@ -959,6 +970,7 @@ extern "C" int msclip_l2norm_bwd(const float* x, int ldx, const float* dy, int l
 
 extern "C" int msclip_clip_loss_bwd_g(const float* S, int lds, const float* lse_row, const float* lse_col, int label_off,
                                       float w, void* G, int ldg, float* dscale_part, int R, int N, int Npad, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_clip_loss_bwd_g, stream, S, lds, lse_row, lse_col, label_off, w, G, ldg, dscale_part, R, N, Npad);
   if (!S || !lse_row || !lse_col || !G || R <= 0 || N <= 0 || Npad < N || ldg < Npad || lds < N) return MSCLIP_EINVAL;
   hipLaunchKernelGGL(clip_g_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, S, lds, lse_row, lse_col, label_off,
                      w, (bf16_t*)G, ldg, dscale_part, R, N, Npad);
@@ -967,6 +979,7 @@ extern "C" int msclip_clip_loss_bwd_g(const float* S, int lds, const float* lse_
 
 extern "C" int msclip_embed_tokens_bwd(const long long* tokens, const float* dx, int lddx, float* demb, float* dpos, int B,
                                        int L, int C, int vocab, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_embed_tokens_bwd, stream, tokens, dx, lddx, demb, dpos, B, L, C, vocab);
   if (!tokens || !dx || !demb || B <= 0 || L <= 0 || C <= 0) return MSCLIP_EINVAL;
   hipLaunchKernelGGL(embed_bwd_kernel, dim3(B * L), dim3(256), 0, (hipStream_t)stream, tokens, dx, lddx, demb, dpos, B, L, C,
                      vocab);
@@ -975,6 +988,7 @@ extern "C" int msclip_embed_tokens_bwd(const long long* tokens, const float* dx,
 
 extern "C" int msclip_embed_tokens_bwd_packed(const long long* tokens, const float* dx, int lddx, const int* cu, float* demb,
                                               float* dpos, int B, int L, int C, int vocab, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_embed_tokens_bwd_packed, stream, tokens, dx, lddx, cu, demb, dpos, B, L, C, vocab);
   if (!tokens || !dx || !cu || !demb || B <= 0 || L <= 0 || C <= 0 || (C % 4) || (lddx % 4)) return MSCLIP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(embed_bwd_packed_kernel, dim3(B * L), dim3(256), 0, st, tokens, dx, lddx, cu, demb, L, C, vocab);
@@ -984,6 +998,7 @@ extern "C" int msclip_embed_tokens_bwd_packed(const long long* tokens, const flo
 
 extern "C" int msclip_adapter_sum(const float* xin, int ldx, const float* t, int ldt, const float* dww, const float* dwb,
                                   float* out, int ldo, int B, int L, int g, int C, int usecls, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_adapter_sum, stream, xin, ldx, t, ldt, dww, dwb, out, ldo, B, L, g, C, usecls);
   if (!xin || !t || !dww || !dwb || !out || B <= 0 || L != g * g + 1) return MSCLIP_EINVAL;
   if (!((C | ldx | ldt | ldo) & 3) && !(((size_t)xin | (size_t)t | (size_t)dww | (size_t)dwb | (size_t)out) & 15))
     hipLaunchKernelGGL(adapter_grid_vec_kernel<false>, dim3(B * L), dim3(256), 0, (hipStream_t)stream, xin, ldx, t, ldt, dww, dwb,
@@ -996,6 +1011,7 @@ extern "C" int msclip_adapter_sum(const float* xin, int ldx, const float* t, int
 
 extern "C" int msclip_adapter_dx(const float* dsum, int lds, const float* dww, float* dx, int lddx, int B, int L, int g, int C,
                                  int usecls, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_adapter_dx, stream, dsum, lds, dww, dx, lddx, B, L, g, C, usecls);
   if (!dsum || !dww || !dx || B <= 0 || L != g * g + 1) return MSCLIP_EINVAL;
   if (!((C | lds | lddx) & 3) && !(((size_t)dsum | (size_t)dww | (size_t)dx) & 15))
     hipLaunchKernelGGL(adapter_grid_vec_kernel<true>, dim3(B * L), dim3(256), 0, (hipStream_t)stream, dsum, lds,
@@ -1008,6 +1024,7 @@ extern "C" int msclip_adapter_dx(const float* dsum, int lds, const float* dww, f
 
 extern "C" int msclip_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
                             float eps, float weight_decay, int step, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_adamw, stream, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step);
   if (!p || !g || !m || !v || n <= 0 || step < 1) return MSCLIP_EINVAL;
   const float c1 = 1.f / (1.f - powf(beta1, (float)step)), c2 = 1.f / (1.f - powf(beta2, (float)step));
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((size_t)n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (size_t)n, lr,
@@ -1017,6 +1034,7 @@ extern "C" int msclip_adamw(float* p, const float* g, float* m, float* v, long l
 
 extern "C" int msclip_adamw_multi(const msclip_adamw_tensor* tensors, int count, float beta1, float beta2, float eps, int step,
                                   void* stream) {
+  MSCLIP_PLAN_UNSUPPORTED(msclip_adamw_multi);
   if (!tensors || count < 0 || step < 1) return MSCLIP_EINVAL;
   for (int i = 0; i < count; ++i)
     if (!tensors[i].p || !tensors[i].g || !tensors[i].m || !tensors[i].v || tensors[i].n <= 0 ||

@@ -14,6 +14,7 @@
 //
 // All of them are HBM-bound streaming kernels: 16-byte accesses, consecutive lanes on consecutive channel chunks.
 #include "common.h"
+#include "plan.h"
 #include "../../include/msclip_hip.h"
 
 namespace {
@@ -643,6 +644,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const TD* __restrict__ d
 
 extern "C" int msclip_im2col(const void* x, int x_kind, void* col, int B, int H, int W, int C, int KH, int KW, int stride,
                              int pad, int Ho, int Wo, int Kp, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_im2col, stream, x, x_kind, col, B, H, W, C, KH, KW, stride, pad, Ho, Wo, Kp);
   if (!x || !col || B <= 0 || H <= 0 || W <= 0 || C <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0 || Ho <= 0 || Wo <= 0)
     return MSCLIP_EINVAL;
   if ((Kp % 8) || Kp < KH * KW * C || x_kind < 0 || x_kind > 2) return MSCLIP_EINVAL;
@@ -672,6 +674,7 @@ extern "C" int msclip_im2col(const void* x, int x_kind, void* col, int B, int H,
 
 extern "C" int msclip_image_conv_wgrad(const float* img, const void* dy, int lddy, float* part, int part_blocks, int B, int S,
                                        int co, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_image_conv_wgrad, stream, img, dy, lddy, part, part_blocks, B, S, co);
   const int Ho = (S + 2 - 3) / 2 + 1;
   if (!img || !dy || !part || B <= 0 || S <= 0 || (S & 3) || S > 256 || Ho > 128 || co <= 0 || co > 64 || (co & 7) || (lddy & 7) ||
       lddy < co || part_blocks < 1 || ((size_t)img & 15) || ((size_t)dy & 15))
@@ -692,6 +695,7 @@ extern "C" int msclip_image_conv_wgrad(const float* img, const void* dy, int ldd
 
 extern "C" int msclip_col2im(const void* dcol, int ld, void* dx, int B, int H, int W, int C, int KH, int KW, int stride,
                              int pad, int Ho, int Wo, int accumulate, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_col2im, stream, dcol, ld, dx, B, H, W, C, KH, KW, stride, pad, Ho, Wo, accumulate);
   if (!dcol || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0)
     return MSCLIP_EINVAL;
   if ((ld % 8) || ld < KH * KW * C || Ho <= 0 || Wo <= 0) return MSCLIP_EINVAL;
@@ -702,6 +706,7 @@ extern "C" int msclip_col2im(const void* dcol, int ld, void* dx, int B, int H, i
 }
 
 extern "C" int msclip_relu_bwd(const void* dy, const void* dy2, const void* y, void* out, long long n, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_relu_bwd, stream, dy, dy2, y, out, n);
   if (!dy || !y || !out || n <= 0 || (n % 8)) return MSCLIP_EINVAL;
   hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for((size_t)n / 8, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
                      (const uint4*)dy, (const uint4*)dy2, (const uint4*)y, (uint4*)out, (size_t)n / 8);
@@ -710,6 +715,7 @@ extern "C" int msclip_relu_bwd(const void* dy, const void* dy2, const void* y, v
 
 extern "C" int msclip_dwpool_bwd(const void* dpool, int ldp, const float* w, void* dtop, int B, int H, int W, int C, int k,
                                  int accumulate, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_dwpool_bwd, stream, dpool, ldp, w, dtop, B, H, W, C, k, accumulate);
   if (!dpool || !w || !dtop || B <= 0 || k <= 0 || H <= 0 || H != W || (H % k) || (C % 8) || (ldp % 8) || ldp < C)
     return MSCLIP_EINVAL;
   const size_t total = (size_t)B * H * W * (C / 8);
@@ -720,6 +726,7 @@ extern "C" int msclip_dwpool_bwd(const void* dpool, int ldp, const float* w, voi
 
 extern "C" int msclip_dwpool_wgrad(const void* dpool, int ldp, const void* top, float* part, int B, int H, int W, int C,
                                    int k, int slabs, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_dwpool_wgrad, stream, dpool, ldp, top, part, B, H, W, C, k, slabs);
   if (!dpool || !top || !part || B <= 0 || k <= 0 || H <= 0 || H != W || (H % k) || C <= 0 || ldp < C || slabs <= 0 ||
       slabs > 65535)
     return MSCLIP_EINVAL;
@@ -734,6 +741,7 @@ extern "C" int msclip_dwpool_wgrad(const void* dpool, int ldp, const void* top, 
 
 extern "C" int msclip_dw3x3_wgrad(const float* dsum, int lds, const float* x, int ldx, float* part, int B, int L, int g, int C,
                                   int slabs, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_dw3x3_wgrad, stream, dsum, lds, x, ldx, part, B, L, g, C, slabs);
   if (!dsum || !x || !part || B <= 0 || L != g * g + 1 || C <= 0 || lds < C || ldx < C || slabs <= 0 || slabs > 65535)
     return MSCLIP_EINVAL;
   const dim3 rows_grid((C + 255) / 256, slabs);
@@ -749,6 +757,7 @@ extern "C" int msclip_dw3x3_wgrad(const float* dsum, int lds, const float* x, in
 
 // ---- train-mode BatchNorm entry points.  x_f32 / dy_f32: 0 = bf16, 1 = fp32 matrices.
 extern "C" int msclip_bn_stats(const void* x, int ld, int x_f32, float* part, int M, int C, int chunks, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_bn_stats, stream, x, ld, x_f32, part, M, C, chunks);
   if (!x || !part || M <= 0 || C <= 0 || ld < C || chunks < 1 || chunks > 65535) return MSCLIP_EINVAL;
   const int rpc = (M + chunks - 1) / chunks;
   const dim3 grid((C + 63) / 64, chunks);
@@ -759,6 +768,7 @@ extern "C" int msclip_bn_stats(const void* x, int ld, int x_f32, float* part, in
 
 extern "C" int msclip_bn_apply(const void* x, int ld, int x_f32, const float* scale, const float* shift, const void* resid,
                                int ldr, void* y, int ldy, int y_f32, int M, int C, int relu, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_bn_apply, stream, x, ld, x_f32, scale, shift, resid, ldr, y, ldy, y_f32, M, C, relu);
   if (!x || !scale || !shift || !y || M <= 0 || C <= 0 || ld < C || ldy < C || (resid && ldr < C)) return MSCLIP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const bf16_t* r = (const bf16_t*)resid;
@@ -794,6 +804,7 @@ extern "C" int msclip_bn_apply(const void* x, int ld, int x_f32, const float* sc
 
 extern "C" int msclip_bn_bwd_reduce(const void* dy, int lddy, int dy_f32, const void* x, int ld, int x_f32, const float* mean,
                                     const float* rstd, float* part, int M, int C, int chunks, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_bn_bwd_reduce, stream, dy, lddy, dy_f32, x, ld, x_f32, mean, rstd, part, M, C, chunks);
   if (!dy || !x || !mean || !rstd || !part || M <= 0 || C <= 0 || ld < C || lddy < C || chunks < 1 || chunks > 65535)
     return MSCLIP_EINVAL;
   const int rpc = (M + chunks - 1) / chunks;
@@ -812,6 +823,7 @@ extern "C" int msclip_bn_bwd_reduce(const void* dy, int lddy, int dy_f32, const 
 extern "C" int msclip_bn_bwd_dx(const void* dy, int lddy, int dy_f32, const void* x, int ld, int x_f32, const float* mean,
                                 const float* rstd, const float* gamma, const float* dbeta, const float* dgamma, void* dx,
                                 int lddx, int M, int C, long long n_stat, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_bn_bwd_dx, stream, dy, lddy, dy_f32, x, ld, x_f32, mean, rstd, gamma, dbeta, dgamma, dx, lddx, M, C, n_stat);
   if (!dy || !x || !mean || !rstd || !gamma || !dbeta || !dgamma || !dx || M <= 0 || C <= 0 || ld < C || lddy < C || lddx < C ||
       n_stat <= 0)
     return MSCLIP_EINVAL;
@@ -868,6 +880,7 @@ __global__ __launch_bounds__(256) void bn_fold_bwd_kernel(const float* __restric
 extern "C" int msclip_bn_fold_bwd(const float* G, long long ldg, const float* w_raw, int cout, int K, const float* dshift,
                                   const float* gamma, const float* mean, const float* var, float eps, float* dW, float* dgamma,
                                   float* dbeta, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_bn_fold_bwd, stream, G, ldg, w_raw, cout, K, dshift, gamma, mean, var, eps, dW, dgamma, dbeta);
   if (!G || !w_raw || !dshift || !gamma || !mean || !var || !dW || !dgamma || !dbeta || cout <= 0 || K <= 0 || ldg < K) return MSCLIP_EINVAL;
   hipLaunchKernelGGL(bn_fold_bwd_kernel, dim3(cout), dim3(256), 0, (hipStream_t)stream, G, ldg, w_raw, K, dshift, gamma, mean, var,
                      eps, dW, dgamma, dbeta);
@@ -943,6 +956,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finish_kernel(const float* __restr
 
 extern "C" int msclip_bn_finish(const float* sums, int r, int C, long long n, const float* gamma, const float* beta, float eps,
                                 float* out, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_bn_finish, stream, sums, r, C, n, gamma, beta, eps, out);
   if (!sums || !gamma || !beta || !out || r <= 0 || C <= 0 || n <= 0) return MSCLIP_EINVAL;
   hipLaunchKernelGGL(bn_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, r, C, 1.f / (float)n, gamma,
                      beta, eps, out, 1);
@@ -951,6 +965,7 @@ extern "C" int msclip_bn_finish(const float* sums, int r, int C, long long n, co
 
 extern "C" int msclip_bn_finish_tiled(const float* sums, int r, int C, long long n, const float* gamma, const float* beta, float eps,
                                       float* out, int rep, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_bn_finish_tiled, stream, sums, r, C, n, gamma, beta, eps, out, rep);
   if (!sums || !gamma || !beta || !out || r <= 0 || C <= 0 || n <= 0 || rep <= 0) return MSCLIP_EINVAL;
   hipLaunchKernelGGL(bn_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, r, C, 1.f / (float)n, gamma,
                      beta, eps, out, rep);
@@ -958,6 +973,7 @@ extern "C" int msclip_bn_finish_tiled(const float* sums, int r, int C, long long
 }
 
 extern "C" int msclip_bn_bwd_finish(const float* part, int chunks, int r, int C, const float* gamma, float* out, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_bn_bwd_finish, stream, part, chunks, r, C, gamma, out);
   if (!part || !gamma || !out || chunks <= 0 || r <= 0 || C <= 0) return MSCLIP_EINVAL;
   hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, part, chunks, r, C, gamma, out);
   return msclip_launch_status();

@@ -8,6 +8,7 @@
 //    (kernel == stride, ibid. 1573-1581 with the PRALLEL_T2B_* geometry).
 #include <stdlib.h>
 #include "common.h"
+#include "plan.h"
 #include "../../include/msclip_hip.h"
 
 namespace {
@@ -355,6 +356,7 @@ __global__ __launch_bounds__(256) void patchify_kernel(const T* __restrict__ img
 
 extern "C" int msclip_stem_conv3x3s2_dual_raw(const void* img, int img_is_bf16, const float* w, float* out_a, float* out_b, int B,
                                               int H, int W, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_stem_conv3x3s2_dual_raw, stream, img, img_is_bf16, w, out_a, out_b, B, H, W);
   if (!img || !w || !out_a || !out_b || B <= 0 || H < 2 || W < 2 || (H & 1) || (W & 1)) return MSCLIP_EINVAL;
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const long long nblk = ((long long)B * Ho * Wo + 31) / 32;
@@ -373,6 +375,7 @@ extern "C" int msclip_stem_conv3x3s2_dual_raw(const void* img, int img_is_bf16, 
 
 extern "C" int msclip_stem_conv3x3s2_dual(const void* img, int img_is_bf16, const float* w, const float* bias,
                                           void* out_a, void* out_b, int B, int H, int W, int C1, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_stem_conv3x3s2_dual, stream, img, img_is_bf16, w, bias, out_a, out_b, B, H, W, C1);
   if (!img || !w || !bias || !out_a || !out_b || B <= 0 || (C1 != 48 && C1 != 64) || H < 2 || W < 2 || (H & 1) || (W & 1)) return MSCLIP_EINVAL;
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const long long total = (long long)B * Ho * Wo;
@@ -413,6 +416,7 @@ extern "C" int msclip_stem_conv3x3s2_dual(const void* img, int img_is_bf16, cons
 
 extern "C" int msclip_dwpool(const void* top, const float* w, void* out, int ldo, int B, int H, int W, int C, int k,
                              void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_dwpool, stream, top, w, out, ldo, B, H, W, C, k);
   if (!top || !w || !out || B <= 0 || k <= 0 || (C % 8) || (ldo % 8) || (H % k) || H != W) return MSCLIP_EINVAL;
   const int g = H / k;
   const char* oldk = getenv("MSCLIP_DWPOOL_SCALAR");            // the thread-per-chunk kernel, for cross-checks only
@@ -433,6 +437,7 @@ extern "C" int msclip_dwpool(const void* top, const float* w, void* out, int ldo
 }
 
 extern "C" int msclip_patchify(const void* img, int img_is_bf16, void* out, int kpad, int B, int H, int W, int P, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_patchify, stream, img, img_is_bf16, out, kpad, B, H, W, P);
   if (!img || !out || B <= 0 || P <= 0 || H != W || (H % P) || kpad < 3 * P * P || (kpad % 64)) return MSCLIP_EINVAL;
   const int g = H / P;
   const size_t lds = (size_t)g * kpad * sizeof(bf16_t);

@@ -22,6 +22,7 @@
 // 8 K-values q*8.. of channel p (A) / of pixel p (B); the result holds channels 4q..4q+3 of pixel p.
 #include <stdlib.h>
 #include "common.h"
+#include "plan.h"
 #include "../../include/msclip_hip.h"
 
 namespace {
@@ -878,6 +879,7 @@ extern "C" int msclip_front_trace_read(unsigned long long* out) {
 
 extern "C" int msclip_conv1x1_conv3x3s2(const void* x, const void* w1, const float* b1, const void* w2,
                                         const float* b2, void* out, int B, int H, int W, int Cout, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_conv1x1_conv3x3s2, stream, x, w1, b1, w2, b2, out, B, H, W, Cout);
   if (!x || !w1 || !b1 || !w2 || !b2 || !out || B <= 0 || H <= 0 || W <= 0 || (Cout != 48 && Cout != 96))
     return MSCLIP_EINVAL;
   FrontArgs a{};
@@ -893,6 +895,7 @@ extern "C" int msclip_conv1x1_conv3x3s2(const void* x, const void* w1, const flo
 extern "C" int msclip_convresblock48_s2(const void* x, const void* w1, const float* b1, const void* w2, const float* b2,
                                         const void* w3, const void* wr, const float* b3r, void* out, int B, int H,
                                         int W, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_convresblock48_s2, stream, x, w1, b1, w2, b2, w3, wr, b3r, out, B, H, W);
   if (!x || !w1 || !b1 || !w2 || !b2 || !w3 || !wr || !b3r || !out || B <= 0 || H <= 0 || W <= 0) return MSCLIP_EINVAL;
   FrontArgs a{};
   a.x = x; a.w1 = w1; a.b1 = b1; a.w2 = (const bf16_t*)w2; a.b2 = b2; a.side = nullptr; a.out = (bf16_t*)out;
@@ -908,6 +911,7 @@ extern "C" int msclip_convresblock48_s2(const void* x, const void* w1, const flo
 extern "C" int msclip_stem_dual_conv3x3s2(const void* img, int img_is_bf16, const float* w, const float* bias,
                                           void* out_b, const void* w2, const float* b2, void* out2, int B, int H,
                                           int W, int Cout, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_stem_dual_conv3x3s2, stream, img, img_is_bf16, w, bias, out_b, w2, b2, out2, B, H, W, Cout);
   if (!img || !w || !bias || !out_b || !w2 || !b2 || !out2 || B <= 0 || H <= 0 || W <= 0 || (Cout != 48 && Cout != 96))
     return MSCLIP_EINVAL;
   FrontArgs a{};

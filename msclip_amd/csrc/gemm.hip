@@ -22,6 +22,7 @@
 #include <stdlib.h>
 #include <type_traits>
 #include "common.h"
+#include "plan.h"
 #include "../../include/msclip_hip.h"
 #include "gemm_epilogue.h"
 
@@ -525,6 +526,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a_i
   // slice s contracts columns [s*K/S, (s+1)*K/S) of both operands into its own fp32 matrix out[s][M][ldo].  A weight
   // gradient is 9-36 output tiles over a 65 024-deep contraction: tiles x slices workgroups of ONE launch fill the chip.
   msclip_gemm_desc a = a_in;
+  if (a.M_dev) a.M = min(a.M, *a.M_dev);           // device-side row count (packed captions): a_in.M is the launch's upper bound
   unsigned kbase = 0;                              // TNL: first token row of this K slice
   const int ktot = a.K;                            // TNL: rows of the operands (tokens beyond it read as zero)
   if (TNL) {
@@ -1132,7 +1134,8 @@ extern "C" const char* msclip_gemm_variant(const msclip_gemm_desc* d) { return k
 // Split-K form for contractions that are deep and narrow (weight gradients: a few output tiles over 10^5 - 10^7 tokens or
 // pixels): `slices` workgroup rows, each contracting K / slices columns into out[slice][M][ldo] (fp32), 128 x 128 tiles.
 extern "C" int msclip_gemm_splitk(const msclip_gemm_desc* d, int slices, void* stream) {
-  if (!d || slices < 1 || slices > 65535 || pick_variant(d) == GV_INVALID) return MSCLIP_EINVAL;
+  MSCLIP_PLAN_HOOK(msclip_gemm_splitk, stream, d, slices);
+  if (!d || slices < 1 || slices > 65535 || pick_variant(d) == GV_INVALID || d->M_dev) return MSCLIP_EINVAL;
   if (d->mode != 0 || d->out_kind != 1 || d->bias || d->resid || d->resid_kind || d->act || d->rpg != 0x7fffffff || d->radd ||
       d->roff || (d->K % (BK * slices)))
     return MSCLIP_EINVAL;
@@ -1155,7 +1158,8 @@ extern "C" int msclip_gemm_splitk(const msclip_gemm_desc* d, int slices, void* s
 // W [T, ldw] (columns = output columns n): the weight gradients of the training step without the operand transposes
 // (gemm_pp_kernel<0, false, 0, true>).  desc: X, W, out, zero, M, N, K = T, ldx, ldw, ldo; everything else unset.
 extern "C" int msclip_gemm_splitk_tn(const msclip_gemm_desc* d, int slices, void* stream) {
-  if (!d || !d->X || !d->W || !d->out || !d->zero || slices < 1 || slices > 65535) return MSCLIP_EINVAL;
+  MSCLIP_PLAN_HOOK(msclip_gemm_splitk_tn, stream, d, slices);
+  if (!d || !d->X || !d->W || !d->out || !d->zero || slices < 1 || slices > 65535 || d->M_dev) return MSCLIP_EINVAL;
   if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->ldx % 8) || (d->ldw % 8) || d->ldx < d->M || d->ldw < d->N || (d->ldo % 4) ||
       d->ldo < d->N || d->mode != 0 || d->out_kind != 1 || d->bias || d->resid || d->resid_kind || d->act || d->out2 || d->xb ||
       d->rowstat || d->W2 || d->rpg != 0x7fffffff || d->radd || d->roff || d->alpha != 1.f)
@@ -1178,6 +1182,7 @@ extern "C" int msclip_gemm_splitk_tn(const msclip_gemm_desc* d, int slices, void
 // K a multiple of 128; out = epilogue(alpha * row_scale[m] * col_scale[n] * sum_k X[m, k] W[n, k]) with the usual bias /
 // activation / residual epilogues.  Dense operands only.
 extern "C" int msclip_gemm_f8(const msclip_gemm_desc* d, const float* row_scale, const float* col_scale, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_gemm_f8, stream, d, row_scale, col_scale);
   if (!d || !d->X || !d->W || !d->out || !d->zero || !row_scale || !col_scale) return MSCLIP_EINVAL;
   if (d->mode != 0 || d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->K % 128) || (d->ldx % 16) || (d->ldw % 16) || d->ldx < d->K ||
       d->ldw < d->K || d->rpg != 0x7fffffff || d->out2 || d->out_kind < 0 || d->out_kind > 2 || d->resid_kind < 0 || d->resid_kind > 2 ||
@@ -1204,8 +1209,10 @@ extern "C" int msclip_gemm_f8(const msclip_gemm_desc* d, const float* row_scale,
 }
 
 extern "C" int msclip_gemm(const msclip_gemm_desc* d, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_gemm, stream, d);
   const GemmVariant v = pick_variant(d);
   if (v == GV_INVALID) return MSCLIP_EINVAL;
+  if (d->M_dev && v != GV_PP) return MSCLIP_EINVAL;   // device-side row counts: the persistent dense ping-pong kernel only
   hipStream_t st = (hipStream_t)stream;
   const int ncu = device_cus();
   const int tiles = ((d->M + 255) / 256) * ((d->N + 255) / 256);

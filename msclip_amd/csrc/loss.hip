@@ -9,6 +9,7 @@
 // in fragment shape.  The same launch also emits the label logit (the diagonal) from the split that contains it.
 // msclip_clip_loss_from_partials merges the splits of both directions into the scalar partial loss of this rank.
 #include "common.h"
+#include "plan.h"
 #include "../../include/msclip_hip.h"
 
 namespace {
@@ -186,6 +187,7 @@ __global__ __launch_bounds__(256) void clip_loss_kernel(const float* __restrict_
 extern "C" int msclip_clip_lse_fused(const void* A, int lda, const void* Bm, int ldb, int R, int N, int E, float scale,
                                      int label_off, int nsplit, float* part_max, float* part_sum, float* diag,
                                      void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_clip_lse_fused, stream, A, lda, Bm, ldb, R, N, E, scale, label_off, nsplit, part_max, part_sum, diag);
   if (!A || !Bm || !part_max || !part_sum || !diag || R <= 0 || N <= 0 || nsplit <= 0) return MSCLIP_EINVAL;
   if (E <= 0 || E > 768 || (E % 16) || (lda % 8) || (ldb % 8)) return MSCLIP_EINVAL;
   if (label_off < 0 || label_off + R > N) return MSCLIP_EINVAL;
@@ -202,6 +204,7 @@ extern "C" int msclip_clip_lse_fused(const void* A, int lda, const void* Bm, int
 extern "C" int msclip_clip_loss_from_partials(const float* pmax_img, const float* psum_img, const float* pmax_txt,
                                               const float* psum_txt, const float* diag, int R, int nsplit, float scale,
                                               float* out, float* lse_out, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_clip_loss_from_partials, stream, pmax_img, psum_img, pmax_txt, psum_txt, diag, R, nsplit, scale, out, lse_out);
   if (!pmax_img || !psum_img || !pmax_txt || !psum_txt || !diag || !out || R <= 0 || nsplit <= 0) return MSCLIP_EINVAL;
   hipLaunchKernelGGL(loss_from_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pmax_img, psum_img,
                      pmax_txt, psum_txt, diag, R, nsplit, scale, out, lse_out);
@@ -209,6 +212,7 @@ extern "C" int msclip_clip_loss_from_partials(const float* pmax_img, const float
 }
 
 extern "C" int msclip_lse_rows(const float* logits, int ld, float* lse, int R, int N, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_lse_rows, stream, logits, ld, lse, R, N);
   if (!logits || !lse || R <= 0 || N <= 0) return MSCLIP_EINVAL;
   hipLaunchKernelGGL(lse_rows_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, logits, ld, lse, N);
   return msclip_launch_status();
@@ -216,6 +220,7 @@ extern "C" int msclip_lse_rows(const float* logits, int ld, float* lse, int R, i
 
 extern "C" int msclip_clip_loss_partial(const float* lse_img, const float* lse_txt, const float* img_rows, int ld,
                                         int label_off, int R, float scale, float* out, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_clip_loss_partial, stream, lse_img, lse_txt, img_rows, ld, label_off, R, scale, out);
   if (!lse_img || !lse_txt || !img_rows || !out || R <= 0) return MSCLIP_EINVAL;
   hipLaunchKernelGGL(clip_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, lse_img, lse_txt, img_rows, ld,
                      label_off, R, scale, out);

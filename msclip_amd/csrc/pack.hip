@@ -12,6 +12,7 @@
 // packing.py computes on the CPU; torch's GPU division / square root are not correctly rounded, so against the GPU tensor
 // algebra a BatchNorm scale can differ by one ulp.
 #include "common.h"
+#include "plan.h"
 #include "../../include/msclip_hip.h"
 
 namespace {
@@ -96,6 +97,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const msclip_pack_ite
 
 extern "C" int msclip_pack_weights(const msclip_pack_item* items_dev, const int* blk_start_dev, int n_items, int n_blocks,
                                    void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_pack_weights, stream, items_dev, blk_start_dev, n_items, n_blocks);
   if (!items_dev || !blk_start_dev || n_items <= 0 || n_blocks <= 0) return MSCLIP_EINVAL;
   hipLaunchKernelGGL(pack_weights_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, items_dev, blk_start_dev, n_items);
   return msclip_launch_status();

@@ -16,6 +16,7 @@
 // Rows of a tile behind its last whole sample belong to the next tile: computed, never stored.
 #include <stdlib.h>
 #include "common.h"
+#include "plan.h"
 #include "../../include/msclip_hip.h"
 
 namespace {
@@ -397,6 +398,7 @@ __global__ __launch_bounds__(256) void qkvattn_tables_kernel(const int* __restri
 
 extern "C" int msclip_qkvattn_tables(const int* cu, int nsamples, int split_sample, int* rowseg, int* tile_first, int* ntiles,
                                      int max_tiles, int max_rows, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_qkvattn_tables, stream, cu, nsamples, split_sample, rowseg, tile_first, ntiles, max_tiles, max_rows);
   if (!cu || !rowseg || !tile_first || !ntiles || nsamples <= 0 || max_tiles <= 0 || (max_rows != 256 && max_rows != 128))
     return MSCLIP_EINVAL;
   hipLaunchKernelGGL(qkvattn_tables_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, cu, nsamples, split_sample, rowseg,
@@ -405,6 +407,7 @@ extern "C" int msclip_qkvattn_tables(const int* cu, int nsamples, int split_samp
 }
 
 extern "C" int msclip_qkv_attention(const msclip_qkvattn_desc* d, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_qkv_attention, stream, d);
   if (!d || !d->X || !d->W || !d->bias || !d->out || !d->cu || !d->tile_first || !d->rowseg || !d->zero) return MSCLIP_EINVAL;
   if (d->heads <= 0 || d->K <= 0 || (d->K % BK) || d->K < 3 * BK || (d->ldx % 8) || (d->ldw % 8) || d->ldw < d->K || (d->ldo % 8) ||
       d->ldo < d->heads * 64 || d->M <= 0 || (!d->ntiles_dev && d->ntiles <= 0))

@@ -6,6 +6,7 @@
 // projected features (ibid. 2983, 3076).
 #include <stdlib.h>
 #include "common.h"
+#include "plan.h"
 #include "../../include/msclip_hip.h"
 
 namespace {
@@ -65,9 +66,11 @@ template <int NV>
 __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, void* out, int ldo, int out_kind,
                                                        float* __restrict__ raw_out, int ld_raw, float* __restrict__ center,
-                                                       float* __restrict__ rowstat, int M, float eps) {
+                                                       float* __restrict__ rowstat, int M, float eps,
+                                                       const int* __restrict__ m_dev) {
   const int lane = threadIdx.x & 63;
   const int m = blockIdx.x * WPB + (threadIdx.x >> 6);
+  if (m_dev) M = min(M, *m_dev);                      // device-side row count (packed captions): the launch covers the upper bound
   if (m >= M) return;
   float4 v[NV];
 #pragma unroll
@@ -88,8 +91,10 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__
 // thread per row, the groups folded in index order (deterministic).
 template <int G4>                                      // G4 = groups / 2 float4 pieces per row (groups = C / 64: 12 or 16), or 0 = any
 __global__ __launch_bounds__(256) void rowstat_finalize_kernel(const float* __restrict__ part, int groups, float* __restrict__ center,
-                                                               float* __restrict__ rowstat, int M, float invC, float eps) {
+                                                               float* __restrict__ rowstat, int M, float invC, float eps,
+                                                               const int* __restrict__ m_dev) {
   const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m_dev) M = min(M, *m_dev);
   if (m >= M) return;
   float s = 0.f, q = 0.f;
   if (G4 > 0) {                                       // all of the row's partials in flight at once
@@ -274,7 +279,7 @@ __global__ __launch_bounds__(64) void len_kernel(const long long* __restrict__ t
 }
 
 __global__ __launch_bounds__(1024) void scan_kernel(const int* __restrict__ len, int* __restrict__ cu, int* __restrict__ eot_row,
-                                                    int B, int row_base) {
+                                                    int B, int row_base, int* __restrict__ dims, int pad_to, int cap_rows) {
   __shared__ int wsum[16], wmax[16];
   __shared__ int carry_s, max_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -311,7 +316,23 @@ __global__ __launch_bounds__(1024) void scan_kernel(const int* __restrict__ len,
     }
     __syncthreads();
   }
-  if (tid == 0) { cu[B] = carry_s; cu[B + 1] = max_s; }
+  if (tid == 0) {
+    cu[B] = carry_s;
+    cu[B + 1] = max_s;
+    if (dims) {
+      // the row counts every launch over the text rows reads on the DEVICE (msclip_text_lengths): no host read sizes them
+      int padded = pad_to > 0 ? (carry_s + pad_to - 1) / pad_to * pad_to : carry_s;
+      if (padded > cap_rows) padded = carry_s;          // (cannot happen when cap_rows is a multiple of pad_to that holds every caption)
+      dims[0] = carry_s;                                // live text rows
+      dims[1] = max_s;                                  // longest caption
+      dims[2] = padded;                                 // text rows incl. the tile padding
+      dims[3] = row_base + padded;                      // rows of the whole token matrix
+      dims[4] = padded - carry_s;                       // padding rows
+      dims[5] = row_base + carry_s;
+      dims[6] = row_base;
+      dims[7] = 0;
+    }
+  }
 }
 
 // x[row_base + cu[b] + l] = emb[tok[b, l]] + pos[l] for l < n_b; rows [cu[B], rows_padded) of the text segment are zeroed
@@ -319,9 +340,11 @@ __global__ __launch_bounds__(1024) void scan_kernel(const int* __restrict__ len,
 template <int NV>
 __global__ __launch_bounds__(256) void embed_packed_kernel(const long long* __restrict__ tok, const float* __restrict__ emb,
                                                            const float* __restrict__ pos, float* __restrict__ x, int ldx,
-                                                           const int* __restrict__ cu, int B, int L, int vocab, int rows_padded) {
+                                                           const int* __restrict__ cu, int B, int L, int vocab, int rows_padded,
+                                                           const int* __restrict__ rows_dev) {
   const int lane = threadIdx.x & 63;
   const int m = blockIdx.x * WPB + (threadIdx.x >> 6);
+  if (rows_dev) rows_padded = min(rows_padded, *rows_dev);        // device-side padded row count (<= the host's bound)
   if (m >= B * L) {
     const int r = cu[B] + (m - B * L);
     if (r < rows_padded) {
@@ -636,6 +659,7 @@ static int launch_ln(const float* x, int ldx, const int* row_idx, int row_mul, i
 extern "C" int msclip_layernorm(const float* x, int ldx, const int* row_idx, int row_mul, int row_add,
                                 const float* gamma, const float* beta, void* out, int ldo, int out_kind,
                                 float* raw_out, int ld_raw, int M, int C, float eps, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_layernorm, stream, x, ldx, row_idx, row_mul, row_add, gamma, beta, out, ldo, out_kind, raw_out, ld_raw, M, C, eps);
   if (!x || !gamma || !beta || !out || M <= 0 || (ldx % 4) || (ldo % 4)) return MSCLIP_EINVAL;
   return launch_ln(x, ldx, row_idx, row_mul, row_add, gamma, beta, out, ldo, out_kind, raw_out, ld_raw, M, C, eps, gamma,
                    beta, M, (hipStream_t)stream);
@@ -643,28 +667,31 @@ extern "C" int msclip_layernorm(const float* x, int ldx, const int* row_idx, int
 
 extern "C" int msclip_layernorm_stats(const float* x, int ldx, const float* gamma, const float* beta, void* out, int ldo,
                                       int out_kind, float* raw_out, int ld_raw, float* center, float* rowstat, int M, int C,
-                                      float eps, void* stream) {
+                                      float eps, const int* m_dev, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_layernorm_stats, stream, x, ldx, gamma, beta, out, ldo, out_kind, raw_out, ld_raw, center, rowstat, M, C, eps, m_dev);
   if (!x || !gamma || !beta || !out || M <= 0 || (ldx % 4) || (ldo % 4) || (raw_out && (ld_raw % 4))) return MSCLIP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((M + WPB - 1) / WPB), blk(256);
-  NV_LAUNCH(C, ln_stats_kernel, grid, blk, st, x, ldx, gamma, beta, out, ldo, out_kind, raw_out, ld_raw, center, rowstat, M, eps)
+  NV_LAUNCH(C, ln_stats_kernel, grid, blk, st, x, ldx, gamma, beta, out, ldo, out_kind, raw_out, ld_raw, center, rowstat, M, eps, m_dev)
   return msclip_launch_status();
 }
 
 extern "C" int msclip_rowstat_finalize(const float* part, int groups, float* center, float* rowstat, int M, int C, float eps,
-                                       void* stream) {
+                                       const int* m_dev, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_rowstat_finalize, stream, part, groups, center, rowstat, M, C, eps, m_dev);
   if (!part || !center || !rowstat || M <= 0 || groups <= 0 || C != groups * 64) return MSCLIP_EINVAL;
   const dim3 grid((M + 255) / 256), blk(256);
   hipStream_t st = (hipStream_t)stream;
-  if (groups == 12) hipLaunchKernelGGL(rowstat_finalize_kernel<6>, grid, blk, 0, st, part, groups, center, rowstat, M, 1.f / (float)C, eps);
-  else if (groups == 16) hipLaunchKernelGGL(rowstat_finalize_kernel<8>, grid, blk, 0, st, part, groups, center, rowstat, M, 1.f / (float)C, eps);
-  else hipLaunchKernelGGL(rowstat_finalize_kernel<0>, grid, blk, 0, st, part, groups, center, rowstat, M, 1.f / (float)C, eps);
+  if (groups == 12) hipLaunchKernelGGL(rowstat_finalize_kernel<6>, grid, blk, 0, st, part, groups, center, rowstat, M, 1.f / (float)C, eps, m_dev);
+  else if (groups == 16) hipLaunchKernelGGL(rowstat_finalize_kernel<8>, grid, blk, 0, st, part, groups, center, rowstat, M, 1.f / (float)C, eps, m_dev);
+  else hipLaunchKernelGGL(rowstat_finalize_kernel<0>, grid, blk, 0, st, part, groups, center, rowstat, M, 1.f / (float)C, eps, m_dev);
   return msclip_launch_status();
 }
 
 extern "C" int msclip_layernorm_split(const float* x, int ldx, const float* gamma, const float* beta,
                                       const float* gamma2, const float* beta2, int split, void* out, int ldo,
                                       int out_kind, int M, int C, float eps, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_layernorm_split, stream, x, ldx, gamma, beta, gamma2, beta2, split, out, ldo, out_kind, M, C, eps);
   if (!x || !gamma || !beta || !gamma2 || !beta2 || !out || M <= 0 || split < 0 || split > M || (ldx % 4) || (ldo % 4))
     return MSCLIP_EINVAL;
   return launch_ln(x, ldx, nullptr, 1, 0, gamma, beta, out, ldo, out_kind, nullptr, 0, M, C, eps, gamma2, beta2, split,
@@ -673,6 +700,7 @@ extern "C" int msclip_layernorm_split(const float* x, int ldx, const float* gamm
 
 extern "C" int msclip_embed_tokens(const long long* tokens, const float* emb, const float* pos, float* x, int ldx,
                                    int* eot_row, int B, int L, int C, int vocab, int row_base, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_embed_tokens, stream, tokens, emb, pos, x, ldx, eot_row, B, L, C, vocab, row_base);
   if (!tokens || !emb || !pos || !x || B <= 0 || L <= 0 || (ldx % 4)) return MSCLIP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int rows = B * L;
@@ -684,17 +712,19 @@ extern "C" int msclip_embed_tokens(const long long* tokens, const float* emb, co
 }
 
 extern "C" int msclip_text_lengths(const long long* tokens, int B, int L, int row_base, int* len, int* cu, int* eot_row,
-                                   void* stream) {
-  if (!tokens || !len || !cu || B <= 0 || L <= 0 || row_base < 0) return MSCLIP_EINVAL;
+                                   int* dims, int pad_to, int cap_rows, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_text_lengths, stream, tokens, B, L, row_base, len, cu, eot_row, dims, pad_to, cap_rows);
+  if (!tokens || !len || !cu || B <= 0 || L <= 0 || row_base < 0 || pad_to < 0 || (dims && cap_rows < B * L)) return MSCLIP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(len_kernel, dim3(B), dim3(64), 0, st, tokens, len, B, L);
-  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, (const int*)len, cu, eot_row, B, row_base);
+  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, (const int*)len, cu, eot_row, B, row_base, dims, pad_to, cap_rows);
   return msclip_launch_status();
 }
 
 extern "C" int msclip_embed_tokens_packed(const long long* tokens, const float* emb, const float* pos, float* x, int ldx,
                                           const int* cu, int B, int L, int C, int vocab, int row_base, int rows_padded,
-                                          void* stream) {
+                                          const int* rows_dev, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_embed_tokens_packed, stream, tokens, emb, pos, x, ldx, cu, B, L, C, vocab, row_base, rows_padded, rows_dev);
   if (!tokens || !emb || !pos || !x || !cu || B <= 0 || L <= 0 || (ldx % 4) || row_base < 0 || rows_padded < 0 ||
       rows_padded > B * L + 255)
     return MSCLIP_EINVAL;
@@ -702,12 +732,13 @@ extern "C" int msclip_embed_tokens_packed(const long long* tokens, const float* 
   const int slots = B * L + 256;                     // every caption slot + at most 255 padding rows (+1: rounding)
   const dim3 grid((slots + WPB - 1) / WPB), blk(256);
   float* xb = x + (size_t)row_base * ldx;
-  NV_LAUNCH(C, embed_packed_kernel, grid, blk, st, tokens, emb, pos, xb, ldx, cu, B, L, vocab, rows_padded)
+  NV_LAUNCH(C, embed_packed_kernel, grid, blk, st, tokens, emb, pos, xb, ldx, cu, B, L, vocab, rows_padded, rows_dev)
   return msclip_launch_status();
 }
 
 extern "C" int msclip_fill_cls(const float* cls, const float* pos, float* x, int ldx, int B, int L, int C,
                                void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_fill_cls, stream, cls, pos, x, ldx, B, L, C);
   if (!cls || !pos || !x || B <= 0 || (ldx % 4)) return MSCLIP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((B + WPB - 1) / WPB), blk(256);
@@ -728,6 +759,7 @@ static bool adapter_sample_form(int C, int L, int ldx, int ldt, int ldo) {
 extern "C" int msclip_adapter_combine_ln(const float* xin, int ldx, const float* t, int ldt, const float* dww,
                                          const float* dwb, const float* gamma, const float* beta, float* xout,
                                          int ldo, int B, int L, int g, int C, int usecls, float eps, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_adapter_combine_ln, stream, xin, ldx, t, ldt, dww, dwb, gamma, beta, xout, ldo, B, L, g, C, usecls, eps);
   if (!xin || !t || !dww || !dwb || !gamma || !beta || !xout || xin == xout || L != g * g + 1) return MSCLIP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const char* perrow = getenv("MSCLIP_ADAPTER_PER_TOKEN");       // the wave-per-token kernel, for cross-checks only
@@ -752,6 +784,7 @@ extern "C" int msclip_adapter_combine_ln_stats(const float* xin, int ldx, const 
                                                const float* dwb, const float* gamma, const float* beta, float* xout, int ldo,
                                                const float* gamma1, const float* beta1, void* lno, int ldl, float* center,
                                                float* rowstat, int B, int L, int g, int C, int usecls, float eps, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_adapter_combine_ln_stats, stream, xin, ldx, t, ldt, dww, dwb, gamma, beta, xout, ldo, gamma1, beta1, lno, ldl, center, rowstat, B, L, g, C, usecls, eps);
   if (!xin || !t || !dww || !dwb || !gamma || !beta || !xout || xin == xout || L != g * g + 1 || !gamma1 || !beta1 || !lno ||
       !center || !rowstat || (ldl & 3))
     return MSCLIP_EINVAL;
@@ -768,6 +801,7 @@ extern "C" int msclip_adapter_combine_ln_stats(const float* xin, int ldx, const 
 
 extern "C" int msclip_l2norm(const float* x, int ldx, float* out_f32, int ldf, void* out_bf16, int ldb, int M, int E,
                              void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_l2norm, stream, x, ldx, out_f32, ldf, out_bf16, ldb, M, E);
   if (!x || (!out_f32 && !out_bf16) || M <= 0 || (E % 4) || (ldx % 4)) return MSCLIP_EINVAL;
   hipLaunchKernelGGL(l2norm_kernel, dim3((M + WPB - 1) / WPB), dim3(256), 0, (hipStream_t)stream, x, ldx, out_f32, ldf,
                      (bf16_t*)out_bf16, ldb, M, E);
@@ -791,6 +825,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const char* __restrict
 
 extern "C" int msclip_gather_rows(const void* x, long long ldx_bytes, const int* row_idx, int row_mul, int row_add, void* out,
                                   long long ldo_bytes, int M, int row_bytes, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_gather_rows, stream, x, ldx_bytes, row_idx, row_mul, row_add, out, ldo_bytes, M, row_bytes);
   if (!x || !out || M <= 0 || row_bytes <= 0 || (row_bytes % 16) || (ldx_bytes % 16) || (ldo_bytes % 16)) return MSCLIP_EINVAL;
   if (((uintptr_t)x | (uintptr_t)out) & 15) return MSCLIP_EINVAL;
   hipLaunchKernelGGL(gather_rows_kernel, dim3((M + WPB - 1) / WPB), dim3(256), 0, (hipStream_t)stream, (const char*)x, ldx_bytes,
@@ -806,9 +841,11 @@ template <int NV>
 __global__ __launch_bounds__(256) void ln_f8_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
                                                     const float* __restrict__ beta, const float* __restrict__ gamma2,
                                                     const float* __restrict__ beta2, int split, unsigned char* __restrict__ q,
-                                                    int ldq, float* __restrict__ row_scale, int M, float eps) {
+                                                    int ldq, float* __restrict__ row_scale, int M, float eps,
+                                                    const int* __restrict__ m_dev) {
   const int lane = threadIdx.x & 63;
   const int m = blockIdx.x * WPB + (threadIdx.x >> 6);
+  if (m_dev) M = min(M, *m_dev);
   if (m >= M) return;
   if (m >= split) {
     gamma = gamma2;
@@ -865,16 +902,18 @@ __global__ __launch_bounds__(256) void quant_f8_rows_kernel(const bf16_t* __rest
 
 extern "C" int msclip_layernorm_f8(const float* x, int ldx, const float* gamma, const float* beta, const float* gamma2,
                                    const float* beta2, int split, void* q, int ldq, float* row_scale, int M, int C, float eps,
-                                   void* stream) {
+                                   const int* m_dev, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_layernorm_f8, stream, x, ldx, gamma, beta, gamma2, beta2, split, q, ldq, row_scale, M, C, eps, m_dev);
   if (!x || !gamma || !beta || !gamma2 || !beta2 || !q || !row_scale || M <= 0 || split < 0 || split > M || (ldx % 4) || (ldq % 4))
     return MSCLIP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((M + WPB - 1) / WPB), blk(256);
-  NV_LAUNCH(C, ln_f8_kernel, grid, blk, st, x, ldx, gamma, beta, gamma2, beta2, split, (unsigned char*)q, ldq, row_scale, M, eps)
+  NV_LAUNCH(C, ln_f8_kernel, grid, blk, st, x, ldx, gamma, beta, gamma2, beta2, split, (unsigned char*)q, ldq, row_scale, M, eps, m_dev)
   return msclip_launch_status();
 }
 
 extern "C" int msclip_quant_f8_rows(const void* x, int ldx, void* q, int ldq, float* row_scale, int M, int C, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_quant_f8_rows, stream, x, ldx, q, ldq, row_scale, M, C);
   if (!x || !q || !row_scale || M <= 0 || C <= 0 || (C % 8) || (ldx % 8) || (ldq % 8)) return MSCLIP_EINVAL;
   hipLaunchKernelGGL(quant_f8_rows_kernel, dim3((M + WPB - 1) / WPB), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
                      (unsigned char*)q, ldq, row_scale, M, C);

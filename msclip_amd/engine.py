@@ -25,9 +25,11 @@ import torch.distributed as dist
 from . import comm as C
 from . import hip
 from . import packing as P
+from .options import EngineOptions
 
 
 _TEXT0 = {}
+_MASKED = {}
 
 
 def _text0_stream(device):
@@ -45,16 +47,32 @@ class Captions:
     (total live rows, longest caption) travel through pinned memory behind `event`.  Staging a batch while the previous one
     is still being computed (an input pipeline's prefetch stage) means the engine never waits for them."""
 
-    def __init__(self, tok, length, cu, eot, host, event):
+    def __init__(self, tok, length, cu, eot, host, event, release=None):
         self.tok, self.len, self.cu, self.eot, self._host, self._event = tok, length, cu, eot, host, event
         self._totals = None
+        self._release = release              # gives the pinned read-back slot back to the engine's pool once it has been read
         self.shape = tok.shape
+
+    def __del__(self):
+        # a batch that was staged but never consumed: its slot may only be reused once the copy into it has landed
+        if self._host is not None and self._release is not None:
+            try:
+                self._event.synchronize()
+                self._release(self._host)
+            except Exception:
+                pass
+
+    def ready(self):
+        """True when totals() would not block (the 8-byte read-back has landed)."""
+        return self._totals is not None or self._event.query()
 
     def totals(self):
         """(total live rows, longest caption): the one host read, taken once."""
         if self._totals is None:
             self._event.synchronize()
             self._totals = (int(self._host[0]), int(self._host[1]))
+            if self._release is not None:
+                self._release(self._host)
             self._host = None
         return self._totals
 
@@ -105,8 +123,11 @@ class Engine:
             raise NotImplementedError("keep the module in fp32 (checkpoint ABI); the engine makes its own bf16 copies")
         self.dev = ref.device
         self.model = model
+        self.opt = EngineOptions.from_env()      # every run-time switch, read once (msclip_amd/options.py); tests replace fields
         self._ws = {}
         self._calib = None              # calibrate_fp8() in progress: {id(_BlockW): (block, [device amax, ...])}
+        self._rec = None                # the launch plan (hip.Plan) that is recording this call's launches, if any
+        self.last_plan = None
         self._fp8_saved = {}            # calibrated hidden scales, restored into the fresh _BlockW objects of a re-pack
         self._fp8_warned = False
         self.force_unfused = False      # the training step runs the conv side layer by layer: every map stays in the workspace
@@ -148,6 +169,7 @@ class Engine:
                 self._pack(self.model)
             self._stamp = stamp
             self._ws = {k: w for k, w in self._ws.items() if not (isinstance(k, tuple) and k and k[0] == "graph")}
+            self.drop_plans()                        # (launch tables hold the old packed tensors' addresses)
             return True
         return False
 
@@ -161,7 +183,7 @@ class Engine:
             return self.refresh(force=True)          # (a re-assigned parameter: the blocks' copies / aliases are of the old tensor)
         with torch.cuda.device(self.dev), torch.no_grad():
             plan = getattr(self, "_pack_plan", None)
-            if plan is not None and not self.patch and os.environ.get("MSCLIP_REPACK_TABLE", "1") != "0":
+            if plan is not None and not self.patch and self.opt.repack_table:
                 # round 5: every derived conv-side tensor rewritten in place by ONE launch (msclip_pack_weights), the two
                 # projection heads by a transposing copy each; everything else the launches read is a view of the parameters
                 plan.run()
@@ -176,6 +198,7 @@ class Engine:
                 self._pack(self.model, blocks=False)
         self._stamp = self._fingerprint()
         self._ws = {k: w for k, w in self._ws.items() if not (isinstance(k, tuple) and k and k[0] == "graph")}
+        self.drop_plans()
         return True
 
     def state_views(self):
@@ -376,7 +399,10 @@ class Engine:
         dev, D, E = self.dev, self.D, self.E
         bf, f32 = torch.bfloat16, torch.float32
         Mv, Mt = Bi * self.Lv, Bt * self.Lt
-        M = Mv + Mt
+        # buffers hold the text rows rounded up to whole 256-row tiles (the padded total of a packed batch can reach that);
+        # w["M"] / w["Mt"] are what the current call runs over (set per call: _text_sizes / _text_dynamic / _text_unpacked)
+        Mt_cap = -(-Mt // 256) * 256
+        M_rows, M = Mv + Mt_cap, Mv + Mt
 
         def buf(*shape, dtype=bf):
             if len(shape) == 2 and dtype == bf:        # 64 elements of finite slack behind every bf16 matrix
@@ -385,7 +411,8 @@ class Engine:
                 return flat[:n].view(shape)
             return torch.empty(shape, dtype=dtype, device=dev)
 
-        w = dict(Mv=Mv, Mt=Mt, M=M)
+        w = dict(Mv=Mv, Mt=Mt, M=M, Mt_cap=Mt_cap)
+        M = M_rows                                           # (allocation size of everything below)
         w["X"] = buf(M, D, dtype=f32)
         w["LNO"], w["QKV"], w["AO"], w["HID"] = buf(M, D), buf(M, 3 * D), buf(M, D), buf(M, 4 * D)
         # LayerNorm fold (_blocks_fold): per-row centre (the row's mean at the previous LayerNorm point), (rstd, mean * rstd) for
@@ -421,6 +448,11 @@ class Engine:
             w["fv_raw"], w["fv"] = buf(Bi, E, dtype=f32), buf(Bi, E, dtype=f32)
         if Bt:
             w["eot"] = torch.empty(Bt, dtype=torch.int32, device=dev)
+            # device-side row counts of a packed batch (dynamic_rows): lengths, prefix sums and msclip_text_lengths' dims block
+            w["len_d"] = torch.empty(Bt, dtype=torch.int32, device=dev)
+            w["cu_d"] = torch.empty(Bt + 2, dtype=torch.int32, device=dev)
+            w["dims"] = torch.zeros(8, dtype=torch.int32, device=dev)
+            w["dyn"] = False
             w["packed"] = False                             # packed captions: w["cap"] = the staged batch (Captions) of this call
             w["ht"] = buf(Bt, D)
             w["ft_raw"], w["ft"] = buf(Bt, E, dtype=f32), buf(Bt, E, dtype=f32)
@@ -469,17 +501,16 @@ class Engine:
         if convs_done:
             return self._tokenise(w["stem"][-1], w, Bi, taps, keep_pre)
         first = self.stem_specs[0]
-        fused = (self.dual_w.shape[1] == 96 and self._fusable_3x3s2(first) and not (hip.env_flag("MSCLIP_FRONT_UNFUSED") or self.force_unfused)
+        fused = (self.dual_w.shape[1] == 96 and self._fusable_3x3s2(first) and not (self.opt.front_unfused or self.force_unfused)
                  and img.numel() * img.element_size() < 2 ** 31
                  and Bi * self.h1 * self.h1 * (self.D // 16) * 2 < 2 ** 31)      # the kernel's own 32-bit offset limits
         if fused:
             # conv1 + parallel stage 0 + stem stage 0 in one pass: conv1's 48-channel map never reaches HBM
             hip.stem_dual_conv3x3s2(img, self.dual_w, self.dual_b, w["P0"], first.weight, first.bias, w["stem"][0])
-            if os.environ.get("MSCLIP_BRANCH_EARLY", "1") != "0" and not torch.cuda.is_current_stream_capturing():
+            if self.opt.branch_early and self._multi_stream_ok():
                 # the parallel branch reads P0 only: it may start here, beside the rest of the stem, instead of behind the whole
                 # front (same-box alternating, three pairs: 10.349 / 10.361 / 10.364 -> 10.328 / 10.345 / 10.339 ms per C2 step)
-                w["p0_ready"] = torch.cuda.Event()
-                w["p0_ready"].record(torch.cuda.current_stream(self.dev))
+                w["p0_ready"] = self._record(torch.cuda.current_stream(self.dev))
             x, rest = w["stem"][0], list(zip(self.stem_specs, w["stem"]))[1:]
         else:
             hip.stem_conv_dual(img, self.dual_w, self.dual_b, self._s1(w, Bi), w["P0"])
@@ -515,10 +546,10 @@ class Engine:
         t1, t2, tr = w["par_tmp"][j]
         src = w["par"][j - 1]
         lead = ((c1.kh, c1.kw, c1.stride, c1.pad, c1.cin, c1.cout) == (1, 1, 1, 0, 48, 48) and self._fusable_3x3s2(c2)
-                and not (hip.env_flag("MSCLIP_FRONT_UNFUSED") or self.force_unfused) and src.numel() * 2 < 2 ** 31)
+                and not (self.opt.front_unfused or self.force_unfused) and src.numel() * 2 < 2 ** 31)
         if (lead and c2.cout == 48 and (cr.kh, cr.kw, cr.stride, cr.pad, cr.cin, cr.cout) == (1, 1, 2, 0, 48, 96)
                 and (c3.kh, c3.kw, c3.stride, c3.pad, c3.cin, c3.cout) == (1, 1, 1, 0, 48, 96)
-                and (cr.h_out, cr.w_out) == (c2.h_out, c2.w_out) and not hip.env_flag("MSCLIP_BLOCK_UNFUSED")):
+                and (cr.h_out, cr.w_out) == (c2.h_out, c2.w_out) and not self.opt.block_unfused):
             # the whole stride-2 bottleneck in one launch: conv1's map, conv2's output and the shortcut stay on chip
             hip.convresblock48_s2(src, c1.weight, c1.bias, c2.weight, c2.bias, c3.weight, cr.weight, self.par_b3r[j],
                                   w["par"][j], Bi, c1.h_in, c1.w_in)
@@ -564,21 +595,42 @@ class Engine:
             n = Bi * self.g * self.g
             w["Ts"] = [torch.empty(n, self.D, dtype=torch.float32, device=self.dev) for _ in self.adapters]
         cur = torch.cuda.current_stream(self.dev)
-        side = C.side_stream(self.dev)
+        side = self.conv_stream()
         ready = w.pop("p0_ready", None)
         if ready is None:
-            ready = torch.cuda.Event()
-            ready.record(cur)                               # the front pass (parallel stage 0's map) is queued
-        side.wait_event(ready)
+            ready = self._record(cur)                       # the front pass (parallel stage 0's map) is queued
+        self._wait(side, ready)
         events = []
         with torch.cuda.stream(side):
             for j in range(len(self.adapters)):
                 self._parallel_stage(j, w, Bi)
                 self._adapter_top(j, w, Bi, w["Ts"][j])
-                ev = torch.cuda.Event()
-                ev.record(side)
-                events.append(ev)
+                events.append(self._record(side))
         return events
+
+    def conv_stream(self):
+        """The side stream of the image-only conv branch: an ordinary stream, or -- EngineOptions.side_cu_mask > 0 -- one confined
+        to that many CUs (hipExtStreamCreateWithCUMask), so that the branch's HBM-bound workgroups stop displacing the
+        persistent GEMM workgroups of the main stream."""
+        n = self.opt.side_cu_mask
+        if n <= 0:
+            return C.side_stream(self.dev)
+        key = (self.dev, n)
+        if key not in _MASKED:
+            _MASKED[key] = hip.cu_masked_stream(self.dev, n)
+        return _MASKED[key]
+
+    # ---- cross-stream edges: a torch event for the eager pass, and the same edge in the launch plan when one is recording
+    def _record(self, stream):
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        ev._plan_id = self._rec.record_event(stream) if self._rec is not None else -1
+        return ev
+
+    def _wait(self, stream, ev):
+        stream.wait_event(ev)
+        if self._rec is not None:
+            self._rec.wait_event(stream, ev._plan_id)
 
     def lateral_on_last(self):
         return (self.n_layers - 1) in self.lateral
@@ -597,7 +649,25 @@ class Engine:
         data-dependent, which costs ONE small host read per call (the total), taken while the image front is already queued.
         MSCLIP_TEXT_PACK=0: every caption computes all context_length rows (the A/B switch; also what a hipGraph capture
         records, since a capture cannot read the host)."""
-        return (os.environ.get("MSCLIP_TEXT_PACK", "1") != "0" and not torch.cuda.is_current_stream_capturing() and self.Lt <= 96)
+        return self.opt.text_pack and self.Lt <= 96
+
+    def _multi_stream_ok(self):
+        """The eager launch loop uses side streams unless the caller is capturing a hipGraph (a capture of a PLAN replay has them:
+        msclip_plan_run forks and joins its side streams with the plan's own events)."""
+        return not torch.cuda.is_current_stream_capturing()
+
+    def dynamic_rows(self, Bi, Bt):
+        """Packed captions with the row count kept ON THE DEVICE (msclip_text_lengths' dims, msclip_gemm_desc.M_dev): every launch
+        over the text rows is sized for the upper bound -- all context_length rows, rounded up to whole 256-row tiles -- and reads
+        the batch's padded total itself.  No host read, so a call never waits for the GPU, a hipGraph capture records the packed
+        step, and one recorded launch table (msclip_plan_*) serves every batch.  Needs the LayerNorm-fold form of the layer loop
+        (whole tiles that never straddle the image / text boundary); otherwise the round-5 path (host reads the total) runs."""
+        if not (Bt and self.opt.dynamic_rows and self.text_pack_enabled()) or self.fused_qkv_attn_enabled() or self._calib is not None:
+            return False
+        if self.fp8_qkv or not self.opt.ln_fold or self.D % 256:
+            return False
+        cap = -(-(Bt * self.Lt) // 256) * 256
+        return cap >= 256 * 16 and (not Bi or ((Bi * self.Lv) % 256 == 0 and Bi * self.Lv >= 256 * 16))
 
     def stage_captions(self, tok):
         """-> Captions: queue the length / prefix-sum kernels of a token batch and the 8-byte read-back on the CURRENT stream
@@ -610,28 +680,62 @@ class Engine:
             cu = torch.empty(Bt + 2, dtype=torch.int32, device=self.dev)
             eot = torch.empty(Bt, dtype=torch.int32, device=self.dev)
             hip.text_lengths(tok, length, cu, eot, row_base=0)
-            if getattr(self, "_cap_pin", None) is None:
-                self._cap_pin, self._cap_slot = torch.zeros(64, 2, dtype=torch.int32).pin_memory(), 0
-            host = self._cap_pin[self._cap_slot % 64]         # (a ring: a staged batch is consumed long before 64 more are staged)
-            self._cap_slot += 1
+            # pinned read-back slots come from a free list and return to it when their batch's totals have been read (round 5 used
+            # a 64-slot ring without an overwrite guard: a deep prefetch queue could have read another batch's row total)
+            pool = self.__dict__.setdefault("_cap_pool", [])
+            host = pool.pop() if pool else torch.zeros(2, dtype=torch.int32).pin_memory()
             host.copy_(cu[Bt:Bt + 2], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.dev))
-        return Captions(tok, length, cu, eot, host, ev)
+        return Captions(tok, length, cu, eot, host, ev, release=pool.append)
 
     def _text_sizes(self, cap, w, Bt):
         """The host read of a staged batch -> this call's row counts (w["Mt"], w["M"], w["pad"])."""
         total, lmax = cap.totals()
+        # the staged batch's device tensors were allocated on the STAGING stream (an input pipeline's prefetch stream): tell the
+        # caching allocator that the stream consuming them is another one, or a block freed when the next batch replaces this one
+        # could be handed to the next stage_captions while this step's kernels still read it
+        cur = torch.cuda.current_stream(self.dev)
+        for t in (cap.tok, cap.len, cap.cu, cap.eot):
+            t.record_stream(cur)
         padded = -(-total // 256) * 256              # whole 256-row GEMM tiles (the LayerNorm fold's modality split never straddles one)
         if padded > Bt * self.Lt or padded < 256 * 16:
             padded = total
-        w.update(packed=True, cap=cap, cu=cap.cu, len=cap.len, Mt_live=total, Lmax=lmax, pad=padded - total, Mt=padded,
-                 M=w["Mv"] + padded)
+        w.update(packed=True, dyn=False, cap=cap, cu=cap.cu, len=cap.len, Mt_live=total, Lmax=lmax, pad=padded - total, Mt=padded,
+                 M=w["Mv"] + padded, mdev_t=None, mdev_all=None)
 
     def _text_unpacked(self, w, Bt):
-        w.update(packed=False, cap=None, Mt_live=Bt * self.Lt, Lmax=self.Lt, pad=0, Mt=Bt * self.Lt, M=w["Mv"] + Bt * self.Lt)
+        w.update(packed=False, dyn=False, cap=None, Mt_live=Bt * self.Lt, Lmax=self.Lt, pad=0, Mt=Bt * self.Lt,
+                 M=w["Mv"] + Bt * self.Lt, mdev_t=None, mdev_all=None)
+
+    def _text_dynamic(self, w, Bt, lmax=None):
+        """Packed captions whose row count stays on the device (dynamic_rows): the call runs over the upper bound w["Mt_cap"] and
+        every launch over the text rows gets a device counter (mdev_t: padded text rows, mdev_all: rows of the whole matrix) or
+        the dims block.  The lengths themselves are computed by _text_front, as the first launches of the text front.  lmax: the
+        longest caption if the host happens to know it (a batch staged ahead whose read-back has landed): picks the attention
+        kernel's tile count; None = context_length."""
+        cap = w["Mt_cap"]
+        w.update(packed=True, dyn=True, cap=None, cu=w["cu_d"], len=w["len_d"], Mt_live=None, Lmax=lmax or self.Lt, pad=255, Mt=cap,
+                 M=w["Mv"] + cap, mdev_t=w["dims"][2:3], mdev_all=w["dims"][3:4])
+
+    @staticmethod
+    def _md(w, r0, r1):
+        """The device-side row counter of a launch over rows [r0, r1) of the token matrix (None: the rows are a host-side constant)."""
+        if not w.get("dyn") or r1 != w["M"]:
+            return None
+        return w["mdev_all"] if r0 == 0 else w["mdev_t"]
+
+    def _live_text_rows(self, w):
+        """Live text rows of this call on the HOST (taps / calibration / accounting only: a dynamic-rows call reads it back)."""
+        if w.get("Mt_live") is None:
+            w["Mt_live"] = int(w["dims"][0].item())
+        return w["Mt_live"]
 
     def _text_front(self, tok, w, Bt):
+        if w.get("dyn"):
+            # lengths, prefix sums, EOT rows (absolute: row_base = Mv) and the dims block, then the embedding of the live rows
+            hip.text_lengths(tok, w["len_d"], w["cu_d"], w["eot"], row_base=w["Mv"], dims=w["dims"], pad_to=256, cap_rows=w["Mt_cap"])
+            return hip.embed_tokens_packed(tok, self.emb, self.tpos, w["X"], w["cu"], w["Mv"], w["Mt"], rows_dev=w["mdev_t"])
         if w.get("packed"):
             torch.add(w["cap"].eot, w["Mv"], out=w["eot"])           # EOT rows of the packed segment -> rows of the token matrix
             return hip.embed_tokens_packed(tok, self.emb, self.tpos, w["X"], w["cu"], w["Mv"], w["Mt"])
@@ -640,7 +744,8 @@ class Engine:
     def _attention_text(self, w, QKV, AO, Bt):
         Mv, M = w["Mv"], w["M"]
         if w.get("packed"):
-            return hip.attention_varlen(QKV[Mv:M], AO[Mv:M], w["cu"], Bt, w["Lmax"], self.heads, True, pad_rows=w["pad"])
+            return hip.attention_varlen(QKV[Mv:M], AO[Mv:M], w["cu"], Bt, w["Lmax"], self.heads, True, pad_rows=w["pad"],
+                                        dims=w["dims"] if w.get("dyn") else None)
         hip.attention(QKV[Mv:M], AO[Mv:M], Bt, self.Lt, self.heads, True)
 
     def _tap_text(self, taps, name, t, w, Bt):
@@ -654,7 +759,7 @@ class Engine:
         cu = w["cu"][:Bt].long()
         pos = torch.arange(self.Lt, device=self.dev)[None, :]
         live = pos < lens[:, None]
-        rows = (cu[:, None] + pos).clamp_(max=w["Mt_live"] - 1)
+        rows = (cu[:, None] + pos).clamp_(max=self._live_text_rows(w) - 1)
         out = t[:w["Mt"]].float()[rows.reshape(-1)].view(Bt, self.Lt, -1)
         taps[name] = out * live[:, :, None]
         taps["text_lengths"] = w["len"].clone()
@@ -666,7 +771,7 @@ class Engine:
         D, Mv = self.D, w["Mv"]
         LNO, QKV, LNC, QC, AOC = w["LNO"], w["QKV"], w["LNC"], w["QC"], w["AOC"]
         for r0, r1, bw in groups:
-            hip.gemm(LNO[r0:r1], bw.wqkv[D:], QKV[r0:r1, D:], bias=bw.bqkv[D:])
+            hip.gemm(LNO[r0:r1], bw.wqkv[D:], QKV[r0:r1, D:], bias=bw.bqkv[D:], mdev=self._md(w, r0, r1))
         if Bi:
             hip.gather_rows(LNO, LNC[:Bi], Bi, row_mul=self.Lv)
         if Bt:
@@ -720,17 +825,21 @@ class Engine:
         calibrate_fp8() (explicit; both modalities of a shared layer, all ranks): an uncalibrated layer, and row counts that are
         not whole 256-row tiles, keep a bf16 hidden matrix and a bf16 c_proj."""
         X, HID, LNQ, RS = w["X"], w["HID"], w["LNQ"], w["RS"]
+        md = self._md(w, r0, r1)
         if bw.hid_scale is None or (r1 - r0) % 256:
-            hip.gemm_f8(LNQ[r0:r1], bw.wfc_q, HID[r0:r1], RS[r0:r1], bw.wfc_s, bias=bw.bfc, act=hip.ACT_QUICKGELU)
+            hip.gemm_f8(LNQ[r0:r1], bw.wfc_q, HID[r0:r1], RS[r0:r1], bw.wfc_s, bias=bw.bfc, act=hip.ACT_QUICKGELU, mdev=md)
             if self._calib is not None:                    # calibrate_fp8(): max |hidden| of this launch, kept on the device
-                self._calib.setdefault(id(bw), (bw, []))[1].append(HID[r0:r1].abs().amax())
-            hip.gemm(HID[r0:r1], bw.wpr, X[r0:r1], bias=bw.bpr, resid=X[r0:r1], resid_kind=hip.RESID_F32)
+                # ... over the rows that hold real tokens: the tile padding behind the last caption (zero embeddings run through
+                # the blocks) must not set a scale
+                live = min(r1, w["Mv"] + self._live_text_rows(w)) if (w.get("packed") and r1 > w["Mv"]) else r1
+                self._calib.setdefault(id(bw), (bw, []))[1].append(HID[r0:live].abs().amax())
+            hip.gemm(HID[r0:r1], bw.wpr, X[r0:r1], bias=bw.bpr, resid=X[r0:r1], resid_kind=hip.RESID_F32, mdev=md)
             return
         HQ = w["HIDQ"]
         hip.gemm_f8(LNQ[r0:r1], bw.wfc_q, HQ[r0:r1], RS[r0:r1], bw.wfc_s, bias=bw.bfc, act=hip.ACT_QUICKGELU,
-                    out_scale=1.0 / bw.hid_scale)
+                    out_scale=1.0 / bw.hid_scale, mdev=md)
         hip.gemm_f8(HQ[r0:r1], bw.wpr_q, X[r0:r1], w["ONES"][r0:r1], bw.wpr_cs, bias=bw.bpr, resid=X[r0:r1], resid_kind=hip.RESID_F32,
-                    fold_out=fold_out)
+                    fold_out=fold_out, mdev=md)
 
     # ------------------------------------------------------------------ fp8 calibration (PRECISION fp8 / fp8-qkv)
     HID_HEADROOM = 1.25                                   # static hidden scale = HID_HEADROOM * calibrated max |hidden| / 448
@@ -809,17 +918,19 @@ class Engine:
         X = w["X"]
         if len(segs) == 2:
             (r0, rs, vb), (_, r1, tb) = segs
-            hip.layernorm_f8(X[r0:r1], vb[which].g, vb[which].b, tb[which].g, tb[which].b, rs - r0, w["LNQ"][r0:r1], w["RS"][r0:r1], r1 - r0)
+            hip.layernorm_f8(X[r0:r1], vb[which].g, vb[which].b, tb[which].g, tb[which].b, rs - r0, w["LNQ"][r0:r1], w["RS"][r0:r1], r1 - r0,
+                             mdev=self._md(w, r0, r1))
         else:
             for r0, r1, b in segs:
-                hip.layernorm_f8(X[r0:r1], b[which].g, b[which].b, b[which].g, b[which].b, r1 - r0, w["LNQ"][r0:r1], w["RS"][r0:r1], r1 - r0)
+                hip.layernorm_f8(X[r0:r1], b[which].g, b[which].b, b[which].g, b[which].b, r1 - r0, w["LNQ"][r0:r1], w["RS"][r0:r1], r1 - r0,
+                                 mdev=self._md(w, r0, r1))
 
     # ------------------------------------------------------------------ LayerNorm fold
     def _fold_eligible(self, w, Bi, Bt):
         """The fold runs on whole 256-row tiles of the ping-pong GEMM that never straddle the image / text boundary."""
         # PRECISION fp8 (c_fc / c_proj on the fp8 MFMA): ln_1 still folds -- in_proj is a bf16 consumer, the fp8 c_proj produces;
         # ln_2 feeds an e4m3 operand with per-token scales (a row maximum: needs the whole row) and keeps its pass.  fp8-qkv: no fold.
-        if self.fp8_qkv or os.environ.get("MSCLIP_LN_FOLD", "1") == "0" or self.D % 256:
+        if self.fp8_qkv or not self.opt.ln_fold or self.D % 256:
             return False
         rows = [n for n in ((w["Mv"] if Bi else 0), (w["M"] - w["Mv"] if Bt else 0)) if n]
         return bool(rows) and all(n % 256 == 0 and n >= 256 * 16 for n in rows)
@@ -843,7 +954,7 @@ class Engine:
         (msclip_qkv_attention: q|k|v staged in LDS, never in HBM) -- what BASELINE.json's north_star names.  Off by default:
         its two-buffer 256 x 192 main loop is slower than the ping-pong GEMM by more than the attention launches cost
         (228 vs 204 us per layer at the packed C2 shapes)."""
-        return hip.env_flag("MSCLIP_FUSED_QKV_ATTN") and self.heads * 64 == self.D and self.Lv <= 96 and self.Lt <= 96
+        return self.opt.fused_qkv_attn and self.heads * 64 == self.D and self.Lv <= 96 and self.Lt <= 96
 
     def _fused_tables(self, w, Bi, Bt):
         """Row / tile tables of this call's token matrix: image samples of Lv rows, then the captions (packed: cu of the staged
@@ -907,16 +1018,17 @@ class Engine:
                 self._foldw["zcs"] = torch.zeros(4 * self.D, dtype=torch.float32, device=self.dev)
             return W, self._foldw["zcs"], b
         LNO, RST = w["LNO"], w["RST"]
+        md = self._md(w, r0, r1)
         if not any(m[3] for m in modes):
             W, _, b = seg_weights(modes[0][0], False)
-            return hip.gemm(LNO[r0:r1], W, out[r0:r1], bias=b, act=act)
+            return hip.gemm(LNO[r0:r1], W, out[r0:r1], bias=b, act=act, mdev=md)
         W1, c1, b1 = seg_weights(modes[0][0], modes[0][3])
         if len(modes) == 1:
             fi = hip.FoldIn(RST[r0:r1], c1)
         else:
             W2, c2, b2 = seg_weights(modes[1][0], modes[1][3])
             fi = hip.FoldIn(RST[r0:r1], c1, W2, b2, c2, modes[1][1] - r0)
-        return hip.gemm(LNO[r0:r1], W1, out[r0:r1], bias=b1, act=act, fold_in=fi)
+        return hip.gemm(LNO[r0:r1], W1, out[r0:r1], bias=b1, act=act, fold_in=fi, mdev=md)
 
     def _blocks_fold(self, w, Bi, Bt, taps, conv_events, compact, layers):
         """The layer loop with the LayerNorms folded into the GEMMs around them (DESIGN.md "LayerNorm fold"): out_proj and c_proj
@@ -944,10 +1056,10 @@ class Engine:
                 if tower == "v" and i in self.lateral:
                     j = self.lateral.index(i)
                     # the adapter applies ln_1 itself (rows in registers) unless this block's out_proj is not the producing kernel
-                    xa_stream = not last_live and not self.fp8 and not hip.env_flag("MSCLIP_ADAPTER_LN1_PASS")
+                    xa_stream = not last_live and not self.fp8 and not self.opt.adapter_ln1_pass
                     ln1 = b["ln1"] if xa_stream else None
                     if conv_events is not None:
-                        torch.cuda.current_stream(self.dev).wait_event(conv_events[j])
+                        self._wait(torch.cuda.current_stream(self.dev), conv_events[j])
                         self._adapter(j, w, Bi, t=w["Ts"][j], ln1=ln1)
                     else:
                         self._parallel_stage(j, w, Bi)
@@ -964,12 +1076,13 @@ class Engine:
                 elif pend[tower]:
                     modes.append((tower, r0, r1, True))
                 else:
-                    hip.layernorm_stats(src, b["ln1"].g, b["ln1"].b, LNO[r0:r1], r1 - r0, CEN[r0:r1], RST[r0:r1], raw_out=raw)
+                    hip.layernorm_stats(src, b["ln1"].g, b["ln1"].b, LNO[r0:r1], r1 - r0, CEN[r0:r1], RST[r0:r1], raw_out=raw,
+                                        mdev=self._md(w, r0, r1))
                     modes.append((tower, r0, r1, False))
                 pend[tower] = False
             shared = len(segs) == 2 and vb["w"] is tb["w"]
             groups = [(segs[0][1], segs[-1][2], modes)] if shared else [(m[1], m[2], [m]) for m in modes]
-            if last_live and not hip.env_flag("MSCLIP_LAST_BLOCK_ALL_QUERIES"):
+            if last_live and not self.opt.last_block_all_queries:
                 assert not any(m[3] for m in modes)       # (the block before the last one does not produce: see below)
                 cg = [(r0, r1, (self.vblk if ms[0][0] == "v" else self.tblk)[i]["w"]) for r0, r1, ms in groups]
                 self._last_block_attention(w, Bi, Bt, cg)
@@ -990,19 +1103,20 @@ class Engine:
             # --- out_proj produces ln_2's operands; c_fc consumes them; c_proj produces the next block's ln_1 operands unless
             #     that block takes a LayerNorm pass anyway (the compact last block; image rows in front of a lateral adapter
             #     are produced too -- one launch over both towers -- and overwritten by the adapter's pass)
-            nxt_fold = i + 1 <= n_last and not (i + 1 == n_last and compact and not hip.env_flag("MSCLIP_LAST_BLOCK_ALL_QUERIES"))
+            nxt_fold = i + 1 <= n_last and not (i + 1 == n_last and compact and not self.opt.last_block_all_queries)
             for r0, r1, ms in groups:
                 bw = (self.vblk if ms[0][0] == "v" else self.tblk)[i]["w"]
+                md = self._md(w, r0, r1)
                 if self.fp8:
                     # out_proj plain (bf16), ln_2 as the e4m3 LayerNorm pass, MLP on the fp8 MFMA; a calibrated c_proj over whole
                     # tiles produces the next block's ln_1 operands like the bf16 one
-                    hip.gemm(AO[r0:r1], bw.wo, X[r0:r1], bias=bw.bo, resid=X[r0:r1], resid_kind=hip.RESID_F32)
+                    hip.gemm(AO[r0:r1], bw.wo, X[r0:r1], bias=bw.bo, resid=X[r0:r1], resid_kind=hip.RESID_F32, mdev=md)
                     segs2 = [(m[1], m[2], (self.vblk if m[0] == "v" else self.tblk)[i]) for m in ms]
                     self._ln_f8(w, segs2, "ln2")
                     prod = nxt_fold and bw.hid_scale is not None and self._calib is None
                     self._mlp_f8(w, r0, r1, bw, fold_out=hip.FoldOut(LNO[r0:r1], CEN[r0:r1], PART[r0:r1]) if prod else None)
                     if prod:
-                        hip.rowstat_finalize(PART[r0:r1], CEN[r0:r1], RST[r0:r1], r1 - r0, D)
+                        hip.rowstat_finalize(PART[r0:r1], CEN[r0:r1], RST[r0:r1], r1 - r0, D, mdev=md)
                         for m in ms:
                             pend[m[0]] = True
                     continue
@@ -1012,17 +1126,17 @@ class Engine:
                     res = w["XA"]
                     if r1 > Mv:
                         fo = hip.FoldOut(LNO[r0:r1], CEN[r0:r1], PART[r0:r1], resid2=X[r0:r1], split=Mv)
-                hip.gemm(AO[r0:r1], bw.wo, X[r0:r1], bias=bw.bo, resid=res, resid_kind=hip.RESID_F32, fold_out=fo)
-                hip.rowstat_finalize(PART[r0:r1], CEN[r0:r1], RST[r0:r1], r1 - r0, D)
+                hip.gemm(AO[r0:r1], bw.wo, X[r0:r1], bias=bw.bo, resid=res, resid_kind=hip.RESID_F32, fold_out=fo, mdev=md)
+                hip.rowstat_finalize(PART[r0:r1], CEN[r0:r1], RST[r0:r1], r1 - r0, D, mdev=md)
                 self._fold_proj(w, i, "fc", r0, r1, [(m[0], m[1], m[2], True) for m in ms], HID, hip.ACT_QUICKGELU)
                 if nxt_fold:
                     hip.gemm(HID[r0:r1], bw.wpr, X[r0:r1], bias=bw.bpr, resid=X[r0:r1], resid_kind=hip.RESID_F32,
-                             fold_out=hip.FoldOut(LNO[r0:r1], CEN[r0:r1], PART[r0:r1]))
-                    hip.rowstat_finalize(PART[r0:r1], CEN[r0:r1], RST[r0:r1], r1 - r0, D)
+                             fold_out=hip.FoldOut(LNO[r0:r1], CEN[r0:r1], PART[r0:r1]), mdev=md)
+                    hip.rowstat_finalize(PART[r0:r1], CEN[r0:r1], RST[r0:r1], r1 - r0, D, mdev=md)
                     for m in ms:
                         pend[m[0]] = True
                 else:
-                    hip.gemm(HID[r0:r1], bw.wpr, X[r0:r1], bias=bw.bpr, resid=X[r0:r1], resid_kind=hip.RESID_F32)
+                    hip.gemm(HID[r0:r1], bw.wpr, X[r0:r1], bias=bw.bpr, resid=X[r0:r1], resid_kind=hip.RESID_F32, mdev=md)
             if taps is not None:
                 if vb is not None:
                     self._tap_tokens(taps, f"vblock{i}", X[:Mv], Bi, self.Lv)
@@ -1050,7 +1164,7 @@ class Engine:
             if vb is not None and i in self.lateral:
                 j = self.lateral.index(i)
                 if conv_events is not None:
-                    torch.cuda.current_stream(self.dev).wait_event(conv_events[j])
+                    self._wait(torch.cuda.current_stream(self.dev), conv_events[j])
                     self._adapter(j, w, Bi, t=w["Ts"][j])
                 else:
                     self._parallel_stage(j, w, Bi)
@@ -1080,7 +1194,7 @@ class Engine:
             groups = [(segs[0][0], segs[-1][1], segs[0][2]["w"])] if len(segs) == 2 and vb["w"] is tb["w"] else \
                      [(r0, r1, b["w"]) for r0, r1, b in segs]
             last_live = i == self.n_layers - 1 and compact
-            if last_live and not f8_qkv and not hip.env_flag("MSCLIP_LAST_BLOCK_ALL_QUERIES"):
+            if last_live and not f8_qkv and not self.opt.last_block_all_queries:
                 self._last_block_attention(w, Bi, Bt, groups)
                 self._last_block_tail(w, Bi, Bt, vb, tb, attended=True)
                 continue
@@ -1150,11 +1264,35 @@ class Engine:
             buf = w[key] = torch.empty(shape, dtype=local.dtype, device=local.device)
         return buf
 
+    def _native_collectives(self):
+        return self.opt.native_collectives and C.native_comm() is not None and (C.comm.collectives or C.native_world() > 1)
+
+    @staticmethod
+    def _native_buf(w, key, local, world):
+        shape = (world * local.shape[0], local.shape[1])
+        buf = w.get(key)
+        if buf is None or tuple(buf.shape) != shape:
+            buf = w[key] = torch.empty(shape, dtype=local.dtype, device=local.device)
+        return buf
+
     def _heads(self, w, Bi, Bt, norm=True, gather=False, compact=False):
         """Projection heads.  With gather=True the image features' all-gather is started as soon as they exist and
         runs on RCCL's stream while the text head computes (returns the gathered operands and the work handles)."""
         allI = allT = wi = wt = None
-        if gather and Bi and Bi == Bt and norm and hip.env_flag("MSCLIP_GATHER_PACKED"):
+        if gather and self._native_collectives():
+            # RCCL through the C ABI on the compute stream (comm.init_native_comm): the two gathers are ordinary stream-ordered
+            # launches -- entries of the launch plan, capturable -- instead of ProcessGroupNCCL work items on a side stream
+            nc, world = C.native_comm(), C.native_world()
+            if Bi:
+                self._head_image(w, Bi, norm, compact)
+                allI = self._native_buf(w, "allI_nat", w["fvb"], world)
+                hip.allgather_feats(nc, w["fvb"], allI)
+            if Bt:
+                self._head_text(w, Bt, norm, compact, Bi)
+                allT = self._native_buf(w, "allT_nat", w["ftb"], world)
+                hip.allgather_feats(nc, w["ftb"], allT)
+            return allI, allT
+        if gather and Bi and Bi == Bt and norm and self.opt.gather_packed:
             # SURVEY s8(e)'s form: ONE all-gather of the packed [B, 2, E] unit features after both heads (half the collectives,
             # twice the payload; it cannot start before the text head).  The default below starts the image gather under the
             # text head instead.  Behind a flag so that the first run on a real node can A/B the two (DESIGN.md s6).
@@ -1201,17 +1339,25 @@ class Engine:
             raise ValueError(f"expected tokens [B, {self.Lt}], got {tuple(tok.shape)}")
         return tok.to(torch.int64).contiguous()
 
+    # per-call state a pass leaves in the workspace (restored before a plan replay: another kind of call may have run in between)
+    _CALL_STATE = ("packed", "dyn", "cap", "cu", "len", "Mt_live", "Lmax", "pad", "Mt", "M", "mdev_t", "mdev_all")
+
     @hip.off_default_stream
     def run(self, img=None, tok=None, norm=True, gather=False, taps=None):
         """Both towers (either may be None) up to the (optionally L2-normalised) features; returns the workspace
         (plus the gathered bf16 features under "allI"/"allT" when gather=True).  `taps` (a dict) receives fp32 copies
-        of the intermediate tensors the reference exposes through forward hooks (tests/golden tap_* names)."""
+        of the intermediate tensors the reference exposes through forward hooks (tests/golden tap_* names).
+
+        The launches of a call depend only on (batch sizes, options, text mode) once the packed row count lives on the device
+        (dynamic_rows), so the first call of a kind records them into a native launch table (hip.Plan / msclip_plan_*) while it
+        runs, and every later call of that kind replays the table: no per-launch Python, ~2 us of host time per launch."""
         with torch.cuda.device(self.dev):
-            if not torch.cuda.is_current_stream_capturing():
+            capturing = torch.cuda.is_current_stream_capturing()
+            if not capturing:
                 self.refresh()
             Bi = img.shape[0] if img is not None else 0
             Bt = tok.shape[0] if tok is not None else 0            # (a tensor or a staged Captions batch)
-            if self.fp8 and self._calib is None and not self.fp8_calibrated() and not torch.cuda.is_current_stream_capturing():
+            if self.fp8 and self._calib is None and not self.fp8_calibrated() and not capturing:
                 if Bi and Bt:
                     self.calibrate_fp8(img, tok)          # first two-modality batch = the calibration batch (explicit call: calibrate_fp8)
                 elif not self._fp8_warned:
@@ -1220,71 +1366,124 @@ class Engine:
                     warnings.warn("PRECISION fp8: the MLP hidden scales are not calibrated yet (engine.calibrate_fp8(images, captions)); "
                                   "single-modality calls run c_proj in bf16 until then")
             w = self._workspace(Bi, Bt, inference=True)
-            w["fold_pending"] = {"v": False, "t": False}
-            w["fused_tabs"] = None
-            conv_events = None
-            side_ok = (taps is None and os.environ.get("MSCLIP_CONV_SIDE_STREAM", "1") != "0"
-                       and not torch.cuda.is_current_stream_capturing())
-            text0 = ts = cap = tokc = None
+            imgc = self._check_img(img) if Bi else None
+            cap = tokc = None
             pack = bool(Bt) and self.text_pack_enabled()
+            dyn = pack and self.dynamic_rows(Bi, Bt)      # the packed row count stays on the device: nothing below reads the host
+            if pack and not dyn and capturing:
+                pack = False                                # (the host-read form of packing cannot be captured: full rows)
             if Bt:
                 if isinstance(tok, Captions):
                     cap, tokc = (tok if pack else None), tok.tok
                 else:
                     tokc = self._check_tok(tok)
-                if not pack:
-                    self._text_unpacked(w, Bt)
-            if Bi and Bt and side_ok and self.vblk[0] is None and os.environ.get("MSCLIP_TEXT0_STREAM", "1") != "0":
-                # Text block 0 is text-only (vision slot 0 is the conv stem, M.py:2040-2051) and depends on the captions only:
-                # the text front and that block run on a second side stream beside the image front (HBM-bound conv passes
-                # beside MFMA-bound projections on disjoint rows / buffers of the workspace); the layer loop waits for it.
-                cur = torch.cuda.current_stream(self.dev)
-                ts = _text0_stream(self.dev)
-                start = torch.cuda.Event()
-                start.record(cur)                               # the workspace is free: the previous step's work is queued
-                ts.wait_event(start)
-                tokc.record_stream(ts)
-            if pack:
-                # packed captions: the total live row count is needed on the HOST (it sizes every launch over the text rows).
-                # A batch staged ahead (stage_captions: an input pipeline's prefetch stage) has it ready; otherwise it is staged
-                # here and the host waits for its 8 bytes -- i.e. until the previous step's queued work has drained -- BEFORE
-                # anything of this call is queued, so that the text front + block 0 still start beside the image front (queued
-                # behind the image front they ran after it: the main queue idled 1.2 ms per step waiting for them).
-                if cap is None:
-                    with torch.cuda.stream(ts if ts is not None else torch.cuda.current_stream(self.dev)):
-                        cap = self.stage_captions(tokc)
-                self._text_sizes(cap, w, Bt)
-                if ts is not None:                              # (staged on one of the two streams, read on both)
-                    for t in (cap.len, cap.cu, cap.eot):
-                        t.record_stream(ts)
-                        t.record_stream(torch.cuda.current_stream(self.dev))
+            lmax = cap.totals()[1] if (dyn and cap is not None and cap.ready()) else None
+            mode = "dyn" if dyn else "pack" if pack else "full"
+            key = self._plan_key(Bi, Bt, imgc, mode, lmax, norm, gather, taps)
+            self.last_plan = None                           # (the launch table this call ran from, if it did: bench.py's probes)
+            if key is not None:
+                plan = w.setdefault("plans", {}).get(key)
+                streams = [torch.cuda.current_stream(self.dev), self.conv_stream(), _text0_stream(self.dev)]
+                ext = [t for t in (imgc, tokc) if t is not None]
+                if plan is not None:
+                    self.last_plan = plan
+                    w.update(plan.state)
+                    if tokc is not None:
+                        tokc.record_stream(streams[2])          # (the text front may read it there)
+                    plan.run(streams, ext)
+                    return w
+                if not capturing:
+                    plan = hip.Plan(self.dev, streams)
+                    self._rec = plan
+                    try:
+                        with plan.recording(externals=ext):
+                            self._run_body(w, imgc, tokc, cap, Bi, Bt, mode, lmax, norm, gather, taps)
+                    finally:
+                        self._rec = None
+                    plan.state = {k: w.get(k) for k in self._CALL_STATE}
+                    w["plans"][key] = plan
+                    self.last_plan = plan
+                    return w
+            return self._run_body(w, imgc, tokc, cap, Bi, Bt, mode, lmax, norm, gather, taps)
 
-            if ts is not None:
-                with torch.cuda.stream(ts):
-                    self._text_front(tokc, w, Bt)
-                    self._blocks(w, 0, Bt, layers=(0,))
-                    text0 = torch.cuda.Event()
-                    text0.record(ts)
-            if Bi:
-                self._vision_front(self._check_img(img), w, Bi, taps)
-                # default (MSCLIP_CONV_SIDE_STREAM=0 turns it off): +1.6 % pairs/s on B/32, +2.2 % on B/16 same-box.  The GEMM
-                # launches it overlaps measure ~11 % longer each, so bench.py takes its per-kernel roofline from a probe
-                # pass with the inline schedule and reports the overlapped figure beside it.
-                if side_ok and self.lateral and self.lateral == sorted(self.lateral) and os.environ.get("MSCLIP_BRANCH_STREAM", "1") != "0":
-                    conv_events = self._conv_branch_on_side_stream(w, Bi)
-            if Bt and text0 is None:
+    def _plan_key(self, Bi, Bt, imgc, mode, lmax, norm, gather, taps):
+        """What a recorded launch table is valid for, or None when this call cannot be replayed from one: taps (host-side copies),
+        an fp8 calibration pass, packed captions sized by a host read, Python-side launch probes, collectives through
+        torch.distributed (unless EngineOptions.native_collectives routes them through the C ABI), the opt-in fused kernel's
+        per-call tables."""
+        if not self.opt.plan or taps is not None or self._calib is not None or (Bt and mode == "pack"):
+            return None
+        if hip.python_probes_active() or self.fused_qkv_attn_enabled():
+            return None
+        if gather and C.comm.collectives and not self._native_collectives():
+            return None
+        nt = 0 if lmax is None else 1 if lmax <= 32 else 2 if lmax <= 64 else 3
+        return (mode, nt, bool(norm), bool(gather), imgc.dtype if imgc is not None else None, self.opt)
+
+    def drop_plans(self):
+        """Forget every recorded launch table (they hold raw addresses of packed weights and workspace buffers)."""
+        for w in self._ws.values():
+            if isinstance(w, dict):
+                w.pop("plans", None)
+
+    def _run_body(self, w, imgc, tokc, cap, Bi, Bt, mode, lmax, norm, gather, taps):
+        w["fold_pending"] = {"v": False, "t": False}
+        w["fused_tabs"] = None
+        conv_events = None
+        side_ok = taps is None and self.opt.conv_side_stream and self._multi_stream_ok()
+        text0 = ts = None
+        if Bt and mode == "full":
+            self._text_unpacked(w, Bt)
+        if Bi and Bt and side_ok and self.vblk[0] is None and self.opt.text0_stream:
+            # Text block 0 is text-only (vision slot 0 is the conv stem, M.py:2040-2051) and depends on the captions only:
+            # the text front and that block run on a second side stream beside the image front (HBM-bound conv passes
+            # beside MFMA-bound projections on disjoint rows / buffers of the workspace); the layer loop waits for it.
+            cur = torch.cuda.current_stream(self.dev)
+            ts = _text0_stream(self.dev)
+            self._wait(ts, self._record(cur))               # the workspace is free: the previous step's work is queued
+            tokc.record_stream(ts)
+        if mode == "dyn":
+            self._text_dynamic(w, Bt, lmax)
+        elif mode == "pack":
+            # packed captions sized by the host (the round-5 path; small batches and dynamic_rows=False): the total live row count
+            # sizes every launch over the text rows.  A batch staged ahead (stage_captions: an input pipeline's prefetch stage)
+            # has it ready; otherwise it is staged here and the host waits for its 8 bytes -- i.e. until the previous step's
+            # queued work has drained -- BEFORE anything of this call is queued, so that the text front + block 0 still start
+            # beside the image front.
+            if cap is None:
+                with torch.cuda.stream(ts if ts is not None else torch.cuda.current_stream(self.dev)):
+                    cap = self.stage_captions(tokc)
+            self._text_sizes(cap, w, Bt)
+            if ts is not None:                              # (staged on one of the two streams, read on both)
+                for t in (cap.len, cap.cu, cap.eot):
+                    t.record_stream(ts)
+                    t.record_stream(torch.cuda.current_stream(self.dev))
+
+        if ts is not None:
+            with torch.cuda.stream(ts):
                 self._text_front(tokc, w, Bt)
-            # the last block's row-wise tail on the live rows only (MSCLIP_FULL_LAST_BLOCK=1: every row, as the taps need it)
-            compact = taps is None and not hip.env_flag("MSCLIP_FULL_LAST_BLOCK") and not self.lateral_on_last()
-            if text0 is not None:
-                torch.cuda.current_stream(self.dev).wait_event(text0)
-                self._blocks(w, Bi, Bt, taps, conv_events, compact, layers=range(1, self.n_layers))
-            else:
-                self._blocks(w, Bi, Bt, taps, conv_events, compact)
-            allI, allT = self._heads(w, Bi, Bt, norm, gather, compact)
-            if gather:
-                w["allI"], w["allT"] = allI, allT
-            return w
+                self._blocks(w, 0, Bt, layers=(0,))
+                text0 = self._record(ts)
+        if Bi:
+            self._vision_front(imgc, w, Bi, taps)
+            # default (EngineOptions.conv_side_stream): +1.6 % pairs/s on B/32, +2.2 % on B/16 same-box.  The GEMM
+            # launches it overlaps measure ~11 % longer each, so bench.py takes its per-kernel roofline from a probe
+            # pass with the inline schedule and reports the overlapped figure beside it.
+            if side_ok and self.lateral and self.lateral == sorted(self.lateral):
+                conv_events = self._conv_branch_on_side_stream(w, Bi)
+        if Bt and text0 is None:
+            self._text_front(tokc, w, Bt)
+        # the last block's row-wise tail on the live rows only (EngineOptions.full_last_block: every row, as the taps need it)
+        compact = taps is None and not self.opt.full_last_block and not self.lateral_on_last()
+        if text0 is not None:
+            self._wait(torch.cuda.current_stream(self.dev), text0)
+            self._blocks(w, Bi, Bt, taps, conv_events, compact, layers=range(1, self.n_layers))
+        else:
+            self._blocks(w, Bi, Bt, taps, conv_events, compact)
+        allI, allT = self._heads(w, Bi, Bt, norm, gather, compact)
+        if gather:
+            w["allI"], w["allT"] = allI, allT
+        return w
 
     # ------------------------------------------------------------------ hipGraph replay
     def graph(self, Bi=0, Bt=0, img_dtype=torch.float32):
@@ -1366,7 +1565,10 @@ class Engine:
         world = n // B
         loss = self.loss_from_features(w["fvb"], w["ftb"], allI, allT, C.local_label_offset(B) if world > 1 else 0)
         if world > 1 or (gather and C.comm.collectives):
-            dist.all_reduce(loss)
+            if self._native_collectives():
+                hip.allreduce(C.native_comm(), loss)
+            else:
+                dist.all_reduce(loss)
         return loss[0]
 
     def loss_from_features(self, loc_i, loc_t, all_i, all_t, label_off):

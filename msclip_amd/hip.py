@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MSCLIP_HIP_LIB") or os.path.join(_HERE, "csrc", "libmsclip_hip.so")   # override: kernel A/B probes only
 INT_MAX = 2 ** 31 - 1
-ABI_VERSION = 6                                          # include/msclip_hip.h MSCLIP_ABI_VERSION
+ABI_VERSION = 7                                          # include/msclip_hip.h MSCLIP_ABI_VERSION
 
 EXPORTS = (
     "msclip_gemm", "msclip_gemm_f8", "msclip_layernorm_stats", "msclip_rowstat_finalize", "msclip_layernorm_f8", "msclip_quant_f8_rows", "msclip_gemm_variant", "msclip_attention", "msclip_attention_lastq", "msclip_layernorm", "msclip_layernorm_split", "msclip_embed_tokens", "msclip_fill_cls",
@@ -30,7 +30,12 @@ EXPORTS = (
     "msclip_attention_bwd_varlen", "msclip_embed_tokens_bwd_packed",
     "msclip_qkv_attention", "msclip_qkvattn_tables", "msclip_pack_weights", "msclip_transpose_bf16_multi", "msclip_image_conv_wgrad", "msclip_colsum_multi",
     "msclip_abi_version", "msclip_build_arch",
-    "msclip_stream_priority_range", "msclip_stream_create", "msclip_stream_destroy",
+    "msclip_stream_priority_range", "msclip_stream_create", "msclip_stream_destroy", "msclip_stream_create_cu_masked",
+    "msclip_plan_create", "msclip_plan_destroy", "msclip_plan_begin", "msclip_plan_bind_external", "msclip_plan_record_event",
+    "msclip_plan_wait_event", "msclip_plan_end", "msclip_plan_abort", "msclip_plan_info", "msclip_plan_op_name", "msclip_plan_run",
+    "msclip_plan_size", "msclip_plan_probe_enable", "msclip_plan_probe_disable", "msclip_plan_probe_runs", "msclip_plan_probe_elapsed",
+    "msclip_comm_unique_id", "msclip_comm_init", "msclip_comm_destroy", "msclip_comm_async_error", "msclip_allgather_feats",
+    "msclip_allreduce",
 )
 
 
@@ -60,6 +65,7 @@ class GemmDesc(ctypes.Structure):
         ("W2", ctypes.c_void_p), ("bias2", ctypes.c_void_p), ("csum", ctypes.c_void_p), ("csum2", ctypes.c_void_p),
         ("rowstat", ctypes.c_void_p), ("seg_split", ctypes.c_int), ("ldxb", ctypes.c_int), ("xb", ctypes.c_void_p),
         ("center", ctypes.c_void_p), ("part", ctypes.c_void_p), ("resid2", ctypes.c_void_p),
+        ("M_dev", ctypes.c_void_p),                  # device int: the kernel runs min(M, *M_dev) rows (packed captions)
     ]
 
 
@@ -99,15 +105,15 @@ def lib():
         L.msclip_gemm_splitk.argtypes = [ctypes.POINTER(GemmDesc), ci, vp]
         L.msclip_gemm_splitk_tn.argtypes = [ctypes.POINTER(GemmDesc), ci, vp]
         L.msclip_gemm_f8.argtypes = [ctypes.POINTER(GemmDesc), vp, vp, vp]
-        L.msclip_layernorm_f8.argtypes = [vp, ci, vp, vp, vp, vp, ci, vp, ci, vp, ci, ci, cf, vp]
+        L.msclip_layernorm_f8.argtypes = [vp, ci, vp, vp, vp, vp, ci, vp, ci, vp, ci, ci, cf, vp, vp]
         L.msclip_quant_f8_rows.argtypes = [vp, ci, vp, ci, vp, ci, ci, vp]
         L.msclip_gemm_variant.argtypes = [ctypes.POINTER(GemmDesc)]
         L.msclip_gemm_variant.restype = ctypes.c_char_p
         L.msclip_attention.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, vp]
         L.msclip_attention_lastq.argtypes = [vp, ci, vp, ci, vp, ci, ci, ci, ci, vp, ci, vp]
         L.msclip_layernorm.argtypes = [vp, ci, vp, ci, ci, vp, vp, vp, ci, ci, vp, ci, ci, ci, cf, vp]
-        L.msclip_layernorm_stats.argtypes = [vp, ci, vp, vp, vp, ci, ci, vp, ci, vp, vp, ci, ci, cf, vp]
-        L.msclip_rowstat_finalize.argtypes = [vp, ci, vp, vp, ci, ci, cf, vp]
+        L.msclip_layernorm_stats.argtypes = [vp, ci, vp, vp, vp, ci, ci, vp, ci, vp, vp, ci, ci, cf, vp, vp]
+        L.msclip_rowstat_finalize.argtypes = [vp, ci, vp, vp, ci, ci, cf, vp, vp]
         L.msclip_layernorm_split.argtypes = [vp, ci, vp, vp, vp, vp, ci, vp, ci, ci, ci, ci, cf, vp]
         L.msclip_embed_tokens.argtypes = [vp, vp, vp, vp, ci, vp, ci, ci, ci, ci, ci, vp]
         L.msclip_fill_cls.argtypes = [vp, vp, vp, ci, ci, ci, ci, vp]
@@ -156,9 +162,9 @@ def lib():
         L.msclip_bn_finish_tiled.argtypes = [vp, ci, ci, ll, vp, vp, cf, vp, ci, vp]
         L.msclip_bn_bwd_finish.argtypes = [vp, ci, ci, ci, vp, vp, vp]
         L.msclip_bn_fold_bwd.argtypes = [vp, ll, vp, ci, ci, vp, vp, vp, vp, cf, vp, vp, vp, vp]
-        L.msclip_text_lengths.argtypes = [vp, ci, ci, ci, vp, vp, vp, vp]
-        L.msclip_embed_tokens_packed.argtypes = [vp, vp, vp, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp]
-        L.msclip_attention_varlen.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]
+        L.msclip_text_lengths.argtypes = [vp, ci, ci, ci, vp, vp, vp, vp, ci, ci, vp]
+        L.msclip_embed_tokens_packed.argtypes = [vp, vp, vp, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, vp]
+        L.msclip_attention_varlen.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]
         L.msclip_attention_lastq_varlen.argtypes = [vp, ci, vp, ci, vp, ci, ci, ci, ci, vp, ci, vp]
         L.msclip_attention_bwd_varlen.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]
         L.msclip_embed_tokens_bwd_packed.argtypes = [vp, vp, ci, vp, vp, vp, ci, ci, ci, ci, vp]
@@ -168,13 +174,38 @@ def lib():
         L.msclip_transpose_bf16_multi.argtypes = [vp, vp, ci, ci, vp]
         L.msclip_colsum_multi.argtypes = [vp, ci, vp]
         L.msclip_image_conv_wgrad.argtypes = [vp, vp, ci, vp, ci, ci, ci, ci, vp]
+        pp = ctypes.POINTER(vp)
+        L.msclip_plan_create.argtypes = [pp]
+        L.msclip_plan_destroy.argtypes = [vp]
+        L.msclip_plan_begin.argtypes = [vp, pp, ci]
+        L.msclip_plan_bind_external.argtypes = [vp, vp, ll]
+        L.msclip_plan_record_event.argtypes = [vp, vp]
+        L.msclip_plan_wait_event.argtypes = [vp, vp, ci]
+        L.msclip_plan_end.argtypes = [vp]
+        L.msclip_plan_abort.argtypes = [vp]
+        L.msclip_plan_info.argtypes = [vp] + [ctypes.POINTER(ci)] * 5
+        L.msclip_plan_op_name.argtypes = [vp, ci]
+        L.msclip_plan_op_name.restype = ctypes.c_char_p
+        L.msclip_plan_run.argtypes = [vp, pp, ci, pp, ci]
+        L.msclip_plan_size.argtypes = [vp]
+        L.msclip_plan_probe_enable.argtypes = [vp, ctypes.POINTER(ci), ci, ci]
+        L.msclip_plan_probe_disable.argtypes = [vp]
+        L.msclip_plan_probe_runs.argtypes = [vp]
+        L.msclip_plan_probe_elapsed.argtypes = [vp, ci, ci, ctypes.POINTER(cf)]
+        L.msclip_stream_create_cu_masked.argtypes = [ci, ci, pp]
+        L.msclip_comm_unique_id.argtypes = [vp]
+        L.msclip_comm_init.argtypes = [ci, ci, vp, pp]
+        L.msclip_comm_destroy.argtypes = [vp]
+        L.msclip_comm_async_error.argtypes = [vp]
+        L.msclip_allgather_feats.argtypes = [vp, vp, vp, ll, ci, vp]
+        L.msclip_allreduce.argtypes = [vp, vp, vp, ll, ci, ci, vp]
         L.msclip_abi_version.restype = ci
         if L.msclip_abi_version() != ABI_VERSION:          # a stale build of the library (the struct layouts / entry points moved on)
             raise HipUnavailable(f"{LIB_PATH} has ABI version {L.msclip_abi_version()}, this binding needs {ABI_VERSION}: rebuild "
                                  "(bash msclip_amd/csrc/build.sh)")
         L.msclip_build_arch.restype = ctypes.c_char_p
         for name in EXPORTS:
-            if name not in ("msclip_build_arch", "msclip_gemm_variant"):
+            if name not in ("msclip_build_arch", "msclip_gemm_variant", "msclip_plan_op_name"):
                 getattr(L, name).restype = ci
         _lib = L
     return _lib
@@ -315,18 +346,40 @@ class KernelProbe:
         self.records = []          # (start_event, end_event, units)
         self.tags = []             # optional per-launch description
         self.bytes = []            # algorithmic HBM bytes of the launch (operands once + residual once + output once)
+        self.rows = []             # (device row count or None, the launch's host-side M): launches sized by a device-side count
 
     def begin(self):
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
         return ev
 
-    def end(self, start, units, tag=None, nbytes=0):
+    def end(self, start, units, tag=None, nbytes=0, rows=None):
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
         self.records.append((start, ev, units))
         self.tags.append(tag)
         self.bytes.append(nbytes)
+        self.rows.append(rows)
+
+    def resolve_rows(self):
+        """Launches whose row count lives on the device (mdev) were recorded with their upper bound M: scale their FLOPs / bytes /
+        shape tags to the rows that really ran (one host read per distinct device counter; call after a synchronize and before
+        summary() / by_shape())."""
+        cache = {}
+        for i, r in enumerate(self.rows):
+            if r is None or r[0] is None:
+                continue
+            t, bound = r
+            key = t.data_ptr()
+            if key not in cache:
+                cache[key] = min(int(t.item()), bound)
+            f = cache[key] / bound
+            s, e, u = self.records[i]
+            self.records[i] = (s, e, u * f)
+            self.bytes[i] = self.bytes[i] * f
+            if self.tags[i] is not None:
+                self.tags[i] = (cache[key],) + tuple(self.tags[i][1:])
+            self.rows[i] = None
 
     def by_shape(self):
         """-> {tag: (launches, total_ms, total_units, total_bytes)}; call after a synchronize."""
@@ -340,6 +393,186 @@ class KernelProbe:
         """-> (launches, total_ms, total_units); call after a synchronize."""
         ms = sum(s.elapsed_time(e) for s, e, _ in self.records)
         return len(self.records), ms, sum(u for _, _, u in self.records)
+
+
+_REC = [None]        # the hip.Plan that is recording (hip.gemm / gemm_f8 note what their table entries compute)
+
+
+class Plan:
+    """A recorded launch table (include/msclip_hip.h "Launch plans", csrc/plan.h): record one step while it runs, replay it natively.
+
+        plan = hip.Plan(dev, [main, side, ...])      # torch streams: slot i = streams[i]; slot 0 must be current while recording
+        with plan.recording(externals=[img, tok]):
+            ... the step, issued as usual (it really runs) ...; cross-stream edges through plan.record_event / plan.wait_event
+        plan.run([main, side, ...], [img2, tok2])    # any later batch of the same shapes
+
+    The table holds raw device addresses: every buffer the step touches (other than the externals) must stay alive and in place
+    for as long as the plan does -- the owner (the engine) drops its plans whenever it re-packs weights or frees a workspace."""
+
+    def __init__(self, device, streams):
+        self.dev = device
+        self.n_streams = len(streams)
+        self._h = ctypes.c_void_p()
+        _check(lib().msclip_plan_create(ctypes.byref(self._h)), "msclip_plan_create")
+        self._rec_streams = list(streams)
+        self._ext_shapes = None
+        self.ready = False
+        self.n_ops = self.n_launches = self.n_events = 0
+        self.keep = []                                    # tensors the table points into that nothing else keeps alive
+        self.meta = []                                    # (entry index, kind, flops, tag, bytes, device row counter, bound M)
+        self._probe = None
+
+    def note(self, kind, flops, tag, nbytes, mdev, M):
+        """Called by the GEMM bindings during the recording: the entry the launch about to be issued will occupy."""
+        self.meta.append((lib().msclip_plan_size(self._h), kind, flops, tag, nbytes, mdev, M))
+
+    def enable_probe(self, kinds, runs):
+        """HIP timing events around every recorded GEMM entry whose kind ("gemm:pp", "gemm:ppconv", "gemm:stream", "gemm:dense128",
+        "gemm_f8", ...) is in `kinds`, for the next `runs` replays; -> number of entries probed."""
+        sel = [m for m in self.meta if m[1] in kinds]
+        if not sel:
+            return 0
+        arr = (ctypes.c_int * len(sel))(*[m[0] for m in sel])
+        _check(lib().msclip_plan_probe_enable(self._h, arr, len(sel), int(runs)), "msclip_plan_probe_enable")
+        self._probe = sel
+        return len(sel)
+
+    def probe_results(self, disable=True):
+        """-> [(kind, ms, flops, tag, bytes)] per probed launch per run (device row counters resolved: FLOPs / bytes of the rows
+        that ran).  Call after a synchronize."""
+        sel, out, cache = self._probe or [], [], {}
+        runs = lib().msclip_plan_probe_runs(self._h)
+        ms = ctypes.c_float()
+        for r in range(max(runs, 0)):
+            for i, (_, kind, flops, tag, nbytes, mdev, M) in enumerate(sel):
+                _check(lib().msclip_plan_probe_elapsed(self._h, r, i, ctypes.byref(ms)), "msclip_plan_probe_elapsed")
+                f = 1.0
+                if mdev is not None:
+                    k = mdev.data_ptr()
+                    if k not in cache:
+                        cache[k] = min(int(mdev.item()), M)
+                    f = cache[k] / M
+                    tag = (cache[k],) + tuple(tag[1:])
+                out.append((kind, ms.value, flops * f, tag, nbytes * f))
+        if disable:
+            lib().msclip_plan_probe_disable(self._h)
+            self._probe = None
+        return out
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                lib().msclip_plan_destroy(h)
+            except Exception:
+                pass
+
+    @staticmethod
+    def _handles(streams):
+        arr = (ctypes.c_void_p * len(streams))(*[ctypes.c_void_p(s.cuda_stream) for s in streams])
+        return arr
+
+    def recording(self, externals=()):
+        plan = self
+
+        class _Rec:
+            def __enter__(self_):
+                arr = plan._handles(plan._rec_streams)
+                _check(lib().msclip_plan_begin(plan._h, arr, plan.n_streams), "msclip_plan_begin")
+                _REC[0] = plan
+                plan._ext_shapes = []
+                for t in externals:
+                    idx = lib().msclip_plan_bind_external(plan._h, _p(t), t.numel() * t.element_size())
+                    if idx < 0:
+                        lib().msclip_plan_abort(plan._h)
+                        raise HipError("msclip_plan_bind_external failed")
+                    plan._ext_shapes.append((tuple(t.shape), t.dtype))
+                return plan
+
+            def __exit__(self_, et, ev, tb):
+                _REC[0] = None
+                if et is not None:
+                    lib().msclip_plan_abort(plan._h)
+                    return False
+                n = lib().msclip_plan_end(plan._h)
+                if n <= 0:
+                    raise HipError("msclip_plan_end: the recording is unusable (a launch on a stream outside the plan's slots, an "
+                                   "entry point with host-array arguments, or nothing was launched)")
+                a, b, c, d, e = (ctypes.c_int() for _ in range(5))
+                lib().msclip_plan_info(plan._h, *[ctypes.byref(x) for x in (a, b, c, d, e)])
+                plan.n_ops, plan.n_launches, plan.n_events = a.value, b.value, c.value
+                plan.ready = True
+                return False
+        return _Rec()
+
+    def record_event(self, stream):
+        """-> event id: 'everything queued on `stream` so far' (the caller records its own torch event for the eager pass)."""
+        eid = lib().msclip_plan_record_event(self._h, ctypes.c_void_p(stream.cuda_stream))
+        if eid < 0:
+            raise HipError("msclip_plan_record_event failed (stream not one of the plan's slots?)")
+        return eid
+
+    def wait_event(self, stream, eid):
+        _check(lib().msclip_plan_wait_event(self._h, ctypes.c_void_p(stream.cuda_stream), eid), "msclip_plan_wait_event")
+
+    def op_names(self):
+        return [lib().msclip_plan_op_name(self._h, i).decode() for i in range(self.n_ops)]
+
+    def run(self, streams, externals=()):
+        assert self.ready and len(streams) == self.n_streams and len(externals) == len(self._ext_shapes)
+        for t, (shape, dtype) in zip(externals, self._ext_shapes):
+            if tuple(t.shape) != shape or t.dtype != dtype or not t.is_contiguous():
+                raise ValueError(f"plan external: expected a contiguous {dtype} tensor of shape {shape}, got {t.dtype} {tuple(t.shape)}")
+        ext = (ctypes.c_void_p * max(len(externals), 1))(*[ctypes.c_void_p(t.data_ptr()) for t in externals])
+        _check(lib().msclip_plan_run(self._h, self._handles(streams), self.n_streams, ext, len(externals)), "msclip_plan_run")
+
+
+class PlanProbeResults:
+    """KernelProbe's reading interface (summary / by_shape / bytes) over Plan.probe_results() rows (ms, flops, tag, bytes)."""
+
+    def __init__(self, rows):
+        self.rows_ = list(rows)
+        self.bytes = [r[3] for r in self.rows_]
+
+    def resolve_rows(self):
+        pass
+
+    def summary(self):
+        return len(self.rows_), sum(r[0] for r in self.rows_), sum(r[1] for r in self.rows_)
+
+    def by_shape(self):
+        out = {}
+        for ms, u, tag, nb in self.rows_:
+            n, m0, u0, b0 = out.get(tag, (0, 0.0, 0.0, 0))
+            out[tag] = (n + 1, m0 + ms, u0 + u, b0 + nb)
+        return out
+
+
+_NCCL_DTYPE = {torch.bfloat16: 0, torch.float32: 1, torch.uint8: 2, torch.int32: 3}
+
+
+def allgather_feats(comm, send, recv):
+    """recv [world * n, ...] = every rank's send [n, ...], rank-major, through the C ABI's RCCL entry point on the CURRENT stream
+    (msclip_allgather_feats; reference lib/utils/comm.py:140-154)."""
+    assert send.is_cuda and recv.is_cuda and send.is_contiguous() and recv.is_contiguous() and send.dtype == recv.dtype
+    assert recv.numel() % send.numel() == 0
+    _check(lib().msclip_allgather_feats(comm, _p(send), _p(recv), send.numel(), _NCCL_DTYPE[send.dtype], _stream()), "msclip_allgather_feats")
+    return recv
+
+
+def allreduce(comm, t, op="sum"):
+    """In-place element-wise sum / max of `t` over the ranks on the CURRENT stream (msclip_allreduce; lib/utils/utils.py:66-73)."""
+    assert t.is_cuda and t.is_contiguous()
+    _check(lib().msclip_allreduce(comm, _p(t), _p(t), t.numel(), _NCCL_DTYPE[t.dtype], {"sum": 0, "max": 1}[op], _stream()), "msclip_allreduce")
+    return t
+
+
+def cu_masked_stream(device, n_cus, from_top=True):
+    """A torch stream whose kernels are confined to n_cus compute units (msclip_stream_create_cu_masked); never destroyed."""
+    ptr = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        _check(lib().msclip_stream_create_cu_masked(int(n_cus), 1 if from_top else 0, ctypes.byref(ptr)), "msclip_stream_create_cu_masked")
+    return torch.cuda.ExternalStream(ptr.value, device=device)
 
 
 _gemm_probe = {}   # kernel variant -> KernelProbe
@@ -366,6 +599,12 @@ def describe_gemm(mode, M, N, K, tile=0, conv=None, ldx=None, resid_kind=0, rpg=
         d.H, d.Wd, d.Cin, d.Ho, d.Wo, d.stride, d.pad = conv
         d.ktab = 1
     return d
+
+
+def python_probes_active():
+    """True while a KernelProbe is attached to the Python bindings (hip.gemm / hip.gemm_f8): such a call must run the eager launch
+    loop (a plan replay never enters the bindings; plan-level probes: Plan.enable_probe)."""
+    return any(p is not None for p in _gemm_probe.values()) or _f8_probe[0] is not None
 
 
 def set_gemm_probe(variant, probe):
@@ -408,11 +647,13 @@ class FoldOut:
 
 def gemm(x, w, out, *, M=None, bias=None, resid=None, resid_kind=0, act=0, alpha=1.0, conv=None, ktab=None,
          ldx=None, ldo=None, ldr=None, rpg=INT_MAX, radd=0, roff=0, N=None, tile=0, out2=None, fold_in=None, fold_out=None,
-         colsum_part=None):
+         colsum_part=None, mdev=None):
     """out = epilogue(alpha * x @ w^T).  x: bf16 [M, K] (or NHWC activation when conv=(H, W, Cin, Ho, Wo, stride, pad)),
     w: bf16 [N, Kpad]; out: bf16 or fp32 2-D buffer.  Training-step forms (ping-pong kernel): out2 = second bf16 output that
     receives the value before the activation; resid_kind = RESID_GELUGRAD multiplies by QuickGELU'(resid) (resid bf16) and,
-    with colsum_part (fp32 [M / 128, N]), also leaves the column sums of every 128 stored rows there."""
+    with colsum_part (fp32 [M / 128, N]), also leaves the column sums of every 128 stored rows there.
+    mdev: a 1-element int32 device tensor; the kernel runs min(M, mdev[0]) rows (msclip_gemm_desc.M_dev: packed captions whose row
+    count never visits the host; M -- x's row count -- is the bound the launch is sized for)."""
     _bf16(w)
     d = GemmDesc()
     d.X, d.W, d.zero, d.out = x.data_ptr(), w.data_ptr(), zero_page(x.device).data_ptr(), out.data_ptr()
@@ -438,6 +679,9 @@ def gemm(x, w, out, *, M=None, bias=None, resid=None, resid_kind=0, act=0, alpha
     d.rpg, d.radd, d.roff = rpg, radd, roff
     d.tile = tile
     d.wg_cap = _WG_CAP[0]
+    if mdev is not None:
+        assert mdev.dtype == torch.int32 and mdev.is_cuda
+        d.M_dev = mdev.data_ptr()
     if fold_in is not None:
         f = fold_in
         _f32(f.rowstat), _f32(f.csum)
@@ -466,10 +710,9 @@ def gemm(x, w, out, *, M=None, bias=None, resid=None, resid_kind=0, act=0, alpha
         assert colsum_part.is_contiguous() and colsum_part.shape == (d.M // 128, d.N)
         d.part = colsum_part.data_ptr()
     probe = (_gemm_probe.get(d.mode) or _gemm_probe.get(gemm_variant(d))) if _gemm_probe else None
-    if probe is not None:
+    rec = _REC[0]
+    if probe is not None or rec is not None:
         k_alg = d.K if conv is None else conv[2] * (ktab_taps(ktab) if ktab is not None else 1)
-        t0 = probe.begin()
-        _check(lib().msclip_gemm(ctypes.byref(d), _stream()), "msclip_gemm")
         esz = 4 if d.out_kind else 2
         x_bytes = d.M * d.K * 2 if conv is None else (d.M // (conv[3] * conv[4])) * conv[0] * conv[1] * conv[2] * 2
         r_bytes = {RESID_NONE: 0, RESID_F32: d.M * d.N * 4, RESID_BF16: d.M * d.N * 2, RESID_TABLE: 0, RESID_GELUGRAD: d.M * d.N * 2,
@@ -479,8 +722,14 @@ def gemm(x, w, out, *, M=None, bias=None, resid=None, resid_kind=0, act=0, alpha
             nbytes += d.M * d.N * 2 + d.M * (d.N // 64) * 8 + d.M * 4
         if fold_in is not None:                       # (rstd, mean * rstd) per row, per tile column; second weight
             nbytes += d.M * 8 * ((d.N + 255) // 256) + (d.N * d.K * 2 if fold_in.w2 is not None else 0)
-        probe.end(t0, 2.0 * d.M * d.N * k_alg, (d.M, d.N, d.K, k_alg, conv is not None, act, resid_kind, d.out_kind), nbytes)
-        return out
+        flops, tag = 2.0 * d.M * d.N * k_alg, (d.M, d.N, d.K, k_alg, conv is not None, act, resid_kind, d.out_kind)
+        if rec is not None:                           # a launch plan is recording: what this table entry computes (Plan.enable_probe)
+            rec.note("gemm:" + gemm_variant(d), flops, tag, nbytes, mdev, d.M)
+        if probe is not None:
+            t0 = probe.begin()
+            _check(lib().msclip_gemm(ctypes.byref(d), _stream()), "msclip_gemm")
+            probe.end(t0, flops, tag, nbytes, rows=(mdev, d.M))
+            return out
     _check(lib().msclip_gemm(ctypes.byref(d), _stream()), "msclip_gemm")
     return out
 
@@ -503,7 +752,7 @@ def quantize_rows_f8(w):
 
 
 def gemm_f8(xq, wq, out, row_scale, col_scale, *, M=None, bias=None, resid=None, resid_kind=0, act=0, alpha=1.0, out_scale=1.0,
-            fold_out=None):
+            fold_out=None, mdev=None):
     """out = epilogue(alpha * row_scale[m] * col_scale[n] * xq @ wq^T) on the fp8 MX MFMA; xq uint8 [M, K] / wq uint8 [N, K]
     hold OCP e4m3 bytes, K % 128 == 0.  out uint8: an e4m3 output, stored value = fp8(epilogue value * out_scale)."""
     assert xq.dtype == torch.uint8 and wq.dtype == torch.uint8 and xq.stride(-1) == 1 and wq.stride(-1) == 1
@@ -521,28 +770,35 @@ def gemm_f8(xq, wq, out, row_scale, col_scale, *, M=None, bias=None, resid=None,
     d.out_kind = 1 if out.dtype == torch.float32 else 2 if out.dtype == torch.uint8 else 0
     d.out_scale = out_scale
     d.wg_cap = _WG_CAP[0]
+    if mdev is not None:
+        assert mdev.dtype == torch.int32 and mdev.is_cuda
+        d.M_dev = mdev.data_ptr()
     if fold_out is not None:                          # c_proj as the producer of the next block's folded ln_1 (FoldOut)
         f = fold_out
         _bf16(f.xb)
         assert f.xb.shape[0] >= d.M and f.center.numel() >= d.M and f.part.numel() >= d.M * (d.N // 64) * 2
         d.xb, d.ldxb, d.center, d.part = f.xb.data_ptr(), f.xb.stride(0), f.center.data_ptr(), f.part.data_ptr()
     assert row_scale.numel() >= d.M and col_scale.numel() >= d.N
-    probe = _f8_probe[0]
-    t0 = probe.begin() if probe is not None else None
-    _check(lib().msclip_gemm_f8(ctypes.byref(d), _p(row_scale), _p(col_scale), _stream()), "msclip_gemm_f8")
-    if probe is not None:
+    probe, rec = _f8_probe[0], _REC[0]
+    if probe is not None or rec is not None:
         esz = {0: 2, 1: 4, 2: 1}[d.out_kind]
         r_bytes = {RESID_NONE: 0, RESID_F32: d.M * d.N * 4, RESID_BF16: d.M * d.N * 2}[resid_kind]
         nbytes = d.M * d.K + d.N * d.K + d.M * d.N * esz + r_bytes + (d.M + d.N) * 4 + (d.N * 4 if bias is not None else 0)
-        probe.end(t0, 2.0 * d.M * d.N * d.K, (d.M, d.N, d.K, d.K, False, act, resid_kind, d.out_kind), nbytes)
+        flops, tag = 2.0 * d.M * d.N * d.K, (d.M, d.N, d.K, d.K, False, act, resid_kind, d.out_kind)
+        if rec is not None:
+            rec.note("gemm_f8", flops, tag, nbytes, mdev, d.M)
+    t0 = probe.begin() if probe is not None else None
+    _check(lib().msclip_gemm_f8(ctypes.byref(d), _p(row_scale), _p(col_scale), _stream()), "msclip_gemm_f8")
+    if probe is not None:
+        probe.end(t0, flops, tag, nbytes, rows=(mdev, d.M))
     return out
 
 
-def layernorm_f8(x, gamma, beta, gamma2, beta2, split, q, row_scale, M, eps=1e-12):
+def layernorm_f8(x, gamma, beta, gamma2, beta2, split, q, row_scale, M, eps=1e-12, mdev=None):
     """q[m] = e4m3(LN(x[m]) / s[m]), row_scale[m] = s[m]; (gamma, beta) for m < split, (gamma2, beta2) from there on."""
     assert x.dtype == torch.float32 and x.stride(-1) == 1 and q.dtype == torch.uint8 and q.stride(-1) == 1
     _check(lib().msclip_layernorm_f8(_p(x), x.stride(0), _p(gamma), _p(beta), _p(gamma2), _p(beta2), split, _p(q), q.stride(0),
-                                     _p(row_scale), M, x.shape[-1], eps, _stream()), "msclip_layernorm_f8")
+                                     _p(row_scale), M, x.shape[-1], eps, _p(mdev), _stream()), "msclip_layernorm_f8")
     return q
 
 
@@ -648,20 +904,20 @@ def layernorm(x, gamma, beta, out, M, *, row_idx=None, row_mul=1, row_add=0, eps
     return out
 
 
-def layernorm_stats(x, gamma, beta, out, M, center, rowstat, *, eps=1e-12, raw_out=None):
+def layernorm_stats(x, gamma, beta, out, M, center, rowstat, *, eps=1e-12, raw_out=None, mdev=None):
     """out[m] = LN(x[m]) over contiguous rows, plus the LayerNorm fold's per-row state: center[m] = mean of the row,
     rowstat[m] = (1, 0) (the consuming projection takes `out` as it is)."""
     assert x.dtype == torch.float32 and x.is_cuda and x.stride(-1) == 1
     _check(lib().msclip_layernorm_stats(_p(x), x.stride(0), _p(gamma), _p(beta), _p(out), out.stride(0),
                                         1 if out.dtype == torch.float32 else 0, _p(raw_out),
                                         raw_out.stride(0) if raw_out is not None else 0, _p(center), _p(rowstat), M, x.shape[-1],
-                                        eps, _stream()), "msclip_layernorm_stats")
+                                        eps, _p(mdev), _stream()), "msclip_layernorm_stats")
     return out
 
 
-def rowstat_finalize(part, center, rowstat, M, C, eps=1e-12):
+def rowstat_finalize(part, center, rowstat, M, C, eps=1e-12, mdev=None):
     """rowstat[m] = (rstd, mu * rstd) and center[m] += mu from a producing GEMM's partial sums part [M, C / 64, 2]."""
-    _check(lib().msclip_rowstat_finalize(_p(part), C // 64, _p(center), _p(rowstat), M, C, eps, _stream()), "msclip_rowstat_finalize")
+    _check(lib().msclip_rowstat_finalize(_p(part), C // 64, _p(center), _p(rowstat), M, C, eps, _p(mdev), _stream()), "msclip_rowstat_finalize")
 
 
 def layernorm_split(x, gamma, beta, gamma2, beta2, split, out, M, eps=1e-12):
@@ -680,33 +936,38 @@ def embed_tokens(tokens, emb, pos, x, eot_row, row_base):
                                      emb.shape[0], row_base, _stream()), "msclip_embed_tokens")
 
 
-def text_lengths(tokens, length, cu, eot_row=None, row_base=0):
+def text_lengths(tokens, length, cu, eot_row=None, row_base=0, dims=None, pad_to=0, cap_rows=0):
     """Packed captions: length[b] = argmax_l tokens[b, l] + 1 (the rows that can influence the EOT row under the causal mask),
-    cu[:B] = exclusive prefix sums, cu[B] = total, cu[B + 1] = max length; eot_row[b] = row_base + cu[b] + length[b] - 1."""
+    cu[:B] = exclusive prefix sums, cu[B] = total, cu[B + 1] = max length; eot_row[b] = row_base + cu[b] + length[b] - 1.
+    dims (int32 [8], optional): the device-side row counts (total, longest, total rounded up to pad_to, row_base + that, padding
+    rows, row_base + total, row_base) that launches read through their mdev / dims arguments instead of a host-side size."""
     B, L = tokens.shape
     assert tokens.dtype == torch.int64 and tokens.is_contiguous() and tokens.is_cuda
     assert length.dtype == torch.int32 and length.numel() >= B and cu.dtype == torch.int32 and cu.numel() >= B + 2
     assert eot_row is None or (eot_row.dtype == torch.int32 and eot_row.numel() >= B)
-    _check(lib().msclip_text_lengths(_p(tokens), B, L, row_base, _p(length), _p(cu), _p(eot_row), _stream()), "msclip_text_lengths")
+    if dims is not None:
+        assert dims.dtype == torch.int32 and dims.numel() >= 8 and cap_rows >= B * L
+    _check(lib().msclip_text_lengths(_p(tokens), B, L, row_base, _p(length), _p(cu), _p(eot_row), _p(dims), pad_to, cap_rows, _stream()),
+           "msclip_text_lengths")
 
 
-def embed_tokens_packed(tokens, emb, pos, x, cu, row_base, rows_padded):
+def embed_tokens_packed(tokens, emb, pos, x, cu, row_base, rows_padded, rows_dev=None):
     """x[row_base + cu[b] + l] = emb[tokens[b, l]] + pos[l] for the live positions; rows up to row_base + rows_padded zeroed."""
     B, L = tokens.shape
     assert tokens.dtype == torch.int64 and tokens.is_contiguous() and cu.dtype == torch.int32 and cu.numel() >= B + 2
     assert x.shape[0] >= row_base + rows_padded
     _check(lib().msclip_embed_tokens_packed(_p(tokens), _p(emb), _p(pos), _p(x), x.stride(0), _p(cu), B, L, x.shape[1], emb.shape[0],
-                                            row_base, rows_padded, _stream()), "msclip_embed_tokens_packed")
+                                            row_base, rows_padded, _p(rows_dev), _stream()), "msclip_embed_tokens_packed")
 
 
-def attention_varlen(qkv, out, cu, nsamples, Lmax, heads, causal, pad_rows=0):
+def attention_varlen(qkv, out, cu, nsamples, Lmax, heads, causal, pad_rows=0, dims=None):
     """attention() over packed captions: sample b = rows cu[b] .. cu[b + 1] of qkv / out (views that start at the text
     segment); the pad_rows output rows behind cu[nsamples] are zeroed."""
     _bf16(qkv)
     _bf16(out)
     assert cu.dtype == torch.int32 and cu.numel() >= nsamples + 2 and 0 <= pad_rows < 256
     _check(lib().msclip_attention_varlen(_p(qkv), _p(out), _p(cu), nsamples, Lmax, heads, qkv.stride(0), out.stride(0), int(causal),
-                                         pad_rows, _stream()), "msclip_attention_varlen")
+                                         pad_rows, _p(dims), _stream()), "msclip_attention_varlen")
     return out
 
 

@@ -1,0 +1,74 @@
+"""Run-time options of the engine in ONE object (round 6: replaces call-time environment reads inside the engine).
+
+`EngineOptions.from_env()` is read ONCE, when an Engine is built (model.engine()); afterwards a stale shell variable cannot
+change numerics or schedules half-way through a run, and a test sets what it wants explicitly:
+
+    eng = model.engine()
+    eng.opt = eng.opt.replace(plan=False)          # e.g. the eager launch loop for an A/B
+
+Every field names the environment variable it is initialised from (0 / 1), so existing command lines keep working.  Switches of
+retired A/B paths whose result is on record in DESIGN.md are not here any more.
+"""
+import dataclasses
+import os
+
+
+def _flag(name, default):
+    v = os.environ.get(name)
+    if v is None or v == "":
+        return default
+    return v != "0"
+
+
+@dataclasses.dataclass(frozen=True)
+class EngineOptions:
+    # ---- text rows
+    text_pack: bool = True            # MSCLIP_TEXT_PACK: captions own argmax + 1 rows instead of context_length
+    dynamic_rows: bool = True         # MSCLIP_DYNAMIC_ROWS: the packed row count stays on the device (msclip_text_lengths dims ->
+    #                                   M_dev / m_dev): no host read per batch, the step is capturable / plannable.  0 = the
+    #                                   round-5 path (host reads the total, sizes every launch exactly)
+    # ---- launch loop
+    plan: bool = True                 # MSCLIP_PLAN: record the step once into a native launch table (msclip_plan_*), replay it per call
+    # ---- schedule
+    conv_side_stream: bool = True     # MSCLIP_CONV_SIDE_STREAM: parallel conv branch + adapter tops on a side stream
+    text0_stream: bool = True         # MSCLIP_TEXT0_STREAM: text front + text block 0 beside the image front
+    branch_early: bool = True         # MSCLIP_BRANCH_EARLY: the branch starts behind the fused stem kernel, not the whole front
+    side_cu_mask: int = 0             # MSCLIP_SIDE_CUS: > 0 = the conv side stream is created with a CU mask of this many CUs
+    #                                   (whole XCD-interleaved set; hipExtStreamCreateWithCUMask), 0 = an ordinary stream
+    # ---- kernel / path selection kept as options (each has a test or a documented A/B that flips it)
+    ln_fold: bool = True              # MSCLIP_LN_FOLD
+    fused_qkv_attn: bool = False      # MSCLIP_FUSED_QKV_ATTN (north_star's fused QKV + SDPA kernel; measured 0.6 % slower: opt-in)
+    front_unfused: bool = False       # MSCLIP_FRONT_UNFUSED
+    block_unfused: bool = False       # MSCLIP_BLOCK_UNFUSED
+    full_last_block: bool = False     # MSCLIP_FULL_LAST_BLOCK
+    last_block_all_queries: bool = False   # MSCLIP_LAST_BLOCK_ALL_QUERIES
+    adapter_ln1_pass: bool = False    # MSCLIP_ADAPTER_LN1_PASS
+    gather_packed: bool = False       # MSCLIP_GATHER_PACKED: one [B, 2, E] all-gather instead of one per modality
+    repack_table: bool = True         # MSCLIP_REPACK_TABLE
+    native_collectives: bool = False  # MSCLIP_NATIVE_COLLECTIVES: feature gather / loss all-reduce through the C ABI's RCCL entry
+    #                                   points (msclip_comm_*) on the compute stream instead of ProcessGroupNCCL
+
+    @classmethod
+    def from_env(cls):
+        return cls(
+            text_pack=_flag("MSCLIP_TEXT_PACK", True),
+            dynamic_rows=_flag("MSCLIP_DYNAMIC_ROWS", True),
+            plan=_flag("MSCLIP_PLAN", True),
+            conv_side_stream=_flag("MSCLIP_CONV_SIDE_STREAM", True),
+            text0_stream=_flag("MSCLIP_TEXT0_STREAM", True),
+            branch_early=_flag("MSCLIP_BRANCH_EARLY", True),
+            side_cu_mask=int(os.environ.get("MSCLIP_SIDE_CUS", "0") or 0),
+            ln_fold=_flag("MSCLIP_LN_FOLD", True),
+            fused_qkv_attn=_flag("MSCLIP_FUSED_QKV_ATTN", False),
+            front_unfused=_flag("MSCLIP_FRONT_UNFUSED", False),
+            block_unfused=_flag("MSCLIP_BLOCK_UNFUSED", False),
+            full_last_block=_flag("MSCLIP_FULL_LAST_BLOCK", False),
+            last_block_all_queries=_flag("MSCLIP_LAST_BLOCK_ALL_QUERIES", False),
+            adapter_ln1_pass=_flag("MSCLIP_ADAPTER_LN1_PASS", False),
+            gather_packed=_flag("MSCLIP_GATHER_PACKED", False),
+            repack_table=_flag("MSCLIP_REPACK_TABLE", True),
+            native_collectives=_flag("MSCLIP_NATIVE_COLLECTIVES", False),
+        )
+
+    def replace(self, **kw):
+        return dataclasses.replace(self, **kw)

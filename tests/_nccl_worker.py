@@ -36,13 +36,35 @@ def main():
     logits = m(img[mine].cuda(), tok[mine].cuda())                    # gather=True from the yaml (GATHER_TENSORS)
     loss = m.contrastive_loss(img[mine].cuda(), tok[mine].cuda())
     # SURVEY s8(e)'s single packed [B, 2, E] gather (behind a flag) against the default two per-modality gathers
-    os.environ["MSCLIP_GATHER_PACKED"] = "1"
+    eng_ = m.engine()
+    eng_.opt = eng_.opt.replace(gather_packed=True)
     logits_pk = m(img[mine].cuda(), tok[mine].cuda())
     loss_pk = m.contrastive_loss(img[mine].cuda(), tok[mine].cuda())
     assert m.engine()._ws[(B, B, "inference") if (B, B, "inference") in m.engine()._ws else (B, B)].get("pk") is not None
-    del os.environ["MSCLIP_GATHER_PACKED"]
+    eng_.opt = eng_.opt.replace(gather_packed=False)
     logits_back = m(img[mine].cuda(), tok[mine].cuda())               # ... and back to the dense buffers
     assert torch.equal(logits_back, logits)
+    # the same collectives through the library's C ABI (msclip_comm_init / msclip_allgather_feats / msclip_allreduce: RCCL on the
+    # compute stream, unique id carried by the process group's store) -- bitwise the ProcessGroupNCCL path, at the small batch
+    # (eager launch loop) and at batch 256 per rank, where the step is a launch-plan replay that CONTAINS the two gathers
+    native = {}
+    if backend == "nccl":
+        Bn = 256
+        imgn, tokn = synth.synth_images(Bn, seed=93 + rank).cuda(), synth.synth_tokens(Bn, seed=94 + rank).cuda()
+        pg_logits = m(imgn, tokn).clone()
+        pg_loss = m.contrastive_loss(imgn, tokn).clone()
+        C.init_native_comm(torch.cuda.current_device())
+        eng_.opt = eng_.opt.replace(native_collectives=True)
+        assert eng_._native_collectives()
+        native["logits"] = m(img[mine].cuda(), tok[mine].cuda()).cpu()
+        native["loss"] = float(m.contrastive_loss(img[mine].cuda(), tok[mine].cuda()))
+        for _ in range(3):                                             # recording pass, then replays
+            nat_logits = m(imgn, tokn)
+            nat_loss = m.contrastive_loss(imgn, tokn)
+        plan = eng_.last_plan
+        native["planned"] = plan is not None and any(n == "msclip_allgather_feats" for n in plan.op_names())
+        native["equal256"] = bool(torch.equal(nat_logits, pg_logits)) and bool(torch.equal(nat_loss, pg_loss))
+        eng_.opt = eng_.opt.replace(native_collectives=False)
     # training step: gradients averaged over the ranks through comm.GradReducer (small buckets: several collectives)
     from msclip_amd import train
     ts = train.TrainStep(m, lr=1e-4, bn="frozen")
@@ -58,8 +80,9 @@ def main():
     torch.cuda.synchronize()
     if rank == 0:
         torch.save({"logits": logits.cpu(), "loss": float(loss), "logits_packed_gather": logits_pk.cpu(), "loss_packed_gather": float(loss_pk), "train_loss": float(tl), "launched": launched,
-                    "grads": kept, "n_grads": n_grads, "train_loss_after_step": float(tl2)}, out)
+                    "grads": kept, "n_grads": n_grads, "train_loss_after_step": float(tl2), "native": native}, out)
     dist.barrier()
+    C.destroy_native_comm()
     dist.destroy_process_group()
 
 

@@ -18,6 +18,13 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def set_opt(monkeypatch, model_or_engine, **fields):
+    """Replace fields of an engine's EngineOptions for the rest of the test (msclip_amd/options.py; restored at teardown)."""
+    eng = model_or_engine.engine() if hasattr(model_or_engine, "engine") else model_or_engine
+    monkeypatch.setattr(eng, "opt", eng.opt.replace(**fields))
+    return eng
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden, synth_sd
+from conftest import golden, set_opt, synth_sd
 from msclip_amd import hip, synth
 from msclip_amd.clip_openai_pe_res_v1 import get_clip_model
 from msclip_amd.config import named_config
@@ -102,13 +102,12 @@ def test_fused_front_paths_against_the_conv_by_conv_chain(gpu_device, monkeypatc
     m = model_for(name)
     img = synth.synth_images(5, seed=37).cuda()
     fused = m.encode_image(img)
-    monkeypatch.setenv("MSCLIP_BLOCK_UNFUSED", "1")
+    set_opt(monkeypatch, m, block_unfused=True)
     no_block = m.encode_image(img)
-    monkeypatch.setenv("MSCLIP_FRONT_UNFUSED", "1")
+    set_opt(monkeypatch, m, front_unfused=True)
     chain = m.encode_image(img)
     monkeypatch.setenv("MSCLIP_FRONT_4WAVE", "1")
-    monkeypatch.setenv("MSCLIP_FRONT_UNFUSED", "0")
-    monkeypatch.setenv("MSCLIP_BLOCK_UNFUSED", "1")
+    set_opt(monkeypatch, m, front_unfused=False, block_unfused=True)
     four_wave = m.encode_image(img)
     for other in (no_block, chain, four_wave):
         assert (fused - other).abs().max().item() <= 2e-3
@@ -312,12 +311,11 @@ def test_reference_taps_on_gpu(gpu_device, monkeypatch, name, fused, pack):
     then exist on the live rows only: their sample points on live rows are compared, the whole-tensor means are not) or all
     77 rows per caption (MSCLIP_TEXT_PACK=0: the complete comparison)."""
     from conftest import summarize
-    monkeypatch.setenv("MSCLIP_TEXT_PACK", "1" if pack else "0")
-    if not fused:
-        monkeypatch.setenv("MSCLIP_FRONT_UNFUSED", "1")
-        monkeypatch.setenv("MSCLIP_BLOCK_UNFUSED", "1")
     g = golden(name)
     m = model_for(name)
+    set_opt(monkeypatch, m, text_pack=bool(pack))
+    if not fused:
+        set_opt(monkeypatch, m, front_unfused=True, block_unfused=True)
     b = int(g["batch"])
     img = synth.synth_images(b, seed=int(g["seed"])).cuda()
     tok = synth.synth_tokens(b, seed=int(g["seed"]) + 1).cuda()
@@ -497,6 +495,11 @@ def test_one_rank_rccl_collectives(gpu_device, tmp_path):
     assert got["loss"] == float(m.contrastive_loss(img, tok))
     # the single packed [B, 2, E] gather (MSCLIP_GATHER_PACKED=1): same features through strided views of one buffer
     assert torch.equal(got["logits_packed_gather"], got["logits"]) and got["loss_packed_gather"] == got["loss"]
+    # RCCL behind the C ABI (msclip_comm_init / msclip_allgather_feats / msclip_allreduce) against ProcessGroupNCCL: bitwise, eager
+    # and as entries of a launch-plan replay (batch 256)
+    nat = got["native"]
+    assert torch.equal(nat["logits"], got["logits"]) and nat["loss"] == got["loss"]
+    assert nat["planned"] and nat["equal256"]
     ts = train.TrainStep(m, lr=1e-4, bn="frozen")
     assert got["train_loss"] == float(ts.forward(img, tok))
     full = ts.backward()
@@ -620,10 +623,10 @@ def test_conv_branch_on_side_stream_is_bitwise_the_inline_schedule(gpu_device, m
     m = model_for("b32-yfcc-msclips")
     img = synth.synth_images(6, seed=91).cuda()
     tok = synth.synth_tokens(6, seed=92).cuda()
-    monkeypatch.setenv("MSCLIP_CONV_SIDE_STREAM", "0")
+    set_opt(monkeypatch, m, conv_side_stream=False)
     a = m.engine().run(img, tok)
     fi, ft = a["fv"].clone(), a["ft"].clone()
-    monkeypatch.delenv("MSCLIP_CONV_SIDE_STREAM")
+    set_opt(monkeypatch, m, conv_side_stream=True)
     for _ in range(3):                                                 # back-to-back steps: buffer reuse across steps
         b = m.engine().run(img, tok)
         assert torch.equal(b["fv"], fi) and torch.equal(b["ft"], ft)
@@ -640,11 +643,11 @@ def test_last_block_on_live_rows_only_matches_the_full_block(gpu_device, monkeyp
     m = model_for(name)
     img = synth.synth_images(5, seed=71).cuda()
     tok = synth.synth_tokens(7, seed=72, min_len=1, max_len=75).cuda()
-    monkeypatch.setenv("MSCLIP_FULL_LAST_BLOCK", "1")
+    set_opt(monkeypatch, m, full_last_block=True)
     fi, ft = m.encode_image(img), m.encode_text(tok)
     lg = m(img, tok[:5])
     loss = m.contrastive_loss(img, tok[:5]).item()
-    monkeypatch.delenv("MSCLIP_FULL_LAST_BLOCK")
+    set_opt(monkeypatch, m, full_last_block=False)
     ci, ct = m.encode_image(img), m.encode_text(tok)
     assert (ci - fi).abs().max().item() <= 1e-3 and (ct - ft).abs().max().item() <= 1e-3
     assert torch.nn.functional.cosine_similarity(ci, fi, dim=-1).min().item() >= 0.99999
@@ -895,12 +898,12 @@ def test_layernorm_fold_against_the_unfused_layer_loop(gpu_device, monkeypatch, 
     calls = []
     real = hip.rowstat_finalize
     monkeypatch.setattr(hip, "rowstat_finalize", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
-    monkeypatch.setenv("MSCLIP_LN_FOLD", "0")
+    set_opt(monkeypatch, m, ln_fold=False, plan=False)            # (plan off: this test counts calls of the Python binding)
     t0 = {}
     w = eng.run(img, tok, taps=t0)
     f0i, f0t = w["fv"].clone(), w["ft"].clone()
     assert not calls
-    monkeypatch.setenv("MSCLIP_LN_FOLD", "1")
+    set_opt(monkeypatch, m, ln_fold=True)
     t1 = {}
     w = eng.run(img, tok, taps=t1)
     f1i, f1t = w["fv"].clone(), w["ft"].clone()
@@ -941,9 +944,9 @@ def test_layernorm_fold_against_the_unfused_layer_loop(gpu_device, monkeypatch, 
             ln.weight.mul_(1.5)
             ln.bias.add_(0.25)
         a = e2.run(img, tok)["fv"].clone()
-        monkeypatch.setenv("MSCLIP_LN_FOLD", "0")
+        set_opt(monkeypatch, m2, ln_fold=False)
         b = e2.run(img, tok)["fv"].clone()
-        monkeypatch.setenv("MSCLIP_LN_FOLD", "1")
+        set_opt(monkeypatch, m2, ln_fold=True)
         assert (a - b).abs().max().item() <= 2e-3 and (a - f0i).abs().max().item() > 5e-3      # both paths moved, together
 
 
@@ -981,11 +984,10 @@ def test_fused_qkv_attention_engine_path_against_reference_goldens(gpu_device, m
     tolerances as the default path, packed captions and full rows."""
     from conftest import summarize
     from msclip_amd import hip
-    monkeypatch.setenv("MSCLIP_FUSED_QKV_ATTN", "1")
-    monkeypatch.setenv("MSCLIP_TEXT_PACK", "1" if pack else "0")
     name = "b32-yfcc-msclips"
     g = golden(name)
     m = model_for(name)
+    set_opt(monkeypatch, m, fused_qkv_attn=True, text_pack=bool(pack), plan=False)     # (plan off: the binding's calls are counted)
     b = int(g["batch"])
     img = synth.synth_images(b, seed=int(g["seed"])).cuda()
     tok = synth.synth_tokens(b, seed=int(g["seed"]) + 1).cuda()
@@ -1022,7 +1024,7 @@ def test_fused_qkv_attention_engine_path_with_the_layernorm_fold(gpu_device, mon
     eng = m.engine()
     w = eng.run(img, tok)
     f0i, f0t = w["fv"].clone(), w["ft"].clone()
-    monkeypatch.setenv("MSCLIP_FUSED_QKV_ATTN", "1")
+    set_opt(monkeypatch, m, fused_qkv_attn=True)
     w = eng.run(img, tok)
     f1i, f1t = w["fv"].clone(), w["ft"].clone()
     for a, b in ((f0i, f1i), (f0t, f1t)):

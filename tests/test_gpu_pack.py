@@ -12,6 +12,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from conftest import set_opt
 from msclip_amd import hip, synth
 
 pytestmark = pytest.mark.gpu
@@ -227,17 +228,23 @@ def test_engine_packed_text_equals_full_rows(gpu_device, monkeypatch, B):
     eng = m.engine()
     img = synth.synth_images(B, seed=71).cuda()
     tok = edge_tokens(B, seed=72).cuda()
-    monkeypatch.setenv("MSCLIP_TEXT_PACK", "0")
+    set_opt(monkeypatch, eng, text_pack=False)
     w = eng.run(img, tok)
     assert not w["packed"] and w["Mt"] == B * 77
     f0i, f0t = w["fv"].clone(), w["ft"].clone()
     l0 = eng.forward_loss(img, tok, gather=False).item()
     lg0 = eng.forward_logits(img, tok, gather=False).clone()
-    monkeypatch.setenv("MSCLIP_TEXT_PACK", "1")
+    set_opt(monkeypatch, eng, text_pack=True)
     w = eng.run(img, tok)
     n = lengths(tok.cpu())
-    assert w["packed"] and w["Mt_live"] == int(n.sum()) and w["Lmax"] == 77 and torch.equal(w["len"].cpu(), n)
+    assert w["packed"] and eng._live_text_rows(w) == int(n.sum()) and w["Lmax"] == 77 and torch.equal(w["len"].cpu(), n)
+    assert w["dyn"] == (B == 512)                           # batch 512: the row count stays on the device (engine.dynamic_rows)
     assert w["Mt"] % 256 == 0 if B == 512 else w["Mt"] == w["Mt_live"]
+    if B == 512:                                            # ... and the device-side dims say what the host-read path computed
+        d = w["dims"].cpu().tolist()
+        tot = int(n.sum())
+        pad = -(-tot // 256) * 256
+        assert d[:7] == [tot, 77, pad, w["Mv"] + pad, pad - tot, w["Mv"] + tot, w["Mv"]]
     f1i, f1t = w["fv"].clone(), w["ft"].clone()
     assert (f1i - f0i).abs().max().item() <= 2e-3 and (f1t - f0t).abs().max().item() <= 2e-3
     assert F.cosine_similarity(f1t, f0t, dim=-1).min().item() >= 0.99995
@@ -247,6 +254,38 @@ def test_engine_packed_text_equals_full_rows(gpu_device, monkeypatch, B):
     for _ in range(2):                                                          # bitwise repeatable
         w2 = eng.run(img, tok)
         assert torch.equal(w2["ft"], f1t) and torch.equal(w2["fv"], f1i)
+
+
+@pytest.mark.parametrize("lens", ["ragged", "edge", "short"])
+def test_device_side_row_counts_are_bitwise_the_host_sized_path(gpu_device, monkeypatch, lens):
+    """engine.dynamic_rows: the packed row count stays on the device (msclip_text_lengths' dims -> msclip_gemm_desc.M_dev and the
+    m_dev / dims arguments; every launch is sized for the upper bound) against the round-5 path where the host reads the total
+    and sizes every launch exactly (dynamic_rows=False): the same tiles run the same arithmetic, so features, loss and logits
+    are BITWISE equal -- for ragged captions, the edge captions, and a batch so short that most of the bound is empty.  Then
+    with stale garbage behind the live rows (a longer batch ran before): still bitwise."""
+    m = _model("b32-yfcc-msclips")
+    eng = m.engine()
+    B = 512
+    img = synth.synth_images(B, seed=171).cuda()
+    tok = {"ragged": lambda: synth.synth_tokens(B, seed=172), "edge": lambda: edge_tokens(B, seed=173),
+           "short": lambda: synth.synth_tokens(B, seed=174, min_len=1, max_len=9)}[lens]().cuda()
+    long_tok = synth.synth_tokens(B, seed=175, min_len=70, max_len=75).cuda()
+    set_opt(monkeypatch, eng, dynamic_rows=False, plan=False)
+    w = eng.run(img, tok)
+    assert w["packed"] and not w["dyn"]
+    f0i, f0t = w["fv"].clone(), w["ft"].clone()
+    l0 = eng.forward_loss(img, tok, gather=False).clone()
+    lg0 = eng.forward_logits(img, tok, gather=False).clone()
+    for plan in (False, True):
+        set_opt(monkeypatch, eng, dynamic_rows=True, plan=plan)
+        eng.run(img, long_tok)                               # leaves other values in every row behind this batch's live rows
+        for _ in range(3 if plan else 1):                    # (plan: the recording pass, then replays)
+            w = eng.run(img, tok)
+            assert w["packed"] and w["dyn"]
+            assert torch.equal(w["fv"], f0i) and torch.equal(w["ft"], f0t)
+        assert torch.equal(eng.forward_loss(img, tok, gather=False), l0)
+        assert torch.equal(eng.forward_logits(img, tok, gather=False), lg0)
+        assert torch.equal(m.encode_text(tok), f0t) or (m.encode_text(tok) - f0t).abs().max().item() <= 2e-3   # text-only call: other tile map
 
 
 def test_engine_packed_text_against_oracle(gpu_device):
@@ -273,10 +312,10 @@ def test_text_block_taps_on_live_rows(gpu_device, monkeypatch):
     B = 8
     img = synth.synth_images(B, seed=73).cuda()
     tok = edge_tokens(B, seed=74).cuda()
-    monkeypatch.setenv("MSCLIP_TEXT_PACK", "0")
+    set_opt(monkeypatch, eng, text_pack=False)
     t0 = {}
     eng.run(img, tok, taps=t0)
-    monkeypatch.setenv("MSCLIP_TEXT_PACK", "1")
+    set_opt(monkeypatch, eng, text_pack=True)
     t1 = {}
     eng.run(img, tok, taps=t1)
     n = t1["text_lengths"].long()
@@ -307,7 +346,7 @@ def test_training_gradients_packed_equal_full_rows(gpu_device, monkeypatch):
     tok = edge_tokens(B, seed=82).cuda()
     out = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("MSCLIP_TEXT_PACK", mode)
+        set_opt(monkeypatch, m, text_pack=(mode == "1"))
         ts = train.TrainStep(m, lr=1e-4)
         loss = ts.forward(img, tok if mode == "0" else m.stage_captions(tok))      # (packed: through a staged batch)
         assert (ts.saved["cap"] is not None) == (mode == "1")

@@ -28,7 +28,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import golden, summarize, synth_sd, GOLDEN
+from conftest import golden, set_opt, summarize, synth_sd, GOLDEN
 from msclip_amd import hip, synth, train
 from msclip_amd.clip_openai_pe_res_v1 import get_clip_model
 from msclip_amd.config import named_config
@@ -1113,10 +1113,10 @@ def test_table_driven_repack_is_the_tensor_algebra_pack(gpu_device, monkeypatch,
                 t.add_(0.05 * t.abs().mean().clamp_min(1e-3) * torch.randn(t.shape, device="cuda", generator=g))
     eng._pack_plan.run()
     got = {k: v.clone() for k, v in persistent.items()}
-    monkeypatch.setenv("MSCLIP_REPACK_TABLE", "0")
+    set_opt(monkeypatch, eng, repack_table=False)
     eng.refresh(force=True)                                            # pure tensor algebra on the changed parameters (new tensors)
     ref = derived(eng)
-    monkeypatch.delenv("MSCLIP_REPACK_TABLE")
+    set_opt(monkeypatch, eng, repack_table=True)
     assert set(got) == set(ref) and len(got) > 60
     for k in ref:
         a, b = got[k], ref[k]

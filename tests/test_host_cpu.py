@@ -79,7 +79,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     lib.msclip_abi_version.restype = ctypes.c_int
     lib.msclip_build_arch.restype = ctypes.c_char_p
-    assert lib.msclip_abi_version() == hip.ABI_VERSION == 6 and lib.msclip_build_arch() == b"gfx950"
+    assert lib.msclip_abi_version() == hip.ABI_VERSION == 7 and lib.msclip_build_arch() == b"gfx950"
     # struct mirror must match the C layout (6 pointers + 24 ints/floats, then a pointer in the middle)
     assert ctypes.sizeof(hip.GemmDesc) % 8 == 0 and hip.GemmDesc.ktab.offset % 8 == 0
 
@@ -365,3 +365,40 @@ def test_lr_schedule_matches_timm_cosine_with_the_reference_yaml_literals():
     cfg = named_config("b32-yfcc-msclips", ["TRAIN.LR_SCHEDULER.METHOD", "MultiStep"])
     with pytest.raises(NotImplementedError):
         train.lr_schedule(cfg)
+
+
+def test_plan_executor_records_and_replays_without_a_gpu():
+    """The native step executor (include/msclip_hip.h "Launch plans") on the host side only: an entry point called while a plan
+    records on this thread is appended to the table BEFORE it validates its arguments, so a call that is rejected (null
+    pointers: no launch, no GPU needed) is still recorded and its replay returns the same rejection; a call on a stream that is
+    not one of the plan's slots makes msclip_plan_end fail; nothing is recorded outside begin / end."""
+    if not os.path.exists(hip.LIB_PATH):
+        hip.build()
+    L = hip.lib()
+    vp = ctypes.c_void_p
+    s1, s2, s3 = vp(0x1000), vp(0x2000), vp(0x3000)
+
+    def finalize(stream):
+        return L.msclip_rowstat_finalize(None, 12, None, None, 256, 768, 1e-12, None, stream)
+
+    h = vp()
+    assert L.msclip_plan_create(ctypes.byref(h)) == 0
+    assert finalize(s1) == -1 and L.msclip_plan_size(h) == 0            # not recording: nothing appended
+    assert L.msclip_plan_begin(h, (vp * 2)(s1, s2), 2) == 0
+    assert finalize(s1) == -1 and finalize(s2) == -1                    # rejected, but recorded
+    assert L.msclip_plan_size(h) == 2
+    assert L.msclip_plan_end(h) == 2
+    assert [L.msclip_plan_op_name(h, i) for i in range(2)] == [b"msclip_rowstat_finalize"] * 2
+    n = [ctypes.c_int() for _ in range(5)]
+    assert L.msclip_plan_info(h, *[ctypes.byref(x) for x in n]) == 0
+    assert [x.value for x in n] == [2, 2, 0, 2, 0]
+    assert finalize(s1) == -1 and L.msclip_plan_size(h) == 2            # recording is over
+    assert L.msclip_plan_run(h, (vp * 2)(s3, s1), 2, None, 0) == -1     # the replayed entry point's own verdict
+    assert L.msclip_plan_run(h, (vp * 1)(s3), 1, None, 0) == -1         # wrong number of stream slots
+    assert L.msclip_plan_destroy(h) == 0
+    h = vp()
+    assert L.msclip_plan_create(ctypes.byref(h)) == 0
+    assert L.msclip_plan_begin(h, (vp * 1)(s1), 1) == 0
+    finalize(s3)                                                        # a stream the plan does not know
+    assert L.msclip_plan_end(h) == -1
+    assert L.msclip_plan_destroy(h) == 0

@@ -29,6 +29,7 @@ def main():
     m = get_clip_model(named_config(a.model))
     m.load_state_dict(synth.synth_state_dict(load_schema(a.model), seed=0), strict=True)
     m = m.cuda().eval()
+    eng = m.engine()
     classes, templates = zeroshot.load_prompts("imagenet")
     classes = classes[:a.classes]
     tok = SimpleTokenizer()
@@ -43,7 +44,7 @@ def main():
            "tokenizer_s": round(t_tok, 2)}
     res = {}
     for mode in ("0", "1", "0", "1"):
-        os.environ["MSCLIP_TEXT_PACK"] = mode
+        eng.opt = eng.opt.replace(text_pack=(mode == "1"))
         for b in batches[:3]:
             m.encode_text(b)
         torch.cuda.synchronize()
