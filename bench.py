@@ -343,6 +343,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     probe, probe8 = detach_probes(probe, probe8)
+    shipped_plan = eng.last_plan if ts is None else None      # the launch table the timed steps replayed (None: eager loop)
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     per_rank = None
     if grouped:
@@ -436,9 +437,9 @@ def main():
                                "not_executed_dead_rows_of_last_block": round(skipped * fmul, 3),
                                "not_executed_rows_behind_eot": round(dead * fmul, 3)},
             "loss": round(loss_val, 5),
-            "launch_loop": ({"kind": "native launch table (msclip_plan_run), recorded on the first step", "entries": eng.last_plan.n_ops,
-                             "launches": eng.last_plan.n_launches, "events": eng.last_plan.n_events}
-                            if (ts is None and eng.last_plan is not None) else {"kind": "Python / ctypes, one call per launch"}),
+            "launch_loop": ({"kind": "native launch table (msclip_plan_run), recorded on the first step", "entries": shipped_plan.n_ops,
+                             "launches": shipped_plan.n_launches, "cross_stream_events": shipped_plan.n_events}
+                            if shipped_plan is not None else {"kind": "Python / ctypes, one call per launch"}),
         }
         if ts is not None:
             rec["metric"] = f"training step (forward + backward + AdamW, BatchNorm: {args.bn} statistics) pairs/sec " + args.model

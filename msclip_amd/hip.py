@@ -682,6 +682,9 @@ def gemm(x, w, out, *, M=None, bias=None, resid=None, resid_kind=0, act=0, alpha
     if mdev is not None:
         assert mdev.dtype == torch.int32 and mdev.is_cuda
         d.M_dev = mdev.data_ptr()
+        if d.tile == 0:
+            d.tile = 4                                # the persistent ping-pong kernel is the one that reads M_dev (auto would pick the
+            #                                           128 x 128 kernel for a bound below ~11 k rows)
     if fold_in is not None:
         f = fold_in
         _f32(f.rowstat), _f32(f.csum)
