@@ -83,6 +83,7 @@ def default_config():
     c.OUTPUT_DIR = "OUTPUT/"
     c.RANK = 0
     c.DIST_BACKEND = "nccl"            # == RCCL on ROCm
+    c.WORKERS = 4                      # decoding threads of the eval input pipeline (default.py:28; the zero-shot DataLoader uses 6)
     c.MODEL = CfgNode({"NAME": "clip_openai_pe_res_v1", "PRETRAINED_MODEL": "", "SPEC": {}})
     # trainer keys the optimizer set-up of the (unreleased) trainer reads (default.py:126-133, 189-190)
     c.TRAIN = CfgNode({"IMAGE_SIZE": [224, 224], "BATCH_SIZE_PER_GPU": 256, "LR": 1e-3, "SCALE_LR": True,

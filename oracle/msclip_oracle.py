@@ -111,9 +111,9 @@ def batch_norm(x: Tensor, sd: SD, prefix: str, eps: float) -> Tensor:
     return x * scale[None, :, None, None] + (b - mu * scale)[None, :, None, None]
 
 
-def causal_mask(n: int) -> Tensor:
+def causal_mask(n: int, device=None) -> Tensor:
     """Additive -inf strictly-upper-triangular mask (M.py:2965-2971)."""
-    return torch.full((n, n), float("-inf")).triu_(1)
+    return torch.full((n, n), float("-inf"), device=device).triu_(1)
 
 
 def attention(x: Tensor, sd: SD, p: str, heads: int, mask: Tensor = None) -> Tensor:
@@ -266,7 +266,7 @@ def encode_text(text: Tensor, sd: SD, arch: Arch, norm: bool = True, taps: dict 
     argmax(token id) (EOT has the largest id), ln_final, @text_projection, L2."""
     residual_block = block_fn or globals()["residual_block"]
     x = sd["token_embedding.weight"][text] + sd["positional_embedding"]
-    mask = causal_mask(text.shape[1])
+    mask = causal_mask(text.shape[1], text.device)
     for i in range(arch.text_layers):
         x = residual_block(x, sd, f"transformer.resblocks.{i}", arch.heads, mask)
         if taps is not None:

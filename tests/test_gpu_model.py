@@ -1032,3 +1032,43 @@ def test_fused_qkv_attention_engine_path_with_the_layernorm_fold(gpu_device, mon
         assert torch.nn.functional.cosine_similarity(a, b, dim=-1).min().item() >= 0.99995
     w = eng.run(img, tok)
     assert torch.equal(w["fv"], f1i) and torch.equal(w["ft"], f1t)
+
+
+def test_eval_input_pipeline_matches_the_single_threaded_loader(gpu_device, tmp_path):
+    """msclip_amd.zeroshot.ImagePipeline (decoding threads -> pinned uint8 staging -> copy stream -> normalisation by table look-up
+    on the GPU; reference tools/zero_shot.py:70-81, 202-217, 262) against the single-threaded PIL + numpy loop that defines the
+    arithmetic: the pixel tensors are bit-identical, hence logits and top-1 too -- over several batches incl. a ragged last one,
+    mixed sizes / modes (RGB, L, RGBA, portrait / landscape)."""
+    from PIL import Image
+    from msclip_amd import zeroshot
+    rng = np.random.default_rng(11)
+    n_cls, per = 4, 9
+    for c in range(n_cls):
+        (tmp_path / "val" / f"n{c:02d}").mkdir(parents=True)
+        for k in range(per):
+            h, w = int(rng.integers(180, 420)), int(rng.integers(180, 420))
+            a = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+            img = Image.fromarray(a)
+            if k % 4 == 1:
+                img = img.convert("L")
+            if k % 4 == 2:
+                img = img.convert("RGBA")
+            img.save(tmp_path / "val" / f"n{c:02d}" / f"{k}.{'png' if k % 2 else 'jpg'}")
+    _, items = zeroshot.image_folder(str(tmp_path / "val"))
+    pipe = zeroshot.ImagePipeline(items, 8, "cuda", workers=4)
+    got = [(x.clone(), y.clone(), n) for x, y, n in pipe]
+    pipe.close()
+    assert sum(n for _, _, n in got) == len(items) == n_cls * per and got[-1][2] == len(items) % 8
+    ref = torch.stack([zeroshot.preprocess(Image.open(p)) for p, _ in items])
+    assert torch.equal(torch.cat([x for x, _, _ in got]).cpu(), ref)
+    assert torch.cat([y for _, y, _ in got]).cpu().tolist() == [c for _, c in items]
+    m = model_for("b32-yfcc-msclips")
+
+    class Tok:
+        def __call__(self, texts, context_length=77):
+            return synth.synth_tokens(len(texts), seed=len(texts[0]))
+    classes, templates = [f"c{i}" for i in range(n_cls)], ["a photo of a {}.", "art of the {}."]
+    a = zeroshot.evaluate(m, Tok(), str(tmp_path / "val"), classes, templates, batch_size=8, log=lambda s: None, return_logits=True, workers=3)
+    b = zeroshot.evaluate(m, Tok(), str(tmp_path / "val"), classes, templates, batch_size=8, log=lambda s: None, return_logits=True, workers=0)
+    assert torch.equal(a["logits"], b["logits"]) and a["top1"] == b["top1"] and a["n"] == b["n"] == len(items)
+    assert a["loader_threads"] == 3 and b["loader_threads"] == 0 and a["images_per_s"] > 0

@@ -37,6 +37,9 @@ def parse_args(argv=None):
     ap.add_argument("--bpe", default=None, help="merges table (default: the packaged one)")
     ap.add_argument("--max-images", type=int, default=None)
     ap.add_argument("--max-classes", type=int, default=None, help="use only the first C class directories / names")
+    ap.add_argument("--workers", type=int, default=None,
+                    help="decoding threads of the input pipeline (default: config WORKERS, the reference's DataLoader setting, "
+                         "zero_shot.py:70-81; 0 = the single-threaded loader)")
     ap.add_argument("opts", help="Modify config options using the command-line", default=None, nargs=argparse.REMAINDER)
     return ap.parse_args(argv)
 
@@ -85,7 +88,8 @@ def zero_shot(args, ds_yaml, log=print):
                             batch_size=config.TEST.BATCH_SIZE_PER_GPU, max_images=args.max_images,
                             max_classes=args.max_classes, size=config.TEST.IMAGE_SIZE[0], mean=config.INPUT.MEAN,
                             std=config.INPUT.STD, dataset=config.DATASET.DATASET,
-                            metric=config.TEST.get("METRIC", "accuracy"), log=log)
+                            metric=config.TEST.get("METRIC", "accuracy"), log=log,
+                            workers=args.workers if args.workers is not None else config.get("WORKERS", None))
     return res
 
 
