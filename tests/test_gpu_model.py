@@ -1053,7 +1053,7 @@ def test_eval_input_pipeline_matches_the_single_threaded_loader(gpu_device, tmp_
                 img = img.convert("L")
             if k % 4 == 2:
                 img = img.convert("RGBA")
-            img.save(tmp_path / "val" / f"n{c:02d}" / f"{k}.{'png' if k % 2 else 'jpg'}")
+            img.save(tmp_path / "val" / f"n{c:02d}" / f"{k}.{'png' if (k % 2 or img.mode == 'RGBA') else 'jpg'}")
     _, items = zeroshot.image_folder(str(tmp_path / "val"))
     pipe = zeroshot.ImagePipeline(items, 8, "cuda", workers=4)
     got = [(x.clone(), y.clone(), n) for x, y, n in pipe]

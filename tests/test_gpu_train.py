@@ -1148,3 +1148,62 @@ def test_table_driven_repack_is_the_tensor_algebra_pack(gpu_device, monkeypatch,
     m.engine().refresh(force=True)                                     # tensor algebra: operands within an ulp of the table's
     f_full = m.encode_image(img)
     assert (f_table - f_full).abs().max().item() <= 1e-3 and F.cosine_similarity(f_table, f_full, dim=-1).min().item() >= 0.99999
+
+
+@pytest.mark.parametrize("bn", ["frozen", "batch"])
+def test_gradients_at_batch_32_against_reference_autograd(gpu_device, bn):
+    """Round 6: the gradient pin at batch 32 -- autograd of the REAL reference on 32 pairs, eval-mode and
+    train-mode BatchNorm (tools/make_golden.py --grads-b32), every tensor of <= 1024 elements stored in full.
+
+    The verdict's conjecture was that the batch-4 fixtures need their 25 % / cosine 0.975 bounds on the conv side and the LayerNorm
+    biases only because 4 samples condition the cancelling sums badly.  Measured: true for the LayerNorm biases and the token
+    side (every such tensor is within 10 % of abs-max / cosine >= 0.99 here, the bounds asserted below), NOT for the conv side:
+    the REFERENCE ITSELF, run under torch.autocast(bfloat16) on this batch, moves its conv-side BatchNorm gradients by up to 25 %
+    (eval) / 35 % (train-mode BN) of abs-max, median 5 % / 11 %, lowest cosine 0.986 / 0.952
+    (tools/ref_bf16_gradient_deviation.py b32-batch32 -> tests/golden/ref_bf16_gradient_deviation.json): bf16 activation / gradient
+    maps summed over 32 x 112 x 112 pixels, not the batch size.  The conv side is therefore bounded by that yardstick -- no further
+    from the fp32 reference than the reference's own bf16 run -- tensor by tensor for the worst case, and in the median."""
+    import os
+    name = "b32-yfcc-msclips"
+    g = np.load(os.path.join(GOLDEN, f"{name}.grads{'_trainbn' if bn == 'batch' else ''}_b32.npz"))
+    dev = _reference_bf16_deviation("train_bn_batch32" if bn == "batch" else "eval_bn_batch32", name)
+    m = _fresh_model(name)
+    ts = train.TrainStep(m, lr=1e-4, bn=bn)
+    b = int(g["batch"])
+    assert b == 32
+    img = synth.synth_images(b, seed=int(g["seed"])).cuda()
+    tok = synth.synth_tokens(b, seed=int(g["seed"]) + 1).cuda()
+    loss = ts.forward(img, tok)
+    assert abs(loss.item() - float(g["loss"])) <= 2e-2, (loss.item(), float(g["loss"]))
+    grads = ts.backward()
+    expect = [k[2:] for k in g.files if k.startswith("g_")]
+    assert sorted(grads) == sorted(expect) and len(expect) == 325
+    worst, am, coss = {}, {}, {}
+    for k in expect:
+        sm, ref = summarize(grads[k]), g["g_" + k]
+        worst[k] = float(np.abs(sm[2:] - ref[2:]).max() / max(float(g["gmax_" + k]), 1e-12))
+        am[k] = abs(sm[1] - ref[1]) / (ref[1] + 1e-12)
+        if "gfull_" + k in g.files:
+            coss[k] = F.cosine_similarity(grads[k].float().cpu().flatten(), torch.from_numpy(g["gfull_" + k]).flatten(), dim=0).item()
+    conv_keys = [k for k in expect if any(f in k for f in CONV_SIDE)]
+    lnb_keys = [k for k in expect if k.endswith(("ln_1.bias", "ln_2.bias", "ln_final.bias", "ln_post.bias", "ln_pre.bias", "ln_adapt.bias"))]
+    tok_keys = [k for k in expect if k not in conv_keys and k not in lnb_keys]
+    vec = [k for k in coss if grads[k].numel() > 1]
+    conv_med, conv_worst = float(np.median([worst[k] for k in conv_keys])), max(worst[k] for k in conv_keys)
+    conv_cos = min(coss[k] for k in conv_keys if k in vec)
+    print(f"batch 32, bn={bn}: {len(expect)} tensors, {len(coss)} compared in full | token side median "
+          f"{float(np.median([worst[k] for k in tok_keys])):.4f} worst {max(worst[k] for k in tok_keys):.4f} | LayerNorm biases worst "
+          f"{max(worst[k] for k in lnb_keys):.4f} cosine {min(coss[k] for k in lnb_keys if k in coss):.4f} | conv side median {conv_med:.4f} "
+          f"(reference bf16: {dev['conv_side']['sample_err_median']:.4f}) worst {conv_worst:.4f} ({dev['conv_side']['sample_err_worst']:.4f}) "
+          f"cosine {conv_cos:.4f} ({dev['conv_side']['cosine_lowest']:.4f})")
+    for k in tok_keys + lnb_keys:
+        scalar = grads[k].numel() == 1                  # logit_scale: one number, a sum of cancelling terms (the yardstick's worst token-side tensor)
+        assert worst[k] <= (max(0.10, dev["token_side"]["sample_err_worst"] + 0.02) if scalar else 0.10), (k, worst[k])
+        if k in coss and not scalar:
+            assert coss[k] >= 0.99, (k, coss[k])
+    assert float(np.median([worst[k] for k in tok_keys])) <= 1.25 * dev["token_side"]["sample_err_median"] + 5e-3
+    for k in conv_keys:
+        assert worst[k] <= dev["conv_side"]["sample_err_worst"] + 0.02, (k, worst[k])
+        if k in vec:
+            assert coss[k] >= dev["conv_side"]["cosine_lowest"] - 5e-3, (k, coss[k])
+    assert conv_med <= dev["conv_side"]["sample_err_median"] + 5e-3, (conv_med, dev["conv_side"]["sample_err_median"])

@@ -36,6 +36,15 @@ def summarize(t):
     return np.concatenate([[f.mean().item(), f.abs().mean().item()], f[idx].numpy()]).astype(np.float32)
 
 
+def build_only(name):
+    """The reference module with the synthetic weights loaded, without writing the forward fixtures."""
+    model, cfg = R.build_reference_model(name)
+    sd = synth.synth_state_dict(synth.schema_of(model), seed=SEED)
+    missing, unexpected = model.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    return model, cfg
+
+
 def run_config(name):
     model, cfg = R.build_reference_model(name)
     schema = synth.schema_of(model)
@@ -146,7 +155,7 @@ def zeroshot_fixture(model, name):
     print(f"{name}: zero-shot fixture top1 {top1:.2f}% on 64 generated images, W {tuple(W.shape)}")
 
 
-def grads_fixture(model, name, train_bn=False, batch=None):
+def grads_fixture(model, name, train_bn=False, batch=None, tag=None, full_limit=4096):
     """f3 (backward) fixture: autograd of the REAL reference through forward(image, text) and the symmetric CE
     0.5 * (CE(logits) + CE(logits^T)) (the loss itself is not in the reference), eval-mode BatchNorm,
     fp32, the golden batch.  Stored per parameter: mean, abs-mean, abs-max and a 64-point strided sample of the gradient (the
@@ -178,7 +187,7 @@ def grads_fixture(model, name, train_bn=False, batch=None):
         seen[id(p)] = k
         out["g_" + k] = summarize(p.grad)
         out["gmax_" + k] = np.float32(p.grad.abs().max().item())
-        if p.grad.numel() <= 4096:
+        if p.grad.numel() <= full_limit:
             out["gfull_" + k] = p.grad.detach().numpy().astype(np.float32)
     if train_bn:
         after = model.state_dict()
@@ -186,7 +195,7 @@ def grads_fixture(model, name, train_bn=False, batch=None):
             out["run_" + k] = after[k].detach().numpy().astype(np.float32)
         model.load_state_dict({**after, **before})         # put the statistics back: later fixtures start from the same model
         model.eval()
-    np.savez_compressed(os.path.join(OUT, f"{name}.grads{'_trainbn' if train_bn else ''}.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, f"{name}.grads{'_trainbn' if train_bn else ''}{tag or ''}.npz"), **out)
     print(f"{name}: grads fixture{' (train-mode BN)' if train_bn else ''}, loss {loss.item():.5f}, "
           f"{sum(k.startswith('g_') for k in out)} gradient tensors")
     for p in model.parameters():
@@ -297,6 +306,14 @@ def main():
     torch.set_num_threads(8)
     if "--prompt-features-only" in sys.argv:
         return refresh_prompt_features()
+    if "--grads-b32" in sys.argv:
+        # round 6: the same reference-autograd fixtures at batch 32, where the cancelling sums behind the
+        # conv-side and LayerNorm-bias gradients are well conditioned (the batch-4 fixture could not see a 10 % systematic error
+        # there).  Sampled summaries + full copies of the <= 1024-element tensors keep each file under 2 MB.
+        model, _ = build_only("b32-yfcc-msclips")
+        grads_fixture(model, "b32-yfcc-msclips", batch=32, tag="_b32", full_limit=1024)
+        grads_fixture(model, "b32-yfcc-msclips", train_bn=True, batch=32, tag="_b32", full_limit=1024)
+        return
     if "--l16" in sys.argv:
         return l16_fixture()
     if "--l14" in sys.argv:                      # BASELINE config C5 proper: patch-14 conv stem, 16 x 16 grid (experiments/model/l14-fp8-msclips.yaml)

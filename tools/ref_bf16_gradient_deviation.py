@@ -93,6 +93,8 @@ def main():
                    "tests/test_gpu_train.py; top-level tags: b32-yfcc-msclips, other models under their name; the batches "
                    "are the gradient fixtures' (tools/make_golden.py::grads_fixture)")
     out["model"] = "b32-yfcc-msclips"
+    if only == "b32-batch32":               # round 6: the yardstick of the batch-32 gradient fixtures (tools/make_golden.py --grads-b32)
+        out.update(run_model("b32-yfcc-msclips", (("eval_bn_batch32", 32, False), ("train_bn_batch32", 32, True))))
     if only in (None, "b32-yfcc-msclips"):
         out.update(run_model("b32-yfcc-msclips", (("eval_bn_batch4", 4, False), ("train_bn_batch16", 16, True))))
     if only in (None, "b16-yfcc-msclips"):
