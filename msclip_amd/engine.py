@@ -744,8 +744,10 @@ class Engine:
     def _attention_text(self, w, QKV, AO, Bt):
         Mv, M = w["Mv"], w["M"]
         if w.get("packed"):
-            return hip.attention_varlen(QKV[Mv:M], AO[Mv:M], w["cu"], Bt, w["Lmax"], self.heads, True, pad_rows=w["pad"],
-                                        dims=w["dims"] if w.get("dyn") else None)
+            # (always the context-length instantiation: on packed captions the 3-tile kernel measures 34 us where the 2-tile one
+            #  a longest caption <= 64 would select takes 47 us, profiles/r06_attention_wpb_occupancy_probe.txt)
+            return hip.attention_varlen(QKV[Mv:M], AO[Mv:M], w["cu"], Bt, max(w["Lmax"], min(self.Lt, 96)), self.heads, True,
+                                        pad_rows=w["pad"], dims=w["dims"] if w.get("dyn") else None)
         hip.attention(QKV[Mv:M], AO[Mv:M], Bt, self.Lt, self.heads, True)
 
     def _tap_text(self, taps, name, t, w, Bt):
