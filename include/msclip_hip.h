@@ -574,6 +574,10 @@ int msclip_bn_fold_bwd(const float* G, long long ldg, const float* w_raw, int co
 int msclip_bn_finish(const float* sums, int r, int C, long long n, const float* gamma, const float* beta, float eps, float* out,
                      void* stream);
 
+/* Allocates what the library would otherwise allocate lazily on the current device (the column sums' ticket counters): call once
+ * per device before capturing a stream or recording a launch plan that contains training-step launches. */
+int msclip_prepare_device(void);
+
 /* ---- Launch plans (round 6; no reference counterpart: the reference's step is a Python loop over ATen calls, M.py:2388-2459,
  * 3126-3141).  A plan is the launch table of one step: while a plan is recording on the calling thread every stream-ordered entry
  * point of this library appends (itself, a copy of its arguments, the slot of its stream) before doing its work -- the recording

@@ -310,20 +310,11 @@ int launch_bwd(const void* qkv, const void* o, const void* dout, void* dqkv, int
   // 96 tokens: 94 KB -> one workgroup of 8 waves
   constexpr int BW = NT16 <= 4 ? 4 : 8;
   const size_t lds = (size_t)(4 * LP * RS + 2 * LP * LS) * 2 + LP * 4 + 2 * (3 * 4 * NT16 * 16) * 4;
-  static bool done = false;
-  if (!done && lds > 65536) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<NT16, CAUSAL, BW>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    done = true;
-  }
+  bool attr_ok = true;
+  if (lds > 65536) MSCLIP_LDS_ATTR((&attn_bwd_kernel<NT16, CAUSAL, BW>), lds, attr_ok);
+  (void)attr_ok;
   const int extra = cu ? (pad_rows + BW - 1) / BW : 0;
-  static int ncu = 0;
-  if (!ncu) {
-    hipDeviceProp_t p;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    ncu = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
-  }
+  const int ncu = msclip_device_cus();
   const int pairs = nsamples * H;
   const int per_cu = NT16 <= 4 ? 2 : 1;
   const int pblocks = pairs < ncu * per_cu ? pairs : ncu * per_cu;
@@ -571,12 +562,9 @@ int launch_bwd_qb(const void* qkv, const void* o, const void* dout, void* dqkv, 
                   hipStream_t st) {
   constexpr int LP = NT16 * 16, LPK = (LP + 31) / 32 * 32, LS = LPK + 8, QB = 32, QS = QB + 8;
   const size_t lds = (size_t)(2 * LP * RS + 64 * LS + 2 * QB * RS + 2 * 64 * QS + 2 * LP * QS + QB * LS) * 2 + (1 + QB_WAVES) * QB * 4;
-  static bool done = false;
-  if (!done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_qb_kernel<NT16, CAUSAL>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    done = true;
-  }
+  bool attr_ok = true;
+  MSCLIP_LDS_ATTR((&attn_bwd_qb_kernel<NT16, CAUSAL>), lds, attr_ok);
+  (void)attr_ok;
   hipLaunchKernelGGL((attn_bwd_qb_kernel<NT16, CAUSAL>), dim3(nsamples * H), dim3(64 * QB_WAVES), lds, st, (const bf16_t*)qkv,
                      (const bf16_t*)o, (const bf16_t*)dout, (bf16_t*)dqkv, L, H, ldq, ldo);
   return msclip_launch_status();

@@ -881,6 +881,10 @@ static unsigned* colsum_counters(int n) {
   return p;
 }
 
+// Everything this library allocates lazily on a device (today: the ticket-counter ring of the single-launch column sums), done
+// up front -- a first use inside a stream capture or a launch-plan replay must not hipMalloc / synchronise.
+extern "C" int msclip_prepare_device(void) { return colsum_counters(0) ? MSCLIP_OK : MSCLIP_ELAUNCH; }
+
 extern "C" int msclip_colsum(const void* x, int ld, int is_f32, float* out, int M, int N, int accumulate, float* scratch,
                              int chunks, void* stream) {
   MSCLIP_PLAN_HOOK(msclip_colsum, stream, x, ld, is_f32, out, M, N, accumulate, scratch, chunks);

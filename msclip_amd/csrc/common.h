@@ -16,6 +16,36 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define MSCLIP_EINVAL (-1)
 #define MSCLIP_ELAUNCH (-2)
 
+// ---- per-DEVICE host-side caches (a process may drive more than one GPU: function attributes and CU counts belong to the device
+// that is current at the call).  Devices beyond the table fall back to slot 0 semantics that re-query every time.
+constexpr int MSCLIP_MAXDEV = 16;
+static inline int msclip_dev_index() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MSCLIP_MAXDEV) return -1;
+  return dev;
+}
+static inline int msclip_device_cus() {
+  static int ncus[MSCLIP_MAXDEV] = {};
+  const int di = msclip_dev_index();
+  if (di >= 0 && ncus[di]) return ncus[di];
+  int dev = 0, n = 0;
+  (void)hipGetDevice(&dev);
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  if (di >= 0) ncus[di] = n;
+  return n;
+}
+// hipFuncAttributeMaxDynamicSharedMemorySize of `kernel`, set once per device (static table per expansion site = per instantiation)
+#define MSCLIP_LDS_ATTR(kernel, bytes, ok)                                                                         \
+  do {                                                                                                             \
+    static bool done_[MSCLIP_MAXDEV] = {};                                                                         \
+    const int di_ = msclip_dev_index();                                                                            \
+    if (di_ < 0 || !done_[di_]) {                                                                                  \
+      (ok) = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                 (int)(bytes)) == hipSuccess;                                                      \
+      if (di_ >= 0) done_[di_] = (ok);                                                                             \
+    }                                                                                                              \
+  } while (0)
+
 static inline int msclip_launch_status() {
   return hipGetLastError() == hipSuccess ? MSCLIP_OK : MSCLIP_ELAUNCH;
 }

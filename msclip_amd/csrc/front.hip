@@ -809,13 +809,9 @@ int launch_front(FrontArgs a, hipStream_t st) {
   // the 8-wave stem kernel fetches the image in aligned 4-pixel pieces: other widths take the single-group kernel
   if ((old4 && old4[0] == '1') || (PROD == 0 && a.Wimg % 4 != 0)) {
     const size_t lds = (size_t)NTT * 16 * WS + MIDB + (PROD == 0 ? PSTB + PATCHB : 0);
-    static bool attr_done = false;
-    if (!attr_done) {
-      if (hipFuncSetAttribute((const void*)front_kernel<PROD, NTT, InT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds) != hipSuccess)
-        return MSCLIP_ELAUNCH;
-      attr_done = true;
-    }
+    bool attr_ok = true;
+    MSCLIP_LDS_ATTR((front_kernel<PROD, NTT, InT>), lds, attr_ok);
+    if (!attr_ok) return MSCLIP_ELAUNCH;
     const int per_cu = (int)(160 * 1024 / lds) > 2 ? 2 : (int)(160 * 1024 / lds);
     int grid = ncu * (per_cu < 1 ? 1 : per_cu);
     if (grid > a.ntile) grid = a.ntile;
@@ -823,13 +819,9 @@ int launch_front(FrontArgs a, hipStream_t st) {
     return msclip_launch_status();
   }
   const size_t lds = (size_t)2 * MIDB + (PROD == 0 ? PSTB + PATCHB : 0) + (size_t)NTT * 16 * WS2 + 128;
-  static bool attr_ws = false;
-  if (!attr_ws) {
-    if (hipFuncSetAttribute((const void*)front_ws_kernel<PROD, NTT, InT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess)
-      return MSCLIP_ELAUNCH;
-    attr_ws = true;
-  }
+  bool attr_ok = true;
+  MSCLIP_LDS_ATTR((front_ws_kernel<PROD, NTT, InT>), lds, attr_ok);
+  if (!attr_ok) return MSCLIP_ELAUNCH;
   int grid = ncu;                                               // one 8-wave workgroup per CU, persistent
   if (grid > a.ntile) grid = a.ntile;
   hipLaunchKernelGGL((front_ws_kernel<PROD, NTT, InT>), dim3(grid), dim3(512), lds, st, a);
@@ -842,13 +834,9 @@ int launch_block_tail(FrontArgs a, hipStream_t st) {
       hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
     ncu = 256;
   const size_t lds = (size_t)2 * MIDB + (size_t)3 * 16 * WS2 + 128 + 2 * 64 * RS + 96 * RS;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)front_ws_kernel<1, 3, bf16_t, true>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return MSCLIP_ELAUNCH;
-    attr_done = true;
-  }
+  bool attr_ok = true;
+  MSCLIP_LDS_ATTR((front_ws_kernel<1, 3, bf16_t, true>), lds, attr_ok);
+  if (!attr_ok) return MSCLIP_ELAUNCH;
   int grid = ncu;
   if (grid > a.ntile) grid = a.ntile;
   hipLaunchKernelGGL((front_ws_kernel<1, 3, bf16_t, true>), dim3(grid), dim3(512), lds, st, a);

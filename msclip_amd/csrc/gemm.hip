@@ -1030,13 +1030,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const msclip_gemm_desc a_i
 
 template <int MODE, int BM, int BN, int WM, int WN>
 static void launch_cfg(const msclip_gemm_desc* d, hipStream_t st, int blocks_per_cu) {
-  static int ncu = 0;
-  if (!ncu) {
-    hipDeviceProp_t p;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    ncu = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
-  }
+  const int ncu = msclip_device_cus();
   const int tiles = ((d->M + BM - 1) / BM) * ((d->N + BN - 1) / BN);
   const int cap = ncu * blocks_per_cu;
   const int grid = tiles < cap ? tiles : cap;
@@ -1047,16 +1041,7 @@ static void launch_cfg(const msclip_gemm_desc* d, hipStream_t st, int blocks_per
 bool msclip_gemm_small_try(const msclip_gemm_desc* d, hipStream_t st, int ncu);   // gemm_small.hip
 bool msclip_gemm_small_eligible(const msclip_gemm_desc* d);
 
-static int device_cus() {
-  static int ncu = 0;
-  if (!ncu) {
-    hipDeviceProp_t p;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    ncu = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
-  }
-  return ncu;
-}
+static int device_cus() { return msclip_device_cus(); }
 
 // ---- kernel choice: ONE function decides, msclip_gemm launches what it says and msclip_gemm_variant reports it
 enum GemmVariant { GV_INVALID = 0, GV_STREAM, GV_PP, GV_DENSE128, GV_PPCONV, GV_CONV192, GV_CONV128, GV_DENSE192 };

@@ -255,12 +255,9 @@ void launch_stream(const msclip_gemm_desc* d, hipStream_t st, int ncu, int wg_pe
   const int chunks = (d->N + NW - 1) / NW;
   const size_t lds = (size_t)NW * (NKC * 128 + 16) + NW * 4 + SWV * SSTG_BYTES;
   if (lds > 65536) {
-    static bool done = false;                                   // per instantiation
-    if (!done) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_stream_kernel<NT, NKC, CONV, SWV>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      done = true;
-    }
+    bool attr_ok = true;                                        // (per instantiation and device)
+    MSCLIP_LDS_ATTR((&gemm_stream_kernel<NT, NKC, CONV, SWV>), lds, attr_ok);
+    (void)attr_ok;
   }
   const int nblk = (d->M + 31) / 32;
   int gx = (wg_per_cu * ncu + chunks - 1) / chunks;

@@ -415,13 +415,7 @@ extern "C" int msclip_qkv_attention(const msclip_qkvattn_desc* d, void* stream) 
   if (d->rowstat && !d->csum) return MSCLIP_EINVAL;
   if (d->W2 && (!d->bias2 || (d->rowstat && !d->csum2) || d->seg_split <= 0)) return MSCLIP_EINVAL;
   if (((size_t)d->bias | (size_t)d->csum | (size_t)d->bias2 | (size_t)d->csum2) & 15) return MSCLIP_EINVAL;
-  static int ncu = 0;
-  if (!ncu) {
-    hipDeviceProp_t p;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    ncu = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
-  }
+  const int ncu = msclip_device_cus();
   int grid = ncu;
   if (!d->ntiles_dev && d->ntiles * d->heads < grid) grid = d->ntiles * d->heads;
   hipLaunchKernelGGL(qkv_attn_kernel, dim3(grid), dim3(NTH), 0, (hipStream_t)stream, *d);

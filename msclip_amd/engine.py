@@ -876,20 +876,30 @@ class Engine:
         for bw in blocks.values():
             bw.hid_scale, bw.wpr_cs = None, None
         self._calib = {}
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        failure, objs, amax = None, [], None
         try:
             self.run(img, tok)
             if not self._calib:
                 raise RuntimeError("calibrate_fp8: no layer recorded a hidden-matrix maximum (did the batch reach the fp8 MLP?)")
             objs = [bw for bw, _ in self._calib.values()]
             amax = torch.stack([torch.stack(vals).amax() for _, vals in self._calib.values()])
-        except BaseException:
-            self._calib = None
-            if saved:                                        # a failed re-calibration keeps the previous scales
-                self.load_fp8_state(saved)
-            raise
+        except Exception as exc:                             # (rank-local: the other ranks are about to enter a collective)
+            failure = exc
         finally:
             self._calib = None
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if multi:
+            # agree on success BEFORE the collective over the maxima: a rank that failed locally must not leave the others
+            # hanging in the all-reduce -- every rank learns that some rank failed and raises
+            flag = torch.tensor([0.0 if failure is None else 1.0], device=self.dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if failure is None and flag.item() > 0:
+                failure = RuntimeError("calibrate_fp8 failed on another rank")
+        if failure is not None:
+            if saved:                                        # a failed re-calibration keeps the previous scales
+                self.load_fp8_state(saved)
+            raise failure
+        if multi:
             dist.all_reduce(amax, op=dist.ReduceOp.MAX)
         host = amax.cpu().tolist()                           # the one host read of the calibration
         for bw, a in zip(objs, host):

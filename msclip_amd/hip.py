@@ -35,7 +35,7 @@ EXPORTS = (
     "msclip_plan_wait_event", "msclip_plan_end", "msclip_plan_abort", "msclip_plan_info", "msclip_plan_op_name", "msclip_plan_run",
     "msclip_plan_size", "msclip_plan_probe_enable", "msclip_plan_probe_disable", "msclip_plan_probe_runs", "msclip_plan_probe_elapsed",
     "msclip_comm_unique_id", "msclip_comm_init", "msclip_comm_destroy", "msclip_comm_async_error", "msclip_allgather_feats",
-    "msclip_allreduce",
+    "msclip_allreduce", "msclip_prepare_device",
 )
 
 
@@ -216,10 +216,17 @@ def env_flag(name):
     return os.environ.get(name, "0") == "1"
 
 
+_PREPARED = set()
+
+
 def require_gpu():
     if not torch.cuda.is_available():
         raise HipUnavailable("no HIP device visible: msclip_amd has no CPU path (use oracle/ only as a test checker)")
-    lib()
+    L = lib()
+    dev = torch.cuda.current_device()
+    if dev not in _PREPARED:                          # lazy per-device allocations of the library, done outside any capture / plan
+        _check(L.msclip_prepare_device(), "msclip_prepare_device")
+        _PREPARED.add(dev)
 
 
 def _check(rc, what):
