@@ -178,7 +178,14 @@ def cpu_baseline(name, sd, batch=32, iters=3):
         for _ in range(iters):
             O.contrastive_loss(O.forward(img, tok, sd, arch))
         dt = (time.perf_counter() - t0) / iters
-    return {"value": round(batch / dt, 3), "unit": "pairs/s", "cores": cores, "kind": "port",
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.lower().startswith("model name")), "unknown")
+    except OSError:
+        pass
+    return {"value": round(batch / dt, 3), "unit": "pairs/s", "cores": cores, "kind": "port", "cpu_model": cpu_model,
+            "host_cores_total": os.cpu_count(),
             "sample": f"{iters} x forward+loss of {batch} pairs, fp32 torch CPU oracle, {torch.get_num_threads()} threads"}
 
 
@@ -540,8 +547,9 @@ def main():
                 rec["mfma_util_pct"] = rec[key]["mfma_busy_pct_whole_step"]      # BASELINE metric's second half (all kernels of a step)
         if world == 1 and ts is None and not args.no_hbm_kernels and not args.no_pmc:
             wsp = eng._workspace(B, B)
+            live = int(lens_host.sum()) if eng.text_pack_enabled() else None      # (device-side row counts: the host copy of the lengths says it)
             rec["hbm_bound_kernels"] = hbm_kernel_rates(args, B, WIDTH[args.model], eng.Lv, eng.Lt, eng.g,
-                                                        Mt_live=wsp.get("Mt_live"), Mt_rows=wsp.get("Mt"))
+                                                        Mt_live=live, Mt_rows=wsp.get("Mt"))
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(args.model, sd)
         if grouped:                     # RCCL's version banner sits in libc's stdout buffer: out with it BEFORE the record, so
