@@ -93,20 +93,7 @@ def preprocess(img, size=224, mean=IMAGENET_MEAN, std=IMAGENET_STD):
     return torch.from_numpy(np.ascontiguousarray(x.transpose(2, 0, 1)))
 
 
-def load_pixels(path, size=224):
-    """Image file -> uint8 [size, size, 3]: the geometric half of `preprocess` (decode, shorter side to `size` bicubic, centre
-    crop).  PIL releases the GIL in its decoders and resamplers, so a thread pool scales over the host cores."""
-    from PIL import Image
-    with Image.open(path) as im:
-        img = im.convert("RGB")
-    w, h = img.size
-    if w <= h:
-        nw, nh = size, int(size * h / w)
-    else:
-        nw, nh = int(size * w / h), size
-    img = img.resize((nw, nh), Image.BICUBIC)
-    left, top = int(round((nw - size) / 2.0)), int(round((nh - size) / 2.0))
-    return np.array(img.crop((left, top, left + size, top + size)), dtype=np.uint8)
+from ._decode_worker import load_pixels            # noqa: E402  (decode + bicubic resize + centre crop -> uint8 [size, size, 3])
 
 
 def normalise_lut(mean=IMAGENET_MEAN, std=IMAGENET_STD):
@@ -124,12 +111,41 @@ class ImagePipeline:
     bit-identical to the host arithmetic) into the NCHW fp32 tensor encode_image takes.  Iterating yields (images, labels,
     n) with the next batches' decoding and copies already in flight."""
 
-    def __init__(self, items, batch_size, device, size=224, mean=IMAGENET_MEAN, std=IMAGENET_STD, workers=None, depth=3):
+    def __init__(self, items, batch_size, device, size=224, mean=IMAGENET_MEAN, std=IMAGENET_STD, workers=None, depth=3, processes=0):
         import concurrent.futures as cf
         self.items, self.bs, self.dev, self.size = list(items), int(batch_size), torch.device(device), size
-        self.workers = max(1, min(64, (os.cpu_count() or 2)) if workers is None else int(workers))
-        self.pool = cf.ThreadPoolExecutor(self.workers)
+        self.workers = max(1, min(16, (os.cpu_count() or 2)) if workers is None else int(workers))
         self.depth = max(2, depth)
+        self.processes = int(processes or 0)
+        self.pool = self.shm = None
+        if self.processes > 0:
+            # decoding PROCESSES (no GIL between them): plain subprocesses of msclip_amd._decode_worker (numpy + PIL only; neither
+            # forks of this process with its live HIP runtime nor multiprocessing children that re-import __main__), writing into
+            # one shared-memory staging area [depth, batch, size, size, 3]; a task = a run of 8 files of a batch, dealt round-robin
+            import queue
+            import subprocess
+            import sys
+            import threading
+            from multiprocessing import shared_memory
+            self.shm = shared_memory.SharedMemory(create=True, size=self.depth * self.bs * size * size * 3)
+            self.shm_np = np.ndarray((self.depth, self.bs, size, size, 3), dtype=np.uint8, buffer=self.shm.buf)
+            pkg_parent = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            env = dict(os.environ, PYTHONPATH=pkg_parent + os.pathsep + os.environ.get("PYTHONPATH", ""))
+            self.procs = [subprocess.Popen([sys.executable, "-u", "-m", "msclip_amd._decode_worker", self.shm.name, str(self.depth),
+                                            str(self.bs), str(size)], stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env, text=True,
+                                           bufsize=1) for _ in range(self.processes)]
+            self.done_q = queue.Queue()
+
+            def reader(proc):
+                for line in proc.stdout:
+                    self.done_q.put(json.loads(line))
+                self.done_q.put([-1, 0, "a decoding process exited"])
+            self.readers = [threading.Thread(target=reader, args=(p,), daemon=True) for p in self.procs]
+            for t in self.readers:
+                t.start()
+            self.pending, self.rr = {}, 0
+        else:
+            self.pool = cf.ThreadPoolExecutor(self.workers)
         self.pin = [torch.empty(self.bs, size, size, 3, dtype=torch.uint8).pin_memory() for _ in range(self.depth)]
         self.gpu = [torch.empty(self.bs, size, size, 3, dtype=torch.uint8, device=self.dev) for _ in range(self.depth)]
         self.free = [torch.cuda.Event() for _ in range(self.depth)]          # "the consumer is done with gpu[k]"
@@ -144,15 +160,40 @@ class ImagePipeline:
     def _submit(self, b):
         k = b % self.depth
         chunk = self.items[b * self.bs:(b + 1) * self.bs]
+        if self.processes > 0:
+            self.pending[b] = len(chunk)
+            for j0 in range(0, len(chunk), 8):
+                proc = self.procs[self.rr % self.processes]
+                self.rr += 1
+                proc.stdin.write(json.dumps([b, k, j0, [p for p, _ in chunk[j0:j0 + 8]]]) + "\n")
+                proc.stdin.flush()
+            return b, chunk
         return [self.pool.submit(self._decode_into, k, j, p) for j, (p, _) in enumerate(chunk)], chunk
+
+    def _wait(self, futs, b):
+        if self.processes == 0:
+            for f in futs:
+                f.result()                                   # (re-raises a decoding error with the worker's traceback)
+            return
+        while self.pending.get(b, 0) > 0:                    # completions of later batches are booked as they arrive
+            try:
+                bb, n, err = self.done_q.get(timeout=120)
+            except Exception:
+                raise RuntimeError("ImagePipeline: the decoding processes do not answer") from None
+            if err is not None:
+                raise RuntimeError("ImagePipeline: decoding failed in a worker process: " + err)
+            self.pending[bb] = self.pending.get(bb, 0) - n
+        del self.pending[b]
+        k = b % self.depth
+        n = min(self.bs, len(self.items) - b * self.bs)
+        self.pin[k][:n].copy_(torch.from_numpy(self.shm_np[k, :n]))
 
     def __iter__(self):
         nb = (len(self.items) + self.bs - 1) // self.bs
         inflight = {b: self._submit(b) for b in range(min(self.depth - 1, nb))}
         for b in range(nb):
             futs, chunk = inflight.pop(b)
-            for f in futs:
-                f.result()                                   # (re-raises a decoding error with the worker's traceback)
+            self._wait(futs, b)
             k, n = b % self.depth, len(chunk)
             cur = torch.cuda.current_stream(self.dev)
             with torch.cuda.stream(self.copy_stream):
@@ -166,7 +207,7 @@ class ImagePipeline:
                 # pin[nxt % depth] was the staging area of batch b - 1, whose copy was queued an iteration ago: the HOST waits for
                 # that copy before the workers overwrite the pinned buffer
                 prev = self.copied.get(nxt % self.depth)
-                if prev is not None:
+                if prev is not None and self.processes == 0:   # (threads write the pinned buffer itself; processes write shared memory)
                     prev.synchronize()
                 inflight[nxt] = self._submit(nxt)
             cur.wait_event(landed)
@@ -177,7 +218,23 @@ class ImagePipeline:
             yield x, y, n
 
     def close(self):
-        self.pool.shutdown(wait=True)
+        if self.pool is not None:
+            self.pool.shutdown(wait=True)
+        if self.shm is not None:
+            for p in self.procs:
+                try:
+                    p.stdin.close()                          # EOF ends the worker's loop
+                except Exception:
+                    pass
+            for p in self.procs:
+                try:
+                    p.wait(timeout=10)
+                except Exception:
+                    p.kill()
+            del self.shm_np
+            self.shm.close()
+            self.shm.unlink()
+            self.shm = None
 
 
 def preprocess_array(a, size=224, mean=IMAGENET_MEAN, std=IMAGENET_STD):
@@ -201,7 +258,7 @@ def image_folder(root):
 @torch.no_grad()
 def evaluate(model, tokenizer, val_root, classnames, templates, batch_size=32, device="cuda", max_images=None,
              size=224, log=print, max_classes=None, mean=IMAGENET_MEAN, std=IMAGENET_STD, dataset="imagenet",
-             metric="accuracy", return_logits=False, workers=None):
+             metric="accuracy", return_logits=False, workers=None, processes=None):
     """Full zero-shot run: returns dict(top1, top5, n, images_per_s).  Logs the reference's final line (zero_shot.py:304-308).
     max_classes keeps the first C class directories and class names (subset runs); max_images a strided subset.
     workers: decoding threads of the input pipeline (ImagePipeline; None = one per host core up to 64; 0 = the single-threaded
@@ -233,7 +290,9 @@ def evaluate(model, tokenizer, val_root, classnames, templates, batch_size=32, d
             x = torch.stack([preprocess(Image.open(p), size, mean, std) for p, _ in chunk]).to(device)
             yield x, torch.tensor([c for _, c in chunk], device=device), len(chunk)
 
-    pipe = ImagePipeline(items, batch_size, device, size, mean, std, workers) if workers != 0 else None
+    if processes is None:                  # default: decoding processes when the host has the cores for it and the run is long enough to
+        processes = min(32, (os.cpu_count() or 2) // 2) if (workers is None and len(items) >= 2048 and (os.cpu_count() or 2) >= 8) else 0
+    pipe = ImagePipeline(items, batch_size, device, size, mean, std, workers, processes=processes) if (workers != 0 or processes) else None
     t_start = time.perf_counter()
     for x, y, nb in (pipe if pipe is not None else serial()):
         chunk = range(nb)
@@ -250,10 +309,12 @@ def evaluate(model, tokenizer, val_root, classnames, templates, batch_size=32, d
         pipe.close()
     top1, top5 = 100.0 * hits1 / max(n, 1), 100.0 * hits5 / max(n, 1)
     log("=> {:.1f} images/s end to end ({} images, {})".format(n / max(elapsed, 1e-9), n,
-        f"{pipe.workers} decoding threads, pinned staging, copy stream" if pipe is not None else "single-threaded loader"))
+        (f"{pipe.processes} decoding processes" if pipe.processes else f"{pipe.workers} decoding threads") + ", pinned staging, copy stream"
+        if pipe is not None else "single-threaded loader"))
     log("=> {dataset}% TEST:\tError@1 {error1:.3f}%\t{metric}@1 {top1:.3f}%\t".format(
         dataset=dataset, metric=metric, top1=top1, error1=100.0 - top1) + "accuracy@5 {:.3f}%\t({} images)".format(top5, n))
-    res = dict(top1=top1, top5=top5, n=n, images_per_s=n / max(elapsed, 1e-9), loader_threads=pipe.workers if pipe is not None else 0)
+    res = dict(top1=top1, top5=top5, n=n, images_per_s=n / max(elapsed, 1e-9), loader_threads=(pipe.workers if pipe.processes == 0 else 0) if pipe is not None else 0,
+               loader_processes=pipe.processes if pipe is not None else 0)
     if return_logits:
         res["logits"], res["classifier"] = torch.cat(keep), W.float().cpu()
         res["labels"] = torch.tensor([c for _, c in items])

@@ -1072,3 +1072,6 @@ def test_eval_input_pipeline_matches_the_single_threaded_loader(gpu_device, tmp_
     b = zeroshot.evaluate(m, Tok(), str(tmp_path / "val"), classes, templates, batch_size=8, log=lambda s: None, return_logits=True, workers=0)
     assert torch.equal(a["logits"], b["logits"]) and a["top1"] == b["top1"] and a["n"] == b["n"] == len(items)
     assert a["loader_threads"] == 3 and b["loader_threads"] == 0 and a["images_per_s"] > 0
+    # decoding PROCESSES (plain subprocesses writing shared memory): the same pixels again
+    c = zeroshot.evaluate(m, Tok(), str(tmp_path / "val"), classes, templates, batch_size=8, log=lambda s: None, return_logits=True, processes=3)
+    assert torch.equal(c["logits"], b["logits"]) and c["loader_processes"] == 3 and c["loader_threads"] == 0

@@ -82,9 +82,16 @@ def main():
     rec["gpu_only_images_per_s"] = round(20 * a.batch / (time.perf_counter() - t0), 1)
     zeroshot.evaluate(m, tok, val, classes, templates[:4], batch_size=a.batch, max_classes=a.classes, workers=a.workers, log=quiet)   # (page cache warm)
     rec["pipeline"] = []
-    for wk in ([a.workers] if a.workers else [4, 16, 32, 64, 128]):
-        res = zeroshot.evaluate(m, tok, val, classes, templates[:4], batch_size=a.batch, max_classes=a.classes, workers=wk, log=quiet)
+    for wk in ([a.workers] if a.workers else [4, 16, 64]):
+        res = zeroshot.evaluate(m, tok, val, classes, templates[:4], batch_size=a.batch, max_classes=a.classes, workers=wk, processes=0, log=quiet)
         rec["pipeline"].append({"images_per_s": round(res["images_per_s"], 1), "threads": res["loader_threads"], "n": res["n"], "top1": res["top1"]})
+    for pr in [8, 16, 32, 64, 96]:
+        if pr > (os.cpu_count() or 1):
+            continue
+        res = zeroshot.evaluate(m, tok, val, classes, templates[:4], batch_size=a.batch, max_classes=a.classes, processes=pr, log=quiet)
+        rec["pipeline"].append({"images_per_s": round(res["images_per_s"], 1), "processes": res["loader_processes"], "n": res["n"], "top1": res["top1"]})
+    res = zeroshot.evaluate(m, tok, val, classes, templates[:4], batch_size=a.batch, max_classes=a.classes, log=quiet)      # the default choice
+    rec["default"] = {"images_per_s": round(res["images_per_s"], 1), "processes": res["loader_processes"], "threads": res["loader_threads"]}
     ser = zeroshot.evaluate(m, tok, val, classes, templates[:4], batch_size=a.batch, max_classes=a.classes, workers=0, log=quiet,
                             max_images=a.serial_images)
     rec["single_thread_loader"] = {"images_per_s": round(ser["images_per_s"], 1), "n": ser["n"]}

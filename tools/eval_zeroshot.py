@@ -40,6 +40,8 @@ def parse_args(argv=None):
     ap.add_argument("--workers", type=int, default=None,
                     help="decoding threads of the input pipeline (default: config WORKERS, the reference's DataLoader setting, "
                          "zero_shot.py:70-81; 0 = the single-threaded loader)")
+    ap.add_argument("--processes", type=int, default=None,
+                    help="decoding PROCESSES instead of threads (default: min(32, cores / 2) for runs of >= 2048 images; 0 = threads)")
     ap.add_argument("opts", help="Modify config options using the command-line", default=None, nargs=argparse.REMAINDER)
     return ap.parse_args(argv)
 
@@ -89,7 +91,7 @@ def zero_shot(args, ds_yaml, log=print):
                             max_classes=args.max_classes, size=config.TEST.IMAGE_SIZE[0], mean=config.INPUT.MEAN,
                             std=config.INPUT.STD, dataset=config.DATASET.DATASET,
                             metric=config.TEST.get("METRIC", "accuracy"), log=log,
-                            workers=args.workers if args.workers is not None else config.get("WORKERS", None))
+                            workers=args.workers if args.workers is not None else None, processes=args.processes)
     return res
 
 
