@@ -167,7 +167,8 @@ def cpu_baseline(name, sd, batch=32, iters=3):
     box's host cores: forward(image, text) + symmetric CE, fp32, on a bounded sample."""
     from msclip_amd import synth
     from oracle import msclip_oracle as O
-    cores = min(os.cpu_count() or 1, 32)     # more intra-op threads than this only adds barrier overhead on these op sizes
+    from msclip_amd.zeroshot import effective_cores
+    cores = min(effective_cores(), 32)       # usable cores (affinity + cgroup quota); more than 32 intra-op threads only adds barrier overhead
     torch.set_num_threads(cores)
     arch = (O.arch_b32() if name.startswith("b32") else O.arch_l16() if name.startswith("l16") else
             O.arch_l14() if name.startswith("l14") else O.arch_b16())
@@ -185,7 +186,7 @@ def cpu_baseline(name, sd, batch=32, iters=3):
     except OSError:
         pass
     return {"value": round(batch / dt, 3), "unit": "pairs/s", "cores": cores, "kind": "port", "cpu_model": cpu_model,
-            "host_cores_total": os.cpu_count(),
+            "host_cores_visible": os.cpu_count(), "host_cores_usable": effective_cores(),
             "sample": f"{iters} x forward+loss of {batch} pairs, fp32 torch CPU oracle, {torch.get_num_threads()} threads"}
 
 

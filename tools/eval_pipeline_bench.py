@@ -89,7 +89,8 @@ def main():
         if pr > (os.cpu_count() or 1):
             continue
         res = zeroshot.evaluate(m, tok, val, classes, templates[:4], batch_size=a.batch, max_classes=a.classes, processes=pr, log=quiet)
-        rec["pipeline"].append({"images_per_s": round(res["images_per_s"], 1), "processes": res["loader_processes"], "n": res["n"], "top1": res["top1"]})
+        rec["pipeline"].append({"images_per_s": round(res["images_per_s"], 1), "processes": res["loader_processes"], "n": res["n"], "top1": res["top1"],
+                                "elapsed_s": round(res["elapsed_s"], 2), "consumer_s": {k: round(v, 2) for k, v in res["loader_stats"].items()}})
     res = zeroshot.evaluate(m, tok, val, classes, templates[:4], batch_size=a.batch, max_classes=a.classes, log=quiet)      # the default choice
     rec["default"] = {"images_per_s": round(res["images_per_s"], 1), "processes": res["loader_processes"], "threads": res["loader_threads"]}
     ser = zeroshot.evaluate(m, tok, val, classes, templates[:4], batch_size=a.batch, max_classes=a.classes, workers=0, log=quiet,
