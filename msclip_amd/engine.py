@@ -613,6 +613,11 @@ class Engine:
         to that many CUs (hipExtStreamCreateWithCUMask), so that the branch's HBM-bound workgroups stop displacing the
         persistent GEMM workgroups of the main stream."""
         n = self.opt.side_cu_mask
+        if n <= 0 and self.opt.side_priority == "low":
+            key = (self.dev, "low")
+            if key not in _MASKED:
+                _MASKED[key] = hip.priority_stream(self.dev, urgent=False)
+            return _MASKED[key]
         if n <= 0:
             return C.side_stream(self.dev)
         key = (self.dev, n)
@@ -718,6 +723,12 @@ class Engine:
         w.update(packed=True, dyn=True, cap=None, cu=w["cu_d"], len=w["len_d"], Mt_live=None, Lmax=lmax or self.Lt, pad=255, Mt=cap,
                  M=w["Mv"] + cap, mdev_t=w["dims"][2:3], mdev_all=w["dims"][3:4])
 
+    def _text_lengths_dynamic(self, tok, w):
+        """The two tiny launches behind every device-side row count: lengths, prefix sums, EOT rows (absolute: row_base = Mv) and the
+        dims block.  Queued on the MAIN stream before the text stream forks off: a 1-workgroup scan that has to find a CU beside
+        the persistent front kernel measured 334 us instead of 6 (profiles/r06_forward_timeline.txt of the first version)."""
+        hip.text_lengths(tok, w["len_d"], w["cu_d"], w["eot"], row_base=w["Mv"], dims=w["dims"], pad_to=256, cap_rows=w["Mt_cap"])
+
     @staticmethod
     def _md(w, r0, r1):
         """The device-side row counter of a launch over rows [r0, r1) of the token matrix (None: the rows are a host-side constant)."""
@@ -733,8 +744,7 @@ class Engine:
 
     def _text_front(self, tok, w, Bt):
         if w.get("dyn"):
-            # lengths, prefix sums, EOT rows (absolute: row_base = Mv) and the dims block, then the embedding of the live rows
-            hip.text_lengths(tok, w["len_d"], w["cu_d"], w["eot"], row_base=w["Mv"], dims=w["dims"], pad_to=256, cap_rows=w["Mt_cap"])
+            # (lengths / prefix sums / EOT rows / dims block: _text_lengths_dynamic, queued by the caller in front of the stream fork)
             return hip.embed_tokens_packed(tok, self.emb, self.tpos, w["X"], w["cu"], w["Mv"], w["Mt"], rows_dev=w["mdev_t"])
         if w.get("packed"):
             torch.add(w["cap"].eot, w["Mv"], out=w["eot"])           # EOT rows of the packed segment -> rows of the token matrix
@@ -1446,6 +1456,8 @@ class Engine:
         text0 = ts = None
         if Bt and mode == "full":
             self._text_unpacked(w, Bt)
+        if mode == "dyn":
+            self._text_lengths_dynamic(tokc, w)
         if Bi and Bt and side_ok and self.vblk[0] is None and self.opt.text0_stream:
             # Text block 0 is text-only (vision slot 0 is the conv stem, M.py:2040-2051) and depends on the captions only:
             # the text front and that block run on a second side stream beside the image front (HBM-bound conv passes

@@ -33,6 +33,7 @@ class EngineOptions:
     conv_side_stream: bool = True     # MSCLIP_CONV_SIDE_STREAM: parallel conv branch + adapter tops on a side stream
     text0_stream: bool = True         # MSCLIP_TEXT0_STREAM: text front + text block 0 beside the image front
     branch_early: bool = True         # MSCLIP_BRANCH_EARLY: the branch starts behind the fused stem kernel, not the whole front
+    side_priority: str = "normal"     # MSCLIP_SIDE_PRIORITY: "low" = the conv side stream is created with the lowest HIP stream priority
     side_cu_mask: int = 0             # MSCLIP_SIDE_CUS: > 0 = the conv side stream is created with a CU mask of this many CUs
     #                                   (whole XCD-interleaved set; hipExtStreamCreateWithCUMask), 0 = an ordinary stream
     # ---- kernel / path selection kept as options (each has a test or a documented A/B that flips it)
@@ -57,6 +58,7 @@ class EngineOptions:
             conv_side_stream=_flag("MSCLIP_CONV_SIDE_STREAM", True),
             text0_stream=_flag("MSCLIP_TEXT0_STREAM", True),
             branch_early=_flag("MSCLIP_BRANCH_EARLY", True),
+            side_priority=os.environ.get("MSCLIP_SIDE_PRIORITY", "normal"),
             side_cu_mask=int(os.environ.get("MSCLIP_SIDE_CUS", "0") or 0),
             ln_fold=_flag("MSCLIP_LN_FOLD", True),
             fused_qkv_attn=_flag("MSCLIP_FUSED_QKV_ATTN", False),

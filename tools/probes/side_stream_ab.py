@@ -34,8 +34,9 @@ def main():
     base = eng.opt
     img, tok = synth.synth_images(a.batch, seed=10).cuda(), synth.synth_tokens(a.batch, seed=100).cuda()
     variants = {f"mask{c}": (base.replace(side_cu_mask=int(c)), False) for c in a.cus.split(",")}
+    variants["low_priority_side"] = (base.replace(side_priority="low"), False)
+    variants["no_text0_stream"] = (base.replace(text0_stream=False), False)
     variants["inline"] = (base.replace(conv_side_stream=False), False)
-    variants["nt2"] = (base, True)
     variants["eager"] = (base.replace(plan=False), False)
     res = {k: [] for k in variants}
     for r in range(a.rounds):
