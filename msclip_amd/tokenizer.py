@@ -11,10 +11,11 @@ defined by it).  `bpe_path=` / MSCLIP_BPE_VOCAB may point at another table in th
 full `bpe_simple_vocab_16e6.txt.gz`.
 
 Text cleaning: the reference calls `ftfy.fix_text` first (simple_tokenizer.py:54-57).  It is used when importable;
-otherwise (ftfy is not installed in this image) the text is NFC-normalised only and a warning is logged once: ids
-are identical to the reference's on text ftfy leaves alone (all ASCII, and already-normalised Unicode -- pinned by
-tests/golden/tokenizer.json, which has non-ASCII cases), and may differ on mojibake / curly quotes / ligatures /
-full-width forms that ftfy would rewrite.
+otherwise (ftfy is not installed in this image) msclip_amd.textfix.fix_text runs: a restatement of ftfy's default pipeline
+(mojibake repair, curly quotes, ligatures, full-width forms, line breaks, control characters, NFC; round 6 -- rounds 1-5 only
+NFC-normalised).  Ids are identical to the reference's on text ftfy leaves alone (all ASCII, and already-normalised Unicode --
+pinned by tests/golden/tokenizer.json, which has non-ASCII cases); on text ftfy rewrites they follow the restatement, which is
+pinned to ftfy's README examples only (parity unpinned against the package itself).
 """
 import gzip
 import html
@@ -24,6 +25,8 @@ import unicodedata
 
 import regex
 import torch
+
+from . import textfix as _textfix
 
 _PRETOKEN = regex.compile(
     r"<\|startoftext\|>|<\|endoftext\|>|'s|'t|'re|'ve|'m|'ll|'d|[\p{L}]+|[\p{N}]|[^\s\p{L}\p{N}]+", regex.IGNORECASE)
@@ -45,9 +48,9 @@ def basic_clean(text):
     else:
         if not text.isascii() and not _warned:
             _warned.append(1)
-            logging.getLogger(__name__).warning("ftfy is not installed: non-ASCII captions are NFC-normalised only "
-                                                "(token ids can differ from the reference's on text ftfy would repair)")
-        text = unicodedata.normalize("NFC", text)
+            logging.getLogger(__name__).info("ftfy is not installed: non-ASCII captions are repaired by msclip_amd.textfix "
+                                             "(a restatement of ftfy.fix_text's default pipeline)")
+        text = _textfix.fix_text(text)
     return html.unescape(html.unescape(text)).strip()
 
 

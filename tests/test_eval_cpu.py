@@ -98,3 +98,33 @@ def test_checkpoint_roundtrip_and_alias_check(tmp_path):
     torch.save(bad, tmp_path / "bad.pth")
     with pytest.raises(RuntimeError, match="disagrees"):
         checkpoint.load_pretrained(get_clip_model(named_config(name)), str(tmp_path / "bad.pth"))
+
+
+def test_text_repair_follows_ftfy_examples():
+    """msclip_amd.textfix.fix_text -- the stand-in for `ftfy.fix_text` (reference simple_tokenizer.py:54-57) where the package is
+    absent -- on the known-answer examples of ftfy's own README / docs (mojibake incl. a run embedded in healthy text and a doubly
+    mangled apostrophe, curly quotes, full-width forms, ligatures, line breaks, terminal escapes, NFC), on text it must leave alone,
+    and through the tokenizer: the repaired caption tokenises like its clean spelling."""
+    from msclip_amd import textfix
+    from msclip_amd.tokenizer import SimpleTokenizer, basic_clean
+    e_acute = "é"
+    cases = [("âœ” No problems", "✔ No problems"),
+             ("l’humanitÃ©", "l'humanit" + e_acute),
+             ("ＬＯＵＤ　ＮＯＩＳＥＳ", "LOUD NOISES"),
+             ("ﬂuﬃest", "fluffiest"),
+             ("“quoted” ‘single’", "\"quoted\" 'single'"),
+             ("doesnÃ¢â‚¬â„¢t", "doesn't"),
+             ("line one\r\nline two three", "line one\nline two\nthree"),
+             ("\x1b[36;44mblue\x1b[0m", "blue"),
+             ("é", e_acute),
+             # left alone: healthy Latin-1 text (its bytes are not UTF-8), capitals that only look like a lead byte, plain ASCII
+             ("a photo of a caf" + e_acute, "a photo of a caf" + e_acute),
+             ("SÃO PAULO", "SÃO PAULO"),
+             ("a photo of a tench.", "a photo of a tench.")]
+    for raw, want in cases:
+        assert textfix.fix_text(raw) == want, (ascii(raw), ascii(textfix.fix_text(raw)), ascii(want))
+        assert textfix.fix_text(want) == want                        # idempotent on its own output
+    tok = SimpleTokenizer()
+    for raw, want in cases[:6]:
+        assert basic_clean(raw) == basic_clean(want)
+        assert torch.equal(tok([raw]), tok([want])), ascii(raw)
