@@ -1397,6 +1397,8 @@ class Engine:
             if Bt:
                 if isinstance(tok, Captions):
                     cap, tokc = (tok if pack else None), tok.tok
+                    # a batch staged on a prefetch stream: its token tensor belongs to that stream's pool, this call reads it here
+                    tokc.record_stream(torch.cuda.current_stream(self.dev))
                 else:
                     tokc = self._check_tok(tok)
             lmax = cap.totals()[1] if (dyn and cap is not None and cap.ready()) else None

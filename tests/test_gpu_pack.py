@@ -367,3 +367,33 @@ def test_training_gradients_packed_equal_full_rows(gpu_device, monkeypatch):
     # the positional embedding's gradient rows that no caption reaches are exactly zero in both
     lmax = int(lengths(tok.cpu()).max())
     assert lmax == 77 or bool((g1["positional_embedding"][lmax:] == 0).all())
+
+
+def test_captions_staged_on_a_prefetch_stream(gpu_device, monkeypatch):
+    """a batch staged on ANOTHER stream than the one that consumes it (an input pipeline's prefetch stage,
+    Engine.stage_captions) -- its device tensors belong to the staging stream's pool, so the engine has to tell the allocator
+    about the consuming streams (record_stream) or a block freed with the batch could be handed to the next stage_captions
+    while kernels still read it.  Stage on a side stream, drop the batch right after the call, stage the next ones on the same
+    stream immediately: features equal the plain-tensor call, for the host-sized path (which reads the staged cu / eot) and the
+    device-side one."""
+    m = _model("b32-yfcc-msclips")
+    eng = m.engine()
+    B = 512
+    img = synth.synth_images(B, seed=301).cuda()
+    toks = [synth.synth_tokens(B, seed=310 + i, min_len=2 + i, max_len=30 + 9 * i).cuda() for i in range(4)]
+    ref = [eng.run(img, t)["ft"].clone() for t in toks]
+    prefetch = torch.cuda.Stream()
+    for dyn in (False, True):
+        set_opt(monkeypatch, eng, dynamic_rows=dyn, plan=dyn)
+        for rep in range(3):
+            for t, want in zip(toks, ref):
+                prefetch.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(prefetch):
+                    cap = eng.stage_captions(t.clone())              # (the clone is the prefetch stage's own buffer)
+                torch.cuda.current_stream().wait_stream(prefetch)
+                w = eng.run(img, cap)
+                del cap                                              # blocks go back to the prefetch stream's pool at once
+                with torch.cuda.stream(prefetch):                    # ... and the next stage grabs memory there while the step runs
+                    junk = [torch.full((B + 2,), -1, dtype=torch.int32, device="cuda") for _ in range(8)]
+                assert torch.equal(w["ft"], want), (dyn, rep)
+                del junk
