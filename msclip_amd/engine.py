@@ -1401,7 +1401,8 @@ class Engine:
                     tokc.record_stream(torch.cuda.current_stream(self.dev))
                 else:
                     tokc = self._check_tok(tok)
-            lmax = cap.totals()[1] if (dyn and cap is not None and cap.ready()) else None
+            lmax = None        # (device-side row counts: every launch is sized for context_length, whatever the host may know --
+            #                     the results do not depend on whether a batch was staged ahead)
             mode = "dyn" if dyn else "pack" if pack else "full"
             key = self._plan_key(Bi, Bt, imgc, mode, lmax, norm, gather, taps)
             self.last_plan = None                           # (the launch table this call ran from, if it did: bench.py's probes)
@@ -1441,8 +1442,7 @@ class Engine:
             return None
         if gather and C.comm.collectives and not self._native_collectives():
             return None
-        nt = 0 if lmax is None else 1 if lmax <= 32 else 2 if lmax <= 64 else 3
-        return (mode, nt, bool(norm), bool(gather), imgc.dtype if imgc is not None else None, self.opt)
+        return (mode, bool(norm), bool(gather), imgc.dtype if imgc is not None else None, self.opt)
 
     def drop_plans(self):
         """Forget every recorded launch table (they hold raw addresses of packed weights and workspace buffers)."""
