@@ -5,6 +5,7 @@ blocks, heads) and train_conv.py (convolutions through im2col / col2im)."""
 import torch
 
 from . import hip
+from . import options
 
 BF = torch.bfloat16
 F32 = torch.float32
@@ -13,11 +14,8 @@ F32 = torch.float32
 def _tn_ok(dy_bf, x_bf, ragged=False):
     """The token-major split-K GEMM (msclip_gemm_splitk_tn: no operand transposes).  The wide gradients (transformer
     projections) are whole 256-channel tiles on both sides; ragged=True admits any channel counts (the conv side's 48-192
-    channels: an edge tile's extra channels only reach outputs that are not stored).  MSCLIP_WGRAD_TN=0 = the transposing path
-    (A/B knob, cross-check), MSCLIP_WGRAD_TN_RAGGED=0 = only for the conv side."""
-    import os
-    if os.environ.get("MSCLIP_WGRAD_TN", "1") == "0" or (ragged and os.environ.get("MSCLIP_WGRAD_TN_RAGGED", "1") == "0"):
-        return False
+    channels: an edge tile's extra channels only reach outputs that are not stored).  Operands that do not qualify (odd strides /
+    channel counts) take the transposing path."""
     if not (dy_bf.stride(1) == 1 and x_bf.stride(1) == 1 and dy_bf.stride(0) % 8 == 0 and x_bf.stride(0) % 8 == 0):
         return False
     if ragged:
@@ -100,7 +98,7 @@ def wgrad_async(dy_bf, x_bf, M, post=None, out=None):
     may be freed: the caching allocator is told about the lane's use); the result may only be touched after join().
     x_bf may be a callable that builds the operand: it runs on the lane as well."""
     dev = dy_bf.device
-    if hip.env_flag("MSCLIP_WGRAD_SYNC") or _ranks_share_a_gpu():
+    if options.TRAIN.wgrad_sync or _ranks_share_a_gpu():
         out = wgrad(dy_bf, x_bf() if callable(x_bf) else x_bf, M, out)    # everything on the calling stream (A/B knob; gloo test setups)
         return post(out) if post is not None else out
     cur, ln = torch.cuda.current_stream(dev), lane(dev)
@@ -141,7 +139,7 @@ class WgradJob:
         self.S = S = max(1, min(256 // tiles, M // 2048))
         Mpad = (M + 64 * S - 1) // (64 * S) * (64 * S)
         dev = dy_bf.device
-        self.sync = hip.env_flag("MSCLIP_WGRAD_SYNC") or _ranks_share_a_gpu()
+        self.sync = options.TRAIN.wgrad_sync or _ranks_share_a_gpu()
         self.tn = _tn_ok(dy_bf, x_bf)
         if self.tn:
             # round 4: the split-K GEMM reads both operands token-major (LDS transpose reads): nothing to do until finish().
@@ -187,7 +185,7 @@ def on_lane(fn, *operands):
     """fn() on the lane stream behind an event (same contract as wgrad_async: operands read-only afterwards, result valid
     after join).  For the other HBM-bound by-products of the backward that nothing on the critical path reads (bias sums)."""
     dev = operands[0].device
-    if hip.env_flag("MSCLIP_WGRAD_SYNC") or _ranks_share_a_gpu():
+    if options.TRAIN.wgrad_sync or _ranks_share_a_gpu():
         return fn()
     cur, ln = torch.cuda.current_stream(dev), lane(dev)
     ready = torch.cuda.Event()

@@ -74,3 +74,29 @@ class EngineOptions:
 
     def replace(self, **kw):
         return dataclasses.replace(self, **kw)
+
+
+@dataclasses.dataclass(frozen=True)
+class TrainOptions:
+    """The training step's remaining switches (msclip_amd/train.py, train_conv.py, gradgemm.py), read from the environment ONCE at
+    import; tests / probes swap the object: `options.TRAIN = options.TRAIN.replace(dgrad_col2im=True)`.  Round 6 removed the
+    switches of retired A/B paths whose numbers are on record in DESIGN.md s8 (MSCLIP_FOLDS_EAGER, _WT_PER_MATRIX, _LN_BWD_UNFUSED,
+    _BIAS_COLSUM_PASS, _IMAGE_COLS_64, _DGRAD_PARITY4, _SHORTCUT_COL2IM, _RELU_BWD_PASS, _FIRST_CONV_GEMM, _ADAPTER_BWD_UNFUSED,
+    _WGRAD_TN, _WGRAD_TN_RAGGED): the shipped path is the only one now, the general-shape fallbacks they guarded stay."""
+    wgrad_sync: bool = False          # MSCLIP_WGRAD_SYNC: weight-gradient jobs on the calling stream instead of the lane stream
+    dgrad_col2im: bool = False        # MSCLIP_DGRAD_COL2IM: conv input gradients through column matrices + col2im (cross-check of the
+    #                                   parity-class implicit GEMMs, tests/test_gpu_train.py)
+    im2col_main: bool = False         # MSCLIP_IM2COL_MAIN: the conv side's column matrices on the main stream instead of the lane
+    colsum_main: bool = False         # MSCLIP_COLSUM_MAIN: the conv side's bias sums on the main stream instead of the lane
+    #                                   (either of the two makes a hipGraph replay of the step right: profiles/r06_train_hipgraph_probe.txt)
+
+    @classmethod
+    def from_env(cls):
+        return cls(wgrad_sync=_flag("MSCLIP_WGRAD_SYNC", False), dgrad_col2im=_flag("MSCLIP_DGRAD_COL2IM", False),
+                   im2col_main=_flag("MSCLIP_IM2COL_MAIN", False), colsum_main=_flag("MSCLIP_COLSUM_MAIN", False))
+
+    def replace(self, **kw):
+        return dataclasses.replace(self, **kw)
+
+
+TRAIN = TrainOptions.from_env()

@@ -27,6 +27,7 @@ import torch.distributed as dist
 from . import comm as C
 from . import hip
 from . import gradgemm
+from . import options
 from .gradgemm import dgrad as _dgrad, wgrad as _wgrad, wgrad_async as _wgrad_async
 from .train_conv import ConvSideBackward, ConvSideBatchNorm
 
@@ -123,10 +124,10 @@ class TrainStep:
             # the inference schedule (layer by layer: force_unfused keeps every map the backward reads in the workspace)
             conv_events = None
             # (same-box A/B: 89.6-90.2 -> 88.5-88.9 ms per step)
-            if (cb is None and not gradgemm._ranks_share_a_gpu() and not hip.env_flag("MSCLIP_WGRAD_SYNC")
+            if (cb is None and not gradgemm._ranks_share_a_gpu() and not options.TRAIN.wgrad_sync
                     and e.lateral == sorted(e.lateral)):
                 conv_events = e._conv_branch_on_side_stream(w, Bi)
-            if (cb is not None and conv_events is None and not gradgemm._ranks_share_a_gpu() and not hip.env_flag("MSCLIP_WGRAD_SYNC")
+            if (cb is not None and conv_events is None and not gradgemm._ranks_share_a_gpu() and not options.TRAIN.wgrad_sync
                     and e.lateral == sorted(e.lateral)):
                 # train-mode BatchNorm: the same for the raw-conv -> statistics -> normalise chains of the parallel branch and
                 # the adapters' top-down halves (they depend on the image only)
@@ -321,17 +322,11 @@ class TrainStep:
             grads = _Grads()
             # Column sums nothing on the critical path reads (LayerNorm parameter gradients, bias gradients): their producers leave
             # per-block partial matrices, ONE msclip_colsum_multi launch folds all of them behind the transformer's backward (round 5:
-            # ~120 msclip_colsum launches per step, 1.1 ms of the main queue; MSCLIP_FOLDS_EAGER=1 = one launch each, at once)
-            folds = None if hip.env_flag("MSCLIP_FOLDS_EAGER") else hip.FoldPlan(dev)
+            # ~120 msclip_colsum launches per step, 1.1 ms of the main queue)
+            folds = hip.FoldPlan(dev)
 
             def fold_into(part, then, scale_n=0, scale=1.0):
-                if folds is not None:
-                    folds.add(part, then, scale_n=scale_n, scale=scale)
-                    return
-                r = hip.colsum(part)
-                if scale_n:
-                    r[:scale_n] *= scale
-                then(r)
+                folds.add(part, then, scale_n=scale_n, scale=scale)
 
             def ln_param_grads(part, key):
                 """part: (dgamma | dbeta) partials [blocks, 2 C] of a LayerNorm backward -> grads[key.weight], grads[key.bias]."""
@@ -414,7 +409,7 @@ class TrainStep:
             # step), all of them up front on the lane stream with this library's transpose kernel, last block first, one event
             # per block -- not four ATen transposed copies per block on the main queue (74 launches, 1.8 ms per step)
             wts, wt_ready = {}, {}
-            if not (hip.env_flag("MSCLIP_WGRAD_SYNC") or gradgemm._ranks_share_a_gpu()):
+            if not (options.TRAIN.wgrad_sync or gradgemm._ranks_share_a_gpu()):
                 cur_s, ln_s = torch.cuda.current_stream(dev), gradgemm.lane(dev)
                 ev0 = torch.cuda.Event()
                 ev0.record(cur_s)
@@ -425,7 +420,7 @@ class TrainStep:
                         if blk is not None and all(blk["w"] is not b for b in sets):
                             sets.append(blk["w"])
                 srcs = [t for bw in sets for t in (bw.wpr, bw.wfc, bw.wo, bw.wqkv)]
-                multi = not hip.env_flag("MSCLIP_WT_PER_MATRIX") and all(t.shape[0] % 64 == 0 for t in srcs)
+                multi = all(t.shape[0] % 64 == 0 for t in srcs)
                 with torch.cuda.stream(ln_s):
                     if multi:
                         # ONE table-driven launch for all of them (48 launches one by one kept the host busy for 0.6 ms at the start
@@ -476,7 +471,7 @@ class TrainStep:
                 return parts if dY_next is not None else None          # (partial sums: set_bias folds them)
 
             # ---- blocks, last to first
-            fuse_cast = not hip.env_flag("MSCLIP_LN_BWD_UNFUSED")
+            fuse_cast = True
             carry = None                      # (dY, bias sums) of this block's MLP half, left by the block above's ln_1 backward
             for i in reversed(range(e.n_layers)):
                 L = sv["layers"][i]
@@ -504,8 +499,7 @@ class TrainStep:
                     if (r1 - r0) % 256 == 0:
                         # dh = (dY . W_proj) * QuickGELU'(h): the activation's derivative in the dgrad GEMM's epilogue, which
                         # also leaves dh's column sums per 128 rows (c_fc's bias gradient without a second pass over dh)
-                        if not hip.env_flag("MSCLIP_BIAS_COLSUM_PASS"):
-                            dh_part[id(bw)] = torch.empty((r1 - r0) // 128, 4 * D, dtype=F32, device=dev)
+                        dh_part[id(bw)] = torch.empty((r1 - r0) // 128, 4 * D, dtype=F32, device=dev)
                         hip.gemm(dY[r0:r1], w_t(bw, 0), dh[r0:r1], resid=L["h"][r0:r1], resid_kind=hip.RESID_GELUGRAD,
                                  colsum_part=dh_part.get(id(bw)))
                     else:
@@ -537,7 +531,7 @@ class TrainStep:
                 # sum over the samples: 1 024 x 3 D fp32 to fold instead of a second pass over dqkv [M, 3 D]); the query-blocked
                 # form of the long sequences does not carry them
                 qpart = None
-                if e.Lv <= 96 and (sv["cap"] is not None or e.Lt <= 96) and not hip.env_flag("MSCLIP_BIAS_COLSUM_PASS"):
+                if e.Lv <= 96 and (sv["cap"] is not None or e.Lt <= 96):
                     qpart = torch.empty(Bi + Bt, 3 * D, dtype=F32, device=dev)
                 if e.vblk[i] is not None:
                     hip.attention_bwd(L["qkv"][:Mv], L["ao"][:Mv], dao[:Mv], dqkv[:Mv], Bi, e.Lv, e.heads, False,
@@ -620,8 +614,7 @@ class TrainStep:
             dvpos = hip.colsum(dtok.view(Bi, e.Lv * D)).view(e.Lv, D)                           # sum over the batch
             grads["visual.positional_embedding"] = dvpos
             grads["visual.class_embedding"] = dvpos[0].clone()
-            if folds is not None:
-                folds.run()                                      # every deferred column sum of the transformer's backward, two launches
+            folds.run()                                      # every deferred column sum of the transformer's backward, two launches
             conv.stem(grads, dtok)
             flush_wgrads()
             gradgemm.join(dev)                                   # the gradients queued on the lane stream

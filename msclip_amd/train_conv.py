@@ -24,6 +24,7 @@ import torch
 
 from . import gradgemm
 from . import hip
+from . import options
 from .gradgemm import wgrad as _wgrad, wgrad_async as _wgrad_async
 
 BF = torch.bfloat16
@@ -66,7 +67,7 @@ _PARITY_PLANS = {}
 
 
 def _image_kalign():
-    return 64 if hip.env_flag("MSCLIP_IMAGE_COLS_64") else 32
+    return 32
 
 
 class ConvSideBackward:
@@ -101,7 +102,7 @@ class ConvSideBackward:
         # geometry only: shared by every ConvSideBackward of the process (the frozen-statistics backward builds one per step,
         # and an index upload is a pageable host-to-device copy that waits for the stream to drain)
         # row pairs on the large maps (112 / 56: 543 -> 314 us, 758 -> 524, 419 -> 367), four classes on the 28 x 28 ones (192 vs 206 us)
-        rows = spec.h_in >= 56 and not hip.env_flag("MSCLIP_DGRAD_PARITY4")
+        rows = spec.h_in >= 56
         key = (str(spec.weight.device), spec.cout, spec.cin, spec.weight.shape[1], spec.w_out, rows)
         plan = self._pplan.get(key)
         if plan is None:
@@ -142,7 +143,7 @@ class ConvSideBackward:
         return ((spec.kh, spec.kw, spec.stride, spec.pad) == (3, 3, 2, 1) and spec.h_in % 2 == 0 and spec.w_in % 2 == 0
                 and spec.cout % 8 == 0 and spec.cin % 8 == 0 and spec.h_in == 2 * spec.h_out and spec.w_in == 2 * spec.w_out
                 and spec.h_in >= 28                  # (14 x 14 maps: the four launches cost more than the small column matrix)
-                and not hip.env_flag("MSCLIP_DGRAD_COL2IM"))
+                and not options.TRAIN.dgrad_col2im)
 
     def _dgrad_parity(self, plan, spec, dpre, dx, B, relu_of=None):
         """relu_of: the saved post-ReLU activation the convolution read (bf16, laid out like dx): the launches then store
@@ -160,8 +161,7 @@ class ConvSideBackward:
 
     def _shortcut_ok(self, spec):
         return ((spec.kh, spec.kw, spec.stride, spec.pad) == (1, 1, 2, 0) and spec.h_in == 2 * spec.h_out
-                and spec.w_in == 2 * spec.w_out and spec.cin % 8 == 0 and not hip.env_flag("MSCLIP_DGRAD_COL2IM")
-                and not hip.env_flag("MSCLIP_SHORTCUT_COL2IM"))
+                and spec.w_in == 2 * spec.w_out and spec.cin % 8 == 0 and not options.TRAIN.dgrad_col2im)
 
     def _shortcut_dgrad_into(self, key, spec, dpre, dx, B):
         """dx[even pixels] += dY . W for a 1x1 / stride-2 convolution (the bottleneck's shortcut), in place into the input
@@ -185,7 +185,7 @@ class ConvSideBackward:
         if col is None:
             if pointwise:
                 col = x_in[:pix]
-            elif lane and not hip.env_flag("MSCLIP_IM2COL_MAIN"):
+            elif lane and not options.TRAIN.im2col_main:
                 # only the weight gradient reads the column matrix: it is built where that runs, on the lane stream, not
                 # in front of the input gradient on the critical path (x_in is a workspace map: nothing writes it before
                 # gradgemm.join at the end of the backward)
@@ -208,7 +208,7 @@ class ConvSideBackward:
                 hip.gemm(dpre, wt, dx, M=pix, N=ci, ldx=co)
             elif self._parity_ok(spec) and self._parity_plan(key, spec):
                 dx = _zbuf(B * spec.h_in * spec.w_in, ci, dpre.device)
-                fuse = relu_of is not None and relu_of.dtype == BF and not hip.env_flag("MSCLIP_RELU_BWD_PASS")
+                fuse = relu_of is not None and relu_of.dtype == BF
                 self._dgrad_parity(self._parity_plan(key, spec), spec, dpre, dx, B, relu_of=relu_of if fuse else None)
                 if fuse:
                     relu_of = None
@@ -243,8 +243,8 @@ class ConvSideBackward:
 
     def _colsum_on_lane(self, dpre, M):
         """Bias gradient (column sums of dY) for a fold whose chain rule runs on the lane anyway (_fold_on_lane): the pass over
-        dY moves off the critical path with it (MSCLIP_COLSUM_MAIN=1: on the calling stream, as before)."""
-        if hip.env_flag("MSCLIP_COLSUM_MAIN"):
+        dY moves off the critical path with it (options.TRAIN.colsum_main: on the calling stream, as before)."""
+        if options.TRAIN.colsum_main:
             return hip.colsum(dpre, M=M)
         return gradgemm.on_lane(lambda: hip.colsum(dpre, M=M), dpre)
 
@@ -273,7 +273,7 @@ class ConvSideBackward:
         """wgrad of a 3x3 / stride 2 convolution on the input image (no input gradient)."""
         pix = self.Bi * self.e.h1 * self.e.h1
         co = dpre.shape[1]
-        if hip.image_conv_wgrad_ok(self.img, dpre) and self.e.h1 <= 128 and not hip.env_flag("MSCLIP_FIRST_CONV_GEMM"):
+        if hip.image_conv_wgrad_ok(self.img, dpre) and self.e.h1 <= 128:
             # one pass over dpre and the image: no patch matrix, the bias sums in the same contraction (round 5)
             dwf, dbias = hip.image_conv_wgrad(self.img, dpre)
         else:
@@ -291,7 +291,7 @@ class ConvSideBackward:
         p = f"visual.transformer.parallel_lateral_adapter.{j}"
         # grid rows (the cls row has no top-down term): their bf16 copy and column sums from ONE pass over dsum (round 5; was a
         # gathering copy, a column-sum pass and a cast)
-        if dsum.is_contiguous() and dsum.shape[0] == Bi * e.Lv and e.Lv == g2 + 1 and not hip.env_flag("MSCLIP_ADAPTER_BWD_UNFUSED"):
+        if dsum.is_contiguous() and dsum.shape[0] == Bi * e.Lv and e.Lv == g2 + 1:
             dT_bf, cs = hip.cast_bf16_colsum(dsum, skip_group=g2)
         else:
             dT = dsum.view(Bi, e.Lv, D)[:, 1:].reshape(Bi * g2, D)
@@ -504,7 +504,7 @@ class ConvSideBatchNorm:
         sp = "visual.transformer.resblocks.0"
         pix = Bi * e.h1 * e.h1
         heads = ((self.raw.w_conv1, sp + ".bn1", e._s1(w, Bi)), (self.raw.w_par0, "visual.transformer.parallel_branch_v.0.bn", w["P0"]))
-        if self.raw.w_dual is not None and e.S % 2 == 0 and not hip.env_flag("MSCLIP_FIRST_CONV_GEMM"):
+        if self.raw.w_dual is not None and e.S % 2 == 0:
             # both raw convolutions from ONE pass over the image (round 5): no patch matrix, no two GEMMs over it
             raws = [torch.empty(pix, 48, dtype=F32, device=e.dev) for _ in heads]
             hip.stem_conv_dual_raw(self.img, self.raw.w_dual, raws[0], raws[1])
@@ -610,7 +610,7 @@ class ConvSideBatchNorm:
         draw = self._bn_bwd(grads, prefix, dpre)
         pix = self.Bi * self.e.h1 * self.e.h1
         co = draw.shape[1]
-        if hip.image_conv_wgrad_ok(self.img, draw) and self.e.h1 <= 128 and not hip.env_flag("MSCLIP_FIRST_CONV_GEMM"):
+        if hip.image_conv_wgrad_ok(self.img, draw) and self.e.h1 <= 128:
             # one pass over draw and the image on the lane: no patch matrix (the bias column is not needed: dbeta comes from the BatchNorm backward)
             grads[wkey] = gradgemm.on_lane(
                 lambda: hip.image_conv_wgrad(self.img, draw)[0].reshape(co, 3, 3, 3).permute(0, 3, 1, 2).contiguous(), draw)

@@ -998,7 +998,8 @@ def test_conv_input_gradient_by_parity_classes(gpu_device, monkeypatch, ci, co, 
     assert bw._parity_ok(spec) == (h >= 28)
     col = hip.im2col(x_in, B, h, h, ci, 3, 3, 2, 1)
     G, db, dx = bw._conv_bwd("t", spec, x_in, dpre, B, col=col)
-    monkeypatch.setenv("MSCLIP_DGRAD_COL2IM", "1")
+    from msclip_amd import options
+    monkeypatch.setattr(options, "TRAIN", options.TRAIN.replace(dgrad_col2im=True))
     G2, db2, dx2 = bw._conv_bwd("t", spec, x_in, dpre, B, col=col)
     wq = spec.weight[:, :9 * ci].float().view(co, 3, 3, ci).permute(0, 3, 1, 2)               # the packed (bf16) filter
     dy = dpre[:pix].float().view(B, ho, ho, co).permute(0, 3, 1, 2)
@@ -1009,7 +1010,7 @@ def test_conv_input_gradient_by_parity_classes(gpu_device, monkeypatch, ci, co, 
     assert (dx2.float() - ref).abs().max().item() <= 1.2e-2 * sc         # (the column matrix rounds every tap's product first)
     assert torch.equal(G, G2) and torch.equal(db, db2)
     # through the ReLU that produced x_in: in the launches' epilogues (msclip_gemm resid_kind 5) = a msclip_relu_bwd pass over dx
-    monkeypatch.delenv("MSCLIP_DGRAD_COL2IM")
+    monkeypatch.setattr(options, "TRAIN", options.TRAIN.replace(dgrad_col2im=False))
     _, _, dxr = bw._conv_bwd("t", spec, x_in, dpre, B, col=col, relu_of=x_in)
     assert torch.equal(dxr, torch.where(x_in[:B * h * h] > 0, dx, torch.zeros_like(dx)))
 
