@@ -87,13 +87,16 @@ class TrainOptions:
     dgrad_col2im: bool = False        # MSCLIP_DGRAD_COL2IM: conv input gradients through column matrices + col2im (cross-check of the
     #                                   parity-class implicit GEMMs, tests/test_gpu_train.py)
     im2col_main: bool = False         # MSCLIP_IM2COL_MAIN: the conv side's column matrices on the main stream instead of the lane
+    compact_last_block: bool = True   # MSCLIP_TRAIN_COMPACT_LAST: the last block's out_proj / ln_2 / MLP (forward and backward) on the
+    #                                   Bi + Bt rows that are read behind it (cls / EOT), as the inference path does (round 6)
     colsum_main: bool = False         # MSCLIP_COLSUM_MAIN: the conv side's bias sums on the main stream instead of the lane
     #                                   (either of the two makes a hipGraph replay of the step right: profiles/r06_train_hipgraph_probe.txt)
 
     @classmethod
     def from_env(cls):
         return cls(wgrad_sync=_flag("MSCLIP_WGRAD_SYNC", False), dgrad_col2im=_flag("MSCLIP_DGRAD_COL2IM", False),
-                   im2col_main=_flag("MSCLIP_IM2COL_MAIN", False), colsum_main=_flag("MSCLIP_COLSUM_MAIN", False))
+                   im2col_main=_flag("MSCLIP_IM2COL_MAIN", False), colsum_main=_flag("MSCLIP_COLSUM_MAIN", False),
+                   compact_last_block=_flag("MSCLIP_TRAIN_COMPACT_LAST", True))
 
     def replace(self, **kw):
         return dataclasses.replace(self, **kw)

@@ -182,7 +182,12 @@ class TrainStep:
                 r_lo = segs[0][0]
                 fresh = r_lo == 0                         # (text block 0 leaves the image rows alone: in place, cloned)
                 L["x_in"] = Xc if fresh else Xc[r_lo:M].clone()
-                XM = torch.empty(M, D, dtype=F32, device=e.dev) if fresh else Xc
+                # Round 6: behind the LAST block only x[:, 0] of every image (M.py:2685) and the EOT row of every caption (M.py:3057-3060)
+                # are read, and out_proj / ln_2 / c_fc / c_proj are row-wise: they run -- forward here, backward in backward() -- on
+                # those Bi + Bt rows instead of on every token (what the inference path has done since round 3; the rows' gradients
+                # are the only non-zero ones behind the block, so every parameter gradient is unchanged)
+                compact = (i == e.n_layers - 1 and len(segs) == 2 and L["adapter"] is None and options.TRAIN.compact_last_block)
+                XM = None if compact else (torch.empty(M, D, dtype=F32, device=e.dev) if fresh else Xc)
                 lno1 = torch.empty(M, D, dtype=BF, device=e.dev)
                 if len(segs) == 2:                          # both towers' rows in one launch (modality-specific gamma / beta per row segment)
                     hip.layernorm_split(Xc[:M], vb["ln1"].g, vb["ln1"].b, tb["ln1"].g, tb["ln1"].b, Mv, lno1[:M], M)
@@ -198,6 +203,29 @@ class TrainStep:
                 if vb is not None:
                     hip.attention(qkv[:Mv], ao[:Mv], Bi, e.Lv, e.heads, False)
                 e._attention_text(w, qkv, ao, Bt)
+                if compact:
+                    nc = Bi + Bt
+                    crow = torch.cat([torch.arange(0, Mv, e.Lv, dtype=torch.int32, device=e.dev), w["eot"][:Bt]])   # live rows of X
+                    xin_c, ao_c = torch.empty(nc, D, dtype=F32, device=e.dev), torch.empty(nc, D, dtype=BF, device=e.dev)
+                    hip.gather_rows(Xc, xin_c, nc, row_idx=crow)
+                    hip.gather_rows(ao, ao_c, nc, row_idx=crow)
+                    cgroups = [(0, nc, vb["w"])] if vb["w"] is tb["w"] else [(0, Bi, vb["w"]), (Bi, nc, tb["w"])]
+                    xm_c = torch.empty(nc, D, dtype=F32, device=e.dev)
+                    for r0, r1, bw in cgroups:
+                        hip.gemm(ao_c[r0:r1], bw.wo, xm_c[r0:r1], bias=bw.bo, resid=xin_c[r0:r1], resid_kind=hip.RESID_F32)
+                    lno2_c = torch.empty(nc, D, dtype=BF, device=e.dev)
+                    hip.layernorm_split(xm_c, vb["ln2"].g, vb["ln2"].b, tb["ln2"].g, tb["ln2"].b, Bi, lno2_c, nc)
+                    h_c, hid_c = torch.empty(nc, 4 * D, dtype=BF, device=e.dev), torch.empty(nc, 4 * D, dtype=BF, device=e.dev)
+                    xn_c = torch.empty(nc, D, dtype=F32, device=e.dev)
+                    for r0, r1, bw in cgroups:
+                        hip.gemm(lno2_c[r0:r1], bw.wfc, h_c[r0:r1], bias=bw.bfc)
+                        hip.quickgelu(h_c[r0:r1], hid_c[r0:r1])
+                        hip.gemm(hid_c[r0:r1], bw.wpr, xn_c[r0:r1], bias=bw.bpr, resid=xm_c[r0:r1], resid_kind=hip.RESID_F32)
+                    L.update(r_lo=r_lo, segs=segs, groups=groups, lno1=lno1, qkv=qkv, ao=ao,
+                             compact=dict(crow=crow, cgroups=cgroups, ao=ao_c, x_mid=xm_c, lno2=lno2_c, h=h_c, hid=hid_c, x_out=xn_c))
+                    sv["layers"][i] = L
+                    sv["compact"] = xn_c
+                    continue
                 for r0, r1, bw in groups:
                     hip.gemm(ao[r0:r1], bw.wo, XM[r0:r1], bias=bw.bo, resid=Xc[r0:r1], resid_kind=hip.RESID_F32)
                 L["x_mid"] = XM if fresh else XM[r_lo:M].clone()
@@ -227,13 +255,23 @@ class TrainStep:
             if cb is not None:
                 cb.update_running_stats()
             # ---- heads + loss
-            sv["x_out"] = Xc if Xc is not X else X[:M].clone()
-            w["X"] = Xc                              # the heads read the final residual matrix
-            try:
-                e._head_image(w, Bi)
-                e._head_text(w, Bt)
-            finally:
-                w["X"] = X
+            if sv.get("compact") is not None:
+                # the heads read the compact matrix of the last block's live rows (image cls rows, then EOT rows)
+                sv["x_out"] = sv["compact"]
+                xc_own, w["XC"] = w["XC"], sv["compact"]
+                try:
+                    e._head_image(w, Bi, compact=True)
+                    e._head_text(w, Bt, compact=True, Bi=Bi)
+                finally:
+                    w["XC"] = xc_own
+            else:
+                sv["x_out"] = Xc if Xc is not X else X[:M].clone()
+                w["X"] = Xc                              # the heads read the final residual matrix
+                try:
+                    e._head_image(w, Bi)
+                    e._head_text(w, Bt)
+                finally:
+                    w["X"] = X
             sv.update(hv=w["hv"].clone(), ht=w["ht"].clone(), fv_raw=w["fv_raw"].clone(), ft_raw=w["ft_raw"].clone(),
                       fv=w["fv"].clone(), ft=w["ft"].clone(), fvb=w["fvb"].clone(), ftb=w["ftb"].clone(), eot=w["eot"].clone())
             # ---- loss.  The inference path forms its logits from bf16 unit features (error ~0.03 on a logit at T = 1/0.07:
@@ -383,17 +421,28 @@ class TrainStep:
                 conv = ConvSideBackward(self)
                 conv.begin(sv["img"], sv["w"], Bi)
 
-            def head(feat_raw, dfeat, hrow, w_proj, ln, key_proj, key_ln, row_idx=None, row_mul=1):
+            compact_x = sv.get("compact")                 # [Bi + Bt, D]: the last block ran its row-wise tail on the live rows only
+            dXC = torch.zeros(Bi + Bt, D, dtype=F32, device=dev) if compact_x is not None else None
+
+            def head(feat_raw, dfeat, hrow, w_proj, ln, key_proj, key_ln, row_idx=None, row_mul=1, c0=None):
                 dfr = torch.empty_like(feat_raw)
                 hip.l2norm_bwd(feat_raw, dfeat, dfr)
                 dfr_b = hip.cast_bf16(dfr)
                 grads[key_proj] = _wgrad(hrow, dfr_b, hrow.shape[0])                           # [D, E] like the parameter
                 dh = torch.empty(hrow.shape[0], D, dtype=F32, device=dev)                      # fp32: it feeds column sums
                 hip.gemm(dfr_b, w_proj.t().contiguous(), dh)                                   # dfr [B, E] @ W [E, D]
-                part, _ = hip.layernorm_bwd(sv["x_out"], dh, ln.g, dX, hrow.shape[0], row_idx=row_idx, row_mul=row_mul, fold=False)
+                if c0 is not None:                        # compact rows c0 .. of x_out / dXC, one per sample
+                    n_ = hrow.shape[0]
+                    part, _ = hip.layernorm_bwd(sv["x_out"][c0:c0 + n_], dh, ln.g, dXC[c0:c0 + n_], n_, fold=False)
+                else:
+                    part, _ = hip.layernorm_bwd(sv["x_out"], dh, ln.g, dX, hrow.shape[0], row_idx=row_idx, row_mul=row_mul, fold=False)
                 ln_param_grads(part, key_ln)
-            head(sv["fv_raw"], dfi, sv["hv"], e.w_vproj, e.ln_post, "visual.proj", "visual.ln_post", row_mul=e.Lv)
-            head(sv["ft_raw"], dft, sv["ht"], e.w_tproj, e.ln_final, "text_projection", "ln_final", row_idx=sv["eot"])
+            if compact_x is not None:
+                head(sv["fv_raw"], dfi, sv["hv"], e.w_vproj, e.ln_post, "visual.proj", "visual.ln_post", c0=0)
+                head(sv["ft_raw"], dft, sv["ht"], e.w_tproj, e.ln_final, "text_projection", "ln_final", c0=Bi)
+            else:
+                head(sv["fv_raw"], dfi, sv["hv"], e.w_vproj, e.ln_post, "visual.proj", "visual.ln_post", row_mul=e.Lv)
+                head(sv["ft_raw"], dft, sv["ht"], e.w_tproj, e.ln_final, "text_projection", "ln_final", row_idx=sv["eot"])
 
             def cast_with_bias_sums(dX, dY, r_lo, groups):
                 """dY[r_lo:M] = bf16(dX[r_lo:M]) -- the operand of a projection's dgrad / wgrad GEMMs -- and {id(block
@@ -479,54 +528,93 @@ class TrainStep:
                 names = {id(e.tblk[i]["w"]): f"transformer.resblocks.{i}"}
                 if e.vblk[i] is not None:                    # shared tensors live under their visual.* name (one Parameter)
                     names[id(e.vblk[i]["w"])] = f"visual.transformer.resblocks.{i}"
-                hid = L["hid"]
-                if carry is not None:
-                    dY, bsum = carry
-                    carry = None
+                cm = L.get("compact")
+                if cm is not None:
+                    # the last block's row-wise tail ran on the Bi + Bt live rows (forward above): its backward on the same rows.  dXC holds
+                    # the heads' gradient wrt the block's output at those rows; every other row's is zero.
+                    assert carry is None
+                    nc = Bi + Bt
+                    xm_c, lno2_c, h_c, hid_c, ao_c = cm["x_mid"], cm["lno2"], cm["h"], cm["hid"], cm["ao"]
+                    dlno2_c = torch.empty(nc, D, dtype=F32, device=dev)
+                    dy_c = hip.cast_bf16(dXC)
+                    for r0, r1, bw in cm["cgroups"]:
+                        p = names[id(bw)]
+                        grads[p + ".mlp.c_proj.weight"] = _wgrad(dy_c[r0:r1], hid_c[r0:r1], r1 - r0)
+                        grads[p + ".mlp.c_proj.bias"] = hip.colsum(dXC[r0:r1])
+                        dh_c = torch.empty(r1 - r0, 4 * D, dtype=BF, device=dev)
+                        hip.quickgelu_bwd(h_c[r0:r1], _dgrad(dy_c[r0:r1], w_t(bw, 0)), dh_c)
+                        grads[p + ".mlp.c_fc.weight"] = _wgrad(dh_c, lno2_c[r0:r1], r1 - r0)
+                        grads[p + ".mlp.c_fc.bias"] = hip.colsum(dh_c)
+                        _dgrad(dh_c, w_t(bw, 1), dlno2_c[r0:r1])
+                    for (c0, c1), b in (((0, Bi), e.vblk[i]), ((Bi, nc), e.tblk[i])):
+                        pre = f"visual.transformer.resblocks.{i}" if b is e.vblk[i] else f"transformer.resblocks.{i}"
+                        part, _ = hip.layernorm_bwd(xm_c[c0:c1], dlno2_c[c0:c1], b["ln2"].g, dXC[c0:c1], c1 - c0, fold=False)
+                        ln_param_grads(part, pre + ".ln_2")
+                    # dXC is now the gradient wrt the rows behind the attention (x_mid): out_proj on the compact rows, then both
+                    # results go back to their rows of the token matrix -- the attention output's gradient (zero elsewhere) and,
+                    # through the residual connection, the block input's
+                    dy2_c = hip.cast_bf16(dXC)
+                    dao_c = torch.empty(nc, D, dtype=BF, device=dev)
+                    for r0, r1, bw in cm["cgroups"]:
+                        p = names[id(bw)]
+                        grads[p + ".attn.out_proj.weight"] = _wgrad(dy2_c[r0:r1], ao_c[r0:r1], r1 - r0)
+                        grads[p + ".attn.out_proj.bias"] = hip.colsum(dXC[r0:r1])
+                        _dgrad(dy2_c[r0:r1], w_t(bw, 2), dao_c[r0:r1])
+                    rows_c = cm["crow"].long()
+                    dao = torch.zeros(M, D, dtype=BF, device=dev)
+                    dao.index_copy_(0, rows_c, dao_c)
+                    dX.index_copy_(0, rows_c, dXC)                   # (dX is still all zero here: nothing but the heads wrote a gradient yet)
+                    dlno = torch.empty(M, D, dtype=F32, device=dev)
+                    dqkv = torch.empty(M, 3 * D, dtype=BF, device=dev)
                 else:
-                    dY = torch.empty(M, D, dtype=BF, device=dev)
-                    bsum = cast_with_bias_sums(dX, dY, r_lo, groups)
-                # gradients of the LayerNorm outputs stay fp32: they are only read by the LayerNorm backward, whose dbeta /
-                # dgamma are column sums of nearly cancelling terms (a bf16 dy costs 10-30 % on those sums at small batch)
-                dlno = torch.empty(M, D, dtype=F32, device=dev)
-                for r0, r1, bw in groups:
-                    p = names[id(bw)]
-                    wide_wgrad(p + ".mlp.c_proj.weight", dY[r0:r1], hid[r0:r1], r1 - r0, (D, 4 * D))
-                    set_bias(p + ".mlp.c_proj.bias", bsum[id(bw)])
-                dh = torch.empty(M, 4 * D, dtype=BF, device=dev)
-                dh_part = {}
-                for r0, r1, bw in groups:
-                    if (r1 - r0) % 256 == 0:
-                        # dh = (dY . W_proj) * QuickGELU'(h): the activation's derivative in the dgrad GEMM's epilogue, which
-                        # also leaves dh's column sums per 128 rows (c_fc's bias gradient without a second pass over dh)
-                        dh_part[id(bw)] = torch.empty((r1 - r0) // 128, 4 * D, dtype=F32, device=dev)
-                        hip.gemm(dY[r0:r1], w_t(bw, 0), dh[r0:r1], resid=L["h"][r0:r1], resid_kind=hip.RESID_GELUGRAD,
-                                 colsum_part=dh_part.get(id(bw)))
+                    hid = L["hid"]
+                    if carry is not None:
+                        dY, bsum = carry
+                        carry = None
                     else:
-                        dhid = _dgrad(dY[r0:r1], w_t(bw, 0))
-                        hip.quickgelu_bwd(L["h"][r0:r1], dhid, dh[r0:r1])
-                del hid
-                for r0, r1, bw in groups:
-                    p = names[id(bw)]
-                    wide_wgrad(p + ".mlp.c_fc.weight", dh[r0:r1], L["lno2"][r0:r1], r1 - r0, (4 * D, D))
-                    if id(bw) in dh_part:
-                        set_bias(p + ".mlp.c_fc.bias", dh_part[id(bw)])
-                    else:
-                        grads[p + ".mlp.c_fc.bias"] = gradgemm.on_lane(lambda a=dh[r0:r1]: hip.colsum(a), dh)
-                    _dgrad(dh[r0:r1], w_t(bw, 1), dlno[r0:r1])
-                del dh
-                # attention half.  dX behind the ln_2 backward is out_proj's output gradient: its bf16 copy and bias sums leave with that pass
-                dY2 = torch.empty(M, D, dtype=BF, device=dev)          # not dY again: the lane stream may still read it (c_proj wgrad)
-                bsum = ln_bwd_segments(L["x_mid"], dlno, segs, groups, r_lo, "ln2", i, dY2 if fuse_cast else None)
-                if bsum is None:
-                    bsum = cast_with_bias_sums(dX, dY2, r_lo, groups)
-                dao = torch.empty(M, D, dtype=BF, device=dev)
-                dqkv = torch.empty(M, 3 * D, dtype=BF, device=dev)      # attention_bwd writes every row of the towers that ran
-                for r0, r1, bw in groups:
-                    p = names[id(bw)]
-                    wide_wgrad(p + ".attn.out_proj.weight", dY2[r0:r1], L["ao"][r0:r1], r1 - r0, (D, D))
-                    set_bias(p + ".attn.out_proj.bias", bsum[id(bw)])
-                    _dgrad(dY2[r0:r1], w_t(bw, 2), dao[r0:r1])
+                        dY = torch.empty(M, D, dtype=BF, device=dev)
+                        bsum = cast_with_bias_sums(dX, dY, r_lo, groups)
+                    # gradients of the LayerNorm outputs stay fp32: they are only read by the LayerNorm backward, whose dbeta /
+                    # dgamma are column sums of nearly cancelling terms (a bf16 dy costs 10-30 % on those sums at small batch)
+                    dlno = torch.empty(M, D, dtype=F32, device=dev)
+                    for r0, r1, bw in groups:
+                        p = names[id(bw)]
+                        wide_wgrad(p + ".mlp.c_proj.weight", dY[r0:r1], hid[r0:r1], r1 - r0, (D, 4 * D))
+                        set_bias(p + ".mlp.c_proj.bias", bsum[id(bw)])
+                    dh = torch.empty(M, 4 * D, dtype=BF, device=dev)
+                    dh_part = {}
+                    for r0, r1, bw in groups:
+                        if (r1 - r0) % 256 == 0:
+                            # dh = (dY . W_proj) * QuickGELU'(h): the activation's derivative in the dgrad GEMM's epilogue, which
+                            # also leaves dh's column sums per 128 rows (c_fc's bias gradient without a second pass over dh)
+                            dh_part[id(bw)] = torch.empty((r1 - r0) // 128, 4 * D, dtype=F32, device=dev)
+                            hip.gemm(dY[r0:r1], w_t(bw, 0), dh[r0:r1], resid=L["h"][r0:r1], resid_kind=hip.RESID_GELUGRAD,
+                                     colsum_part=dh_part.get(id(bw)))
+                        else:
+                            dhid = _dgrad(dY[r0:r1], w_t(bw, 0))
+                            hip.quickgelu_bwd(L["h"][r0:r1], dhid, dh[r0:r1])
+                    del hid
+                    for r0, r1, bw in groups:
+                        p = names[id(bw)]
+                        wide_wgrad(p + ".mlp.c_fc.weight", dh[r0:r1], L["lno2"][r0:r1], r1 - r0, (4 * D, D))
+                        if id(bw) in dh_part:
+                            set_bias(p + ".mlp.c_fc.bias", dh_part[id(bw)])
+                        else:
+                            grads[p + ".mlp.c_fc.bias"] = gradgemm.on_lane(lambda a=dh[r0:r1]: hip.colsum(a), dh)
+                        _dgrad(dh[r0:r1], w_t(bw, 1), dlno[r0:r1])
+                    del dh
+                    # attention half.  dX behind the ln_2 backward is out_proj's output gradient: its bf16 copy and bias sums leave with that pass
+                    dY2 = torch.empty(M, D, dtype=BF, device=dev)          # not dY again: the lane stream may still read it (c_proj wgrad)
+                    bsum = ln_bwd_segments(L["x_mid"], dlno, segs, groups, r_lo, "ln2", i, dY2 if fuse_cast else None)
+                    if bsum is None:
+                        bsum = cast_with_bias_sums(dX, dY2, r_lo, groups)
+                    dao = torch.empty(M, D, dtype=BF, device=dev)
+                    dqkv = torch.empty(M, 3 * D, dtype=BF, device=dev)      # attention_bwd writes every row of the towers that ran
+                    for r0, r1, bw in groups:
+                        p = names[id(bw)]
+                        wide_wgrad(p + ".attn.out_proj.weight", dY2[r0:r1], L["ao"][r0:r1], r1 - r0, (D, D))
+                        set_bias(p + ".attn.out_proj.bias", bsum[id(bw)])
+                        _dgrad(dY2[r0:r1], w_t(bw, 2), dao[r0:r1])
                 # the attention backward also leaves every sample's token sums of its dqkv rows (in_proj's bias gradient = their
                 # sum over the samples: 1 024 x 3 D fp32 to fold instead of a second pass over dqkv [M, 3 D]); the query-blocked
                 # form of the long sequences does not carry them
