@@ -630,7 +630,7 @@ int msclip_comm_async_error(void* comm);
 int msclip_allgather_feats(void* comm, const void* send, void* recv, long long count, int dtype, void* stream);
 int msclip_allreduce(void* comm, const void* send, void* recv, long long count, int dtype, int op, void* stream);
 
-#define MSCLIP_ABI_VERSION 7   /* 7 (round 6): device-side row counts (M_dev / m_dev / dims), the plan executor, RCCL entry points; 6 /  5 (round 5): packed-caption entry points, msclip_qkv_attention / msclip_qkvattn_tables, msclip_pack_weights, single-launch msclip_colsum */
+#define MSCLIP_ABI_VERSION 7   /* 7 (round 6): device-side row counts (M_dev / m_dev / dims), the plan executor, RCCL entry points, msclip_prepare_device; 5-6 (round 5): packed-caption entry points, msclip_qkv_attention / msclip_qkvattn_tables, msclip_pack_weights, single-launch msclip_colsum */
 int msclip_abi_version(void);
 const char* msclip_build_arch(void);
 

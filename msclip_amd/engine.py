@@ -651,9 +651,9 @@ class Engine:
         """Captions run PACKED by default: under the causal mask (M.py:2965-2971) no row behind a caption's EOT position can
         reach the EOT row encode_text returns (M.py:3057-3060), in any block, so caption b owns n_b = argmax + 1 rows of the
         token matrix instead of 77.  Identical features / logits / loss / gradients; the token matrix's row count becomes
-        data-dependent, which costs ONE small host read per call (the total), taken while the image front is already queued.
-        MSCLIP_TEXT_PACK=0: every caption computes all context_length rows (the A/B switch; also what a hipGraph capture
-        records, since a capture cannot read the host)."""
+        data-dependent: it stays on the device (dynamic_rows: every launch reads it there) or -- small batches, the training step,
+        EngineOptions.dynamic_rows = False -- is read by the host once per call, BEFORE anything of the call is queued
+        (stage_captions hides that read).  EngineOptions.text_pack = False: every caption computes all context_length rows."""
         return self.opt.text_pack and self.Lt <= 96
 
     def _multi_stream_ok(self):
