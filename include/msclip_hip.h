@@ -504,6 +504,28 @@ int msclip_bn_bwd_reduce(const void* dy, int lddy, int dy_f32, const void* x, in
 int msclip_bn_bwd_dx(const void* dy, int lddy, int dy_f32, const void* x, int ld, int x_f32, const float* mean,
                      const float* rstd, const float* gamma, const float* dbeta, const float* dgamma, void* dx, int lddx, int M,
                      int C, long long n_stat, void* stream);
+/* msclip_bn_bwd_fused (round 6): the two passes above for the shape the training step has (bf16 gradients, fp32 raw maps, C and
+ * every leading dimension % 4 == 0, 16-byte aligned bases), four columns per thread, with
+ *   - the ReLU in front of the BatchNorm applied on the fly: d = bf16(dy [+ dy2]) * (y > 0), bit for bit what msclip_relu_bwd
+ *     writes (y = the block's bf16 output; dy2 / y may be null), and
+ *   - one or two BatchNorms behind the same d (a residual block's main path and its shortcut: M.py:1898-1936, 1812-1861) per pass.
+ * pass 0: s->part [chunks][2][C] = (sum d, sum d * xhat) per row chunk (fold with msclip_bn_bwd_finish);
+ * pass 1: s->dx (bf16) = gamma rstd (d - dbeta / n_stat - xhat dgamma / n_stat).  Not recordable in a plan (host structs). */
+typedef struct msclip_bn_bwd_side {
+  const float* x;       /* raw convolution output [M][ld], fp32 */
+  int ld;
+  const float* mean;    /* [C] */
+  const float* rstd;    /* [C] */
+  const float* gamma;   /* pass 1 */
+  const float* dbeta;   /* pass 1 */
+  const float* dgamma;  /* pass 1 */
+  void* dx;             /* pass 1: bf16 [M][lddx] */
+  int lddx;
+  float* part;          /* pass 0 */
+} msclip_bn_bwd_side;
+int msclip_bn_bwd_fused(int pass, const void* dy, int lddy, const void* dy2, int lddy2, const void* y, int ldy,
+                        const msclip_bn_bwd_side* s1, const msclip_bn_bwd_side* s2, int M, int C, int chunks, long long n_stat,
+                        void* stream);
 
 /* One parameter tensor of msclip_adamw_multi (host-side array; lr / weight_decay per tensor = the reference's parameter
  * groups, lib/optim/build.py via CUSTOM.LR_SHARE / WD_SHARE and TRAIN.WITHOUT_WD_LIST). */

@@ -640,6 +640,136 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const TD* __restrict__ d
   }
 }
 
+
+// ---- train-mode BatchNorm backward, the shape the training step has: bf16 upstream gradient, fp32 raw maps, C and the leading
+// dimensions multiples of 4.  Three things the scalar kernels above do not do: (1) a thread owns 4 consecutive columns (16-byte
+// loads of the raw map, 8-byte loads / stores of the bf16 gradients); (2) the ReLU in front of the BatchNorm(s) is applied on the
+// fly -- d = bf16(dy [+ dy2]) * (y > 0), exactly what msclip_relu_bwd would have written -- so that pass and its map are gone;
+// (3) two BatchNorms that receive the SAME upstream gradient (a residual block's main path and its shortcut) share one pass.
+struct BnBwdSide {
+  const float* x;        // raw convolution output [M][ld]
+  int ld;
+  const float* mean;     // [C] (tiled with the row fold)
+  const float* rstd;
+  const float* gamma;    // dx pass
+  const float* dbeta;
+  const float* dgamma;
+  bf16_t* dx;
+  int lddx;
+  float* part;           // reduce pass: [chunks][2][C]
+};
+
+__device__ __forceinline__ float4 bn_ld_bf16x4(const bf16_t* p) {
+  const uint2 r = *(const uint2*)p;
+  return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                     __uint_as_float(r.y & 0xffff0000u));
+}
+__device__ __forceinline__ float bn_round_bf16(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+
+// the upstream gradient of one (row, column quad) as the unfused path's msclip_relu_bwd output would hold it
+__device__ __forceinline__ float4 bn_upstream(const bf16_t* dy, const bf16_t* dy2, const bf16_t* y, size_t o_dy, size_t o_dy2,
+                                              size_t o_y) {
+  float4 d = bn_ld_bf16x4(dy + o_dy);
+  if (dy2) {
+    const float4 e = bn_ld_bf16x4(dy2 + o_dy2);
+    d = make_float4(bn_round_bf16(d.x + e.x), bn_round_bf16(d.y + e.y), bn_round_bf16(d.z + e.z), bn_round_bf16(d.w + e.w));
+  }
+  if (y) {
+    const float4 a = bn_ld_bf16x4(y + o_y);
+    d.x = a.x > 0.f ? d.x : 0.f; d.y = a.y > 0.f ? d.y : 0.f; d.z = a.z > 0.f ? d.z : 0.f; d.w = a.w > 0.f ? d.w : 0.f;
+  }
+  return d;
+}
+
+// part[chunk][0][c] = sum d, part[chunk][1][c] = sum d * xhat per side.  block = 4 row groups x 64 column quads (the scalar
+// kernel's row order: group w adds rows m0 + w, m0 + w + 4, ...; the groups are added in order)
+template <int NB>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const bf16_t* __restrict__ dy, int lddy, const bf16_t* __restrict__ dy2,
+                                                                int lddy2, const bf16_t* __restrict__ y, int ldy, BnBwdSide a,
+                                                                BnBwdSide b, int M, int C, int rows_per_chunk) {
+  __shared__ float4 red[NB][2][4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + lane) * 4;
+  const int m0 = blockIdx.y * rows_per_chunk, m1 = min(M, m0 + rows_per_chunk);
+  float4 s[NB], q[NB];
+#pragma unroll
+  for (int k = 0; k < NB; ++k) s[k] = q[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < C) {
+    float4 mu[NB], rs[NB];
+    mu[0] = *(const float4*)(a.mean + c);
+    rs[0] = *(const float4*)(a.rstd + c);
+    if constexpr (NB == 2) {
+      mu[1] = *(const float4*)(b.mean + c);
+      rs[1] = *(const float4*)(b.rstd + c);
+    }
+#pragma unroll 4
+    for (int m = m0 + w; m < m1; m += 4) {
+      const float4 d = bn_upstream(dy, dy2, y, (size_t)m * lddy + c, (size_t)m * lddy2 + c, (size_t)m * ldy + c);
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        const float4 xv = *(const float4*)((k ? b.x : a.x) + (size_t)m * (k ? b.ld : a.ld) + c);
+        s[k].x += d.x; s[k].y += d.y; s[k].z += d.z; s[k].w += d.w;
+        q[k].x = fmaf(d.x, (xv.x - mu[k].x) * rs[k].x, q[k].x);
+        q[k].y = fmaf(d.y, (xv.y - mu[k].y) * rs[k].y, q[k].y);
+        q[k].z = fmaf(d.z, (xv.z - mu[k].z) * rs[k].z, q[k].z);
+        q[k].w = fmaf(d.w, (xv.w - mu[k].w) * rs[k].w, q[k].w);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    red[k][0][w][lane] = s[k];
+    red[k][1][w][lane] = q[k];
+  }
+  __syncthreads();
+  if (w < 2 * NB && c < C) {                     // wave (side, which sum)
+    const int k = w >> 1, h = w & 1;
+    const float4 r0 = red[k][h][0][lane], r1 = red[k][h][1][lane], r2 = red[k][h][2][lane], r3 = red[k][h][3][lane];
+    float* part = (k ? b.part : a.part) + ((size_t)blockIdx.y * 2 + h) * C + c;
+    *(float4*)part = make_float4(r0.x + r1.x + r2.x + r3.x, r0.y + r1.y + r2.y + r3.y, r0.z + r1.z + r2.z + r3.z,
+                                 r0.w + r1.w + r2.w + r3.w);
+  }
+}
+
+// dx = gamma * rstd * (d - dbeta / n - xhat * dgamma / n) per side, bf16
+template <int NB>
+__global__ __launch_bounds__(256) void bn_bwd_dx_vec_kernel(const bf16_t* __restrict__ dy, int lddy, const bf16_t* __restrict__ dy2,
+                                                            int lddy2, const bf16_t* __restrict__ y, int ldy, BnBwdSide a, BnBwdSide b,
+                                                            int M, int C, float inv_n, int rows_per_chunk) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + lane) * 4;
+  if (c >= C) return;
+  float4 mu[NB], rs[NB], g[NB], kb[NB], kg[NB];
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    const BnBwdSide& sd = k ? b : a;
+    mu[k] = *(const float4*)(sd.mean + c);
+    rs[k] = *(const float4*)(sd.rstd + c);
+    const float4 ga = *(const float4*)(sd.gamma + c), db = *(const float4*)(sd.dbeta + c), dg = *(const float4*)(sd.dgamma + c);
+    g[k] = make_float4(ga.x * rs[k].x, ga.y * rs[k].y, ga.z * rs[k].z, ga.w * rs[k].w);
+    kb[k] = make_float4(db.x * inv_n, db.y * inv_n, db.z * inv_n, db.w * inv_n);
+    kg[k] = make_float4(dg.x * inv_n, dg.y * inv_n, dg.z * inv_n, dg.w * inv_n);
+  }
+  const int m0 = blockIdx.y * rows_per_chunk, m1 = min(M, m0 + rows_per_chunk);
+#pragma unroll 4
+  for (int m = m0 + w; m < m1; m += 4) {
+    const float4 d = bn_upstream(dy, dy2, y, (size_t)m * lddy + c, (size_t)m * lddy2 + c, (size_t)m * ldy + c);
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      const BnBwdSide& sd = k ? b : a;
+      const float4 xv = *(const float4*)(sd.x + (size_t)m * sd.ld + c);
+      const float v0 = g[k].x * (d.x - kb[k].x - (xv.x - mu[k].x) * rs[k].x * kg[k].x);
+      const float v1 = g[k].y * (d.y - kb[k].y - (xv.y - mu[k].y) * rs[k].y * kg[k].y);
+      const float v2 = g[k].z * (d.z - kb[k].z - (xv.z - mu[k].z) * rs[k].z * kg[k].z);
+      const float v3 = g[k].w * (d.w - kb[k].w - (xv.w - mu[k].w) * rs[k].w * kg[k].w);
+      uint2 o;
+      o.x = pack_bf16x2(v0, v1);
+      o.y = pack_bf16x2(v2, v3);
+      *(uint2*)(sd.dx + (size_t)m * sd.lddx + c) = o;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int msclip_im2col(const void* x, int x_kind, void* col, int B, int H, int W, int C, int KH, int KW, int stride,
@@ -842,6 +972,56 @@ extern "C" int msclip_bn_bwd_dx(const void* dy, int lddy, int dy_f32, const void
   else if (dy_f32) BN_DX(bf16_t, float);
   else BN_DX(bf16_t, bf16_t);
 #undef BN_DX
+  return msclip_launch_status();
+}
+
+// Fused form of (msclip_relu_bwd ->) msclip_bn_bwd_reduce / msclip_bn_bwd_dx for one or two BatchNorms behind the same upstream
+// gradient (include/msclip_hip.h).  pass 0 = the reduce (fills part1 / part2 [chunks][2][C]), pass 1 = the dx pass.
+extern "C" int msclip_bn_bwd_fused(int pass, const void* dy, int lddy, const void* dy2, int lddy2, const void* y, int ldy,
+                                   const msclip_bn_bwd_side* s1, const msclip_bn_bwd_side* s2, int M, int C, int chunks,
+                                   long long n_stat, void* stream) {
+  MSCLIP_PLAN_UNSUPPORTED(msclip_bn_bwd_fused)      // (side descriptors are host structs; the training step is not a plan)
+  if ((pass != 0 && pass != 1) || !dy || !s1 || M <= 0 || C <= 0 || (C & 3) || (lddy & 3) || lddy < C || ((size_t)dy & 7) ||
+      (dy2 && ((lddy2 & 3) || lddy2 < C || ((size_t)dy2 & 7))) || (y && ((ldy & 3) || ldy < C || ((size_t)y & 7))))
+    return MSCLIP_EINVAL;
+  BnBwdSide sd[2] = {};
+  for (int k = 0; k < 2; ++k) {
+    const msclip_bn_bwd_side* s = k ? s2 : s1;
+    if (!s) continue;
+    if (!s->x || !s->mean || !s->rstd || (s->ld & 3) || s->ld < C || ((size_t)s->x & 15) || ((size_t)s->mean & 15) || ((size_t)s->rstd & 15))
+      return MSCLIP_EINVAL;
+    if (pass == 0 && (!s->part || ((size_t)s->part & 15))) return MSCLIP_EINVAL;
+    if (pass == 1 && (!s->gamma || !s->dbeta || !s->dgamma || !s->dx || (s->lddx & 3) || s->lddx < C || ((size_t)s->dx & 7) ||
+                      ((size_t)s->gamma & 15) || ((size_t)s->dbeta & 15) || ((size_t)s->dgamma & 15)))
+      return MSCLIP_EINVAL;
+    sd[k] = BnBwdSide{s->x, s->ld, s->mean, s->rstd, s->gamma, s->dbeta, s->dgamma, (bf16_t*)s->dx, s->lddx, s->part};
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int cb = (C / 4 + 63) / 64;
+  if (pass == 0) {
+    if (chunks < 1 || chunks > 65535) return MSCLIP_EINVAL;
+    const int rpc = (M + chunks - 1) / chunks;
+    const dim3 grid(cb, chunks);
+    if (s2)
+      hipLaunchKernelGGL(bn_bwd_reduce_vec_kernel<2>, grid, dim3(256), 0, st, (const bf16_t*)dy, lddy, (const bf16_t*)dy2, lddy2,
+                         (const bf16_t*)y, ldy, sd[0], sd[1], M, C, rpc);
+    else
+      hipLaunchKernelGGL(bn_bwd_reduce_vec_kernel<1>, grid, dim3(256), 0, st, (const bf16_t*)dy, lddy, (const bf16_t*)dy2, lddy2,
+                         (const bf16_t*)y, ldy, sd[0], sd[0], M, C, rpc);
+    return msclip_launch_status();
+  }
+  if (n_stat <= 0) return MSCLIP_EINVAL;
+  int nch = chunks > 0 ? chunks : (M + 31) / 32;
+  if ((long long)nch * cb > 16384) nch = 16384 / cb > 0 ? 16384 / cb : 1;
+  const int rpc = (M + nch - 1) / nch;
+  const dim3 grid(cb, (M + rpc - 1) / rpc);
+  const float inv_n = 1.f / (float)n_stat;
+  if (s2)
+    hipLaunchKernelGGL(bn_bwd_dx_vec_kernel<2>, grid, dim3(256), 0, st, (const bf16_t*)dy, lddy, (const bf16_t*)dy2, lddy2,
+                       (const bf16_t*)y, ldy, sd[0], sd[1], M, C, inv_n, rpc);
+  else
+    hipLaunchKernelGGL(bn_bwd_dx_vec_kernel<1>, grid, dim3(256), 0, st, (const bf16_t*)dy, lddy, (const bf16_t*)dy2, lddy2,
+                       (const bf16_t*)y, ldy, sd[0], sd[0], M, C, inv_n, rpc);
   return msclip_launch_status();
 }
 

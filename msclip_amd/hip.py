@@ -25,7 +25,7 @@ EXPORTS = (
     "msclip_attention_bwd", "msclip_l2norm_bwd", "msclip_clip_loss_bwd_g", "msclip_embed_tokens_bwd", "msclip_adapter_sum",
     "msclip_adapter_dx", "msclip_adamw", "msclip_adamw_multi", "msclip_im2col", "msclip_col2im", "msclip_relu_bwd", "msclip_dwpool_bwd",
     "msclip_dwpool_wgrad", "msclip_dw3x3_wgrad", "msclip_gemm_splitk", "msclip_gemm_splitk_tn", "msclip_bn_stats", "msclip_bn_apply",
-    "msclip_bn_bwd_reduce", "msclip_bn_bwd_dx", "msclip_bn_fold_bwd", "msclip_bn_finish", "msclip_bn_finish_tiled", "msclip_bn_bwd_finish",
+    "msclip_bn_bwd_reduce", "msclip_bn_bwd_dx", "msclip_bn_bwd_fused", "msclip_bn_fold_bwd", "msclip_bn_finish", "msclip_bn_finish_tiled", "msclip_bn_bwd_finish",
     "msclip_text_lengths", "msclip_embed_tokens_packed", "msclip_attention_varlen", "msclip_attention_lastq_varlen",
     "msclip_attention_bwd_varlen", "msclip_embed_tokens_bwd_packed",
     "msclip_qkv_attention", "msclip_qkvattn_tables", "msclip_pack_weights", "msclip_transpose_bf16_multi", "msclip_image_conv_wgrad", "msclip_colsum_multi",
@@ -45,6 +45,13 @@ class HipUnavailable(RuntimeError):
 
 class HipError(RuntimeError):
     pass
+
+
+class BnBwdSide(ctypes.Structure):
+    """Mirror of struct msclip_bn_bwd_side."""
+    _fields_ = [("x", ctypes.c_void_p), ("ld", ctypes.c_int), ("mean", ctypes.c_void_p), ("rstd", ctypes.c_void_p),
+                ("gamma", ctypes.c_void_p), ("dbeta", ctypes.c_void_p), ("dgamma", ctypes.c_void_p), ("dx", ctypes.c_void_p),
+                ("lddx", ctypes.c_int), ("part", ctypes.c_void_p)]
 
 
 class GemmDesc(ctypes.Structure):
@@ -161,6 +168,7 @@ def lib():
         L.msclip_bn_finish.argtypes = [vp, ci, ci, ll, vp, vp, cf, vp, vp]
         L.msclip_bn_finish_tiled.argtypes = [vp, ci, ci, ll, vp, vp, cf, vp, ci, vp]
         L.msclip_bn_bwd_finish.argtypes = [vp, ci, ci, ci, vp, vp, vp]
+        L.msclip_bn_bwd_fused.argtypes = [ci, vp, ci, vp, ci, vp, ci, ctypes.POINTER(BnBwdSide), ctypes.POINTER(BnBwdSide), ci, ci, ci, ll, vp]
         L.msclip_bn_fold_bwd.argtypes = [vp, ll, vp, ci, ci, vp, vp, vp, vp, cf, vp, vp, vp, vp]
         L.msclip_text_lengths.argtypes = [vp, ci, ci, ci, vp, vp, vp, vp, ci, ci, vp]
         L.msclip_embed_tokens_packed.argtypes = [vp, vp, vp, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, vp]
@@ -1584,6 +1592,58 @@ def bn_bwd(dy, x, mean, rstd, gamma, dx, M=None):
         _check(lib().msclip_bn_bwd_dx(_p(dy), dy.stride(0), df, _p(x), x.stride(0), xf, _p(mean), _p(rstd), _p(gamma),
                                       _p(dbeta), _p(dgamma), _p(dx), dx.stride(0), M, C, M, _stream()), "msclip_bn_bwd_dx")
     return dgamma, dbeta
+
+
+def bn_bwd_fused_ok(dy, sides, y=None, dy2=None, M=None):
+    """Shapes msclip_bn_bwd_fused takes: bf16 contiguous [M, C] gradients / mask map, fp32 contiguous raw maps, C % 4 == 0."""
+    M = sides[0][0].shape[0] if M is None else M
+    C = sides[0][0].shape[1]
+    mats = [dy] + [t for t in (y, dy2) if t is not None]
+    if C % 4 or len(sides) not in (1, 2) or any(t.dtype != torch.bfloat16 or t.shape[1] != C or not t.is_contiguous() or t.shape[0] < M
+                                                  for t in mats):
+        return False
+    return all(x.dtype == torch.float32 and x.is_contiguous() and x.shape[1] == C and x.shape[0] >= M and
+               dx.dtype == torch.bfloat16 and dx.is_contiguous() and dx.shape[1] == C and dx.shape[0] >= M
+               for x, _, _, _, dx in sides)
+
+
+def bn_bwd_fused(dy, sides, y=None, dy2=None, M=None, chunks=None, dx_chunks=0):
+    """Train-mode BatchNorm backward of one or two BatchNorms behind the same upstream gradient d = bf16(dy [+ dy2]) * (y > 0)
+    (msclip_bn_bwd_fused: no msclip_relu_bwd pass, no map of d; four columns per thread).  sides = [(x_raw fp32 [M, C], mean, rstd,
+    gamma, dx bf16 [M, C]), ...] -> [(dgamma, dbeta), ...]; every dx is filled."""
+    M = sides[0][0].shape[0] if M is None else M
+    C = sides[0][0].shape[1]
+    assert bn_bwd_fused_ok(dy, sides, y, dy2, M)
+    mats = [dy[:M]] + [t[:M] for t in (y, dy2) if t is not None] + [x[:M] for x, *_ in sides] + [s[4][:M] for s in sides]
+    r = _bn_fold_rows(M, C, *mats)
+    Mw, Cw = M // r, C * r
+    # row chunks of the reduce pass: 128-256 rows each, at least ~200 of them where the map has the rows (sweep of
+    # tools/probes/bn_bwd_fused_bench.py: 14^2 / 7^2 maps lose 2 x with the 1 024-row chunks of the scalar kernels)
+    ch = max(1, min(1568, max(Mw // 256, 196), Mw // 32))
+    if chunks:
+        ch = chunks                                      # (probe: tools/probes/bn_bwd_fused_bench.py)
+    dev = dy.device
+    sd, keep = [], []
+    for x, mean, rstd, gamma, dx in sides:
+        t = getattr(mean, "_bn_tiled", None)
+        if r > 1 and t is not None and t[1] == r and getattr(rstd, "_bn_tiled", (None,))[0] is t[0]:
+            mw, rw = t[0][0], t[0][2]                    # bn_stats' own tiled rows
+        else:
+            mw, rw = (mean.repeat(r), rstd.repeat(r)) if r > 1 else (mean.contiguous(), rstd.contiguous())
+        part = torch.empty(ch, 2 * Cw, dtype=torch.float32, device=dev)
+        tail = torch.empty(3, Cw, dtype=torch.float32, device=dev)
+        keep.append((mw, rw, part, tail))
+        sd.append(BnBwdSide(_p(x), Cw, _p(mw), _p(rw), _p(tail[2]), _p(tail[0]), _p(tail[1]), _p(dx), Cw, _p(part)))
+    s2 = ctypes.byref(sd[1]) if len(sd) == 2 else None
+    args = (_p(dy), Cw, _p(dy2) if dy2 is not None else None, Cw, _p(y) if y is not None else None, Cw, ctypes.byref(sd[0]), s2, Mw, Cw)
+    st = _stream()
+    _check(lib().msclip_bn_bwd_fused(0, *args, ch, M, st), "msclip_bn_bwd_fused (reduce)")
+    out = []
+    for (x, mean, rstd, gamma, dx), (mw, rw, part, tail) in zip(sides, keep):
+        _check(lib().msclip_bn_bwd_finish(_p(part), ch, r, C, _p(gamma), _p(tail), st), "msclip_bn_bwd_finish")
+        out.append((tail[1, :C], tail[0, :C]))
+    _check(lib().msclip_bn_bwd_fused(1, *args, dx_chunks, M, st), "msclip_bn_bwd_fused (dx)")
+    return out
 
 
 def bn_fold_bwd(G, w_raw, dshift, gamma, mean, var, eps):

@@ -89,6 +89,9 @@ class TrainOptions:
     im2col_main: bool = False         # MSCLIP_IM2COL_MAIN: the conv side's column matrices on the main stream instead of the lane
     compact_last_block: bool = True   # MSCLIP_TRAIN_COMPACT_LAST: the last block's out_proj / ln_2 / MLP (forward and backward) on the
     #                                   Bi + Bt rows that are read behind it (cls / EOT), as the inference path does (round 6)
+    bn_bwd_fused: bool = True         # MSCLIP_BN_BWD_FUSED: train-mode BatchNorm backward with the ReLU mask applied on the fly and the
+    #                                   two BatchNorms of a residual block in one pass (msclip_bn_bwd_fused); 0 = msclip_relu_bwd
+    #                                   + one msclip_bn_bwd_reduce / _dx pair per BatchNorm (round 5)
     colsum_main: bool = False         # MSCLIP_COLSUM_MAIN: the conv side's bias sums on the main stream instead of the lane
     #                                   (either of the two makes a hipGraph replay of the step right: profiles/r06_train_hipgraph_probe.txt)
 
@@ -96,7 +99,7 @@ class TrainOptions:
     def from_env(cls):
         return cls(wgrad_sync=_flag("MSCLIP_WGRAD_SYNC", False), dgrad_col2im=_flag("MSCLIP_DGRAD_COL2IM", False),
                    im2col_main=_flag("MSCLIP_IM2COL_MAIN", False), colsum_main=_flag("MSCLIP_COLSUM_MAIN", False),
-                   compact_last_block=_flag("MSCLIP_TRAIN_COMPACT_LAST", True))
+                   compact_last_block=_flag("MSCLIP_TRAIN_COMPACT_LAST", True), bn_bwd_fused=_flag("MSCLIP_BN_BWD_FUSED", True))
 
     def replace(self, **kw):
         return dataclasses.replace(self, **kw)

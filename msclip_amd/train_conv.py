@@ -601,13 +601,31 @@ class ConvSideBatchNorm:
         grads[prefix + ".weight"], grads[prefix + ".bias"] = dg, db
         return dx
 
+    def _bn_bwd_masked(self, grads, prefixes, dy, y=None, dy2=None):
+        """The BatchNorms `prefixes` (one, or a residual block's two) behind d = (dy [+ dy2]) * (y > 0): one fused reduce + one fused
+        dx pass (msclip_bn_bwd_fused) where the shapes allow, the ReLU pass + a pass pair per BatchNorm else.  -> [dx per prefix]"""
+        saved = [self.saved[p] for p in prefixes]
+        M = saved[0][4]
+        if options.TRAIN.bn_bwd_fused and dy.dtype == BF and all(sv[4] == M for sv in saved):
+            dxs = [_zbuf(sv[0].shape[0], sv[0].shape[1], sv[0].device) for sv in saved]
+            sides = [(sv[0], sv[1], sv[2], sv[3], dx) for sv, dx in zip(saved, dxs)]
+        else:
+            sides = None
+        if sides is not None and hip.bn_bwd_fused_ok(dy, sides, y, dy2, M):
+            res = hip.bn_bwd_fused(dy, sides, y=y, dy2=dy2, M=M)
+            for p, (dg, db) in zip(prefixes, res):
+                grads[p + ".weight"], grads[p + ".bias"] = dg, db
+            return dxs
+        dpre = self.bw._relu_bwd(dy, y, dy2=dy2) if y is not None else dy
+        return [self._bn_bwd(grads, p, dpre) for p in prefixes]
+
     def _conv(self, grads, key, spec, wkey, x_in, draw, need_dx=True, relu_of=None):
         G, _, dx = self.bw._conv_bwd(key, spec, x_in, draw, self.Bi, need_dx=need_dx, lane=True, relu_of=relu_of)
         grads[wkey] = G                                  # final after gradgemm.join (end of the backward / bucket flush)
         return dx
 
-    def _first(self, grads, wkey, prefix, dpre):
-        draw = self._bn_bwd(grads, prefix, dpre)
+    def _first(self, grads, wkey, prefix, dy, y=None, dy2=None):
+        draw, = self._bn_bwd_masked(grads, [prefix], dy, y=y, dy2=dy2)
         pix = self.Bi * self.e.h1 * self.e.h1
         co = draw.shape[1]
         if hip.image_conv_wgrad_ok(self.img, draw) and self.e.h1 <= 128:
@@ -652,24 +670,23 @@ class ConvSideBatchNorm:
     def _stage_bwd(self, grads, j):
         e, w = self.e, self.w
         da, db_ = self.bw.dpar
-        dpre = self.bw._relu_bwd(da, w["par"][j], dy2=db_)
         self.bw.dpar = [None, None]
         if j == 0:
-            self._first(grads, "visual.transformer.parallel_branch_v.0.conv.weight", "visual.transformer.parallel_branch_v.0.bn", dpre)
+            self._first(grads, "visual.transformer.parallel_branch_v.0.conv.weight", "visual.transformer.parallel_branch_v.0.bn", da,
+                        y=w["par"][j], dy2=db_)
             return
         c1, c2, cr, c3, q = self.raw.par[j]
         t1, t2, _ = w["par_tmp"][j]
         src = w["par"][j - 1]
-        d3 = self._bn_bwd(grads, q + ".bn3", dpre)
-        dr = self._bn_bwd(grads, q + ".residual_bn", dpre)
-        del dpre
+        d3, dr = self._bn_bwd_masked(grads, [q + ".bn3", q + ".residual_bn"], da, y=w["par"][j], dy2=db_)
+        del da, db_
         dt2 = self._conv(grads, ("par", j, 3), c3, q + ".conv3.weight", t2, d3)
         short = self.bw._shortcut_ok(cr)     # the shortcut's input gradient is added into conv1's below (no map of its own)
         dsrc_a = self._conv(grads, ("par", j, "r"), cr, q + ".residual_conv.weight", src, dr, need_dx=not short)
         del d3
         if not short:
             del dr
-        d2 = self._bn_bwd(grads, q + ".bn2", self.bw._relu_bwd(dt2, t2))
+        d2, = self._bn_bwd_masked(grads, [q + ".bn2"], dt2, y=t2)
         dt1 = self._conv(grads, ("par", j, 2), c2, q + ".conv2.weight", t1, d2, relu_of=t1)      # (through t1's ReLU)
         del d2, dt2
         d1 = self._bn_bwd(grads, q + ".bn1", dt1)
@@ -693,10 +710,7 @@ class ConvSideBatchNorm:
         for i in reversed(range(len(self.raw.stem))):
             main, short, q = self.raw.stem[i]
             x_in = w["stem"][i - 1] if i else w["S1"]
-            dpre = self.bw._relu_bwd(dy, w["stem"][i], dy2=dy2)
-            dm = self._bn_bwd(grads, q + ".bn1", dpre)
-            ds = self._bn_bwd(grads, q + ".downsample.1", dpre)
-            del dpre
+            dm, ds = self._bn_bwd_masked(grads, [q + ".bn1", q + ".downsample.1"], dy, y=w["stem"][i], dy2=dy2)
             dy = self._conv(grads, ("stem", i, "m"), main, q + ".conv1.weight", x_in, dm)
             if self.bw._shortcut_ok(short):              # the 1x1 / stride-2 shortcut's input gradient: added into the main path's map
                 self._conv(grads, ("stem", i, "s"), short, q + ".downsample.0.weight", x_in, ds, need_dx=False)
@@ -704,6 +718,6 @@ class ConvSideBatchNorm:
                 dy2 = None
             else:
                 dy2 = self._conv(grads, ("stem", i, "s"), short, q + ".downsample.0.weight", x_in, ds)
-        self._first(grads, sp + ".conv1.weight", sp + ".bn1", self.bw._relu_bwd(dy, w["S1"], dy2=dy2))
+        self._first(grads, sp + ".conv1.weight", sp + ".bn1", dy, y=w["S1"], dy2=dy2)
         self.bw.col_img = None
         self.saved = {}                                  # the raw maps (several GB at batch 512) are not kept between steps

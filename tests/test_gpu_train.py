@@ -610,6 +610,33 @@ def test_batchnorm_train_kernels(gpu_device, dtype, M, C):
         assert rel(dxb, xr2.grad) <= 1e-2
 
 
+@pytest.mark.parametrize("M,C,two,mask,add", [(6272, 48, True, True, True), (3000, 768, False, True, False), (4096, 96, True, True, False),
+                                              (777, 192, False, False, True), (50176, 48, False, True, True)])
+def test_batchnorm_backward_fused_with_relu_mask(gpu_device, M, C, two, mask, add):
+    """msclip_bn_bwd_fused (round 6): d = bf16(dy [+ dy2]) * (y > 0) formed on the fly, one or two BatchNorms per pass, four columns
+    per thread -- against msclip_relu_bwd followed by one msclip_bn_bwd_reduce / _dx pair per BatchNorm (the round-5 path, itself
+    pinned to autograd of F.batch_norm above), row-folded narrow maps and a ragged row count included."""
+    dy, dy2 = rnd(M, C, seed=1, dtype=BF), rnd(M, C, seed=2, dtype=BF)
+    y = torch.relu(rnd(M, C, seed=3)).to(BF)
+    xs = [(rnd(M, C, seed=10 + k) * 1.5 + 0.3).float().contiguous() for k in range(2 if two else 1)]
+    gams = [rnd(C, seed=20 + k) * 0.5 + 1.0 for k in range(len(xs))]
+    stats = [hip.bn_stats(x, gamma=g, beta=torch.zeros_like(g), eps=1e-5) for x, g in zip(xs, gams)]
+    dpre = hip.relu_bwd(dy, y, dy2=dy2 if add else None) if mask else (hip.relu_bwd(dy, torch.ones_like(y), dy2=dy2) if add else dy)
+    want = []
+    for x, g, st in zip(xs, gams, stats):
+        dx = torch.empty(M, C, dtype=BF, device="cuda")
+        dg, db = hip.bn_bwd(dpre, x, st[0], st[2], g, dx)
+        want.append((dg.clone(), db.clone(), dx))
+    dxs = [torch.full((M, C), float("nan"), dtype=BF, device="cuda") for _ in xs]
+    sides = [(x, st[0], st[2], g, dx) for x, g, st, dx in zip(xs, gams, stats, dxs)]
+    assert hip.bn_bwd_fused_ok(dy, sides, y if mask else None, dy2 if add else None, M)
+    got = hip.bn_bwd_fused(dy, sides, y=y if mask else None, dy2=dy2 if add else None, M=M)
+    for (dg, db), dx, (wg, wb, wdx) in zip(got, dxs, want):
+        assert rel(dg, wg) <= 2e-5 and rel(db, wb) <= 2e-5, (rel(dg, wg), rel(db, wb))
+        # the same fp32 expression on the same bf16 inputs: equal up to a bf16 rounding tie moved by the 1e-5 of the sums
+        assert rel(dx, wdx) <= 8e-3 and (dx.float() != wdx.float()).float().mean().item() <= 1e-3
+
+
 def _reference_bf16_deviation(tag, model=None):
     """The reference's OWN gradient deviation when it runs under torch.autocast(bfloat16) instead of fp32 (same weights,
     same batch, the metrics of these tests; tools/ref_bf16_gradient_deviation.py): the yardstick for the tolerances."""
@@ -1208,6 +1235,29 @@ def test_gradients_at_batch_32_against_reference_autograd(gpu_device, bn):
         if k in vec:
             assert coss[k] >= dev["conv_side"]["cosine_lowest"] - 5e-3, (k, coss[k])
     assert conv_med <= dev["conv_side"]["sample_err_median"] + 5e-3, (conv_med, dev["conv_side"]["sample_err_median"])
+
+
+def test_fused_batchnorm_backward_in_the_step_equals_the_pass_per_batchnorm_path(gpu_device, monkeypatch):
+    """options.TRAIN.bn_bwd_fused (default) against the round-5 path in the whole train-mode step: same loss, every conv-side
+    gradient equal to summation-order noise (the reference-autograd fixtures above run the fused default)."""
+    from msclip_amd import options
+    m = _fresh_model("b32-yfcc-msclips")
+    img = synth.synth_images(24, seed=601).cuda()
+    tok = synth.synth_tokens(24, seed=602, min_len=2, max_len=40).cuda()
+    out = {}
+    for fused in (False, True):
+        monkeypatch.setattr(options, "TRAIN", options.TRAIN.replace(bn_bwd_fused=fused))
+        ts = train.TrainStep(m, lr=1e-4, bn="batch")
+        loss = ts.forward(img, tok)
+        out[fused] = (loss.item(), {k: v.float().clone() for k, v in ts.backward().items()})
+    (l0, g0), (l1, g1) = out[False], out[True]
+    assert l0 == l1 and sorted(g0) == sorted(g1)
+    worst = {}
+    for k in g0:
+        a, b = g0[k].flatten(), g1[k].flatten()
+        worst[k] = (a - b).abs().max().item() / max(a.abs().max().item(), 1e-12)
+    print("fused vs per-BatchNorm backward: worst", sorted(worst.items(), key=lambda kv: -kv[1])[:4])
+    assert max(worst.values()) <= 2e-2 and float(np.median(list(worst.values()))) <= 2e-3
 
 
 @pytest.mark.parametrize("bn,B", [("frozen", 12), ("batch", 256)])
