@@ -594,7 +594,9 @@ class ConvSideBatchNorm:
             torch._foreach_add_([bufs[k + ".num_batches_tracked"] for k in keys], 1)
 
     # ------------------------------------------------------------------ backward
-    def _bn_bwd(self, grads, prefix, dy):
+    def _bn_bwd(self, grads, prefix, dy, _plain=False):
+        if not _plain and options.TRAIN.bn_bwd_fused and dy.dtype == BF:
+            return self._bn_bwd_masked(grads, [prefix], dy)[0]       # (the 4-columns-per-thread passes; falls back to here)
         x_raw, mean, rstd, gam, M = self.saved[prefix]
         dx = torch.empty_like(dy) if dy.dtype == F32 else _zbuf(x_raw.shape[0], x_raw.shape[1], x_raw.device)
         dg, db = hip.bn_bwd(dy, x_raw, mean, rstd, gam, dx, M)
@@ -617,7 +619,8 @@ class ConvSideBatchNorm:
                 grads[p + ".weight"], grads[p + ".bias"] = dg, db
             return dxs
         dpre = self.bw._relu_bwd(dy, y, dy2=dy2) if y is not None else dy
-        return [self._bn_bwd(grads, p, dpre) for p in prefixes]
+        assert y is not None or dy2 is None
+        return [self._bn_bwd(grads, p, dpre, _plain=True) for p in prefixes]
 
     def _conv(self, grads, key, spec, wkey, x_in, draw, need_dx=True, relu_of=None):
         G, _, dx = self.bw._conv_bwd(key, spec, x_in, draw, self.Bi, need_dx=need_dx, lane=True, relu_of=relu_of)
