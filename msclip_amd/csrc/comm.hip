@@ -33,11 +33,8 @@ struct Rccl {
   bool ok = false;
 };
 
-Rccl& rccl() {
-  static Rccl r;
-  static bool tried = false;
-  if (tried) return r;
-  tried = true;
+Rccl load_rccl() {
+  Rccl r;
   const char* names[] = {"librccl.so.1", "librccl.so"};
   for (const char* n : names) {                                // an instance that is already in the process (torch's) first
     r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
@@ -62,6 +59,11 @@ Rccl& rccl() {
   SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
   r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.AllReduce;
+  return r;
+}
+
+Rccl& rccl() {
+  static Rccl r = load_rccl();                                 // (one load, thread-safe: C++11 static initialisation)
   return r;
 }
 
