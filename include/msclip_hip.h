@@ -292,6 +292,17 @@ int msclip_stem_conv3x3s2_dual(const void* img, int img_is_bf16, const float* w,
  * filters are rounded to bf16 for the MFMA like every convolution operand here.  No patch matrix. */
 int msclip_stem_conv3x3s2_dual_raw(const void* img, int img_is_bf16, const float* w, float* out_a, float* out_b, int B, int H, int W,
                                    void* stream);
+/* Round 6: the two-pass form of train-mode BatchNorm over the same two convolutions (M.py:1939-1946 conv1 + bn1; :2260-2273 the
+ * parallel branch's stage 0) -- the raw maps are never written.
+ * msclip_stem_conv3x3s2_dual_stats: part [part_waves][2][2][48] fp32 = per wave (sum x, sum x^2) of conv a, then conv b (part_waves
+ *   a multiple of 4 = 4 x the launch's workgroups; fold the rows with msclip_colsum).
+ * msclip_stem_conv3x3s2_dual_norm: the convolutions again; consts [4][96] fp32 = (scale, shift, a, b) per channel, conv a's 48
+ *   channels first: y = relu(x scale + shift) (the expression of msclip_bn_apply), xhat = x a + b (a = rstd, b = -mean rstd), all four
+ *   outputs bf16 [B * H/2 * W/2][48].  The backward reads xhat where it read the raw fp32 map (mean 0, rstd 1, gamma := scale). */
+int msclip_stem_conv3x3s2_dual_stats(const void* img, int img_is_bf16, const float* w, float* part, int part_waves, int B, int H, int W,
+                                     void* stream);
+int msclip_stem_conv3x3s2_dual_norm(const void* img, int img_is_bf16, const float* w, const float* consts, void* y_a, void* y_b,
+                                    void* xhat_a, void* xhat_b, int B, int H, int W, void* stream);
 
 /* The same pass fused with the 3x3/s2/p1 convolution that consumes branch a (stem resnet_stage.conv_0 with its folded
  * 1x1 shortcut and ReLU, M.py:1920-1936): branch a's 48-channel map stays in LDS (8x8 output tiles, 17x17 windows),
@@ -512,7 +523,7 @@ int msclip_bn_bwd_dx(const void* dy, int lddy, int dy_f32, const void* x, int ld
  * pass 0: s->part [chunks][2][C] = (sum d, sum d * xhat) per row chunk (fold with msclip_bn_bwd_finish);
  * pass 1: s->dx (bf16) = gamma rstd (d - dbeta / n_stat - xhat dgamma / n_stat).  Not recordable in a plan (host structs). */
 typedef struct msclip_bn_bwd_side {
-  const float* x;       /* raw convolution output [M][ld], fp32 */
+  const void* x;        /* [M][ld]: the raw convolution output, fp32 -- or (x_bf16) xhat in bf16 with mean = 0, rstd = 1, gamma := gamma rstd */
   int ld;
   const float* mean;    /* [C] */
   const float* rstd;    /* [C] */
@@ -522,6 +533,7 @@ typedef struct msclip_bn_bwd_side {
   void* dx;             /* pass 1: bf16 [M][lddx] */
   int lddx;
   float* part;          /* pass 0 */
+  int x_bf16;           /* both sides of a call alike */
 } msclip_bn_bwd_side;
 int msclip_bn_bwd_fused(int pass, const void* dy, int lddy, const void* dy2, int lddy2, const void* y, int ldy,
                         const msclip_bn_bwd_side* s1, const msclip_bn_bwd_side* s2, int M, int C, int chunks, long long n_stat,

@@ -647,7 +647,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const TD* __restrict__ d
 // fly -- d = bf16(dy [+ dy2]) * (y > 0), exactly what msclip_relu_bwd would have written -- so that pass and its map are gone;
 // (3) two BatchNorms that receive the SAME upstream gradient (a residual block's main path and its shortcut) share one pass.
 struct BnBwdSide {
-  const float* x;        // raw convolution output [M][ld]
+  const void* x;         // [M][ld]: the raw convolution output (fp32), or xhat (bf16: mean 0 / rstd 1 / gamma := scale; two-pass forward)
   int ld;
   const float* mean;     // [C] (tiled with the row fold)
   const float* rstd;
@@ -665,6 +665,11 @@ __device__ __forceinline__ float4 bn_ld_bf16x4(const bf16_t* p) {
                      __uint_as_float(r.y & 0xffff0000u));
 }
 __device__ __forceinline__ float bn_round_bf16(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+template <typename XT>
+__device__ __forceinline__ float4 bn_ld_x4(const void* x, size_t off) {
+  if constexpr (sizeof(XT) == 4) return *(const float4*)((const float*)x + off);
+  else return bn_ld_bf16x4((const bf16_t*)x + off);
+}
 
 // the upstream gradient of one (row, column quad) as the unfused path's msclip_relu_bwd output would hold it
 __device__ __forceinline__ float4 bn_upstream(const bf16_t* dy, const bf16_t* dy2, const bf16_t* y, size_t o_dy, size_t o_dy2,
@@ -683,7 +688,7 @@ __device__ __forceinline__ float4 bn_upstream(const bf16_t* dy, const bf16_t* dy
 
 // part[chunk][0][c] = sum d, part[chunk][1][c] = sum d * xhat per side.  block = 4 row groups x 64 column quads (the scalar
 // kernel's row order: group w adds rows m0 + w, m0 + w + 4, ...; the groups are added in order)
-template <int NB>
+template <int NB, typename XT>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const bf16_t* __restrict__ dy, int lddy, const bf16_t* __restrict__ dy2,
                                                                 int lddy2, const bf16_t* __restrict__ y, int ldy, BnBwdSide a,
                                                                 BnBwdSide b, int M, int C, int rows_per_chunk) {
@@ -707,7 +712,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const bf16_t* __
       const float4 d = bn_upstream(dy, dy2, y, (size_t)m * lddy + c, (size_t)m * lddy2 + c, (size_t)m * ldy + c);
 #pragma unroll
       for (int k = 0; k < NB; ++k) {
-        const float4 xv = *(const float4*)((k ? b.x : a.x) + (size_t)m * (k ? b.ld : a.ld) + c);
+        const float4 xv = bn_ld_x4<XT>(k ? b.x : a.x, (size_t)m * (k ? b.ld : a.ld) + c);
         s[k].x += d.x; s[k].y += d.y; s[k].z += d.z; s[k].w += d.w;
         q[k].x = fmaf(d.x, (xv.x - mu[k].x) * rs[k].x, q[k].x);
         q[k].y = fmaf(d.y, (xv.y - mu[k].y) * rs[k].y, q[k].y);
@@ -732,7 +737,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const bf16_t* __
 }
 
 // dx = gamma * rstd * (d - dbeta / n - xhat * dgamma / n) per side, bf16
-template <int NB>
+template <int NB, typename XT>
 __global__ __launch_bounds__(256) void bn_bwd_dx_vec_kernel(const bf16_t* __restrict__ dy, int lddy, const bf16_t* __restrict__ dy2,
                                                             int lddy2, const bf16_t* __restrict__ y, int ldy, BnBwdSide a, BnBwdSide b,
                                                             int M, int C, float inv_n, int rows_per_chunk) {
@@ -757,7 +762,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_vec_kernel(const bf16_t* __rest
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
       const BnBwdSide& sd = k ? b : a;
-      const float4 xv = *(const float4*)(sd.x + (size_t)m * sd.ld + c);
+      const float4 xv = bn_ld_x4<XT>(sd.x, (size_t)m * sd.ld + c);
       const float v0 = g[k].x * (d.x - kb[k].x - (xv.x - mu[k].x) * rs[k].x * kg[k].x);
       const float v1 = g[k].y * (d.y - kb[k].y - (xv.y - mu[k].y) * rs[k].y * kg[k].y);
       const float v2 = g[k].z * (d.z - kb[k].z - (xv.z - mu[k].z) * rs[k].z * kg[k].z);
@@ -988,7 +993,8 @@ extern "C" int msclip_bn_bwd_fused(int pass, const void* dy, int lddy, const voi
   for (int k = 0; k < 2; ++k) {
     const msclip_bn_bwd_side* s = k ? s2 : s1;
     if (!s) continue;
-    if (!s->x || !s->mean || !s->rstd || (s->ld & 3) || s->ld < C || ((size_t)s->x & 15) || ((size_t)s->mean & 15) || ((size_t)s->rstd & 15))
+    if (!s->x || !s->mean || !s->rstd || (s->ld & 3) || s->ld < C || ((size_t)s->x & (s->x_bf16 ? 7 : 15)) || ((size_t)s->mean & 15) ||
+        ((size_t)s->rstd & 15) || (s->x_bf16 != 0) != (s1->x_bf16 != 0))
       return MSCLIP_EINVAL;
     if (pass == 0 && (!s->part || ((size_t)s->part & 15))) return MSCLIP_EINVAL;
     if (pass == 1 && (!s->gamma || !s->dbeta || !s->dgamma || !s->dx || (s->lddx & 3) || s->lddx < C || ((size_t)s->dx & 7) ||
@@ -1002,12 +1008,14 @@ extern "C" int msclip_bn_bwd_fused(int pass, const void* dy, int lddy, const voi
     if (chunks < 1 || chunks > 65535) return MSCLIP_EINVAL;
     const int rpc = (M + chunks - 1) / chunks;
     const dim3 grid(cb, chunks);
-    if (s2)
-      hipLaunchKernelGGL(bn_bwd_reduce_vec_kernel<2>, grid, dim3(256), 0, st, (const bf16_t*)dy, lddy, (const bf16_t*)dy2, lddy2,
-                         (const bf16_t*)y, ldy, sd[0], sd[1], M, C, rpc);
-    else
-      hipLaunchKernelGGL(bn_bwd_reduce_vec_kernel<1>, grid, dim3(256), 0, st, (const bf16_t*)dy, lddy, (const bf16_t*)dy2, lddy2,
-                         (const bf16_t*)y, ldy, sd[0], sd[0], M, C, rpc);
+#define BN_RED_VEC(NB, XT, B2)                                                                                               \
+  hipLaunchKernelGGL((bn_bwd_reduce_vec_kernel<NB, XT>), grid, dim3(256), 0, st, (const bf16_t*)dy, lddy, (const bf16_t*)dy2, lddy2, \
+                     (const bf16_t*)y, ldy, sd[0], sd[B2], M, C, rpc)
+    if (s2 && s1->x_bf16) BN_RED_VEC(2, bf16_t, 1);
+    else if (s2) BN_RED_VEC(2, float, 1);
+    else if (s1->x_bf16) BN_RED_VEC(1, bf16_t, 0);
+    else BN_RED_VEC(1, float, 0);
+#undef BN_RED_VEC
     return msclip_launch_status();
   }
   if (n_stat <= 0) return MSCLIP_EINVAL;
@@ -1016,12 +1024,14 @@ extern "C" int msclip_bn_bwd_fused(int pass, const void* dy, int lddy, const voi
   const int rpc = (M + nch - 1) / nch;
   const dim3 grid(cb, (M + rpc - 1) / rpc);
   const float inv_n = 1.f / (float)n_stat;
-  if (s2)
-    hipLaunchKernelGGL(bn_bwd_dx_vec_kernel<2>, grid, dim3(256), 0, st, (const bf16_t*)dy, lddy, (const bf16_t*)dy2, lddy2,
-                       (const bf16_t*)y, ldy, sd[0], sd[1], M, C, inv_n, rpc);
-  else
-    hipLaunchKernelGGL(bn_bwd_dx_vec_kernel<1>, grid, dim3(256), 0, st, (const bf16_t*)dy, lddy, (const bf16_t*)dy2, lddy2,
-                       (const bf16_t*)y, ldy, sd[0], sd[0], M, C, inv_n, rpc);
+#define BN_DX_VEC(NB, XT, B2)                                                                                                \
+  hipLaunchKernelGGL((bn_bwd_dx_vec_kernel<NB, XT>), grid, dim3(256), 0, st, (const bf16_t*)dy, lddy, (const bf16_t*)dy2, lddy2, \
+                     (const bf16_t*)y, ldy, sd[0], sd[B2], M, C, inv_n, rpc)
+  if (s2 && s1->x_bf16) BN_DX_VEC(2, bf16_t, 1);
+  else if (s2) BN_DX_VEC(2, float, 1);
+  else if (s1->x_bf16) BN_DX_VEC(1, bf16_t, 0);
+  else BN_DX_VEC(1, float, 0);
+#undef BN_DX_VEC
   return msclip_launch_status();
 }
 

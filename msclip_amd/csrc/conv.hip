@@ -79,21 +79,35 @@ __global__ __launch_bounds__(256) void stem_dual_kernel(const InT* __restrict__ 
 // The pass is HBM-bound: 4 B/pixel/channel in, 2 x 96 B per output pixel out.
 // RAW (msclip_stem_conv3x3s2_dual_raw; the training step under train-mode BatchNorm, which normalises the RAW convolution outputs
 // with batch statistics): no bias, no ReLU, fp32 outputs [pixels][48] -- the staging planes and the output runs are twice as long.
-template <typename InT, bool RAW = false>
+// BN_STATS / BN_NORM (round 6; msclip_stem_conv3x3s2_dual_stats / _norm): the two-pass form of the same train-mode BatchNorm.  The raw
+// fp32 maps are never written: pass 1 runs the convolutions for their per-channel sums only (sum x, sum x^2 per wave ->
+// part [waves][conv][2][48], folded by msclip_colsum), pass 2 runs them again and normalises in the epilogue -- y = relu(x scale +
+// shift), the same expression msclip_bn_apply evaluates, and xhat = x a + b (a = rstd, b = -mean rstd), both bf16: xhat is what the
+// backward reads instead of the raw map.  18 -> 8 bytes per map element over the forward (the image is read twice: 0.3 GB).
+enum { STEM_FOLDED = 0, STEM_RAW = 1, STEM_BN_STATS = 2, STEM_BN_NORM = 3 };
+template <typename InT, int MODE = STEM_FOLDED>
 __global__ __launch_bounds__(256) void stem_dual_mfma_kernel(const InT* __restrict__ img, const float* __restrict__ w,
                                                              const float* __restrict__ bias, void* __restrict__ out_a_,
                                                              void* __restrict__ out_b_, int B, int H, int W, int Ho,
-                                                             int Wo) {
+                                                             int Wo, void* __restrict__ out_c_ = nullptr,
+                                                             void* __restrict__ out_d_ = nullptr, float* __restrict__ part = nullptr) {
+  constexpr bool RAW = MODE == STEM_RAW;
   constexpr int PLANE = RAW ? 6144 : 3072;            // bytes of one staged output: 32 pixels x 48 channels
-  __shared__ __attribute__((aligned(16))) char stg_all[4 * 2 * PLANE];
-  __shared__ __attribute__((aligned(16))) float bias_l[96];
-  if (threadIdx.x < 96) bias_l[threadIdx.x] = RAW ? 0.f : bias[threadIdx.x];
+  constexpr int NPLANE = MODE == STEM_BN_NORM ? 4 : 2;
+  __shared__ __attribute__((aligned(16))) char stg_all[MODE == STEM_BN_STATS ? 16 : 4 * NPLANE * PLANE];
+  // FOLDED: bias [96]; BN_NORM: `bias` points at [4][96] = scale, shift, a, b per channel (conv a's 48 channels, then conv b's)
+  __shared__ __attribute__((aligned(16))) float bias_l[MODE == STEM_BN_NORM ? 384 : 96];
+  if (MODE == STEM_BN_NORM) {
+    for (int i = threadIdx.x; i < 384; i += 256) bias_l[i] = bias[i];
+  } else if (threadIdx.x < 96) {
+    bias_l[threadIdx.x] = MODE == STEM_FOLDED ? bias[threadIdx.x] : 0.f;
+  }
   __syncthreads();
   char* out_a = (char*)out_a_;
   char* out_b = (char*)out_b_;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  char* stg = stg_all + wave * 2 * PLANE;
+  char* stg = stg_all + (MODE == STEM_BN_STATS ? 0 : wave * NPLANE * PLANE);
   const int fr = lane & 31, fhi = lane >> 5;
 
   // filter bank as A fragments: tile t (32 output channels), k-step s (16 taps): lane (fr, fhi) holds taps
@@ -138,6 +152,13 @@ __global__ __launch_bounds__(256) void stem_dual_mfma_kernel(const InT* __restri
     }
   };
 
+  // BN_STATS: this lane's running sums over its pixel column, per owned channel (3 tiles x 16)
+  float ssum[MODE == STEM_BN_STATS ? 48 : 1], qsum[MODE == STEM_BN_STATS ? 48 : 1];
+  if constexpr (MODE == STEM_BN_STATS) {
+#pragma unroll
+    for (int i = 0; i < 48; ++i) ssum[i] = qsum[i] = 0.f;
+  }
+
   long long blk = (long long)blockIdx.x * 4 + wave;
   float xc[16], xn[16];
   if (blk < nblk) load_block(blk, xc);
@@ -153,41 +174,94 @@ __global__ __launch_bounds__(256) void stem_dual_mfma_kernel(const InT* __restri
     for (int t = 0; t < 3; ++t) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const float4 b4 = *(const float4*)(bias_l + t * 32 + g * 8 + fhi * 4);
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (MODE == STEM_FOLDED) b4 = *(const float4*)(bias_l + t * 32 + g * 8 + fhi * 4);
         acc[t][g * 4 + 0] = b4.x; acc[t][g * 4 + 1] = b4.y; acc[t][g * 4 + 2] = b4.z; acc[t][g * 4 + 3] = b4.w;
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t][s2], xf[s2], acc[t], 0, 0, 0);
     }
-    // stage: plane 0 = out_a rows [32][48], plane 1 = out_b rows; lane (fr, fhi) owns channels t*32 + g*8 + fhi*4 .. +4
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int c = t * 32 + g * 8 + fhi * 4;                  // never straddles 48
-        const int plane = c >= 48, cc = c - plane * 48;
-        if constexpr (RAW) {
-          *(float4*)(stg + plane * PLANE + fr * 192 + cc * 4) =
-              make_float4(acc[t][g * 4 + 0], acc[t][g * 4 + 1], acc[t][g * 4 + 2], acc[t][g * 4 + 3]);
-        } else {
-          uint2 o;
-          o.x = pack_bf16x2(fmaxf(acc[t][g * 4 + 0], 0.f), fmaxf(acc[t][g * 4 + 1], 0.f));
-          o.y = pack_bf16x2(fmaxf(acc[t][g * 4 + 2], 0.f), fmaxf(acc[t][g * 4 + 3], 0.f));
-          *(uint2*)(stg + plane * PLANE + fr * 96 + cc * 2) = o;
-        }
-      }
     const long long p0 = blk * 32;
-    constexpr int PXB = RAW ? 192 : 96;                          // bytes per pixel of one output; PXB / 16 chunks per pixel
+    if constexpr (MODE == STEM_BN_STATS) {
+      if (p0 + fr < total) {                                       // (the clamped pixels of the last block are duplicates)
 #pragma unroll
-    for (int i = 0; i < PLANE / 1024; ++i) {
-      const int ch = i * 64 + lane;                              // 16-byte chunk of the plane's contiguous run
-      if (p0 + ch / (PXB / 16) < total) {
-        *(uint4*)(out_a + (size_t)p0 * PXB + ch * 16) = *(const uint4*)(stg + ch * 16);
-        *(uint4*)(out_b + (size_t)p0 * PXB + ch * 16) = *(const uint4*)(stg + PLANE + ch * 16);
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            ssum[t * 16 + r] += acc[t][r];
+            qsum[t * 16 + r] = fmaf(acc[t][r], acc[t][r], qsum[t * 16 + r]);
+          }
+      }
+    } else {
+      // stage: plane 0 = out_a rows [32][48], plane 1 = out_b rows; lane (fr, fhi) owns channels t*32 + g*8 + fhi*4 .. +4
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int c = t * 32 + g * 8 + fhi * 4;                  // never straddles 48
+          const int plane = c >= 48, cc = c - plane * 48;
+          if constexpr (RAW) {
+            *(float4*)(stg + plane * PLANE + fr * 192 + cc * 4) =
+                make_float4(acc[t][g * 4 + 0], acc[t][g * 4 + 1], acc[t][g * 4 + 2], acc[t][g * 4 + 3]);
+          } else if constexpr (MODE == STEM_BN_NORM) {
+            const float4 sc = *(const float4*)(bias_l + c), sh = *(const float4*)(bias_l + 96 + c);
+            const float4 ka = *(const float4*)(bias_l + 192 + c), kb = *(const float4*)(bias_l + 288 + c);
+            uint2 o, xh;
+            o.x = pack_bf16x2(fmaxf(fmaf(acc[t][g * 4 + 0], sc.x, sh.x), 0.f), fmaxf(fmaf(acc[t][g * 4 + 1], sc.y, sh.y), 0.f));
+            o.y = pack_bf16x2(fmaxf(fmaf(acc[t][g * 4 + 2], sc.z, sh.z), 0.f), fmaxf(fmaf(acc[t][g * 4 + 3], sc.w, sh.w), 0.f));
+            xh.x = pack_bf16x2(fmaf(acc[t][g * 4 + 0], ka.x, kb.x), fmaf(acc[t][g * 4 + 1], ka.y, kb.y));
+            xh.y = pack_bf16x2(fmaf(acc[t][g * 4 + 2], ka.z, kb.z), fmaf(acc[t][g * 4 + 3], ka.w, kb.w));
+            *(uint2*)(stg + plane * PLANE + fr * 96 + cc * 2) = o;
+            *(uint2*)(stg + (2 + plane) * PLANE + fr * 96 + cc * 2) = xh;
+          } else {
+            uint2 o;
+            o.x = pack_bf16x2(fmaxf(acc[t][g * 4 + 0], 0.f), fmaxf(acc[t][g * 4 + 1], 0.f));
+            o.y = pack_bf16x2(fmaxf(acc[t][g * 4 + 2], 0.f), fmaxf(acc[t][g * 4 + 3], 0.f));
+            *(uint2*)(stg + plane * PLANE + fr * 96 + cc * 2) = o;
+          }
+        }
+      constexpr int PXB = RAW ? 192 : 96;                          // bytes per pixel of one output; PXB / 16 chunks per pixel
+#pragma unroll
+      for (int i = 0; i < PLANE / 1024; ++i) {
+        const int ch = i * 64 + lane;                              // 16-byte chunk of the plane's contiguous run
+        if (p0 + ch / (PXB / 16) < total) {
+          *(uint4*)(out_a + (size_t)p0 * PXB + ch * 16) = *(const uint4*)(stg + ch * 16);
+          *(uint4*)(out_b + (size_t)p0 * PXB + ch * 16) = *(const uint4*)(stg + PLANE + ch * 16);
+          if constexpr (MODE == STEM_BN_NORM) {
+            *(uint4*)((char*)out_c_ + (size_t)p0 * PXB + ch * 16) = *(const uint4*)(stg + 2 * PLANE + ch * 16);
+            *(uint4*)((char*)out_d_ + (size_t)p0 * PXB + ch * 16) = *(const uint4*)(stg + 3 * PLANE + ch * 16);
+          }
+        }
       }
     }
 #pragma unroll
     for (int j = 0; j < 16; ++j) xc[j] = xn[j];
+  }
+  if constexpr (MODE == STEM_BN_STATS) {
+    // fold the 32 pixel columns that share fhi; lanes 0 / 32 write their 48 channels: part [wave][conv][2][48]
+#pragma unroll
+    for (int i = 0; i < 48; ++i) {
+      float a = ssum[i], q = qsum[i];
+#pragma unroll
+      for (int m = 1; m < 32; m <<= 1) {
+        a += __shfl_xor(a, m, 64);
+        q += __shfl_xor(q, m, 64);
+      }
+      ssum[i] = a;
+      qsum[i] = q;
+    }
+    if (fr == 0) {
+      float* pw = part + ((size_t)blockIdx.x * 4 + wave) * 192;
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;   // accumulator row r of tile t in this half-wave
+          const int conv = c >= 48, cc = c - conv * 48;
+          pw[conv * 96 + cc] = ssum[t * 16 + r];
+          pw[conv * 96 + 48 + cc] = qsum[t * 16 + r];
+        }
+    }
   }
 }
 
@@ -365,11 +439,51 @@ extern "C" int msclip_stem_conv3x3s2_dual_raw(const void* img, int img_is_bf16, 
   const dim3 grid((unsigned)g), blk(256);
   hipStream_t st = (hipStream_t)stream;
   if (img_is_bf16)
-    hipLaunchKernelGGL((stem_dual_mfma_kernel<bf16_t, true>), grid, blk, 0, st, (const bf16_t*)img, w, (const float*)nullptr,
+    hipLaunchKernelGGL((stem_dual_mfma_kernel<bf16_t, STEM_RAW>), grid, blk, 0, st, (const bf16_t*)img, w, (const float*)nullptr,
                        (void*)out_a, (void*)out_b, B, H, W, Ho, Wo);
   else
-    hipLaunchKernelGGL((stem_dual_mfma_kernel<float, true>), grid, blk, 0, st, (const float*)img, w, (const float*)nullptr,
+    hipLaunchKernelGGL((stem_dual_mfma_kernel<float, STEM_RAW>), grid, blk, 0, st, (const float*)img, w, (const float*)nullptr,
                        (void*)out_a, (void*)out_b, B, H, W, Ho, Wo);
+  return msclip_launch_status();
+}
+
+// Two-pass train-mode BatchNorm over the two image convolutions (include/msclip_hip.h).  Pass 1: part [waves][2 convs][2][48].
+extern "C" int msclip_stem_conv3x3s2_dual_stats(const void* img, int img_is_bf16, const float* w, float* part, int part_waves, int B,
+                                                int H, int W, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_stem_conv3x3s2_dual_stats, stream, img, img_is_bf16, w, part, part_waves, B, H, W);
+  if (!img || !w || !part || part_waves < 4 || (part_waves & 3) || B <= 0 || H < 2 || W < 2 || (H & 1) || (W & 1)) return MSCLIP_EINVAL;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const dim3 grid((unsigned)(part_waves / 4)), blk(256);          // every wave writes its row (zeros when it had no block)
+  hipStream_t st = (hipStream_t)stream;
+  if (img_is_bf16)
+    hipLaunchKernelGGL((stem_dual_mfma_kernel<bf16_t, STEM_BN_STATS>), grid, blk, 0, st, (const bf16_t*)img, w, (const float*)nullptr,
+                       (void*)nullptr, (void*)nullptr, B, H, W, Ho, Wo, (void*)nullptr, (void*)nullptr, part);
+  else
+    hipLaunchKernelGGL((stem_dual_mfma_kernel<float, STEM_BN_STATS>), grid, blk, 0, st, (const float*)img, w, (const float*)nullptr,
+                       (void*)nullptr, (void*)nullptr, B, H, W, Ho, Wo, (void*)nullptr, (void*)nullptr, part);
+  return msclip_launch_status();
+}
+
+// Pass 2: consts [4][96] = (scale, shift, a, b) per channel, conv a's 48 channels first; y_* = relu(x scale + shift), xhat_* = x a + b
+// (bf16 [pixels][48] each).
+extern "C" int msclip_stem_conv3x3s2_dual_norm(const void* img, int img_is_bf16, const float* w, const float* consts, void* y_a,
+                                               void* y_b, void* xhat_a, void* xhat_b, int B, int H, int W, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_stem_conv3x3s2_dual_norm, stream, img, img_is_bf16, w, consts, y_a, y_b, xhat_a, xhat_b, B, H, W);
+  if (!img || !w || !consts || !y_a || !y_b || !xhat_a || !xhat_b || B <= 0 || H < 2 || W < 2 || (H & 1) || (W & 1) ||
+      ((size_t)consts & 15))
+    return MSCLIP_EINVAL;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const long long nblk = ((long long)B * Ho * Wo + 31) / 32;
+  long long g = (nblk + 3) / 4;
+  if (g > 256 * 3) g = 256 * 3;                                  // 48 KB of staging per workgroup: three per CU
+  const dim3 grid((unsigned)g), blk(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (img_is_bf16)
+    hipLaunchKernelGGL((stem_dual_mfma_kernel<bf16_t, STEM_BN_NORM>), grid, blk, 0, st, (const bf16_t*)img, w, consts, y_a, y_b, B, H, W,
+                       Ho, Wo, xhat_a, xhat_b, (float*)nullptr);
+  else
+    hipLaunchKernelGGL((stem_dual_mfma_kernel<float, STEM_BN_NORM>), grid, blk, 0, st, (const float*)img, w, consts, y_a, y_b, B, H, W,
+                       Ho, Wo, xhat_a, xhat_b, (float*)nullptr);
   return msclip_launch_status();
 }
 

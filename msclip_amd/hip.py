@@ -18,7 +18,7 @@ ABI_VERSION = 7                                          # include/msclip_hip.h 
 
 EXPORTS = (
     "msclip_gemm", "msclip_gemm_f8", "msclip_layernorm_stats", "msclip_rowstat_finalize", "msclip_layernorm_f8", "msclip_quant_f8_rows", "msclip_gemm_variant", "msclip_attention", "msclip_attention_lastq", "msclip_layernorm", "msclip_layernorm_split", "msclip_embed_tokens", "msclip_fill_cls",
-    "msclip_adapter_combine_ln", "msclip_adapter_combine_ln_stats", "msclip_l2norm", "msclip_gather_rows", "msclip_stem_conv3x3s2_dual", "msclip_stem_conv3x3s2_dual_raw", "msclip_dwpool",
+    "msclip_adapter_combine_ln", "msclip_adapter_combine_ln_stats", "msclip_l2norm", "msclip_gather_rows", "msclip_stem_conv3x3s2_dual", "msclip_stem_conv3x3s2_dual_raw", "msclip_stem_conv3x3s2_dual_stats", "msclip_stem_conv3x3s2_dual_norm", "msclip_dwpool",
     "msclip_stem_dual_conv3x3s2", "msclip_conv1x1_conv3x3s2", "msclip_convresblock48_s2", "msclip_patchify",
     "msclip_lse_rows", "msclip_clip_loss_partial", "msclip_clip_lse_fused", "msclip_clip_loss_from_partials",
     "msclip_transpose_bf16", "msclip_cast_bf16", "msclip_cast_bf16_colsum", "msclip_colsum", "msclip_quickgelu", "msclip_quickgelu_bwd", "msclip_layernorm_bwd",
@@ -51,7 +51,7 @@ class BnBwdSide(ctypes.Structure):
     """Mirror of struct msclip_bn_bwd_side."""
     _fields_ = [("x", ctypes.c_void_p), ("ld", ctypes.c_int), ("mean", ctypes.c_void_p), ("rstd", ctypes.c_void_p),
                 ("gamma", ctypes.c_void_p), ("dbeta", ctypes.c_void_p), ("dgamma", ctypes.c_void_p), ("dx", ctypes.c_void_p),
-                ("lddx", ctypes.c_int), ("part", ctypes.c_void_p)]
+                ("lddx", ctypes.c_int), ("part", ctypes.c_void_p), ("x_bf16", ctypes.c_int)]
 
 
 class GemmDesc(ctypes.Structure):
@@ -130,6 +130,8 @@ def lib():
         L.msclip_gather_rows.argtypes = [vp, ctypes.c_longlong, vp, ci, ci, vp, ctypes.c_longlong, ci, ci, vp]
         L.msclip_stem_conv3x3s2_dual.argtypes = [vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, vp]
         L.msclip_stem_conv3x3s2_dual_raw.argtypes = [vp, ci, vp, vp, vp, ci, ci, ci, vp]
+        L.msclip_stem_conv3x3s2_dual_stats.argtypes = [vp, ci, vp, vp, ci, ci, ci, ci, vp]
+        L.msclip_stem_conv3x3s2_dual_norm.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]
         L.msclip_dwpool.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
         L.msclip_stem_dual_conv3x3s2.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
         L.msclip_conv1x1_conv3x3s2.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
@@ -1113,6 +1115,39 @@ def stem_conv_dual_raw(img, w, out_a, out_b):
                                                 _stream()), "msclip_stem_conv3x3s2_dual_raw")
 
 
+def stem_conv_dual_bn(img, w, affine, y_a, y_b, xhat_a, xhat_b, eps=1e-5):
+    """Train-mode BatchNorm over both Cin = 3 convolutions in two passes over the image, the raw maps never written
+    (msclip_stem_conv3x3s2_dual_stats / _norm): affine = [(gamma, beta)] per convolution; y = relu(BN(conv)) and xhat (the
+    normalised value, what the backward reads) bf16 [B * Ho * Wo, 48] each.
+    -> [(mean, biased var, rstd, scale, shift)] per convolution (fp32 [48])."""
+    B, _, H, W = img.shape
+    pix = B * (H // 2) * (W // 2)
+    assert img.is_contiguous() and img.dtype in (torch.float32, torch.bfloat16) and H % 2 == 0 and W % 2 == 0
+    _f32(w)
+    assert tuple(w.shape) == (27, 96) and len(affine) == 2
+    for t in (y_a, y_b, xhat_a, xhat_b):
+        _bf16(t)
+        assert t.is_contiguous() and t.shape[1] == 48 and t.shape[0] >= pix
+    dev = img.device
+    waves = 4 * min(768, (pix + 127) // 128)
+    part = torch.empty(waves, 192, dtype=torch.float32, device=dev)
+    st = _stream()
+    _check(lib().msclip_stem_conv3x3s2_dual_stats(_p(img), int(img.dtype == torch.bfloat16), _p(w), _p(part), waves, B, H, W, st),
+           "msclip_stem_conv3x3s2_dual_stats")
+    sums = colsum(part)                                      # [conv][2][48]
+    outs, consts = [], torch.empty(4, 96, dtype=torch.float32, device=dev)
+    for k, (gamma, beta) in enumerate(affine):
+        o = torch.empty(5, 48, dtype=torch.float32, device=dev)
+        _check(lib().msclip_bn_finish_tiled(_p(sums[k * 96:]), 1, 48, pix, _p(gamma), _p(beta), eps, _p(o), 1, st), "msclip_bn_finish_tiled")
+        outs.append(tuple(o[j] for j in range(5)))
+        sl = slice(k * 48, k * 48 + 48)
+        consts[0, sl], consts[1, sl], consts[2, sl] = o[3], o[4], o[2]
+        torch.mul(o[0], o[2], out=consts[3, sl]).neg_()      # b = -mean rstd
+    _check(lib().msclip_stem_conv3x3s2_dual_norm(_p(img), int(img.dtype == torch.bfloat16), _p(w), _p(consts), _p(y_a), _p(y_b),
+                                                 _p(xhat_a), _p(xhat_b), B, H, W, st), "msclip_stem_conv3x3s2_dual_norm")
+    return outs
+
+
 def stem_dual_conv3x3s2(img, w, bias, out_b, w2, b2, out2):
     """Both Cin=3 convs + the 3x3/s2 conv that consumes the first one's map (which never reaches HBM)."""
     B, _, H, W = img.shape
@@ -1595,15 +1630,16 @@ def bn_bwd(dy, x, mean, rstd, gamma, dx, M=None):
 
 
 def bn_bwd_fused_ok(dy, sides, y=None, dy2=None, M=None):
-    """Shapes msclip_bn_bwd_fused takes: bf16 contiguous [M, C] gradients / mask map, fp32 contiguous raw maps, C % 4 == 0."""
+    """Shapes msclip_bn_bwd_fused takes: bf16 contiguous [M, C] gradients / mask map, contiguous raw maps (fp32; or bf16 = the
+    normalised values of the two-pass forward, all sides alike), C % 4 == 0."""
     M = sides[0][0].shape[0] if M is None else M
     C = sides[0][0].shape[1]
     mats = [dy] + [t for t in (y, dy2) if t is not None]
     if C % 4 or len(sides) not in (1, 2) or any(t.dtype != torch.bfloat16 or t.shape[1] != C or not t.is_contiguous() or t.shape[0] < M
                                                   for t in mats):
         return False
-    return all(x.dtype == torch.float32 and x.is_contiguous() and x.shape[1] == C and x.shape[0] >= M and
-               dx.dtype == torch.bfloat16 and dx.is_contiguous() and dx.shape[1] == C and dx.shape[0] >= M
+    return all(x.dtype == sides[0][0].dtype and x.dtype in (torch.float32, torch.bfloat16) and x.is_contiguous() and x.shape[1] == C and
+               x.shape[0] >= M and dx.dtype == torch.bfloat16 and dx.is_contiguous() and dx.shape[1] == C and dx.shape[0] >= M
                for x, _, _, _, dx in sides)
 
 
@@ -1633,7 +1669,8 @@ def bn_bwd_fused(dy, sides, y=None, dy2=None, M=None, chunks=None, dx_chunks=0):
         part = torch.empty(ch, 2 * Cw, dtype=torch.float32, device=dev)
         tail = torch.empty(3, Cw, dtype=torch.float32, device=dev)
         keep.append((mw, rw, part, tail))
-        sd.append(BnBwdSide(_p(x), Cw, _p(mw), _p(rw), _p(tail[2]), _p(tail[0]), _p(tail[1]), _p(dx), Cw, _p(part)))
+        sd.append(BnBwdSide(_p(x), Cw, _p(mw), _p(rw), _p(tail[2]), _p(tail[0]), _p(tail[1]), _p(dx), Cw, _p(part),
+                            int(x.dtype == torch.bfloat16)))
     s2 = ctypes.byref(sd[1]) if len(sd) == 2 else None
     args = (_p(dy), Cw, _p(dy2) if dy2 is not None else None, Cw, _p(y) if y is not None else None, Cw, ctypes.byref(sd[0]), s2, Mw, Cw)
     st = _stream()

@@ -92,6 +92,9 @@ class TrainOptions:
     bn_bwd_fused: bool = True         # MSCLIP_BN_BWD_FUSED: train-mode BatchNorm backward with the ReLU mask applied on the fly and the
     #                                   two BatchNorms of a residual block in one pass (msclip_bn_bwd_fused); 0 = msclip_relu_bwd
     #                                   + one msclip_bn_bwd_reduce / _dx pair per BatchNorm (round 5)
+    bn_two_pass: bool = True          # MSCLIP_BN_TWO_PASS: train-mode BatchNorm of the two convolutions on the input image in two passes
+    #                                   over the image (statistics, then normalise + ReLU in the epilogue; the normalised values
+    #                                   kept in bf16 for the backward) instead of raw fp32 maps + a statistics + a normalise pass
     colsum_main: bool = False         # MSCLIP_COLSUM_MAIN: the conv side's bias sums on the main stream instead of the lane
     #                                   (either of the two makes a hipGraph replay of the step right: profiles/r06_train_hipgraph_probe.txt)
 
@@ -99,7 +102,8 @@ class TrainOptions:
     def from_env(cls):
         return cls(wgrad_sync=_flag("MSCLIP_WGRAD_SYNC", False), dgrad_col2im=_flag("MSCLIP_DGRAD_COL2IM", False),
                    im2col_main=_flag("MSCLIP_IM2COL_MAIN", False), colsum_main=_flag("MSCLIP_COLSUM_MAIN", False),
-                   compact_last_block=_flag("MSCLIP_TRAIN_COMPACT_LAST", True), bn_bwd_fused=_flag("MSCLIP_BN_BWD_FUSED", True))
+                   compact_last_block=_flag("MSCLIP_TRAIN_COMPACT_LAST", True), bn_bwd_fused=_flag("MSCLIP_BN_BWD_FUSED", True),
+                   bn_two_pass=_flag("MSCLIP_BN_TWO_PASS", True))
 
     def replace(self, **kw):
         return dataclasses.replace(self, **kw)

@@ -504,7 +504,20 @@ class ConvSideBatchNorm:
         sp = "visual.transformer.resblocks.0"
         pix = Bi * e.h1 * e.h1
         heads = ((self.raw.w_conv1, sp + ".bn1", e._s1(w, Bi)), (self.raw.w_par0, "visual.transformer.parallel_branch_v.0.bn", w["P0"]))
-        if self.raw.w_dual is not None and e.S % 2 == 0:
+        if self.raw.w_dual is not None and e.S % 2 == 0 and options.TRAIN.bn_two_pass:
+            # two passes over the image (round 6): statistics, then convolution + normalise + ReLU; no raw map exists, the backward
+            # reads the normalised values xhat (bf16) with mean 0 / rstd 1 / gamma := gamma rstd
+            sd = self.raw.sd
+            xh = [_zbuf(pix, 48, e.dev) for _ in heads]
+            res = hip.stem_conv_dual_bn(self.img, self.raw.w_dual, [(sd[p + ".weight"], sd[p + ".bias"]) for _, p, _ in heads],
+                                        heads[0][2], heads[1][2], xh[0], xh[1], eps=1e-5)
+            zero, one = hip._bn_unit(48, e.dev)[1], hip._bn_unit(48, e.dev)[0]
+            for (_, prefix, _), x, (mean, var, rstd, scale, shift) in zip(heads, xh, res):
+                self.saved[prefix] = (x, zero, one, scale, pix)
+                self.stats[prefix] = (mean, var, pix)
+            raws = []
+            heads = ()
+        elif self.raw.w_dual is not None and e.S % 2 == 0:
             # both raw convolutions from ONE pass over the image (round 5): no patch matrix, no two GEMMs over it
             raws = [torch.empty(pix, 48, dtype=F32, device=e.dev) for _ in heads]
             hip.stem_conv_dual_raw(self.img, self.raw.w_dual, raws[0], raws[1])

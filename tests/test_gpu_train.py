@@ -51,6 +51,12 @@ def rel(got, ref):
     return ((got.float() - ref.float()).abs().max() / ref.float().abs().max().clamp_min(1e-12)).item()
 
 
+def close(got, ref, atol, rtol=0.0):
+    got, ref = got.float(), ref.float()
+    err = (got - ref).abs()
+    assert bool((err <= atol + rtol * ref.abs()).all()), f"max err {err.max().item():.4g} (ref absmax {ref.abs().max().item():.4g})"
+
+
 def test_transpose_cast_colsum_gelu(gpu_device):
     x = rnd(1000, 200, seed=1, dtype=BF)
     t = hip.transpose_bf16(x)
@@ -430,6 +436,45 @@ def test_stem_dual_conv_raw_outputs(gpu_device, B, S, dt):
     r = torch.empty(B * Ho * Ho, 48, device="cuda")
     hip.gemm(col, wm, r)
     assert rel(oa[:B * Ho * Ho], r) < 2e-5
+
+
+@pytest.mark.parametrize("B,S,dt", [(3, 32, torch.float32), (2, 224, torch.float32), (5, 38, BF), (16, 224, torch.float32)])
+def test_stem_dual_conv_two_pass_batchnorm(gpu_device, B, S, dt):
+    """msclip_stem_conv3x3s2_dual_stats / _norm (round 6): train-mode BatchNorm of both image convolutions without a raw map --
+    against the raw-map path (msclip_stem_conv3x3s2_dual_raw + msclip_bn_stats + msclip_bn_apply) and against F.batch_norm on
+    F.conv2d of the bf16-rounded operands; the normalised values the backward reads; nothing written behind the maps."""
+    Ho = S // 2
+    pix = B * Ho * Ho
+    img = rnd(B, 3, S, S, seed=61).to(dt)
+    wa, wb = rnd(48, 3, 3, 3, seed=62, scale=0.3), rnd(48, 3, 3, 3, seed=63, scale=0.3)
+    w = torch.cat([wa.reshape(48, 27), wb.reshape(48, 27)], 0).t().contiguous()
+    aff = [(rnd(48, seed=64 + k) * 0.5 + 1.0, rnd(48, seed=66 + k)) for k in range(2)]
+    ys = [torch.full((pix + 3, 48), 7.0, dtype=BF, device="cuda") for _ in range(2)]
+    xh = [torch.full((pix + 3, 48), 7.0, dtype=BF, device="cuda") for _ in range(2)]
+    res = hip.stem_conv_dual_bn(img, w, aff, ys[0], ys[1], xh[0], xh[1], eps=1e-5)
+    raws = [torch.empty(pix, 48, device="cuda") for _ in range(2)]
+    hip.stem_conv_dual_raw(img, w, raws[0], raws[1])
+    xr = img.to(BF).float()
+    for k, wt in enumerate((wa, wb)):
+        gam, bet = aff[k]
+        mean, var, rstd, scale, shift = hip.bn_stats(raws[k], gamma=gam, beta=bet, eps=1e-5)
+        assert rel(res[k][0], mean) <= 2e-5 and rel(res[k][1], var) <= 1e-4 and rel(res[k][3], scale) <= 1e-4
+        want = torch.empty(pix, 48, dtype=BF, device="cuda")
+        hip.bn_apply(raws[k], scale, shift, want, relu=True)
+        # the same expression on the same fp32 accumulators with statistics equal to 1e-5: bf16 values equal but for rounding ties
+        assert rel(ys[k][:pix], want) <= 8e-3 and (ys[k][:pix].float() != want.float()).float().mean().item() <= 2e-3
+        assert rel(xh[k][:pix], (raws[k] - mean) * rstd) <= 6e-3
+        ref = F.batch_norm(F.conv2d(xr, wt.to(BF).float(), stride=2, padding=1), None, None, gam, bet, training=True, eps=1e-5)
+        close(ys[k][:pix], torch.relu(ref).permute(0, 2, 3, 1).reshape(pix, 48), 2e-2, 1e-2)
+        assert bool((ys[k][pix:] == 7.0).all()) and bool((xh[k][pix:] == 7.0).all())
+        # the backward from xhat (bf16; mean 0, rstd 1, gamma := scale) against the backward from the raw fp32 map
+        dy = rnd(pix, 48, seed=70 + k, dtype=BF)
+        dx_raw, dx_hat = (torch.empty(pix, 48, dtype=BF, device="cuda") for _ in range(2))
+        (dg0, db0), = hip.bn_bwd_fused(dy, [(raws[k], mean, rstd, gam, dx_raw)], y=ys[k][:pix])
+        zero, one = torch.zeros(48, device="cuda"), torch.ones(48, device="cuda")
+        (dg1, db1), = hip.bn_bwd_fused(dy, [(xh[k][:pix].contiguous(), zero, one, scale.contiguous(), dx_hat)], y=ys[k][:pix])
+        # (dgamma = sum d xhat is a cancelling sum for a random d: xhat's bf16 rounding, 2^-9 per term, shows undiminished)
+        assert rel(dg1, dg0) <= 8e-3 and rel(db1, db0) <= 1e-5 and rel(dx_hat, dx_raw) <= 1e-2, (rel(dg1, dg0), rel(db1, db0), rel(dx_hat, dx_raw))
 
 
 @pytest.mark.parametrize("B,S,co", [(3, 32, 48), (2, 224, 24), (5, 36, 16), (2, 64, 64), (1, 256, 40)])
@@ -1235,6 +1280,39 @@ def test_gradients_at_batch_32_against_reference_autograd(gpu_device, bn):
         if k in vec:
             assert coss[k] >= dev["conv_side"]["cosine_lowest"] - 5e-3, (k, coss[k])
     assert conv_med <= dev["conv_side"]["sample_err_median"] + 5e-3, (conv_med, dev["conv_side"]["sample_err_median"])
+
+
+def test_two_pass_image_batchnorm_in_the_step_equals_the_raw_map_path(gpu_device, monkeypatch):
+    """options.TRAIN.bn_two_pass (default) against raw fp32 maps + statistics / normalise passes in the whole train-mode step: the
+    loss equal to bf16 rounding ties of the two activation maps, every gradient to the noise of xhat's one bf16 rounding."""
+    from msclip_amd import options
+    m = _fresh_model("b32-yfcc-msclips")
+    img = synth.synth_images(96, seed=611).cuda()
+    tok = synth.synth_tokens(96, seed=612, min_len=2, max_len=40).cuda()
+    out = {}
+    for two in (False, True):
+        monkeypatch.setattr(options, "TRAIN", options.TRAIN.replace(bn_two_pass=two))
+        ts = train.TrainStep(m, lr=1e-4, bn="batch")
+        loss = ts.forward(img, tok)
+        out[two] = (loss.item(), {k: v.float().clone() for k, v in ts.backward().items()})
+    (l0, g0), (l1, g1) = out[False], out[True]
+    assert abs(l0 - l1) <= 2e-3 * max(1.0, abs(l0)) and sorted(g0) == sorted(g1)
+    worst = {}
+    for k in g0:
+        a, b = g0[k].flatten(), g1[k].flatten()
+        worst[k] = (a - b).abs().max().item() / max(a.abs().max().item(), 1e-12)
+    print("two-pass vs raw-map BatchNorm: loss", l0, l1, "worst", sorted(worst.items(), key=lambda kv: -kv[1])[:4],
+          "median", float(np.median(list(worst.values()))))
+    # (the two forwards differ by bf16 rounding ties of the first two maps; five stages of batch-statistics BatchNorm behind them
+    #  re-normalise the perturbed values, so the deep conv-side gradients move by percents between two EQUALLY valid roundings --
+    #  at batch 24 up to 25 % on parallel_branch_v.4, the order of the reference's own bf16 deviation; both forms are pinned to the
+    #  reference's autograd separately by the fixtures above, which run the default = two passes)
+    head = [k for k in g0 if k.startswith(("visual.transformer.resblocks.0.conv1", "visual.transformer.resblocks.0.bn1",
+                                           "visual.transformer.parallel_branch_v.0."))]
+    assert len(head) == 6
+    cos = {k: F.cosine_similarity(g0[k].flatten(), g1[k].flatten(), dim=0).item() for k in g0 if g0[k].numel() > 1}
+    print("lowest cosine", sorted(cos.items(), key=lambda kv: kv[1])[:4], "first convs / BatchNorms", {k: round(worst[k], 4) for k in head})
+    assert min(cos.values()) >= 0.95 and float(np.median(list(worst.values()))) <= 4e-2      # (measured 0.9946 / 2.5e-2 at batch 96)
 
 
 def test_fused_batchnorm_backward_in_the_step_equals_the_pass_per_batchnorm_path(gpu_device, monkeypatch):
