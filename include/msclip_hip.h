@@ -91,6 +91,17 @@ typedef struct msclip_gemm_desc {
                           * runs min(M, *M_dev) rows -- the row count of a packed caption batch lives on the device
                           * (msclip_text_lengths' dims), M is the upper bound the launch is sized and validated for; the value
                           * must satisfy the same divisibility rules as M (whole 256-row tiles for the fold forms) */
+  /* Train-mode BatchNorm in two passes over the convolution's INPUT instead of a raw fp32 output map (round 6; streaming kernel
+   * only = msclip_gemm_variant "stream": pointwise / 1x1 stride-2 convolutions and the 3x3 ones over 48 input channels,
+   * M.py:1812-1861, 1898-1936 in train()).  bn_mode 1 (statistics): nothing is stored; every wave of the launch leaves the column
+   * sums of its rows, part[wave][0][n] = sum x, part[wave][1][n] = sum x^2 (fp32 [part_rows][2][N], part_rows >= the launch's
+   * waves is enforced by shrinking the launch; rows of waves that do not exist stay untouched: zero them, fold with msclip_colsum).
+   * bn_mode 2 (normalise): bn_consts [5][N] = msclip_bn_finish's output rows (mean, variance, rstd, scale, shift): out = act(x scale +
+   * shift [+ resid, resid_kind 2]) (bf16) and out2 = xhat = (x - mean) rstd (bf16 [M][ldo]) -- what the backward reads instead of
+   * the raw map.  bias must be NULL, alpha 1, N % 8 == 0, no row scatter. */
+  int bn_mode;
+  int part_rows;
+  const float* bn_consts;
 } msclip_gemm_desc;
 
 int msclip_gemm(const msclip_gemm_desc* desc, void* stream);
@@ -296,13 +307,14 @@ int msclip_stem_conv3x3s2_dual_raw(const void* img, int img_is_bf16, const float
  * parallel branch's stage 0) -- the raw maps are never written.
  * msclip_stem_conv3x3s2_dual_stats: part [part_waves][2][2][48] fp32 = per wave (sum x, sum x^2) of conv a, then conv b (part_waves
  *   a multiple of 4 = 4 x the launch's workgroups; fold the rows with msclip_colsum).
- * msclip_stem_conv3x3s2_dual_norm: the convolutions again; consts [4][96] fp32 = (scale, shift, a, b) per channel, conv a's 48
- *   channels first: y = relu(x scale + shift) (the expression of msclip_bn_apply), xhat = x a + b (a = rstd, b = -mean rstd), all four
- *   outputs bf16 [B * H/2 * W/2][48].  The backward reads xhat where it read the raw fp32 map (mean 0, rstd 1, gamma := scale). */
+ * msclip_stem_conv3x3s2_dual_norm: the convolutions again; stats_a / stats_b fp32 [5][48] = msclip_bn_finish's output rows (mean,
+ *   variance, rstd, scale, shift) per convolution: y = relu(x scale + shift) (the expression of msclip_bn_apply), xhat = (x - mean)
+ *   rstd, all four outputs bf16 [B * H/2 * W/2][48].  The backward reads xhat where it read the raw fp32 map (mean 0, rstd 1,
+ *   gamma := scale). */
 int msclip_stem_conv3x3s2_dual_stats(const void* img, int img_is_bf16, const float* w, float* part, int part_waves, int B, int H, int W,
                                      void* stream);
-int msclip_stem_conv3x3s2_dual_norm(const void* img, int img_is_bf16, const float* w, const float* consts, void* y_a, void* y_b,
-                                    void* xhat_a, void* xhat_b, int B, int H, int W, void* stream);
+int msclip_stem_conv3x3s2_dual_norm(const void* img, int img_is_bf16, const float* w, const float* stats_a, const float* stats_b,
+                                    void* y_a, void* y_b, void* xhat_a, void* xhat_b, int B, int H, int W, void* stream);
 
 /* The same pass fused with the 3x3/s2/p1 convolution that consumes branch a (stem resnet_stage.conv_0 with its folded
  * 1x1 shortcut and ReLU, M.py:1920-1936): branch a's 48-channel map stays in LDS (8x8 output tiles, 17x17 windows),
@@ -664,7 +676,7 @@ int msclip_comm_async_error(void* comm);
 int msclip_allgather_feats(void* comm, const void* send, void* recv, long long count, int dtype, void* stream);
 int msclip_allreduce(void* comm, const void* send, void* recv, long long count, int dtype, int op, void* stream);
 
-#define MSCLIP_ABI_VERSION 7   /* 7 (round 6): device-side row counts (M_dev / m_dev / dims), the plan executor, RCCL entry points, msclip_prepare_device; 5-6 (round 5): packed-caption entry points, msclip_qkv_attention / msclip_qkvattn_tables, msclip_pack_weights, single-launch msclip_colsum */
+#define MSCLIP_ABI_VERSION 8   /* 8 (round 6, late): msclip_gemm_desc.bn_mode / part_rows / bn_consts, msclip_bn_bwd_fused, msclip_stem_conv3x3s2_dual_stats / _norm; 7 (round 6): device-side row counts (M_dev / m_dev / dims), the plan executor, RCCL entry points, msclip_prepare_device; 5-6 (round 5): packed-caption entry points, msclip_qkv_attention / msclip_qkvattn_tables, msclip_pack_weights, single-launch msclip_colsum */
 int msclip_abi_version(void);
 const char* msclip_build_arch(void);
 

@@ -90,15 +90,24 @@ __global__ __launch_bounds__(256) void stem_dual_mfma_kernel(const InT* __restri
                                                              const float* __restrict__ bias, void* __restrict__ out_a_,
                                                              void* __restrict__ out_b_, int B, int H, int W, int Ho,
                                                              int Wo, void* __restrict__ out_c_ = nullptr,
-                                                             void* __restrict__ out_d_ = nullptr, float* __restrict__ part = nullptr) {
+                                                             void* __restrict__ out_d_ = nullptr, float* __restrict__ part = nullptr,
+                                                             const float* __restrict__ bias_b = nullptr) {
   constexpr bool RAW = MODE == STEM_RAW;
   constexpr int PLANE = RAW ? 6144 : 3072;            // bytes of one staged output: 32 pixels x 48 channels
   constexpr int NPLANE = MODE == STEM_BN_NORM ? 4 : 2;
   __shared__ __attribute__((aligned(16))) char stg_all[MODE == STEM_BN_STATS ? 16 : 4 * NPLANE * PLANE];
-  // FOLDED: bias [96]; BN_NORM: `bias` points at [4][96] = scale, shift, a, b per channel (conv a's 48 channels, then conv b's)
+  // FOLDED: bias [96]; BN_NORM: [4][96] = scale, shift, a, b per channel (conv a's 48 channels, then conv b's)
   __shared__ __attribute__((aligned(16))) float bias_l[MODE == STEM_BN_NORM ? 384 : 96];
   if (MODE == STEM_BN_NORM) {
-    for (int i = threadIdx.x; i < 384; i += 256) bias_l[i] = bias[i];
+    // bias / bias_b = msclip_bn_finish's rows [5][48] (mean, var, rstd, scale, shift) of conv a / conv b
+    if (threadIdx.x < 96) {
+      const int c = threadIdx.x;
+      const float* k = (c < 48 ? bias : bias_b) + (c < 48 ? c : c - 48);
+      bias_l[c] = k[3 * 48];
+      bias_l[96 + c] = k[4 * 48];
+      bias_l[192 + c] = k[2 * 48];
+      bias_l[288 + c] = -k[0] * k[2 * 48];
+    }
   } else if (threadIdx.x < 96) {
     bias_l[threadIdx.x] = MODE == STEM_FOLDED ? bias[threadIdx.x] : 0.f;
   }
@@ -464,13 +473,13 @@ extern "C" int msclip_stem_conv3x3s2_dual_stats(const void* img, int img_is_bf16
   return msclip_launch_status();
 }
 
-// Pass 2: consts [4][96] = (scale, shift, a, b) per channel, conv a's 48 channels first; y_* = relu(x scale + shift), xhat_* = x a + b
-// (bf16 [pixels][48] each).
-extern "C" int msclip_stem_conv3x3s2_dual_norm(const void* img, int img_is_bf16, const float* w, const float* consts, void* y_a,
-                                               void* y_b, void* xhat_a, void* xhat_b, int B, int H, int W, void* stream) {
-  MSCLIP_PLAN_HOOK(msclip_stem_conv3x3s2_dual_norm, stream, img, img_is_bf16, w, consts, y_a, y_b, xhat_a, xhat_b, B, H, W);
-  if (!img || !w || !consts || !y_a || !y_b || !xhat_a || !xhat_b || B <= 0 || H < 2 || W < 2 || (H & 1) || (W & 1) ||
-      ((size_t)consts & 15))
+// Pass 2: stats_a / stats_b [5][48] = msclip_bn_finish's rows (mean, var, rstd, scale, shift) of conv a / conv b; y_* = relu(x scale +
+// shift), xhat_* = (x - mean) rstd (bf16 [pixels][48] each).
+extern "C" int msclip_stem_conv3x3s2_dual_norm(const void* img, int img_is_bf16, const float* w, const float* stats_a,
+                                               const float* stats_b, void* y_a, void* y_b, void* xhat_a, void* xhat_b, int B, int H,
+                                               int W, void* stream) {
+  MSCLIP_PLAN_HOOK(msclip_stem_conv3x3s2_dual_norm, stream, img, img_is_bf16, w, stats_a, stats_b, y_a, y_b, xhat_a, xhat_b, B, H, W);
+  if (!img || !w || !stats_a || !stats_b || !y_a || !y_b || !xhat_a || !xhat_b || B <= 0 || H < 2 || W < 2 || (H & 1) || (W & 1))
     return MSCLIP_EINVAL;
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const long long nblk = ((long long)B * Ho * Wo + 31) / 32;
@@ -479,11 +488,11 @@ extern "C" int msclip_stem_conv3x3s2_dual_norm(const void* img, int img_is_bf16,
   const dim3 grid((unsigned)g), blk(256);
   hipStream_t st = (hipStream_t)stream;
   if (img_is_bf16)
-    hipLaunchKernelGGL((stem_dual_mfma_kernel<bf16_t, STEM_BN_NORM>), grid, blk, 0, st, (const bf16_t*)img, w, consts, y_a, y_b, B, H, W,
-                       Ho, Wo, xhat_a, xhat_b, (float*)nullptr);
+    hipLaunchKernelGGL((stem_dual_mfma_kernel<bf16_t, STEM_BN_NORM>), grid, blk, 0, st, (const bf16_t*)img, w, stats_a, y_a, y_b, B, H, W,
+                       Ho, Wo, xhat_a, xhat_b, (float*)nullptr, stats_b);
   else
-    hipLaunchKernelGGL((stem_dual_mfma_kernel<float, STEM_BN_NORM>), grid, blk, 0, st, (const float*)img, w, consts, y_a, y_b, B, H, W,
-                       Ho, Wo, xhat_a, xhat_b, (float*)nullptr);
+    hipLaunchKernelGGL((stem_dual_mfma_kernel<float, STEM_BN_NORM>), grid, blk, 0, st, (const float*)img, w, stats_a, y_a, y_b, B, H, W,
+                       Ho, Wo, xhat_a, xhat_b, (float*)nullptr, stats_b);
   return msclip_launch_status();
 }
 

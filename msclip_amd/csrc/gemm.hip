@@ -1063,6 +1063,10 @@ static GemmVariant pick_variant(const msclip_gemm_desc* d) {
   // kernels only
   if (d->resid_kind == 5 && (d->mode != 1 || !d->resid || (d->ldr & 3) || d->tile == 4 || d->out2 || d->rowstat || d->W2 || d->xb))
     return GV_INVALID;
+  // train-mode BatchNorm passes (bn_mode 1 / 2): the streaming kernel or nothing (no other kernel carries the epilogues)
+  if (d->bn_mode)
+    return (d->tile == 0 || d->tile == 5) && !d->rowstat && !d->W2 && !d->xb && !d->M_dev && msclip_gemm_small_eligible(d) ? GV_STREAM
+                                                                                                                         : GV_INVALID;
   // training-step epilogue forms (second pre-activation output; multiply by QuickGELU'(resid)): ping-pong kernels only,
   // whole 256-row tiles only (the guarded edge-tile epilogue does not carry them)
   const bool train_epi = d->out2 || d->resid_kind == 4;

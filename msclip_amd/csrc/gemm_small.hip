@@ -24,7 +24,11 @@ constexpr int SSTG_ROW = 144;               // staging row: 32 fp32 + 16 B pad (
 constexpr int SSTG_BYTES = 32 * SSTG_ROW;   // per wave
 
 // NT: 32-column tiles per wave, NKC: K / 64, SWV: waves per workgroup
-template <int NT, int NKC, bool CONV, int SWV>
+// BN (msclip_gemm_desc.bn_mode; instantiations of their own so that the standard kernel stays what it was): 1 = column sums of the
+// accumulators instead of an output (train-mode BatchNorm statistics: a lane keeps the sums of its 8 columns over its rows of every
+// block, four exchanges fold the 16 lanes that share the columns at the end, the wave writes its row of `part`), 2 = normalise
+// epilogue (out = act(x scale + shift [+ resid]), out2 = x a + b, constants per column in LDS).
+template <int NT, int NKC, bool CONV, int SWV, int BN = 0>
 __global__ __launch_bounds__(SWV * 64) void gemm_stream_kernel(const msclip_gemm_desc a) {
   extern __shared__ __attribute__((aligned(16))) char slds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -32,8 +36,9 @@ __global__ __launch_bounds__(SWV * 64) void gemm_stream_kernel(const msclip_gemm
   constexpr int NW = NT * 32, K = NKC * 64;
   constexpr int wstride = K * 2 + 16;                           // bytes per weight row in LDS
   char* wl = slds;                                              // [NW][wstride]
-  float* bl = (float*)(slds + NW * wstride);                    // [NW]
-  char* stg = slds + NW * wstride + NW * 4 + wave * SSTG_BYTES;
+  constexpr int NBL = BN == 2 ? 4 * NW : NW;
+  float* bl = (float*)(slds + NW * wstride);                    // [NW] bias; BN 2: [4][NW] = scale, shift, a, b
+  char* stg = slds + NW * wstride + NBL * 4 + wave * SSTG_BYTES;
   const int n0 = blockIdx.y * NW;
 
   // ---- resident operands
@@ -45,7 +50,20 @@ __global__ __launch_bounds__(SWV * 64) void gemm_stream_kernel(const msclip_gemm
     if (n0 + r < a.N) v = *(const uint4*)(W + (size_t)(n0 + r) * a.ldw + c * 8);
     *(uint4*)(wl + r * wstride + c * 16) = v;
   }
-  for (int i = tid; i < NW; i += SWV * 64) bl[i] = (a.bias && n0 + i < a.N) ? a.bias[n0 + i] : 0.f;
+  if constexpr (BN == 2) {
+    // bn_consts = msclip_bn_finish's rows (mean, var, rstd, scale, shift) -> (scale, shift, a = rstd, b = -mean rstd) per column
+    for (int c = tid; c < NW; c += SWV * 64) {
+      const bool in = n0 + c < a.N;
+      const float* k = a.bn_consts + n0 + c;
+      const float mean = in ? k[0] : 0.f, rstd = in ? k[2 * (size_t)a.N] : 0.f;
+      bl[c] = in ? k[3 * (size_t)a.N] : 0.f;
+      bl[NW + c] = in ? k[4 * (size_t)a.N] : 0.f;
+      bl[2 * NW + c] = rstd;
+      bl[3 * NW + c] = -mean * rstd;
+    }
+  } else {
+    for (int i = tid; i < NW; i += SWV * 64) bl[i] = (a.bias && n0 + i < a.N) ? a.bias[n0 + i] : 0.f;
+  }
   __syncthreads();
 
   const int fr = lane & 31, fhi = lane >> 5;
@@ -96,6 +114,12 @@ __global__ __launch_bounds__(SWV * 64) void gemm_stream_kernel(const msclip_gemm
   // read-back mapping of the staging block: pass p covers rows 16p + lane/4, the lane owns columns 8*(lane%4) .. +8
   const int rr = lane >> 2, rc = lane & 3;
   const bool vec = !((a.N | a.ldo | (a.resid_kind ? a.ldr : 0)) & 7);
+
+  float csum[BN == 1 ? NT * 8 : 1], csq[BN == 1 ? NT * 8 : 1];   // BN 1: this lane's column sums (tile t, column rc * 8 + j)
+  if constexpr (BN == 1) {
+#pragma unroll
+    for (int i = 0; i < NT * 8; ++i) csum[i] = csq[i] = 0.f;
+  }
 
   int blk = blockIdx.x * SWV + wave;
   uint4 xq[2][4];
@@ -179,7 +203,45 @@ __global__ __launch_bounds__(SWV * 64) void gemm_stream_kernel(const msclip_gemm
         const float4 lo = *(const float4*)(stg + row * SSTG_ROW + rc * 32);
         const float4 hi = *(const float4*)(stg + row * SSTG_ROW + rc * 32 + 16);
         float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        if constexpr (BN == 1) {
+          if (m < a.M) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              csum[t * 8 + j] += v[j];
+              csq[t * 8 + j] = fmaf(v[j], v[j], csq[t * 8 + j]);
+            }
+          }
+          continue;
+        }
         const float* bp = bl + t * 32 + rc * 8;
+        if constexpr (BN == 2) {
+          if (m < a.M && n < a.N) {
+            float y[8], xh[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              y[j] = fmaf(v[j], bp[j], bp[NW + j]);
+              xh[j] = fmaf(v[j], bp[2 * NW + j], bp[3 * NW + j]);
+            }
+            if (a.resid_kind == 2) {
+              float f[8];
+              unpack_bf16x8(*(const uint4*)((const bf16_t*)a.resid + (size_t)m * a.ldr + n), f);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) y[j] += f[j];
+            }
+            if (a.act == 2) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) y[j] = fmaxf(y[j], 0.f);
+            }
+            uint4 o, h;
+            o.x = pack_bf16x2(y[0], y[1]); o.y = pack_bf16x2(y[2], y[3]);
+            o.z = pack_bf16x2(y[4], y[5]); o.w = pack_bf16x2(y[6], y[7]);
+            h.x = pack_bf16x2(xh[0], xh[1]); h.y = pack_bf16x2(xh[2], xh[3]);
+            h.z = pack_bf16x2(xh[4], xh[5]); h.w = pack_bf16x2(xh[6], xh[7]);
+            *(uint4*)((bf16_t*)a.out + (size_t)m * a.ldo + n) = o;
+            *(uint4*)((bf16_t*)a.out2 + (size_t)m * a.ldo + n) = h;
+          }
+          continue;
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += bp[j];
         if (a.act == 1) {
@@ -247,24 +309,50 @@ __global__ __launch_bounds__(SWV * 64) void gemm_stream_kernel(const msclip_gemm
       }
     }
   }
+  if constexpr (BN == 1) {
+    // the 16 lanes that share (lane & 3) hold the same columns: fold them, lanes 0-3 write the wave's row
+    float* prow = a.part + ((size_t)blockIdx.x * SWV + wave) * 2 * a.N;
+#pragma unroll
+    for (int i = 0; i < NT * 8; ++i) {
+      float u = csum[i], q = csq[i];
+#pragma unroll
+      for (int msk = 4; msk < 64; msk <<= 1) {
+        u += __shfl_xor(u, msk, 64);
+        q += __shfl_xor(q, msk, 64);
+      }
+      const int n = n0 + (i >> 3) * 32 + rc * 8 + (i & 7);
+      if (rr == 0 && n < a.N) {
+        prow[n] = u;
+        prow[a.N + n] = q;
+      }
+    }
+  }
 }
 
-template <int NT, int NKC, bool CONV, int SWV>
-void launch_stream(const msclip_gemm_desc* d, hipStream_t st, int ncu, int wg_per_cu) {
+template <int NT, int NKC, bool CONV, int SWV, int BN = 0>
+void launch_stream_bn(const msclip_gemm_desc* d, hipStream_t st, int ncu, int wg_per_cu) {
   constexpr int NW = NT * 32;
   const int chunks = (d->N + NW - 1) / NW;
-  const size_t lds = (size_t)NW * (NKC * 128 + 16) + NW * 4 + SWV * SSTG_BYTES;
+  const size_t lds = (size_t)NW * (NKC * 128 + 16) + (BN == 2 ? 4 : 1) * NW * 4 + SWV * SSTG_BYTES;
   if (lds > 65536) {
     bool attr_ok = true;                                        // (per instantiation and device)
-    MSCLIP_LDS_ATTR((&gemm_stream_kernel<NT, NKC, CONV, SWV>), lds, attr_ok);
+    MSCLIP_LDS_ATTR((&gemm_stream_kernel<NT, NKC, CONV, SWV, BN>), lds, attr_ok);
     (void)attr_ok;
   }
   const int nblk = (d->M + 31) / 32;
   int gx = (wg_per_cu * ncu + chunks - 1) / chunks;
   const int need = (nblk + SWV - 1) / SWV;
   if (gx > need) gx = need;
+  if (BN == 1 && gx > d->part_rows / SWV) gx = d->part_rows / SWV;      // (every wave owns a row of `part`)
   if (gx < 1) gx = 1;
-  hipLaunchKernelGGL((gemm_stream_kernel<NT, NKC, CONV, SWV>), dim3(gx, chunks), dim3(SWV * 64), lds, st, *d);
+  hipLaunchKernelGGL((gemm_stream_kernel<NT, NKC, CONV, SWV, BN>), dim3(gx, chunks), dim3(SWV * 64), lds, st, *d);
+}
+
+template <int NT, int NKC, bool CONV, int SWV>
+void launch_stream(const msclip_gemm_desc* d, hipStream_t st, int ncu, int wg_per_cu) {
+  if (d->bn_mode == 1) launch_stream_bn<NT, NKC, CONV, SWV, 1>(d, st, ncu, wg_per_cu);
+  else if (d->bn_mode == 2) launch_stream_bn<NT, NKC, CONV, SWV, 2>(d, st, ncu, wg_per_cu);
+  else launch_stream_bn<NT, NKC, CONV, SWV, 0>(d, st, ncu, wg_per_cu);
 }
 
 template <bool CONV>
@@ -310,6 +398,14 @@ bool dispatch_stream(const msclip_gemm_desc* d, hipStream_t st, int ncu) {
 // msclip_gemm_variant() use.
 bool msclip_gemm_small_eligible(const msclip_gemm_desc* d) {
   if ((d->K % 64) || d->M < 4096) return false;
+  if (d->bn_mode) {                                             // train-mode BatchNorm passes: aligned, unscattered launches only
+    const int SWVmax = 8;
+    if (d->bn_mode < 1 || d->bn_mode > 2 || d->bias || d->alpha != 1.f || (d->N & 7) || d->rpg != 0x7fffffff) return false;
+    if (d->bn_mode == 1 && (!d->part || d->part_rows < SWVmax)) return false;
+    if (d->bn_mode == 2 && (!d->bn_consts || !d->out2 || d->out_kind != 0 || (d->ldo & 7) || (d->resid_kind != 0 && d->resid_kind != 2) ||
+                            (d->resid_kind == 2 && (!d->resid || (d->ldr & 7))) || (d->act != 0 && d->act != 2)))
+      return false;
+  }
   if (d->resid_kind == 3 || d->resid_kind == 4 || (d->rpg != 0x7fffffff && d->resid_kind && d->resid_kind < 5)) return false;    // (row scatter: plain stores or the ReLU mask)
   if (d->ldw % 8) return false;
   if (d->mode == 0) return d->K <= 192 && !(d->ldx % 8);

@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MSCLIP_HIP_LIB") or os.path.join(_HERE, "csrc", "libmsclip_hip.so")   # override: kernel A/B probes only
 INT_MAX = 2 ** 31 - 1
-ABI_VERSION = 7                                          # include/msclip_hip.h MSCLIP_ABI_VERSION
+ABI_VERSION = 8                                          # include/msclip_hip.h MSCLIP_ABI_VERSION
 
 EXPORTS = (
     "msclip_gemm", "msclip_gemm_f8", "msclip_layernorm_stats", "msclip_rowstat_finalize", "msclip_layernorm_f8", "msclip_quant_f8_rows", "msclip_gemm_variant", "msclip_attention", "msclip_attention_lastq", "msclip_layernorm", "msclip_layernorm_split", "msclip_embed_tokens", "msclip_fill_cls",
@@ -73,6 +73,7 @@ class GemmDesc(ctypes.Structure):
         ("rowstat", ctypes.c_void_p), ("seg_split", ctypes.c_int), ("ldxb", ctypes.c_int), ("xb", ctypes.c_void_p),
         ("center", ctypes.c_void_p), ("part", ctypes.c_void_p), ("resid2", ctypes.c_void_p),
         ("M_dev", ctypes.c_void_p),                  # device int: the kernel runs min(M, *M_dev) rows (packed captions)
+        ("bn_mode", ctypes.c_int), ("part_rows", ctypes.c_int), ("bn_consts", ctypes.c_void_p),   # two-pass train-mode BatchNorm
     ]
 
 
@@ -131,7 +132,7 @@ def lib():
         L.msclip_stem_conv3x3s2_dual.argtypes = [vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, vp]
         L.msclip_stem_conv3x3s2_dual_raw.argtypes = [vp, ci, vp, vp, vp, ci, ci, ci, vp]
         L.msclip_stem_conv3x3s2_dual_stats.argtypes = [vp, ci, vp, vp, ci, ci, ci, ci, vp]
-        L.msclip_stem_conv3x3s2_dual_norm.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]
+        L.msclip_stem_conv3x3s2_dual_norm.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]
         L.msclip_dwpool.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
         L.msclip_stem_dual_conv3x3s2.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
         L.msclip_conv1x1_conv3x3s2.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
@@ -618,6 +619,14 @@ def describe_gemm(mode, M, N, K, tile=0, conv=None, ldx=None, resid_kind=0, rpg=
     return d
 
 
+def gemm_bn_two_pass_ok(spec_cin, N, K, M, conv=None):
+    """Does msclip_gemm take this convolution in its train-mode BatchNorm modes (msclip_gemm_desc.bn_mode: the streaming kernel's
+    statistics / normalise epilogues)?  Asked from the library (msclip_gemm_variant on a shape-only descriptor)."""
+    d = describe_gemm(0 if conv is None else 1, M, N, K, conv=conv, ldx=spec_cin)
+    d.bn_mode, d.part, d.part_rows = 1, 1, 2048
+    return N % 8 == 0 and gemm_variant(d) == "stream"
+
+
 def python_probes_active():
     """True while a KernelProbe is attached to the Python bindings (hip.gemm / hip.gemm_f8): such a call must run the eager launch
     loop (a plan replay never enters the bindings; plan-level probes: Plan.enable_probe)."""
@@ -664,7 +673,7 @@ class FoldOut:
 
 def gemm(x, w, out, *, M=None, bias=None, resid=None, resid_kind=0, act=0, alpha=1.0, conv=None, ktab=None,
          ldx=None, ldo=None, ldr=None, rpg=INT_MAX, radd=0, roff=0, N=None, tile=0, out2=None, fold_in=None, fold_out=None,
-         colsum_part=None, mdev=None):
+         colsum_part=None, mdev=None, bn_stats_part=None, bn_consts=None):
     """out = epilogue(alpha * x @ w^T).  x: bf16 [M, K] (or NHWC activation when conv=(H, W, Cin, Ho, Wo, stride, pad)),
     w: bf16 [N, Kpad]; out: bf16 or fp32 2-D buffer.  Training-step forms (ping-pong kernel): out2 = second bf16 output that
     receives the value before the activation; resid_kind = RESID_GELUGRAD multiplies by QuickGELU'(resid) (resid bf16) and,
@@ -729,6 +738,14 @@ def gemm(x, w, out, *, M=None, bias=None, resid=None, resid_kind=0, act=0, alpha
         assert fold_out is None and resid_kind == RESID_GELUGRAD and d.M % 128 == 0
         assert colsum_part.is_contiguous() and colsum_part.shape == (d.M // 128, d.N)
         d.part = colsum_part.data_ptr()
+    if bn_stats_part is not None:                     # msclip_gemm_desc.bn_mode 1: column sums of the product instead of an output
+        _f32(bn_stats_part)
+        assert bn_stats_part.is_contiguous() and bn_stats_part.dim() == 2 and bn_stats_part.shape[1] == 2 * d.N and bias is None
+        d.bn_mode, d.part, d.part_rows = 1, bn_stats_part.data_ptr(), bn_stats_part.shape[0]
+    elif bn_consts is not None:                       # bn_mode 2 (bn_finish's [5][N] rows): out = act(x scale + shift [+ resid]), out2 = xhat
+        _f32(bn_consts)
+        assert bn_consts.is_contiguous() and tuple(bn_consts.shape) == (5, d.N) and out2 is not None and bias is None
+        d.bn_mode, d.bn_consts = 2, bn_consts.data_ptr()
     probe = (_gemm_probe.get(d.mode) or _gemm_probe.get(gemm_variant(d))) if _gemm_probe else None
     rec = _REC[0]
     if probe is not None or rec is not None:
@@ -1135,17 +1152,12 @@ def stem_conv_dual_bn(img, w, affine, y_a, y_b, xhat_a, xhat_b, eps=1e-5):
     _check(lib().msclip_stem_conv3x3s2_dual_stats(_p(img), int(img.dtype == torch.bfloat16), _p(w), _p(part), waves, B, H, W, st),
            "msclip_stem_conv3x3s2_dual_stats")
     sums = colsum(part)                                      # [conv][2][48]
-    outs, consts = [], torch.empty(4, 96, dtype=torch.float32, device=dev)
+    o = torch.empty(2, 5, 48, dtype=torch.float32, device=dev)
     for k, (gamma, beta) in enumerate(affine):
-        o = torch.empty(5, 48, dtype=torch.float32, device=dev)
-        _check(lib().msclip_bn_finish_tiled(_p(sums[k * 96:]), 1, 48, pix, _p(gamma), _p(beta), eps, _p(o), 1, st), "msclip_bn_finish_tiled")
-        outs.append(tuple(o[j] for j in range(5)))
-        sl = slice(k * 48, k * 48 + 48)
-        consts[0, sl], consts[1, sl], consts[2, sl] = o[3], o[4], o[2]
-        torch.mul(o[0], o[2], out=consts[3, sl]).neg_()      # b = -mean rstd
-    _check(lib().msclip_stem_conv3x3s2_dual_norm(_p(img), int(img.dtype == torch.bfloat16), _p(w), _p(consts), _p(y_a), _p(y_b),
+        bn_finish(sums[k * 96:], 48, pix, gamma, beta, eps, o[k])
+    _check(lib().msclip_stem_conv3x3s2_dual_norm(_p(img), int(img.dtype == torch.bfloat16), _p(w), _p(o[0]), _p(o[1]), _p(y_a), _p(y_b),
                                                  _p(xhat_a), _p(xhat_b), B, H, W, st), "msclip_stem_conv3x3s2_dual_norm")
-    return outs
+    return [tuple(o[k, j] for j in range(5)) for k in range(2)]
 
 
 def stem_dual_conv3x3s2(img, w, bias, out_b, w2, b2, out2):
@@ -1572,6 +1584,15 @@ def _bn_unit(C, device):
     if k not in _BN_UNIT:
         _BN_UNIT[k] = (torch.ones(C, dtype=torch.float32, device=device), torch.zeros(C, dtype=torch.float32, device=device))
     return _BN_UNIT[k]
+
+
+def bn_finish(sums, C, n, gamma, beta, eps, out):
+    """sums [2][C] = (sum x, sum x^2) over n rows -> out [5][C] = mean, biased variance, rstd, scale = gamma rstd, shift = beta - mean
+    scale (msclip_bn_finish_tiled, no row fold)."""
+    _f32(sums); _f32(out)
+    assert sums.numel() >= 2 * C and tuple(out.shape) == (5, C) and out.is_contiguous()
+    _check(lib().msclip_bn_finish_tiled(_p(sums), 1, C, n, _p(gamma), _p(beta), eps, _p(out), 1, _stream()), "msclip_bn_finish_tiled")
+    return out
 
 
 def bn_apply(x, scale, shift, out, M=None, relu=False, resid=None):

@@ -477,6 +477,7 @@ class ConvSideBatchNorm:
         self.ts = train_step
         self.e = train_step.eng
         self.raw = _RawSpecs(self.e)
+        self._two_pass = {}                              # conv shape -> does msclip_gemm take it in its BatchNorm modes
         self.bw = ConvSideBackward(train_step)           # its generic pieces (_conv_bwd, _relu_bwd, patch matrix) are reused
 
     # ------------------------------------------------------------------ forward
@@ -488,6 +489,51 @@ class ConvSideBatchNorm:
         self.saved[prefix] = (x_raw, mean, rstd, g, M)
         self.stats[prefix] = (mean, var, M)
         return out
+
+    def _two_pass_ok(self, spec, M):
+        """Does msclip_gemm run this convolution in its BatchNorm modes (the streaming kernel's shapes)?  Asked once per shape."""
+        if not options.TRAIN.bn_two_pass:
+            return False
+        pointwise = spec.kh == 1 and spec.kw == 1 and spec.stride == 1 and spec.pad == 0
+        key = (spec.cin, spec.cout, spec.weight.shape[1], M, None if pointwise else spec.geometry())
+        if key not in self._two_pass:
+            self._two_pass[key] = hip.gemm_bn_two_pass_ok(spec.cin, spec.cout, spec.weight.shape[1], M, conv=key[4])
+        return self._two_pass[key]
+
+    def _conv_bn(self, x, spec, prefix, eps, out, M, relu=False, resid=None, two_pass=None):
+        """out = [relu](BN_batch(conv(x)) [+ resid]).  Convolutions the streaming kernel runs (pointwise, 1 x 1 stride 2, 3 x 3 over 48
+        channels) in two passes over x -- statistics, then normalise in the epilogue, xhat (bf16) kept for the backward; no raw map
+        (options.TRAIN.bn_two_pass) --, the others as raw fp32 map + statistics pass + normalise pass.  two_pass: the caller's choice
+        for BatchNorms whose backward shares one pass (both sides of a residual block must keep the same kind of map)."""
+        e, Bi = self.e, self.Bi
+        pointwise = spec.kh == 1 and spec.kw == 1 and spec.stride == 1 and spec.pad == 0
+        kw = dict(M=M, N=spec.cout, ldx=spec.cin) if pointwise else dict(M=M, N=spec.cout, conv=spec.geometry(), ktab=spec.ktab)
+        if two_pass is None:
+            two_pass = self._two_pass_ok(spec, M)
+        if two_pass:                                         # (raw specs carry a zero bias)
+            assert out.stride(0) == spec.cout and (resid is None or resid.stride(0) == spec.cout)
+            part = self._part_rows(spec.cout, e.dev)
+            hip.gemm(x, spec.weight, part, bn_stats_part=part, **kw)
+            sd = self.raw.sd
+            g = sd[prefix + ".weight"]
+            sums = hip.colsum(part)
+            o = torch.empty(5, spec.cout, dtype=F32, device=e.dev)
+            hip.bn_finish(sums, spec.cout, M, g, sd[prefix + ".bias"], eps, o)
+            mean, var, rstd, scale, shift = (o[k] for k in range(5))
+            xh = _zbuf(out.shape[0], spec.cout, e.dev)
+            hip.gemm(x, spec.weight, out, out2=xh, bn_consts=o, act=hip.ACT_RELU if relu else hip.ACT_NONE, resid=resid,
+                     resid_kind=hip.RESID_BF16 if resid is not None else hip.RESID_NONE, **kw)
+            zero, one = hip._bn_unit(spec.cout, e.dev)[1], hip._bn_unit(spec.cout, e.dev)[0]
+            self.saved[prefix] = (xh, zero, one, scale, M)
+            self.stats[prefix] = (mean, var, M)
+            return out
+        r = torch.empty(M, spec.cout, dtype=F32, device=e.dev)       # raw conv outputs stay fp32 until normalised
+        e._conv(x, spec, r, Bi)
+        return self._bn(r, prefix, eps, out, M, relu=relu, resid=resid)
+
+    def _part_rows(self, N, dev):
+        """Zeroed [2048, 2 N] partial-sum rows of a statistics launch (a wave per row; rows of waves that do not exist stay zero)."""
+        return torch.zeros(2048, 2 * N, dtype=F32, device=dev)
 
     def begin(self, img, w, Bi):
         self.raw.refresh()
@@ -533,13 +579,10 @@ class ConvSideBatchNorm:
         x = w["S1"]
         for i, (main, short, q) in enumerate(self.raw.stem):
             M = Bi * main.h_out * main.w_out
-            rm = torch.empty(M, main.cout, dtype=F32, device=e.dev)
-            rs = torch.empty(M, short.cout, dtype=F32, device=e.dev)
-            e._conv(x, main, rm, Bi)
-            e._conv(x, short, rs, Bi)
             tmp = _zbuf(M, main.cout, e.dev)
-            self._bn(rm, q + ".bn1", 1e-5, tmp, M)
-            self._bn(rs, q + ".downsample.1", 1e-5, w["stem"][i], M, relu=True, resid=tmp)
+            tp = self._two_pass_ok(main, M) and self._two_pass_ok(short, M)
+            self._conv_bn(x, main, q + ".bn1", 1e-5, tmp, M, two_pass=tp)
+            self._conv_bn(x, short, q + ".downsample.1", 1e-5, w["stem"][i], M, relu=True, resid=tmp, two_pass=tp)
             x = w["stem"][i]
 
     def stage(self, j):
@@ -550,15 +593,15 @@ class ConvSideBatchNorm:
         t1, t2, tr = w["par_tmp"][j]
         src = w["par"][j - 1]
 
-        def run(spec, x, bn, out, relu, resid=None):
+        def run(spec, x, bn, out, relu, resid=None, two_pass=None):
             M = Bi * spec.h_out * spec.w_out
-            r = torch.empty(M, spec.cout, dtype=F32, device=e.dev)
-            e._conv(x, spec, r, Bi)
-            self._bn(r, f"{q}.{bn}", 1e-6, out, M, relu=relu, resid=resid)
+            self._conv_bn(x, spec, f"{q}.{bn}", 1e-6, out, M, relu=relu, resid=resid, two_pass=two_pass)
         run(c1, src, "bn1", t1, True)
         run(c2, t1, "bn2", t2, True)
-        run(cr, src, "residual_bn", tr, False)
-        run(c3, t2, "bn3", w["par"][j], True, resid=tr)
+        M3 = Bi * c3.h_out * c3.w_out
+        tp = self._two_pass_ok(cr, M3) and self._two_pass_ok(c3, M3)    # bn3 and residual_bn share their backward pass
+        run(cr, src, "residual_bn", tr, False, two_pass=tp)
+        run(c3, t2, "bn3", w["par"][j], True, resid=tr, two_pass=tp)
 
     def adapter_top(self, j, out):
         """pool = BN(dwconv_{k=s}(par[j])) -> w["pool"][j]; out = pw(pool)."""

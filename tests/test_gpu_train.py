@@ -477,6 +477,43 @@ def test_stem_dual_conv_two_pass_batchnorm(gpu_device, B, S, dt):
         assert rel(dg1, dg0) <= 8e-3 and rel(db1, db0) <= 1e-5 and rel(dx_hat, dx_raw) <= 1e-2, (rel(dg1, dg0), rel(db1, db0), rel(dx_hat, dx_raw))
 
 
+@pytest.mark.parametrize("ci,co,k,stride,H,B,resid", [(48, 48, 1, 1, 56, 3, False), (48, 96, 1, 2, 56, 6, True), (48, 96, 3, 2, 56, 6, False),
+                                                      (48, 48, 3, 2, 40, 11, False), (96, 192, 1, 2, 28, 22, True), (96, 96, 1, 1, 28, 7, False),
+                                                      (192, 384, 1, 1, 14, 24, True)])
+def test_conv_two_pass_batchnorm_on_the_streaming_kernel(gpu_device, ci, co, k, stride, H, B, resid):
+    """msclip_gemm_desc.bn_mode 1 / 2 (round 6): train-mode BatchNorm of a convolution the streaming kernel runs, without a raw map --
+    column sums from a first pass (per-wave partial rows), normalise + optional residual + ReLU and xhat from a second -- against the
+    raw fp32 map + msclip_bn_stats + msclip_bn_apply path on the same operands."""
+    from msclip_amd import packing as P
+    pad = 1 if k == 3 else 0
+    x = rnd(B * H * H + 8, ci, seed=81, dtype=BF)                      # NHWC rows (+ slack for the K padding of pointwise launches)
+    wt = rnd(co, ci, k, k, seed=82, scale=(2.0 / (ci * k * k)) ** 0.5)
+    spec = P.ConvSpec(wt, torch.zeros(co), H, H, stride, pad).to("cuda")
+    M = B * spec.h_out * spec.w_out
+    pointwise = k == 1 and stride == 1
+    kw = dict(M=M, N=co, ldx=ci) if pointwise else dict(M=M, N=co, conv=spec.geometry(), ktab=spec.ktab)
+    assert hip.gemm_bn_two_pass_ok(ci, co, spec.weight.shape[1], M, conv=None if pointwise else spec.geometry())
+    gam, bet = rnd(co, seed=83) * 0.5 + 1.0, rnd(co, seed=84)
+    res = rnd(M, co, seed=85, dtype=BF) if resid else None
+    raw = torch.empty(M, co, device="cuda")
+    hip.gemm(x, spec.weight, raw, **kw)
+    mean, var, rstd, scale, shift = hip.bn_stats(raw, gamma=gam, beta=bet, eps=1e-6)
+    want = torch.empty(M, co, dtype=BF, device="cuda")
+    hip.bn_apply(raw, scale, shift, want, relu=True, resid=res)
+    part = torch.zeros(2048, 2 * co, device="cuda")
+    hip.gemm(x, spec.weight, part, bn_stats_part=part, **kw)
+    o = torch.empty(5, co, device="cuda")
+    hip.bn_finish(hip.colsum(part), co, M, gam, bet, 1e-6, o)
+    assert rel(o[0], mean) <= 2e-5 and rel(o[1], var) <= 1e-4 and rel(o[3], scale) <= 1e-4 and rel(o[4], shift) <= 1e-4
+    y = torch.full((M + 2, co), 7.0, dtype=BF, device="cuda")
+    xh = torch.full((M + 2, co), 7.0, dtype=BF, device="cuda")
+    hip.gemm(x, spec.weight, y[:M], out2=xh[:M], bn_consts=o, act=hip.ACT_RELU, resid=res,
+             resid_kind=hip.RESID_BF16 if resid else hip.RESID_NONE, **kw)
+    assert rel(y[:M], want) <= 8e-3 and (y[:M].float() != want.float()).float().mean().item() <= 2e-3
+    assert rel(xh[:M], (raw - mean) * rstd) <= 6e-3
+    assert bool((y[M:] == 7.0).all()) and bool((xh[M:] == 7.0).all())
+
+
 @pytest.mark.parametrize("B,S,co", [(3, 32, 48), (2, 224, 24), (5, 36, 16), (2, 64, 64), (1, 256, 40)])
 def test_image_conv_wgrad_without_a_patch_matrix(gpu_device, B, S, co):
     """msclip_image_conv_wgrad (the stem's conv1 / parallel stage 0 on the input image): dW and the bias sums from one pass over dy
