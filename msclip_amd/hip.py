@@ -1674,9 +1674,10 @@ def bn_bwd_fused(dy, sides, y=None, dy2=None, M=None, chunks=None, dx_chunks=0):
     mats = [dy[:M]] + [t[:M] for t in (y, dy2) if t is not None] + [x[:M] for x, *_ in sides] + [s[4][:M] for s in sides]
     r = _bn_fold_rows(M, C, *mats)
     Mw, Cw = M // r, C * r
-    # row chunks of the reduce pass: 128-256 rows each, at least ~200 of them where the map has the rows (sweep of
-    # tools/probes/bn_bwd_fused_bench.py: 14^2 / 7^2 maps lose 2 x with the 1 024-row chunks of the scalar kernels)
-    ch = max(1, min(1568, max(Mw // 256, 196), Mw // 32))
+    # row chunks of the reduce pass: 128-512 rows each, at least ~200 of them where the map has the rows (sweep of
+    # tools/probes/bn_bwd_fused_bench.py: 14^2 / 7^2 maps lose 2 x with the 1 024-row chunks of the scalar kernels; beyond 784 chunks
+    # msclip_bn_bwd_finish -- a workgroup per channel walks every chunk's partials -- costs more than the reduce pass gains)
+    ch = max(1, min(784, max(Mw // 256, 196), Mw // 32))
     if chunks:
         ch = chunks                                      # (probe: tools/probes/bn_bwd_fused_bench.py)
     dev = dy.device

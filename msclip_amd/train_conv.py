@@ -440,8 +440,41 @@ class _RawSpecs:
         self.refresh()
 
     def refresh(self):
+        """The raw operands of this step from the module's parameters.  options.TRAIN.raw_pack_table (default): ONE msclip_pack_weights
+        launch from a device-resident item table (built once per set of parameter tensors) rewrites every one of them in place;
+        else ~60 ATen permute / cast / copy launches (round 5; the cross-check of the table)."""
         e = self.e
         sd = e.state_views()
+        if options.TRAIN.raw_pack_table and e.dev.type == "cuda":
+            if getattr(self, "_table", None) is None or self._table_sd is not sd:
+                self._refresh_eager(sd)                      # allocates the operand tensors (and fills them once)
+                self._table, self._table_sd = self._build_table(sd), sd
+            self._table.run()
+            self.sd = sd
+            return
+        self._refresh_eager(sd)
+
+    def _build_table(self, sd):
+        t = hip.PackPlan(self.e.dev)
+        for sp_, key in self.items:
+            t.add(sd[key], out=sp_.weight)                   # bf16 [co][kpad], (kh, kw, ci) order, zero padded
+        sp = "visual.transformer.resblocks.0"
+        wa, wb = sd[sp + ".conv1.weight"], sd["visual.transformer.parallel_branch_v.0.conv.weight"]
+        t.add(wa, out=self.w_conv1)
+        t.add(wb, out=self.w_par0)
+        if self.w_dual is not None:                          # fp32 [27][96]: rows (ci, kh, kw) as the filters lie in memory
+            t.add(wa, out=self.w_dual, mode=1, col0=0, ld=96)
+            t.add(wb, out=self.w_dual, mode=1, col0=48, ld=96)
+        for j in range(5):
+            p = f"visual.transformer.parallel_lateral_adapter.{j}"
+            wd = sd[p + ".top2bottom_dw_conv.conv.weight"]
+            t.add(wd, out=self.pool[j], mode=1, col0=0, ld=wd.shape[0])      # [k*k][C]
+            wbt = sd[p + ".bottom_dw_conv.conv.weight"]
+            t.add(wbt, out=self.dww[j], mode=1, col0=0, ld=wbt.shape[0])     # [9][D]
+        return t.finalize()
+
+    def _refresh_eager(self, sd):
+        e = self.e
         for sp_, key in self.items:
             # [Cout, Cin, KH, KW] fp32 -> the spec's [Cout, Kpad] bf16 matrix in (kh, kw, ci) order: ONE strided, converting copy
             # into its first K columns (the pad columns stay zero) instead of permute / pad / cast / copy

@@ -1319,6 +1319,39 @@ def test_gradients_at_batch_32_against_reference_autograd(gpu_device, bn):
     assert conv_med <= dev["conv_side"]["sample_err_median"] + 5e-3, (conv_med, dev["conv_side"]["sample_err_median"])
 
 
+def test_raw_conv_operands_from_one_table_launch(gpu_device, monkeypatch):
+    """options.TRAIN.raw_pack_table: the raw (unfolded) conv-side operands of the train-mode BatchNorm step rewritten by ONE
+    msclip_pack_weights launch from a device-resident item table -- bitwise the ~60 ATen permute / cast / copy launches it
+    replaces, before and after an in-place parameter update."""
+    from msclip_amd import options, train_conv as TC
+    m = _fresh_model("b32-yfcc-msclips")
+    eng = m.engine()
+
+    def operands(raw):
+        out = {f"spec{i}": sp.weight for i, (sp, _) in enumerate(raw.items)}
+        out.update(w_conv1=raw.w_conv1, w_par0=raw.w_par0, w_dual=raw.w_dual)
+        out.update({f"pool{j}": t for j, t in enumerate(raw.pool)})
+        out.update({f"dww{j}": t for j, t in enumerate(raw.dww)})
+        return {k: v.clone() for k, v in out.items()}
+    monkeypatch.setattr(options, "TRAIN", options.TRAIN.replace(raw_pack_table=True))
+    table = TC._RawSpecs(eng)
+    monkeypatch.setattr(options, "TRAIN", options.TRAIN.replace(raw_pack_table=False))
+    eager = TC._RawSpecs(eng)
+    for rnd_ in range(2):
+        monkeypatch.setattr(options, "TRAIN", options.TRAIN.replace(raw_pack_table=True))
+        table.refresh()
+        assert table._table is not None and table._table.n_items == len(table.items) + 2 + 2 + 10
+        monkeypatch.setattr(options, "TRAIN", options.TRAIN.replace(raw_pack_table=False))
+        eager.refresh()
+        a, b = operands(table), operands(eager)
+        assert sorted(a) == sorted(b) and len(a) >= 40
+        for k in a:
+            assert a[k].dtype == b[k].dtype and torch.equal(a[k], b[k]), k
+        with torch.no_grad():                                           # an optimizer step's in-place update
+            for p_ in m.parameters():
+                p_.mul_(1.0 + 0.01 * (rnd_ + 1)).add_(1e-3)
+
+
 def test_two_pass_image_batchnorm_in_the_step_equals_the_raw_map_path(gpu_device, monkeypatch):
     """options.TRAIN.bn_two_pass (default) against raw fp32 maps + statistics / normalise passes in the whole train-mode step: the
     loss equal to bf16 rounding ties of the two activation maps, every gradient to the noise of xhat's one bf16 rounding."""
