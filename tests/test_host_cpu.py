@@ -79,7 +79,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     lib.msclip_abi_version.restype = ctypes.c_int
     lib.msclip_build_arch.restype = ctypes.c_char_p
-    assert lib.msclip_abi_version() == hip.ABI_VERSION == 7 and lib.msclip_build_arch() == b"gfx950"
+    assert lib.msclip_abi_version() == hip.ABI_VERSION == 8 and lib.msclip_build_arch() == b"gfx950"
     # struct mirror must match the C layout (6 pointers + 24 ints/floats, then a pointer in the middle)
     assert ctypes.sizeof(hip.GemmDesc) % 8 == 0 and hip.GemmDesc.ktab.offset % 8 == 0
 
