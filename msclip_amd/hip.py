@@ -1586,6 +1586,45 @@ def _bn_unit(C, device):
     return _BN_UNIT[k]
 
 
+def bn_stats_partials(x, chunks=None):
+    """part [chunks][2][C] fp32 = (sum x, sum x^2) per row chunk of x [M, C] (msclip_bn_stats without the fold)."""
+    M, C = x.shape
+    assert x.stride(1) == 1 and x.dtype in (torch.float32, torch.bfloat16)
+    ch = chunks if chunks is not None else _bn_chunks(M)
+    part = torch.empty(ch, 2 * C, dtype=torch.float32, device=x.device)
+    _check(lib().msclip_bn_stats(_p(x), x.stride(0), int(x.dtype == torch.float32), _p(part), M, C, ch, _stream()), "msclip_bn_stats")
+    return part
+
+
+def bn_bwd_token_columns(dy, x, mean, rstd, gamma, dx, L, n_stat):
+    """Train-mode BatchNorm backward of a BatchNorm over the rows 1 .. L - 1 of every sample of a token matrix [B L, D], with the
+    matrices viewed as [B, L * D] (a sample per row, a (token, channel) pair per column): fp32 dy, x (raw map), dx.  Token 0's
+    columns (the class token, which the BatchNorm does not see) run with mean 0, rstd 1, gamma 1 and are left out of the sums, so
+    dx = dy there: ONE dx pass writes the whole matrix.  -> (dgamma [D], dbeta [D])."""
+    B, LD = dy.shape
+    D = LD // L
+    for t in (dy, x, dx):
+        assert t.dtype == torch.float32 and t.shape == (B, LD) and t.stride(1) == 1
+    dev = dy.device
+    mean_t, rstd_t = mean.repeat(L), rstd.repeat(L)
+    mean_t[:D].zero_()
+    rstd_t[:D].fill_(1.0)
+    ch = _bn_chunks(B)
+    part = torch.empty(ch, 2 * LD, dtype=torch.float32, device=dev)
+    st = _stream()
+    _check(lib().msclip_bn_bwd_reduce(_p(dy), dy.stride(0), 1, _p(x), x.stride(0), 1, _p(mean_t), _p(rstd_t), _p(part), B, LD, ch, st),
+           "msclip_bn_bwd_reduce")
+    part.view(ch, 2, L, D)[:, :, 0].zero_()                 # the class token's columns take no part in the sums
+    tail = torch.empty(3, LD, dtype=torch.float32, device=dev)          # (dbeta, dgamma, gamma), each tiled L times
+    _check(lib().msclip_bn_bwd_finish(_p(part), ch, L, D, _p(gamma), _p(tail), st), "msclip_bn_bwd_finish")
+    dbeta, dgamma = tail[0, D:2 * D].clone(), tail[1, D:2 * D].clone()
+    tail.view(3, L, D)[:2, 0].zero_()
+    tail.view(3, L, D)[2, 0].fill_(1.0)
+    _check(lib().msclip_bn_bwd_dx(_p(dy), dy.stride(0), 1, _p(x), x.stride(0), 1, _p(mean_t), _p(rstd_t), _p(tail[2]), _p(tail[0]),
+                                  _p(tail[1]), _p(dx), dx.stride(0), B, LD, n_stat, st), "msclip_bn_bwd_dx")
+    return dgamma, dbeta
+
+
 def bn_finish(sums, C, n, gamma, beta, eps, out):
     """sums [2][C] = (sum x, sum x^2) over n rows -> out [5][C] = mean, biased variance, rstd, scale = gamma rstd, shift = beta - mean
     scale (msclip_bn_finish_tiled, no row fold)."""

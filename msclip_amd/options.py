@@ -97,6 +97,9 @@ class TrainOptions:
     #                                   kept in bf16 for the backward) instead of raw fp32 maps + a statistics + a normalise pass
     raw_pack_table: bool = True       # MSCLIP_RAW_PACK_TABLE: train-mode BatchNorm's raw conv operands refreshed by one msclip_pack_weights
     #                                   launch per step instead of ~60 ATen launches
+    adapter_bn_views: bool = True     # MSCLIP_ADAPTER_BN_VIEWS: the lateral adapters' batch-statistics BatchNorm (over the grid rows of a
+    #                                   token matrix) on whole samples viewed as rows of L * D columns, the class token's columns
+    #                                   neutralised -- no gather / clone / scatter copies of the [B L, D] maps (round 6)
     colsum_main: bool = False         # MSCLIP_COLSUM_MAIN: the conv side's bias sums on the main stream instead of the lane
     #                                   (either of the two makes a hipGraph replay of the step right: profiles/r06_train_hipgraph_probe.txt)
 
@@ -105,7 +108,8 @@ class TrainOptions:
         return cls(wgrad_sync=_flag("MSCLIP_WGRAD_SYNC", False), dgrad_col2im=_flag("MSCLIP_DGRAD_COL2IM", False),
                    im2col_main=_flag("MSCLIP_IM2COL_MAIN", False), colsum_main=_flag("MSCLIP_COLSUM_MAIN", False),
                    compact_last_block=_flag("MSCLIP_TRAIN_COMPACT_LAST", True), bn_bwd_fused=_flag("MSCLIP_BN_BWD_FUSED", True),
-                   bn_two_pass=_flag("MSCLIP_BN_TWO_PASS", True), raw_pack_table=_flag("MSCLIP_RAW_PACK_TABLE", True))
+                   bn_two_pass=_flag("MSCLIP_BN_TWO_PASS", True), raw_pack_table=_flag("MSCLIP_RAW_PACK_TABLE", True),
+                   adapter_bn_views=_flag("MSCLIP_ADAPTER_BN_VIEWS", True))
 
     def replace(self, **kw):
         return dataclasses.replace(self, **kw)

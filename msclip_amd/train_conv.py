@@ -511,6 +511,7 @@ class ConvSideBatchNorm:
         self.e = train_step.eng
         self.raw = _RawSpecs(self.e)
         self._two_pass = {}                              # conv shape -> does msclip_gemm take it in its BatchNorm modes
+        self._zeros = {}                                 # read-only zero operands of the adapters' raw depthwise pass
         self.bw = ConvSideBackward(train_step)           # its generic pieces (_conv_bwd, _relu_bwd, patch matrix) are reused
 
     # ------------------------------------------------------------------ forward
@@ -653,13 +654,30 @@ class ConvSideBatchNorm:
         e, Bi = self.e, self.Bi
         D, g, L = e.D, e.g, e.Lv
         p = f"visual.transformer.parallel_lateral_adapter.{j}.bottom_dw_conv.bn"
-        zero_t = torch.zeros(Bi * g * g, D, dtype=F32, device=e.dev)
-        zero_b = torch.zeros(D, dtype=F32, device=e.dev)
-        raw_full = torch.empty(Bi * L, D, dtype=F32, device=e.dev)
-        hip.adapter_sum(X, zero_t, self.raw.dww[j], zero_b, raw_full, Bi, L, g, e.usecls)
-        graw = raw_full.view(Bi, L, D)[:, 1:].reshape(Bi * g * g, D)
         sd = self.raw.sd
         gam = sd[p + ".weight"]
+        raw_full = torch.empty(Bi * L, D, dtype=F32, device=e.dev)
+        if options.TRAIN.adapter_bn_views:
+            # no copy of the grid rows and no fill: a sample is ONE row of L * D columns, the statistics are taken per (token, channel)
+            # column and the class token's columns are left out of the fold over tokens
+            key = (Bi * g * g, D)
+            if key not in self._zeros:
+                self._zeros[key] = (torch.zeros(Bi * g * g, D, dtype=F32, device=e.dev), torch.zeros(D, dtype=F32, device=e.dev))
+            zero_t, zero_b = self._zeros[key]                            # (read-only)
+            hip.adapter_sum(X, zero_t, self.raw.dww[j], zero_b, raw_full, Bi, L, g, e.usecls)
+            part = hip.bn_stats_partials(raw_full.view(Bi, L * D))       # [1][2][L * D]
+            sums = part.view(2, L, D)[:, 1:].sum(1)
+            o = torch.empty(5, D, dtype=F32, device=e.dev)
+            hip.bn_finish(sums, D, Bi * g * g, gam, sd[p + ".bias"], 1e-5, o)
+            mean, var, rstd, scale, shift = (o[k] for k in range(5))
+            hip.adapter_sum(X, t, (self.raw.dww[j] * scale).contiguous(), shift, out, Bi, L, g, e.usecls)
+            self.saved[p] = (raw_full, mean, rstd, gam, Bi * g * g, L)   # (6 entries: the map still holds the class rows)
+            self.stats[p] = (mean, var, Bi * g * g)
+            return
+        zero_t = torch.zeros(Bi * g * g, D, dtype=F32, device=e.dev)
+        zero_b = torch.zeros(D, dtype=F32, device=e.dev)
+        hip.adapter_sum(X, zero_t, self.raw.dww[j], zero_b, raw_full, Bi, L, g, e.usecls)
+        graw = raw_full.view(Bi, L, D)[:, 1:].reshape(Bi * g * g, D)
         mean, var, rstd, scale, shift = hip.bn_stats(graw, gamma=gam, beta=sd[p + ".bias"], eps=1e-5)
         hip.adapter_sum(X, t, (self.raw.dww[j] * scale).contiguous(), shift, out, Bi, L, g, e.usecls)
         self.saved[p] = (graw, mean, rstd, gam, Bi * g * g)
@@ -735,14 +753,25 @@ class ConvSideBatchNorm:
         g, D, C, k, hw, L = e.g, e.D, a["C"], a["k"], e.par_hw[j], e.Lv
         g2 = g * g
         p = f"visual.transformer.parallel_lateral_adapter.{j}"
-        dT = dsum.view(Bi, L, D)[:, 1:].reshape(Bi * g2, D)
-        # bottom: BN(dw3x3(grid)) with batch statistics
-        draw = self._bn_bwd(grads, p + ".bottom_dw_conv.bn", dT)
-        dfull = dsum.clone()
-        dfull.view(Bi, L, D)[:, 1:] = draw.view(Bi, g2, D)
+        sv = self.saved[p + ".bottom_dw_conv.bn"]
+        if len(sv) == 6:
+            # (options.TRAIN.adapter_bn_views) the BatchNorm backward over whole samples as rows of L * D columns: the class token's
+            # columns get mean 0 / rstd 1 / gamma 1 and no share of the sums, i.e. dx = dy there -- one pass writes the whole matrix
+            # that msclip_adapter_dx reads; no gather of the grid rows, no clone, no scatter back
+            x_full, mean, rstd, gam, n, _ = sv
+            dfull = torch.empty_like(dsum)
+            dg, db = hip.bn_bwd_token_columns(dsum.view(Bi, L * D), x_full.view(Bi, L * D), mean, rstd, gam, dfull.view(Bi, L * D), L, n)
+            grads[p + ".bottom_dw_conv.bn.weight"], grads[p + ".bottom_dw_conv.bn.bias"] = dg, db
+            dT_bf = hip.cast_bf16_colsum(dsum, fold=False, skip_group=g2)[0]
+        else:
+            dT = dsum.view(Bi, L, D)[:, 1:].reshape(Bi * g2, D)
+            # bottom: BN(dw3x3(grid)) with batch statistics
+            draw = self._bn_bwd(grads, p + ".bottom_dw_conv.bn", dT)
+            dfull = dsum.clone()
+            dfull.view(Bi, L, D)[:, 1:] = draw.view(Bi, g2, D)
+            dT_bf = hip.cast_bf16(dT)
         grads[p + ".bottom_dw_conv.conv.weight"] = hip.dw3x3_wgrad(dfull, x_pre, Bi, L, g).t().reshape(D, 1, 3, 3)
         # top-down: T = Wp . BN(dwpool(par[j]))
-        dT_bf = hip.cast_bf16(dT)
         pw = self.raw.pw[j]
         grads[p + ".top2bottom_pw_conv.conv.weight"] = _wgrad_async(dT_bf, w["pool"][j], Bi * g2,
                                                                     post=lambda d: d.reshape(D, C, 1, 1))

@@ -876,7 +876,11 @@ def test_gradients_with_train_mode_batchnorm(gpu_device, name):
     tok_keys = [k for k in expect if k not in conv_keys and k not in lnb_keys]
     assert float(np.median([worst[k] for k in tok_keys])) <= 1.25 * dev["token_side"]["sample_err_median"] + 5e-3
     assert float(np.median([worst[k] for k in conv_keys])) <= 1.25 * dev["conv_side"]["sample_err_median"] + 5e-3
-    assert max(worst[k] for k in conv_keys) <= dev["conv_side"]["sample_err_worst"] + 2e-2
+    # (the WORST of ~150 conv-side tensors is a noisy statistic: across the eight numerically equivalent schedules of this step --
+    #  options.TRAIN adapter_bn_views x bn_two_pass x bn_bwd_fused, which only move summation orders and rounding points -- it takes
+    #  0.261-0.316 on ViT-B/16 batch 8 and 0.293-0.309 on ViT-B/32 batch 16 while the median stays at 0.094-0.097 and the lowest cosine
+    #  at 0.966-0.969: profiles/r06_trainbn_fixture_spread.txt.  Margin = that spread.)
+    assert max(worst[k] for k in conv_keys) <= dev["conv_side"]["sample_err_worst"] + 4e-2
     assert min(coss[k] for k in conv_keys if k in coss) >= dev["conv_side"]["cosine_lowest"] - 5e-3
 
 
@@ -1319,6 +1323,30 @@ def test_gradients_at_batch_32_against_reference_autograd(gpu_device, bn):
     assert conv_med <= dev["conv_side"]["sample_err_median"] + 5e-3, (conv_med, dev["conv_side"]["sample_err_median"])
 
 
+def test_batchnorm_backward_over_token_columns(gpu_device):
+    """hip.bn_bwd_token_columns: the lateral adapter's BatchNorm (over the grid rows of a token matrix, class rows excluded) run on
+    whole samples as rows of L * D columns -- against msclip_bn_bwd_* on a gathered copy of the grid rows, class rows passed through."""
+    B, L, D = 24, 50, 768
+    g2 = L - 1
+    x, dy = rnd(B * L, D, seed=1) * 1.5 + 0.2, rnd(B * L, D, seed=2)
+    gam = rnd(D, seed=3) * 0.5 + 1.0
+    xg = x.view(B, L, D)[:, 1:].reshape(B * g2, D)
+    dyg = dy.view(B, L, D)[:, 1:].reshape(B * g2, D)
+    part = hip.bn_stats_partials(x.view(B, L * D))
+    sums = part.view(2, L, D)[:, 1:].sum(1)
+    o = torch.empty(5, D, device="cuda")
+    hip.bn_finish(sums, D, B * g2, gam, torch.zeros_like(gam), 1e-5, o)
+    mean, var, rstd = hip.bn_stats(xg, gamma=gam, beta=torch.zeros_like(gam), eps=1e-5)[:3]
+    assert rel(o[0], mean) <= 1e-5 and rel(o[1], var) <= 1e-4 and rel(o[2], rstd) <= 1e-4
+    want = torch.empty_like(dyg)
+    wg, wb = hip.bn_bwd(dyg, xg, mean, rstd, gam, want)
+    dx = torch.full((B * L, D), float("nan"), device="cuda")
+    dg, db = hip.bn_bwd_token_columns(dy.view(B, L * D), x.view(B, L * D), mean, rstd, gam, dx.view(B, L * D), L, B * g2)
+    assert rel(dg, wg) <= 1e-4 and rel(db, wb) <= 1e-4
+    assert torch.equal(dx.view(B, L, D)[:, 0], dy.view(B, L, D)[:, 0])                  # class rows: dx = dy
+    assert rel(dx.view(B, L, D)[:, 1:].reshape(B * g2, D), want) <= 1e-4
+
+
 def test_raw_conv_operands_from_one_table_launch(gpu_device, monkeypatch):
     """options.TRAIN.raw_pack_table: the raw (unfolded) conv-side operands of the train-mode BatchNorm step rewritten by ONE
     msclip_pack_weights launch from a device-resident item table -- bitwise the ~60 ATen permute / cast / copy launches it
@@ -1383,6 +1411,28 @@ def test_two_pass_image_batchnorm_in_the_step_equals_the_raw_map_path(gpu_device
     cos = {k: F.cosine_similarity(g0[k].flatten(), g1[k].flatten(), dim=0).item() for k in g0 if g0[k].numel() > 1}
     print("lowest cosine", sorted(cos.items(), key=lambda kv: kv[1])[:4], "first convs / BatchNorms", {k: round(worst[k], 4) for k in head})
     assert min(cos.values()) >= 0.95 and float(np.median(list(worst.values()))) <= 4e-2      # (measured 0.9946 / 2.5e-2 at batch 96)
+
+
+def test_adapter_batchnorm_on_views_equals_the_gathered_rows_path(gpu_device, monkeypatch):
+    """options.TRAIN.adapter_bn_views (default) against gather / clone / scatter copies around the adapters' BatchNorm in the whole
+    train-mode step (same arithmetic, another summation order of the statistics)."""
+    from msclip_amd import options
+    m = _fresh_model("b32-yfcc-msclips")
+    img = synth.synth_images(32, seed=621).cuda()
+    tok = synth.synth_tokens(32, seed=622, min_len=2, max_len=40).cuda()
+    out = {}
+    for views in (False, True):
+        monkeypatch.setattr(options, "TRAIN", options.TRAIN.replace(adapter_bn_views=views))
+        ts = train.TrainStep(m, lr=1e-4, bn="batch")
+        loss = ts.forward(img, tok)
+        out[views] = (loss.item(), {k: v.float().clone() for k, v in ts.backward().items()})
+    (l0, g0), (l1, g1) = out[False], out[True]
+    assert abs(l0 - l1) <= 2e-3 * max(1.0, abs(l0)) and sorted(g0) == sorted(g1)
+    worst = {k: (g0[k] - g1[k]).abs().max().item() / max(g0[k].abs().max().item(), 1e-12) for k in g0}
+    cos = {k: F.cosine_similarity(g0[k].flatten(), g1[k].flatten(), dim=0).item() for k in g0 if g0[k].numel() > 1}
+    print("adapter BatchNorm on views vs gathered rows: loss", l0, l1, "worst", sorted(worst.items(), key=lambda kv: -kv[1])[:3],
+          "median", float(np.median(list(worst.values()))), "lowest cosine", min(cos.values()))
+    assert min(cos.values()) >= 0.95 and float(np.median(list(worst.values()))) <= 4e-2
 
 
 def test_fused_batchnorm_backward_in_the_step_equals_the_pass_per_batchnorm_path(gpu_device, monkeypatch):
