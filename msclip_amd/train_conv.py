@@ -368,7 +368,7 @@ class ConvSideBackward:
         e, w, Bi, sd = self.e, self.w, self.Bi, self.sd
         g2, D = e.g * e.g, e.D
         sp = "visual.transformer.resblocks.0"
-        dlast = hip.cast_bf16(dtok.view(Bi, e.Lv, D)[:, 1:].reshape(Bi * g2, D))
+        dlast = hip.cast_bf16_colsum(dtok[:Bi * e.Lv], fold=False, skip_group=g2)[0]     # the grid rows (class rows skipped), one pass, no gather copy
         x = w["stem"][-1]
         grads[sp + ".last_conv.weight"] = _wgrad(dlast, x[:Bi * g2], Bi * g2).reshape(D, x.shape[1], 1, 1)
         wt = self._wt.get("last")
@@ -821,7 +821,7 @@ class ConvSideBatchNorm:
         e, w, Bi = self.e, self.w, self.Bi
         g2, D = e.g * e.g, e.D
         sp = "visual.transformer.resblocks.0"
-        dlast = hip.cast_bf16(dtok.view(Bi, e.Lv, D)[:, 1:].reshape(Bi * g2, D))
+        dlast = hip.cast_bf16_colsum(dtok[:Bi * e.Lv], fold=False, skip_group=g2)[0]     # the grid rows (class rows skipped), one pass, no gather copy
         x = w["stem"][-1]
         cin = x.shape[1]
         grads[sp + ".last_conv.weight"] = _wgrad_async(dlast, x[:Bi * g2], Bi * g2, post=lambda d: d.reshape(D, cin, 1, 1))
